@@ -1,0 +1,472 @@
+// gsr_math.h -- per-element arithmetic of the rasterizer (binary32), shared by every kernel.
+//
+// Written from the published 3DGS algorithm (Kerbl et al. 2023 sec. 4-6) and the boundary the
+// reference calls (scene/gaussian_model_ht.py:806-894); NOT derived from the un-vendored CUDA
+// module.  The functions are __host__ __device__ so the same arithmetic can be driven by a
+// sequential host harness (tests/hostemu) in the GPU-less authoring container; the product only
+// ever runs them inside the HIP kernels of gsr_kernels.hip.
+//
+// Conventions
+//   * 4x4 matrices are read linearly as column-major (the reference stores them transposed:
+//     scene/cameras.py:76-98), i.e. row r of the true matrix is m[r], m[4+r], m[8+r], m[12+r].
+//   * quaternion (w,x,y,z) = (r,x,y,z), used un-normalised (the caller normalises:
+//     gaussian_model_ht.py:131-133); Sigma = R S^2 R^T (utils/general_utils.py:76-108).
+//   * SH layout [M][3] coefficient-major (gaussian_model_ht.py:176-179); basis utils/sh_utils.py:57-100.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define GSR_HD __host__ __device__ __forceinline__
+#else
+#define GSR_HD inline
+#endif
+
+namespace gsr {
+
+constexpr int kTile = 16;
+constexpr float kNearZ = 0.2f;
+constexpr float kLowpass = 0.3f;
+constexpr float kAlphaMin = 1.0f / 255.0f;
+constexpr float kAlphaMax = 0.99f;
+constexpr float kTStop = 1e-4f;
+
+constexpr float SH_C0 = 0.28209479177387814f;
+constexpr float SH_C1 = 0.4886025119029199f;
+constexpr float SH_C2_0 = 1.0925484305920792f, SH_C2_1 = -1.0925484305920792f, SH_C2_2 = 0.31539156525252005f,
+                SH_C2_3 = -1.0925484305920792f, SH_C2_4 = 0.5462742152960396f;
+constexpr float SH_C3_0 = -0.5900435899266435f, SH_C3_1 = 2.890611442640554f, SH_C3_2 = -0.4570457994644658f,
+                SH_C3_3 = 0.3731763325901154f, SH_C3_4 = -0.4570457994644658f, SH_C3_5 = 1.445305721320277f,
+                SH_C3_6 = -0.5900435899266435f;
+
+// Projected 2D Gaussian, 48 bytes, 16-byte aligned: what the blend kernels gather per instance.
+struct alignas(16) Splat {
+    float px, py, ca, cb;      // pixel-space mean, conic A, B
+    float cc, op, depth, r;    // conic C, opacity, view depth, red
+    float g, b;                // green, blue
+    int32_t radius;            // ceil(3 sigma) in pixels, 0 = invisible
+    uint32_t tiles;            // number of 16x16 tiles touched
+};
+static_assert(sizeof(Splat) == 48, "Splat must be 48 bytes");
+
+struct Camera {
+    float vm[16], pm[16];
+    float cam[3];
+    float tanfovx, tanfovy, fx, fy;
+    float scale_mod;
+    int W, H, tiles_x, tiles_y, D, M;
+};
+
+GSR_HD int imin(int a, int b) { return a < b ? a : b; }
+GSR_HD int imax(int a, int b) { return a > b ? a : b; }
+
+GSR_HD float fast_rcp(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(x);
+#else
+    return 1.0f / x;
+#endif
+}
+
+GSR_HD float fast_exp(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __expf(x);
+#else
+    return expf(x);
+#endif
+}
+
+// binary32 view depth with ONE fixed rounding sequence (same in oracle/gsr_oracle.c:depth_key):
+// the value is the near-cull test, the sort key and the depth feature.
+GSR_HD float depth_key(const float* vm, float x, float y, float z)
+{
+    return fmaf(vm[10], z, fmaf(vm[6], y, fmaf(vm[2], x, vm[14])));
+}
+
+GSR_HD void quat_to_rot(const float q[4], float R[9])
+{
+    const float r = q[0], x = q[1], y = q[2], z = q[3];
+    R[0] = 1.f - 2.f * (y * y + z * z); R[1] = 2.f * (x * y - r * z); R[2] = 2.f * (x * z + r * y);
+    R[3] = 2.f * (x * y + r * z); R[4] = 1.f - 2.f * (x * x + z * z); R[5] = 2.f * (y * z - r * x);
+    R[6] = 2.f * (x * z - r * y); R[7] = 2.f * (y * z + r * x); R[8] = 1.f - 2.f * (x * x + y * y);
+}
+
+// Sigma = L L^T, L = R diag(mod*s); packed xx,xy,xz,yy,yz,zz
+GSR_HD void cov3d_from_scale_rot(const float s[3], float mod, const float q[4], float cov[6])
+{
+    float R[9];
+    quat_to_rot(q, R);
+    const float s0 = mod * s[0], s1 = mod * s[1], s2 = mod * s[2];
+    const float L00 = R[0] * s0, L01 = R[1] * s1, L02 = R[2] * s2;
+    const float L10 = R[3] * s0, L11 = R[4] * s1, L12 = R[5] * s2;
+    const float L20 = R[6] * s0, L21 = R[7] * s1, L22 = R[8] * s2;
+    cov[0] = L00 * L00 + L01 * L01 + L02 * L02;
+    cov[1] = L00 * L10 + L01 * L11 + L02 * L12;
+    cov[2] = L00 * L20 + L01 * L21 + L02 * L22;
+    cov[3] = L10 * L10 + L11 * L11 + L12 * L12;
+    cov[4] = L10 * L20 + L11 * L21 + L12 * L22;
+    cov[5] = L20 * L20 + L21 * L21 + L22 * L22;
+}
+
+// Rows of the 2x3 screen-space Jacobian times the view rotation (M = J * Wr) and the clamped
+// view-space position.  Returns false if behind the near plane.
+struct ProjFrame {
+    float t0, t1, t2;       // view-space mean, x/y after frustum clamp
+    float xmul, ymul;       // 0 where the clamp is active
+    float m0[3], m1[3];     // rows of M
+    float J00, J02, J11, J12;
+};
+
+GSR_HD void proj_frame(const Camera& c, float X, float Y, float Z, ProjFrame& f)
+{
+    const float* vm = c.vm;
+    float t0 = vm[0] * X + vm[4] * Y + vm[8] * Z + vm[12];
+    float t1 = vm[1] * X + vm[5] * Y + vm[9] * Z + vm[13];
+    const float t2 = vm[2] * X + vm[6] * Y + vm[10] * Z + vm[14];
+    const float limx = 1.3f * c.tanfovx, limy = 1.3f * c.tanfovy;
+    const float inv_z = 1.0f / t2;
+    const float txtz = t0 * inv_z, tytz = t1 * inv_z;
+    f.xmul = (txtz < -limx || txtz > limx) ? 0.f : 1.f;
+    f.ymul = (tytz < -limy || tytz > limy) ? 0.f : 1.f;
+    t0 = fminf(limx, fmaxf(-limx, txtz)) * t2;
+    t1 = fminf(limy, fmaxf(-limy, tytz)) * t2;
+    f.t0 = t0; f.t1 = t1; f.t2 = t2;
+    f.J00 = c.fx * inv_z; f.J02 = -c.fx * t0 * inv_z * inv_z;
+    f.J11 = c.fy * inv_z; f.J12 = -c.fy * t1 * inv_z * inv_z;
+    for (int k = 0; k < 3; k++) {
+        f.m0[k] = f.J00 * vm[k * 4 + 0] + f.J02 * vm[k * 4 + 2];
+        f.m1[k] = f.J11 * vm[k * 4 + 1] + f.J12 * vm[k * 4 + 2];
+    }
+}
+
+// cov2D = M Sigma M^T + 0.3 I  -> (a, b, c)
+GSR_HD void cov2d_from_frame(const ProjFrame& f, const float cov[6], float& a, float& b, float& c,
+                             float Sm0[3], float Sm1[3])
+{
+    Sm0[0] = cov[0] * f.m0[0] + cov[1] * f.m0[1] + cov[2] * f.m0[2];
+    Sm0[1] = cov[1] * f.m0[0] + cov[3] * f.m0[1] + cov[4] * f.m0[2];
+    Sm0[2] = cov[2] * f.m0[0] + cov[4] * f.m0[1] + cov[5] * f.m0[2];
+    Sm1[0] = cov[0] * f.m1[0] + cov[1] * f.m1[1] + cov[2] * f.m1[2];
+    Sm1[1] = cov[1] * f.m1[0] + cov[3] * f.m1[1] + cov[4] * f.m1[2];
+    Sm1[2] = cov[2] * f.m1[0] + cov[4] * f.m1[1] + cov[5] * f.m1[2];
+    a = f.m0[0] * Sm0[0] + f.m0[1] * Sm0[1] + f.m0[2] * Sm0[2] + kLowpass;
+    b = f.m0[0] * Sm1[0] + f.m0[1] * Sm1[1] + f.m0[2] * Sm1[2];
+    c = f.m1[0] * Sm1[0] + f.m1[1] * Sm1[1] + f.m1[2] * Sm1[2] + kLowpass;
+}
+
+GSR_HD void tile_rect(float px, float py, int radius, int tiles_x, int tiles_y, int& x0, int& y0, int& x1, int& y1)
+{
+    const float inv = 1.0f / kTile;
+    const float r = (float)radius;
+    x0 = imin(tiles_x, imax(0, (int)((px - r) * inv)));
+    y0 = imin(tiles_y, imax(0, (int)((py - r) * inv)));
+    x1 = imin(tiles_x, imax(0, (int)((px + r + (kTile - 1)) * inv)));
+    y1 = imin(tiles_y, imax(0, (int)((py + r + (kTile - 1)) * inv)));
+}
+
+// SH colour (before +0.5 / clamp) for one channel; sh points at coefficient 0 of that channel,
+// consecutive coefficients are `stride` floats apart.
+GSR_HD float sh_channel(int deg, const float* sh, int stride, float x, float y, float z)
+{
+    float res = SH_C0 * sh[0];
+    if (deg > 0) {
+        res = res - SH_C1 * y * sh[1 * stride] + SH_C1 * z * sh[2 * stride] - SH_C1 * x * sh[3 * stride];
+        if (deg > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            res = res + SH_C2_0 * xy * sh[4 * stride] + SH_C2_1 * yz * sh[5 * stride] +
+                  SH_C2_2 * (2.f * zz - xx - yy) * sh[6 * stride] + SH_C2_3 * xz * sh[7 * stride] +
+                  SH_C2_4 * (xx - yy) * sh[8 * stride];
+            if (deg > 2) {
+                res = res + SH_C3_0 * y * (3.f * xx - yy) * sh[9 * stride] + SH_C3_1 * xy * z * sh[10 * stride] +
+                      SH_C3_2 * y * (4.f * zz - xx - yy) * sh[11 * stride] +
+                      SH_C3_3 * z * (2.f * zz - 3.f * xx - 3.f * yy) * sh[12 * stride] +
+                      SH_C3_4 * x * (4.f * zz - xx - yy) * sh[13 * stride] +
+                      SH_C3_5 * z * (xx - yy) * sh[14 * stride] + SH_C3_6 * x * (xx - 3.f * yy) * sh[15 * stride];
+            }
+        }
+    }
+    return res;
+}
+
+// Forward projection of one Gaussian.  `sh` may be null when `color_pre` is given (and vice versa);
+// `cov_pre` null means build Sigma from scale/rot.  sh coefficient k of channel ch is at
+// sh[k*sh_kstride + ch*sh_cstride] (lets the caller hand either the global [M][3] row or an LDS copy).
+GSR_HD void preprocess_one(const Camera& c, const float mean[3], const float* scale, const float* rot,
+                           const float* cov_pre, float opacity, const float* sh, int sh_kstride, int sh_cstride,
+                           const float* color_pre, Splat& out)
+{
+    out.px = 0.f; out.py = 0.f; out.ca = 0.f; out.cb = 0.f; out.cc = 0.f; out.op = 0.f; out.depth = 0.f;
+    out.r = 0.f; out.g = 0.f; out.b = 0.f; out.radius = 0; out.tiles = 0;
+    const float X = mean[0], Y = mean[1], Z = mean[2];
+    const float zk = depth_key(c.vm, X, Y, Z);
+    out.depth = zk;
+    if (!(zk > kNearZ)) return;
+    const float* pm = c.pm;
+    const float hx = pm[0] * X + pm[4] * Y + pm[8] * Z + pm[12];
+    const float hy = pm[1] * X + pm[5] * Y + pm[9] * Z + pm[13];
+    const float hw = pm[3] * X + pm[7] * Y + pm[11] * Z + pm[15];
+    const float pw = 1.0f / (hw + 1e-7f);
+    float cov[6];
+    if (cov_pre) {
+        for (int k = 0; k < 6; k++) cov[k] = cov_pre[k];
+    } else {
+        cov3d_from_scale_rot(scale, c.scale_mod, rot, cov);
+    }
+    ProjFrame f;
+    proj_frame(c, X, Y, Z, f);
+    float a, b, cc, Sm0[3], Sm1[3];
+    cov2d_from_frame(f, cov, a, b, cc, Sm0, Sm1);
+    const float det = a * cc - b * b;
+    if (det == 0.f) return;
+    const float dinv = 1.0f / det;
+    const float mid = 0.5f * (a + cc);
+    const float disc = sqrtf(fmaxf(0.1f, mid * mid - det));
+    const float lam = fmaxf(mid + disc, mid - disc);
+    const int radius = (int)ceilf(3.f * sqrtf(lam));
+    const float px = ((hx * pw + 1.f) * c.W - 1.f) * 0.5f;
+    const float py = ((hy * pw + 1.f) * c.H - 1.f) * 0.5f;
+    int x0, y0, x1, y1;
+    tile_rect(px, py, radius, c.tiles_x, c.tiles_y, x0, y0, x1, y1);
+    const int nt = (x1 - x0) * (y1 - y0);
+    if (nt == 0) return;
+    float col[3];
+    if (color_pre) {
+        col[0] = color_pre[0]; col[1] = color_pre[1]; col[2] = color_pre[2];
+    } else {
+        float dx = X - c.cam[0], dy = Y - c.cam[1], dz = Z - c.cam[2];
+        const float inv_n = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+        dx *= inv_n; dy *= inv_n; dz *= inv_n;
+        for (int ch = 0; ch < 3; ch++)
+            col[ch] = fmaxf(sh_channel(c.D, sh + ch * sh_cstride, sh_kstride, dx, dy, dz) + 0.5f, 0.f);
+    }
+    out.px = px; out.py = py;
+    out.ca = cc * dinv; out.cb = -b * dinv; out.cc = a * dinv;
+    out.op = opacity;
+    out.r = col[0]; out.g = col[1]; out.b = col[2];
+    out.radius = radius; out.tiles = (uint32_t)nt;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Blend: one (pixel, Gaussian) step, front to back.
+// ------------------------------------------------------------------------------------------------
+struct PixelAcc {
+    float T, C0, C1, C2, D, A;
+};
+
+// returns alpha (0 if the Gaussian is skipped for this pixel)
+GSR_HD float pair_alpha(float pxf, float pyf, float sx, float sy, float ca, float cb, float cc, float op, float& G,
+                        float& dx, float& dy)
+{
+    dx = sx - pxf; dy = sy - pyf;
+    const float power = -0.5f * (ca * dx * dx + cc * dy * dy) - cb * dx * dy;
+    G = fast_exp(power);
+    const float alpha = fminf(kAlphaMax, op * G);
+    return (power > 0.f || alpha < kAlphaMin) ? 0.f : alpha;
+}
+
+// forward accumulate; returns false when the pixel terminates (this Gaussian is NOT blended)
+GSR_HD bool blend_step_fwd(PixelAcc& p, float alpha, float r, float g, float b, float depth)
+{
+    const float test_T = p.T * (1.f - alpha);
+    if (test_T < kTStop) return false;
+    const float w = alpha * p.T;
+    p.C0 = fmaf(r, w, p.C0); p.C1 = fmaf(g, w, p.C1); p.C2 = fmaf(b, w, p.C2);
+    p.D = fmaf(depth, w, p.D); p.A += w;
+    p.T = test_T;
+    return true;
+}
+
+// Backward replay, front to back.  s* start as the forward totals and shrink to the suffix sums:
+//   d out/d alpha_i = c_i T_i - (sum_{k>i} c_k a_k T_k + T_f bg) / (1 - alpha_i)
+struct PixelBwd {
+    float T, sC0, sC1, sC2, sD, sA;      // running state
+    float gC0, gC1, gC2, gD, gA, bgdot;  // upstream gradients of this pixel; bgdot = T_final * <bg, gC>
+};
+
+struct PairGrad {   // per-(pixel,Gaussian) contributions, summed over pixels
+    float gx, gy;           // d/d pixel-space mean
+    float gA, gB, gC;       // d/d conic (true partials)
+    float gop;              // d/d opacity
+    float gr, gg, gb, gz;   // d/d colour, d/d depth feature
+};
+
+GSR_HD void blend_step_bwd(PixelBwd& p, float alpha, float G, float dx, float dy, float ca, float cb, float cc,
+                           float op, float r, float g, float b, float depth, PairGrad& o)
+{
+    const float w = alpha * p.T;
+    p.sC0 = fmaf(-r, w, p.sC0); p.sC1 = fmaf(-g, w, p.sC1); p.sC2 = fmaf(-b, w, p.sC2);
+    p.sD = fmaf(-depth, w, p.sD); p.sA -= w;
+    const float inv1a = fast_rcp(1.f - alpha);
+    float dLda = p.gC0 * (r * p.T - p.sC0 * inv1a) + p.gC1 * (g * p.T - p.sC1 * inv1a) + p.gC2 * (b * p.T - p.sC2 * inv1a);
+    dLda += p.gD * (depth * p.T - p.sD * inv1a);
+    dLda += p.gA * (p.T - p.sA * inv1a);
+    dLda -= p.bgdot * inv1a;
+    const float dLdpow = G * op * dLda;   // straight-through at the 0.99 clamp
+    o.gx += dLdpow * (-ca * dx - cb * dy);
+    o.gy += dLdpow * (-cc * dy - cb * dx);
+    o.gA += -0.5f * dx * dx * dLdpow;
+    o.gB += -dx * dy * dLdpow;
+    o.gC += -0.5f * dy * dy * dLdpow;
+    o.gop += G * dLda;
+    o.gr += w * p.gC0; o.gg += w * p.gC1; o.gb += w * p.gC2; o.gz += w * p.gD;
+    p.T *= (1.f - alpha);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Per-Gaussian backward (everything after the blend gradients have been reduced per Gaussian).
+// Inputs: g_px,g_py  dL/d pixel-space mean; gA,gB,gC dL/d conic (true partials);
+//         g_rgb[3] dL/d colour; g_z dL/d depth feature.
+// ------------------------------------------------------------------------------------------------
+struct GaussGrads {
+    float mean[3];
+    float mean2d[2];   // module convention: d/d ndc = d/d pixel * (W/2, H/2)
+    float scale[3], rot[4], cov[6];
+};
+
+// accumulates dL/d(mean) through the colour and writes dL/dsh (coefficient k, channel ch at
+// dsh[k*dk + ch*dc]).  Coefficients >= (deg+1)^2 are written as zero up to M.
+GSR_HD void sh_backward(const Camera& c, const float mean[3], const float* sh, int sk, int sc, const float g_rgb_in[3],
+                        float* dsh, int dk, int dc, float dmean[3])
+{
+    float dx = mean[0] - c.cam[0], dy = mean[1] - c.cam[1], dz = mean[2] - c.cam[2];
+    const float inv_n = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+    const float x = dx * inv_n, y = dy * inv_n, z = dz * inv_n;
+    float gr[3];
+    for (int ch = 0; ch < 3; ch++) {
+        const float v = sh_channel(c.D, sh + ch * sc, sk, x, y, z) + 0.5f;
+        gr[ch] = v < 0.f ? 0.f : g_rgb_in[ch];
+    }
+    float basis[16], bx[16], by[16], bz[16];
+    for (int k = 0; k < 16; k++) { basis[k] = 0.f; bx[k] = 0.f; by[k] = 0.f; bz[k] = 0.f; }
+    basis[0] = SH_C0;
+    if (c.D > 0) {
+        basis[1] = -SH_C1 * y; by[1] = -SH_C1;
+        basis[2] = SH_C1 * z; bz[2] = SH_C1;
+        basis[3] = -SH_C1 * x; bx[3] = -SH_C1;
+        if (c.D > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            basis[4] = SH_C2_0 * xy; bx[4] = SH_C2_0 * y; by[4] = SH_C2_0 * x;
+            basis[5] = SH_C2_1 * yz; by[5] = SH_C2_1 * z; bz[5] = SH_C2_1 * y;
+            basis[6] = SH_C2_2 * (2.f * zz - xx - yy); bx[6] = SH_C2_2 * -2.f * x; by[6] = SH_C2_2 * -2.f * y; bz[6] = SH_C2_2 * 4.f * z;
+            basis[7] = SH_C2_3 * xz; bx[7] = SH_C2_3 * z; bz[7] = SH_C2_3 * x;
+            basis[8] = SH_C2_4 * (xx - yy); bx[8] = SH_C2_4 * 2.f * x; by[8] = SH_C2_4 * -2.f * y;
+            if (c.D > 2) {
+                basis[9] = SH_C3_0 * y * (3.f * xx - yy); bx[9] = SH_C3_0 * 6.f * xy; by[9] = SH_C3_0 * (3.f * xx - 3.f * yy);
+                basis[10] = SH_C3_1 * xy * z; bx[10] = SH_C3_1 * yz; by[10] = SH_C3_1 * xz; bz[10] = SH_C3_1 * xy;
+                basis[11] = SH_C3_2 * y * (4.f * zz - xx - yy); bx[11] = SH_C3_2 * -2.f * xy;
+                by[11] = SH_C3_2 * (4.f * zz - xx - 3.f * yy); bz[11] = SH_C3_2 * 8.f * yz;
+                basis[12] = SH_C3_3 * z * (2.f * zz - 3.f * xx - 3.f * yy); bx[12] = SH_C3_3 * -6.f * xz;
+                by[12] = SH_C3_3 * -6.f * yz; bz[12] = SH_C3_3 * (6.f * zz - 3.f * xx - 3.f * yy);
+                basis[13] = SH_C3_4 * x * (4.f * zz - xx - yy); bx[13] = SH_C3_4 * (4.f * zz - 3.f * xx - yy);
+                by[13] = SH_C3_4 * -2.f * xy; bz[13] = SH_C3_4 * 8.f * xz;
+                basis[14] = SH_C3_5 * z * (xx - yy); bx[14] = SH_C3_5 * 2.f * xz; by[14] = SH_C3_5 * -2.f * yz; bz[14] = SH_C3_5 * (xx - yy);
+                basis[15] = SH_C3_6 * x * (xx - 3.f * yy); bx[15] = SH_C3_6 * (3.f * xx - 3.f * yy); by[15] = SH_C3_6 * -6.f * xy;
+            }
+        }
+    }
+    const int nc = (c.D + 1) * (c.D + 1);
+    float gdx = 0.f, gdy = 0.f, gdz = 0.f;
+    for (int k = 0; k < 16; k++) {
+        if (k < nc) {
+            for (int ch = 0; ch < 3; ch++) {
+                const float s = sh[k * sk + ch * sc];
+                dsh[k * dk + ch * dc] = basis[k] * gr[ch];
+                gdx += bx[k] * s * gr[ch]; gdy += by[k] * s * gr[ch]; gdz += bz[k] * s * gr[ch];
+            }
+        } else if (k < c.M) {
+            for (int ch = 0; ch < 3; ch++) dsh[k * dk + ch * dc] = 0.f;
+        }
+    }
+    const float dot = gdx * x + gdy * y + gdz * z;
+    dmean[0] += (gdx - x * dot) * inv_n;
+    dmean[1] += (gdy - y * dot) * inv_n;
+    dmean[2] += (gdz - z * dot) * inv_n;
+}
+
+GSR_HD void gauss_backward(const Camera& c, const float mean[3], const float* scale, const float* rot,
+                           const float* cov_pre, float g_px, float g_py, float gA, float gB, float gC, float g_z,
+                           GaussGrads& o)
+{
+    const float X = mean[0], Y = mean[1], Z = mean[2];
+    float cov[6];
+    if (cov_pre) {
+        for (int k = 0; k < 6; k++) cov[k] = cov_pre[k];
+    } else {
+        cov3d_from_scale_rot(scale, c.scale_mod, rot, cov);
+    }
+    ProjFrame f;
+    proj_frame(c, X, Y, Z, f);
+    float a, b, cc, Sm0[3], Sm1[3];
+    cov2d_from_frame(f, cov, a, b, cc, Sm0, Sm1);
+    // conic -> cov2D (guard 1e-7 recalled from the public module)
+    const float det = a * cc - b * b;
+    const float d2i = 1.0f / (det * det + 1e-7f);
+    const float ga = d2i * (-cc * cc * gA + b * cc * gB - b * b * gC);
+    const float gb = d2i * (2.f * b * cc * gA - (det + 2.f * b * b) * gB + 2.f * a * b * gC);
+    const float gc = d2i * (-b * b * gA + a * b * gB - a * a * gC);
+    // cov2D -> Sigma (6 unique entries)
+    const float* m0 = f.m0; const float* m1 = f.m1;
+    float gS[6];
+    gS[0] = ga * m0[0] * m0[0] + gb * m0[0] * m1[0] + gc * m1[0] * m1[0];
+    gS[3] = ga * m0[1] * m0[1] + gb * m0[1] * m1[1] + gc * m1[1] * m1[1];
+    gS[5] = ga * m0[2] * m0[2] + gb * m0[2] * m1[2] + gc * m1[2] * m1[2];
+    gS[1] = 2.f * ga * m0[0] * m0[1] + gb * (m0[0] * m1[1] + m0[1] * m1[0]) + 2.f * gc * m1[0] * m1[1];
+    gS[2] = 2.f * ga * m0[0] * m0[2] + gb * (m0[0] * m1[2] + m0[2] * m1[0]) + 2.f * gc * m1[0] * m1[2];
+    gS[4] = 2.f * ga * m0[1] * m0[2] + gb * (m0[1] * m1[2] + m0[2] * m1[1]) + 2.f * gc * m1[1] * m1[2];
+    // cov2D -> M rows -> J -> view-space mean
+    float gm0[3], gm1[3];
+    for (int r = 0; r < 3; r++) { gm0[r] = 2.f * ga * Sm0[r] + gb * Sm1[r]; gm1[r] = 2.f * gc * Sm1[r] + gb * Sm0[r]; }
+    const float* vm = c.vm;
+    float gJ00 = 0.f, gJ02 = 0.f, gJ11 = 0.f, gJ12 = 0.f;
+    for (int k = 0; k < 3; k++) {
+        gJ00 += gm0[k] * vm[k * 4 + 0]; gJ02 += gm0[k] * vm[k * 4 + 2];
+        gJ11 += gm1[k] * vm[k * 4 + 1]; gJ12 += gm1[k] * vm[k * 4 + 2];
+    }
+    const float iz = 1.0f / f.t2, tz2 = iz * iz, tz3 = tz2 * iz;
+    const float gt0 = f.xmul * -c.fx * tz2 * gJ02;
+    const float gt1 = f.ymul * -c.fy * tz2 * gJ12;
+    const float gt2 = -c.fx * tz2 * gJ00 - c.fy * tz2 * gJ11 + 2.f * c.fx * f.t0 * tz3 * gJ02 + 2.f * c.fy * f.t1 * tz3 * gJ12;
+    // screen position -> mean
+    const float* pm = c.pm;
+    const float hx = pm[0] * X + pm[4] * Y + pm[8] * Z + pm[12];
+    const float hy = pm[1] * X + pm[5] * Y + pm[9] * Z + pm[13];
+    const float hw = pm[3] * X + pm[7] * Y + pm[11] * Z + pm[15];
+    const float mw = 1.0f / (hw + 1e-7f);
+    const float gnx = g_px * 0.5f * c.W, gny = g_py * 0.5f * c.H;
+    o.mean2d[0] = gnx; o.mean2d[1] = gny;
+    for (int k = 0; k < 3; k++) {
+        float d = vm[k * 4 + 0] * gt0 + vm[k * 4 + 1] * gt1 + vm[k * 4 + 2] * (gt2 + g_z);
+        d += (pm[k * 4 + 0] * mw - pm[k * 4 + 3] * hx * mw * mw) * gnx + (pm[k * 4 + 1] * mw - pm[k * 4 + 3] * hy * mw * mw) * gny;
+        o.mean[k] = d;
+    }
+    for (int k = 0; k < 6; k++) o.cov[k] = gS[k];
+    for (int k = 0; k < 3; k++) o.scale[k] = 0.f;
+    for (int k = 0; k < 4; k++) o.rot[k] = 0.f;
+    if (!cov_pre) {
+        float R[9];
+        quat_to_rot(rot, R);
+        const float sv[3] = {c.scale_mod * scale[0], c.scale_mod * scale[1], c.scale_mod * scale[2]};
+        const float Gf[9] = {gS[0], 0.5f * gS[1], 0.5f * gS[2], 0.5f * gS[1], gS[3], 0.5f * gS[4], 0.5f * gS[2], 0.5f * gS[4], gS[5]};
+        float gR[9];
+        for (int bcol = 0; bcol < 3; bcol++) {
+            float gs = 0.f;
+            for (int arow = 0; arow < 3; arow++) {
+                float acc = 0.f;
+                for (int k = 0; k < 3; k++) acc += Gf[arow * 3 + k] * R[k * 3 + bcol];
+                const float gL = 2.f * acc * sv[bcol];   // dL/dL[arow][bcol]
+                gs += gL * R[arow * 3 + bcol];
+                gR[arow * 3 + bcol] = gL * sv[bcol];
+            }
+            o.scale[bcol] = gs * c.scale_mod;
+        }
+        const float r = rot[0], x = rot[1], y = rot[2], z = rot[3];
+        o.rot[0] = 2.f * (-z * gR[1] + y * gR[2] + z * gR[3] - x * gR[5] - y * gR[6] + x * gR[7]);
+        o.rot[1] = 2.f * (y * gR[1] + z * gR[2] + y * gR[3] - 2.f * x * gR[4] - r * gR[5] + z * gR[6] + r * gR[7] - 2.f * x * gR[8]);
+        o.rot[2] = 2.f * (-2.f * y * gR[0] + x * gR[1] + r * gR[2] + x * gR[3] + z * gR[5] - r * gR[6] + z * gR[7] - 2.f * y * gR[8]);
+        o.rot[3] = 2.f * (-2.f * z * gR[0] - r * gR[1] + x * gR[2] + r * gR[3] - 2.f * z * gR[4] + y * gR[5] + x * gR[6] + y * gR[7]);
+    }
+}
+
+}  // namespace gsr

@@ -1,0 +1,169 @@
+// tests/hostemu/hostemu.cpp -- sequential HOST driver of csrc/gsr_math.h (TEST INFRASTRUCTURE).
+//
+// The authoring container has no GPU.  This harness runs the *same* binary32 per-element arithmetic the
+// HIP kernels run (gsr_math.h is __host__ __device__) through a plain sequential pipeline, so the maths can
+// be checked against the float64 oracle before a kernel ever touches a GPU.  It is never imported by the
+// product; the product path fails loudly when the HIP library is missing.
+#include <algorithm>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../3dgs_hierarchical_training_amd/csrc/gsr_math.h"
+
+using namespace gsr;
+
+extern "C" {
+
+struct EmuIn {   // same layout as oracle/gsr_oracle.c:GsrOracleIn
+    int32_t N, M, D, W, H, prefiltered;
+    float scale_modifier, tanfovx, tanfovy;
+    const float *means3D, *scales, *rotations, *cov3D_precomp, *opacities, *shs, *colors_precomp;
+    const float *viewmatrix, *projmatrix, *campos, *bg;
+};
+
+struct EmuCtx {
+    EmuIn in;
+    Camera cam;
+    std::vector<Splat> splat;
+    std::vector<uint32_t> list;
+    std::vector<int64_t> tile_start;
+    std::vector<float> finalT, acc;   // acc [P,5]
+    std::vector<uint32_t> ncontrib;
+};
+
+static Camera make_cam(const EmuIn& in)
+{
+    Camera c;
+    memcpy(c.vm, in.viewmatrix, 64); memcpy(c.pm, in.projmatrix, 64); memcpy(c.cam, in.campos, 12);
+    c.tanfovx = in.tanfovx; c.tanfovy = in.tanfovy;
+    c.fx = in.W / (2.f * in.tanfovx); c.fy = in.H / (2.f * in.tanfovy);
+    c.scale_mod = in.scale_modifier; c.W = in.W; c.H = in.H;
+    c.tiles_x = (in.W + kTile - 1) / kTile; c.tiles_y = (in.H + kTile - 1) / kTile;
+    c.D = in.D; c.M = in.M;
+    return c;
+}
+
+EmuCtx* hostemu_forward(const EmuIn* in, float* out_color, float* out_depth, float* out_alpha, int32_t* radii)
+{
+    EmuCtx* c = new EmuCtx();
+    c->in = *in;
+    c->cam = make_cam(*in);
+    const Camera& cam = c->cam;
+    const int N = in->N, W = in->W, H = in->H, T = cam.tiles_x * cam.tiles_y;
+    c->splat.resize(N);
+    for (int i = 0; i < N; i++) {
+        preprocess_one(cam, in->means3D + 3 * (size_t)i, in->scales ? in->scales + 3 * (size_t)i : nullptr,
+                       in->rotations ? in->rotations + 4 * (size_t)i : nullptr,
+                       in->cov3D_precomp ? in->cov3D_precomp + 6 * (size_t)i : nullptr, in->opacities[i],
+                       in->shs ? in->shs + (size_t)i * in->M * 3 : nullptr, 3, 1,
+                       in->colors_precomp ? in->colors_precomp + 3 * (size_t)i : nullptr, c->splat[i]);
+        if (radii) radii[i] = c->splat[i].radius;
+    }
+    // depth order (stable on index), then stable by tile  == (tile, depth bits, index)
+    std::vector<uint32_t> order;
+    for (int i = 0; i < N; i++) if (c->splat[i].radius > 0) order.push_back(i);
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+        uint32_t ka, kb; memcpy(&ka, &c->splat[a].depth, 4); memcpy(&kb, &c->splat[b].depth, 4); return ka < kb; });
+    std::vector<std::pair<uint32_t, uint32_t>> inst;  // (tile, gid) in emission order
+    for (uint32_t g : order) {
+        int x0, y0, x1, y1;
+        tile_rect(c->splat[g].px, c->splat[g].py, c->splat[g].radius, cam.tiles_x, cam.tiles_y, x0, y0, x1, y1);
+        for (int y = y0; y < y1; y++) for (int x = x0; x < x1; x++) inst.push_back({(uint32_t)(y * cam.tiles_x + x), g});
+    }
+    std::stable_sort(inst.begin(), inst.end(), [](auto& a, auto& b) { return a.first < b.first; });
+    c->tile_start.assign(T + 1, 0);
+    for (auto& p : inst) c->tile_start[p.first + 1]++;
+    for (int t = 0; t < T; t++) c->tile_start[t + 1] += c->tile_start[t];
+    c->list.resize(inst.size());
+    for (size_t k = 0; k < inst.size(); k++) c->list[k] = inst[k].second;
+    const size_t P = (size_t)W * H;
+    c->finalT.assign(P, 1.f); c->acc.assign(P * 5, 0.f); c->ncontrib.assign(P, 0);
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            const int t = (y / kTile) * cam.tiles_x + (x / kTile);
+            PixelAcc p = {1.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            uint32_t contributor = 0, last = 0;
+            for (int64_t k = c->tile_start[t]; k < c->tile_start[t + 1]; k++) {
+                contributor++;
+                const Splat& s = c->splat[c->list[k]];
+                float G, dx, dy;
+                const float alpha = pair_alpha((float)x, (float)y, s.px, s.py, s.ca, s.cb, s.cc, s.op, G, dx, dy);
+                if (alpha == 0.f) continue;
+                if (!blend_step_fwd(p, alpha, s.r, s.g, s.b, s.depth)) break;
+                last = contributor;
+            }
+            const size_t pid = (size_t)y * W + x;
+            c->finalT[pid] = p.T; c->ncontrib[pid] = last;
+            float* a = &c->acc[5 * pid];
+            a[0] = p.C0; a[1] = p.C1; a[2] = p.C2; a[3] = p.D; a[4] = p.A;
+            if (out_color) for (int ch = 0; ch < 3; ch++) out_color[ch * P + pid] = a[ch] + p.T * in->bg[ch];
+            if (out_depth) out_depth[pid] = p.D;
+            if (out_alpha) out_alpha[pid] = p.A;
+        }
+    return c;
+}
+
+int64_t hostemu_num_rendered(EmuCtx* c) { return (int64_t)c->list.size(); }
+
+void hostemu_backward(EmuCtx* c, const float* g_color, const float* g_depth, const float* g_alpha, float* d_means3D,
+                      float* d_means2D, float* d_opacity, float* d_colors, float* d_shs, float* d_scales,
+                      float* d_rotations, float* d_cov3D)
+{
+    const EmuIn& in = c->in;
+    const Camera& cam = c->cam;
+    const int N = in.N, W = in.W, H = in.H;
+    const size_t P = (size_t)W * H;
+    std::vector<PairGrad> gg(N);
+    memset(gg.data(), 0, sizeof(PairGrad) * N);
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            const size_t pid = (size_t)y * W + x;
+            const int t = (y / kTile) * cam.tiles_x + (x / kTile);
+            const float* a = &c->acc[5 * pid];
+            PixelBwd p;
+            p.T = 1.f; p.sC0 = a[0]; p.sC1 = a[1]; p.sC2 = a[2]; p.sD = a[3]; p.sA = a[4];
+            p.gC0 = g_color ? g_color[pid] : 0.f; p.gC1 = g_color ? g_color[P + pid] : 0.f; p.gC2 = g_color ? g_color[2 * P + pid] : 0.f;
+            p.gD = g_depth ? g_depth[pid] : 0.f; p.gA = g_alpha ? g_alpha[pid] : 0.f;
+            p.bgdot = c->finalT[pid] * (in.bg[0] * p.gC0 + in.bg[1] * p.gC1 + in.bg[2] * p.gC2);
+            const int64_t s0 = c->tile_start[t];
+            for (uint32_t k = 0; k < c->ncontrib[pid]; k++) {
+                const uint32_t g = c->list[s0 + k];
+                const Splat& s = c->splat[g];
+                float G, dx, dy;
+                const float alpha = pair_alpha((float)x, (float)y, s.px, s.py, s.ca, s.cb, s.cc, s.op, G, dx, dy);
+                if (alpha == 0.f) continue;
+                blend_step_bwd(p, alpha, G, dx, dy, s.ca, s.cb, s.cc, s.op, s.r, s.g, s.b, s.depth, gg[g]);
+            }
+        }
+    for (int i = 0; i < N; i++) {
+        const Splat& s = c->splat[i];
+        float* dsh = d_shs ? d_shs + (size_t)i * in.M * 3 : nullptr;
+        for (int k = 0; k < 3; k++) { d_means3D[3 * i + k] = 0.f; d_means2D[3 * i + k] = 0.f; }
+        d_opacity[i] = 0.f;
+        if (d_colors) for (int k = 0; k < 3; k++) d_colors[3 * i + k] = 0.f;
+        if (dsh) for (int k = 0; k < in.M * 3; k++) dsh[k] = 0.f;
+        if (d_scales) for (int k = 0; k < 3; k++) d_scales[3 * i + k] = 0.f;
+        if (d_rotations) for (int k = 0; k < 4; k++) d_rotations[4 * i + k] = 0.f;
+        if (d_cov3D) for (int k = 0; k < 6; k++) d_cov3D[6 * i + k] = 0.f;
+        if (s.radius <= 0) continue;
+        const PairGrad& g = gg[i];
+        GaussGrads o;
+        gauss_backward(cam, in.means3D + 3 * (size_t)i, in.scales ? in.scales + 3 * (size_t)i : nullptr,
+                       in.rotations ? in.rotations + 4 * (size_t)i : nullptr,
+                       in.cov3D_precomp ? in.cov3D_precomp + 6 * (size_t)i : nullptr, g.gx, g.gy, g.gA, g.gB, g.gC, g.gz, o);
+        float dmean[3] = {o.mean[0], o.mean[1], o.mean[2]};
+        const float grgb[3] = {g.gr, g.gg, g.gb};
+        if (in.shs) sh_backward(cam, in.means3D + 3 * (size_t)i, in.shs + (size_t)i * in.M * 3, 3, 1, grgb, dsh, 3, 1, dmean);
+        else for (int k = 0; k < 3; k++) d_colors[3 * i + k] = grgb[k];
+        for (int k = 0; k < 3; k++) d_means3D[3 * i + k] = dmean[k];
+        d_means2D[3 * i] = o.mean2d[0]; d_means2D[3 * i + 1] = o.mean2d[1];
+        d_opacity[i] = g.gop;
+        if (in.cov3D_precomp) { for (int k = 0; k < 6; k++) d_cov3D[6 * i + k] = o.cov[k]; }
+        else { for (int k = 0; k < 3; k++) d_scales[3 * i + k] = o.scale[k]; for (int k = 0; k < 4; k++) d_rotations[4 * i + k] = o.rot[k]; }
+    }
+}
+
+void hostemu_free(EmuCtx* c) { delete c; }
+}
