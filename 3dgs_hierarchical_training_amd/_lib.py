@@ -1,0 +1,103 @@
+"""ctypes view of the C ABI in include/gsr.h (libgsr_hip.so).  No fallback: if the library is missing the
+import of the product path fails loudly."""
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must be imported first so libgsr_hip.so binds to torch's libamdhip64)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libgsr_hip.so")
+
+ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
+GSR_ALLOC_BINNING, GSR_ALLOC_SCRATCH = 0, 1
+
+
+class GsrForwardArgs(C.Structure):
+    _fields_ = [
+        ("N", C.c_int32), ("M", C.c_int32), ("D", C.c_int32), ("W", C.c_int32), ("H", C.c_int32),
+        ("prefiltered", C.c_int32), ("debug", C.c_int32),
+        ("scale_modifier", C.c_float), ("tanfovx", C.c_float), ("tanfovy", C.c_float),
+        ("means3D", C.c_void_p), ("scales", C.c_void_p), ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p),
+        ("opacities", C.c_void_p), ("shs", C.c_void_p), ("colors_precomp", C.c_void_p),
+        ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p), ("campos", C.c_void_p), ("bg", C.c_void_p),
+        ("out_color", C.c_void_p), ("out_depth", C.c_void_p), ("out_alpha", C.c_void_p), ("radii", C.c_void_p),
+        ("geom", C.c_void_p), ("image", C.c_void_p),
+        ("alloc", ALLOC_FN), ("alloc_user", C.c_void_p),
+    ]
+
+
+class GsrForwardOut(C.Structure):
+    _fields_ = [("num_rendered", C.c_int64), ("binning", C.c_void_p), ("binning_bytes", C.c_size_t)]
+
+
+class GsrBackwardArgs(C.Structure):
+    _fields_ = [
+        ("N", C.c_int32), ("M", C.c_int32), ("D", C.c_int32), ("W", C.c_int32), ("H", C.c_int32),
+        ("scale_modifier", C.c_float), ("tanfovx", C.c_float), ("tanfovy", C.c_float),
+        ("means3D", C.c_void_p), ("scales", C.c_void_p), ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p),
+        ("opacities", C.c_void_p), ("shs", C.c_void_p), ("colors_precomp", C.c_void_p),
+        ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p), ("campos", C.c_void_p), ("bg", C.c_void_p),
+        ("geom", C.c_void_p), ("image", C.c_void_p), ("binning", C.c_void_p), ("num_rendered", C.c_int64),
+        ("grad_color", C.c_void_p), ("grad_depth", C.c_void_p), ("grad_alpha", C.c_void_p),
+        ("d_means3D", C.c_void_p), ("d_means2D", C.c_void_p), ("d_opacities", C.c_void_p),
+        ("d_colors_precomp", C.c_void_p), ("d_shs", C.c_void_p), ("d_scales", C.c_void_p),
+        ("d_rotations", C.c_void_p), ("d_cov3D_precomp", C.c_void_p), ("scratch", C.c_void_p),
+    ]
+
+
+EXPORTS = [
+    "gsr_geom_bytes", "gsr_image_bytes", "gsr_forward_scratch_bytes", "gsr_binning_bytes",
+    "gsr_binning_scratch_bytes", "gsr_backward_scratch_bytes", "gsr_forward", "gsr_backward",
+    "gsr_mark_visible", "gsr_last_error", "gsr_version", "gsr_set_option", "gsr_sort_pairs_u32",
+    "gsr_sort_pairs_u16", "gsr_sort_scratch_bytes", "gsr_image_staged_offset", "gsr_profile_read",
+]
+
+_lib = None
+
+
+def load():
+    """Load libgsr_hip.so (once).  Raises RuntimeError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the HIP extension is not built (run `python __graft_entry__.py` or "
+            "`python 3dgs_hierarchical_training_amd/build.py`).  There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for fn in ["gsr_geom_bytes", "gsr_forward_scratch_bytes", "gsr_backward_scratch_bytes"]:
+        getattr(lib, fn).restype = C.c_size_t
+        getattr(lib, fn).argtypes = [C.c_int32]
+    lib.gsr_image_bytes.restype = C.c_size_t
+    lib.gsr_image_bytes.argtypes = [C.c_int32, C.c_int32]
+    lib.gsr_image_staged_offset.restype = C.c_size_t
+    lib.gsr_image_staged_offset.argtypes = [C.c_int32, C.c_int32]
+    lib.gsr_profile_read.restype = C.c_int
+    lib.gsr_profile_read.argtypes = [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    lib.gsr_binning_bytes.restype = C.c_size_t
+    lib.gsr_binning_bytes.argtypes = [C.c_int64, C.c_int32, C.c_int32]
+    lib.gsr_binning_scratch_bytes.restype = C.c_size_t
+    lib.gsr_binning_scratch_bytes.argtypes = [C.c_int64]
+    lib.gsr_sort_scratch_bytes.restype = C.c_size_t
+    lib.gsr_sort_scratch_bytes.argtypes = [C.c_uint32]
+    lib.gsr_forward.restype = C.c_int
+    lib.gsr_forward.argtypes = [C.POINTER(GsrForwardArgs), C.POINTER(GsrForwardOut), C.c_void_p]
+    lib.gsr_backward.restype = C.c_int
+    lib.gsr_backward.argtypes = [C.POINTER(GsrBackwardArgs), C.c_void_p]
+    lib.gsr_mark_visible.restype = C.c_int
+    lib.gsr_mark_visible.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.gsr_last_error.restype = C.c_char_p
+    lib.gsr_version.restype = C.c_int
+    lib.gsr_set_option.restype = C.c_int
+    lib.gsr_set_option.argtypes = [C.c_char_p, C.c_int]
+    for fn in ["gsr_sort_pairs_u32", "gsr_sort_pairs_u16"]:
+        getattr(lib, fn).restype = C.c_int
+        getattr(lib, fn).argtypes = [C.c_void_p] * 4 + [C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_size_t,
+                                                        C.POINTER(C.c_int), C.c_void_p]
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed (code {rc}): {load().gsr_last_error().decode()}")

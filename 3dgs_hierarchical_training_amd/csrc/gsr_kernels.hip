@@ -1,0 +1,963 @@
+// gsr_kernels.hip -- hand-written HIP kernels (gfx950 / CDNA4, wave64) + the C ABI of include/gsr.h.
+//
+// Pipeline (DESIGN.md has the byte accounting):
+//   forward   K1 k_preprocess      per Gaussian: cull, project, cov2D, conic, radius, SH colour -> 48-B Splat
+//             K2 radix sort        32-bit depth keys over N (4 passes)           -> depth order
+//             K3 k_tile_counts / k_block_scan  tiles-touched in depth order -> offsets, R (one D2H read)
+//             K4 k_emit            cooperative, coalesced emission of (tile u16, gid u32) in depth order
+//             K5 radix sort        16-bit tile keys over R (<=2 passes, stable) -> (tile, depth, id) order
+//             K6 k_tile_ranges     per-tile [start,end)
+//             K7 k_blend_fwd       per-tile front-to-back compositing, LDS-staged double-buffered lists
+//   backward  K8 k_blend_bwd       front-to-back replay, wave64 DPP reductions, one atomic set per (tile, Gaussian)
+//             K9 k_preprocess_bwd  per Gaussian: conic/cov2D/cov3D/projection/SH chain rule
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <mutex>
+#include <vector>
+
+#include "../../include/gsr.h"
+#include "gsr_math.h"
+#include "radix_sort.h"
+
+namespace gsr {
+
+// ------------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+static int g_blend_ppt = 0;   // 0 = default
+static int g_bwd_ppt = 0;
+
+static int fail(int code, const char* fmt, const char* detail = "")
+{
+    snprintf(g_err, sizeof g_err, fmt, detail);
+    return code;
+}
+
+#define GSR_HIP(expr)                                                         \
+    do {                                                                      \
+        hipError_t e_ = (expr);                                               \
+        if (e_ != hipSuccess) return fail(GSR_ERR_HIP, #expr ": %s", hipGetErrorString(e_)); \
+    } while (0)
+
+static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// Optional per-kernel timing with HIP events on the caller's stream (bench.py roofline leg).
+enum ProfId { P_PRE_FWD, P_SORT_DEPTH, P_SCAN, P_EMIT, P_SORT_TILE, P_RANGES, P_BLEND_FWD, P_BLEND_BWD, P_PRE_BWD, P_COUNT };
+static const char* kProfNames[P_COUNT] = {"preprocess_fwd", "sort_depth", "scan", "emit", "sort_tile", "ranges",
+                                          "blend_fwd", "blend_bwd", "preprocess_bwd"};
+static int g_profile = 0;
+struct ProfPair { hipEvent_t a, b; };
+static std::mutex g_prof_mutex;
+static std::vector<ProfPair> g_prof_events[P_COUNT];
+struct ProfScope {
+    int id; hipStream_t st; hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(int id_, hipStream_t st_) : id(id_), st(st_)
+    {
+        if (!g_profile) return;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
+        (void)hipEventRecord(a, st);
+    }
+    ~ProfScope()
+    {
+        if (!a) return;
+        (void)hipEventRecord(b, st);
+        std::lock_guard<std::mutex> lk(g_prof_mutex);
+        g_prof_events[id].push_back({a, b});
+    }
+};
+
+struct CamParams {
+    const float *vm, *pm, *campos;
+    float tanfovx, tanfovy, scale_mod;
+    int W, H, D, M;
+};
+
+__device__ __forceinline__ Camera load_camera(const CamParams& p)
+{
+    Camera c;
+#pragma unroll
+    for (int k = 0; k < 16; k++) { c.vm[k] = p.vm[k]; c.pm[k] = p.pm[k]; }
+    c.cam[0] = p.campos ? p.campos[0] : 0.f; c.cam[1] = p.campos ? p.campos[1] : 0.f; c.cam[2] = p.campos ? p.campos[2] : 0.f;
+    c.tanfovx = p.tanfovx; c.tanfovy = p.tanfovy;
+    c.fx = p.W / (2.f * p.tanfovx); c.fy = p.H / (2.f * p.tanfovy);
+    c.scale_mod = p.scale_mod; c.W = p.W; c.H = p.H;
+    c.tiles_x = (p.W + kTile - 1) / kTile; c.tiles_y = (p.H + kTile - 1) / kTile;
+    c.D = p.D; c.M = p.M;
+    return c;
+}
+
+// wave64 sum via DPP (row_shr 1,2,4,8 then row_bcast15 / row_bcast31): total lands in lane 63.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v)
+{
+    const int r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false);
+    return v + __int_as_float(r);
+}
+__device__ __forceinline__ float wave_sum_to_lane63(float v)
+{
+    v = dpp_add<0x111, 0xf>(v);   // row_shr:1
+    v = dpp_add<0x112, 0xf>(v);   // row_shr:2
+    v = dpp_add<0x114, 0xf>(v);   // row_shr:4
+    v = dpp_add<0x118, 0xf>(v);   // row_shr:8
+    v = dpp_add<0x142, 0xa>(v);   // row_bcast:15 -> rows 1,3
+    v = dpp_add<0x143, 0xc>(v);   // row_bcast:31 -> rows 2,3
+    return v;
+}
+
+constexpr int kPreThreads = 128;
+constexpr int kShStride = 49;   // 48 floats + 1 pad: conflict-free column reads
+
+// ------------------------------------------------------------------------------------------------
+// K1: per-Gaussian projection.  SH rows are staged through LDS with coalesced loads.
+// ------------------------------------------------------------------------------------------------
+template <int DEG>
+__global__ __launch_bounds__(kPreThreads) void k_preprocess(CamParams cp, int N, const float* __restrict__ means,
+                                                            const float* __restrict__ scales, const float* __restrict__ rots,
+                                                            const float* __restrict__ cov_pre, const float* __restrict__ opac,
+                                                            const float* __restrict__ shs, const float* __restrict__ colors,
+                                                            Splat* __restrict__ splat, int32_t* __restrict__ radii,
+                                                            uint32_t* __restrict__ dkey, uint32_t* __restrict__ gid)
+{
+    constexpr int NC3 = 3 * (DEG + 1) * (DEG + 1);
+    __shared__ float s_sh[kPreThreads * kShStride];
+    const int tid = threadIdx.x;
+    const int base = blockIdx.x * kPreThreads;
+    const int i = base + tid;
+    if (shs) {
+        const int nG = min(kPreThreads, N - base);
+        const size_t row = (size_t)cp.M * 3;
+        for (int f = tid; f < nG * NC3; f += kPreThreads) {
+            const int g = f / NC3, e = f - g * NC3;
+            s_sh[g * kShStride + e] = shs[(size_t)(base + g) * row + e];
+        }
+        __syncthreads();
+    }
+    if (i >= N) return;
+    Camera cam = load_camera(cp);
+    cam.D = DEG;
+    const float mean[3] = {means[3 * (size_t)i], means[3 * (size_t)i + 1], means[3 * (size_t)i + 2]};
+    float sc[3] = {0, 0, 0}, rq[4] = {1, 0, 0, 0}, cv[6], colp[3];
+    if (cov_pre) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) cv[k] = cov_pre[6 * (size_t)i + k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 3; k++) sc[k] = scales[3 * (size_t)i + k];
+#pragma unroll
+        for (int k = 0; k < 4; k++) rq[k] = rots[4 * (size_t)i + k];
+    }
+    if (colors) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) colp[k] = colors[3 * (size_t)i + k];
+    }
+    Splat s;
+    preprocess_one(cam, mean, sc, rq, cov_pre ? cv : nullptr, opac[i], shs ? &s_sh[tid * kShStride] : nullptr, 3, 1,
+                   colors ? colp : nullptr, s);
+    splat[i] = s;
+    radii[i] = s.radius;
+    dkey[i] = s.radius > 0 ? __float_as_uint(s.depth) : 0xffffffffu;
+    gid[i] = (uint32_t)i;
+}
+
+__global__ void k_mark_visible(int N, const float* __restrict__ means, const float* __restrict__ vm, uint8_t* __restrict__ present)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    float v[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) v[k] = vm[k];
+    present[i] = depth_key(v, means[3 * (size_t)i], means[3 * (size_t)i + 1], means[3 * (size_t)i + 2]) > kNearZ ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3: tiles-touched in depth order -> per-block sums -> exclusive block offsets + total
+// ------------------------------------------------------------------------------------------------
+constexpr int kEmitThreads = 256;
+
+__device__ __forceinline__ uint32_t block_inclusive_scan_256(uint32_t v, uint32_t* s_wave /*[4]*/, uint32_t& total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t x = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t y = __shfl_up(x, off, 64);
+        if (lane >= off) x += y;
+    }
+    if (lane == 63) s_wave[wave] = x;
+    __syncthreads();
+    uint32_t add = 0;
+    for (int w = 0; w < wave; w++) add += s_wave[w];
+    total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    return x + add;
+}
+
+__global__ __launch_bounds__(kEmitThreads) void k_tile_counts(int N, const uint32_t* __restrict__ sorted_gid,
+                                                              const Splat* __restrict__ splat, uint32_t* __restrict__ block_sums)
+{
+    __shared__ uint32_t s_wave[4];
+    const int j = blockIdx.x * kEmitThreads + threadIdx.x;
+    uint32_t t = 0;
+    if (j < N) t = splat[sorted_gid[j]].tiles;
+    uint32_t total;
+    block_inclusive_scan_256(t, s_wave, total);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+// single workgroup: exclusive scan of block_sums[nb] in place; total (64-bit) -> *total_out
+__global__ __launch_bounds__(1024) void k_block_scan(uint32_t* __restrict__ block_sums, int nb, unsigned long long* __restrict__ total_out)
+{
+    __shared__ unsigned long long s_part[1024];
+    const int tid = threadIdx.x;
+    const int chunk = (nb + 1023) / 1024;
+    const int lo = min(nb, tid * chunk), hi = min(nb, lo + chunk);
+    unsigned long long sum = 0;
+    for (int b = lo; b < hi; b++) sum += block_sums[b];
+    s_part[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const unsigned long long v = (tid >= off) ? s_part[tid - off] : 0ull;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    unsigned long long run = s_part[tid] - sum;
+    for (int b = lo; b < hi; b++) {
+        const uint32_t c = block_sums[b];
+        block_sums[b] = (uint32_t)run;
+        run += c;
+    }
+    if (tid == 1023) *total_out = s_part[1023];
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4: emit (tile, gid) instances in depth order.  A block owns 256 depth-sorted Gaussians and a contiguous
+// output range; lanes take consecutive output slots (coalesced stores) and find their (Gaussian, tile)
+// by binary search in the block's inclusive scan.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kEmitThreads) void k_emit(int N, int tiles_x, int tiles_y, const uint32_t* __restrict__ sorted_gid,
+                                                       const Splat* __restrict__ splat, const uint32_t* __restrict__ block_offsets,
+                                                       uint16_t* __restrict__ out_tile, uint32_t* __restrict__ out_gid)
+{
+    __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t s_incl[kEmitThreads];
+    __shared__ uint32_t s_gid[kEmitThreads];
+    __shared__ int s_x0[kEmitThreads], s_y0[kEmitThreads], s_w[kEmitThreads];
+    const int tid = threadIdx.x;
+    const int j = blockIdx.x * kEmitThreads + tid;
+    uint32_t t = 0, g = 0;
+    int x0 = 0, y0 = 0, w = 1;
+    if (j < N) {
+        g = sorted_gid[j];
+        const Splat s = splat[g];
+        t = s.tiles;
+        if (t) {
+            int x1, y1;
+            tile_rect(s.px, s.py, s.radius, tiles_x, tiles_y, x0, y0, x1, y1);
+            w = x1 - x0;
+        }
+    }
+    uint32_t total;
+    const uint32_t incl = block_inclusive_scan_256(t, s_wave, total);
+    s_incl[tid] = incl; s_gid[tid] = g; s_x0[tid] = x0; s_y0[tid] = y0; s_w[tid] = w;
+    __syncthreads();
+    const uint32_t out_base = block_offsets[blockIdx.x];
+    for (uint32_t q = tid; q < total; q += kEmitThreads) {
+        int lo = 0, hi = kEmitThreads - 1;   // first index with s_incl > q
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (s_incl[mid] > q) hi = mid; else lo = mid + 1;
+        }
+        const uint32_t excl = lo ? s_incl[lo - 1] : 0u;
+        const int k = (int)(q - excl);
+        const int ww = s_w[lo];
+        const int ty = k / ww, tx = k - ty * ww;
+        out_tile[out_base + q] = (uint16_t)((s_y0[lo] + ty) * tiles_x + s_x0[lo] + tx);
+        out_gid[out_base + q] = s_gid[lo];
+    }
+}
+
+// K6: per-tile [start, end) from the tile-sorted keys (ranges pre-zeroed)
+__global__ void k_tile_ranges(uint32_t R, const uint16_t* __restrict__ keys, uint2* __restrict__ ranges)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R) return;
+    const uint32_t t = keys[i];
+    if (i == 0) ranges[t].x = 0;
+    else {
+        const uint32_t p = keys[i - 1];
+        if (p != t) { ranges[p].y = i; ranges[t].x = i; }
+    }
+    if (i == R - 1) ranges[t].y = R;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K7: forward blend.  One workgroup per 16x16 tile, PPT pixels per thread (NT = 256/PPT threads).
+// Lists are staged NT instances at a time through a double-buffered LDS ring; the next batch's gathers
+// are in flight while the current one is composited.  XCD-aware tile mapping: block b runs on XCD b%8, so
+// each XCD gets a contiguous band of tiles (neighbouring tiles share splats -> shared L2 lines).
+// image state planes (floats): 0 final_T, 1 n_contrib(u32), 2..4 C, 5 D, 6 A
+// ------------------------------------------------------------------------------------------------
+constexpr int kImgPlanes = 7;
+
+__device__ __forceinline__ int xcd_tile(int b, int T)
+{
+    const int per = (T + 7) >> 3;
+    return (b & 7) * per + (b >> 3);
+}
+
+template <int PPT>
+__global__ __launch_bounds__(256 / PPT) void k_blend_fwd(int W, int H, int tiles_x, int T, const uint2* __restrict__ ranges,
+                                                         const uint32_t* __restrict__ list, const Splat* __restrict__ splat,
+                                                         const float* __restrict__ bg, float* __restrict__ out_color,
+                                                         float* __restrict__ out_depth, float* __restrict__ out_alpha,
+                                                         float* __restrict__ img, uint32_t* __restrict__ staged)
+{
+    constexpr int NT = 256 / PPT;
+    __shared__ float4 s_a[2][NT], s_b[2][NT], s_c[2][NT];
+    const int tile = xcd_tile(blockIdx.x, T);
+    if (tile >= T) return;
+    const int tid = threadIdx.x;
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const int px = tx * kTile + (tid & 15);
+    const int py0 = ty * kTile + (tid >> 4) * PPT;
+    const float pxf = (float)px;
+    const uint2 rg = ranges[tile];
+    const int n = (int)(rg.y - rg.x);
+    const int nb = (n + NT - 1) / NT;
+
+    PixelAcc acc[PPT];
+    uint32_t last[PPT];
+    bool done[PPT];
+#pragma unroll
+    for (int p = 0; p < PPT; p++) {
+        acc[p] = {1.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        last[p] = 0;
+        done[p] = !(px < W && (py0 + p) < H);
+    }
+    float4 ra = {0, 0, 0, 0}, rb = ra, rc = ra;
+    if (tid < n) {
+        const float4* sp = reinterpret_cast<const float4*>(splat + list[rg.x + tid]);
+        ra = sp[0]; rb = sp[1]; rc = sp[2];
+    }
+    int batches = 0;
+    for (int b = 0; b < nb; b++) {
+        const int buf = b & 1;
+        s_a[buf][tid] = ra; s_b[buf][tid] = rb; s_c[buf][tid] = rc;
+        bool all_done = true;
+#pragma unroll
+        for (int p = 0; p < PPT; p++) all_done = all_done && done[p];
+        if (__syncthreads_and(all_done)) break;
+        batches = b + 1;
+        const int nxt = (b + 1) * NT + tid;
+        if (nxt < n) {
+            const float4* sp = reinterpret_cast<const float4*>(splat + list[rg.x + nxt]);
+            ra = sp[0]; rb = sp[1]; rc = sp[2];
+        }
+        if (!all_done) {
+            const int cnt = min(NT, n - b * NT);
+            for (int j = 0; j < cnt; j++) {
+                const float4 A = s_a[buf][j], B = s_b[buf][j], C = s_c[buf][j];
+#pragma unroll
+                for (int p = 0; p < PPT; p++) {
+                    if (done[p]) continue;
+                    float G, dx, dy;
+                    const float alpha = pair_alpha(pxf, (float)(py0 + p), A.x, A.y, A.z, A.w, B.x, B.y, G, dx, dy);
+                    if (alpha == 0.f) continue;
+                    if (!blend_step_fwd(acc[p], alpha, B.w, C.x, C.y, B.z)) { done[p] = true; continue; }
+                    last[p] = (uint32_t)(b * NT + j + 1);
+                }
+            }
+        }
+    }
+    if (tid == 0) staged[tile] = (uint32_t)min(n, batches * NT);   // instances actually staged (R_eff)
+    const size_t P = (size_t)W * H;
+    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
+#pragma unroll
+    for (int p = 0; p < PPT; p++) {
+        const int py = py0 + p;
+        if (px < W && py < H) {
+            const size_t pid = (size_t)py * W + px;
+            const PixelAcc& a = acc[p];
+            img[pid] = a.T;
+            reinterpret_cast<uint32_t*>(img)[P + pid] = last[p];
+            img[2 * P + pid] = a.C0; img[3 * P + pid] = a.C1; img[4 * P + pid] = a.C2;
+            img[5 * P + pid] = a.D; img[6 * P + pid] = a.A;
+            out_color[pid] = a.C0 + a.T * bg0;
+            out_color[P + pid] = a.C1 + a.T * bg1;
+            out_color[2 * P + pid] = a.C2 + a.T * bg2;
+            out_depth[pid] = a.D;
+            out_alpha[pid] = a.A;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K8: backward blend.  Same staging; front-to-back replay from the stored totals.  The per-(pixel,Gaussian)
+// contributions are summed over the thread's pixels, reduced across the wave with DPP, combined across
+// the tile's waves in LDS, and flushed with ONE set of 10 float atomics per (tile, Gaussian) by the
+// thread that staged that Gaussian (parallel across lanes, not serialised on a leader).
+// ggrad record (12 floats / Gaussian): gx gy gA gB gC gop gr gg gb gz - -
+// ------------------------------------------------------------------------------------------------
+constexpr int kGG = 12;
+
+template <int PPT>
+__global__ __launch_bounds__(256 / PPT) void k_blend_bwd(int W, int H, int tiles_x, int T, const uint2* __restrict__ ranges,
+                                                         const uint32_t* __restrict__ list, const Splat* __restrict__ splat,
+                                                         const float* __restrict__ bg, const float* __restrict__ img,
+                                                         const float* __restrict__ g_color, const float* __restrict__ g_depth,
+                                                         const float* __restrict__ g_alpha, float* __restrict__ ggrad)
+{
+    constexpr int NT = 256 / PPT;
+    constexpr int NW = NT / 64;
+    __shared__ float4 s_a[2][NT], s_b[2][NT], s_c[2][NT];
+    __shared__ uint32_t s_gid[2][NT];
+    __shared__ float s_part[NW][NT][10];
+    __shared__ uint32_t s_max[NW];
+    const int tile = xcd_tile(blockIdx.x, T);
+    if (tile >= T) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const int px = tx * kTile + (tid & 15);
+    const int py0 = ty * kTile + (tid >> 4) * PPT;
+    const float pxf = (float)px;
+    const uint2 rg = ranges[tile];
+    const size_t P = (size_t)W * H;
+    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
+
+    PixelBwd st[PPT];
+    uint32_t ncon[PPT];
+    uint32_t nmax = 0;
+#pragma unroll
+    for (int p = 0; p < PPT; p++) {
+        const int py = py0 + p;
+        ncon[p] = 0;
+        st[p] = {1.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (px < W && py < H) {
+            const size_t pid = (size_t)py * W + px;
+            ncon[p] = reinterpret_cast<const uint32_t*>(img)[P + pid];
+            st[p].sC0 = img[2 * P + pid]; st[p].sC1 = img[3 * P + pid]; st[p].sC2 = img[4 * P + pid];
+            st[p].sD = img[5 * P + pid]; st[p].sA = img[6 * P + pid];
+            if (g_color) { st[p].gC0 = g_color[pid]; st[p].gC1 = g_color[P + pid]; st[p].gC2 = g_color[2 * P + pid]; }
+            if (g_depth) st[p].gD = g_depth[pid];
+            if (g_alpha) st[p].gA = g_alpha[pid];
+            st[p].bgdot = img[pid] * (bg0 * st[p].gC0 + bg1 * st[p].gC1 + bg2 * st[p].gC2);
+            nmax = max(nmax, ncon[p]);
+        }
+    }
+    // block max of n_contrib = how far the list has to be replayed
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, off, 64));
+    if (lane == 0) s_max[wave] = nmax;
+    __syncthreads();
+    nmax = 0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) nmax = max(nmax, s_max[w]);
+    const int n = (int)nmax;
+    const int nb = (n + NT - 1) / NT;
+
+    float4 ra = {0, 0, 0, 0}, rb = ra, rc = ra;
+    uint32_t rg_id = 0;
+    if (tid < n) {
+        rg_id = list[rg.x + tid];
+        const float4* sp = reinterpret_cast<const float4*>(splat + rg_id);
+        ra = sp[0]; rb = sp[1]; rc = sp[2];
+    }
+    for (int b = 0; b < nb; b++) {
+        const int buf = b & 1;
+        s_a[buf][tid] = ra; s_b[buf][tid] = rb; s_c[buf][tid] = rc; s_gid[buf][tid] = rg_id;
+#pragma unroll
+        for (int w = 0; w < NW; w++)
+#pragma unroll
+            for (int k = 0; k < 10; k++) s_part[w][tid][k] = 0.f;
+        __syncthreads();
+        const int nxt = (b + 1) * NT + tid;
+        if (nxt < n) {
+            rg_id = list[rg.x + nxt];
+            const float4* sp = reinterpret_cast<const float4*>(splat + rg_id);
+            ra = sp[0]; rb = sp[1]; rc = sp[2];
+        }
+        const int cnt = min(NT, n - b * NT);
+        for (int j = 0; j < cnt; j++) {
+            const float4 A = s_a[buf][j], B = s_b[buf][j], C = s_c[buf][j];
+            const uint32_t idx = (uint32_t)(b * NT + j + 1);
+            PairGrad pg = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            bool touched = false;
+#pragma unroll
+            for (int p = 0; p < PPT; p++) {
+                if (idx > ncon[p]) continue;
+                float G, dx, dy;
+                const float alpha = pair_alpha(pxf, (float)(py0 + p), A.x, A.y, A.z, A.w, B.x, B.y, G, dx, dy);
+                if (alpha == 0.f) continue;
+                blend_step_bwd(st[p], alpha, G, dx, dy, A.z, A.w, B.x, B.y, B.w, C.x, C.y, B.z, pg);
+                touched = true;
+            }
+            if (__any(touched)) {   // wave-uniform
+                float v[10] = {pg.gx, pg.gy, pg.gA, pg.gB, pg.gC, pg.gop, pg.gr, pg.gg, pg.gb, pg.gz};
+#pragma unroll
+                for (int k = 0; k < 10; k++) v[k] = wave_sum_to_lane63(v[k]);
+                if (lane == 63) {
+#pragma unroll
+                    for (int k = 0; k < 10; k++) s_part[wave][j][k] = v[k];
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < cnt) {
+            float v[10];
+#pragma unroll
+            for (int k = 0; k < 10; k++) {
+                float s = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; w++) s += s_part[w][tid][k];
+                v[k] = s;
+            }
+            bool nz = false;
+#pragma unroll
+            for (int k = 0; k < 10; k++) nz = nz || (v[k] != 0.f);
+            if (nz) {
+                float* dst = ggrad + (size_t)s_gid[buf][tid] * kGG;
+#pragma unroll
+                for (int k = 0; k < 10; k++) atomicAdd(dst + k, v[k]);
+            }
+        }
+        // s_part is re-zeroed at the top of the next iteration by the same thread rows, after which a
+        // barrier follows; the reads above are per-row (tid) so no extra barrier is needed here.
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K9: per-Gaussian backward.  SH rows in, dSH rows out through the same LDS tile (coalesced both ways).
+// ------------------------------------------------------------------------------------------------
+template <int DEG>
+__global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, int N, const float* __restrict__ means,
+                                                                const float* __restrict__ scales, const float* __restrict__ rots,
+                                                                const float* __restrict__ cov_pre, const float* __restrict__ shs,
+                                                                const Splat* __restrict__ splat, const float* __restrict__ ggrad,
+                                                                float* __restrict__ d_means, float* __restrict__ d_means2d,
+                                                                float* __restrict__ d_opac, float* __restrict__ d_colors,
+                                                                float* __restrict__ d_shs, float* __restrict__ d_scales,
+                                                                float* __restrict__ d_rots, float* __restrict__ d_cov)
+{
+    constexpr int NC3 = 3 * (DEG + 1) * (DEG + 1);
+    __shared__ float s_sh[kPreThreads * kShStride];
+    const int tid = threadIdx.x;
+    const int base = blockIdx.x * kPreThreads;
+    const int i = base + tid;
+    const int nG = min(kPreThreads, N - base);
+    if (shs) {
+        const size_t row = (size_t)cp.M * 3;
+        for (int f = tid; f < nG * NC3; f += kPreThreads) {
+            const int g = f / NC3, e = f - g * NC3;
+            s_sh[g * kShStride + e] = shs[(size_t)(base + g) * row + e];
+        }
+        __syncthreads();
+    }
+    if (i < N) {
+        Camera cam = load_camera(cp);
+        cam.D = DEG;
+        const Splat s = splat[i];
+        float dmean[3] = {0.f, 0.f, 0.f}, m2d[2] = {0.f, 0.f}, dop = 0.f;
+        float dsc[3] = {0.f, 0.f, 0.f}, drq[4] = {0.f, 0.f, 0.f, 0.f}, dcv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float grgb[3] = {0.f, 0.f, 0.f};
+        if (s.radius > 0) {
+            const float4* gp = reinterpret_cast<const float4*>(ggrad + (size_t)i * kGG);
+            const float4 g0 = gp[0], g1 = gp[1], g2 = gp[2];   // gx gy gA gB | gC gop gr gg | gb gz - -
+            const float mean[3] = {means[3 * (size_t)i], means[3 * (size_t)i + 1], means[3 * (size_t)i + 2]};
+            float sc[3] = {0, 0, 0}, rq[4] = {1, 0, 0, 0}, cv[6];
+            if (cov_pre) {
+#pragma unroll
+                for (int k = 0; k < 6; k++) cv[k] = cov_pre[6 * (size_t)i + k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 3; k++) sc[k] = scales[3 * (size_t)i + k];
+#pragma unroll
+                for (int k = 0; k < 4; k++) rq[k] = rots[4 * (size_t)i + k];
+            }
+            GaussGrads o;
+            gauss_backward(cam, mean, sc, rq, cov_pre ? cv : nullptr, g0.x, g0.y, g0.z, g0.w, g1.x, g2.y, o);
+            dmean[0] = o.mean[0]; dmean[1] = o.mean[1]; dmean[2] = o.mean[2];
+            m2d[0] = o.mean2d[0]; m2d[1] = o.mean2d[1];
+            dop = g1.y;
+            grgb[0] = g1.z; grgb[1] = g1.w; grgb[2] = g2.x;
+#pragma unroll
+            for (int k = 0; k < 3; k++) dsc[k] = o.scale[k];
+#pragma unroll
+            for (int k = 0; k < 4; k++) drq[k] = o.rot[k];
+#pragma unroll
+            for (int k = 0; k < 6; k++) dcv[k] = o.cov[k];
+            if (shs) sh_backward(cam, mean, &s_sh[tid * kShStride], 3, 1, grgb, &s_sh[tid * kShStride], 3, 1, dmean);
+        } else if (shs) {
+            for (int e = 0; e < NC3; e++) s_sh[tid * kShStride + e] = 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++) d_means[3 * (size_t)i + k] = dmean[k];
+        d_means2d[3 * (size_t)i] = m2d[0]; d_means2d[3 * (size_t)i + 1] = m2d[1]; d_means2d[3 * (size_t)i + 2] = 0.f;
+        d_opac[i] = dop;
+        if (d_colors) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) d_colors[3 * (size_t)i + k] = grgb[k];
+        }
+        if (d_scales) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) d_scales[3 * (size_t)i + k] = dsc[k];
+        }
+        if (d_rots) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) d_rots[4 * (size_t)i + k] = drq[k];
+        }
+        if (d_cov) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) d_cov[6 * (size_t)i + k] = dcv[k];
+        }
+    }
+    if (shs && d_shs) {
+        __syncthreads();
+        const int row = cp.M * 3;
+        for (int f = tid; f < nG * row; f += kPreThreads) {
+            const int g = f / row, e = f - g * row;
+            d_shs[(size_t)(base + g) * row + e] = e < NC3 ? s_sh[g * kShStride + e] : 0.f;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+struct GeomLayout {   // gsr_geom: only the splats survive until backward
+    size_t splat;
+    size_t total;
+};
+static GeomLayout geom_layout(int32_t N)
+{
+    GeomLayout g;
+    g.splat = 0;
+    g.total = align256((size_t)(N > 0 ? N : 1) * sizeof(Splat));
+    return g;
+}
+
+struct FwdScratch {   // N-sized scratch of the forward
+    size_t dkey, gid, dkey_alt, gid_alt, block_sums, total, sort;
+    size_t bytes;
+};
+static FwdScratch fwd_scratch_layout(int32_t N)
+{
+    const size_t n = (size_t)(N > 0 ? N : 1);
+    FwdScratch s;
+    size_t o = 0;
+    s.dkey = o; o += align256(n * 4);
+    s.gid = o; o += align256(n * 4);
+    s.dkey_alt = o; o += align256(n * 4);
+    s.gid_alt = o; o += align256(n * 4);
+    s.block_sums = o; o += align256(((n + kEmitThreads - 1) / kEmitThreads) * 4);
+    s.total = o; o += 256;
+    s.sort = o; o += radix_scratch_bytes((uint32_t)n);
+    s.bytes = o;
+    return s;
+}
+
+struct BinLayout {   // persistent: list + ranges
+    size_t list, ranges, bytes;
+};
+static BinLayout bin_layout(int64_t R, int32_t W, int32_t H)
+{
+    const size_t T = (size_t)((W + kTile - 1) / kTile) * ((H + kTile - 1) / kTile);
+    BinLayout b;
+    b.ranges = 0;
+    b.list = align256((T ? T : 1) * sizeof(uint2));
+    b.bytes = b.list + align256((size_t)(R > 0 ? R : 1) * 4);
+    return b;
+}
+
+struct BinScratch {
+    size_t tile, tile_alt, gid_alt, sort, bytes;
+};
+static BinScratch bin_scratch_layout(int64_t R)
+{
+    const size_t r = (size_t)(R > 0 ? R : 1);
+    BinScratch s;
+    size_t o = 0;
+    s.tile = o; o += align256(r * 2);
+    s.tile_alt = o; o += align256(r * 2);
+    s.gid_alt = o; o += align256(r * 4);
+    s.sort = o; o += radix_scratch_bytes((uint32_t)r);
+    s.bytes = o;
+    return s;
+}
+
+static std::mutex g_pin_mutex;
+static unsigned long long* g_pinned = nullptr;
+
+static int check_common(int32_t N, int32_t M, int32_t D, int32_t W, int32_t H)
+{
+    if (N < 0 || W <= 0 || H <= 0) return fail(GSR_ERR_ARG, "bad sizes%s");
+    if (D < 0 || D > 3) return fail(GSR_ERR_ARG, "sh_degree must be 0..3%s");
+    if (M < 0 || M > 16) return fail(GSR_ERR_ARG, "at most 16 SH coefficients per Gaussian%s");
+    const long long T = (long long)((W + kTile - 1) / kTile) * ((H + kTile - 1) / kTile);
+    if (T > 65535) return fail(GSR_ERR_RANGE, "image has more than 65535 tiles%s");
+    return GSR_OK;
+}
+
+template <int PPT>
+static void launch_blend_fwd(int W, int H, int tiles_x, int T, const uint2* ranges, const uint32_t* list, const Splat* splat,
+                             const float* bg, float* oc, float* od, float* oa, float* img, uint32_t* staged, hipStream_t st)
+{
+    const int grid = 8 * ((T + 7) / 8);
+    hipLaunchKernelGGL(k_blend_fwd<PPT>, dim3(grid), dim3(256 / PPT), 0, st, W, H, tiles_x, T, ranges, list, splat, bg, oc, od, oa, img, staged);
+}
+template <int PPT>
+static void launch_blend_bwd(int W, int H, int tiles_x, int T, const uint2* ranges, const uint32_t* list, const Splat* splat,
+                             const float* bg, const float* img, const float* gc, const float* gd, const float* ga, float* gg,
+                             hipStream_t st)
+{
+    const int grid = 8 * ((T + 7) / 8);
+    hipLaunchKernelGGL(k_blend_bwd<PPT>, dim3(grid), dim3(256 / PPT), 0, st, W, H, tiles_x, T, ranges, list, splat, bg, img, gc, gd, ga, gg);
+}
+
+}  // namespace gsr
+
+using namespace gsr;
+
+extern "C" {
+
+size_t gsr_image_staged_offset(int32_t W, int32_t H);
+
+size_t gsr_geom_bytes(int32_t N) { return geom_layout(N).total; }
+size_t gsr_image_staged_offset(int32_t W, int32_t H) { return align256((size_t)W * H * kImgPlanes * 4); }
+size_t gsr_image_bytes(int32_t W, int32_t H)
+{
+    const size_t T = (size_t)((W + kTile - 1) / kTile) * ((H + kTile - 1) / kTile);
+    return gsr_image_staged_offset(W, H) + align256(T * 4);
+}
+
+int gsr_profile_read(const char* name, double* total_ms, int64_t* count)
+{
+    if (!name || !total_ms || !count) return GSR_ERR_ARG;
+    for (int id = 0; id < P_COUNT; id++) {
+        if (strcmp(name, kProfNames[id])) continue;
+        std::lock_guard<std::mutex> lk(g_prof_mutex);
+        double tot = 0; int64_t n = 0;
+        for (auto& p : g_prof_events[id]) {
+            float ms = 0.f;
+            if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { tot += ms; n++; }
+            (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b);
+        }
+        g_prof_events[id].clear();
+        *total_ms = tot; *count = n;
+        return GSR_OK;
+    }
+    return GSR_ERR_ARG;
+}
+size_t gsr_forward_scratch_bytes(int32_t N) { return fwd_scratch_layout(N).bytes; }
+size_t gsr_binning_bytes(int64_t R, int32_t W, int32_t H) { return bin_layout(R, W, H).bytes; }
+size_t gsr_binning_scratch_bytes(int64_t R) { return bin_scratch_layout(R).bytes; }
+size_t gsr_backward_scratch_bytes(int32_t N) { return align256((size_t)(N > 0 ? N : 1) * kGG * 4); }
+size_t gsr_sort_scratch_bytes(uint32_t n) { return radix_scratch_bytes(n); }
+const char* gsr_last_error(void) { return g_err; }
+int gsr_version(void) { return 100; }
+
+int gsr_set_option(const char* name, int value)
+{
+    if (!name) return GSR_ERR_ARG;
+    if (!strcmp(name, "blend_fwd_ppt")) { if (value != 0 && value != 1 && value != 2 && value != 4) return GSR_ERR_ARG; g_blend_ppt = value; return GSR_OK; }
+    if (!strcmp(name, "profile")) { g_profile = value ? 1 : 0; return GSR_OK; }
+    if (!strcmp(name, "blend_bwd_ppt")) { if (value != 0 && value != 1 && value != 2 && value != 4) return GSR_ERR_ARG; g_bwd_ppt = value; return GSR_OK; }
+    return GSR_ERR_ARG;
+}
+
+int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
+{
+    hipStream_t st = (hipStream_t)stream_;
+    if (!a || !out) return fail(GSR_ERR_ARG, "null args%s");
+    int rc = check_common(a->N, a->M, a->D, a->W, a->H);
+    if (rc) return rc;
+    if (!a->out_color || !a->out_depth || !a->out_alpha || !a->image || !a->bg || !a->alloc)
+        return fail(GSR_ERR_ARG, "missing output / workspace pointer%s");
+    const int N = a->N, W = a->W, H = a->H;
+    const int tiles_x = (W + kTile - 1) / kTile, tiles_y = (H + kTile - 1) / kTile, T = tiles_x * tiles_y;
+    out->num_rendered = 0; out->binning = nullptr; out->binning_bytes = 0;
+    uint64_t R = 0;
+    Splat* splat = static_cast<Splat*>(a->geom);
+    uint32_t* sorted_gid = nullptr;
+    uint8_t* fs = nullptr;
+    FwdScratch L = fwd_scratch_layout(N);
+    if (N > 0) {
+        if (!a->means3D || !a->opacities || !a->geom || !a->radii || !a->viewmatrix || !a->projmatrix)
+            return fail(GSR_ERR_ARG, "missing input pointer%s");
+        if ((a->shs == nullptr) == (a->colors_precomp == nullptr)) return fail(GSR_ERR_ARG, "provide exactly one of shs / colors_precomp%s");
+        if ((a->cov3D_precomp == nullptr) == (a->scales == nullptr || a->rotations == nullptr))
+            return fail(GSR_ERR_ARG, "provide exactly one of (scales, rotations) / cov3D_precomp%s");
+        if (a->shs && (!a->campos || a->M < (a->D + 1) * (a->D + 1))) return fail(GSR_ERR_ARG, "shs needs campos and M >= (D+1)^2%s");
+        fs = static_cast<uint8_t*>(a->alloc(L.bytes, GSR_ALLOC_SCRATCH, a->alloc_user));
+        if (!fs) return fail(GSR_ERR_ALLOC, "scratch allocation failed%s");
+        uint32_t* dkey = reinterpret_cast<uint32_t*>(fs + L.dkey);
+        uint32_t* gid = reinterpret_cast<uint32_t*>(fs + L.gid);
+        uint32_t* dkey_alt = reinterpret_cast<uint32_t*>(fs + L.dkey_alt);
+        uint32_t* gid_alt = reinterpret_cast<uint32_t*>(fs + L.gid_alt);
+        uint32_t* block_sums = reinterpret_cast<uint32_t*>(fs + L.block_sums);
+        unsigned long long* total = reinterpret_cast<unsigned long long*>(fs + L.total);
+        CamParams cp = {a->viewmatrix, a->projmatrix, a->campos, a->tanfovx, a->tanfovy, a->scale_modifier, W, H, a->D, a->M};
+        const int grid = (N + kPreThreads - 1) / kPreThreads;
+#define GSR_PRE(DEG)                                                                                                         \
+    hipLaunchKernelGGL(k_preprocess<DEG>, dim3(grid), dim3(kPreThreads), 0, st, cp, N, a->means3D, a->scales, a->rotations, \
+                       a->cov3D_precomp, a->opacities, a->shs, a->colors_precomp, splat, a->radii, dkey, gid)
+        {
+            ProfScope ps(P_PRE_FWD, st);
+            switch (a->shs ? a->D : 0) {
+                case 0: GSR_PRE(0); break;
+                case 1: GSR_PRE(1); break;
+                case 2: GSR_PRE(2); break;
+                default: GSR_PRE(3); break;
+            }
+        }
+#undef GSR_PRE
+        int in_alt = 0;
+        {
+            ProfScope ps(P_SORT_DEPTH, st);
+            GSR_HIP(radix_sort_pairs<uint32_t>(dkey, gid, dkey_alt, gid_alt, (uint32_t)N, 0, 32, fs + L.sort, &in_alt, st));
+        }
+        sorted_gid = in_alt ? gid_alt : gid;
+        const int nb = (N + kEmitThreads - 1) / kEmitThreads;
+        {
+            ProfScope ps(P_SCAN, st);
+            hipLaunchKernelGGL(k_tile_counts, dim3(nb), dim3(kEmitThreads), 0, st, N, sorted_gid, splat, block_sums);
+            hipLaunchKernelGGL(k_block_scan, dim3(1), dim3(1024), 0, st, block_sums, nb, total);
+        }
+        GSR_HIP(hipGetLastError());
+        {
+            std::lock_guard<std::mutex> lk(g_pin_mutex);
+            if (!g_pinned) GSR_HIP(hipHostMalloc((void**)&g_pinned, 64, hipHostMallocDefault));
+            GSR_HIP(hipMemcpyAsync(g_pinned, total, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+            GSR_HIP(hipStreamSynchronize(st));
+            R = *g_pinned;
+        }
+        if (R > 0xfffffff0ull) return fail(GSR_ERR_RANGE, "more than 2^32 instances%s");
+    }
+    BinLayout B = bin_layout((int64_t)R, W, H);
+    uint8_t* bin = static_cast<uint8_t*>(a->alloc(B.bytes, GSR_ALLOC_BINNING, a->alloc_user));
+    if (!bin) return fail(GSR_ERR_ALLOC, "binning allocation failed%s");
+    uint2* ranges = reinterpret_cast<uint2*>(bin + B.ranges);
+    uint32_t* list = reinterpret_cast<uint32_t*>(bin + B.list);
+    GSR_HIP(hipMemsetAsync(ranges, 0, (size_t)T * sizeof(uint2), st));
+    if (R > 0) {
+        BinScratch S = bin_scratch_layout((int64_t)R);
+        uint8_t* bs = static_cast<uint8_t*>(a->alloc(S.bytes, GSR_ALLOC_SCRATCH, a->alloc_user));
+        if (!bs) return fail(GSR_ERR_ALLOC, "binning scratch allocation failed%s");
+        uint16_t* tkey = reinterpret_cast<uint16_t*>(bs + S.tile);
+        uint16_t* tkey_alt = reinterpret_cast<uint16_t*>(bs + S.tile_alt);
+        uint32_t* gid_alt2 = reinterpret_cast<uint32_t*>(bs + S.gid_alt);
+        uint32_t* block_sums = reinterpret_cast<uint32_t*>(fs + L.block_sums);
+        const int nb = (N + kEmitThreads - 1) / kEmitThreads;
+        int bits = 1;
+        while ((1 << bits) < T) bits++;
+        const int passes = (bits + 7) / 8;
+        // arrange the ping-pong so that the sorted gids land directly in `list`
+        uint32_t* v0 = (passes & 1) ? gid_alt2 : list;
+        uint32_t* v1 = (passes & 1) ? list : gid_alt2;
+        {
+            ProfScope ps(P_EMIT, st);
+            hipLaunchKernelGGL(k_emit, dim3(nb), dim3(kEmitThreads), 0, st, N, tiles_x, tiles_y, sorted_gid, splat, block_sums, tkey, v0);
+        }
+        int in_alt = 0;
+        {
+            ProfScope ps(P_SORT_TILE, st);
+            GSR_HIP(radix_sort_pairs<uint16_t>(tkey, v0, tkey_alt, v1, (uint32_t)R, 0, passes * 8, bs + S.sort, &in_alt, st));
+        }
+        const uint16_t* skey = in_alt ? tkey_alt : tkey;
+        {
+            ProfScope ps(P_RANGES, st);
+            hipLaunchKernelGGL(k_tile_ranges, dim3(((uint32_t)R + 255) / 256), dim3(256), 0, st, (uint32_t)R, skey, ranges);
+        }
+    }
+    const int ppt = g_blend_ppt ? g_blend_ppt : 2;
+    float* img = static_cast<float*>(a->image);
+    uint32_t* staged = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(a->image) + gsr_image_staged_offset(W, H));
+    {
+        ProfScope ps(P_BLEND_FWD, st);
+        if (ppt == 1) launch_blend_fwd<1>(W, H, tiles_x, T, ranges, list, splat, a->bg, a->out_color, a->out_depth, a->out_alpha, img, staged, st);
+        else if (ppt == 2) launch_blend_fwd<2>(W, H, tiles_x, T, ranges, list, splat, a->bg, a->out_color, a->out_depth, a->out_alpha, img, staged, st);
+        else launch_blend_fwd<4>(W, H, tiles_x, T, ranges, list, splat, a->bg, a->out_color, a->out_depth, a->out_alpha, img, staged, st);
+    }
+    GSR_HIP(hipGetLastError());
+    out->num_rendered = (int64_t)R;
+    out->binning = bin;
+    out->binning_bytes = B.bytes;
+    return GSR_OK;
+}
+
+int gsr_backward(const GsrBackwardArgs* a, void* stream_)
+{
+    hipStream_t st = (hipStream_t)stream_;
+    if (!a) return fail(GSR_ERR_ARG, "null args%s");
+    int rc = check_common(a->N, a->M, a->D, a->W, a->H);
+    if (rc) return rc;
+    const int N = a->N, W = a->W, H = a->H;
+    if (N == 0) return GSR_OK;
+    if (!a->geom || !a->image || !a->binning || !a->scratch || !a->d_means3D || !a->d_means2D || !a->d_opacities)
+        return fail(GSR_ERR_ARG, "missing workspace / gradient pointer%s");
+    const int tiles_x = (W + kTile - 1) / kTile, tiles_y = (H + kTile - 1) / kTile, T = tiles_x * tiles_y;
+    const Splat* splat = static_cast<const Splat*>(a->geom);
+    BinLayout B = bin_layout(a->num_rendered, W, H);
+    const uint8_t* bin = static_cast<const uint8_t*>(a->binning);
+    const uint2* ranges = reinterpret_cast<const uint2*>(bin + B.ranges);
+    const uint32_t* list = reinterpret_cast<const uint32_t*>(bin + B.list);
+    float* gg = static_cast<float*>(a->scratch);
+    GSR_HIP(hipMemsetAsync(gg, 0, (size_t)N * kGG * 4, st));
+    if (a->num_rendered > 0) {
+        const int ppt = g_bwd_ppt ? g_bwd_ppt : 2;
+        const float* img = static_cast<const float*>(a->image);
+        ProfScope ps(P_BLEND_BWD, st);
+        if (ppt == 1) launch_blend_bwd<1>(W, H, tiles_x, T, ranges, list, splat, a->bg, img, a->grad_color, a->grad_depth, a->grad_alpha, gg, st);
+        else if (ppt == 2) launch_blend_bwd<2>(W, H, tiles_x, T, ranges, list, splat, a->bg, img, a->grad_color, a->grad_depth, a->grad_alpha, gg, st);
+        else launch_blend_bwd<4>(W, H, tiles_x, T, ranges, list, splat, a->bg, img, a->grad_color, a->grad_depth, a->grad_alpha, gg, st);
+    }
+    CamParams cp = {a->viewmatrix, a->projmatrix, a->campos, a->tanfovx, a->tanfovy, a->scale_modifier, W, H, a->D, a->M};
+    const int grid = (N + kPreThreads - 1) / kPreThreads;
+#define GSR_PREB(DEG)                                                                                                            \
+    hipLaunchKernelGGL(k_preprocess_bwd<DEG>, dim3(grid), dim3(kPreThreads), 0, st, cp, N, a->means3D, a->scales, a->rotations, \
+                       a->cov3D_precomp, a->shs, splat, gg, a->d_means3D, a->d_means2D, a->d_opacities, a->d_colors_precomp,    \
+                       a->d_shs, a->d_scales, a->d_rotations, a->d_cov3D_precomp)
+    {
+        ProfScope ps(P_PRE_BWD, st);
+        switch (a->shs ? a->D : 0) {
+            case 0: GSR_PREB(0); break;
+            case 1: GSR_PREB(1); break;
+            case 2: GSR_PREB(2); break;
+            default: GSR_PREB(3); break;
+        }
+    }
+#undef GSR_PREB
+    GSR_HIP(hipGetLastError());
+    return GSR_OK;
+}
+
+int gsr_mark_visible(int32_t N, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present, void* stream_)
+{
+    (void)projmatrix;
+    if (N < 0 || (N > 0 && (!means3D || !viewmatrix || !present))) return fail(GSR_ERR_ARG, "bad mark_visible args%s");
+    if (N == 0) return GSR_OK;
+    hipLaunchKernelGGL(k_mark_visible, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream_, N, means3D, viewmatrix, present);
+    GSR_HIP(hipGetLastError());
+    return GSR_OK;
+}
+
+int gsr_sort_pairs_u32(uint32_t* keys, uint32_t* vals, uint32_t* keys_alt, uint32_t* vals_alt, uint32_t n, int begin_bit, int end_bit,
+                       void* scratch, size_t scratch_bytes, int* result_in_alt, void* stream)
+{
+    if (scratch_bytes < radix_scratch_bytes(n) || !result_in_alt) return fail(GSR_ERR_ARG, "sort scratch too small%s");
+    GSR_HIP(radix_sort_pairs<uint32_t>(keys, vals, keys_alt, vals_alt, n, begin_bit, end_bit, scratch, result_in_alt, (hipStream_t)stream));
+    return GSR_OK;
+}
+
+int gsr_sort_pairs_u16(uint16_t* keys, uint32_t* vals, uint16_t* keys_alt, uint32_t* vals_alt, uint32_t n, int begin_bit, int end_bit,
+                       void* scratch, size_t scratch_bytes, int* result_in_alt, void* stream)
+{
+    if (scratch_bytes < radix_scratch_bytes(n) || !result_in_alt) return fail(GSR_ERR_ARG, "sort scratch too small%s");
+    GSR_HIP(radix_sort_pairs<uint16_t>(keys, vals, keys_alt, vals_alt, n, begin_bit, end_bit, scratch, result_in_alt, (hipStream_t)stream));
+    return GSR_OK;
+}
+
+}  // extern "C"

@@ -85,23 +85,28 @@ GSR_HD float depth_key(const float* vm, float x, float y, float z)
     return fmaf(vm[10], z, fmaf(vm[6], y, fmaf(vm[2], x, vm[14])));
 }
 
-GSR_HD void quat_to_rot(const float q[4], float R[9])
+// The forward projection is instantiated in double (RT = double): the per-Gaussian work is negligible next
+// to the blend, and a correctly-rounded Splat removes the dominant binary32 error of the image (measured:
+// max |err| vs the float64 oracle 9.8e-6 -> 4.1e-6 at 980x545).  The backward uses RT = float.
+template <typename RT>
+GSR_HD void quat_to_rot(const float q[4], RT R[9])
 {
-    const float r = q[0], x = q[1], y = q[2], z = q[3];
-    R[0] = 1.f - 2.f * (y * y + z * z); R[1] = 2.f * (x * y - r * z); R[2] = 2.f * (x * z + r * y);
-    R[3] = 2.f * (x * y + r * z); R[4] = 1.f - 2.f * (x * x + z * z); R[5] = 2.f * (y * z - r * x);
-    R[6] = 2.f * (x * z - r * y); R[7] = 2.f * (y * z + r * x); R[8] = 1.f - 2.f * (x * x + y * y);
+    const RT r = q[0], x = q[1], y = q[2], z = q[3];
+    R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - r * z); R[2] = 2 * (x * z + r * y);
+    R[3] = 2 * (x * y + r * z); R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - r * x);
+    R[6] = 2 * (x * z - r * y); R[7] = 2 * (y * z + r * x); R[8] = 1 - 2 * (x * x + y * y);
 }
 
 // Sigma = L L^T, L = R diag(mod*s); packed xx,xy,xz,yy,yz,zz
-GSR_HD void cov3d_from_scale_rot(const float s[3], float mod, const float q[4], float cov[6])
+template <typename RT>
+GSR_HD void cov3d_from_scale_rot(const float s[3], float mod, const float q[4], RT cov[6])
 {
-    float R[9];
-    quat_to_rot(q, R);
-    const float s0 = mod * s[0], s1 = mod * s[1], s2 = mod * s[2];
-    const float L00 = R[0] * s0, L01 = R[1] * s1, L02 = R[2] * s2;
-    const float L10 = R[3] * s0, L11 = R[4] * s1, L12 = R[5] * s2;
-    const float L20 = R[6] * s0, L21 = R[7] * s1, L22 = R[8] * s2;
+    RT R[9];
+    quat_to_rot<RT>(q, R);
+    const RT s0 = (RT)mod * s[0], s1 = (RT)mod * s[1], s2 = (RT)mod * s[2];
+    const RT L00 = R[0] * s0, L01 = R[1] * s1, L02 = R[2] * s2;
+    const RT L10 = R[3] * s0, L11 = R[4] * s1, L12 = R[5] * s2;
+    const RT L20 = R[6] * s0, L21 = R[7] * s1, L22 = R[8] * s2;
     cov[0] = L00 * L00 + L01 * L01 + L02 * L02;
     cov[1] = L00 * L10 + L01 * L11 + L02 * L12;
     cov[2] = L00 * L20 + L01 * L21 + L02 * L22;
@@ -112,29 +117,32 @@ GSR_HD void cov3d_from_scale_rot(const float s[3], float mod, const float q[4], 
 
 // Rows of the 2x3 screen-space Jacobian times the view rotation (M = J * Wr) and the clamped
 // view-space position.  Returns false if behind the near plane.
+template <typename RT>
 struct ProjFrame {
-    float t0, t1, t2;       // view-space mean, x/y after frustum clamp
-    float xmul, ymul;       // 0 where the clamp is active
-    float m0[3], m1[3];     // rows of M
-    float J00, J02, J11, J12;
+    RT t0, t1, t2;       // view-space mean, x/y after frustum clamp
+    RT xmul, ymul;       // 0 where the clamp is active
+    RT m0[3], m1[3];     // rows of M
+    RT J00, J02, J11, J12;
 };
 
-GSR_HD void proj_frame(const Camera& c, float X, float Y, float Z, ProjFrame& f)
+template <typename RT>
+GSR_HD void proj_frame(const Camera& c, RT X, RT Y, RT Z, ProjFrame<RT>& f)
 {
     const float* vm = c.vm;
-    float t0 = vm[0] * X + vm[4] * Y + vm[8] * Z + vm[12];
-    float t1 = vm[1] * X + vm[5] * Y + vm[9] * Z + vm[13];
-    const float t2 = vm[2] * X + vm[6] * Y + vm[10] * Z + vm[14];
-    const float limx = 1.3f * c.tanfovx, limy = 1.3f * c.tanfovy;
-    const float inv_z = 1.0f / t2;
-    const float txtz = t0 * inv_z, tytz = t1 * inv_z;
-    f.xmul = (txtz < -limx || txtz > limx) ? 0.f : 1.f;
-    f.ymul = (tytz < -limy || tytz > limy) ? 0.f : 1.f;
-    t0 = fminf(limx, fmaxf(-limx, txtz)) * t2;
-    t1 = fminf(limy, fmaxf(-limy, tytz)) * t2;
+    RT t0 = vm[0] * X + vm[4] * Y + vm[8] * Z + vm[12];
+    RT t1 = vm[1] * X + vm[5] * Y + vm[9] * Z + vm[13];
+    const RT t2 = vm[2] * X + vm[6] * Y + vm[10] * Z + vm[14];
+    const RT limx = (RT)1.3 * c.tanfovx, limy = (RT)1.3 * c.tanfovy;
+    const RT inv_z = 1 / t2;
+    const RT txtz = t0 * inv_z, tytz = t1 * inv_z;
+    f.xmul = (txtz < -limx || txtz > limx) ? 0 : 1;
+    f.ymul = (tytz < -limy || tytz > limy) ? 0 : 1;
+    t0 = (txtz < -limx ? -limx : (txtz > limx ? limx : txtz)) * t2;
+    t1 = (tytz < -limy ? -limy : (tytz > limy ? limy : tytz)) * t2;
     f.t0 = t0; f.t1 = t1; f.t2 = t2;
-    f.J00 = c.fx * inv_z; f.J02 = -c.fx * t0 * inv_z * inv_z;
-    f.J11 = c.fy * inv_z; f.J12 = -c.fy * t1 * inv_z * inv_z;
+    const RT fx = (RT)c.W / (2 * (RT)c.tanfovx), fy = (RT)c.H / (2 * (RT)c.tanfovy);
+    f.J00 = fx * inv_z; f.J02 = -fx * t0 * inv_z * inv_z;
+    f.J11 = fy * inv_z; f.J12 = -fy * t1 * inv_z * inv_z;
     for (int k = 0; k < 3; k++) {
         f.m0[k] = f.J00 * vm[k * 4 + 0] + f.J02 * vm[k * 4 + 2];
         f.m1[k] = f.J11 * vm[k * 4 + 1] + f.J12 * vm[k * 4 + 2];
@@ -142,8 +150,8 @@ GSR_HD void proj_frame(const Camera& c, float X, float Y, float Z, ProjFrame& f)
 }
 
 // cov2D = M Sigma M^T + 0.3 I  -> (a, b, c)
-GSR_HD void cov2d_from_frame(const ProjFrame& f, const float cov[6], float& a, float& b, float& c,
-                             float Sm0[3], float Sm1[3])
+template <typename RT>
+GSR_HD void cov2d_from_frame(const ProjFrame<RT>& f, const RT cov[6], RT& a, RT& b, RT& c, RT Sm0[3], RT Sm1[3])
 {
     Sm0[0] = cov[0] * f.m0[0] + cov[1] * f.m0[1] + cov[2] * f.m0[2];
     Sm0[1] = cov[1] * f.m0[0] + cov[3] * f.m0[1] + cov[4] * f.m0[2];
@@ -151,9 +159,9 @@ GSR_HD void cov2d_from_frame(const ProjFrame& f, const float cov[6], float& a, f
     Sm1[0] = cov[0] * f.m1[0] + cov[1] * f.m1[1] + cov[2] * f.m1[2];
     Sm1[1] = cov[1] * f.m1[0] + cov[3] * f.m1[1] + cov[4] * f.m1[2];
     Sm1[2] = cov[2] * f.m1[0] + cov[4] * f.m1[1] + cov[5] * f.m1[2];
-    a = f.m0[0] * Sm0[0] + f.m0[1] * Sm0[1] + f.m0[2] * Sm0[2] + kLowpass;
+    a = f.m0[0] * Sm0[0] + f.m0[1] * Sm0[1] + f.m0[2] * Sm0[2] + (RT)0.3;
     b = f.m0[0] * Sm1[0] + f.m0[1] * Sm1[1] + f.m0[2] * Sm1[2];
-    c = f.m1[0] * Sm1[0] + f.m1[1] * Sm1[1] + f.m1[2] * Sm1[2] + kLowpass;
+    c = f.m1[0] * Sm1[0] + f.m1[1] * Sm1[1] + f.m1[2] * Sm1[2] + (RT)0.3;
 }
 
 GSR_HD void tile_rect(float px, float py, int radius, int tiles_x, int tiles_y, int& x0, int& y0, int& x1, int& y1)
@@ -168,22 +176,29 @@ GSR_HD void tile_rect(float px, float py, int radius, int tiles_x, int tiles_y, 
 
 // SH colour (before +0.5 / clamp) for one channel; sh points at coefficient 0 of that channel,
 // consecutive coefficients are `stride` floats apart.
-GSR_HD float sh_channel(int deg, const float* sh, int stride, float x, float y, float z)
+template <typename RT>
+GSR_HD RT sh_channel(int deg, const float* sh, int stride, RT x, RT y, RT z)
 {
-    float res = SH_C0 * sh[0];
+    constexpr RT SH_C0 = (RT)0.28209479177387814, SH_C1 = (RT)0.4886025119029199;
+    constexpr RT SH_C2_0 = (RT)1.0925484305920792, SH_C2_1 = (RT)-1.0925484305920792, SH_C2_2 = (RT)0.31539156525252005,
+                 SH_C2_3 = (RT)-1.0925484305920792, SH_C2_4 = (RT)0.5462742152960396;
+    constexpr RT SH_C3_0 = (RT)-0.5900435899266435, SH_C3_1 = (RT)2.890611442640554, SH_C3_2 = (RT)-0.4570457994644658,
+                 SH_C3_3 = (RT)0.3731763325901154, SH_C3_4 = (RT)-0.4570457994644658, SH_C3_5 = (RT)1.445305721320277,
+                 SH_C3_6 = (RT)-0.5900435899266435;
+    RT res = SH_C0 * sh[0];
     if (deg > 0) {
         res = res - SH_C1 * y * sh[1 * stride] + SH_C1 * z * sh[2 * stride] - SH_C1 * x * sh[3 * stride];
         if (deg > 1) {
-            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            const RT xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
             res = res + SH_C2_0 * xy * sh[4 * stride] + SH_C2_1 * yz * sh[5 * stride] +
-                  SH_C2_2 * (2.f * zz - xx - yy) * sh[6 * stride] + SH_C2_3 * xz * sh[7 * stride] +
+                  SH_C2_2 * (2 * zz - xx - yy) * sh[6 * stride] + SH_C2_3 * xz * sh[7 * stride] +
                   SH_C2_4 * (xx - yy) * sh[8 * stride];
             if (deg > 2) {
-                res = res + SH_C3_0 * y * (3.f * xx - yy) * sh[9 * stride] + SH_C3_1 * xy * z * sh[10 * stride] +
-                      SH_C3_2 * y * (4.f * zz - xx - yy) * sh[11 * stride] +
-                      SH_C3_3 * z * (2.f * zz - 3.f * xx - 3.f * yy) * sh[12 * stride] +
-                      SH_C3_4 * x * (4.f * zz - xx - yy) * sh[13 * stride] +
-                      SH_C3_5 * z * (xx - yy) * sh[14 * stride] + SH_C3_6 * x * (xx - 3.f * yy) * sh[15 * stride];
+                res = res + SH_C3_0 * y * (3 * xx - yy) * sh[9 * stride] + SH_C3_1 * xy * z * sh[10 * stride] +
+                      SH_C3_2 * y * (4 * zz - xx - yy) * sh[11 * stride] +
+                      SH_C3_3 * z * (2 * zz - 3 * xx - 3 * yy) * sh[12 * stride] +
+                      SH_C3_4 * x * (4 * zz - xx - yy) * sh[13 * stride] +
+                      SH_C3_5 * z * (xx - yy) * sh[14 * stride] + SH_C3_6 * x * (xx - 3 * yy) * sh[15 * stride];
             }
         }
     }
@@ -197,36 +212,38 @@ GSR_HD void preprocess_one(const Camera& c, const float mean[3], const float* sc
                            const float* cov_pre, float opacity, const float* sh, int sh_kstride, int sh_cstride,
                            const float* color_pre, Splat& out)
 {
+    typedef double RT;   // see the note above quat_to_rot
     out.px = 0.f; out.py = 0.f; out.ca = 0.f; out.cb = 0.f; out.cc = 0.f; out.op = 0.f; out.depth = 0.f;
     out.r = 0.f; out.g = 0.f; out.b = 0.f; out.radius = 0; out.tiles = 0;
-    const float X = mean[0], Y = mean[1], Z = mean[2];
-    const float zk = depth_key(c.vm, X, Y, Z);
+    const float zk = depth_key(c.vm, mean[0], mean[1], mean[2]);
     out.depth = zk;
     if (!(zk > kNearZ)) return;
+    const RT X = mean[0], Y = mean[1], Z = mean[2];
     const float* pm = c.pm;
-    const float hx = pm[0] * X + pm[4] * Y + pm[8] * Z + pm[12];
-    const float hy = pm[1] * X + pm[5] * Y + pm[9] * Z + pm[13];
-    const float hw = pm[3] * X + pm[7] * Y + pm[11] * Z + pm[15];
-    const float pw = 1.0f / (hw + 1e-7f);
-    float cov[6];
+    const RT hx = pm[0] * X + pm[4] * Y + pm[8] * Z + pm[12];
+    const RT hy = pm[1] * X + pm[5] * Y + pm[9] * Z + pm[13];
+    const RT hw = pm[3] * X + pm[7] * Y + pm[11] * Z + pm[15];
+    const RT pw = 1 / (hw + (RT)1e-7);
+    RT cov[6];
     if (cov_pre) {
         for (int k = 0; k < 6; k++) cov[k] = cov_pre[k];
     } else {
-        cov3d_from_scale_rot(scale, c.scale_mod, rot, cov);
+        cov3d_from_scale_rot<RT>(scale, c.scale_mod, rot, cov);
     }
-    ProjFrame f;
-    proj_frame(c, X, Y, Z, f);
-    float a, b, cc, Sm0[3], Sm1[3];
-    cov2d_from_frame(f, cov, a, b, cc, Sm0, Sm1);
-    const float det = a * cc - b * b;
-    if (det == 0.f) return;
-    const float dinv = 1.0f / det;
-    const float mid = 0.5f * (a + cc);
-    const float disc = sqrtf(fmaxf(0.1f, mid * mid - det));
-    const float lam = fmaxf(mid + disc, mid - disc);
-    const int radius = (int)ceilf(3.f * sqrtf(lam));
-    const float px = ((hx * pw + 1.f) * c.W - 1.f) * 0.5f;
-    const float py = ((hy * pw + 1.f) * c.H - 1.f) * 0.5f;
+    ProjFrame<RT> f;
+    proj_frame<RT>(c, X, Y, Z, f);
+    RT a, b, cc, Sm0[3], Sm1[3];
+    cov2d_from_frame<RT>(f, cov, a, b, cc, Sm0, Sm1);
+    const RT det = a * cc - b * b;
+    if (det == 0) return;
+    const RT dinv = 1 / det;
+    const RT mid = (RT)0.5 * (a + cc);
+    RT disc = mid * mid - det;
+    disc = sqrt(disc < (RT)0.1 ? (RT)0.1 : disc);
+    const RT l1 = mid + disc, l2 = mid - disc;
+    const int radius = (int)ceil(3 * sqrt(l1 > l2 ? l1 : l2));
+    const float px = (float)(((hx * pw + 1) * c.W - 1) * (RT)0.5);
+    const float py = (float)(((hy * pw + 1) * c.H - 1) * (RT)0.5);
     int x0, y0, x1, y1;
     tile_rect(px, py, radius, c.tiles_x, c.tiles_y, x0, y0, x1, y1);
     const int nt = (x1 - x0) * (y1 - y0);
@@ -235,14 +252,16 @@ GSR_HD void preprocess_one(const Camera& c, const float mean[3], const float* sc
     if (color_pre) {
         col[0] = color_pre[0]; col[1] = color_pre[1]; col[2] = color_pre[2];
     } else {
-        float dx = X - c.cam[0], dy = Y - c.cam[1], dz = Z - c.cam[2];
-        const float inv_n = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+        RT dx = X - c.cam[0], dy = Y - c.cam[1], dz = Z - c.cam[2];
+        const RT inv_n = 1 / sqrt(dx * dx + dy * dy + dz * dz);
         dx *= inv_n; dy *= inv_n; dz *= inv_n;
-        for (int ch = 0; ch < 3; ch++)
-            col[ch] = fmaxf(sh_channel(c.D, sh + ch * sh_cstride, sh_kstride, dx, dy, dz) + 0.5f, 0.f);
+        for (int ch = 0; ch < 3; ch++) {
+            const RT v = sh_channel<RT>(c.D, sh + ch * sh_cstride, sh_kstride, dx, dy, dz) + (RT)0.5;
+            col[ch] = v < 0 ? 0.f : (float)v;
+        }
     }
     out.px = px; out.py = py;
-    out.ca = cc * dinv; out.cb = -b * dinv; out.cc = a * dinv;
+    out.ca = (float)(cc * dinv); out.cb = (float)(-b * dinv); out.cc = (float)(a * dinv);
     out.op = opacity;
     out.r = col[0]; out.g = col[1]; out.b = col[2];
     out.radius = radius; out.tiles = (uint32_t)nt;
@@ -335,7 +354,7 @@ GSR_HD void sh_backward(const Camera& c, const float mean[3], const float* sh, i
     const float x = dx * inv_n, y = dy * inv_n, z = dz * inv_n;
     float gr[3];
     for (int ch = 0; ch < 3; ch++) {
-        const float v = sh_channel(c.D, sh + ch * sc, sk, x, y, z) + 0.5f;
+        const float v = sh_channel<float>(c.D, sh + ch * sc, sk, x, y, z) + 0.5f;
         gr[ch] = v < 0.f ? 0.f : g_rgb_in[ch];
     }
     float basis[16], bx[16], by[16], bz[16];
@@ -394,12 +413,12 @@ GSR_HD void gauss_backward(const Camera& c, const float mean[3], const float* sc
     if (cov_pre) {
         for (int k = 0; k < 6; k++) cov[k] = cov_pre[k];
     } else {
-        cov3d_from_scale_rot(scale, c.scale_mod, rot, cov);
+        cov3d_from_scale_rot<float>(scale, c.scale_mod, rot, cov);
     }
-    ProjFrame f;
-    proj_frame(c, X, Y, Z, f);
+    ProjFrame<float> f;
+    proj_frame<float>(c, X, Y, Z, f);
     float a, b, cc, Sm0[3], Sm1[3];
-    cov2d_from_frame(f, cov, a, b, cc, Sm0, Sm1);
+    cov2d_from_frame<float>(f, cov, a, b, cc, Sm0, Sm1);
     // conic -> cov2D (guard 1e-7 recalled from the public module)
     const float det = a * cc - b * b;
     const float d2i = 1.0f / (det * det + 1e-7f);
@@ -446,7 +465,7 @@ GSR_HD void gauss_backward(const Camera& c, const float mean[3], const float* sc
     for (int k = 0; k < 4; k++) o.rot[k] = 0.f;
     if (!cov_pre) {
         float R[9];
-        quat_to_rot(rot, R);
+        quat_to_rot<float>(rot, R);
         const float sv[3] = {c.scale_mod * scale[0], c.scale_mod * scale[1], c.scale_mod * scale[2]};
         const float Gf[9] = {gS[0], 0.5f * gS[1], 0.5f * gS[2], 0.5f * gS[1], gS[3], 0.5f * gS[4], 0.5f * gS[2], 0.5f * gS[4], gS[5]};
         float gR[9];

@@ -1,0 +1,210 @@
+// radix_sort.h -- stable LSD radix sort of (key, u32 value) pairs for gfx950, hand-written.
+//
+// Used twice per forward (DESIGN.md "binning"): 32-bit depth keys over the N Gaussians, then 16-bit tile
+// keys over the R instances.  One pass = 8 bits = three launches:
+//   k_radix_hist     per-block digit histogram (block = 4096 keys)        -> hist[digit][block]
+//   k_radix_scan     one workgroup per digit: exclusive scan over blocks + digit base
+//   k_radix_scatter  stable in-block ranking with wave64 match-any ballots, LDS-staged so that the
+//                    global writes of one digit run are consecutive lanes -> coalesced
+// Stability inside a block comes from an explicit (round, wave, lane) order: the count matrix
+// cnt[round][wave][digit] is prefix-summed in that order, no atomics are involved in ranking.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gsr {
+
+constexpr int kSortThreads = 256;
+constexpr int kSortIPT = 16;                                // items per thread
+constexpr int kSortTile = kSortThreads * kSortIPT;          // 4096 keys per block
+constexpr int kSortWaves = kSortThreads / 64;
+
+__device__ __forceinline__ unsigned long long lanemask_lt()
+{
+    const unsigned lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    return (1ull << lane) - 1ull;
+}
+
+template <typename KeyT>
+__global__ __launch_bounds__(kSortThreads) void k_radix_hist(const KeyT* __restrict__ keys, uint32_t n, int shift,
+                                                             uint32_t* __restrict__ hist, uint32_t nblocks,
+                                                             uint32_t* __restrict__ totals)
+{
+    __shared__ uint32_t h[256];
+    const int tid = threadIdx.x;
+    h[tid] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * (uint32_t)kSortTile;
+#pragma unroll
+    for (int r = 0; r < kSortIPT; r++) {
+        const uint32_t idx = base + r * kSortThreads + tid;
+        if (idx < n) atomicAdd(&h[((uint32_t)keys[idx] >> shift) & 0xffu], 1u);
+    }
+    __syncthreads();
+    hist[(uint32_t)tid * nblocks + blockIdx.x] = h[tid];
+    if (h[tid]) atomicAdd(&totals[tid], h[tid]);
+}
+
+// grid = 256 (one workgroup per digit).  hist[d][*] -> exclusive prefix over blocks, plus the
+// exclusive prefix over the totals of digits < d (totals[] accumulated by k_radix_hist).
+__global__ __launch_bounds__(256) void k_radix_scan(uint32_t* __restrict__ hist, uint32_t nblocks,
+                                                    const uint32_t* __restrict__ totals)
+{
+    __shared__ uint32_t s_part[256];
+    const int tid = threadIdx.x;
+    const int d = blockIdx.x;
+    uint32_t digit_base = 0;
+    for (int k = 0; k < d; k++) digit_base += totals[k];   // uniform -> scalar loads
+    // scan this digit's row: each thread owns a contiguous chunk
+    uint32_t* row = hist + (size_t)d * nblocks;
+    const uint32_t chunk = (nblocks + 255u) / 256u;
+    const uint32_t lo = min(nblocks, (uint32_t)tid * chunk), hi = min(nblocks, lo + chunk);
+    uint32_t sum = 0;
+    for (uint32_t b = lo; b < hi; b++) sum += row[b];
+    s_part[tid] = sum;
+    __syncthreads();
+    // exclusive scan of the 256 partials (Hillis-Steele in LDS)
+    for (int off = 1; off < 256; off <<= 1) {
+        uint32_t v = (tid >= off) ? s_part[tid - off] : 0u;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = digit_base + s_part[tid] - sum;
+    for (uint32_t b = lo; b < hi; b++) {
+        const uint32_t c = row[b];
+        row[b] = run;
+        run += c;
+    }
+}
+
+template <typename KeyT>
+__global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const KeyT* __restrict__ kin, const uint32_t* __restrict__ vin,
+                                                                KeyT* __restrict__ kout, uint32_t* __restrict__ vout, uint32_t n,
+                                                                int shift, const uint32_t* __restrict__ hist, uint32_t nblocks)
+{
+    __shared__ uint16_t cnt[kSortIPT][kSortWaves][256];   // 32 KiB
+    __shared__ KeyT s_keys[kSortTile];
+    __shared__ uint32_t s_vals[kSortTile];
+    __shared__ uint32_t s_start[256];    // block-local exclusive start of each digit
+    __shared__ uint32_t s_gbase[256];    // global base of each digit for this block minus s_start
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const uint32_t base = blockIdx.x * (uint32_t)kSortTile;
+    const uint32_t valid = min((uint32_t)kSortTile, n - base);
+
+    {   // zero the count matrix (16384 u16 = 8192 u32)
+        uint32_t* z = reinterpret_cast<uint32_t*>(&cnt[0][0][0]);
+#pragma unroll
+        for (int k = 0; k < (kSortIPT * kSortWaves * 256 / 2) / kSortThreads; k++) z[k * kSortThreads + tid] = 0u;
+    }
+    KeyT key[kSortIPT];
+    uint32_t val[kSortIPT];
+    uint32_t dig[kSortIPT];
+    uint32_t rnk[kSortIPT];
+#pragma unroll
+    for (int r = 0; r < kSortIPT; r++) {
+        const uint32_t p = r * kSortThreads + tid;
+        if (p < valid) {
+            key[r] = kin[base + p];
+            val[r] = vin[base + p];
+            dig[r] = ((uint32_t)key[r] >> shift) & 0xffu;
+        } else {
+            key[r] = (KeyT)~(KeyT)0; val[r] = 0u; dig[r] = 255u;   // padding sorts behind every real item
+        }
+    }
+    __syncthreads();
+    const unsigned long long lt = lanemask_lt();
+#pragma unroll
+    for (int r = 0; r < kSortIPT; r++) {
+        unsigned long long peers = ~0ull;
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const bool bit = (dig[r] >> b) & 1u;
+            const unsigned long long m = __ballot(bit);
+            peers &= bit ? m : ~m;
+        }
+        rnk[r] = (uint32_t)__popcll(peers & lt);
+        if (rnk[r] == 0) cnt[r][wave][dig[r]] = (uint16_t)__popcll(peers);
+    }
+    __syncthreads();
+    {   // thread = digit: exclusive prefix over (round, wave) in stable order
+        uint32_t run = 0;
+#pragma unroll
+        for (int r = 0; r < kSortIPT; r++)
+#pragma unroll
+            for (int w = 0; w < kSortWaves; w++) {
+                const uint32_t c = cnt[r][w][tid];
+                cnt[r][w][tid] = (uint16_t)run;
+                run += c;
+            }
+        s_start[tid] = run;   // digit total, scanned below
+    }
+    __syncthreads();
+    {   // exclusive scan of the digit totals
+        const uint32_t mine = s_start[tid];
+        for (int off = 1; off < 256; off <<= 1) {
+            const uint32_t v = (tid >= off) ? s_start[tid - off] : 0u;
+            __syncthreads();
+            s_start[tid] += v;
+            __syncthreads();
+        }
+        const uint32_t excl = s_start[tid] - mine;
+        __syncthreads();
+        s_start[tid] = excl;
+        s_gbase[tid] = hist[(size_t)tid * nblocks + blockIdx.x] - excl;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kSortIPT; r++) {
+        const uint32_t lp = s_start[dig[r]] + cnt[r][wave][dig[r]] + rnk[r];
+        s_keys[lp] = key[r];
+        s_vals[lp] = val[r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kSortIPT; r++) {
+        const uint32_t p = r * kSortThreads + tid;
+        if (p < valid) {
+            const KeyT k = s_keys[p];
+            const uint32_t d = ((uint32_t)k >> shift) & 0xffu;
+            const uint32_t g = s_gbase[d] + p;
+            kout[g] = k;
+            vout[g] = s_vals[p];
+        }
+    }
+}
+
+inline size_t radix_scratch_bytes(uint32_t n)
+{
+    const size_t nblocks = ((size_t)n + kSortTile - 1) / kSortTile;
+    return ((256 * (nblocks ? nblocks : 1) + 8 * 256) * sizeof(uint32_t) + 255) & ~(size_t)255;   // hist + totals[8 passes]
+}
+
+// Sorts bits [begin_bit, end_bit) in 8-bit passes, ping-ponging between (keys,vals) and (keys_alt,vals_alt).
+// Returns 1 in *in_alt if the result ended in the alt buffers.
+template <typename KeyT>
+inline hipError_t radix_sort_pairs(KeyT* keys, uint32_t* vals, KeyT* keys_alt, uint32_t* vals_alt, uint32_t n, int begin_bit,
+                                   int end_bit, void* scratch, int* in_alt, hipStream_t stream)
+{
+    *in_alt = 0;
+    if (n == 0) return hipSuccess;
+    const uint32_t nblocks = (n + kSortTile - 1) / kSortTile;
+    uint32_t* hist = static_cast<uint32_t*>(scratch);
+    uint32_t* totals = hist + (size_t)256 * nblocks;
+    hipError_t e = hipMemsetAsync(totals, 0, 8 * 256 * sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    KeyT *kin = keys, *kout = keys_alt;
+    uint32_t *vin = vals, *vout = vals_alt;
+    for (int shift = begin_bit; shift < end_bit; shift += 8, totals += 256) {
+        hipLaunchKernelGGL(k_radix_hist<KeyT>, dim3(nblocks), dim3(kSortThreads), 0, stream, kin, n, shift, hist, nblocks, totals);
+        hipLaunchKernelGGL(k_radix_scan, dim3(256), dim3(256), 0, stream, hist, nblocks, totals);
+        hipLaunchKernelGGL(k_radix_scatter<KeyT>, dim3(nblocks), dim3(kSortThreads), 0, stream, kin, vin, kout, vout, n, shift,
+                           hist, nblocks);
+        KeyT* tk = kin; kin = kout; kout = tk;
+        uint32_t* tv = vin; vin = vout; vout = tv;
+        *in_alt ^= 1;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace gsr

@@ -1,0 +1,232 @@
+"""Host-side mirror of the reference's rasterizer interface, on top of the C ABI of include/gsr.h.
+
+Same names, argument meaning and error behaviour as the module the reference imports
+(`from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer`:
+/root/reference/scene/gaussian_model_ht.py:39-42, gaussian_renderer/__init__.py:12), called as at
+gaussian_model_ht.py:809-880 and returning the 4-tuple unpacked at :881-894
+(color[3,H,W], radii[N] int32, depth[1,H,W], alpha[1,H,W]).
+
+PyTorch is plumbing only: device memory (caching allocator), the current HIP stream and autograd.  All
+arithmetic happens in the hand-written HIP kernels of csrc/gsr_kernels.hip.  There is no CPU path: tensors
+must live on a ROCm device and libgsr_hip.so must be built, otherwise a RuntimeError is raised.
+"""
+import ctypes as C
+from typing import NamedTuple, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    """The 12 keywords built at gaussian_model_ht.py:809-822 / gaussian_renderer/__init__.py:38-51."""
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+# diagnostics of the most recent forward (bench.py reads R and the per-tile staged counters from here)
+_LAST = {"num_rendered": 0, "image": None, "W": 0, "H": 0}
+
+
+def last_call_info():
+    """{'num_rendered': R, 'staged': R_eff} of the most recent forward on this process."""
+    lib = L.load()
+    img, W, H = _LAST["image"], _LAST["W"], _LAST["H"]
+    staged = 0
+    if img is not None:
+        off = lib.gsr_image_staged_offset(W, H)
+        T = ((W + 15) // 16) * ((H + 15) // 16)
+        staged = int(img[off:off + 4 * T].view(torch.int32).sum().item())
+    return {"num_rendered": _LAST["num_rendered"], "staged": staged}
+
+
+def _f32c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    """float32 + contiguous (viewmatrix / campos arrive as non-contiguous views: SURVEY Appendix B)."""
+    if t is None:
+        return None
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if (t is None or t.numel() == 0) else t.data_ptr()
+
+
+def _empty_to_none(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    return None if (t is None or t.numel() == 0) else t
+
+
+class _Workspace:
+    """Allocator handed to gsr_forward: R-sized buffers come from torch's caching allocator."""
+
+    def __init__(self, device):
+        self.device = device
+        self.binning = None
+        self.scratch = []
+        self.cb = L.ALLOC_FN(self._alloc)
+
+    def _alloc(self, nbytes, tag, _user):
+        try:
+            buf = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+        except Exception:  # out of memory -> NULL -> GSR_ERR_ALLOC
+            return None
+        if tag == L.GSR_ALLOC_BINNING:
+            self.binning = buf
+        else:
+            self.scratch.append(buf)
+        return buf.data_ptr()
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+        lib = L.load()
+        rs = raster_settings
+        dev = means3D.device
+        if dev.type != "cuda":
+            raise RuntimeError("GaussianRasterizer: tensors must be on a ROCm/HIP device (no CPU fallback)")
+        means3D = _f32c(means3D)
+        N = means3D.shape[0]
+        sh, colors_precomp = _f32c(_empty_to_none(sh)), _f32c(_empty_to_none(colors_precomp))
+        scales, rotations = _f32c(_empty_to_none(scales)), _f32c(_empty_to_none(rotations))
+        cov3Ds_precomp = _f32c(_empty_to_none(cov3Ds_precomp))
+        opacities = _f32c(opacities)
+        vm, pm = _f32c(rs.viewmatrix.to(dev)), _f32c(rs.projmatrix.to(dev))
+        campos, bg = _f32c(rs.campos.to(dev)), _f32c(rs.bg.to(dev))
+        H, W = int(rs.image_height), int(rs.image_width)
+        M = int(sh.shape[1]) if sh is not None else 0
+
+        color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+        depth = torch.empty((1, H, W), dtype=torch.float32, device=dev)
+        alpha = torch.empty((1, H, W), dtype=torch.float32, device=dev)
+        radii = torch.empty((N,), dtype=torch.int32, device=dev)
+        geom = torch.empty(lib.gsr_geom_bytes(N), dtype=torch.uint8, device=dev)
+        image = torch.empty(lib.gsr_image_bytes(W, H), dtype=torch.uint8, device=dev)
+        ws = _Workspace(dev)
+
+        a = L.GsrForwardArgs()
+        a.N, a.M, a.D, a.W, a.H = N, M, int(rs.sh_degree), W, H
+        a.prefiltered, a.debug = int(bool(rs.prefiltered)), int(bool(rs.debug))
+        a.scale_modifier, a.tanfovx, a.tanfovy = float(rs.scale_modifier), float(rs.tanfovx), float(rs.tanfovy)
+        a.means3D, a.scales, a.rotations, a.cov3D_precomp = _ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(cov3Ds_precomp)
+        a.opacities, a.shs, a.colors_precomp = _ptr(opacities), _ptr(sh), _ptr(colors_precomp)
+        a.viewmatrix, a.projmatrix, a.campos, a.bg = _ptr(vm), _ptr(pm), _ptr(campos), _ptr(bg)
+        a.out_color, a.out_depth, a.out_alpha, a.radii = color.data_ptr(), depth.data_ptr(), alpha.data_ptr(), _ptr(radii)
+        a.geom, a.image = geom.data_ptr(), image.data_ptr()
+        a.alloc, a.alloc_user = ws.cb, None
+        out = L.GsrForwardOut()
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            L.check(lib.gsr_forward(C.byref(a), C.byref(out), C.c_void_p(stream)), "gsr_forward")
+        ws.scratch.clear()  # stream-ordered reuse by the caching allocator is safe: same stream
+
+        _LAST.update(num_rendered=int(out.num_rendered), image=image, W=W, H=H)
+        ctx.raster_settings = rs
+        ctx.num_rendered = int(out.num_rendered)
+        ctx.dims = (N, M, H, W)
+        ctx.has = (sh is not None, colors_precomp is not None, scales is not None, cov3Ds_precomp is not None)
+        z = means3D.new_empty(0)
+        # NOTE: depth is deliberately NOT saved -- the caller mutates it in place (ht3dgs_trainer.py:1290-1292).
+        ctx.save_for_backward(means3D, opacities, sh if sh is not None else z, colors_precomp if colors_precomp is not None else z,
+                              scales if scales is not None else z, rotations if rotations is not None else z,
+                              cov3Ds_precomp if cov3Ds_precomp is not None else z, vm, pm, campos, bg, geom, image,
+                              ws.binning)
+        ctx.mark_non_differentiable(radii)
+        return color, radii, depth, alpha
+
+    @staticmethod
+    def backward(ctx, grad_color, grad_radii, grad_depth, grad_alpha):
+        lib = L.load()
+        rs = ctx.raster_settings
+        (means3D, opacities, sh, colors_precomp, scales, rotations, cov3Ds_precomp, vm, pm, campos, bg, geom, image,
+         binning) = ctx.saved_tensors
+        N, M, H, W = ctx.dims
+        has_sh, has_col, has_scale, has_cov = ctx.has
+        dev = means3D.device
+        grad_color, grad_depth, grad_alpha = _f32c(grad_color), _f32c(grad_depth), _f32c(grad_alpha)
+
+        d_means3D = torch.empty((N, 3), dtype=torch.float32, device=dev)
+        d_means2D = torch.empty((N, 3), dtype=torch.float32, device=dev)
+        d_opac = torch.empty((N, 1), dtype=torch.float32, device=dev)
+        d_sh = torch.empty((N, M, 3), dtype=torch.float32, device=dev) if has_sh else None
+        d_col = torch.empty((N, 3), dtype=torch.float32, device=dev) if has_col else None
+        d_scales = torch.empty((N, 3), dtype=torch.float32, device=dev) if has_scale else None
+        d_rot = torch.empty((N, 4), dtype=torch.float32, device=dev) if has_scale else None
+        d_cov = torch.empty((N, 6), dtype=torch.float32, device=dev) if has_cov else None
+        scratch = torch.empty(lib.gsr_backward_scratch_bytes(N), dtype=torch.uint8, device=dev)
+
+        a = L.GsrBackwardArgs()
+        a.N, a.M, a.D, a.W, a.H = N, M, int(rs.sh_degree), W, H
+        a.scale_modifier, a.tanfovx, a.tanfovy = float(rs.scale_modifier), float(rs.tanfovx), float(rs.tanfovy)
+        a.means3D, a.opacities = _ptr(means3D), _ptr(opacities)
+        a.scales, a.rotations = (_ptr(scales), _ptr(rotations)) if has_scale else (None, None)
+        a.cov3D_precomp = _ptr(cov3Ds_precomp) if has_cov else None
+        a.shs = _ptr(sh) if has_sh else None
+        a.colors_precomp = _ptr(colors_precomp) if has_col else None
+        a.viewmatrix, a.projmatrix, a.campos, a.bg = _ptr(vm), _ptr(pm), _ptr(campos), _ptr(bg)
+        a.geom, a.image, a.binning, a.num_rendered = geom.data_ptr(), image.data_ptr(), binning.data_ptr(), ctx.num_rendered
+        a.grad_color, a.grad_depth, a.grad_alpha = _ptr(grad_color), _ptr(grad_depth), _ptr(grad_alpha)
+        a.d_means3D, a.d_means2D, a.d_opacities = _ptr(d_means3D), _ptr(d_means2D), _ptr(d_opac)
+        a.d_colors_precomp, a.d_shs = _ptr(d_col), _ptr(d_sh)
+        a.d_scales, a.d_rotations, a.d_cov3D_precomp = _ptr(d_scales), _ptr(d_rot), _ptr(d_cov)
+        a.scratch = scratch.data_ptr()
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            L.check(lib.gsr_backward(C.byref(a), C.c_void_p(stream)), "gsr_backward")
+        return d_means3D, d_means2D, d_sh, d_col, d_opac, d_scales, d_rot, d_cov, None
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                                     raster_settings)
+
+
+class GaussianRasterizer(nn.Module):
+    """Callable exactly as at gaussian_model_ht.py:824,871-880 and gaussian_renderer/__init__.py:53,88-96."""
+
+    def __init__(self, raster_settings: GaussianRasterizationSettings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions: torch.Tensor) -> torch.Tensor:
+        """Frustum (near-plane) visibility mask; present in the module's API, unused by the reference."""
+        lib = L.load()
+        rs = self.raster_settings
+        with torch.no_grad():
+            p = _f32c(positions)
+            dev = p.device
+            if dev.type != "cuda":
+                raise RuntimeError("markVisible: tensors must be on a ROCm/HIP device (no CPU fallback)")
+            vm, pm = _f32c(rs.viewmatrix.to(dev)), _f32c(rs.projmatrix.to(dev))
+            present = torch.empty((p.shape[0],), dtype=torch.uint8, device=dev)
+            with torch.cuda.device(dev):
+                stream = torch.cuda.current_stream(dev).cuda_stream
+                L.check(lib.gsr_mark_visible(p.shape[0], _ptr(p), _ptr(vm), _ptr(pm), _ptr(present), C.c_void_p(stream)),
+                        "gsr_mark_visible")
+        return present.bool()
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        rs = self.raster_settings
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or (
+                (scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        e = torch.Tensor([])
+        return rasterize_gaussians(means3D, means2D, shs if shs is not None else e,
+                                   colors_precomp if colors_precomp is not None else e, opacities,
+                                   scales if scales is not None else e, rotations if rotations is not None else e,
+                                   cov3D_precomp if cov3D_precomp is not None else e, rs)

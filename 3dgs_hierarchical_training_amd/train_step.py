@@ -1,0 +1,144 @@
+"""The benchmark's counterpart of the reference's training iteration around the rasterizer.
+
+Mirrors, with stock torch ops outside the hot path (SURVEY.md section 8c last row):
+  * parameter store + activations   /root/reference/scene/gaussian_model_ht.py:49-65,128-133,176-188
+  * render wrapper                  gaussian_model_ht.py:775-894 (CF3DGS_Render.render, in-kernel SH / cov3D)
+  * loss (1-l)*L1 + l*(1-SSIM)      /root/reference/trainer/losses.py:98-136,147-209, lambda_dssim = 0.2
+                                    (/root/reference/arguments/__init__.py:134)
+  * Adam(eps=1e-15), per-group LRs  gaussian_model_ht.py:263-289, arguments/__init__.py:116-131
+  * train_step order                /root/reference/trainer/ht3dgs_trainer.py:81-169
+It does not import the reference.  The rasterizer is the MI355X-native one (rasterizer.py -> C ABI -> HIP).
+"""
+import math
+from typing import Dict
+
+import torch
+import torch.nn.functional as F
+
+from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+
+
+def inverse_sigmoid(x):
+    return torch.log(x / (1 - x))
+
+
+def _gauss_window(window_size: int, sigma: float, channel: int, device, dtype):
+    g = torch.tensor([math.exp(-(x - window_size // 2) ** 2 / float(2 * sigma ** 2)) for x in range(window_size)])
+    g = (g / g.sum()).unsqueeze(1)
+    w2d = g.mm(g.t()).float().unsqueeze(0).unsqueeze(0)
+    return w2d.expand(channel, 1, window_size, window_size).contiguous().to(device=device, dtype=dtype)
+
+
+_WINDOWS = {}
+
+
+def ssim(img1: torch.Tensor, img2: torch.Tensor, window_size: int = 11) -> torch.Tensor:
+    """11x11 Gaussian-window SSIM, sigma 1.5, zero padding, mean over the map (losses.py:147-209)."""
+    if img1.dim() == 3:
+        img1, img2 = img1.unsqueeze(0), img2.unsqueeze(0)
+    ch = img1.shape[1]
+    key = (ch, window_size, img1.device, img1.dtype)
+    if key not in _WINDOWS:
+        _WINDOWS[key] = _gauss_window(window_size, 1.5, ch, img1.device, img1.dtype)
+    w = _WINDOWS[key]
+    pad = window_size // 2
+    mu1 = F.conv2d(img1, w, padding=pad, groups=ch)
+    mu2 = F.conv2d(img2, w, padding=pad, groups=ch)
+    mu1_sq, mu2_sq, mu1_mu2 = mu1.pow(2), mu2.pow(2), mu1 * mu2
+    s1 = F.conv2d(img1 * img1, w, padding=pad, groups=ch) - mu1_sq
+    s2 = F.conv2d(img2 * img2, w, padding=pad, groups=ch) - mu2_sq
+    s12 = F.conv2d(img1 * img2, w, padding=pad, groups=ch) - mu1_mu2
+    C1, C2 = 0.01 ** 2, 0.03 ** 2
+    m = ((2 * mu1_mu2 + C1) * (2 * s12 + C2)) / ((mu1_sq + mu2_sq + C1) * (s1 + s2 + C2))
+    return m.mean()
+
+
+def photometric_loss(pred: torch.Tensor, gt: torch.Tensor, lambda_dssim: float = 0.2) -> torch.Tensor:
+    l1 = torch.abs(pred - gt).mean()
+    return (1.0 - lambda_dssim) * l1 + lambda_dssim * (1.0 - ssim(pred, gt))
+
+
+class GaussianParams:
+    """Raw (pre-activation) parameters, laid out as HTGaussianModel keeps them."""
+
+    def __init__(self, scene: Dict, device, spatial_lr_scale: float = 1.0):
+        d = device
+        self.max_sh_degree = int(round(math.sqrt(scene["shs"].shape[1]))) - 1
+        self.active_sh_degree = int(scene["sh_degree"])
+        self._xyz = scene["means3D"].to(d).clone().requires_grad_(True)
+        self._features_dc = scene["shs"][:, :1].to(d).clone().contiguous().requires_grad_(True)
+        self._features_rest = scene["shs"][:, 1:].to(d).clone().contiguous().requires_grad_(True)
+        self._scaling = torch.log(scene["scales"].to(d)).requires_grad_(True)
+        self._rotation = scene["rotations"].to(d).clone().requires_grad_(True)
+        self._opacity = inverse_sigmoid(scene["opacities"].to(d).clamp(1e-4, 1 - 1e-4)).requires_grad_(True)
+        groups = [
+            {"params": [self._xyz], "lr": 0.00016 * spatial_lr_scale, "name": "xyz"},
+            {"params": [self._features_dc], "lr": 0.0025, "name": "f_dc"},
+            {"params": [self._features_rest], "lr": 0.0025 / 20.0, "name": "f_rest"},
+            {"params": [self._opacity], "lr": 0.05, "name": "opacity"},
+            {"params": [self._scaling], "lr": 0.005, "name": "scaling"},
+            {"params": [self._rotation], "lr": 0.001, "name": "rotation"},
+        ]
+        self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
+
+    @property
+    def num_points(self):
+        return self._xyz.shape[0]
+
+    @property
+    def get_xyz(self):
+        return self._xyz
+
+    @property
+    def get_scaling(self):
+        return torch.exp(self._scaling)
+
+    @property
+    def get_rotation(self):
+        return F.normalize(self._rotation)
+
+    @property
+    def get_opacity(self):
+        return torch.sigmoid(self._opacity)
+
+    @property
+    def get_features(self):
+        return torch.cat((self._features_dc, self._features_rest), dim=1)
+
+
+def make_settings(scene: Dict, device, sh_degree: int, bg=None) -> GaussianRasterizationSettings:
+    bg = scene["bg"] if bg is None else bg
+    return GaussianRasterizationSettings(
+        image_height=int(scene["image_height"]), image_width=int(scene["image_width"]),
+        tanfovx=float(scene["tanfovx"]), tanfovy=float(scene["tanfovy"]), bg=bg.to(device).float(),
+        scale_modifier=1.0, viewmatrix=scene["viewmatrix"].to(device), projmatrix=scene["projmatrix"].to(device),
+        sh_degree=sh_degree, campos=scene["campos"].to(device), prefiltered=False, debug=False)
+
+
+def render(params: GaussianParams, settings: GaussianRasterizationSettings) -> Dict:
+    """CF3DGS_Render.render with compute_cov3D_python = convert_SHs_python = False."""
+    xyz = params.get_xyz
+    screenspace_points = torch.zeros_like(xyz, requires_grad=True) + 0
+    try:
+        screenspace_points.retain_grad()
+    except Exception:
+        pass
+    rasterizer = GaussianRasterizer(raster_settings=settings)
+    out = rasterizer(means3D=xyz, means2D=screenspace_points, shs=params.get_features, colors_precomp=None,
+                     opacities=params.get_opacity, scales=params.get_scaling, rotations=params.get_rotation,
+                     cov3D_precomp=None)
+    rendered_image, radii, rendered_depth, rendered_alpha = out
+    return {"image": rendered_image.clamp(0, 1), "depth": rendered_depth, "alpha": rendered_alpha,
+            "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii}
+
+
+def train_step(params: GaussianParams, settings: GaussianRasterizationSettings, gt: torch.Tensor,
+               lambda_dssim: float = 0.2) -> Dict:
+    """render -> loss -> backward -> Adam step (ht3dgs_trainer.py:102-166 without densification)."""
+    pkg = render(params, settings)
+    loss = photometric_loss(pkg["image"], gt, lambda_dssim)
+    loss.backward()
+    params.optimizer.step()
+    params.optimizer.zero_grad(set_to_none=True)
+    pkg["loss"] = loss.detach()
+    return pkg

@@ -1,0 +1,140 @@
+/*
+ * include/gsr.h -- C ABI of the MI355X (gfx950) Gaussian rasterizer library libgsr_hip.so.
+ *
+ * Drop-in boundary.  The reference binds its rasterizer through the Python module
+ * `diff_gaussian_rasterization` (call sites: /root/reference/scene/gaussian_model_ht.py:809-880,
+ * /root/reference/gaussian_renderer/__init__.py:38-96, /root/reference/scene/gaussian_model.py:935-1009),
+ * whose native extension `_C` is an UN-VENDORED submodule (/root/reference/.gitmodules:4-6).  The three entry
+ * points a maintainer's FFI for this path would bind are restated here as plain C:
+ *
+ *   gsr_forward       <- the extension's forward  ("rasterize_gaussians"), invoked by GaussianRasterizer.forward
+ *                        as called at gaussian_model_ht.py:871-880; returns what :881-894 unpacks
+ *   gsr_backward      <- the extension's backward ("rasterize_gaussians_backward"), reached by loss.backward()
+ *                        at /root/reference/trainer/ht3dgs_trainer.py:135; produces the grads consumed at
+ *                        gaussian_model_ht.py:718-721 (means2D) and by the Adam groups :275-289
+ *   gsr_mark_visible  <- the extension's "mark_visible" (GaussianRasterizer.markVisible; unused by the reference)
+ *
+ * Rules: extern "C", raw DEVICE pointers and sizes only, no torch types, no exceptions.  Every call is
+ * asynchronous on `stream` (a hipStream_t passed as void*) except for one device->host read of the instance
+ * count inside gsr_forward.  Return 0 on success, a negative GSR_ERR_* otherwise; gsr_last_error() gives text.
+ * All float tensors are binary32, contiguous.  4x4 matrices are read linearly as the reference stores them
+ * (transposed, /root/reference/scene/cameras.py:76-98).
+ */
+#ifndef GSR_H
+#define GSR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSR_OK 0
+#define GSR_ERR_ARG (-1)
+#define GSR_ERR_HIP (-2)
+#define GSR_ERR_ALLOC (-3)
+#define GSR_ERR_RANGE (-4)
+
+#define GSR_ALLOC_BINNING 0 /* kept by the caller until gsr_backward */
+#define GSR_ALLOC_SCRATCH 1 /* may be released (stream-ordered) as soon as gsr_forward returns */
+
+/* Allocator callback: return a device pointer to `bytes` bytes (>=256-byte aligned) or NULL. */
+typedef void* (*gsr_alloc_fn)(size_t bytes, int tag, void* user);
+
+typedef struct GsrForwardArgs {
+    int32_t N;           /* Gaussians */
+    int32_t M;           /* SH coefficients stored per Gaussian (row stride of shs), e.g. 16 */
+    int32_t D;           /* active SH degree 0..3 (raster_settings.sh_degree) */
+    int32_t W, H;        /* image_width, image_height */
+    int32_t prefiltered; /* accepted, ignored (reference always passes False: gaussian_model_ht.py:820) */
+    int32_t debug;       /* accepted, ignored (reference always passes False: gaussian_model_ht.py:821) */
+    float scale_modifier, tanfovx, tanfovy;
+    const float* means3D;        /* [N,3] */
+    const float* scales;         /* [N,3]  or NULL when cov3D_precomp is given */
+    const float* rotations;      /* [N,4]  (w,x,y,z) */
+    const float* cov3D_precomp;  /* [N,6]  xx,xy,xz,yy,yz,zz or NULL */
+    const float* opacities;      /* [N] */
+    const float* shs;            /* [N,M,3] or NULL when colors_precomp is given */
+    const float* colors_precomp; /* [N,3] or NULL */
+    const float* viewmatrix;     /* 16 floats, device */
+    const float* projmatrix;     /* 16 floats, device */
+    const float* campos;         /* 3 floats, device */
+    const float* bg;             /* 3 floats, device */
+    float* out_color;            /* [3,H,W] */
+    float* out_depth;            /* [1,H,W] */
+    float* out_alpha;            /* [1,H,W] */
+    int32_t* radii;              /* [N] */
+    void* geom;                  /* gsr_geom_bytes(N) bytes, kept until backward */
+    void* image;                 /* gsr_image_bytes(W,H) bytes, kept until backward */
+    gsr_alloc_fn alloc;          /* called for the R-sized buffers once R is known */
+    void* alloc_user;
+} GsrForwardArgs;
+
+typedef struct GsrForwardOut {
+    int64_t num_rendered; /* R: (tile, Gaussian) instances */
+    void* binning;        /* pointer returned by alloc(GSR_ALLOC_BINNING); pass to gsr_backward */
+    size_t binning_bytes;
+} GsrForwardOut;
+
+typedef struct GsrBackwardArgs {
+    int32_t N, M, D, W, H;
+    float scale_modifier, tanfovx, tanfovy;
+    const float *means3D, *scales, *rotations, *cov3D_precomp, *opacities, *shs, *colors_precomp;
+    const float *viewmatrix, *projmatrix, *campos, *bg;
+    const void* geom;    /* from forward */
+    const void* image;   /* from forward */
+    const void* binning; /* from forward */
+    int64_t num_rendered;
+    const float* grad_color; /* [3,H,W] or NULL */
+    const float* grad_depth; /* [1,H,W] or NULL */
+    const float* grad_alpha; /* [1,H,W] or NULL */
+    float* d_means3D;        /* [N,3] */
+    float* d_means2D;        /* [N,3]  (d/d ndc x, d/d ndc y, 0): gaussian_model_ht.py:718-721 */
+    float* d_opacities;      /* [N] */
+    float* d_colors_precomp; /* [N,3] or NULL */
+    float* d_shs;            /* [N,M,3] or NULL */
+    float* d_scales;         /* [N,3] or NULL */
+    float* d_rotations;      /* [N,4] or NULL */
+    float* d_cov3D_precomp;  /* [N,6] or NULL */
+    void* scratch;           /* gsr_backward_scratch_bytes(N) bytes */
+} GsrBackwardArgs;
+
+size_t gsr_geom_bytes(int32_t N);
+size_t gsr_image_bytes(int32_t W, int32_t H);
+/* byte offset inside the image workspace of the per-tile uint32 "instances actually staged" counters that
+ * the forward blend writes (their sum is R_eff of the roofline accounting) */
+size_t gsr_image_staged_offset(int32_t W, int32_t H);
+size_t gsr_forward_scratch_bytes(int32_t N);
+size_t gsr_binning_bytes(int64_t R, int32_t W, int32_t H);
+size_t gsr_binning_scratch_bytes(int64_t R);
+size_t gsr_backward_scratch_bytes(int32_t N);
+
+int gsr_forward(const GsrForwardArgs* args, GsrForwardOut* out, void* stream);
+int gsr_backward(const GsrBackwardArgs* args, void* stream);
+int gsr_mark_visible(int32_t N, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                     uint8_t* present, void* stream);
+
+const char* gsr_last_error(void);
+int gsr_version(void);
+
+/* Process-wide knobs: "blend_fwd_ppt" / "blend_bwd_ppt" = pixels per thread of the blend kernels (1, 2, 4;
+ * 0 = default); "profile" = 1 records HIP events around every stage on the caller's stream. */
+int gsr_set_option(const char* name, int value);
+/* Sum of the recorded durations of stage `name` ("preprocess_fwd", "sort_depth", "scan", "emit", "sort_tile",
+ * "ranges", "blend_fwd", "blend_bwd", "preprocess_bwd") since the last read; synchronises on the events. */
+int gsr_profile_read(const char* name, double* total_ms, int64_t* count);
+
+/* Building blocks exported for the unit tests of tests/test_gpu_blocks.py (device pointers). */
+int gsr_sort_pairs_u32(uint32_t* keys, uint32_t* vals, uint32_t* keys_alt, uint32_t* vals_alt, uint32_t n,
+                       int begin_bit, int end_bit, void* scratch, size_t scratch_bytes, int* result_in_alt,
+                       void* stream);
+int gsr_sort_pairs_u16(uint16_t* keys, uint32_t* vals, uint16_t* keys_alt, uint32_t* vals_alt, uint32_t n,
+                       int begin_bit, int end_bit, void* scratch, size_t scratch_bytes, int* result_in_alt,
+                       void* stream);
+size_t gsr_sort_scratch_bytes(uint32_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSR_H */

@@ -181,7 +181,7 @@ static void sh_to_rgb(int deg, const float *sh, const real dir[3], real out[3])
 }
 
 /* rounding-edge margins of the blend decisions (absolute); calibrated in tests/test_oracle_cpu.py */
-static double g_margin_alpha = 1e-7, g_margin_T = 2e-8, g_margin_power = 1e-7;
+static double g_margin_alpha = 2e-8, g_margin_T = 1e-9, g_margin_power = 1e-7;
 void gsr_oracle_set_margins(double a, double t, double p) { g_margin_alpha = a; g_margin_T = t; g_margin_power = p; }
 
 static int cmp_u64(const void *a, const void *b)
@@ -385,6 +385,7 @@ static void blend_all(Ctx *c)
     const GsrOracleIn *I = &c->in;
     const int W = I->W, H = I->H, tx = c->tiles_x;
     int64_t pairs = 0;
+    const double coord_ulp = 6e-8 * (W > H ? W : H);
 #pragma omp parallel for schedule(dynamic, 4) reduction(+ : pairs)
     for (int t = 0; t < c->tiles_x * c->tiles_y; t++) {
         int ty0 = (t / tx) * TILE, tx0 = (t % tx) * TILE;
@@ -394,6 +395,7 @@ static void blend_all(Ctx *c)
                 real T = 1, C[3] = {0, 0, 0}, Dp = 0, A = 0;
                 uint32_t contributor = 0, last = 0;
                 uint8_t amb = 0;
+                double relT = 0;
                 for (int64_t k = s; k < e; k++) {
                     contributor++;
                     pairs++;
@@ -402,14 +404,21 @@ static void blend_all(Ctx *c)
                     const real *co = c->conic + 3 * (size_t)g;
                     real o = I->opacities[g];
                     real power = (real)-0.5 * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
-                    if (power > (real)-g_margin_power && o >= ALPHA_MIN) amb = 1;
+                    /* binary32 error model of the HIP path: the pixel-space mean carries ~ulp(max(W,H)),
+                     * so power carries |grad power| * ulp plus its own rounding; alpha = o*exp(power)
+                     * inherits alpha * dpower.  The running T collects the relative errors of (1-alpha). */
+                    double dpow = 4.0 * ((fabs((double)(co[0] * dx + co[1] * dy)) + fabs((double)(co[2] * dy + co[1] * dx))) * coord_ulp +
+                                         6e-8 * (fabs((double)(co[0] * dx * dx)) + fabs((double)(co[2] * dy * dy)) + fabs((double)(co[1] * dx * dy)) + 1.0));
+                    if (power > (real)-(g_margin_power + dpow) && o >= ALPHA_MIN) amb = 1;
                     if (power > 0) continue;
                     real alpha = o * R_EXP(power);
                     if (alpha > ALPHA_MAX) alpha = ALPHA_MAX;
-                    if (fabs((double)(alpha - ALPHA_MIN)) < g_margin_alpha) amb = 1;
+                    double dalpha = (double)alpha * dpow + g_margin_alpha;
+                    if (fabs((double)(alpha - ALPHA_MIN)) < dalpha) amb = 1;
                     if (alpha < ALPHA_MIN) continue;
                     real test_T = T * (1 - alpha);
-                    if (fabs((double)(test_T - T_STOP)) < g_margin_T) amb = 1;
+                    relT += dalpha / (1.0 - (double)alpha) + 1.2e-7;
+                    if (fabs((double)(test_T - T_STOP)) < (double)test_T * relT + g_margin_T) amb = 1;
                     if (test_T < T_STOP) break;
                     real w = alpha * T;
                     const real *rgb = c->rgb + 3 * (size_t)g;

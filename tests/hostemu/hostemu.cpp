@@ -45,6 +45,10 @@ static Camera make_cam(const EmuIn& in)
     return c;
 }
 
+// experiment hook: when non-null, overrides the projected state with externally computed (e.g. f64-rounded) values
+static const float *g_ov_xy = nullptr, *g_ov_conic = nullptr, *g_ov_rgb = nullptr;
+void hostemu_override_geom(const float* xy, const float* conic, const float* rgb) { g_ov_xy = xy; g_ov_conic = conic; g_ov_rgb = rgb; }
+
 EmuCtx* hostemu_forward(const EmuIn* in, float* out_color, float* out_depth, float* out_alpha, int32_t* radii)
 {
     EmuCtx* c = new EmuCtx();
@@ -59,6 +63,12 @@ EmuCtx* hostemu_forward(const EmuIn* in, float* out_color, float* out_depth, flo
                        in->cov3D_precomp ? in->cov3D_precomp + 6 * (size_t)i : nullptr, in->opacities[i],
                        in->shs ? in->shs + (size_t)i * in->M * 3 : nullptr, 3, 1,
                        in->colors_precomp ? in->colors_precomp + 3 * (size_t)i : nullptr, c->splat[i]);
+        if (g_ov_xy && c->splat[i].radius > 0) {
+            Splat& s = c->splat[i];
+            s.px = g_ov_xy[2 * i]; s.py = g_ov_xy[2 * i + 1];
+            s.ca = g_ov_conic[3 * i]; s.cb = g_ov_conic[3 * i + 1]; s.cc = g_ov_conic[3 * i + 2];
+            s.r = g_ov_rgb[3 * i]; s.g = g_ov_rgb[3 * i + 1]; s.b = g_ov_rgb[3 * i + 2];
+        }
         if (radii) radii[i] = c->splat[i].radius;
     }
     // depth order (stable on index), then stable by tile  == (tile, depth bits, index)
