@@ -50,6 +50,7 @@ EXPORTS = [
     "gsr_binning_scratch_bytes", "gsr_backward_scratch_bytes", "gsr_forward", "gsr_backward",
     "gsr_mark_visible", "gsr_last_error", "gsr_version", "gsr_set_option", "gsr_sort_pairs_u32",
     "gsr_sort_pairs_u16", "gsr_sort_scratch_bytes", "gsr_image_staged_offset", "gsr_profile_read",
+    "gsr_loss_workspace_bytes", "gsr_loss_forward", "gsr_loss_backward",
 ]
 
 _lib = None
@@ -74,6 +75,14 @@ def load():
     lib.gsr_image_staged_offset.argtypes = [C.c_int32, C.c_int32]
     lib.gsr_profile_read.restype = C.c_int
     lib.gsr_profile_read.argtypes = [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    lib.gsr_loss_workspace_bytes.restype = C.c_size_t
+    lib.gsr_loss_workspace_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32]
+    lib.gsr_loss_forward.restype = C.c_int
+    lib.gsr_loss_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32,
+                                     C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.gsr_loss_backward.restype = C.c_int
+    lib.gsr_loss_backward.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.gsr_binning_bytes.restype = C.c_size_t
     lib.gsr_binning_bytes.argtypes = [C.c_int64, C.c_int32, C.c_int32]
     lib.gsr_binning_scratch_bytes.restype = C.c_size_t

@@ -159,7 +159,7 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess(CamParams cp, int N,
                    colors ? colp : nullptr, s);
     splat[i] = s;
     radii[i] = s.radius;
-    dkey[i] = s.radius > 0 ? __float_as_uint(s.depth) : 0xffffffffu;
+    dkey[i] = s.tiles > 0 ? __float_as_uint(s.depth) : 0xffffffffu;
     gid[i] = (uint32_t)i;
 }
 
@@ -234,49 +234,83 @@ __global__ __launch_bounds__(1024) void k_block_scan(uint32_t* __restrict__ bloc
 }
 
 // ------------------------------------------------------------------------------------------------
-// K4: emit (tile, gid) instances in depth order.  A block owns 256 depth-sorted Gaussians and a contiguous
-// output range; lanes take consecutive output slots (coalesced stores) and find their (Gaussian, tile)
-// by binary search in the block's inclusive scan.
+// K4: emit (tile, gid) instances in depth order, dropping the instances the exact tile test rejects.
+// A block owns 256 depth-sorted Gaussians; it enumerates the candidate (Gaussian, tile) slots of their
+// bounding rects 256 at a time (lanes take consecutive slots and find their Gaussian by binary search in the
+// block's LDS scan), tests each, and compacts the survivors IN ORDER with a ballot/popcount block scan, so the
+// output stays (depth, id)-ordered and the stores of one chunk are consecutive addresses.  The block's output
+// base is the exclusive scan of Splat::tiles (the exact counts k_preprocess made with the same test).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kEmitThreads) void k_emit(int N, int tiles_x, int tiles_y, const uint32_t* __restrict__ sorted_gid,
-                                                       const Splat* __restrict__ splat, const uint32_t* __restrict__ block_offsets,
-                                                       uint16_t* __restrict__ out_tile, uint32_t* __restrict__ out_gid)
+__global__ __launch_bounds__(kEmitThreads) void k_emit(int N, int W, int H, int tiles_x, int tiles_y,
+                                                       const uint32_t* __restrict__ sorted_gid, const Splat* __restrict__ splat,
+                                                       const uint32_t* __restrict__ block_offsets, uint16_t* __restrict__ out_tile,
+                                                       uint32_t* __restrict__ out_gid)
 {
     __shared__ uint32_t s_wave[4];
     __shared__ uint32_t s_incl[kEmitThreads];
     __shared__ uint32_t s_gid[kEmitThreads];
     __shared__ int s_x0[kEmitThreads], s_y0[kEmitThreads], s_w[kEmitThreads];
-    const int tid = threadIdx.x;
+    __shared__ float4 s_geo[kEmitThreads];   // px, py, ca, cb
+    __shared__ float2 s_geo2[kEmitThreads];  // cc, tau
+    __shared__ uint32_t s_cnt[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = blockIdx.x * kEmitThreads + tid;
-    uint32_t t = 0, g = 0;
+    uint32_t full = 0, g = 0;
     int x0 = 0, y0 = 0, w = 1;
+    float4 geo = {0.f, 0.f, 1.f, 0.f};
+    float2 geo2 = {1.f, -1.f};
     if (j < N) {
         g = sorted_gid[j];
         const Splat s = splat[g];
-        t = s.tiles;
-        if (t) {
+        if (s.tiles) {
             int x1, y1;
             tile_rect(s.px, s.py, s.radius, tiles_x, tiles_y, x0, y0, x1, y1);
             w = x1 - x0;
+            full = (uint32_t)(w * (y1 - y0));
+            geo = make_float4(s.px, s.py, s.ca, s.cb);
+            geo2 = make_float2(s.cc, splat_tau(s.op));
         }
     }
     uint32_t total;
-    const uint32_t incl = block_inclusive_scan_256(t, s_wave, total);
-    s_incl[tid] = incl; s_gid[tid] = g; s_x0[tid] = x0; s_y0[tid] = y0; s_w[tid] = w;
+    const uint32_t incl = block_inclusive_scan_256(full, s_wave, total);
+    s_incl[tid] = incl; s_gid[tid] = g; s_x0[tid] = x0; s_y0[tid] = y0; s_w[tid] = w; s_geo[tid] = geo; s_geo2[tid] = geo2;
     __syncthreads();
-    const uint32_t out_base = block_offsets[blockIdx.x];
-    for (uint32_t q = tid; q < total; q += kEmitThreads) {
-        int lo = 0, hi = kEmitThreads - 1;   // first index with s_incl > q
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (s_incl[mid] > q) hi = mid; else lo = mid + 1;
+    uint32_t run = block_offsets[blockIdx.x];
+    const unsigned long long lt = lanemask_lt();
+    for (uint32_t base = 0; base < total; base += kEmitThreads) {
+        const uint32_t q = base + tid;
+        bool ok = false;
+        uint32_t tile = 0, gg = 0;
+        if (q < total) {
+            int lo = 0, hi = kEmitThreads - 1;   // first index with s_incl > q
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (s_incl[mid] > q) hi = mid; else lo = mid + 1;
+            }
+            const uint32_t excl = lo ? s_incl[lo - 1] : 0u;
+            const int k = (int)(q - excl);
+            const int ww = s_w[lo];
+            const int ty = k / ww, tx = k - ty * ww;
+            const int gx = s_x0[lo] + tx, gy = s_y0[lo] + ty;
+            const float4 a = s_geo[lo];
+            const float2 b = s_geo2[lo];
+            ok = tile_accept(a.x, a.y, a.z, a.w, b.x, b.y, gx, gy, W, H);
+            tile = (uint32_t)(gy * tiles_x + gx);
+            gg = s_gid[lo];
         }
-        const uint32_t excl = lo ? s_incl[lo - 1] : 0u;
-        const int k = (int)(q - excl);
-        const int ww = s_w[lo];
-        const int ty = k / ww, tx = k - ty * ww;
-        out_tile[out_base + q] = (uint16_t)((s_y0[lo] + ty) * tiles_x + s_x0[lo] + tx);
-        out_gid[out_base + q] = s_gid[lo];
+        const unsigned long long m = __ballot(ok);
+        if (lane == 0) s_cnt[wave] = (uint32_t)__popcll(m);
+        __syncthreads();
+        uint32_t pre = 0, chunk = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const uint32_t c = s_cnt[k]; pre += (k < wave) ? c : 0u; chunk += c; }
+        if (ok) {
+            const uint32_t pos = run + pre + (uint32_t)__popcll(m & lt);
+            out_tile[pos] = (uint16_t)tile;
+            out_gid[pos] = gg;
+        }
+        run += chunk;
+        __syncthreads();
     }
 }
 
@@ -859,7 +893,7 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
         uint32_t* v1 = (passes & 1) ? list : gid_alt2;
         {
             ProfScope ps(P_EMIT, st);
-            hipLaunchKernelGGL(k_emit, dim3(nb), dim3(kEmitThreads), 0, st, N, tiles_x, tiles_y, sorted_gid, splat, block_sums, tkey, v0);
+            hipLaunchKernelGGL(k_emit, dim3(nb), dim3(kEmitThreads), 0, st, N, W, H, tiles_x, tiles_y, sorted_gid, splat, block_sums, tkey, v0);
         }
         int in_alt = 0;
         {
@@ -872,7 +906,7 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
             hipLaunchKernelGGL(k_tile_ranges, dim3(((uint32_t)R + 255) / 256), dim3(256), 0, st, (uint32_t)R, skey, ranges);
         }
     }
-    const int ppt = g_blend_ppt ? g_blend_ppt : 2;
+    const int ppt = g_blend_ppt ? g_blend_ppt : 1;
     float* img = static_cast<float*>(a->image);
     uint32_t* staged = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(a->image) + gsr_image_staged_offset(W, H));
     {

@@ -45,7 +45,7 @@ struct alignas(16) Splat {
     float cc, op, depth, r;    // conic C, opacity, view depth, red
     float g, b;                // green, blue
     int32_t radius;            // ceil(3 sigma) in pixels, 0 = invisible
-    uint32_t tiles;            // number of 16x16 tiles touched
+    uint32_t tiles;            // number of 16x16 tiles that receive a contribution (exact culling)
 };
 static_assert(sizeof(Splat) == 48, "Splat must be 48 bytes");
 
@@ -174,6 +174,54 @@ GSR_HD void tile_rect(float px, float py, int radius, int tiles_x, int tiles_y, 
     y1 = imin(tiles_y, imax(0, (int)((py + r + (kTile - 1)) * inv)));
 }
 
+// ------------------------------------------------------------------------------------------------
+// Exact, image-preserving tile culling.  A pixel receives a contribution only if power <= 0 and
+// o*exp(power) >= 1/255, i.e. q = A dx^2 + 2 B dx dy + C dy^2 <= tau = 2 ln(255 o).  A (Gaussian, tile) instance
+// whose minimum q over the tile's pixel-centre box exceeds tau (plus slack for binary32 rounding) blends
+// nothing and is dropped before the sort.  The rendered image is unchanged; only lists get shorter.
+// The SAME function decides the count (k_preprocess) and the emission (k_emit): results must be bit-identical.
+// ------------------------------------------------------------------------------------------------
+GSR_HD float splat_tau(float opacity)
+{
+    return opacity > 0.f ? 2.0f * logf(255.0f * opacity) : -1.0f;
+}
+
+GSR_HD bool tile_accept(float px, float py, float ca, float cb, float cc, float tau, int tx, int ty, int W, int H)
+{
+    const float slack = 1e-3f * (1.0f + fabsf(tau));
+    if (tau < -slack) return false;                       // opacity below 1/255: contributes nowhere
+    const float bx0 = (float)(tx * kTile), by0 = (float)(ty * kTile);
+    const float bx1 = fminf(bx0 + (float)(kTile - 1), (float)(W - 1)), by1 = fminf(by0 + (float)(kTile - 1), (float)(H - 1));
+    const float dx0 = bx0 - px, dx1 = bx1 - px, dy0 = by0 - py, dy1 = by1 - py;
+    if (dx0 <= 0.f && dx1 >= 0.f && dy0 <= 0.f && dy1 >= 0.f) return true;   // centre inside the box
+    float qmin = 3.0e38f;
+    const float rc = cb / cc, ra = cb / ca;
+    {   // vertical edges x = dx0, dx1: minimise over y
+        float y = fminf(dy1, fmaxf(dy0, -rc * dx0));
+        qmin = fminf(qmin, ca * dx0 * dx0 + 2.f * cb * dx0 * y + cc * y * y);
+        y = fminf(dy1, fmaxf(dy0, -rc * dx1));
+        qmin = fminf(qmin, ca * dx1 * dx1 + 2.f * cb * dx1 * y + cc * y * y);
+    }
+    {   // horizontal edges
+        float x = fminf(dx1, fmaxf(dx0, -ra * dy0));
+        qmin = fminf(qmin, ca * x * x + 2.f * cb * x * dy0 + cc * dy0 * dy0);
+        x = fminf(dx1, fmaxf(dx0, -ra * dy1));
+        qmin = fminf(qmin, ca * x * x + 2.f * cb * x * dy1 + cc * dy1 * dy1);
+    }
+    return qmin <= tau + slack;
+}
+
+struct Splat;
+GSR_HD uint32_t count_accepted_tiles(float px, float py, float ca, float cb, float cc, float op, int x0, int y0, int x1, int y1,
+                                     int W, int H)
+{
+    const float tau = splat_tau(op);
+    uint32_t n = 0;
+    for (int ty = y0; ty < y1; ty++)
+        for (int tx = x0; tx < x1; tx++) n += tile_accept(px, py, ca, cb, cc, tau, tx, ty, W, H) ? 1u : 0u;
+    return n;
+}
+
 // SH colour (before +0.5 / clamp) for one channel; sh points at coefficient 0 of that channel,
 // consecutive coefficients are `stride` floats apart.
 template <typename RT>
@@ -264,7 +312,8 @@ GSR_HD void preprocess_one(const Camera& c, const float mean[3], const float* sc
     out.ca = (float)(cc * dinv); out.cb = (float)(-b * dinv); out.cc = (float)(a * dinv);
     out.op = opacity;
     out.r = col[0]; out.g = col[1]; out.b = col[2];
-    out.radius = radius; out.tiles = (uint32_t)nt;
+    out.radius = radius;
+    out.tiles = count_accepted_tiles(out.px, out.py, out.ca, out.cb, out.cc, out.op, x0, y0, x1, y1, c.W, c.H);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -15,6 +15,7 @@ from typing import Dict
 import torch
 import torch.nn.functional as F
 
+from .loss import fused_photometric_loss
 from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
 
 
@@ -79,7 +80,9 @@ class GaussianParams:
             {"params": [self._scaling], "lr": 0.005, "name": "scaling"},
             {"params": [self._rotation], "lr": 0.001, "name": "rotation"},
         ]
-        self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
+        # same update rule as the reference's torch.optim.Adam(l, lr=0.0, eps=1e-15); `fused` only selects the
+        # single-pass implementation (one kernel per group instead of the foreach chain)
+        self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15, fused=self._xyz.is_cuda)
 
     @property
     def num_points(self):
@@ -115,7 +118,7 @@ def make_settings(scene: Dict, device, sh_degree: int, bg=None) -> GaussianRaste
         sh_degree=sh_degree, campos=scene["campos"].to(device), prefiltered=False, debug=False)
 
 
-def render(params: GaussianParams, settings: GaussianRasterizationSettings) -> Dict:
+def render(params: GaussianParams, settings: GaussianRasterizationSettings, clamp: bool = True) -> Dict:
     """CF3DGS_Render.render with compute_cov3D_python = convert_SHs_python = False."""
     xyz = params.get_xyz
     screenspace_points = torch.zeros_like(xyz, requires_grad=True) + 0
@@ -128,15 +131,19 @@ def render(params: GaussianParams, settings: GaussianRasterizationSettings) -> D
                      opacities=params.get_opacity, scales=params.get_scaling, rotations=params.get_rotation,
                      cov3D_precomp=None)
     rendered_image, radii, rendered_depth, rendered_alpha = out
-    return {"image": rendered_image.clamp(0, 1), "depth": rendered_depth, "alpha": rendered_alpha,
-            "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii}
+    return {"image": rendered_image.clamp(0, 1) if clamp else None, "raw_image": rendered_image, "depth": rendered_depth,
+            "alpha": rendered_alpha, "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii}
 
 
 def train_step(params: GaussianParams, settings: GaussianRasterizationSettings, gt: torch.Tensor,
-               lambda_dssim: float = 0.2) -> Dict:
-    """render -> loss -> backward -> Adam step (ht3dgs_trainer.py:102-166 without densification)."""
-    pkg = render(params, settings)
-    loss = photometric_loss(pkg["image"], gt, lambda_dssim)
+               lambda_dssim: float = 0.2, fused_loss: bool = True) -> Dict:
+    """render -> loss -> backward -> Adam step (ht3dgs_trainer.py:102-166 without densification).
+    fused_loss=True evaluates clamp + L1 + SSIM in the HIP loss kernels; False uses the torch restatement."""
+    pkg = render(params, settings, clamp=not fused_loss)
+    if fused_loss:
+        loss = fused_photometric_loss(pkg["raw_image"], gt, lambda_dssim, clamp=True)
+    else:
+        loss = photometric_loss(pkg["image"], gt, lambda_dssim)
     loss.backward()
     params.optimizer.step()
     params.optimizer.zero_grad(set_to_none=True)

@@ -125,6 +125,19 @@ int gsr_set_option(const char* name, int value);
  * "ranges", "blend_fwd", "blend_bwd", "preprocess_bwd") since the last read; synchronises on the events. */
 int gsr_profile_read(const char* name, double* total_ms, int64_t* count);
 
+/* ---- "next" row f-3: fused photometric loss of the train step -----------------------
+ * loss = (1-lambda)*mean|x-y| + lambda*(1-mean SSIM(x,y)), x = clamp(render,0,1) when clamp01_render != 0.
+ * Replaces the torch ops of /root/reference/trainer/losses.py:98-136 (Loss.forward) and :147-209 (11x11 Gaussian
+ * window SSIM) applied to the clamped render of /root/reference/scene/gaussian_model_ht.py:883.
+ * out3 = {loss, mean ssim, mean l1}; workspace (gsr_loss_workspace_bytes) is kept for the backward.
+ * grad_loss: device pointer to the upstream scalar gradient, or NULL for 1. */
+size_t gsr_loss_workspace_bytes(int32_t C, int32_t H, int32_t W);
+int gsr_loss_forward(const float* render, const float* target, int32_t C, int32_t H, int32_t W, float lambda_dssim,
+                     int32_t clamp01_render, void* workspace, float* out3, void* stream);
+int gsr_loss_backward(const float* render, const float* target, int32_t C, int32_t H, int32_t W, float lambda_dssim,
+                      int32_t clamp01_render, const void* workspace, const float* grad_loss, float* d_render,
+                      void* stream);
+
 /* Building blocks exported for the unit tests of tests/test_gpu_blocks.py (device pointers). */
 int gsr_sort_pairs_u32(uint32_t* keys, uint32_t* vals, uint32_t* keys_alt, uint32_t* vals_alt, uint32_t n,
                        int begin_bit, int end_bit, void* scratch, size_t scratch_bytes, int* result_in_alt,

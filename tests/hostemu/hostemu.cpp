@@ -73,14 +73,20 @@ EmuCtx* hostemu_forward(const EmuIn* in, float* out_color, float* out_depth, flo
     }
     // depth order (stable on index), then stable by tile  == (tile, depth bits, index)
     std::vector<uint32_t> order;
-    for (int i = 0; i < N; i++) if (c->splat[i].radius > 0) order.push_back(i);
+    for (int i = 0; i < N; i++) if (c->splat[i].tiles > 0) order.push_back(i);
     std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
         uint32_t ka, kb; memcpy(&ka, &c->splat[a].depth, 4); memcpy(&kb, &c->splat[b].depth, 4); return ka < kb; });
     std::vector<std::pair<uint32_t, uint32_t>> inst;  // (tile, gid) in emission order
     for (uint32_t g : order) {
         int x0, y0, x1, y1;
         tile_rect(c->splat[g].px, c->splat[g].py, c->splat[g].radius, cam.tiles_x, cam.tiles_y, x0, y0, x1, y1);
-        for (int y = y0; y < y1; y++) for (int x = x0; x < x1; x++) inst.push_back({(uint32_t)(y * cam.tiles_x + x), g});
+        const Splat& s = c->splat[g];
+        const float tau = splat_tau(s.op);
+        uint32_t n = 0;
+        for (int y = y0; y < y1; y++)
+            for (int x = x0; x < x1; x++)
+                if (tile_accept(s.px, s.py, s.ca, s.cb, s.cc, tau, x, y, W, H)) { inst.push_back({(uint32_t)(y * cam.tiles_x + x), g}); n++; }
+        if (n != s.tiles) abort();   // count (preprocess) and emission must agree
     }
     std::stable_sort(inst.begin(), inst.end(), [](auto& a, auto& b) { return a.first < b.first; });
     c->tile_start.assign(T + 1, 0);
