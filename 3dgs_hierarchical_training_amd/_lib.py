@@ -23,6 +23,7 @@ class GsrForwardArgs(C.Structure):
         ("out_color", C.c_void_p), ("out_depth", C.c_void_p), ("out_alpha", C.c_void_p), ("radii", C.c_void_p),
         ("geom", C.c_void_p), ("image", C.c_void_p),
         ("alloc", ALLOC_FN), ("alloc_user", C.c_void_p),
+        ("shs_rest", C.c_void_p), ("raw_params", C.c_int32),
     ]
 
 
@@ -42,7 +43,13 @@ class GsrBackwardArgs(C.Structure):
         ("d_means3D", C.c_void_p), ("d_means2D", C.c_void_p), ("d_opacities", C.c_void_p),
         ("d_colors_precomp", C.c_void_p), ("d_shs", C.c_void_p), ("d_scales", C.c_void_p),
         ("d_rotations", C.c_void_p), ("d_cov3D_precomp", C.c_void_p), ("scratch", C.c_void_p),
+        ("shs_rest", C.c_void_p), ("d_shs_rest", C.c_void_p), ("raw_params", C.c_int32),
     ]
+
+
+class GsrAdamTensor(C.Structure):
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+                ("n", C.c_uint64), ("lr", C.c_float)]
 
 
 EXPORTS = [
@@ -50,7 +57,7 @@ EXPORTS = [
     "gsr_binning_scratch_bytes", "gsr_backward_scratch_bytes", "gsr_forward", "gsr_backward",
     "gsr_mark_visible", "gsr_last_error", "gsr_version", "gsr_set_option", "gsr_sort_pairs_u32",
     "gsr_sort_pairs_u16", "gsr_sort_scratch_bytes", "gsr_image_staged_offset", "gsr_profile_read",
-    "gsr_loss_workspace_bytes", "gsr_loss_forward", "gsr_loss_backward",
+    "gsr_loss_workspace_bytes", "gsr_loss_forward", "gsr_loss_backward", "gsr_adam_step",
 ]
 
 _lib = None
@@ -83,6 +90,8 @@ def load():
     lib.gsr_loss_backward.restype = C.c_int
     lib.gsr_loss_backward.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.gsr_adam_step.restype = C.c_int
+    lib.gsr_adam_step.argtypes = [C.POINTER(GsrAdamTensor), C.c_int32, C.c_float, C.c_float, C.c_float, C.c_int64, C.c_void_p]
     lib.gsr_binning_bytes.restype = C.c_size_t
     lib.gsr_binning_bytes.argtypes = [C.c_int64, C.c_int32, C.c_int32]
     lib.gsr_binning_scratch_bytes.restype = C.c_size_t

@@ -108,17 +108,32 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v)
     return v;
 }
 
+// sum over each 16-lane DPP row: total lands in lanes 15, 31, 47, 63
+__device__ __forceinline__ float row_sum_to_lane15(float v)
+{
+    v = dpp_add<0x111, 0xf>(v);
+    v = dpp_add<0x112, 0xf>(v);
+    v = dpp_add<0x114, 0xf>(v);
+    v = dpp_add<0x118, 0xf>(v);
+    return v;
+}
+
 constexpr int kPreThreads = 128;
 constexpr int kShStride = 49;   // 48 floats + 1 pad: conflict-free column reads
 
 // ------------------------------------------------------------------------------------------------
 // K1: per-Gaussian projection.  SH rows are staged through LDS with coalesced loads.
 // ------------------------------------------------------------------------------------------------
-template <int DEG>
+// RAW = true ("next" row f-2): the kernel consumes the model's raw parameters and applies the activations of
+// /root/reference/scene/gaussian_model_ht.py:49-65,128-133,176-188 itself -- scale = exp(_scaling),
+// q = normalize(_rotation), opacity = sigmoid(_opacity), SH = cat(_features_dc, _features_rest) -- so the
+// torch exp / sigmoid / normalize / cat kernels (and their backward) disappear from the train step.
+template <int DEG, bool RAW>
 __global__ __launch_bounds__(kPreThreads) void k_preprocess(CamParams cp, int N, const float* __restrict__ means,
                                                             const float* __restrict__ scales, const float* __restrict__ rots,
                                                             const float* __restrict__ cov_pre, const float* __restrict__ opac,
-                                                            const float* __restrict__ shs, const float* __restrict__ colors,
+                                                            const float* __restrict__ shs, const float* __restrict__ shs_rest,
+                                                            const float* __restrict__ colors,
                                                             Splat* __restrict__ splat, int32_t* __restrict__ radii,
                                                             uint32_t* __restrict__ dkey, uint32_t* __restrict__ gid)
 {
@@ -129,10 +144,22 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess(CamParams cp, int N,
     const int i = base + tid;
     if (shs) {
         const int nG = min(kPreThreads, N - base);
-        const size_t row = (size_t)cp.M * 3;
-        for (int f = tid; f < nG * NC3; f += kPreThreads) {
-            const int g = f / NC3, e = f - g * NC3;
-            s_sh[g * kShStride + e] = shs[(size_t)(base + g) * row + e];
+        if (shs_rest) {   // split storage: dc [N,1,3] + rest [N,M-1,3]; two straight, divergence-free streams
+            const size_t row = (size_t)(cp.M - 1) * 3;
+            for (int f = tid; f < nG * 3; f += kPreThreads) s_sh[(f / 3) * kShStride + (f % 3)] = shs[(size_t)base * 3 + f];
+            if (NC3 > 3) {
+                constexpr int NR = NC3 > 3 ? NC3 - 3 : 1;
+                for (int f = tid; f < nG * NR; f += kPreThreads) {
+                    const int g = f / NR, e = f - g * NR;
+                    s_sh[g * kShStride + 3 + e] = shs_rest[(size_t)(base + g) * row + e];
+                }
+            }
+        } else {
+            const size_t row = (size_t)cp.M * 3;
+            for (int f = tid; f < nG * NC3; f += kPreThreads) {
+                const int g = f / NC3, e = f - g * NC3;
+                s_sh[g * kShStride + e] = shs[(size_t)(base + g) * row + e];
+            }
         }
         __syncthreads();
     }
@@ -154,8 +181,19 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess(CamParams cp, int N,
 #pragma unroll
         for (int k = 0; k < 3; k++) colp[k] = colors[3 * (size_t)i + k];
     }
+    float op = opac[i];
+    if (RAW) {
+        if (!cov_pre) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) sc[k] = expf(sc[k]);
+            const float inv = 1.0f / fmaxf(sqrtf(rq[0] * rq[0] + rq[1] * rq[1] + rq[2] * rq[2] + rq[3] * rq[3]), 1e-12f);
+#pragma unroll
+            for (int k = 0; k < 4; k++) rq[k] *= inv;
+        }
+        op = 1.0f / (1.0f + expf(-op));
+    }
     Splat s;
-    preprocess_one(cam, mean, sc, rq, cov_pre ? cv : nullptr, opac[i], shs ? &s_sh[tid * kShStride] : nullptr, 3, 1,
+    preprocess_one(cam, mean, sc, rq, cov_pre ? cv : nullptr, op, shs ? &s_sh[tid * kShStride] : nullptr, 3, 1,
                    colors ? colp : nullptr, s);
     splat[i] = s;
     radii[i] = s.radius;
@@ -430,6 +468,102 @@ __global__ __launch_bounds__(256 / PPT) void k_blend_fwd(int W, int H, int tiles
 }
 
 // ------------------------------------------------------------------------------------------------
+// K7 (packed variant): two vertically adjacent pixels per lane as float2 -> v_pk_* arithmetic, branch-free
+// per-pixel skip / stop (masked alpha), only the whole-wave skip is a branch.  Same power expression as
+// k_blend_bwd2 so forward and backward agree on every skip decision bit for bit.
+// ------------------------------------------------------------------------------------------------
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(128) void k_blend_fwd2(int W, int H, int tiles_x, int T, const uint2* __restrict__ ranges,
+                                                    const uint32_t* __restrict__ list, const Splat* __restrict__ splat,
+                                                    const float* __restrict__ bg, float* __restrict__ out_color,
+                                                    float* __restrict__ out_depth, float* __restrict__ out_alpha,
+                                                    float* __restrict__ img, uint32_t* __restrict__ staged)
+{
+    constexpr int NT = 128;
+    __shared__ float4 s_a[2][NT], s_b[2][NT], s_c[2][NT];
+    const int tile = xcd_tile(blockIdx.x, T);
+    if (tile >= T) return;
+    const int tid = threadIdx.x;
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const int px = tx * kTile + (tid & 15);
+    const int py0 = ty * kTile + (tid >> 4) * 2;
+    const float pxf = (float)px;
+    const f2 pyf = {(float)py0, (float)(py0 + 1)};
+    const uint2 rg = ranges[tile];
+    const int n = (int)(rg.y - rg.x);
+    const int nb = (n + NT - 1) / NT;
+    f2 Tt = {1.f, 1.f}, C0 = {0.f, 0.f}, C1 = C0, C2 = C0, Dd = C0, Aa = C0;
+    uint32_t last0 = 0, last1 = 0;
+    bool done0 = !(px < W && py0 < H), done1 = !(px < W && (py0 + 1) < H);
+    float4 ra = {0, 0, 0, 0}, rb = ra, rc = ra;
+    if (tid < n) {
+        const float4* sp = reinterpret_cast<const float4*>(splat + list[rg.x + tid]);
+        ra = sp[0]; rb = sp[1]; rc = sp[2];
+    }
+    int batches = 0;
+    for (int b = 0; b < nb; b++) {
+        const int buf = b & 1;
+        s_a[buf][tid] = ra; s_b[buf][tid] = rb; s_c[buf][tid] = rc;
+        const bool all_done = done0 && done1;
+        if (__syncthreads_and(all_done)) break;
+        batches = b + 1;
+        const int nxt = (b + 1) * NT + tid;
+        if (nxt < n) {
+            const float4* sp = reinterpret_cast<const float4*>(splat + list[rg.x + nxt]);
+            ra = sp[0]; rb = sp[1]; rc = sp[2];
+        }
+        if (!all_done) {
+            const int cnt = min(NT, n - b * NT);
+            for (int j = 0; j < cnt; j++) {
+                const float4 A = s_a[buf][j], B = s_b[buf][j], C = s_c[buf][j];
+                const float ca = A.z, cb = A.w, cc = B.x, op = B.y;
+                const float dx = A.x - pxf;
+                const f2 dy = A.y - pyf;
+                const float hx = ca * dx * dx, bx = cb * dx;
+                const f2 power = -0.5f * (cc * dy * dy + hx) - bx * dy;
+                f2 alpha = {op * fast_exp(power.x), op * fast_exp(power.y)};
+                alpha.x = fminf(kAlphaMax, alpha.x); alpha.y = fminf(kAlphaMax, alpha.y);
+                const bool v0 = !(power.x > 0.f || alpha.x < kAlphaMin) && !done0;
+                const bool v1 = !(power.y > 0.f || alpha.y < kAlphaMin) && !done1;
+                if (__any(v0 || v1)) {
+                    const f2 test = Tt * (1.f - alpha);
+                    const bool stop0 = v0 && test.x < kTStop, stop1 = v1 && test.y < kTStop;
+                    const bool b0 = v0 && !stop0, b1 = v1 && !stop1;   // blended
+                    done0 = done0 || stop0; done1 = done1 || stop1;
+                    alpha.x = b0 ? alpha.x : 0.f; alpha.y = b1 ? alpha.y : 0.f;
+                    const f2 w = alpha * Tt;
+                    C0 += B.w * w; C1 += C.x * w; C2 += C.y * w; Dd += B.z * w; Aa += w;
+                    Tt.x = b0 ? test.x : Tt.x; Tt.y = b1 ? test.y : Tt.y;
+                    const uint32_t idx = (uint32_t)(b * NT + j + 1);
+                    last0 = b0 ? idx : last0; last1 = b1 ? idx : last1;
+                }
+            }
+        }
+    }
+    if (tid == 0) staged[tile] = (uint32_t)min(n, batches * NT);
+    const size_t P = (size_t)W * H;
+    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+        const int py = py0 + p;
+        if (px < W && py < H) {
+            const size_t pid = (size_t)py * W + px;
+            const float t = Tt[p];
+            img[pid] = t;
+            reinterpret_cast<uint32_t*>(img)[P + pid] = p ? last1 : last0;
+            img[2 * P + pid] = C0[p]; img[3 * P + pid] = C1[p]; img[4 * P + pid] = C2[p];
+            img[5 * P + pid] = Dd[p]; img[6 * P + pid] = Aa[p];
+            out_color[pid] = C0[p] + t * bg0;
+            out_color[P + pid] = C1[p] + t * bg1;
+            out_color[2 * P + pid] = C2[p] + t * bg2;
+            out_depth[pid] = Dd[p];
+            out_alpha[pid] = Aa[p];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // K8: backward blend.  Same staging; front-to-back replay from the stored totals.  The per-(pixel,Gaussian)
 // contributions are summed over the thread's pixels, reduced across the wave with DPP, combined across
 // the tile's waves in LDS, and flushed with ONE set of 10 float atomics per (tile, Gaussian) by the
@@ -564,16 +698,167 @@ __global__ __launch_bounds__(256 / PPT) void k_blend_bwd(int W, int H, int tiles
 }
 
 // ------------------------------------------------------------------------------------------------
+// K8 (default): packed-math variant.  Each lane owns the two vertically adjacent pixels (x, y0) and (x, y0+1);
+// everything per pixel is a float2 so the arithmetic maps to v_pk_mul/add/fma_f32 (two pixels per VALU issue
+// slot).  HAS_DA = false drops the depth / alpha-output terms when those upstream gradients are absent (the
+// reference never puts loss on them: lambda_depth = 0, /root/reference/arguments/__init__.py:135).  Skip
+// decisions are branch-free per pixel (masked alpha and G); only the whole-wave skip is a branch.
+// ------------------------------------------------------------------------------------------------
+template <bool HAS_DA>
+__global__ __launch_bounds__(128) void k_blend_bwd2(int W, int H, int tiles_x, int T, const uint2* __restrict__ ranges,
+                                                    const uint32_t* __restrict__ list, const Splat* __restrict__ splat,
+                                                    const float* __restrict__ bg, const float* __restrict__ img,
+                                                    const float* __restrict__ g_color, const float* __restrict__ g_depth,
+                                                    const float* __restrict__ g_alpha, float* __restrict__ ggrad)
+{
+    constexpr int NT = 128, NW = 2, NV = HAS_DA ? 10 : 9;
+    __shared__ float4 s_a[2][NT], s_b[2][NT], s_c[2][NT];
+    __shared__ uint32_t s_gid[2][NT];
+    __shared__ float s_part[NW][NT][NV];
+    __shared__ uint32_t s_max[NW];
+    const int tile = xcd_tile(blockIdx.x, T);
+    if (tile >= T) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const int px = tx * kTile + (tid & 15);
+    const int py0 = ty * kTile + (tid >> 4) * 2;
+    const float pxf = (float)px;
+    const f2 pyf = {(float)py0, (float)(py0 + 1)};
+    const uint2 rg = ranges[tile];
+    const size_t P = (size_t)W * H;
+    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
+
+    f2 Tt = {1.f, 1.f}, sC0 = {0.f, 0.f}, sC1 = sC0, sC2 = sC0, sD = sC0, sA = sC0;
+    f2 gC0 = sC0, gC1 = sC0, gC2 = sC0, gD = sC0, gA = sC0, bgdot = sC0;
+    uint32_t ncon[2] = {0u, 0u};
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+        const int py = py0 + p;
+        if (px < W && py < H) {
+            const size_t pid = (size_t)py * W + px;
+            ncon[p] = reinterpret_cast<const uint32_t*>(img)[P + pid];
+            sC0[p] = img[2 * P + pid]; sC1[p] = img[3 * P + pid]; sC2[p] = img[4 * P + pid];
+            if (g_color) { gC0[p] = g_color[pid]; gC1[p] = g_color[P + pid]; gC2[p] = g_color[2 * P + pid]; }
+            if (HAS_DA) {
+                sD[p] = img[5 * P + pid]; sA[p] = img[6 * P + pid];
+                if (g_depth) gD[p] = g_depth[pid];
+                if (g_alpha) gA[p] = g_alpha[pid];
+            }
+            bgdot[p] = img[pid] * (bg0 * gC0[p] + bg1 * gC1[p] + bg2 * gC2[p]);
+        }
+    }
+    uint32_t nmax = max(ncon[0], ncon[1]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, off, 64));
+    if (lane == 0) s_max[wave] = nmax;
+    __syncthreads();
+    const int n = (int)max(s_max[0], s_max[1]);
+    const int nb = (n + NT - 1) / NT;
+
+    float4 ra = {0, 0, 0, 0}, rb = ra, rc = ra;
+    uint32_t rg_id = 0;
+    if (tid < n) {
+        rg_id = list[rg.x + tid];
+        const float4* sp = reinterpret_cast<const float4*>(splat + rg_id);
+        ra = sp[0]; rb = sp[1]; rc = sp[2];
+    }
+    for (int b = 0; b < nb; b++) {
+        const int buf = b & 1;
+        s_a[buf][tid] = ra; s_b[buf][tid] = rb; s_c[buf][tid] = rc; s_gid[buf][tid] = rg_id;
+#pragma unroll
+        for (int w = 0; w < NW; w++)
+#pragma unroll
+            for (int k = 0; k < NV; k++) s_part[w][tid][k] = 0.f;
+        __syncthreads();
+        const int nxt = (b + 1) * NT + tid;
+        if (nxt < n) {
+            rg_id = list[rg.x + nxt];
+            const float4* sp = reinterpret_cast<const float4*>(splat + rg_id);
+            ra = sp[0]; rb = sp[1]; rc = sp[2];
+        }
+        const int cnt = min(NT, n - b * NT);
+        for (int j = 0; j < cnt; j++) {
+            const float4 A = s_a[buf][j], B = s_b[buf][j], C = s_c[buf][j];   // (manual LDS prefetch measured slower)
+            const uint32_t idx = (uint32_t)(b * NT + j + 1);
+            const float ca = A.z, cb = A.w, cc = B.x, op = B.y, zd = B.z, cr = B.w, cg = C.x, cbl = C.y;
+            const float dx = A.x - pxf;
+            const f2 dy = A.y - pyf;
+            const float hx = ca * dx * dx, bx = cb * dx;
+            const f2 power = -0.5f * (cc * dy * dy + hx) - bx * dy;
+            f2 G = {fast_exp(power.x), fast_exp(power.y)};
+            f2 alpha = op * G;
+            alpha.x = fminf(kAlphaMax, alpha.x); alpha.y = fminf(kAlphaMax, alpha.y);
+            const bool v0 = !(power.x > 0.f || alpha.x < kAlphaMin) && idx <= ncon[0];
+            const bool v1 = !(power.y > 0.f || alpha.y < kAlphaMin) && idx <= ncon[1];
+            if (__any(v0 || v1)) {   // wave-uniform
+                alpha.x = v0 ? alpha.x : 0.f; alpha.y = v1 ? alpha.y : 0.f;
+                G.x = v0 ? G.x : 0.f; G.y = v1 ? G.y : 0.f;
+                const f2 w = alpha * Tt;
+                sC0 -= cr * w; sC1 -= cg * w; sC2 -= cbl * w;
+                const f2 om = 1.f - alpha;
+                const f2 inv = {fast_rcp(om.x), fast_rcp(om.y)};
+                f2 dLda = gC0 * (cr * Tt - sC0 * inv) + gC1 * (cg * Tt - sC1 * inv) + gC2 * (cbl * Tt - sC2 * inv);
+                if (HAS_DA) {
+                    sD -= zd * w; sA -= w;
+                    dLda += gD * (zd * Tt - sD * inv) + gA * (Tt - sA * inv);
+                }
+                dLda -= bgdot * inv;
+                const f2 dLdpow = G * (op * dLda);
+                const f2 ex = -(ca * dx) - cb * dy;     // d power / d dx
+                const f2 ey = -(cc * dy) - bx;           // d power / d dy
+                const f2 t_gx = dLdpow * ex, t_gy = dLdpow * ey;
+                const f2 t_gB = dLdpow * dy;
+                const f2 t_gC = t_gB * dy;
+                const f2 t_op = G * dLda;
+                const f2 t_r = w * gC0, t_g = w * gC1, t_b = w * gC2;
+                float v[10];
+                v[0] = t_gx.x + t_gx.y; v[1] = t_gy.x + t_gy.y;
+                const float sdl = dLdpow.x + dLdpow.y;
+                v[2] = -0.5f * dx * dx * sdl;                    // gA
+                v[3] = -dx * (t_gB.x + t_gB.y);                  // gB
+                v[4] = -0.5f * (t_gC.x + t_gC.y);                // gC
+                v[5] = t_op.x + t_op.y;
+                v[6] = t_r.x + t_r.y; v[7] = t_g.x + t_g.y; v[8] = t_b.x + t_b.y;
+                if (HAS_DA) { const f2 t_z = w * gD; v[9] = t_z.x + t_z.y; }
+                Tt *= om;
+                // (measured: replacing the last two DPP steps by ds_add_f32 from the 4 row leaders is 1.7x SLOWER --
+                //  LDS float atomics serialise; keep the whole reduction in VALU/DPP)
+#pragma unroll
+                for (int k = 0; k < NV; k++) v[k] = wave_sum_to_lane63(v[k]);
+                if (lane == 63) {
+#pragma unroll
+                    for (int k = 0; k < NV; k++) s_part[wave][j][k] = v[k];
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < cnt) {
+            float v[NV];
+            bool nz = false;
+#pragma unroll
+            for (int k = 0; k < NV; k++) { v[k] = s_part[0][tid][k] + s_part[1][tid][k]; nz = nz || (v[k] != 0.f); }
+            if (nz) {
+                float* dst = ggrad + (size_t)s_gid[buf][tid] * kGG;
+#pragma unroll
+                for (int k = 0; k < NV; k++) atomicAdd(dst + k, v[k]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // K9: per-Gaussian backward.  SH rows in, dSH rows out through the same LDS tile (coalesced both ways).
 // ------------------------------------------------------------------------------------------------
-template <int DEG>
+template <int DEG, bool RAW>
 __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, int N, const float* __restrict__ means,
                                                                 const float* __restrict__ scales, const float* __restrict__ rots,
                                                                 const float* __restrict__ cov_pre, const float* __restrict__ shs,
+                                                                const float* __restrict__ shs_rest,
                                                                 const Splat* __restrict__ splat, const float* __restrict__ ggrad,
                                                                 float* __restrict__ d_means, float* __restrict__ d_means2d,
                                                                 float* __restrict__ d_opac, float* __restrict__ d_colors,
-                                                                float* __restrict__ d_shs, float* __restrict__ d_scales,
+                                                                float* __restrict__ d_shs, float* __restrict__ d_shs_rest,
+                                                                float* __restrict__ d_scales,
                                                                 float* __restrict__ d_rots, float* __restrict__ d_cov)
 {
     constexpr int NC3 = 3 * (DEG + 1) * (DEG + 1);
@@ -583,10 +868,22 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, in
     const int i = base + tid;
     const int nG = min(kPreThreads, N - base);
     if (shs) {
-        const size_t row = (size_t)cp.M * 3;
-        for (int f = tid; f < nG * NC3; f += kPreThreads) {
-            const int g = f / NC3, e = f - g * NC3;
-            s_sh[g * kShStride + e] = shs[(size_t)(base + g) * row + e];
+        if (shs_rest) {
+            const size_t row = (size_t)(cp.M - 1) * 3;
+            for (int f = tid; f < nG * 3; f += kPreThreads) s_sh[(f / 3) * kShStride + (f % 3)] = shs[(size_t)base * 3 + f];
+            if (NC3 > 3) {
+                constexpr int NR = NC3 > 3 ? NC3 - 3 : 1;
+                for (int f = tid; f < nG * NR; f += kPreThreads) {
+                    const int g = f / NR, e = f - g * NR;
+                    s_sh[g * kShStride + 3 + e] = shs_rest[(size_t)(base + g) * row + e];
+                }
+            }
+        } else {
+            const size_t row = (size_t)cp.M * 3;
+            for (int f = tid; f < nG * NC3; f += kPreThreads) {
+                const int g = f / NC3, e = f - g * NC3;
+                s_sh[g * kShStride + e] = shs[(size_t)(base + g) * row + e];
+            }
         }
         __syncthreads();
     }
@@ -611,12 +908,29 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, in
 #pragma unroll
                 for (int k = 0; k < 4; k++) rq[k] = rots[4 * (size_t)i + k];
             }
+            float rinv = 1.f;
+            if (RAW && !cov_pre) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) sc[k] = expf(sc[k]);
+                rinv = 1.0f / fmaxf(sqrtf(rq[0] * rq[0] + rq[1] * rq[1] + rq[2] * rq[2] + rq[3] * rq[3]), 1e-12f);
+#pragma unroll
+                for (int k = 0; k < 4; k++) rq[k] *= rinv;
+            }
             GaussGrads o;
             gauss_backward(cam, mean, sc, rq, cov_pre ? cv : nullptr, g0.x, g0.y, g0.z, g0.w, g1.x, g2.y, o);
             dmean[0] = o.mean[0]; dmean[1] = o.mean[1]; dmean[2] = o.mean[2];
             m2d[0] = o.mean2d[0]; m2d[1] = o.mean2d[1];
             dop = g1.y;
             grgb[0] = g1.z; grgb[1] = g1.w; grgb[2] = g2.x;
+            if (RAW) {   // chain through exp / normalize / sigmoid
+                const float sg = s.op;   // the activated opacity stored by the forward
+                dop *= sg * (1.f - sg);
+#pragma unroll
+                for (int k = 0; k < 3; k++) o.scale[k] *= sc[k];
+                const float dot = rq[0] * o.rot[0] + rq[1] * o.rot[1] + rq[2] * o.rot[2] + rq[3] * o.rot[3];
+#pragma unroll
+                for (int k = 0; k < 4; k++) o.rot[k] = (o.rot[k] - rq[k] * dot) * rinv;
+            }
 #pragma unroll
             for (int k = 0; k < 3; k++) dsc[k] = o.scale[k];
 #pragma unroll
@@ -651,9 +965,27 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, in
     if (shs && d_shs) {
         __syncthreads();
         const int row = cp.M * 3;
-        for (int f = tid; f < nG * row; f += kPreThreads) {
-            const int g = f / row, e = f - g * row;
-            d_shs[(size_t)(base + g) * row + e] = e < NC3 ? s_sh[g * kShStride + e] : 0.f;
+        // rows are contiguous in memory, so when the active degree uses every stored coefficient the store is one
+        // straight stream with compile-time index arithmetic; the general case pays a run-time division
+        if (d_shs_rest) {
+            const int rrow = row - 3;
+            for (int f = tid; f < nG * 3; f += kPreThreads) d_shs[(size_t)base * 3 + f] = s_sh[(f / 3) * kShStride + (f % 3)];
+            if (rrow == NC3 - 3) {
+                constexpr int NR = NC3 > 3 ? NC3 - 3 : 1;
+                for (int f = tid; f < nG * NR; f += kPreThreads) d_shs_rest[(size_t)base * NR + f] = s_sh[(f / NR) * kShStride + 3 + (f % NR)];
+            } else {
+                for (int f = tid; f < nG * rrow; f += kPreThreads) {
+                    const int g = f / rrow, e = f - g * rrow + 3;
+                    d_shs_rest[(size_t)(base + g) * rrow + (e - 3)] = e < NC3 ? s_sh[g * kShStride + e] : 0.f;
+                }
+            }
+        } else if (row == NC3) {
+            for (int f = tid; f < nG * NC3; f += kPreThreads) d_shs[(size_t)base * NC3 + f] = s_sh[(f / NC3) * kShStride + (f % NC3)];
+        } else {
+            for (int f = tid; f < nG * row; f += kPreThreads) {
+                const int g = f / row, e = f - g * row;
+                d_shs[(size_t)(base + g) * row + e] = e < NC3 ? s_sh[g * kShStride + e] : 0.f;
+            }
         }
     }
 }
@@ -796,9 +1128,10 @@ int gsr_version(void) { return 100; }
 int gsr_set_option(const char* name, int value)
 {
     if (!name) return GSR_ERR_ARG;
-    if (!strcmp(name, "blend_fwd_ppt")) { if (value != 0 && value != 1 && value != 2 && value != 4) return GSR_ERR_ARG; g_blend_ppt = value; return GSR_OK; }
+    if (!strcmp(name, "blend_fwd_ppt")) { if (value < 0 || value > 4) return GSR_ERR_ARG; g_blend_ppt = value; return GSR_OK; }
     if (!strcmp(name, "profile")) { g_profile = value ? 1 : 0; return GSR_OK; }
-    if (!strcmp(name, "blend_bwd_ppt")) { if (value != 0 && value != 1 && value != 2 && value != 4) return GSR_ERR_ARG; g_bwd_ppt = value; return GSR_OK; }
+    // 2 = packed-math kernel (default), 3 = scalar 2-pixel kernel (kept for A/B), 1 / 4 = scalar 1 / 4 pixels
+    if (!strcmp(name, "blend_bwd_ppt")) { if (value < 0 || value > 4) return GSR_ERR_ARG; g_bwd_ppt = value; return GSR_OK; }
     return GSR_ERR_ARG;
 }
 
@@ -835,9 +1168,10 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
         unsigned long long* total = reinterpret_cast<unsigned long long*>(fs + L.total);
         CamParams cp = {a->viewmatrix, a->projmatrix, a->campos, a->tanfovx, a->tanfovy, a->scale_modifier, W, H, a->D, a->M};
         const int grid = (N + kPreThreads - 1) / kPreThreads;
-#define GSR_PRE(DEG)                                                                                                         \
-    hipLaunchKernelGGL(k_preprocess<DEG>, dim3(grid), dim3(kPreThreads), 0, st, cp, N, a->means3D, a->scales, a->rotations, \
-                       a->cov3D_precomp, a->opacities, a->shs, a->colors_precomp, splat, a->radii, dkey, gid)
+#define GSR_PRE_(DEG, RAW)                                                                                                          \
+    hipLaunchKernelGGL((k_preprocess<DEG, RAW>), dim3(grid), dim3(kPreThreads), 0, st, cp, N, a->means3D, a->scales, a->rotations, \
+                       a->cov3D_precomp, a->opacities, a->shs, a->shs_rest, a->colors_precomp, splat, a->radii, dkey, gid)
+#define GSR_PRE(DEG) do { if (a->raw_params) GSR_PRE_(DEG, true); else GSR_PRE_(DEG, false); } while (0)
         {
             ProfScope ps(P_PRE_FWD, st);
             switch (a->shs ? a->D : 0) {
@@ -848,6 +1182,7 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
             }
         }
 #undef GSR_PRE
+#undef GSR_PRE_
         int in_alt = 0;
         {
             ProfScope ps(P_SORT_DEPTH, st);
@@ -912,7 +1247,10 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
     {
         ProfScope ps(P_BLEND_FWD, st);
         if (ppt == 1) launch_blend_fwd<1>(W, H, tiles_x, T, ranges, list, splat, a->bg, a->out_color, a->out_depth, a->out_alpha, img, staged, st);
-        else if (ppt == 2) launch_blend_fwd<2>(W, H, tiles_x, T, ranges, list, splat, a->bg, a->out_color, a->out_depth, a->out_alpha, img, staged, st);
+        else if (ppt == 2)
+            hipLaunchKernelGGL(k_blend_fwd2, dim3(8 * ((T + 7) / 8)), dim3(128), 0, st, W, H, tiles_x, T, ranges, list, splat, a->bg,
+                               a->out_color, a->out_depth, a->out_alpha, img, staged);
+        else if (ppt == 3) launch_blend_fwd<2>(W, H, tiles_x, T, ranges, list, splat, a->bg, a->out_color, a->out_depth, a->out_alpha, img, staged, st);
         else launch_blend_fwd<4>(W, H, tiles_x, T, ranges, list, splat, a->bg, a->out_color, a->out_depth, a->out_alpha, img, staged, st);
     }
     GSR_HIP(hipGetLastError());
@@ -945,15 +1283,24 @@ int gsr_backward(const GsrBackwardArgs* a, void* stream_)
         const float* img = static_cast<const float*>(a->image);
         ProfScope ps(P_BLEND_BWD, st);
         if (ppt == 1) launch_blend_bwd<1>(W, H, tiles_x, T, ranges, list, splat, a->bg, img, a->grad_color, a->grad_depth, a->grad_alpha, gg, st);
-        else if (ppt == 2) launch_blend_bwd<2>(W, H, tiles_x, T, ranges, list, splat, a->bg, img, a->grad_color, a->grad_depth, a->grad_alpha, gg, st);
+        else if (ppt == 2) {
+            const int grid = 8 * ((T + 7) / 8);
+            if (a->grad_depth || a->grad_alpha)
+                hipLaunchKernelGGL(k_blend_bwd2<true>, dim3(grid), dim3(128), 0, st, W, H, tiles_x, T, ranges, list, splat, a->bg, img,
+                                   a->grad_color, a->grad_depth, a->grad_alpha, gg);
+            else
+                hipLaunchKernelGGL(k_blend_bwd2<false>, dim3(grid), dim3(128), 0, st, W, H, tiles_x, T, ranges, list, splat, a->bg, img,
+                                   a->grad_color, a->grad_depth, a->grad_alpha, gg);
+        } else if (ppt == 3) launch_blend_bwd<2>(W, H, tiles_x, T, ranges, list, splat, a->bg, img, a->grad_color, a->grad_depth, a->grad_alpha, gg, st);
         else launch_blend_bwd<4>(W, H, tiles_x, T, ranges, list, splat, a->bg, img, a->grad_color, a->grad_depth, a->grad_alpha, gg, st);
     }
     CamParams cp = {a->viewmatrix, a->projmatrix, a->campos, a->tanfovx, a->tanfovy, a->scale_modifier, W, H, a->D, a->M};
     const int grid = (N + kPreThreads - 1) / kPreThreads;
-#define GSR_PREB(DEG)                                                                                                            \
-    hipLaunchKernelGGL(k_preprocess_bwd<DEG>, dim3(grid), dim3(kPreThreads), 0, st, cp, N, a->means3D, a->scales, a->rotations, \
-                       a->cov3D_precomp, a->shs, splat, gg, a->d_means3D, a->d_means2D, a->d_opacities, a->d_colors_precomp,    \
-                       a->d_shs, a->d_scales, a->d_rotations, a->d_cov3D_precomp)
+#define GSR_PREB_(DEG, RAW)                                                                                                             \
+    hipLaunchKernelGGL((k_preprocess_bwd<DEG, RAW>), dim3(grid), dim3(kPreThreads), 0, st, cp, N, a->means3D, a->scales, a->rotations, \
+                       a->cov3D_precomp, a->shs, a->shs_rest, splat, gg, a->d_means3D, a->d_means2D, a->d_opacities,                  \
+                       a->d_colors_precomp, a->d_shs, a->d_shs_rest, a->d_scales, a->d_rotations, a->d_cov3D_precomp)
+#define GSR_PREB(DEG) do { if (a->raw_params) GSR_PREB_(DEG, true); else GSR_PREB_(DEG, false); } while (0)
     {
         ProfScope ps(P_PRE_BWD, st);
         switch (a->shs ? a->D : 0) {
@@ -964,6 +1311,7 @@ int gsr_backward(const GsrBackwardArgs* a, void* stream_)
         }
     }
 #undef GSR_PREB
+#undef GSR_PREB_
     GSR_HIP(hipGetLastError());
     return GSR_OK;
 }

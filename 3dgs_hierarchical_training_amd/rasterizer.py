@@ -91,7 +91,8 @@ class _Workspace:
 
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
+                sh_rest=None, raw_params=False):
         lib = L.load()
         rs = raster_settings
         dev = means3D.device
@@ -106,7 +107,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         vm, pm = _f32c(rs.viewmatrix.to(dev)), _f32c(rs.projmatrix.to(dev))
         campos, bg = _f32c(rs.campos.to(dev)), _f32c(rs.bg.to(dev))
         H, W = int(rs.image_height), int(rs.image_width)
-        M = int(sh.shape[1]) if sh is not None else 0
+        sh_rest = _f32c(_empty_to_none(sh_rest))
+        M = (int(sh.shape[1]) + (int(sh_rest.shape[1]) if sh_rest is not None else 0)) if sh is not None else 0
 
         color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
         depth = torch.empty((1, H, W), dtype=torch.float32, device=dev)
@@ -126,6 +128,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         a.out_color, a.out_depth, a.out_alpha, a.radii = color.data_ptr(), depth.data_ptr(), alpha.data_ptr(), _ptr(radii)
         a.geom, a.image = geom.data_ptr(), image.data_ptr()
         a.alloc, a.alloc_user = ws.cb, None
+        a.shs_rest, a.raw_params = _ptr(sh_rest), int(bool(raw_params))
         out = L.GsrForwardOut()
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
@@ -137,13 +140,15 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.num_rendered = int(out.num_rendered)
         ctx.dims = (N, M, H, W)
         ctx.has = (sh is not None, colors_precomp is not None, scales is not None, cov3Ds_precomp is not None)
+        ctx.raw = (sh_rest is not None, bool(raw_params))
         z = means3D.new_empty(0)
         # NOTE: depth is deliberately NOT saved -- the caller mutates it in place (ht3dgs_trainer.py:1290-1292).
         ctx.save_for_backward(means3D, opacities, sh if sh is not None else z, colors_precomp if colors_precomp is not None else z,
                               scales if scales is not None else z, rotations if rotations is not None else z,
                               cov3Ds_precomp if cov3Ds_precomp is not None else z, vm, pm, campos, bg, geom, image,
-                              ws.binning)
+                              ws.binning, sh_rest if sh_rest is not None else z)
         ctx.mark_non_differentiable(radii)
+        ctx.set_materialize_grads(False)   # unused depth / alpha outputs arrive as None -> specialised backward
         return color, radii, depth, alpha
 
     @staticmethod
@@ -151,16 +156,20 @@ class _RasterizeGaussians(torch.autograd.Function):
         lib = L.load()
         rs = ctx.raster_settings
         (means3D, opacities, sh, colors_precomp, scales, rotations, cov3Ds_precomp, vm, pm, campos, bg, geom, image,
-         binning) = ctx.saved_tensors
+         binning, sh_rest) = ctx.saved_tensors
+        has_rest, raw_params = ctx.raw
         N, M, H, W = ctx.dims
         has_sh, has_col, has_scale, has_cov = ctx.has
         dev = means3D.device
         grad_color, grad_depth, grad_alpha = _f32c(grad_color), _f32c(grad_depth), _f32c(grad_alpha)
+        if grad_color is None and grad_depth is None and grad_alpha is None:
+            return (None,) * 11
 
         d_means3D = torch.empty((N, 3), dtype=torch.float32, device=dev)
         d_means2D = torch.empty((N, 3), dtype=torch.float32, device=dev)
         d_opac = torch.empty((N, 1), dtype=torch.float32, device=dev)
-        d_sh = torch.empty((N, M, 3), dtype=torch.float32, device=dev) if has_sh else None
+        d_sh = torch.empty((N, 1 if has_rest else M, 3), dtype=torch.float32, device=dev) if has_sh else None
+        d_sh_rest = torch.empty((N, M - 1, 3), dtype=torch.float32, device=dev) if (has_sh and has_rest) else None
         d_col = torch.empty((N, 3), dtype=torch.float32, device=dev) if has_col else None
         d_scales = torch.empty((N, 3), dtype=torch.float32, device=dev) if has_scale else None
         d_rot = torch.empty((N, 4), dtype=torch.float32, device=dev) if has_scale else None
@@ -182,15 +191,27 @@ class _RasterizeGaussians(torch.autograd.Function):
         a.d_colors_precomp, a.d_shs = _ptr(d_col), _ptr(d_sh)
         a.d_scales, a.d_rotations, a.d_cov3D_precomp = _ptr(d_scales), _ptr(d_rot), _ptr(d_cov)
         a.scratch = scratch.data_ptr()
+        a.shs_rest = _ptr(sh_rest) if has_rest else None
+        a.d_shs_rest, a.raw_params = _ptr(d_sh_rest), int(raw_params)
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
             L.check(lib.gsr_backward(C.byref(a), C.c_void_p(stream)), "gsr_backward")
-        return d_means3D, d_means2D, d_sh, d_col, d_opac, d_scales, d_rot, d_cov, None
+        return d_means3D, d_means2D, d_sh, d_col, d_opac, d_scales, d_rot, d_cov, None, d_sh_rest, None
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                                      raster_settings)
+
+
+def rasterize_gaussians_raw(means3D, means2D, features_dc, features_rest, opacity_logit, log_scales, rotations_raw,
+                            raster_settings):
+    """Extension ("next" row f-2): rasterize straight from HTGaussianModel's raw parameters (_xyz, _features_dc,
+    _features_rest, _opacity, _scaling, _rotation; /root/reference/scene/gaussian_model_ht.py:74-82) with the
+    activations of :49-65,128-133,176-188 fused into the HIP kernels; gradients are w.r.t. the raw tensors."""
+    e = torch.Tensor([])
+    return _RasterizeGaussians.apply(means3D, means2D, features_dc, e, opacity_logit, log_scales, rotations_raw, e,
+                                     raster_settings, features_rest, True)
 
 
 class GaussianRasterizer(nn.Module):

@@ -16,7 +16,8 @@ import torch
 import torch.nn.functional as F
 
 from .loss import fused_photometric_loss
-from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+from .optim import FusedAdam
+from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer, rasterize_gaussians_raw
 
 
 def inverse_sigmoid(x):
@@ -62,7 +63,7 @@ def photometric_loss(pred: torch.Tensor, gt: torch.Tensor, lambda_dssim: float =
 class GaussianParams:
     """Raw (pre-activation) parameters, laid out as HTGaussianModel keeps them."""
 
-    def __init__(self, scene: Dict, device, spatial_lr_scale: float = 1.0):
+    def __init__(self, scene: Dict, device, spatial_lr_scale: float = 1.0, optimizer: str = "hip"):
         d = device
         self.max_sh_degree = int(round(math.sqrt(scene["shs"].shape[1]))) - 1
         self.active_sh_degree = int(scene["sh_degree"])
@@ -82,7 +83,12 @@ class GaussianParams:
         ]
         # same update rule as the reference's torch.optim.Adam(l, lr=0.0, eps=1e-15); `fused` only selects the
         # single-pass implementation (one kernel per group instead of the foreach chain)
-        self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15, fused=self._xyz.is_cuda)
+        if optimizer == "hip":        # gsr_adam_step: all six groups in one HIP launch
+            self.optimizer = FusedAdam(groups, lr=0.0, eps=1e-15)
+        elif optimizer == "torch_fused":
+            self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15, fused=self._xyz.is_cuda)
+        else:                         # the reference's own construction (foreach implementation)
+            self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
 
     @property
     def num_points(self):
@@ -118,28 +124,35 @@ def make_settings(scene: Dict, device, sh_degree: int, bg=None) -> GaussianRaste
         sh_degree=sh_degree, campos=scene["campos"].to(device), prefiltered=False, debug=False)
 
 
-def render(params: GaussianParams, settings: GaussianRasterizationSettings, clamp: bool = True) -> Dict:
-    """CF3DGS_Render.render with compute_cov3D_python = convert_SHs_python = False."""
+def render(params: GaussianParams, settings: GaussianRasterizationSettings, clamp: bool = True,
+           fused_activations: bool = False) -> Dict:
+    """CF3DGS_Render.render with compute_cov3D_python = convert_SHs_python = False.
+    fused_activations=True hands the raw parameters to the kernels (exp / sigmoid / normalize / cat in-kernel)."""
     xyz = params.get_xyz
     screenspace_points = torch.zeros_like(xyz, requires_grad=True) + 0
     try:
         screenspace_points.retain_grad()
     except Exception:
         pass
-    rasterizer = GaussianRasterizer(raster_settings=settings)
-    out = rasterizer(means3D=xyz, means2D=screenspace_points, shs=params.get_features, colors_precomp=None,
-                     opacities=params.get_opacity, scales=params.get_scaling, rotations=params.get_rotation,
-                     cov3D_precomp=None)
+    if fused_activations:
+        out = rasterize_gaussians_raw(xyz, screenspace_points, params._features_dc, params._features_rest, params._opacity,
+                                      params._scaling, params._rotation, settings)
+    else:
+        rasterizer = GaussianRasterizer(raster_settings=settings)
+        out = rasterizer(means3D=xyz, means2D=screenspace_points, shs=params.get_features, colors_precomp=None,
+                         opacities=params.get_opacity, scales=params.get_scaling, rotations=params.get_rotation,
+                         cov3D_precomp=None)
     rendered_image, radii, rendered_depth, rendered_alpha = out
     return {"image": rendered_image.clamp(0, 1) if clamp else None, "raw_image": rendered_image, "depth": rendered_depth,
             "alpha": rendered_alpha, "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii}
 
 
 def train_step(params: GaussianParams, settings: GaussianRasterizationSettings, gt: torch.Tensor,
-               lambda_dssim: float = 0.2, fused_loss: bool = True) -> Dict:
+               lambda_dssim: float = 0.2, fused_loss: bool = True, fused_activations: bool = True) -> Dict:
     """render -> loss -> backward -> Adam step (ht3dgs_trainer.py:102-166 without densification).
-    fused_loss=True evaluates clamp + L1 + SSIM in the HIP loss kernels; False uses the torch restatement."""
-    pkg = render(params, settings, clamp=not fused_loss)
+    fused_loss=True evaluates clamp + L1 + SSIM in the HIP loss kernels; False uses the torch restatement.
+    fused_activations=True runs exp / sigmoid / normalize / cat inside the rasterizer kernels."""
+    pkg = render(params, settings, clamp=not fused_loss, fused_activations=fused_activations)
     if fused_loss:
         loss = fused_photometric_loss(pkg["raw_image"], gt, lambda_dssim, clamp=True)
     else:

@@ -69,6 +69,11 @@ typedef struct GsrForwardArgs {
     void* image;                 /* gsr_image_bytes(W,H) bytes, kept until backward */
     gsr_alloc_fn alloc;          /* called for the R-sized buffers once R is known */
     void* alloc_user;
+    /* ---- extension, "next" row f-2 (fused activations; zero/NULL = the reference's calling convention) ---- */
+    const float* shs_rest;       /* if non-NULL: shs is _features_dc [N,1,3] and shs_rest is _features_rest [N,M-1,3]
+                                    (gaussian_model_ht.py:176-179 concatenates them every call) */
+    int32_t raw_params;          /* 1: scales = log-scales, rotations un-normalised, opacities = logits; the
+                                    activations of gaussian_model_ht.py:49-65,128-133,187-188 run in-kernel */
 } GsrForwardArgs;
 
 typedef struct GsrForwardOut {
@@ -98,6 +103,10 @@ typedef struct GsrBackwardArgs {
     float* d_rotations;      /* [N,4] or NULL */
     float* d_cov3D_precomp;  /* [N,6] or NULL */
     void* scratch;           /* gsr_backward_scratch_bytes(N) bytes */
+    /* ---- extension f-2: same meaning as in GsrForwardArgs; gradients are returned w.r.t. the raw parameters ---- */
+    const float* shs_rest;
+    float* d_shs_rest;       /* [N,M-1,3] when shs_rest is given (then d_shs is [N,1,3]) */
+    int32_t raw_params;
 } GsrBackwardArgs;
 
 size_t gsr_geom_bytes(int32_t N);
@@ -137,6 +146,21 @@ int gsr_loss_forward(const float* render, const float* target, int32_t C, int32_
 int gsr_loss_backward(const float* render, const float* target, int32_t C, int32_t H, int32_t W, float lambda_dssim,
                       int32_t clamp01_render, const void* workspace, const float* grad_loss, float* d_render,
                       void* stream);
+
+/* ---- "next" row f-2: multi-tensor Adam step in one launch ------------------------------------------------
+ * Same update rule as torch.optim.Adam(l, lr=0.0, eps=1e-15) of /root/reference/scene/gaussian_model_ht.py:275-289
+ * (no amsgrad, no weight decay); `step` is the 1-based step count used for the bias corrections. */
+#define GSR_ADAM_MAX_TENSORS 8
+typedef struct GsrAdamTensor {
+    float* param;
+    const float* grad;
+    float* exp_avg;
+    float* exp_avg_sq;
+    uint64_t n;  /* elements */
+    float lr;
+} GsrAdamTensor;
+int gsr_adam_step(const GsrAdamTensor* tensors, int32_t count, float beta1, float beta2, float eps, int64_t step,
+                  void* stream);
 
 /* Building blocks exported for the unit tests of tests/test_gpu_blocks.py (device pointers). */
 int gsr_sort_pairs_u32(uint32_t* keys, uint32_t* vals, uint32_t* keys_alt, uint32_t* vals_alt, uint32_t n,

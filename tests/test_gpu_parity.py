@@ -24,7 +24,7 @@ CASES = [
 ]
 
 
-def _run_case(N, W, H, deg, posed, mode, bg, ppt=None, noncontig=False):
+def _run_case(N, W, H, deg, posed, mode, bg, ppt=None, noncontig=False, color_only=False):
     import hip_runner
     sc = parity.syn.make_scene(N, W, H, sh_degree=deg, seed=N % 97, posed=posed)
     kw = parity.scene_kwargs(sc, mode, bg=bg)
@@ -33,6 +33,8 @@ def _run_case(N, W, H, deg, posed, mode, bg, ppt=None, noncontig=False):
     gc, gd, ga = parity.upstream_grads(H, W, seed=3)
     keep = o.px_ambig == 0
     gc *= keep[None]; gd *= keep; ga *= keep
+    if color_only:   # loss on the image only: depth / alpha grads are None at the boundary (the reference's case)
+        gd = ga = None
     ref = o.backward(gc, gd, ga)
     out = hip_runner.run_hip(kw, (gc, gd, ga), noncontig=noncontig)
     rep = parity.check_forward(out["fwd"], o, f"hip fwd {N}/{W}x{H}/deg{deg}/{mode}")
@@ -46,7 +48,12 @@ def test_parity_vs_oracle(case):
     _run_case(*case)
 
 
-@pytest.mark.parametrize("ppt", [1, 2, 4])
+@pytest.mark.parametrize("case", [CASES[1], CASES[3], CASES[5]], ids=lambda c: f"{c[0]}-{c[1]}x{c[2]}-d{c[3]}-{c[5]}")
+def test_parity_color_loss_only(case):
+    _run_case(*case, color_only=True)
+
+
+@pytest.mark.parametrize("ppt", [1, 2, 3, 4])
 def test_blend_variants_agree(ppt):
     import importlib
     L = importlib.import_module("3dgs_hierarchical_training_amd._lib")
