@@ -108,6 +108,42 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v)
     return v;
 }
 
+// ---- transposed ("butterfly") wave reduction of NV values --------------------------------------------------
+// Reducing NV values one by one costs 6 DPP adds each.  Instead, at every halving step two VALUES are paired:
+// half of the lanes keep value a and receive the partner lane's a, the other half keep b and receive b, so one
+// DPP add retires half a step of TWO values.  After four steps a single register holds, per lane, the 16-lane
+// row sum of the value its low lane bits select; two cross-row shuffles finish it.  9 values: 27 VALU + 2
+// shuffles instead of 54 DPP adds, and the result is written by 9 lanes in ONE LDS store.
+//   quad_perm [1,0,3,2] = 0xB1 (lane^1), [2,3,0,1] = 0x4E (lane^2), row_ror:4 = 0x124, row_ror:8 = 0x128
+template <int CTRL>
+__device__ __forceinline__ float bfly_pair(float a, float b, bool hi)
+{
+    const float keep = hi ? b : a, send = hi ? a : b;
+    return keep + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ float bfly_single(float a)
+{
+    return a + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), CTRL, 0xf, 0xf, false));
+}
+// returns t with: lanes (l&15) in 0..7 -> total of v[l&7]; lanes 8..15 -> total of v[8] (NV = 9) or v[8 + (l&1)] (NV = 10)
+template <int NV>
+__device__ __forceinline__ float wave_reduce_transposed(const float* v, int lane)
+{
+    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
+    const float r01 = bfly_pair<0xB1>(v[0], v[1], b0), r23 = bfly_pair<0xB1>(v[2], v[3], b0);
+    const float r45 = bfly_pair<0xB1>(v[4], v[5], b0), r67 = bfly_pair<0xB1>(v[6], v[7], b0);
+    const float r8 = (NV == 10) ? bfly_pair<0xB1>(v[8], v[NV - 1], b0) : bfly_single<0xB1>(v[8]);
+    const float q03 = bfly_pair<0x4E>(r01, r23, b1), q47 = bfly_pair<0x4E>(r45, r67, b1);
+    const float q8 = bfly_single<0x4E>(r8);
+    const float o07 = bfly_pair<0x124>(q03, q47, b2);
+    const float o8 = bfly_single<0x124>(q8);
+    float t = bfly_pair<0x128>(o07, o8, b3);
+    t += __shfl_xor(t, 16, 64);
+    t += __shfl_xor(t, 32, 64);
+    return t;
+}
+
 // sum over each 16-lane DPP row: total lands in lanes 15, 31, 47, 63
 __device__ __forceinline__ float row_sum_to_lane15(float v)
 {
@@ -821,14 +857,11 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(int W, int H, int tiles_x, i
                 v[6] = t_r.x + t_r.y; v[7] = t_g.x + t_g.y; v[8] = t_b.x + t_b.y;
                 if (HAS_DA) { const f2 t_z = w * gD; v[9] = t_z.x + t_z.y; }
                 Tt *= om;
-                // (measured: replacing the last two DPP steps by ds_add_f32 from the 4 row leaders is 1.7x SLOWER --
-                //  LDS float atomics serialise; keep the whole reduction in VALU/DPP)
-#pragma unroll
-                for (int k = 0; k < NV; k++) v[k] = wave_sum_to_lane63(v[k]);
-                if (lane == 63) {
-#pragma unroll
-                    for (int k = 0; k < NV; k++) s_part[wave][j][k] = v[k];
-                }
+                // (measured: finishing the reduction with ds_add_f32 from the row leaders is 1.7x SLOWER -- LDS float
+                //  atomics serialise; the transposed DPP reduction below halves the VALU cost instead)
+                const float t = wave_reduce_transposed<NV>(v, lane);
+                if (lane < 8) s_part[wave][j][lane] = t;
+                else if (lane < NV) s_part[wave][j][lane] = t;
             }
         }
         __syncthreads();
