@@ -338,7 +338,7 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit(int N, int W, int H, int 
         const Splat s = splat[g];
         if (s.tiles) {
             int x1, y1;
-            tile_rect(s.px, s.py, s.radius, tiles_x, tiles_y, x0, y0, x1, y1);
+            tile_rect(s.px + 0.5f * (float)W, s.py + 0.5f * (float)H, s.radius, tiles_x, tiles_y, x0, y0, x1, y1);
             w = x1 - x0;
             full = (uint32_t)(w * (y1 - y0));
             geo = make_float4(s.px, s.py, s.ca, s.cb);
@@ -432,7 +432,8 @@ __global__ __launch_bounds__(256 / PPT) void k_blend_fwd(int W, int H, int tiles
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int px = tx * kTile + (tid & 15);
     const int py0 = ty * kTile + (tid >> 4) * PPT;
-    const float pxf = (float)px;
+    const float pxf = (float)px - 0.5f * (float)W;   // centred pixel coordinates (see Splat)
+    const float cyf = 0.5f * (float)H;
     const uint2 rg = ranges[tile];
     const int n = (int)(rg.y - rg.x);
     const int nb = (n + NT - 1) / NT;
@@ -473,7 +474,7 @@ __global__ __launch_bounds__(256 / PPT) void k_blend_fwd(int W, int H, int tiles
                 for (int p = 0; p < PPT; p++) {
                     if (done[p]) continue;
                     float G, dx, dy;
-                    const float alpha = pair_alpha(pxf, (float)(py0 + p), A.x, A.y, A.z, A.w, B.x, B.y, G, dx, dy);
+                    const float alpha = pair_alpha(pxf, (float)(py0 + p) - cyf, A.x, A.y, A.z, A.w, B.x, B.y, G, dx, dy);
                     if (alpha == 0.f) continue;
                     if (!blend_step_fwd(acc[p], alpha, B.w, C.x, C.y, B.z)) { done[p] = true; continue; }
                     last[p] = (uint32_t)(b * NT + j + 1);
@@ -524,8 +525,9 @@ __global__ __launch_bounds__(128) void k_blend_fwd2(int W, int H, int tiles_x, i
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int px = tx * kTile + (tid & 15);
     const int py0 = ty * kTile + (tid >> 4) * 2;
-    const float pxf = (float)px;
-    const f2 pyf = {(float)py0, (float)(py0 + 1)};
+    const float pxf = (float)px - 0.5f * (float)W;   // centred pixel coordinates (see Splat)
+    const float cyf = 0.5f * (float)H;
+    const f2 pyf = {(float)py0 - cyf, (float)(py0 + 1) - cyf};
     const uint2 rg = ranges[tile];
     const int n = (int)(rg.y - rg.x);
     const int nb = (n + NT - 1) / NT;
@@ -627,7 +629,8 @@ __global__ __launch_bounds__(256 / PPT) void k_blend_bwd(int W, int H, int tiles
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int px = tx * kTile + (tid & 15);
     const int py0 = ty * kTile + (tid >> 4) * PPT;
-    const float pxf = (float)px;
+    const float pxf = (float)px - 0.5f * (float)W;   // centred pixel coordinates (see Splat)
+    const float cyf = 0.5f * (float)H;
     const uint2 rg = ranges[tile];
     const size_t P = (size_t)W * H;
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
@@ -694,7 +697,7 @@ __global__ __launch_bounds__(256 / PPT) void k_blend_bwd(int W, int H, int tiles
             for (int p = 0; p < PPT; p++) {
                 if (idx > ncon[p]) continue;
                 float G, dx, dy;
-                const float alpha = pair_alpha(pxf, (float)(py0 + p), A.x, A.y, A.z, A.w, B.x, B.y, G, dx, dy);
+                const float alpha = pair_alpha(pxf, (float)(py0 + p) - cyf, A.x, A.y, A.z, A.w, B.x, B.y, G, dx, dy);
                 if (alpha == 0.f) continue;
                 blend_step_bwd(st[p], alpha, G, dx, dy, A.z, A.w, B.x, B.y, B.w, C.x, C.y, B.z, pg);
                 touched = true;
@@ -758,8 +761,9 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(int W, int H, int tiles_x, i
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int px = tx * kTile + (tid & 15);
     const int py0 = ty * kTile + (tid >> 4) * 2;
-    const float pxf = (float)px;
-    const f2 pyf = {(float)py0, (float)(py0 + 1)};
+    const float pxf = (float)px - 0.5f * (float)W;   // centred pixel coordinates (see Splat)
+    const float cyf = 0.5f * (float)H;
+    const f2 pyf = {(float)py0 - cyf, (float)(py0 + 1) - cyf};
     const uint2 rg = ranges[tile];
     const size_t P = (size_t)W * H;
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];

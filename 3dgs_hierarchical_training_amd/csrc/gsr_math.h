@@ -40,8 +40,11 @@ constexpr float SH_C3_0 = -0.5900435899266435f, SH_C3_1 = 2.890611442640554f, SH
                 SH_C3_6 = -0.5900435899266435f;
 
 // Projected 2D Gaussian, 48 bytes, 16-byte aligned: what the blend kernels gather per instance.
+// px, py are stored RELATIVE TO THE IMAGE CENTRE (W/2, H/2): pixel centres minus the centre are exact in
+// binary32, so dx = px - pixel carries only the rounding of |px| <= W/2 instead of W (halves the dominant
+// coordinate error at 1920x1080: max image error vs the float64 oracle 1.24e-5 -> below 1e-5).
 struct alignas(16) Splat {
-    float px, py, ca, cb;      // pixel-space mean, conic A, B
+    float px, py, ca, cb;      // centred pixel-space mean, conic A, B
     float cc, op, depth, r;    // conic C, opacity, view depth, red
     float g, b;                // green, blue
     int32_t radius;            // ceil(3 sigma) in pixels, 0 = invisible
@@ -186,12 +189,11 @@ GSR_HD float splat_tau(float opacity)
     return opacity > 0.f ? 2.0f * logf(255.0f * opacity) : -1.0f;
 }
 
-GSR_HD bool tile_accept(float px, float py, float ca, float cb, float cc, float tau, int tx, int ty, int W, int H)
+// conservative test on an arbitrary pixel-centre box [bx0,bx1] x [by0,by1] (inclusive)
+GSR_HD bool box_accept(float px, float py, float ca, float cb, float cc, float tau, float bx0, float by0, float bx1, float by1)
 {
     const float slack = 1e-3f * (1.0f + fabsf(tau));
     if (tau < -slack) return false;                       // opacity below 1/255: contributes nowhere
-    const float bx0 = (float)(tx * kTile), by0 = (float)(ty * kTile);
-    const float bx1 = fminf(bx0 + (float)(kTile - 1), (float)(W - 1)), by1 = fminf(by0 + (float)(kTile - 1), (float)(H - 1));
     const float dx0 = bx0 - px, dx1 = bx1 - px, dy0 = by0 - py, dy1 = by1 - py;
     if (dx0 <= 0.f && dx1 >= 0.f && dy0 <= 0.f && dy1 >= 0.f) return true;   // centre inside the box
     float qmin = 3.0e38f;
@@ -209,6 +211,15 @@ GSR_HD bool tile_accept(float px, float py, float ca, float cb, float cc, float 
         qmin = fminf(qmin, ca * x * x + 2.f * cb * x * dy1 + cc * dy1 * dy1);
     }
     return qmin <= tau + slack;
+}
+
+// px, py and the box are in centred coordinates (see Splat)
+GSR_HD bool tile_accept(float px, float py, float ca, float cb, float cc, float tau, int tx, int ty, int W, int H)
+{
+    const float cx = 0.5f * (float)W, cy = 0.5f * (float)H;
+    const float bx0 = (float)(tx * kTile) - cx, by0 = (float)(ty * kTile) - cy;
+    const float bx1 = fminf(bx0 + (float)(kTile - 1), (float)(W - 1) - cx), by1 = fminf(by0 + (float)(kTile - 1), (float)(H - 1) - cy);
+    return box_accept(px, py, ca, cb, cc, tau, bx0, by0, bx1, by1);
 }
 
 struct Splat;
@@ -290,10 +301,11 @@ GSR_HD void preprocess_one(const Camera& c, const float mean[3], const float* sc
     disc = sqrt(disc < (RT)0.1 ? (RT)0.1 : disc);
     const RT l1 = mid + disc, l2 = mid - disc;
     const int radius = (int)ceil(3 * sqrt(l1 > l2 ? l1 : l2));
-    const float px = (float)(((hx * pw + 1) * c.W - 1) * (RT)0.5);
-    const float py = (float)(((hy * pw + 1) * c.H - 1) * (RT)0.5);
+    // centred pixel coordinates: ((ndc+1) W - 1)/2 - W/2 = (ndc W - 1)/2
+    const float px = (float)((hx * pw * c.W - 1) * (RT)0.5);
+    const float py = (float)((hy * pw * c.H - 1) * (RT)0.5);
     int x0, y0, x1, y1;
-    tile_rect(px, py, radius, c.tiles_x, c.tiles_y, x0, y0, x1, y1);
+    tile_rect(px + 0.5f * (float)c.W, py + 0.5f * (float)c.H, radius, c.tiles_x, c.tiles_y, x0, y0, x1, y1);
     const int nt = (x1 - x0) * (y1 - y0);
     if (nt == 0) return;
     float col[3];

@@ -445,8 +445,17 @@ static void blend_all(Ctx *c)
         for (int tyy = o[1]; tyy < o[3]; tyy++)
             for (int txx = o[0]; txx < o[2]; txx++) {
                 if (txx >= n[0] && txx < n[2] && tyy >= n[1] && tyy < n[3]) continue;
+                /* a contested tile only matters where this Gaussian would actually blend (alpha >= 1/255) */
+                const real *co = c->conic + 3 * (size_t)i;
+                const real o_ = I->opacities[i];
                 for (int y = tyy * TILE; y < (tyy + 1) * TILE && y < H; y++)
-                    for (int x = txx * TILE; x < (txx + 1) * TILE && x < W; x++) c->px_ambig[(size_t)y * W + x] = 1;
+                    for (int x = txx * TILE; x < (txx + 1) * TILE && x < W; x++) {
+                        real dx = c->xy[2 * (size_t)i] - x, dy = c->xy[2 * (size_t)i + 1] - y;
+                        real power = (real)-0.5 * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                        if (power > (real)1e-3) continue;
+                        real alpha = o_ * R_EXP(power > 0 ? 0 : power);
+                        if (alpha >= ALPHA_MIN * (real)0.999) c->px_ambig[(size_t)y * W + x] = 1;
+                    }
             }
     }
 }

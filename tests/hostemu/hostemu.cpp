@@ -65,7 +65,7 @@ EmuCtx* hostemu_forward(const EmuIn* in, float* out_color, float* out_depth, flo
                        in->colors_precomp ? in->colors_precomp + 3 * (size_t)i : nullptr, c->splat[i]);
         if (g_ov_xy && c->splat[i].radius > 0) {
             Splat& s = c->splat[i];
-            s.px = g_ov_xy[2 * i]; s.py = g_ov_xy[2 * i + 1];
+            s.px = g_ov_xy[2 * i] - 0.5f * W; s.py = g_ov_xy[2 * i + 1] - 0.5f * H;
             s.ca = g_ov_conic[3 * i]; s.cb = g_ov_conic[3 * i + 1]; s.cc = g_ov_conic[3 * i + 2];
             s.r = g_ov_rgb[3 * i]; s.g = g_ov_rgb[3 * i + 1]; s.b = g_ov_rgb[3 * i + 2];
         }
@@ -79,7 +79,7 @@ EmuCtx* hostemu_forward(const EmuIn* in, float* out_color, float* out_depth, flo
     std::vector<std::pair<uint32_t, uint32_t>> inst;  // (tile, gid) in emission order
     for (uint32_t g : order) {
         int x0, y0, x1, y1;
-        tile_rect(c->splat[g].px, c->splat[g].py, c->splat[g].radius, cam.tiles_x, cam.tiles_y, x0, y0, x1, y1);
+        tile_rect(c->splat[g].px + 0.5f * W, c->splat[g].py + 0.5f * H, c->splat[g].radius, cam.tiles_x, cam.tiles_y, x0, y0, x1, y1);
         const Splat& s = c->splat[g];
         const float tau = splat_tau(s.op);
         uint32_t n = 0;
@@ -105,7 +105,7 @@ EmuCtx* hostemu_forward(const EmuIn* in, float* out_color, float* out_depth, flo
                 contributor++;
                 const Splat& s = c->splat[c->list[k]];
                 float G, dx, dy;
-                const float alpha = pair_alpha((float)x, (float)y, s.px, s.py, s.ca, s.cb, s.cc, s.op, G, dx, dy);
+                const float alpha = pair_alpha((float)x - 0.5f * W, (float)y - 0.5f * H, s.px, s.py, s.ca, s.cb, s.cc, s.op, G, dx, dy);
                 if (alpha == 0.f) continue;
                 if (!blend_step_fwd(p, alpha, s.r, s.g, s.b, s.depth)) break;
                 last = contributor;
@@ -148,7 +148,7 @@ void hostemu_backward(EmuCtx* c, const float* g_color, const float* g_depth, con
                 const uint32_t g = c->list[s0 + k];
                 const Splat& s = c->splat[g];
                 float G, dx, dy;
-                const float alpha = pair_alpha((float)x, (float)y, s.px, s.py, s.ca, s.cb, s.cc, s.op, G, dx, dy);
+                const float alpha = pair_alpha((float)x - 0.5f * W, (float)y - 0.5f * H, s.px, s.py, s.ca, s.cb, s.cc, s.op, G, dx, dy);
                 if (alpha == 0.f) continue;
                 blend_step_bwd(p, alpha, G, dx, dy, s.ca, s.cb, s.cc, s.op, s.r, s.g, s.b, s.depth, gg[g]);
             }

@@ -24,7 +24,7 @@ CASES = [
 ]
 
 
-def _run_case(N, W, H, deg, posed, mode, bg, ppt=None, noncontig=False, color_only=False):
+def _run_case(N, W, H, deg, posed, mode, bg, ppt=None, noncontig=False, color_only=False, ambig_max_frac=None):
     import hip_runner
     sc = parity.syn.make_scene(N, W, H, sh_degree=deg, seed=N % 97, posed=posed)
     kw = parity.scene_kwargs(sc, mode, bg=bg)
@@ -37,7 +37,7 @@ def _run_case(N, W, H, deg, posed, mode, bg, ppt=None, noncontig=False, color_on
         gd = ga = None
     ref = o.backward(gc, gd, ga)
     out = hip_runner.run_hip(kw, (gc, gd, ga), noncontig=noncontig)
-    rep = parity.check_forward(out["fwd"], o, f"hip fwd {N}/{W}x{H}/deg{deg}/{mode}")
+    rep = parity.check_forward(out["fwd"], o, f"hip fwd {N}/{W}x{H}/deg{deg}/{mode}", ambig_max_frac)
     grep = parity.check_grads(out["grads"], ref, f"hip bwd {N}/{W}x{H}/deg{deg}/{mode}")
     print(rep, {k: "%.1e" % v for k, v in grep.items()})
     o.close()
@@ -46,6 +46,53 @@ def _run_case(N, W, H, deg, posed, mode, bg, ppt=None, noncontig=False, color_on
 @pytest.mark.parametrize("case", CASES, ids=lambda c: f"{c[0]}-{c[1]}x{c[2]}-d{c[3]}-{c[5]}")
 def test_parity_vs_oracle(case):
     _run_case(*case)
+
+
+# BASELINE.json configs at FULL size, straight against the oracle (it is OpenMP C: seconds on the GPU box's host)
+FULL = [
+    (300000, 980, 545, 3, True, "sh", (0.0, 0.0, 0.0)),      # configs[1]: ~300k Gaussians, 980x545, SH 3
+    (1000000, 980, 545, 3, False, "sh", (0.0, 0.0, 0.0)),    # the metric's workload
+    (1000000, 1920, 1080, 3, True, "sh", (0.0, 0.0, 0.0)),   # configs[2]: 1M, 1920x1080
+    (4000000, 980, 545, 3, True, "sh", (0.0, 0.0, 0.0)),     # configs[4]: 4M Gaussians
+]
+
+
+@pytest.mark.parametrize("case", FULL, ids=lambda c: f"{c[0]}-{c[1]}x{c[2]}")
+def test_parity_full_size(case):
+    # thousands of (pixel, Gaussian) evaluations per pixel: the share of pixels with at least one evaluation on a
+    # rounding edge grows with the list length; every unambiguous pixel still has to be within 1e-5
+    _run_case(*case, color_only=True, ambig_max_frac=0.35)
+
+
+def test_full_size_properties():
+    """Size-independent properties at the metric's size (1M, 980x545):
+    (1) alpha + final transmittance = 1: colour(bg=1) - colour(bg=0) == 1 - alpha per pixel;
+    (2) relabelling the Gaussians (a permutation of the inputs) leaves the image unchanged up to depth ties;
+    (3) linearity of the backward in the upstream gradient."""
+    import hip_runner
+    sc = parity.syn.make_scene(1000000, 980, 545, sh_degree=3, seed=11)
+    kw0 = parity.scene_kwargs(sc, "sh", bg=(0.0, 0.0, 0.0))
+    kw1 = parity.scene_kwargs(sc, "sh", bg=(1.0, 1.0, 1.0))
+    gc = parity.upstream_grads(545, 980, seed=1)[0]
+    o0 = hip_runner.run_hip(kw0, (gc, None, None))
+    o1 = hip_runner.run_hip(kw1)
+    c0, _, _, a0 = o0["fwd"]
+    c1 = o1["fwd"][0]
+    assert np.abs((c1 - c0) - (1.0 - a0)).max() < 2e-6
+    perm = torch.randperm(1000000, generator=torch.Generator().manual_seed(3))
+    kwp = dict(kw0)
+    for k in ("means3D", "opacities", "shs", "scales", "rotations"):
+        kwp[k] = kw0[k][perm].contiguous()
+    op = hip_runner.run_hip(kwp, (gc, None, None))
+    d = np.abs(op["fwd"][0] - c0)
+    assert (d > 1e-5).mean() < 5e-3 and d.max() < 5e-2      # equal-depth ties (binary32 z) reorder a few pixels
+    inv = torch.argsort(perm).numpy()
+    gm = op["grads"]["means3D"][inv]
+    ref = o0["grads"]["means3D"]
+    assert np.abs(gm - ref).max() <= 2e-3 * np.abs(ref).max()
+    o2 = hip_runner.run_hip(kw0, (2.0 * gc, None, None))
+    for k in ("means3D", "opacities", "scales"):
+        assert np.abs(o2["grads"][k] - 2.0 * o0["grads"][k]).max() <= 1e-4 * np.abs(o0["grads"][k]).max() + 1e-12
 
 
 @pytest.mark.parametrize("case", [CASES[1], CASES[3], CASES[5]], ids=lambda c: f"{c[0]}-{c[1]}x{c[2]}-d{c[3]}-{c[5]}")
