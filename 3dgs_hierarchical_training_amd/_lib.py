@@ -44,6 +44,7 @@ class GsrBackwardArgs(C.Structure):
         ("d_colors_precomp", C.c_void_p), ("d_shs", C.c_void_p), ("d_scales", C.c_void_p),
         ("d_rotations", C.c_void_p), ("d_cov3D_precomp", C.c_void_p), ("scratch", C.c_void_p),
         ("shs_rest", C.c_void_p), ("d_shs_rest", C.c_void_p), ("raw_params", C.c_int32),
+        ("d_viewmatrix", C.c_void_p), ("d_projmatrix", C.c_void_p), ("d_campos", C.c_void_p),
     ]
 
 

@@ -886,7 +886,12 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(int W, int H, int tiles_x, i
 // ------------------------------------------------------------------------------------------------
 // K9: per-Gaussian backward.  SH rows in, dSH rows out through the same LDS tile (coalesced both ways).
 // ------------------------------------------------------------------------------------------------
-template <int DEG, bool RAW>
+// CAM = true additionally produces dL/d(viewmatrix, projmatrix, campos) (north_star's dL/dviewmatrix; BASELINE
+// config 5): per-thread contributions are reduced over the block and written as one 35-float partial per block;
+// k_cam_reduce sums the partials deterministically.
+constexpr int kCamVals = 35;
+
+template <int DEG, bool RAW, bool CAM>
 __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, int N, const float* __restrict__ means,
                                                                 const float* __restrict__ scales, const float* __restrict__ rots,
                                                                 const float* __restrict__ cov_pre, const float* __restrict__ shs,
@@ -896,14 +901,22 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, in
                                                                 float* __restrict__ d_opac, float* __restrict__ d_colors,
                                                                 float* __restrict__ d_shs, float* __restrict__ d_shs_rest,
                                                                 float* __restrict__ d_scales,
-                                                                float* __restrict__ d_rots, float* __restrict__ d_cov)
+                                                                float* __restrict__ d_rots, float* __restrict__ d_cov,
+                                                                float* __restrict__ cam_partial)
 {
     constexpr int NC3 = 3 * (DEG + 1) * (DEG + 1);
     __shared__ float s_sh[kPreThreads * kShStride];
+    __shared__ float s_cam[CAM ? (kPreThreads / 64) * kCamVals : 1];
     const int tid = threadIdx.x;
     const int base = blockIdx.x * kPreThreads;
     const int i = base + tid;
     const int nG = min(kPreThreads, N - base);
+    CamGrads cg;
+    if (CAM) {
+#pragma unroll
+        for (int q = 0; q < 16; q++) { cg.vm[q] = 0.f; cg.pm[q] = 0.f; }
+        cg.cam[0] = cg.cam[1] = cg.cam[2] = 0.f;
+    }
     if (shs) {
         if (shs_rest) {
             const size_t row = (size_t)(cp.M - 1) * 3;
@@ -954,7 +967,7 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, in
                 for (int k = 0; k < 4; k++) rq[k] *= rinv;
             }
             GaussGrads o;
-            gauss_backward(cam, mean, sc, rq, cov_pre ? cv : nullptr, g0.x, g0.y, g0.z, g0.w, g1.x, g2.y, o);
+            gauss_backward(cam, mean, sc, rq, cov_pre ? cv : nullptr, g0.x, g0.y, g0.z, g0.w, g1.x, g2.y, o, CAM ? &cg : nullptr);
             dmean[0] = o.mean[0]; dmean[1] = o.mean[1]; dmean[2] = o.mean[2];
             m2d[0] = o.mean2d[0]; m2d[1] = o.mean2d[1];
             dop = g1.y;
@@ -974,7 +987,12 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, in
             for (int k = 0; k < 4; k++) drq[k] = o.rot[k];
 #pragma unroll
             for (int k = 0; k < 6; k++) dcv[k] = o.cov[k];
-            if (shs) sh_backward(cam, mean, &s_sh[tid * kShStride], 3, 1, grgb, &s_sh[tid * kShStride], 3, 1, dmean);
+            if (shs) {
+                sh_backward(cam, mean, &s_sh[tid * kShStride], 3, 1, grgb, &s_sh[tid * kShStride], 3, 1, dmean);
+                if (CAM) {   // the view direction is (p - campos)/|.|: d/dcampos = -(its share of d/dp)
+                    cg.cam[0] = o.mean[0] - dmean[0]; cg.cam[1] = o.mean[1] - dmean[1]; cg.cam[2] = o.mean[2] - dmean[2];
+                }
+            }
         } else if (shs) {
             for (int e = 0; e < NC3; e++) s_sh[tid * kShStride + e] = 0.f;
         }
@@ -997,6 +1015,24 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, in
         if (d_cov) {
 #pragma unroll
             for (int k = 0; k < 6; k++) d_cov[6 * (size_t)i + k] = dcv[k];
+        }
+    }
+    if (CAM) {
+        const int lane = tid & 63, wave = tid >> 6;
+        float cv35[kCamVals];
+#pragma unroll
+        for (int q = 0; q < 16; q++) { cv35[q] = cg.vm[q]; cv35[16 + q] = cg.pm[q]; }
+        cv35[32] = cg.cam[0]; cv35[33] = cg.cam[1]; cv35[34] = cg.cam[2];
+#pragma unroll
+        for (int q = 0; q < kCamVals; q++) {
+            const float t = wave_sum_to_lane63(cv35[q]);
+            if (lane == 63) s_cam[wave * kCamVals + q] = t;
+        }
+        __syncthreads();
+        if (tid < kCamVals) {
+            float t = 0.f;
+            for (int w = 0; w < kPreThreads / 64; w++) t += s_cam[w * kCamVals + tid];
+            cam_partial[(size_t)blockIdx.x * kCamVals + tid] = t;
         }
     }
     if (shs && d_shs) {
@@ -1024,6 +1060,28 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, in
                 d_shs[(size_t)(base + g) * row + e] = e < NC3 ? s_sh[g * kShStride + e] : 0.f;
             }
         }
+    }
+}
+
+// one block per camera entry: deterministic sum of the per-block partials
+__global__ __launch_bounds__(256) void k_cam_reduce(const float* __restrict__ partial, int nblocks, float* __restrict__ d_vm,
+                                                    float* __restrict__ d_pm, float* __restrict__ d_campos)
+{
+    __shared__ double s[256];
+    const int q = blockIdx.x;
+    double a = 0;
+    for (int b = threadIdx.x; b < nblocks; b += 256) a += partial[(size_t)b * kCamVals + q];
+    s[threadIdx.x] = a;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) s[threadIdx.x] += s[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float v = (float)s[0];
+        if (q < 16) { if (d_vm) d_vm[q] = v; }
+        else if (q < 32) { if (d_pm) d_pm[q - 16] = v; }
+        else if (d_campos) d_campos[q - 32] = v;
     }
 }
 
@@ -1157,7 +1215,11 @@ int gsr_profile_read(const char* name, double* total_ms, int64_t* count)
 size_t gsr_forward_scratch_bytes(int32_t N) { return fwd_scratch_layout(N).bytes; }
 size_t gsr_binning_bytes(int64_t R, int32_t W, int32_t H) { return bin_layout(R, W, H).bytes; }
 size_t gsr_binning_scratch_bytes(int64_t R) { return bin_scratch_layout(R).bytes; }
-size_t gsr_backward_scratch_bytes(int32_t N) { return align256((size_t)(N > 0 ? N : 1) * kGG * 4); }
+size_t gsr_backward_scratch_bytes(int32_t N)
+{
+    const size_t n = (size_t)(N > 0 ? N : 1);
+    return align256(n * kGG * 4) + align256(((n + kPreThreads - 1) / kPreThreads) * kCamVals * 4);
+}
 size_t gsr_sort_scratch_bytes(uint32_t n) { return radix_scratch_bytes(n); }
 const char* gsr_last_error(void) { return g_err; }
 int gsr_version(void) { return 100; }
@@ -1304,7 +1366,12 @@ int gsr_backward(const GsrBackwardArgs* a, void* stream_)
     int rc = check_common(a->N, a->M, a->D, a->W, a->H);
     if (rc) return rc;
     const int N = a->N, W = a->W, H = a->H;
-    if (N == 0) return GSR_OK;
+    if (N == 0) {
+        if (a->d_viewmatrix) GSR_HIP(hipMemsetAsync(a->d_viewmatrix, 0, 64, st));
+        if (a->d_projmatrix) GSR_HIP(hipMemsetAsync(a->d_projmatrix, 0, 64, st));
+        if (a->d_campos) GSR_HIP(hipMemsetAsync(a->d_campos, 0, 12, st));
+        return GSR_OK;
+    }
     if (!a->geom || !a->image || !a->binning || !a->scratch || !a->d_means3D || !a->d_means2D || !a->d_opacities)
         return fail(GSR_ERR_ARG, "missing workspace / gradient pointer%s");
     const int tiles_x = (W + kTile - 1) / kTile, tiles_y = (H + kTile - 1) / kTile, T = tiles_x * tiles_y;
@@ -1333,11 +1400,17 @@ int gsr_backward(const GsrBackwardArgs* a, void* stream_)
     }
     CamParams cp = {a->viewmatrix, a->projmatrix, a->campos, a->tanfovx, a->tanfovy, a->scale_modifier, W, H, a->D, a->M};
     const int grid = (N + kPreThreads - 1) / kPreThreads;
-#define GSR_PREB_(DEG, RAW)                                                                                                             \
-    hipLaunchKernelGGL((k_preprocess_bwd<DEG, RAW>), dim3(grid), dim3(kPreThreads), 0, st, cp, N, a->means3D, a->scales, a->rotations, \
-                       a->cov3D_precomp, a->shs, a->shs_rest, splat, gg, a->d_means3D, a->d_means2D, a->d_opacities,                  \
-                       a->d_colors_precomp, a->d_shs, a->d_shs_rest, a->d_scales, a->d_rotations, a->d_cov3D_precomp)
-#define GSR_PREB(DEG) do { if (a->raw_params) GSR_PREB_(DEG, true); else GSR_PREB_(DEG, false); } while (0)
+    const bool want_cam = a->d_viewmatrix || a->d_projmatrix || a->d_campos;
+    float* cam_partial = reinterpret_cast<float*>(static_cast<uint8_t*>(a->scratch) + align256((size_t)N * kGG * 4));
+#define GSR_PREB_(DEG, RAW, CAM)                                                                                                             \
+    hipLaunchKernelGGL((k_preprocess_bwd<DEG, RAW, CAM>), dim3(grid), dim3(kPreThreads), 0, st, cp, N, a->means3D, a->scales, a->rotations, \
+                       a->cov3D_precomp, a->shs, a->shs_rest, splat, gg, a->d_means3D, a->d_means2D, a->d_opacities,                       \
+                       a->d_colors_precomp, a->d_shs, a->d_shs_rest, a->d_scales, a->d_rotations, a->d_cov3D_precomp, cam_partial)
+#define GSR_PREB(DEG)                                                     \
+    do {                                                                  \
+        if (a->raw_params) { if (want_cam) GSR_PREB_(DEG, true, true); else GSR_PREB_(DEG, true, false); }   \
+        else { if (want_cam) GSR_PREB_(DEG, false, true); else GSR_PREB_(DEG, false, false); }               \
+    } while (0)
     {
         ProfScope ps(P_PRE_BWD, st);
         switch (a->shs ? a->D : 0) {
@@ -1349,6 +1422,8 @@ int gsr_backward(const GsrBackwardArgs* a, void* stream_)
     }
 #undef GSR_PREB
 #undef GSR_PREB_
+    if (want_cam)
+        hipLaunchKernelGGL(k_cam_reduce, dim3(kCamVals), dim3(256), 0, st, cam_partial, grid, a->d_viewmatrix, a->d_projmatrix, a->d_campos);
     GSR_HIP(hipGetLastError());
     return GSR_OK;
 }

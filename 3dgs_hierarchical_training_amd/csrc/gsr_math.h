@@ -465,9 +465,15 @@ GSR_HD void sh_backward(const Camera& c, const float mean[3], const float* sh, i
     dmean[2] += (gdz - z * dot) * inv_n;
 }
 
+// Camera gradients (north_star: dL/d viewmatrix; extension of SURVEY.md 8f-4 also covers projmatrix and campos).
+// Entries follow the linear (column-major) storage of the matrices: vm[k*4 + r] = row r, column k.
+struct CamGrads {
+    float vm[16], pm[16], cam[3];
+};
+
 GSR_HD void gauss_backward(const Camera& c, const float mean[3], const float* scale, const float* rot,
                            const float* cov_pre, float g_px, float g_py, float gA, float gB, float gC, float g_z,
-                           GaussGrads& o)
+                           GaussGrads& o, CamGrads* cg = nullptr)
 {
     const float X = mean[0], Y = mean[1], Z = mean[2];
     float cov[6];
@@ -520,6 +526,24 @@ GSR_HD void gauss_backward(const Camera& c, const float mean[3], const float* sc
         float d = vm[k * 4 + 0] * gt0 + vm[k * 4 + 1] * gt1 + vm[k * 4 + 2] * (gt2 + g_z);
         d += (pm[k * 4 + 0] * mw - pm[k * 4 + 3] * hx * mw * mw) * gnx + (pm[k * 4 + 1] * mw - pm[k * 4 + 3] * hy * mw * mw) * gny;
         o.mean[k] = d;
+    }
+    if (cg) {
+        const float ph[4] = {X, Y, Z, 1.f};
+        const float gtv[3] = {gt0, gt1, gt2 + g_z};
+        for (int k = 0; k < 4; k++) {
+            // view-space position t = V p_h (rows 0..2) and the depth feature (row 2, folded into gtv[2])
+            cg->vm[k * 4 + 0] = gtv[0] * ph[k]; cg->vm[k * 4 + 1] = gtv[1] * ph[k]; cg->vm[k * 4 + 2] = gtv[2] * ph[k];
+            cg->vm[k * 4 + 3] = 0.f;
+            // homogeneous clip position (rows 0, 1, 3 of the full projection; row 2 is unused by the rasterizer)
+            cg->pm[k * 4 + 0] = gnx * mw * ph[k]; cg->pm[k * 4 + 1] = gny * mw * ph[k]; cg->pm[k * 4 + 2] = 0.f;
+            cg->pm[k * 4 + 3] = -(gnx * hx + gny * hy) * mw * mw * ph[k];
+        }
+        for (int k = 0; k < 3; k++) {   // rotation block through M = J Wr
+            cg->vm[k * 4 + 0] += gm0[k] * f.J00;
+            cg->vm[k * 4 + 1] += gm1[k] * f.J11;
+            cg->vm[k * 4 + 2] += gm0[k] * f.J02 + gm1[k] * f.J12;
+        }
+        cg->cam[0] = 0.f; cg->cam[1] = 0.f; cg->cam[2] = 0.f;
     }
     for (int k = 0; k < 6; k++) o.cov[k] = gS[k];
     for (int k = 0; k < 3; k++) o.scale[k] = 0.f;

@@ -92,7 +92,9 @@ class _Workspace:
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
-                sh_rest=None, raw_params=False):
+                sh_rest=None, raw_params=False, viewmatrix=None, projmatrix=None, campos=None):
+        # viewmatrix / projmatrix / campos are ALSO passed as explicit tensor inputs (same objects as in
+        # raster_settings) so that autograd can return their gradients: a NamedTuple cannot carry grads.
         lib = L.load()
         rs = raster_settings
         dev = means3D.device
@@ -104,8 +106,10 @@ class _RasterizeGaussians(torch.autograd.Function):
         scales, rotations = _f32c(_empty_to_none(scales)), _f32c(_empty_to_none(rotations))
         cov3Ds_precomp = _f32c(_empty_to_none(cov3Ds_precomp))
         opacities = _f32c(opacities)
-        vm, pm = _f32c(rs.viewmatrix.to(dev)), _f32c(rs.projmatrix.to(dev))
-        campos, bg = _f32c(rs.campos.to(dev)), _f32c(rs.bg.to(dev))
+        vm = _f32c((viewmatrix if viewmatrix is not None else rs.viewmatrix).to(dev))
+        pm = _f32c((projmatrix if projmatrix is not None else rs.projmatrix).to(dev))
+        campos = _f32c((campos if campos is not None else rs.campos).to(dev))
+        bg = _f32c(rs.bg.to(dev))
         H, W = int(rs.image_height), int(rs.image_width)
         sh_rest = _f32c(_empty_to_none(sh_rest))
         M = (int(sh.shape[1]) + (int(sh_rest.shape[1]) if sh_rest is not None else 0)) if sh is not None else 0
@@ -163,7 +167,11 @@ class _RasterizeGaussians(torch.autograd.Function):
         dev = means3D.device
         grad_color, grad_depth, grad_alpha = _f32c(grad_color), _f32c(grad_depth), _f32c(grad_alpha)
         if grad_color is None and grad_depth is None and grad_alpha is None:
-            return (None,) * 11
+            return (None,) * 14
+        need_vm, need_pm, need_cp = ctx.needs_input_grad[11], ctx.needs_input_grad[12], ctx.needs_input_grad[13]
+        d_vm = torch.empty((4, 4), dtype=torch.float32, device=dev) if need_vm else None
+        d_pm = torch.empty((4, 4), dtype=torch.float32, device=dev) if need_pm else None
+        d_cp = torch.empty((3,), dtype=torch.float32, device=dev) if need_cp else None
 
         d_means3D = torch.empty((N, 3), dtype=torch.float32, device=dev)
         d_means2D = torch.empty((N, 3), dtype=torch.float32, device=dev)
@@ -193,15 +201,23 @@ class _RasterizeGaussians(torch.autograd.Function):
         a.scratch = scratch.data_ptr()
         a.shs_rest = _ptr(sh_rest) if has_rest else None
         a.d_shs_rest, a.raw_params = _ptr(d_sh_rest), int(raw_params)
+        a.d_viewmatrix, a.d_projmatrix, a.d_campos = _ptr(d_vm), _ptr(d_pm), _ptr(d_cp)
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
             L.check(lib.gsr_backward(C.byref(a), C.c_void_p(stream)), "gsr_backward")
-        return d_means3D, d_means2D, d_sh, d_col, d_opac, d_scales, d_rot, d_cov, None, d_sh_rest, None
+        return (d_means3D, d_means2D, d_sh, d_col, d_opac, d_scales, d_rot, d_cov, None, d_sh_rest, None, d_vm, d_pm, d_cp)
+
+
+def _cam_inputs(rs):
+    """Only route the camera tensors through autograd when one of them wants a gradient."""
+    if any(torch.is_tensor(t) and t.requires_grad for t in (rs.viewmatrix, rs.projmatrix, rs.campos)):
+        return rs.viewmatrix, rs.projmatrix, rs.campos
+    return None, None, None
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                                     raster_settings)
+                                     raster_settings, None, False, *_cam_inputs(raster_settings))
 
 
 def rasterize_gaussians_raw(means3D, means2D, features_dc, features_rest, opacity_logit, log_scales, rotations_raw,
@@ -211,7 +227,7 @@ def rasterize_gaussians_raw(means3D, means2D, features_dc, features_rest, opacit
     activations of :49-65,128-133,176-188 fused into the HIP kernels; gradients are w.r.t. the raw tensors."""
     e = torch.Tensor([])
     return _RasterizeGaussians.apply(means3D, means2D, features_dc, e, opacity_logit, log_scales, rotations_raw, e,
-                                     raster_settings, features_rest, True)
+                                     raster_settings, features_rest, True, *_cam_inputs(raster_settings))
 
 
 class GaussianRasterizer(nn.Module):

@@ -107,6 +107,11 @@ typedef struct GsrBackwardArgs {
     const float* shs_rest;
     float* d_shs_rest;       /* [N,M-1,3] when shs_rest is given (then d_shs is [N,1,3]) */
     int32_t raw_params;
+    /* ---- camera gradients (north_star: dL/dviewmatrix; BASELINE config 5).  NULL = not wanted.  Entries follow
+     * the linear storage of the inputs.  projmatrix row 2 (clip z) does not influence the render: its grad is 0. */
+    float* d_viewmatrix;     /* 16 */
+    float* d_projmatrix;     /* 16 */
+    float* d_campos;         /* 3 */
 } GsrBackwardArgs;
 
 size_t gsr_geom_bytes(int32_t N);

@@ -46,7 +46,7 @@ def _lib(precision="f64"):
         lib.gsr_oracle_forward.restype = C.c_void_p
         lib.gsr_oracle_forward.argtypes = [C.POINTER(GsrOracleIn)] + [C.c_void_p] * 6
         lib.gsr_oracle_backward.restype = None
-        lib.gsr_oracle_backward.argtypes = [C.c_void_p] + [C.c_void_p] * 11
+        lib.gsr_oracle_backward.argtypes = [C.c_void_p] + [C.c_void_p] * 12
         lib.gsr_oracle_free.argtypes = [C.c_void_p]
         lib.gsr_oracle_num_rendered.restype = C.c_int64
         lib.gsr_oracle_num_rendered.argtypes = [C.c_void_p]
@@ -146,13 +146,15 @@ class OracleRender:
         gc = _f32(g_color, (3, self.H, self.W)) if g_color is not None else None
         gd = _f32(g_depth, (self.H, self.W)) if g_depth is not None else None
         ga = _f32(g_alpha, (self.H, self.W)) if g_alpha is not None else None
+        cam = np.zeros(35)
         out = dict(means3D=np.zeros((N, 3)), means2D=np.zeros((N, 3)), opacities=np.zeros((N, 1)),
                    colors_precomp=np.zeros((N, 3)), shs=np.zeros((N, M, 3)), scales=np.zeros((N, 3)),
                    rotations=np.zeros((N, 4)), cov3D_precomp=np.zeros((N, 6)))
         self.lib.gsr_oracle_backward(self.ctx, _ptr(gc), _ptr(gd), _ptr(ga), _ptr(out["means3D"]),
                                      _ptr(out["means2D"]), _ptr(out["opacities"]),
                                      _ptr(out["colors_precomp"]), _ptr(out["shs"]), _ptr(out["scales"]),
-                                     _ptr(out["rotations"]), _ptr(out["cov3D_precomp"]))
+                                     _ptr(out["rotations"]), _ptr(out["cov3D_precomp"]), _ptr(cam))
+        out["viewmatrix"], out["projmatrix"], out["campos"] = cam[:16].reshape(4, 4), cam[16:32].reshape(4, 4), cam[32:]
         return out
 
     def close(self):

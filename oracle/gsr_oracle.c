@@ -545,7 +545,8 @@ void gsr_oracle_get_geom(const Ctx *c, float *xy, float *depth, float *conic, fl
  * ------------------------------------------------------------------------------------------ */
 void gsr_oracle_backward(const Ctx *c, const float *g_color, const float *g_depth, const float *g_alpha,
                          double *d_means3D, double *d_means2D, double *d_opacity, double *d_colors,
-                         double *d_shs, double *d_scales, double *d_rotations, double *d_cov3D)
+                         double *d_shs, double *d_scales, double *d_rotations, double *d_cov3D,
+                         double *d_camera /* 35 = viewmatrix[16], projmatrix[16], campos[3] (linear order) or NULL */)
 {
     const GsrOracleIn *I = &c->in;
     const int N = I->N, W = I->W, H = I->H, tx = c->tiles_x;
@@ -624,7 +625,12 @@ void gsr_oracle_backward(const Ctx *c, const float *g_color, const float *g_dept
 
     const float *vm = I->viewmatrix, *pm = I->projmatrix;
     const double fx = W / (2 * (double)I->tanfovx), fy = H / (2 * (double)I->tanfovy);
-#pragma omp parallel for schedule(static)
+    if (d_camera) for (int k = 0; k < 35; k++) d_camera[k] = 0;
+#pragma omp parallel
+    {
+    double camloc[35];
+    for (int k = 0; k < 35; k++) camloc[k] = 0;
+#pragma omp for schedule(static)
     for (int i = 0; i < N; i++) {
         double dm[3] = {0, 0, 0};
         if (d_means2D) { d_means2D[3 * (size_t)i] = d_means2D[3 * (size_t)i + 1] = d_means2D[3 * (size_t)i + 2] = 0; }
@@ -700,6 +706,8 @@ void gsr_oracle_backward(const Ctx *c, const float *g_color, const float *g_dept
             /* through v/|v| : (I - d d^T)/|v| */
             double dot = gdir[0] * x + gdir[1] * y + gdir[2] * z;
             dm[0] += (gdir[0] - x * dot) / n; dm[1] += (gdir[1] - y * dot) / n; dm[2] += (gdir[2] - z * dot) / n;
+            /* direction = (p - campos)/|.|  =>  d/dcampos = -d/dp of this term */
+            camloc[32] -= dm[0]; camloc[33] -= dm[1]; camloc[34] -= dm[2];
         }
 
         /* ---- conic -> cov2D ---- */
@@ -753,6 +761,17 @@ void gsr_oracle_backward(const Ctx *c, const float *g_color, const float *g_dept
         double gt2 = -fx * tz2 * gJ00 - fy * tz2 * gJ11 + 2 * fx * t0 * tz3 * gJ02 + 2 * fy * t1 * tz3 * gJ12;
         for (int k = 0; k < 3; k++)
             dm[k] += vm[k * 4 + 0] * gt0 + vm[k * 4 + 1] * gt1 + vm[k * 4 + 2] * gt2;
+        {   /* camera: t = V p_h (rows 0..2, depth feature folded into row 2), rotation block through M = J Wr */
+            double ph[4] = {X, Y, Z, 1.0};
+            double g2 = gt2 + g_z[i];
+            for (int k = 0; k < 4; k++) {
+                camloc[k * 4 + 0] += gt0 * ph[k]; camloc[k * 4 + 1] += gt1 * ph[k]; camloc[k * 4 + 2] += g2 * ph[k];
+            }
+            for (int k = 0; k < 3; k++) {
+                camloc[k * 4 + 0] += gm0[k] * J00; camloc[k * 4 + 1] += gm1[k] * J11;
+                camloc[k * 4 + 2] += gm0[k] * J02 + gm1[k] * J12;
+            }
+        }
 
         /* ---- screen position -> mean ---- */
         double hx = pm[0] * X + pm[4] * Y + pm[8] * Z + pm[12];
@@ -764,6 +783,13 @@ void gsr_oracle_backward(const Ctx *c, const float *g_color, const float *g_dept
         for (int k = 0; k < 3; k++) {
             dm[k] += (pm[k * 4 + 0] * mw - pm[k * 4 + 3] * hx * mw * mw) * gnx +
                      (pm[k * 4 + 1] * mw - pm[k * 4 + 3] * hy * mw * mw) * gny;
+        }
+        {   /* projection matrix rows 0, 1, 3 (row 2 = clip z is unused) */
+            double ph[4] = {X, Y, Z, 1.0};
+            for (int k = 0; k < 4; k++) {
+                camloc[16 + k * 4 + 0] += gnx * mw * ph[k]; camloc[16 + k * 4 + 1] += gny * mw * ph[k];
+                camloc[16 + k * 4 + 3] += -(gnx * hx + gny * hy) * mw * mw * ph[k];
+            }
         }
         /* ---- depth feature = view z ---- */
         for (int k = 0; k < 3; k++) dm[k] += vm[k * 4 + 2] * g_z[i];
@@ -804,6 +830,11 @@ void gsr_oracle_backward(const Ctx *c, const float *g_color, const float *g_dept
             }
         }
     }
+    if (d_camera) {
+#pragma omp critical
+        for (int k = 0; k < 35; k++) d_camera[k] += camloc[k];
+    }
+    } /* omp parallel */
     free(g_xy); free(g_conic); free(g_rgb); free(g_z); free(g_op);
 }
 

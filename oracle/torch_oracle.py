@@ -208,7 +208,8 @@ def render_from_f32(inputs, grads_out=None):
         v = inputs.get(k)
         t[k] = None if v is None else torch.tensor(np.asarray(v, np.float64), requires_grad=True)
     t["means2D"] = torch.zeros(t["means3D"].shape[0], 3, dtype=torch.float64, requires_grad=True)
-    const = {k: torch.tensor(np.asarray(inputs[k], np.float64)) for k in ["viewmatrix", "projmatrix", "campos", "bg"]}
+    const = {k: torch.tensor(np.asarray(inputs[k], np.float64), requires_grad=(k != "bg"))
+             for k in ["viewmatrix", "projmatrix", "campos", "bg"]}
     color, radii, depth, alpha = render(
         t["means3D"], t["opacities"], const["viewmatrix"], const["projmatrix"], const["campos"], const["bg"],
         inputs["image_height"], inputs["image_width"], inputs["tanfovx"], inputs["tanfovy"],
@@ -223,7 +224,7 @@ def render_from_f32(inputs, grads_out=None):
             loss = loss + (depth * gd.reshape(depth.shape)).sum()
         if ga is not None:
             loss = loss + (alpha * ga.reshape(alpha.shape)).sum()
-        leaves = [(k, v) for k, v in t.items() if v is not None]
+        leaves = [(k, v) for k, v in t.items() if v is not None] + [(k, const[k]) for k in ("viewmatrix", "projmatrix", "campos")]
         gs = torch.autograd.grad(loss, [v for _, v in leaves], allow_unused=True)
         out["grads"] = {k: (g.numpy() if g is not None else np.zeros(tuple(v.shape))) for (k, v), g in zip(leaves, gs)}
     return out

@@ -7,8 +7,10 @@ from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianR
 GRAD_KEYS = ["means3D", "opacities", "shs", "colors_precomp", "scales", "rotations", "cov3D_precomp"]
 
 
-def settings_from(kw, dev, noncontig=False):
+def settings_from(kw, dev, noncontig=False, cam_grad=False):
     vm, pm, cp = kw["viewmatrix"].to(dev), kw["projmatrix"].to(dev), kw["campos"].to(dev)
+    if cam_grad:
+        vm, pm, cp = vm.clone().requires_grad_(True), pm.clone().requires_grad_(True), cp.clone().requires_grad_(True)
     if noncontig:  # the reference hands a transpose view and a row slice
         vm = vm.t().contiguous().t()
         cp = torch.stack([cp, cp], 1)[:, 0]
@@ -19,7 +21,7 @@ def settings_from(kw, dev, noncontig=False):
         viewmatrix=vm, projmatrix=pm, sh_degree=int(kw.get("sh_degree", 0)), campos=cp, prefiltered=False, debug=False)
 
 
-def run_hip(kw, grads=None, dev="cuda:0", noncontig=False):
+def run_hip(kw, grads=None, dev="cuda:0", noncontig=False, cam_grad=False):
     dev = torch.device(dev)
     t = {}
     for k in GRAD_KEYS:
@@ -27,7 +29,8 @@ def run_hip(kw, grads=None, dev="cuda:0", noncontig=False):
         t[k] = None if v is None else v.detach().to(dev).float().requires_grad_(grads is not None)
     N = t["means3D"].shape[0]
     m2d = torch.zeros(N, 3, device=dev, requires_grad=grads is not None)
-    rast = GaussianRasterizer(settings_from(kw, dev, noncontig))
+    rs = settings_from(kw, dev, noncontig, cam_grad and grads is not None)
+    rast = GaussianRasterizer(rs)
     color, radii, depth, alpha = rast(means3D=t["means3D"], means2D=m2d, shs=t["shs"], colors_precomp=t["colors_precomp"],
                                       opacities=t["opacities"], scales=t["scales"], rotations=t["rotations"],
                                       cov3D_precomp=t["cov3D_precomp"])
@@ -45,5 +48,7 @@ def run_hip(kw, grads=None, dev="cuda:0", noncontig=False):
             return (v.grad if v.grad is not None else torch.zeros_like(v)).detach().cpu().numpy()
         g = {k: _g(v) for k, v in t.items() if v is not None}
         g["means2D"] = _g(m2d)
+        if cam_grad:
+            g["viewmatrix"], g["projmatrix"], g["campos"] = _g(rs.viewmatrix), _g(rs.projmatrix), _g(rs.campos)
         out["grads"] = g
     return out

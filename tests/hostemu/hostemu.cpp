@@ -125,8 +125,10 @@ int64_t hostemu_num_rendered(EmuCtx* c) { return (int64_t)c->list.size(); }
 
 void hostemu_backward(EmuCtx* c, const float* g_color, const float* g_depth, const float* g_alpha, float* d_means3D,
                       float* d_means2D, float* d_opacity, float* d_colors, float* d_shs, float* d_scales,
-                      float* d_rotations, float* d_cov3D)
+                      float* d_rotations, float* d_cov3D, float* d_camera /* 35 or null */)
 {
+    double camacc[35];
+    for (int k = 0; k < 35; k++) camacc[k] = 0;
     const EmuIn& in = c->in;
     const Camera& cam = c->cam;
     const int N = in.N, W = in.W, H = in.H;
@@ -166,19 +168,26 @@ void hostemu_backward(EmuCtx* c, const float* g_color, const float* g_depth, con
         if (s.radius <= 0) continue;
         const PairGrad& g = gg[i];
         GaussGrads o;
+        CamGrads cg;
         gauss_backward(cam, in.means3D + 3 * (size_t)i, in.scales ? in.scales + 3 * (size_t)i : nullptr,
                        in.rotations ? in.rotations + 4 * (size_t)i : nullptr,
-                       in.cov3D_precomp ? in.cov3D_precomp + 6 * (size_t)i : nullptr, g.gx, g.gy, g.gA, g.gB, g.gC, g.gz, o);
+                       in.cov3D_precomp ? in.cov3D_precomp + 6 * (size_t)i : nullptr, g.gx, g.gy, g.gA, g.gB, g.gC, g.gz, o, &cg);
         float dmean[3] = {o.mean[0], o.mean[1], o.mean[2]};
         const float grgb[3] = {g.gr, g.gg, g.gb};
-        if (in.shs) sh_backward(cam, in.means3D + 3 * (size_t)i, in.shs + (size_t)i * in.M * 3, 3, 1, grgb, dsh, 3, 1, dmean);
+        if (in.shs) {
+            sh_backward(cam, in.means3D + 3 * (size_t)i, in.shs + (size_t)i * in.M * 3, 3, 1, grgb, dsh, 3, 1, dmean);
+            for (int k = 0; k < 3; k++) cg.cam[k] = o.mean[k] - dmean[k];
+        }
         else for (int k = 0; k < 3; k++) d_colors[3 * i + k] = grgb[k];
+        for (int k = 0; k < 16; k++) { camacc[k] += cg.vm[k]; camacc[16 + k] += cg.pm[k]; }
+        for (int k = 0; k < 3; k++) camacc[32 + k] += cg.cam[k];
         for (int k = 0; k < 3; k++) d_means3D[3 * i + k] = dmean[k];
         d_means2D[3 * i] = o.mean2d[0]; d_means2D[3 * i + 1] = o.mean2d[1];
         d_opacity[i] = g.gop;
         if (in.cov3D_precomp) { for (int k = 0; k < 6; k++) d_cov3D[6 * i + k] = o.cov[k]; }
         else { for (int k = 0; k < 3; k++) d_scales[3 * i + k] = o.scale[k]; for (int k = 0; k < 4; k++) d_rotations[4 * i + k] = o.rot[k]; }
     }
+    if (d_camera) for (int k = 0; k < 35; k++) d_camera[k] = (float)camacc[k];
 }
 
 void hostemu_free(EmuCtx* c) { delete c; }

@@ -109,7 +109,7 @@ def hostemu_lib():
         lib = C.CDLL(so)
         lib.hostemu_forward.restype = C.c_void_p
         lib.hostemu_forward.argtypes = [C.POINTER(binding.GsrOracleIn)] + [C.c_void_p] * 4
-        lib.hostemu_backward.argtypes = [C.c_void_p] * 12
+        lib.hostemu_backward.argtypes = [C.c_void_p] * 13
         lib.hostemu_free.argtypes = [C.c_void_p]
         lib.hostemu_num_rendered.restype = C.c_int64
         lib.hostemu_num_rendered.argtypes = [C.c_void_p]
@@ -132,8 +132,10 @@ def hostemu_run(oracle: "binding.OracleRender", grads=None):
                  opacities=np.zeros((N, 1), np.float32), colors_precomp=np.zeros((N, 3), np.float32),
                  shs=np.zeros((N, M, 3), np.float32), scales=np.zeros((N, 3), np.float32),
                  rotations=np.zeros((N, 4), np.float32), cov3D_precomp=np.zeros((N, 6), np.float32))
+        cam = np.zeros(35, np.float32)
         lib.hostemu_backward(ctx, p(gc), p(gd), p(ga), p(g["means3D"]), p(g["means2D"]), p(g["opacities"]),
-                             p(g["colors_precomp"]), p(g["shs"]), p(g["scales"]), p(g["rotations"]), p(g["cov3D_precomp"]))
+                             p(g["colors_precomp"]), p(g["shs"]), p(g["scales"]), p(g["rotations"]), p(g["cov3D_precomp"]), p(cam))
+        g["viewmatrix"], g["projmatrix"], g["campos"] = cam[:16].reshape(4, 4), cam[16:32].reshape(4, 4), cam[32:]
         out["grads"] = g
     lib.hostemu_free(ctx)
     return out

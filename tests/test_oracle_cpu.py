@@ -68,6 +68,9 @@ def test_kernel_arithmetic_on_host_vs_oracle(N, W, H, deg, posed, mode):
     emu = parity.hostemu_run(o, (gc, gd, ga))
     parity.check_forward(emu["fwd"], o, "hostemu")
     got = {k: v for k, v in emu["grads"].items() if kw.get(k) is not None or k in ("means2D", "opacities", "means3D")}
+    got["viewmatrix"], got["projmatrix"] = emu["grads"]["viewmatrix"], emu["grads"]["projmatrix"]
+    if mode == "sh":
+        got["campos"] = emu["grads"]["campos"]
     parity.check_grads(got, ref, "hostemu")
 
 
