@@ -59,6 +59,7 @@ EXPORTS = [
     "gsr_mark_visible", "gsr_last_error", "gsr_version", "gsr_set_option", "gsr_sort_pairs_u32",
     "gsr_sort_pairs_u16", "gsr_sort_scratch_bytes", "gsr_image_staged_offset", "gsr_profile_read",
     "gsr_loss_workspace_bytes", "gsr_loss_forward", "gsr_loss_backward", "gsr_adam_step",
+    "gsr_knn_scratch_bytes", "gsr_knn_mean_dist2",
 ]
 
 _lib = None
@@ -91,6 +92,10 @@ def load():
     lib.gsr_loss_backward.restype = C.c_int
     lib.gsr_loss_backward.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.gsr_knn_scratch_bytes.restype = C.c_size_t
+    lib.gsr_knn_scratch_bytes.argtypes = [C.c_int32]
+    lib.gsr_knn_mean_dist2.restype = C.c_int
+    lib.gsr_knn_mean_dist2.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.gsr_adam_step.restype = C.c_int
     lib.gsr_adam_step.argtypes = [C.POINTER(GsrAdamTensor), C.c_int32, C.c_float, C.c_float, C.c_float, C.c_int64, C.c_void_p]
     lib.gsr_binning_bytes.restype = C.c_size_t

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_hist(const KeyT* __restr
 
 // grid = 256 (one workgroup per digit).  hist[d][*] -> exclusive prefix over blocks, plus the
 // exclusive prefix over the totals of digits < d (totals[] accumulated by k_radix_hist).
-__global__ __launch_bounds__(256) void k_radix_scan(uint32_t* __restrict__ hist, uint32_t nblocks,
+static __global__ __launch_bounds__(256) void k_radix_scan(uint32_t* __restrict__ hist, uint32_t nblocks,
                                                     const uint32_t* __restrict__ totals)
 {
     __shared__ uint32_t s_part[256];

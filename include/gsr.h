@@ -167,6 +167,13 @@ typedef struct GsrAdamTensor {
 int gsr_adam_step(const GsrAdamTensor* tensors, int32_t count, float beta1, float beta2, float eps, int64_t step,
                   void* stream);
 
+/* ---- "next" row f-1: simple_knn._C.distCUDA2 ----------------------------------------------------------------
+ * out[i] = mean of the squared distances from points[i] to its 3 nearest other points (exact), the semantics of the
+ * reference's SciPy twin /root/reference/scene/gaussian_model_ht.py:31-36; called at :211-216. */
+size_t gsr_knn_scratch_bytes(int32_t N);
+int gsr_knn_mean_dist2(const float* points /*[N,3]*/, int32_t N, float* out /*[N]*/, void* scratch, size_t scratch_bytes,
+                       void* stream);
+
 /* Building blocks exported for the unit tests of tests/test_gpu_blocks.py (device pointers). */
 int gsr_sort_pairs_u32(uint32_t* keys, uint32_t* vals, uint32_t* keys_alt, uint32_t* vals_alt, uint32_t n,
                        int begin_bit, int end_bit, void* scratch, size_t scratch_bytes, int* result_in_alt,

@@ -1,28 +1,32 @@
-"""`distCUDA2(points[N,3]) -> [N]`: mean squared distance to the 3 nearest neighbours.
+"""`distCUDA2(points[N,3]) -> [N]`: mean squared distance to the 3 nearest neighbours, on the MI355X.
 
-Semantics pinned by the reference's own SciPy twin (/root/reference/scene/gaussian_model_ht.py:31-36:
-KDTree.query(k=4), drop self, mean of squared distances).  SURVEY.md section 8f ranks a hand-written HIP
-kernel (Morton sort + windowed 3-NN) as the first "next" row; until then this runs as exact brute-force
-k-NN in chunked torch ops ON THE GPU (no CPU fallback: a non-device tensor raises).
+Drop-in for the reference's un-vendored `simple_knn._C` (/root/reference/.gitmodules:1-3), imported at
+/root/reference/scene/gaussian_model_ht.py:20 and called at :211-216.  Semantics pinned by the reference's own
+SciPy twin (:31-36: KDTree.query(k=4), drop self, mean of squared distances).  Exact 3-NN in hand-written HIP
+(csrc/knn_kernels.hip: Morton sort + per-box AABB pruning) behind the C ABI `gsr_knn_mean_dist2`.
+No CPU fallback: a non-device tensor raises.
 """
+import ctypes as C
+import importlib
+
 import torch
+
+_L = importlib.import_module("3dgs_hierarchical_training_amd._lib")
 
 
 def distCUDA2(points: torch.Tensor) -> torch.Tensor:
     if points.device.type != "cuda":
-        raise RuntimeError("distCUDA2: points must be on a ROCm/HIP device")
+        raise RuntimeError("distCUDA2: points must be on a ROCm/HIP device (no CPU fallback)")
+    lib = _L.load()
     p = points.detach().float().contiguous()
     n = p.shape[0]
     out = torch.empty(n, dtype=torch.float32, device=p.device)
     if n == 0:
         return out
-    sq = (p * p).sum(1)
-    chunk = max(1, min(n, (1 << 28) // max(n, 1)))  # <= 1 GiB of fp32 distances per chunk
-    k = min(4, n)
-    for s in range(0, n, chunk):
-        q = p[s:s + chunk]
-        d2 = (sq[s:s + chunk, None] + sq[None, :] - 2.0 * (q @ p.t())).clamp_min_(0.0)
-        d2[torch.arange(q.shape[0], device=p.device), torch.arange(s, s + q.shape[0], device=p.device)] = 0.0
-        nn = torch.topk(d2, k, dim=1, largest=False).values[:, 1:]
-        out[s:s + chunk] = nn.mean(1) if k > 1 else 0.0
+    sb = lib.gsr_knn_scratch_bytes(n)
+    scratch = torch.empty(sb, dtype=torch.uint8, device=p.device)
+    with torch.cuda.device(p.device):
+        st = torch.cuda.current_stream(p.device).cuda_stream
+        _L.check(lib.gsr_knn_mean_dist2(p.data_ptr(), n, out.data_ptr(), scratch.data_ptr(), sb, C.c_void_p(st)),
+                 "gsr_knn_mean_dist2")
     return out
