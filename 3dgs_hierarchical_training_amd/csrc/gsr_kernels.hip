@@ -139,8 +139,18 @@ __device__ __forceinline__ float wave_reduce_transposed(const float* v, int lane
     const float o07 = bfly_pair<0x124>(q03, q47, b2);
     const float o8 = bfly_single<0x124>(q8);
     float t = bfly_pair<0x128>(o07, o8, b3);
-    t += __shfl_xor(t, 16, 64);
-    t += __shfl_xor(t, 32, 64);
+    // cross-row: gfx950 row / half swaps keep the whole reduction in the VALU (ds_bpermute would put two LDS round
+    // trips on the dependency chain of every (wave, Gaussian))
+    {
+        const unsigned u = __float_as_uint(t);
+        const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);   // rows (0,1) and (2,3) exchange
+        t = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    {
+        const unsigned u = __float_as_uint(t);
+        const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);   // halves exchange
+        t = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
     return t;
 }
 

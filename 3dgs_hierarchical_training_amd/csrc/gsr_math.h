@@ -312,12 +312,14 @@ GSR_HD void preprocess_one(const Camera& c, const float mean[3], const float* sc
     if (color_pre) {
         col[0] = color_pre[0]; col[1] = color_pre[1]; col[2] = color_pre[2];
     } else {
-        RT dx = X - c.cam[0], dy = Y - c.cam[1], dz = Z - c.cam[2];
-        const RT inv_n = 1 / sqrt(dx * dx + dy * dy + dz * dz);
+        // colour enters the image linearly, so binary32 is enough here (relative error ~1e-7); only the geometry
+        // above (conic = inverse of a nearly singular 2x2, pixel position) needs the float64 evaluation
+        float dx = mean[0] - c.cam[0], dy = mean[1] - c.cam[1], dz = mean[2] - c.cam[2];
+        const float inv_n = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
         dx *= inv_n; dy *= inv_n; dz *= inv_n;
         for (int ch = 0; ch < 3; ch++) {
-            const RT v = sh_channel<RT>(c.D, sh + ch * sh_cstride, sh_kstride, dx, dy, dz) + (RT)0.5;
-            col[ch] = v < 0 ? 0.f : (float)v;
+            const float v = sh_channel<float>(c.D, sh + ch * sh_cstride, sh_kstride, dx, dy, dz) + 0.5f;
+            col[ch] = v < 0.f ? 0.f : v;
         }
     }
     out.px = px; out.py = py;
