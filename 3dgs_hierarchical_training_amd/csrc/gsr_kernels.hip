@@ -30,6 +30,9 @@ namespace gsr {
 static thread_local char g_err[512] = "";
 static int g_blend_ppt = 0;   // 0 = default
 static int g_bwd_ppt = 0;
+// 1 (default) = onesweep (decoupled look-back) for the depth sort over N, histogram+scan+scatter for the tile
+// sort over R (measured: 115 vs 140 us and 164 vs 157 us); 0 = three-kernel passes everywhere; 2 = onesweep everywhere
+static int g_sort_algo = 1;
 
 static int fail(int code, const char* fmt, const char* detail = "")
 {
@@ -1242,6 +1245,7 @@ int gsr_set_option(const char* name, int value)
     if (!name) return GSR_ERR_ARG;
     if (!strcmp(name, "blend_fwd_ppt")) { if (value < 0 || value > 4) return GSR_ERR_ARG; g_blend_ppt = value; return GSR_OK; }
     if (!strcmp(name, "profile")) { g_profile = value ? 1 : 0; return GSR_OK; }
+    if (!strcmp(name, "sort_algo")) { if (value < 0 || value > 2) return GSR_ERR_ARG; g_sort_algo = value; return GSR_OK; }
     // 2 = packed-math kernel (default), 3 = scalar 2-pixel kernel (kept for A/B), 1 / 4 = scalar 1 / 4 pixels
     if (!strcmp(name, "blend_bwd_ppt")) { if (value < 0 || value > 4) return GSR_ERR_ARG; g_bwd_ppt = value; return GSR_OK; }
     return GSR_ERR_ARG;
@@ -1298,7 +1302,8 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
         int in_alt = 0;
         {
             ProfScope ps(P_SORT_DEPTH, st);
-            GSR_HIP(radix_sort_pairs<uint32_t>(dkey, gid, dkey_alt, gid_alt, (uint32_t)N, 0, 32, fs + L.sort, &in_alt, st));
+            GSR_HIP(g_sort_algo ? onesweep_sort_pairs<uint32_t>(dkey, gid, dkey_alt, gid_alt, (uint32_t)N, 0, 32, fs + L.sort, &in_alt, st)
+                                : radix_sort_pairs<uint32_t>(dkey, gid, dkey_alt, gid_alt, (uint32_t)N, 0, 32, fs + L.sort, &in_alt, st));
         }
         sorted_gid = in_alt ? gid_alt : gid;
         const int nb = (N + kEmitThreads - 1) / kEmitThreads;
@@ -1345,7 +1350,8 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
         int in_alt = 0;
         {
             ProfScope ps(P_SORT_TILE, st);
-            GSR_HIP(radix_sort_pairs<uint16_t>(tkey, v0, tkey_alt, v1, (uint32_t)R, 0, passes * 8, bs + S.sort, &in_alt, st));
+            GSR_HIP(g_sort_algo == 2 ? onesweep_sort_pairs<uint16_t>(tkey, v0, tkey_alt, v1, (uint32_t)R, 0, passes * 8, bs + S.sort, &in_alt, st)
+                                : radix_sort_pairs<uint16_t>(tkey, v0, tkey_alt, v1, (uint32_t)R, 0, passes * 8, bs + S.sort, &in_alt, st));
         }
         const uint16_t* skey = in_alt ? tkey_alt : tkey;
         {
@@ -1455,7 +1461,10 @@ int gsr_sort_pairs_u32(uint32_t* keys, uint32_t* vals, uint32_t* keys_alt, uint3
                        void* scratch, size_t scratch_bytes, int* result_in_alt, void* stream)
 {
     if (scratch_bytes < radix_scratch_bytes(n) || !result_in_alt) return fail(GSR_ERR_ARG, "sort scratch too small%s");
-    GSR_HIP(radix_sort_pairs<uint32_t>(keys, vals, keys_alt, vals_alt, n, begin_bit, end_bit, scratch, result_in_alt, (hipStream_t)stream));
+    if (g_sort_algo && end_bit - begin_bit <= 32)
+        GSR_HIP(onesweep_sort_pairs<uint32_t>(keys, vals, keys_alt, vals_alt, n, begin_bit, end_bit, scratch, result_in_alt, (hipStream_t)stream));
+    else
+        GSR_HIP(radix_sort_pairs<uint32_t>(keys, vals, keys_alt, vals_alt, n, begin_bit, end_bit, scratch, result_in_alt, (hipStream_t)stream));
     return GSR_OK;
 }
 
@@ -1463,7 +1472,10 @@ int gsr_sort_pairs_u16(uint16_t* keys, uint32_t* vals, uint16_t* keys_alt, uint3
                        void* scratch, size_t scratch_bytes, int* result_in_alt, void* stream)
 {
     if (scratch_bytes < radix_scratch_bytes(n) || !result_in_alt) return fail(GSR_ERR_ARG, "sort scratch too small%s");
-    GSR_HIP(radix_sort_pairs<uint16_t>(keys, vals, keys_alt, vals_alt, n, begin_bit, end_bit, scratch, result_in_alt, (hipStream_t)stream));
+    if (g_sort_algo)
+        GSR_HIP(onesweep_sort_pairs<uint16_t>(keys, vals, keys_alt, vals_alt, n, begin_bit, end_bit, scratch, result_in_alt, (hipStream_t)stream));
+    else
+        GSR_HIP(radix_sort_pairs<uint16_t>(keys, vals, keys_alt, vals_alt, n, begin_bit, end_bit, scratch, result_in_alt, (hipStream_t)stream));
     return GSR_OK;
 }
 

@@ -174,10 +174,201 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const KeyT* __re
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Onesweep variant: one launch per 8-bit pass (+ one launch that histograms ALL passes up front).
+// Each block takes a ticket (= which 4096-key tile it owns, so lower tiles are always already running), ranks
+// its keys exactly as k_radix_scatter does, publishes its per-digit counts and finds its global offsets by
+// decoupled look-back over the earlier tiles' status words.  A status word is ONE 32-bit value
+// {flag:2, count:30} written and polled with relaxed agent-scope atomics (write-through / L1-bypassing on
+// gfx950): the data IS the flag, so no fence is needed (MI355X guide G16, form R2).  Every started block
+// publishes its LOCAL count before it waits on anything, so the look-back can always walk back to tile 0:
+// no circular wait.  Versus hist+scan+scatter this reads the keys once per pass and saves two launches.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t kOsLocal = 1u << 30, kOsIncl = 2u << 30, kOsMask = (1u << 30) - 1u;
+
+template <typename KeyT, int PASSES>
+__global__ __launch_bounds__(256) void k_radix_ghist(const KeyT* __restrict__ keys, uint32_t n, int begin_bit,
+                                                     uint32_t* __restrict__ ghist /*[PASSES][256]*/)
+{
+    __shared__ uint32_t h[PASSES][256];
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int p = 0; p < PASSES; p++) h[p][tid] = 0;
+    __syncthreads();
+    for (uint32_t i = blockIdx.x * 256 + tid; i < n; i += gridDim.x * 256) {
+        const uint32_t k = (uint32_t)keys[i] >> begin_bit;
+#pragma unroll
+        for (int p = 0; p < PASSES; p++) atomicAdd(&h[p][(k >> (8 * p)) & 0xffu], 1u);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < PASSES; p++)
+        if (h[p][tid]) atomicAdd(&ghist[p * 256 + tid], h[p][tid]);
+}
+
+template <typename KeyT>
+__global__ __launch_bounds__(kSortThreads) void k_onesweep(const KeyT* __restrict__ kin, const uint32_t* __restrict__ vin,
+                                                           KeyT* __restrict__ kout, uint32_t* __restrict__ vout, uint32_t n, int shift,
+                                                           const uint32_t* __restrict__ ghist /*[256] this pass*/,
+                                                           uint32_t* __restrict__ status /*[nblocks][256]*/,
+                                                           uint32_t* __restrict__ ticket)
+{
+    __shared__ uint16_t cnt[kSortIPT][kSortWaves][256];
+    __shared__ KeyT s_keys[kSortTile];
+    __shared__ uint32_t s_vals[kSortTile];
+    __shared__ uint32_t s_start[256];
+    __shared__ uint32_t s_gbase[256];
+    __shared__ uint32_t s_scan[256];
+    __shared__ uint32_t s_tile;
+    const int tid = threadIdx.x, wave = tid >> 6;
+    if (tid == 0) s_tile = atomicAdd(ticket, 1u);
+    {
+        uint32_t* z = reinterpret_cast<uint32_t*>(&cnt[0][0][0]);
+#pragma unroll
+        for (int k = 0; k < (kSortIPT * kSortWaves * 256 / 2) / kSortThreads; k++) z[k * kSortThreads + tid] = 0u;
+    }
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    const uint32_t base = tile * (uint32_t)kSortTile;
+    const uint32_t valid = min((uint32_t)kSortTile, n - base);
+    KeyT key[kSortIPT];
+    uint32_t val[kSortIPT], dig[kSortIPT], rnk[kSortIPT];
+#pragma unroll
+    for (int r = 0; r < kSortIPT; r++) {
+        const uint32_t p = r * kSortThreads + tid;
+        if (p < valid) {
+            key[r] = kin[base + p];
+            val[r] = vin[base + p];
+            dig[r] = ((uint32_t)key[r] >> shift) & 0xffu;
+        } else {
+            key[r] = (KeyT)~(KeyT)0; val[r] = 0u; dig[r] = 255u;
+        }
+    }
+    const unsigned long long lt = lanemask_lt();
+#pragma unroll
+    for (int r = 0; r < kSortIPT; r++) {
+        unsigned long long peers = ~0ull;
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const bool bit = (dig[r] >> b) & 1u;
+            const unsigned long long m = __ballot(bit);
+            peers &= bit ? m : ~m;
+        }
+        rnk[r] = (uint32_t)__popcll(peers & lt);
+        if (rnk[r] == 0) cnt[r][wave][dig[r]] = (uint16_t)__popcll(peers);
+    }
+    __syncthreads();
+    uint32_t mine;   // this tile's count of digit `tid` (padding counted in digit 255; removed below)
+    {
+        uint32_t run = 0;
+#pragma unroll
+        for (int r = 0; r < kSortIPT; r++)
+#pragma unroll
+            for (int w = 0; w < kSortWaves; w++) {
+                const uint32_t c = cnt[r][w][tid];
+                cnt[r][w][tid] = (uint16_t)run;
+                run += c;
+            }
+        mine = run;
+    }
+    const uint32_t real = (tid == 255) ? mine - ((uint32_t)kSortTile - valid) : mine;   // real keys of this digit
+    uint32_t* my_status = status + (size_t)tile * 256 + tid;
+    __hip_atomic_store(my_status, kOsLocal | real, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // local exclusive start of each digit (block scan of `mine`) and digit base (block scan of the global histogram)
+    s_start[tid] = mine;
+    s_scan[tid] = ghist[tid];
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const uint32_t v = (tid >= off) ? s_start[tid - off] : 0u;
+        const uint32_t g = (tid >= off) ? s_scan[tid - off] : 0u;
+        __syncthreads();
+        s_start[tid] += v; s_scan[tid] += g;
+        __syncthreads();
+    }
+    const uint32_t lstart = s_start[tid] - mine;
+    const uint32_t dbase = s_scan[tid] - ghist[tid];
+    // decoupled look-back over earlier tiles
+    uint32_t excl = 0;
+    for (int t = (int)tile - 1; t >= 0;) {
+        const uint32_t v = __hip_atomic_load(status + (size_t)t * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t f = v & ~kOsMask;
+        if (f == 0u) { __builtin_amdgcn_s_sleep(1); continue; }
+        excl += v & kOsMask;
+        if (f == kOsIncl) break;
+        t--;
+    }
+    __hip_atomic_store(my_status, kOsIncl | (excl + real), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    s_start[tid] = lstart;
+    s_gbase[tid] = dbase + excl - lstart;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kSortIPT; r++) {
+        const uint32_t lp = s_start[dig[r]] + cnt[r][wave][dig[r]] + rnk[r];
+        s_keys[lp] = key[r];
+        s_vals[lp] = val[r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kSortIPT; r++) {
+        const uint32_t p = r * kSortThreads + tid;
+        if (p < valid) {
+            const KeyT k = s_keys[p];
+            const uint32_t d = ((uint32_t)k >> shift) & 0xffu;
+            const uint32_t g = s_gbase[d] + p;
+            kout[g] = k;
+            vout[g] = s_vals[p];
+        }
+    }
+}
+
+inline size_t onesweep_scratch_bytes(uint32_t n)
+{
+    const size_t nblocks = ((size_t)n + kSortTile - 1) / kSortTile;
+    // ghist[4][256] + tickets[4] (padded) + status[4 passes][nblocks][256]
+    return ((4 * 256 + 64 + 4 * (nblocks ? nblocks : 1) * 256) * sizeof(uint32_t) + 255) & ~(size_t)255;
+}
+
+// begin_bit..end_bit in 8-bit passes (at most 4).  Same contract as radix_sort_pairs.
+template <typename KeyT>
+inline hipError_t onesweep_sort_pairs(KeyT* keys, uint32_t* vals, KeyT* keys_alt, uint32_t* vals_alt, uint32_t n, int begin_bit,
+                                      int end_bit, void* scratch, int* in_alt, hipStream_t stream)
+{
+    *in_alt = 0;
+    if (n == 0) return hipSuccess;
+    const int passes = (end_bit - begin_bit + 7) / 8;
+    if (passes < 1 || passes > 4) return hipErrorInvalidValue;
+    const uint32_t nblocks = (n + kSortTile - 1) / kSortTile;
+    uint32_t* ghist = static_cast<uint32_t*>(scratch);
+    uint32_t* tickets = ghist + 4 * 256;
+    uint32_t* status = tickets + 64;
+    hipError_t e = hipMemsetAsync(scratch, 0, (4 * 256 + 64 + (size_t)passes * nblocks * 256) * sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    const uint32_t hgrid = nblocks < 128u ? nblocks : 128u;
+    switch (passes) {
+        case 1: hipLaunchKernelGGL((k_radix_ghist<KeyT, 1>), dim3(hgrid), dim3(256), 0, stream, keys, n, begin_bit, ghist); break;
+        case 2: hipLaunchKernelGGL((k_radix_ghist<KeyT, 2>), dim3(hgrid), dim3(256), 0, stream, keys, n, begin_bit, ghist); break;
+        case 3: hipLaunchKernelGGL((k_radix_ghist<KeyT, 3>), dim3(hgrid), dim3(256), 0, stream, keys, n, begin_bit, ghist); break;
+        default: hipLaunchKernelGGL((k_radix_ghist<KeyT, 4>), dim3(hgrid), dim3(256), 0, stream, keys, n, begin_bit, ghist); break;
+    }
+    KeyT *kin = keys, *kout = keys_alt;
+    uint32_t *vin = vals, *vout = vals_alt;
+    for (int p = 0; p < passes; p++) {
+        hipLaunchKernelGGL(k_onesweep<KeyT>, dim3(nblocks), dim3(kSortThreads), 0, stream, kin, vin, kout, vout, n, begin_bit + 8 * p,
+                           ghist + p * 256, status + (size_t)p * nblocks * 256, tickets + p);
+        KeyT* tk = kin; kin = kout; kout = tk;
+        uint32_t* tv = vin; vin = vout; vout = tv;
+        *in_alt ^= 1;
+    }
+    return hipGetLastError();
+}
+
 inline size_t radix_scratch_bytes(uint32_t n)
 {
     const size_t nblocks = ((size_t)n + kSortTile - 1) / kSortTile;
-    return ((256 * (nblocks ? nblocks : 1) + 8 * 256) * sizeof(uint32_t) + 255) & ~(size_t)255;   // hist + totals[8 passes]
+    const size_t three_kernel = ((256 * (nblocks ? nblocks : 1) + 8 * 256) * sizeof(uint32_t) + 255) & ~(size_t)255;   // hist + totals
+    const size_t onesweep = ((4 * 256 + 64 + 4 * (nblocks ? nblocks : 1) * 256) * sizeof(uint32_t) + 255) & ~(size_t)255;
+    return three_kernel > onesweep ? three_kernel : onesweep;
 }
 
 // Sorts bits [begin_bit, end_bit) in 8-bit passes, ping-ponging between (keys,vals) and (keys_alt,vals_alt).

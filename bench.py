@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fwd-ppt", type=int, default=0)
     ap.add_argument("--bwd-ppt", type=int, default=0)
+    ap.add_argument("--sort-algo", type=int, default=-1, help="1 = onesweep (default), 0 = hist+scan+scatter per pass")
     return ap.parse_args()
 
 
@@ -103,6 +104,8 @@ def main():
         lib.gsr_set_option(b"blend_fwd_ppt", args.fwd_ppt)
     if args.bwd_ppt:
         lib.gsr_set_option(b"blend_bwd_ppt", args.bwd_ppt)
+    if args.sort_algo >= 0:
+        lib.gsr_set_option(b"sort_algo", args.sort_algo)
 
     N, W, H, deg = args.gaussians, args.width, args.height, args.sh_degree
     scene = syn.make_scene(N, W, H, sh_degree=deg, seed=rank)

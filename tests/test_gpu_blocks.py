@@ -10,6 +10,14 @@ pytestmark = pytest.mark.gpu
 L = importlib.import_module("3dgs_hierarchical_training_amd._lib")
 
 
+@pytest.fixture(params=[0, 2], ids=["three-kernel", "onesweep"], autouse=True)
+def sort_algo(request):
+    lib = L.load()
+    lib.gsr_set_option(b"sort_algo", request.param)
+    yield request.param
+    lib.gsr_set_option(b"sort_algo", 1)
+
+
 def _sort(keys, vals, bits, u16=False):
     lib = L.load()
     dev = torch.device("cuda:0")
