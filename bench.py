@@ -165,8 +165,20 @@ def main():
     blend_ms = stage_ms["blend_fwd"]
     alg_bytes = 44.0 * R_eff + 28.0 * P + 8.0 * T
     achieved = (alg_bytes / (blend_ms * 1e-3) / 1e9) if blend_ms else None
+    # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950
+    # read-side x2 correction; tools/pmc_profile.sh + tools/pmc_summary.py).  PMC collection cannot run inside this
+    # process, so the figure is taken from the committed summary when it was measured on this very workload.
+    traffic = None
+    pmc_file = os.path.join(REPO, "profiles", "r01_pmc_blend.json")
+    if (N, W, H, deg) == (1_000_000, 980, 545, 3) and os.path.exists(pmc_file):
+        try:
+            ks = json.load(open(pmc_file))["kernels"]
+            traffic = next(v["hbm_traffic_bytes"] for k, v in ks.items() if "k_blend_fwd" in k)
+        except Exception:
+            traffic = None
     roofline = {"kernel": "k_blend_fwd", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+                "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+                "traffic_source": "profiles/r01_pmc_blend.json (rocprofv3 --pmc, separate passes)" if traffic else None,
                 "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": blend_ms,
                 "launches_timed": prof["blend_fwd"][1], "R": R, "R_eff": R_eff, "P": P, "T": T}
     res = {
