@@ -137,6 +137,56 @@ def test_camera_gradients(case):
     print(rep)
 
 
+@pytest.mark.parametrize("M,deg", [(1, 0), (4, 1), (9, 2), (16, 2)])
+def test_fewer_stored_sh_coefficients(M, deg):
+    """max_sh_degree below 3: shs is [N,M,3] with M = (max_deg+1)^2 (gaussian_model_ht.py:193-199)."""
+    import hip_runner
+    N, W, H = 8000, 200, 150
+    sc = parity.syn.make_scene(N, W, H, sh_degree=deg, seed=21, posed=True)
+    sc["shs"] = sc["shs"][:, :M].contiguous()
+    kw = parity.scene_kwargs(sc, "sh", bg=(0.1, 0.1, 0.1))
+    o = binding.OracleRender(**kw)
+    o.forward()
+    gc, gd, ga = parity.upstream_grads(H, W, seed=2)
+    keep = o.px_ambig == 0
+    gc *= keep[None]; gd *= keep; ga *= keep
+    ref = o.backward(gc, gd, ga)
+    out = hip_runner.run_hip(kw, (gc, gd, ga))
+    parity.check_forward(out["fwd"], o, f"M={M}")
+    assert out["grads"]["shs"].shape == (N, M, 3)
+    parity.check_grads(out["grads"], ref, f"M={M}")
+
+
+def test_scale_modifier():
+    import hip_runner
+    N, W, H = 10000, 256, 192
+    sc = parity.syn.make_scene(N, W, H, sh_degree=3, seed=22, posed=True)
+    sc["scale_modifier"] = 0.7
+    kw = parity.scene_kwargs(sc, "sh")
+    o = binding.OracleRender(**kw)
+    o.forward()
+    gc, gd, ga = parity.upstream_grads(H, W, seed=2)
+    keep = o.px_ambig == 0
+    gc *= keep[None]; gd *= keep; ga *= keep
+    ref = o.backward(gc, gd, ga)
+    out = hip_runner.run_hip(kw, (gc, gd, ga))
+    parity.check_forward(out["fwd"], o, "scale_modifier")
+    parity.check_grads(out["grads"], ref, "scale_modifier")
+
+
+def test_mark_visible():
+    import hip_runner
+    from diff_gaussian_rasterization import GaussianRasterizer
+    dev = torch.device("cuda:0")
+    sc = parity.syn.make_scene(5000, 128, 96, sh_degree=0, seed=23, posed=True, frac_behind=0.3)
+    kw = parity.scene_kwargs(sc, "sh")
+    o = binding.OracleRender(**kw)
+    o.forward()
+    vis = GaussianRasterizer(hip_runner.settings_from(kw, dev)).markVisible(kw["means3D"].to(dev)).cpu().numpy()
+    assert vis.dtype == np.bool_ and np.array_equal(vis, o.geom()["depth"] > 0.2)
+    assert np.all(vis[o.radii > 0])
+
+
 def test_noncontiguous_settings():
     _run_case(5000, 160, 120, 3, True, "sh", (0.0, 0.0, 0.0), noncontig=True)
 
