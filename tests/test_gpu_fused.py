@@ -75,3 +75,38 @@ def test_train_step_variants_agree():
         lb.append(float(ts.train_step(pb, settings, gt, fused_loss=False, fused_activations=False)["loss"]))
     assert la[-1] < la[0]
     assert np.allclose(la, lb, rtol=2e-4), (la, lb)
+
+
+def test_calc_importance_matches_oracle():
+    """Merge-time pruning score (ht3dgs_trainer.py:1427-1462): |dL/dSH| with grad_out = 1 through clamp(0,1),
+    summed over views, / num_pixels -- against the float64 oracle's backward."""
+    from oracle import binding
+    hier = importlib.import_module("3dgs_hierarchical_training_amd.hierarchy")
+    dev = torch.device("cuda:0")
+    N, W, H = 20000, 320, 240
+    views, ref = [], np.zeros((N, 16, 3))
+    base = parity.syn.make_scene(N, W, H, sh_degree=3, seed=31, posed=False)
+    for s in (1, 2):
+        cam = parity.syn.make_scene(8, W, H, sh_degree=3, seed=100 + s, posed=True)   # only its camera is used
+        sc = dict(base)
+        for k in ("viewmatrix", "projmatrix", "campos", "tanfovx", "tanfovy"):
+            sc[k] = cam[k]
+        views.append(ts.make_settings(sc, dev, 3))
+        kw = parity.scene_kwargs(sc, "sh")
+        o = binding.OracleRender(**kw)
+        color = o.forward()[0]
+        g = ((color >= 0) & (color <= 1)).astype(np.float32)        # d clamp(x,0,1).sum() / dx
+        ref += np.abs(o.backward(g, None, None)["shs"])
+        o.close()
+    ref = ref.reshape(N, 48) / (2 * W * H)
+    p = ts.GaussianParams(base, dev, optimizer="torch")
+    seg = {k: getattr(p, k).detach() for k in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation")}
+    imp = hier.calc_importance(seg, views).cpu().numpy()
+    assert imp.shape == (N, 48)
+    # all-ones upstream gradient on every pixel (ambiguous ones included): a rounding-edge flip moves one
+    # contribution of one pixel, far below the scale of a sum over all pixels
+    assert np.abs(imp - ref).max() <= 1e-3 * ref.max()
+    drop = hier.prune_mask(torch.from_numpy(imp), 0.5)
+    assert int(drop.sum()) == N // 2
+    sc_ref = ref.max(1)
+    assert sc_ref[drop.numpy()].mean() < sc_ref[~drop.numpy()].mean()
