@@ -438,7 +438,7 @@ __global__ __launch_bounds__(256 / PPT) void k_blend_fwd(int W, int H, int tiles
                                                          float* __restrict__ img, uint32_t* __restrict__ staged)
 {
     constexpr int NT = 256 / PPT;
-    __shared__ float4 s_a[2][NT], s_b[2][NT], s_c[2][NT];
+    __shared__ float4 s_a[1][NT], s_b[1][NT], s_c[1][NT];   // single buffer (see k_blend_bwd2): more tiles per CU
     const int tile = xcd_tile(blockIdx.x, T);
     if (tile >= T) return;
     const int tid = threadIdx.x;
@@ -467,7 +467,8 @@ __global__ __launch_bounds__(256 / PPT) void k_blend_fwd(int W, int H, int tiles
     }
     int batches = 0;
     for (int b = 0; b < nb; b++) {
-        const int buf = b & 1;
+        const int buf = 0;
+        if (b) __syncthreads();
         s_a[buf][tid] = ra; s_b[buf][tid] = rb; s_c[buf][tid] = rc;
         bool all_done = true;
 #pragma unroll
@@ -764,8 +765,10 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(int W, int H, int tiles_x, i
                                                     const float* __restrict__ g_alpha, float* __restrict__ ggrad)
 {
     constexpr int NT = 128, NW = 2, NV = HAS_DA ? 10 : 9;
-    __shared__ float4 s_a[2][NT], s_b[2][NT], s_c[2][NT];
-    __shared__ uint32_t s_gid[2][NT];
+    // single staging buffer: a batch is ~10^4 cycles of compute, so the second barrier per batch is free, and the
+    // smaller LDS footprint lets more tiles share a CU (latency hiding: waves were 33% in s_waitcnt / barriers)
+    __shared__ float4 s_a[1][NT], s_b[1][NT], s_c[1][NT];
+    __shared__ uint32_t s_gid[1][NT];
     __shared__ float s_part[NW][NT][NV];
     __shared__ uint32_t s_max[NW];
     const int tile = xcd_tile(blockIdx.x, T);
@@ -820,7 +823,8 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(int W, int H, int tiles_x, i
 #pragma unroll
         for (int k = 0; k < NV; k++) s_part[w][tid][k] = 0.f;   // the flush below re-zeroes what it consumes
     for (int b = 0; b < nb; b++) {
-        const int buf = b & 1;
+        const int buf = 0;
+        if (b) __syncthreads();   // everyone is done reading the previous batch (and its flush read s_gid)
         s_a[buf][tid] = ra; s_b[buf][tid] = rb; s_c[buf][tid] = rc; s_gid[buf][tid] = rg_id;
         __syncthreads();
         const int nxt = (b + 1) * NT + tid;
