@@ -170,6 +170,43 @@ __device__ __forceinline__ float row_sum_to_lane15(float v)
 constexpr int kPreThreads = 128;
 constexpr int kShStride = 49;   // 48 floats + 1 pad: conflict-free column reads
 
+// Coalesced 16-byte streaming of a block's contiguous [nG][ROW] float rows into / out of the padded LDS tile
+// (row stride kShStride, first column `col0`).  Used when the rows are dense in memory (the stored row IS the
+// active row), the block base is 16-byte aligned and nG*ROW is a multiple of 4; otherwise the scalar loops run.
+template <int ROW>
+__device__ __forceinline__ void stage_in_vec(float* s_sh, int col0, const float* __restrict__ src, int nG, int tid)
+{
+    const float4* s4 = reinterpret_cast<const float4*>(src);
+    for (int v = tid; v < (nG * ROW) / 4; v += kPreThreads) {
+        const float4 x = s4[v];
+        const int f = 4 * v;
+        int g = f / ROW, e = f - g * ROW;
+        const float xs[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            s_sh[g * kShStride + col0 + e] = xs[q];
+            if (++e == ROW) { e = 0; g++; }
+        }
+    }
+}
+template <int ROW>
+__device__ __forceinline__ void stage_out_vec(const float* s_sh, int col0, float* __restrict__ dst, int nG, int tid)
+{
+    float4* d4 = reinterpret_cast<float4*>(dst);
+    for (int v = tid; v < (nG * ROW) / 4; v += kPreThreads) {
+        const int f = 4 * v;
+        int g = f / ROW, e = f - g * ROW;
+        float xs[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            xs[q] = s_sh[g * kShStride + col0 + e];
+            if (++e == ROW) { e = 0; g++; }
+        }
+        d4[v] = make_float4(xs[0], xs[1], xs[2], xs[3]);
+    }
+}
+__device__ __forceinline__ bool vec_ok(const void* p, int nfloats) { return (((uintptr_t)p & 15) == 0) && ((nfloats & 3) == 0); }
+
 // ------------------------------------------------------------------------------------------------
 // K1: per-Gaussian projection.  SH rows are staged through LDS with coalesced loads.
 // ------------------------------------------------------------------------------------------------
@@ -195,17 +232,23 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess(CamParams cp, int N,
         const int nG = min(kPreThreads, N - base);
         if (shs_rest) {   // split storage: dc [N,1,3] + rest [N,M-1,3]; two straight, divergence-free streams
             const size_t row = (size_t)(cp.M - 1) * 3;
-            for (int f = tid; f < nG * 3; f += kPreThreads) s_sh[(f / 3) * kShStride + (f % 3)] = shs[(size_t)base * 3 + f];
+            const float* dc0 = shs + (size_t)base * 3;
+            if (vec_ok(dc0, nG * 3)) stage_in_vec<3>(s_sh, 0, dc0, nG, tid);
+            else for (int f = tid; f < nG * 3; f += kPreThreads) s_sh[(f / 3) * kShStride + (f % 3)] = dc0[f];
             if (NC3 > 3) {
                 constexpr int NR = NC3 > 3 ? NC3 - 3 : 1;
-                for (int f = tid; f < nG * NR; f += kPreThreads) {
+                const float* r0 = shs_rest + (size_t)base * row;
+                if (row == NR && vec_ok(r0, nG * NR)) stage_in_vec<NR>(s_sh, 3, r0, nG, tid);
+                else for (int f = tid; f < nG * NR; f += kPreThreads) {
                     const int g = f / NR, e = f - g * NR;
                     s_sh[g * kShStride + 3 + e] = shs_rest[(size_t)(base + g) * row + e];
                 }
             }
         } else {
             const size_t row = (size_t)cp.M * 3;
-            for (int f = tid; f < nG * NC3; f += kPreThreads) {
+            const float* r0 = shs + (size_t)base * row;
+            if (row == NC3 && vec_ok(r0, nG * NC3)) stage_in_vec<NC3>(s_sh, 0, r0, nG, tid);
+            else for (int f = tid; f < nG * NC3; f += kPreThreads) {
                 const int g = f / NC3, e = f - g * NC3;
                 s_sh[g * kShStride + e] = shs[(size_t)(base + g) * row + e];
             }
@@ -940,17 +983,23 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, in
     if (shs) {
         if (shs_rest) {
             const size_t row = (size_t)(cp.M - 1) * 3;
-            for (int f = tid; f < nG * 3; f += kPreThreads) s_sh[(f / 3) * kShStride + (f % 3)] = shs[(size_t)base * 3 + f];
+            const float* dc0 = shs + (size_t)base * 3;
+            if (vec_ok(dc0, nG * 3)) stage_in_vec<3>(s_sh, 0, dc0, nG, tid);
+            else for (int f = tid; f < nG * 3; f += kPreThreads) s_sh[(f / 3) * kShStride + (f % 3)] = dc0[f];
             if (NC3 > 3) {
                 constexpr int NR = NC3 > 3 ? NC3 - 3 : 1;
-                for (int f = tid; f < nG * NR; f += kPreThreads) {
+                const float* r0 = shs_rest + (size_t)base * row;
+                if (row == NR && vec_ok(r0, nG * NR)) stage_in_vec<NR>(s_sh, 3, r0, nG, tid);
+                else for (int f = tid; f < nG * NR; f += kPreThreads) {
                     const int g = f / NR, e = f - g * NR;
                     s_sh[g * kShStride + 3 + e] = shs_rest[(size_t)(base + g) * row + e];
                 }
             }
         } else {
             const size_t row = (size_t)cp.M * 3;
-            for (int f = tid; f < nG * NC3; f += kPreThreads) {
+            const float* r0 = shs + (size_t)base * row;
+            if (row == NC3 && vec_ok(r0, nG * NC3)) stage_in_vec<NC3>(s_sh, 0, r0, nG, tid);
+            else for (int f = tid; f < nG * NC3; f += kPreThreads) {
                 const int g = f / NC3, e = f - g * NC3;
                 s_sh[g * kShStride + e] = shs[(size_t)(base + g) * row + e];
             }
@@ -1062,10 +1111,14 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, in
         // straight stream with compile-time index arithmetic; the general case pays a run-time division
         if (d_shs_rest) {
             const int rrow = row - 3;
-            for (int f = tid; f < nG * 3; f += kPreThreads) d_shs[(size_t)base * 3 + f] = s_sh[(f / 3) * kShStride + (f % 3)];
+            float* dc0 = d_shs + (size_t)base * 3;
+            if (vec_ok(dc0, nG * 3)) stage_out_vec<3>(s_sh, 0, dc0, nG, tid);
+            else for (int f = tid; f < nG * 3; f += kPreThreads) dc0[f] = s_sh[(f / 3) * kShStride + (f % 3)];
             if (rrow == NC3 - 3) {
                 constexpr int NR = NC3 > 3 ? NC3 - 3 : 1;
-                for (int f = tid; f < nG * NR; f += kPreThreads) d_shs_rest[(size_t)base * NR + f] = s_sh[(f / NR) * kShStride + 3 + (f % NR)];
+                float* r0 = d_shs_rest + (size_t)base * NR;
+                if (NC3 > 3 && vec_ok(r0, nG * NR)) stage_out_vec<NR>(s_sh, 3, r0, nG, tid);
+                else for (int f = tid; f < nG * NR; f += kPreThreads) r0[f] = s_sh[(f / NR) * kShStride + 3 + (f % NR)];
             } else {
                 for (int f = tid; f < nG * rrow; f += kPreThreads) {
                     const int g = f / rrow, e = f - g * rrow + 3;
@@ -1073,7 +1126,9 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, in
                 }
             }
         } else if (row == NC3) {
-            for (int f = tid; f < nG * NC3; f += kPreThreads) d_shs[(size_t)base * NC3 + f] = s_sh[(f / NC3) * kShStride + (f % NC3)];
+            float* r0 = d_shs + (size_t)base * NC3;
+            if (vec_ok(r0, nG * NC3)) stage_out_vec<NC3>(s_sh, 0, r0, nG, tid);
+            else for (int f = tid; f < nG * NC3; f += kPreThreads) r0[f] = s_sh[(f / NC3) * kShStride + (f % NC3)];
         } else {
             for (int f = tid; f < nG * row; f += kPreThreads) {
                 const int g = f / row, e = f - g * row;
