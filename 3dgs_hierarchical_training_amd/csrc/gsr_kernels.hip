@@ -380,15 +380,13 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit(int N, int W, int H, int 
     __shared__ uint32_t s_incl[kEmitThreads];
     __shared__ uint32_t s_gid[kEmitThreads];
     __shared__ int s_x0[kEmitThreads], s_y0[kEmitThreads], s_w[kEmitThreads];
-    __shared__ float4 s_geo[kEmitThreads];   // px, py, ca, cb
-    __shared__ float2 s_geo2[kEmitThreads];  // cc, tau
+    __shared__ TileTest s_tt[kEmitThreads];
     __shared__ uint32_t s_cnt[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = blockIdx.x * kEmitThreads + tid;
     uint32_t full = 0, g = 0;
     int x0 = 0, y0 = 0, w = 1;
-    float4 geo = {0.f, 0.f, 1.f, 0.f};
-    float2 geo2 = {1.f, -1.f};
+    TileTest tt = make_tile_test(0.f, 0.f, 1.f, 0.f, 1.f, 0.f);
     if (j < N) {
         g = sorted_gid[j];
         const Splat s = splat[g];
@@ -397,13 +395,12 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit(int N, int W, int H, int 
             tile_rect(s.px + 0.5f * (float)W, s.py + 0.5f * (float)H, s.radius, tiles_x, tiles_y, x0, y0, x1, y1);
             w = x1 - x0;
             full = (uint32_t)(w * (y1 - y0));
-            geo = make_float4(s.px, s.py, s.ca, s.cb);
-            geo2 = make_float2(s.cc, splat_tau(s.op));
+            tt = make_tile_test(s.px, s.py, s.ca, s.cb, s.cc, s.op);
         }
     }
     uint32_t total;
     const uint32_t incl = block_inclusive_scan_256(full, s_wave, total);
-    s_incl[tid] = incl; s_gid[tid] = g; s_x0[tid] = x0; s_y0[tid] = y0; s_w[tid] = w; s_geo[tid] = geo; s_geo2[tid] = geo2;
+    s_incl[tid] = incl; s_gid[tid] = g; s_x0[tid] = x0; s_y0[tid] = y0; s_w[tid] = w; s_tt[tid] = tt;
     __syncthreads();
     uint32_t run = block_offsets[blockIdx.x];
     const unsigned long long lt = lanemask_lt();
@@ -422,9 +419,7 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit(int N, int W, int H, int 
             const int ww = s_w[lo];
             const int ty = k / ww, tx = k - ty * ww;
             const int gx = s_x0[lo] + tx, gy = s_y0[lo] + ty;
-            const float4 a = s_geo[lo];
-            const float2 b = s_geo2[lo];
-            ok = tile_accept(a.x, a.y, a.z, a.w, b.x, b.y, gx, gy, W, H);
+            ok = tile_accept(s_tt[lo], gx, gy, W, H);
             tile = (uint32_t)(gy * tiles_x + gx);
             gg = s_gid[lo];
         }

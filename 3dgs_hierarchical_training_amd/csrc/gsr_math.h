@@ -189,47 +189,63 @@ GSR_HD float splat_tau(float opacity)
     return opacity > 0.f ? 2.0f * logf(255.0f * opacity) : -1.0f;
 }
 
-// conservative test on an arbitrary pixel-centre box [bx0,bx1] x [by0,by1] (inclusive)
-GSR_HD bool box_accept(float px, float py, float ca, float cb, float cc, float tau, float bx0, float by0, float bx1, float by1)
+// Per-Gaussian constants of the tile test, computed ONCE per Gaussian by both users (k_preprocess's count and
+// k_emit's emission).  Everything below is written with explicit fmaf / single operations so that the compiler
+// has no freedom to contract differently in the two kernels: the two evaluations must agree bit for bit.
+struct TileTest {
+    float px, py, ca, cb2, cc, rc, ra, hi;   // hi = tau + slack, or negative "reject all" sentinel
+    bool none;                               // opacity below 1/255: contributes nowhere
+};
+GSR_HD TileTest make_tile_test(float px, float py, float ca, float cb, float cc, float op)
 {
+    TileTest t;
+    const float tau = splat_tau(op);
     const float slack = 1e-3f * (1.0f + fabsf(tau));
-    if (tau < -slack) return false;                       // opacity below 1/255: contributes nowhere
-    const float dx0 = bx0 - px, dx1 = bx1 - px, dy0 = by0 - py, dy1 = by1 - py;
+    t.px = px; t.py = py; t.ca = ca; t.cb2 = 2.f * cb; t.cc = cc;
+    t.rc = cb / cc; t.ra = cb / ca;
+    t.hi = tau + slack;
+    t.none = tau < -slack;
+    return t;
+}
+GSR_HD float quad_form(const TileTest& t, float x, float y)   // ca x^2 + 2 cb x y + cc y^2
+{
+    const float u = fmaf(t.ca, x, t.cb2 * y);
+    return fmaf(t.cc * y, y, u * x);
+}
+// conservative test on an arbitrary pixel-centre box [bx0,bx1] x [by0,by1] (inclusive, centred coordinates)
+GSR_HD bool box_accept(const TileTest& t, float bx0, float by0, float bx1, float by1)
+{
+    if (t.none) return false;
+    const float dx0 = bx0 - t.px, dx1 = bx1 - t.px, dy0 = by0 - t.py, dy1 = by1 - t.py;
     if (dx0 <= 0.f && dx1 >= 0.f && dy0 <= 0.f && dy1 >= 0.f) return true;   // centre inside the box
-    float qmin = 3.0e38f;
-    const float rc = cb / cc, ra = cb / ca;
-    {   // vertical edges x = dx0, dx1: minimise over y
-        float y = fminf(dy1, fmaxf(dy0, -rc * dx0));
-        qmin = fminf(qmin, ca * dx0 * dx0 + 2.f * cb * dx0 * y + cc * y * y);
-        y = fminf(dy1, fmaxf(dy0, -rc * dx1));
-        qmin = fminf(qmin, ca * dx1 * dx1 + 2.f * cb * dx1 * y + cc * y * y);
-    }
-    {   // horizontal edges
-        float x = fminf(dx1, fmaxf(dx0, -ra * dy0));
-        qmin = fminf(qmin, ca * x * x + 2.f * cb * x * dy0 + cc * dy0 * dy0);
-        x = fminf(dx1, fmaxf(dx0, -ra * dy1));
-        qmin = fminf(qmin, ca * x * x + 2.f * cb * x * dy1 + cc * dy1 * dy1);
-    }
-    return qmin <= tau + slack;
+    // minimum of the convex form over the box is on its boundary: 1-D minimisation along each edge
+    float y = fminf(dy1, fmaxf(dy0, -t.rc * dx0));
+    float qmin = quad_form(t, dx0, y);
+    y = fminf(dy1, fmaxf(dy0, -t.rc * dx1));
+    qmin = fminf(qmin, quad_form(t, dx1, y));
+    float x = fminf(dx1, fmaxf(dx0, -t.ra * dy0));
+    qmin = fminf(qmin, quad_form(t, x, dy0));
+    x = fminf(dx1, fmaxf(dx0, -t.ra * dy1));
+    qmin = fminf(qmin, quad_form(t, x, dy1));
+    return qmin <= t.hi;
 }
 
-// px, py and the box are in centred coordinates (see Splat)
-GSR_HD bool tile_accept(float px, float py, float ca, float cb, float cc, float tau, int tx, int ty, int W, int H)
+// the 16x16 tile (tx, ty) of a W x H image
+GSR_HD bool tile_accept(const TileTest& t, int tx, int ty, int W, int H)
 {
     const float cx = 0.5f * (float)W, cy = 0.5f * (float)H;
     const float bx0 = (float)(tx * kTile) - cx, by0 = (float)(ty * kTile) - cy;
     const float bx1 = fminf(bx0 + (float)(kTile - 1), (float)(W - 1) - cx), by1 = fminf(by0 + (float)(kTile - 1), (float)(H - 1) - cy);
-    return box_accept(px, py, ca, cb, cc, tau, bx0, by0, bx1, by1);
+    return box_accept(t, bx0, by0, bx1, by1);
 }
 
-struct Splat;
 GSR_HD uint32_t count_accepted_tiles(float px, float py, float ca, float cb, float cc, float op, int x0, int y0, int x1, int y1,
                                      int W, int H)
 {
-    const float tau = splat_tau(op);
+    const TileTest t = make_tile_test(px, py, ca, cb, cc, op);
     uint32_t n = 0;
     for (int ty = y0; ty < y1; ty++)
-        for (int tx = x0; tx < x1; tx++) n += tile_accept(px, py, ca, cb, cc, tau, tx, ty, W, H) ? 1u : 0u;
+        for (int tx = x0; tx < x1; tx++) n += tile_accept(t, tx, ty, W, H) ? 1u : 0u;
     return n;
 }
 

@@ -81,11 +81,11 @@ EmuCtx* hostemu_forward(const EmuIn* in, float* out_color, float* out_depth, flo
         int x0, y0, x1, y1;
         tile_rect(c->splat[g].px + 0.5f * W, c->splat[g].py + 0.5f * H, c->splat[g].radius, cam.tiles_x, cam.tiles_y, x0, y0, x1, y1);
         const Splat& s = c->splat[g];
-        const float tau = splat_tau(s.op);
+        const TileTest tt = make_tile_test(s.px, s.py, s.ca, s.cb, s.cc, s.op);
         uint32_t n = 0;
         for (int y = y0; y < y1; y++)
             for (int x = x0; x < x1; x++)
-                if (tile_accept(s.px, s.py, s.ca, s.cb, s.cc, tau, x, y, W, H)) { inst.push_back({(uint32_t)(y * cam.tiles_x + x), g}); n++; }
+                if (tile_accept(tt, x, y, W, H)) { inst.push_back({(uint32_t)(y * cam.tiles_x + x), g}); n++; }
         if (n != s.tiles) abort();   // count (preprocess) and emission must agree
     }
     std::stable_sort(inst.begin(), inst.end(), [](auto& a, auto& b) { return a.first < b.first; });
