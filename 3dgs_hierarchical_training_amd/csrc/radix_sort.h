@@ -35,10 +35,30 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_hist(const KeyT* __restr
     h[tid] = 0;
     __syncthreads();
     const uint32_t base = blockIdx.x * (uint32_t)kSortTile;
+    if (base + kSortTile <= n && (((uintptr_t)(keys + base)) & 15) == 0) {
+        // full tile: 16-byte loads (order is irrelevant for a histogram)
+        constexpr int KPV = 16 / (int)sizeof(KeyT);                 // keys per 16-byte vector
+        constexpr int NV = kSortTile / KPV / kSortThreads;           // vectors per thread
+        const uint4* v4 = reinterpret_cast<const uint4*>(keys + base);
 #pragma unroll
-    for (int r = 0; r < kSortIPT; r++) {
-        const uint32_t idx = base + r * kSortThreads + tid;
-        if (idx < n) atomicAdd(&h[((uint32_t)keys[idx] >> shift) & 0xffu], 1u);
+        for (int r = 0; r < NV; r++) {
+            const uint4 q = v4[r * kSortThreads + tid];
+            const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                if (sizeof(KeyT) == 4) atomicAdd(&h[(w[c] >> shift) & 0xffu], 1u);
+                else {
+                    atomicAdd(&h[((w[c] & 0xffffu) >> shift) & 0xffu], 1u);
+                    atomicAdd(&h[((w[c] >> 16) >> shift) & 0xffu], 1u);
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < kSortIPT; r++) {
+            const uint32_t idx = base + r * kSortThreads + tid;
+            if (idx < n) atomicAdd(&h[((uint32_t)keys[idx] >> shift) & 0xffu], 1u);
+        }
     }
     __syncthreads();
     hist[(uint32_t)tid * nblocks + blockIdx.x] = h[tid];
