@@ -21,7 +21,11 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if force or _stale():
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-               "-Wno-unused-result"] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+               "-Wno-unused-result",
+               # keep scalar f32 arithmetic scalar: hipcc's SLP pass packs adjacent adds/muls into v_pk_*_f32 and pays
+               # for it in v_mov operand shuffles (MI355X guide, "packed f32 VALU ... an anti-lever"); the kernels
+               # that want packed math ask for it explicitly with float2 vector types
+               "-fno-slp-vectorize"] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -534,7 +534,7 @@ __global__ __launch_bounds__(256 / PPT) void k_blend_fwd(int W, int H, int tiles
             }
         }
     }
-    if (tid == 0) staged[tile] = (uint32_t)min(n, batches * NT);   // instances actually staged (R_eff)
+    if (tid == 0) staged[tile * 4] = (uint32_t)min(n, batches * NT);   // instances actually staged (R_eff)
     const size_t P = (size_t)W * H;
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
 #pragma unroll
@@ -553,6 +553,90 @@ __global__ __launch_bounds__(256 / PPT) void k_blend_fwd(int W, int H, int tiles
             out_depth[pid] = a.D;
             out_alpha[pid] = a.A;
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K7 (wave-per-sub-tile variant).  One 64-lane wave = one workgroup = one 8x8 pixel block; the four waves of a
+// tile are independent: each stages the tile's list itself in batches of 64 (the gathers of the other three hit
+// L2), needs no workgroup barrier, and stops as soon as ITS 64 pixels are saturated.  Compared with one
+// 256-thread workgroup per tile this removes the barrier stalls (40% of wave time) and the coarse 256-instance
+// staging granularity (tiles were staged to 512 instances when ~300 were needed).
+// block b: XCD b & 7, slot k = b >> 3; tile = xcd * per + (k >> 2), sub-tile = k & 3 -> a tile's four waves share an XCD.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_blend_fwd_w(int W, int H, int tiles_x, int T, const uint2* __restrict__ ranges,
+                                                    const uint32_t* __restrict__ list, const Splat* __restrict__ splat,
+                                                    const float* __restrict__ bg, float* __restrict__ out_color,
+                                                    float* __restrict__ out_depth, float* __restrict__ out_alpha,
+                                                    float* __restrict__ img, uint32_t* __restrict__ staged4)
+{
+    constexpr int NT = 64;
+    __shared__ float4 s_a[2][NT], s_b[2][NT], s_c[2][NT];
+    const int per = (T + 7) >> 3;
+    const int kslot = blockIdx.x >> 3;
+    const int tile = (blockIdx.x & 7) * per + (kslot >> 2), sub = kslot & 3;
+    if (tile >= T || (kslot >> 2) >= per) return;
+    const int lane = threadIdx.x;
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const int px = tx * kTile + (sub & 1) * 8 + (lane & 7);
+    const int py = ty * kTile + (sub >> 1) * 8 + (lane >> 3);
+    const float pxf = (float)px - 0.5f * (float)W, pyf = (float)py - 0.5f * (float)H;
+    const uint2 rg = ranges[tile];
+    const int n = (int)(rg.y - rg.x);
+    const int nb = (n + NT - 1) / NT;
+    PixelAcc acc = {1.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    uint32_t last = 0;
+    bool done = !(px < W && py < H);
+    float4 ra = {0, 0, 0, 0}, rb = ra, rc = ra;
+    // the staged copy carries the conic pre-multiplied for the exponent in base 2:
+    //   log2(G) = A' dx^2 + B' dx dy + C' dy^2,  A' = -log2(e)/2 * A, B' = -log2(e) * B, C' = -log2(e)/2 * C
+    constexpr float kL2E = 1.4426950408889634f;
+    if (lane < n) {
+        const float4* sp = reinterpret_cast<const float4*>(splat + list[rg.x + lane]);
+        ra = sp[0]; rb = sp[1]; rc = sp[2];
+        ra.z *= -0.5f * kL2E; ra.w *= -kL2E; rb.x *= -0.5f * kL2E;
+    }
+    int batches = 0;
+    for (int b = 0; b < nb; b++) {
+        const int buf = b & 1;
+        if (__all(done)) break;
+        s_a[buf][lane] = ra; s_b[buf][lane] = rb; s_c[buf][lane] = rc;
+        __syncthreads();   // single-wave workgroup: just orders the LDS writes before the broadcast reads
+        batches = b + 1;
+        const int nxt = (b + 1) * NT + lane;
+        if (nxt < n) {
+            const float4* sp = reinterpret_cast<const float4*>(splat + list[rg.x + nxt]);
+            ra = sp[0]; rb = sp[1]; rc = sp[2];
+            ra.z *= -0.5f * kL2E; ra.w *= -kL2E; rb.x *= -0.5f * kL2E;
+        }
+        const int cnt = min(NT, n - b * NT);
+        for (int j = 0; j < cnt; j++) {
+            const float4 A = s_a[buf][j], B = s_b[buf][j], C = s_c[buf][j];
+            if (done) continue;
+            const float dx = A.x - pxf, dy = A.y - pyf;
+            const float p2 = fmaf(B.x * dy, dy, fmaf(A.w, dy, A.z * dx) * dx);   // log2 of the Gaussian weight
+#if defined(__HIP_DEVICE_COMPILE__)
+            const float alpha = fminf(kAlphaMax, B.y * __builtin_amdgcn_exp2f(p2));
+#else
+            const float alpha = fminf(kAlphaMax, B.y * exp2f(p2));
+#endif
+            if (p2 > 0.f || alpha < kAlphaMin) continue;
+            if (!blend_step_fwd(acc, alpha, B.w, C.x, C.y, B.z)) { done = true; continue; }
+            last = (uint32_t)(b * NT + j + 1);
+        }
+    }
+    if (lane == 0) staged4[tile * 4 + sub] = (uint32_t)min(n, batches * NT);
+    if (px < W && py < H) {
+        const size_t P = (size_t)W * H, pid = (size_t)py * W + px;
+        img[pid] = acc.T;
+        reinterpret_cast<uint32_t*>(img)[P + pid] = last;
+        img[2 * P + pid] = acc.C0; img[3 * P + pid] = acc.C1; img[4 * P + pid] = acc.C2;
+        img[5 * P + pid] = acc.D; img[6 * P + pid] = acc.A;
+        out_color[pid] = acc.C0 + acc.T * bg[0];
+        out_color[P + pid] = acc.C1 + acc.T * bg[1];
+        out_color[2 * P + pid] = acc.C2 + acc.T * bg[2];
+        out_depth[pid] = acc.D;
+        out_alpha[pid] = acc.A;
     }
 }
 
@@ -631,7 +715,7 @@ __global__ __launch_bounds__(128) void k_blend_fwd2(int W, int H, int tiles_x, i
             }
         }
     }
-    if (tid == 0) staged[tile] = (uint32_t)min(n, batches * NT);
+    if (tid == 0) staged[tile * 4] = (uint32_t)min(n, batches * NT);
     const size_t P = (size_t)W * H;
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
 #pragma unroll
@@ -1261,7 +1345,7 @@ size_t gsr_image_staged_offset(int32_t W, int32_t H) { return align256((size_t)W
 size_t gsr_image_bytes(int32_t W, int32_t H)
 {
     const size_t T = (size_t)((W + kTile - 1) / kTile) * ((H + kTile - 1) / kTile);
-    return gsr_image_staged_offset(W, H) + align256(T * 4);
+    return gsr_image_staged_offset(W, H) + align256(T * 4 * 4);   // four per-sub-tile counters per tile
 }
 
 int gsr_profile_read(const char* name, double* total_ms, int64_t* count)
@@ -1297,7 +1381,8 @@ int gsr_version(void) { return 100; }
 int gsr_set_option(const char* name, int value)
 {
     if (!name) return GSR_ERR_ARG;
-    if (!strcmp(name, "blend_fwd_ppt")) { if (value < 0 || value > 4) return GSR_ERR_ARG; g_blend_ppt = value; return GSR_OK; }
+    // 1 / 3 / 4 = one workgroup per tile with 1 / 2 / 4 pixels per lane (scalar), 2 = packed 2-pixel, 5 = one wave per 8x8 sub-tile
+    if (!strcmp(name, "blend_fwd_ppt")) { if (value < 0 || value > 5) return GSR_ERR_ARG; g_blend_ppt = value; return GSR_OK; }
     if (!strcmp(name, "profile")) { g_profile = value ? 1 : 0; return GSR_OK; }
     if (!strcmp(name, "sort_algo")) { if (value < 0 || value > 2) return GSR_ERR_ARG; g_sort_algo = value; return GSR_OK; }
     // 2 = packed-math kernel (default), 3 = scalar 2-pixel kernel (kept for A/B), 1 / 4 = scalar 1 / 4 pixels
@@ -1413,12 +1498,16 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
             hipLaunchKernelGGL(k_tile_ranges, dim3(((uint32_t)R + 255) / 256), dim3(256), 0, st, (uint32_t)R, skey, ranges);
         }
     }
-    const int ppt = g_blend_ppt ? g_blend_ppt : 1;
+    const int ppt = g_blend_ppt ? g_blend_ppt : 5;   // default: one wave per 8x8 sub-tile
     float* img = static_cast<float*>(a->image);
     uint32_t* staged = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(a->image) + gsr_image_staged_offset(W, H));
+    GSR_HIP(hipMemsetAsync(staged, 0, (size_t)T * 16, st));
     {
         ProfScope ps(P_BLEND_FWD, st);
-        if (ppt == 1) launch_blend_fwd<1>(W, H, tiles_x, T, ranges, list, splat, a->bg, a->out_color, a->out_depth, a->out_alpha, img, staged, st);
+        if (ppt == 5)
+            hipLaunchKernelGGL(k_blend_fwd_w, dim3(8 * 4 * ((T + 7) / 8)), dim3(64), 0, st, W, H, tiles_x, T, ranges, list, splat, a->bg,
+                               a->out_color, a->out_depth, a->out_alpha, img, staged);
+        else if (ppt == 1) launch_blend_fwd<1>(W, H, tiles_x, T, ranges, list, splat, a->bg, a->out_color, a->out_depth, a->out_alpha, img, staged, st);
         else if (ppt == 2)
             hipLaunchKernelGGL(k_blend_fwd2, dim3(8 * ((T + 7) / 8)), dim3(128), 0, st, W, H, tiles_x, T, ranges, list, splat, a->bg,
                                a->out_color, a->out_depth, a->out_alpha, img, staged);

@@ -47,7 +47,9 @@ def last_call_info():
     if img is not None:
         off = lib.gsr_image_staged_offset(W, H)
         T = ((W + 15) // 16) * ((H + 15) // 16)
-        staged = int(img[off:off + 4 * T].view(torch.int32).sum().item())
+        # four counters per tile (one per 8x8 sub-tile wave; tile-level kernels use slot 0): the tile's staged depth
+        # is the deepest of its waves
+        staged = int(img[off:off + 16 * T].view(torch.int32).view(T, 4).max(dim=1).values.sum().item())
     return {"num_rendered": _LAST["num_rendered"], "staged": staged}
 
 
