@@ -906,8 +906,11 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(int W, int H, int tiles_x, i
     const size_t P = (size_t)W * H;
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
 
-    f2 Tt = {1.f, 1.f}, sC0 = {0.f, 0.f}, sC1 = sC0, sC2 = sC0, sD = sC0, sA = sC0;
-    f2 gC0 = sC0, gC1 = sC0, gC2 = sC0, gD = sC0, gA = sC0, bgdot = sC0;
+    // S = <gC, suffix colour> + gD * suffix depth + gA * suffix alpha + T_final <bg, gC>: the only combination of the
+    // suffix sums the gradient needs, so ONE running value per pixel replaces five (and the bg term rides along)
+    const f2 zero2 = {0.f, 0.f};
+    f2 Tt = {1.f, 1.f}, S = zero2;
+    f2 gC0 = zero2, gC1 = zero2, gC2 = zero2, gD = zero2, gA = zero2;
     uint32_t ncon[2] = {0u, 0u};
 #pragma unroll
     for (int p = 0; p < 2; p++) {
@@ -915,14 +918,14 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(int W, int H, int tiles_x, i
         if (px < W && py < H) {
             const size_t pid = (size_t)py * W + px;
             ncon[p] = reinterpret_cast<const uint32_t*>(img)[P + pid];
-            sC0[p] = img[2 * P + pid]; sC1[p] = img[3 * P + pid]; sC2[p] = img[4 * P + pid];
             if (g_color) { gC0[p] = g_color[pid]; gC1[p] = g_color[P + pid]; gC2[p] = g_color[2 * P + pid]; }
+            float s = gC0[p] * img[2 * P + pid] + gC1[p] * img[3 * P + pid] + gC2[p] * img[4 * P + pid];
             if (HAS_DA) {
-                sD[p] = img[5 * P + pid]; sA[p] = img[6 * P + pid];
                 if (g_depth) gD[p] = g_depth[pid];
                 if (g_alpha) gA[p] = g_alpha[pid];
+                s += gD[p] * img[5 * P + pid] + gA[p] * img[6 * P + pid];
             }
-            bgdot[p] = img[pid] * (bg0 * gC0[p] + bg1 * gC1[p] + bg2 * gC2[p]);
+            S[p] = s + img[pid] * (bg0 * gC0[p] + bg1 * gC1[p] + bg2 * gC2[p]);
         }
     }
     uint32_t nmax = max(ncon[0], ncon[1]);
@@ -973,15 +976,12 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(int W, int H, int tiles_x, i
                 alpha.x = v0 ? alpha.x : 0.f; alpha.y = v1 ? alpha.y : 0.f;
                 G.x = v0 ? G.x : 0.f; G.y = v1 ? G.y : 0.f;
                 const f2 w = alpha * Tt;
-                sC0 -= cr * w; sC1 -= cg * w; sC2 -= cbl * w;
+                f2 gc = gC0 * cr + gC1 * cg + gC2 * cbl;          // <gC, colour of this Gaussian> (+ depth / alpha terms)
+                if (HAS_DA) gc += gD * zd + gA;
+                S -= gc * w;
                 const f2 om = 1.f - alpha;
                 const f2 inv = {fast_rcp(om.x), fast_rcp(om.y)};
-                f2 dLda = gC0 * (cr * Tt - sC0 * inv) + gC1 * (cg * Tt - sC1 * inv) + gC2 * (cbl * Tt - sC2 * inv);
-                if (HAS_DA) {
-                    sD -= zd * w; sA -= w;
-                    dLda += gD * (zd * Tt - sD * inv) + gA * (Tt - sA * inv);
-                }
-                dLda -= bgdot * inv;
+                const f2 dLda = gc * Tt - S * inv;
                 const f2 dLdpow = G * (op * dLda);
                 const f2 ex = -(ca * dx) - cb * dy;     // d power / d dx
                 const f2 ey = -(cc * dy) - bx;           // d power / d dy
@@ -1018,157 +1018,6 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(int W, int H, int tiles_x, i
                 if (r < NV) {
                     const float v = s_part[0][jj][r] + s_part[1][jj][r];
                     s_part[0][jj][r] = 0.f; s_part[1][jj][r] = 0.f;   // ready for the next batch (its writers sit behind a barrier)
-                    if (v != 0.f) atomicAdd(ggrad + (size_t)s_gid[buf][jj] * kGG + r, v);
-                }
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// K8 (wave-per-half-tile variant): the same packed arithmetic with one 64-lane wave per workgroup owning a 16x8
-// pixel half of the tile: own 64-instance staging, own replay depth (max n_contrib of ITS pixels), no cross-wave
-// combine, no workgroup barrier.
-// ------------------------------------------------------------------------------------------------
-template <bool HAS_DA>
-__global__ __launch_bounds__(64) void k_blend_bwd_w(int W, int H, int tiles_x, int T, const uint2* __restrict__ ranges,
-                                                    const uint32_t* __restrict__ list, const Splat* __restrict__ splat,
-                                                    const float* __restrict__ bg, const float* __restrict__ img,
-                                                    const float* __restrict__ g_color, const float* __restrict__ g_depth,
-                                                    const float* __restrict__ g_alpha, float* __restrict__ ggrad)
-{
-    constexpr int NT = 64, NW = 1, NV = HAS_DA ? 10 : 9;
-    // single staging buffer: a batch is ~10^4 cycles of compute, so the second barrier per batch is free, and the
-    // smaller LDS footprint lets more tiles share a CU (latency hiding: waves were 33% in s_waitcnt / barriers)
-    __shared__ float4 s_a[1][NT], s_b[1][NT], s_c[1][NT];
-    __shared__ uint32_t s_gid[1][NT];
-    __shared__ float s_part[NW][NT][NV];
-    // block b: XCD b & 7, slot k = b >> 3; tile = xcd * per + (k >> 1), half = k & 1 (rows 0-7 / 8-15 of the tile)
-    const int per = (T + 7) >> 3;
-    const int kslot = blockIdx.x >> 3;
-    const int tile = (blockIdx.x & 7) * per + (kslot >> 1), wave = 0, half = kslot & 1;
-    if (tile >= T || (kslot >> 1) >= per) return;
-    const int tid = threadIdx.x, lane = tid;
-    const int tx = tile % tiles_x, ty = tile / tiles_x;
-    const int px = tx * kTile + (tid & 15);
-    const int py0 = ty * kTile + half * 8 + (tid >> 4) * 2;
-    const float pxf = (float)px - 0.5f * (float)W;   // centred pixel coordinates (see Splat)
-    const float cyf = 0.5f * (float)H;
-    const f2 pyf = {(float)py0 - cyf, (float)(py0 + 1) - cyf};
-    const uint2 rg = ranges[tile];
-    const size_t P = (size_t)W * H;
-    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
-
-    f2 Tt = {1.f, 1.f}, sC0 = {0.f, 0.f}, sC1 = sC0, sC2 = sC0, sD = sC0, sA = sC0;
-    f2 gC0 = sC0, gC1 = sC0, gC2 = sC0, gD = sC0, gA = sC0, bgdot = sC0;
-    uint32_t ncon[2] = {0u, 0u};
-#pragma unroll
-    for (int p = 0; p < 2; p++) {
-        const int py = py0 + p;
-        if (px < W && py < H) {
-            const size_t pid = (size_t)py * W + px;
-            ncon[p] = reinterpret_cast<const uint32_t*>(img)[P + pid];
-            sC0[p] = img[2 * P + pid]; sC1[p] = img[3 * P + pid]; sC2[p] = img[4 * P + pid];
-            if (g_color) { gC0[p] = g_color[pid]; gC1[p] = g_color[P + pid]; gC2[p] = g_color[2 * P + pid]; }
-            if (HAS_DA) {
-                sD[p] = img[5 * P + pid]; sA[p] = img[6 * P + pid];
-                if (g_depth) gD[p] = g_depth[pid];
-                if (g_alpha) gA[p] = g_alpha[pid];
-            }
-            bgdot[p] = img[pid] * (bg0 * gC0[p] + bg1 * gC1[p] + bg2 * gC2[p]);
-        }
-    }
-    uint32_t nmax = max(ncon[0], ncon[1]);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, off, 64));
-    const int n = (int)nmax;   // this wave's own replay depth (finer than the tile's)
-    const int nb = (n + NT - 1) / NT;
-
-    float4 ra = {0, 0, 0, 0}, rb = ra, rc = ra;
-    uint32_t rg_id = 0;
-    if (tid < n) {
-        rg_id = list[rg.x + tid];
-        const float4* sp = reinterpret_cast<const float4*>(splat + rg_id);
-        ra = sp[0]; rb = sp[1]; rc = sp[2];
-    }
-#pragma unroll
-    for (int w = 0; w < NW; w++)
-#pragma unroll
-        for (int k = 0; k < NV; k++) s_part[w][tid][k] = 0.f;   // the flush below re-zeroes what it consumes
-    for (int b = 0; b < nb; b++) {
-        const int buf = 0;
-        if (b) __syncthreads();   // everyone is done reading the previous batch (and its flush read s_gid)
-        s_a[buf][tid] = ra; s_b[buf][tid] = rb; s_c[buf][tid] = rc; s_gid[buf][tid] = rg_id;
-        __syncthreads();
-        const int nxt = (b + 1) * NT + tid;
-        if (nxt < n) {
-            rg_id = list[rg.x + nxt];
-            const float4* sp = reinterpret_cast<const float4*>(splat + rg_id);
-            ra = sp[0]; rb = sp[1]; rc = sp[2];
-        }
-        const int cnt = min(NT, n - b * NT);
-        for (int j = 0; j < cnt; j++) {
-            const float4 A = s_a[buf][j], B = s_b[buf][j], C = s_c[buf][j];   // (manual LDS prefetch measured slower)
-            const uint32_t idx = (uint32_t)(b * NT + j + 1);
-            const float ca = A.z, cb = A.w, cc = B.x, op = B.y, zd = B.z, cr = B.w, cg = C.x, cbl = C.y;
-            const float dx = A.x - pxf;
-            const f2 dy = A.y - pyf;
-            const float hx = ca * dx * dx, bx = cb * dx;
-            const f2 power = -0.5f * (cc * dy * dy + hx) - bx * dy;
-            f2 G = {fast_exp(power.x), fast_exp(power.y)};
-            f2 alpha = op * G;
-            alpha.x = fminf(kAlphaMax, alpha.x); alpha.y = fminf(kAlphaMax, alpha.y);
-            const bool v0 = !(power.x > 0.f || alpha.x < kAlphaMin) && idx <= ncon[0];
-            const bool v1 = !(power.y > 0.f || alpha.y < kAlphaMin) && idx <= ncon[1];
-            if (__any(v0 || v1)) {   // wave-uniform
-                alpha.x = v0 ? alpha.x : 0.f; alpha.y = v1 ? alpha.y : 0.f;
-                G.x = v0 ? G.x : 0.f; G.y = v1 ? G.y : 0.f;
-                const f2 w = alpha * Tt;
-                sC0 -= cr * w; sC1 -= cg * w; sC2 -= cbl * w;
-                const f2 om = 1.f - alpha;
-                const f2 inv = {fast_rcp(om.x), fast_rcp(om.y)};
-                f2 dLda = gC0 * (cr * Tt - sC0 * inv) + gC1 * (cg * Tt - sC1 * inv) + gC2 * (cbl * Tt - sC2 * inv);
-                if (HAS_DA) {
-                    sD -= zd * w; sA -= w;
-                    dLda += gD * (zd * Tt - sD * inv) + gA * (Tt - sA * inv);
-                }
-                dLda -= bgdot * inv;
-                const f2 dLdpow = G * (op * dLda);
-                const f2 ex = -(ca * dx) - cb * dy;     // d power / d dx
-                const f2 ey = -(cc * dy) - bx;           // d power / d dy
-                const f2 t_gx = dLdpow * ex, t_gy = dLdpow * ey;
-                const f2 t_gB = dLdpow * dy;
-                const f2 t_gC = t_gB * dy;
-                const f2 t_op = G * dLda;
-                const f2 t_r = w * gC0, t_g = w * gC1, t_b = w * gC2;
-                float v[10];
-                v[0] = t_gx.x + t_gx.y; v[1] = t_gy.x + t_gy.y;
-                const float sdl = dLdpow.x + dLdpow.y;
-                v[2] = -0.5f * dx * dx * sdl;                    // gA
-                v[3] = -dx * (t_gB.x + t_gB.y);                  // gB
-                v[4] = -0.5f * (t_gC.x + t_gC.y);                // gC
-                v[5] = t_op.x + t_op.y;
-                v[6] = t_r.x + t_r.y; v[7] = t_g.x + t_g.y; v[8] = t_b.x + t_b.y;
-                if (HAS_DA) { const f2 t_z = w * gD; v[9] = t_z.x + t_z.y; }
-                Tt *= om;
-                // (measured: finishing the reduction with ds_add_f32 from the row leaders is 1.7x SLOWER -- LDS float
-                //  atomics serialise; the transposed DPP reduction below halves the VALU cost instead)
-                const float t = wave_reduce_transposed<NV>(v, lane);
-                if (lane < 8) s_part[wave][j][lane] = t;
-                else if (lane < NV) s_part[wave][j][lane] = t;
-            }
-        }
-        __syncthreads();
-        // flush: 16 lanes per Gaussian, lane r adds component r, so one atomic instruction touches 8 records of
-        // 9-10 CONSECUTIVE floats (8 cache lines per wave instruction) instead of 64 scattered records -- device-scope
-        // float atomics are fabric transactions on this chip, and they were 27% of this kernel when issued one
-        // component at a time per lane
-        {
-            const int r = tid & 15, q = tid >> 4;   // 8 groups of 16 lanes
-            for (int jj = q; jj < cnt; jj += NT / 16) {
-                if (r < NV) {
-                    const float v = s_part[0][jj][r];
-                    s_part[0][jj][r] = 0.f;   // ready for the next batch (its writers sit behind a barrier)
                     if (v != 0.f) atomicAdd(ggrad + (size_t)s_gid[buf][jj] * kGG + r, v);
                 }
             }
@@ -1537,7 +1386,7 @@ int gsr_set_option(const char* name, int value)
     if (!strcmp(name, "profile")) { g_profile = value ? 1 : 0; return GSR_OK; }
     if (!strcmp(name, "sort_algo")) { if (value < 0 || value > 2) return GSR_ERR_ARG; g_sort_algo = value; return GSR_OK; }
     // 2 = packed-math kernel (default), 3 = scalar 2-pixel kernel (kept for A/B), 1 / 4 = scalar 1 / 4 pixels
-    if (!strcmp(name, "blend_bwd_ppt")) { if (value < 0 || value > 5) return GSR_ERR_ARG; g_bwd_ppt = value; return GSR_OK; }
+    if (!strcmp(name, "blend_bwd_ppt")) { if (value < 0 || value > 4) return GSR_ERR_ARG; g_bwd_ppt = value; return GSR_OK; }
     return GSR_ERR_ARG;
 }
 
@@ -1700,15 +1549,7 @@ int gsr_backward(const GsrBackwardArgs* a, void* stream_)
         const float* img = static_cast<const float*>(a->image);
         ProfScope ps(P_BLEND_BWD, st);
         if (ppt == 1) launch_blend_bwd<1>(W, H, tiles_x, T, ranges, list, splat, a->bg, img, a->grad_color, a->grad_depth, a->grad_alpha, gg, st);
-        else if (ppt == 5) {
-            const int grid = 8 * 2 * ((T + 7) / 8);
-            if (a->grad_depth || a->grad_alpha)
-                hipLaunchKernelGGL(k_blend_bwd_w<true>, dim3(grid), dim3(64), 0, st, W, H, tiles_x, T, ranges, list, splat, a->bg, img,
-                                   a->grad_color, a->grad_depth, a->grad_alpha, gg);
-            else
-                hipLaunchKernelGGL(k_blend_bwd_w<false>, dim3(grid), dim3(64), 0, st, W, H, tiles_x, T, ranges, list, splat, a->bg, img,
-                                   a->grad_color, a->grad_depth, a->grad_alpha, gg);
-        } else if (ppt == 2) {
+                else if (ppt == 2) {
             const int grid = 8 * ((T + 7) / 8);
             if (a->grad_depth || a->grad_alpha)
                 hipLaunchKernelGGL(k_blend_bwd2<true>, dim3(grid), dim3(128), 0, st, W, H, tiles_x, T, ranges, list, splat, a->bg, img,

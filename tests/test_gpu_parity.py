@@ -107,7 +107,7 @@ def test_blend_variants_agree(ppt):
     lib = L.load()
     try:
         assert lib.gsr_set_option(b"blend_fwd_ppt", ppt) == 0
-        assert lib.gsr_set_option(b"blend_bwd_ppt", ppt) == 0
+        assert lib.gsr_set_option(b"blend_bwd_ppt", min(ppt, 4)) == 0
         _run_case(20000, 330, 250, 3, True, "sh", (0.2, 0.3, 0.1))
     finally:
         lib.gsr_set_option(b"blend_fwd_ppt", 0)
