@@ -45,7 +45,13 @@ class GsrBackwardArgs(C.Structure):
         ("d_rotations", C.c_void_p), ("d_cov3D_precomp", C.c_void_p), ("scratch", C.c_void_p),
         ("shs_rest", C.c_void_p), ("d_shs_rest", C.c_void_p), ("raw_params", C.c_int32),
         ("d_viewmatrix", C.c_void_p), ("d_projmatrix", C.c_void_p), ("d_campos", C.c_void_p),
+        ("fused_adam", C.c_void_p),
     ]
+
+
+class GsrFusedAdam(C.Structure):
+    _fields_ = [("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("reserved", C.c_int32),
+                ("step", C.c_int64), ("lr", C.c_float * 6), ("exp_avg", C.c_void_p * 6), ("exp_avg_sq", C.c_void_p * 6)]
 
 
 class GsrAdamTensor(C.Structure):

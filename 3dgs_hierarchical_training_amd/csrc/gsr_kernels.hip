@@ -20,6 +20,7 @@
 
 #include "../../include/gsr.h"
 #include "gsr_math.h"
+#include "adam_math.h"
 #include "radix_sort.h"
 
 namespace gsr {
@@ -1026,6 +1027,54 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(int W, int H, int tiles_x, i
 }
 
 // ------------------------------------------------------------------------------------------------
+// Optimizer-in-backward (GsrFusedAdam): gradients of one block's Gaussians sit in LDS as padded rows; the block's
+// parameter / moment rows are contiguous in memory, so the update is a 16-byte stream over p, m, v with the gradient
+// gathered from LDS.  `row` floats are stored per Gaussian, of which the first `nact` have a gradient in the tile
+// (the rest -- SH bands above the active degree -- see g = 0 but still decay their moments, as dense Adam does).
+// ------------------------------------------------------------------------------------------------
+struct AdamDev {
+    float* m[6];
+    float* v[6];
+    float step_size[6];   // lr / (1 - beta1^t)
+    float b1, b2, eps, inv_bc2s;
+};
+
+__device__ __forceinline__ void adam_rows(const float* s_g, int stride, int col0, int row, int nact, float* __restrict__ p,
+                                          float* __restrict__ m, float* __restrict__ v, int nG, int tid, float step_size,
+                                          const AdamDev& ad)
+{
+    const int total = nG * row;
+    if (((((uintptr_t)p | (uintptr_t)m | (uintptr_t)v) & 15) == 0) && (total & 3) == 0) {
+        float4* p4 = reinterpret_cast<float4*>(p);
+        float4* m4 = reinterpret_cast<float4*>(m);
+        float4* v4 = reinterpret_cast<float4*>(v);
+        for (int q = tid; q < total / 4; q += kPreThreads) {
+            float4 pp = p4[q], mm = m4[q], vv = v4[q];
+            const int f = 4 * q;
+            int g = f / row, e = f - g * row;
+            float gs[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                gs[c] = e < nact ? s_g[g * stride + col0 + e] : 0.f;
+                if (++e == row) { e = 0; g++; }
+            }
+            adam_one(pp.x, gs[0], mm.x, vv.x, ad.b1, ad.b2, ad.eps, step_size, ad.inv_bc2s);
+            adam_one(pp.y, gs[1], mm.y, vv.y, ad.b1, ad.b2, ad.eps, step_size, ad.inv_bc2s);
+            adam_one(pp.z, gs[2], mm.z, vv.z, ad.b1, ad.b2, ad.eps, step_size, ad.inv_bc2s);
+            adam_one(pp.w, gs[3], mm.w, vv.w, ad.b1, ad.b2, ad.eps, step_size, ad.inv_bc2s);
+            p4[q] = pp; m4[q] = mm; v4[q] = vv;
+        }
+    } else {
+        for (int f = tid; f < total; f += kPreThreads) {
+            const int g = f / row, e = f - g * row;
+            float pp = p[f], mm = m[f], vv = v[f];
+            adam_one(pp, e < nact ? s_g[g * stride + col0 + e] : 0.f, mm, vv, ad.b1, ad.b2, ad.eps, step_size, ad.inv_bc2s);
+            p[f] = pp; m[f] = mm; v[f] = vv;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // K9: per-Gaussian backward.  SH rows in, dSH rows out through the same LDS tile (coalesced both ways).
 // ------------------------------------------------------------------------------------------------
 // CAM = true additionally produces dL/d(viewmatrix, projmatrix, campos) (north_star's dL/dviewmatrix; BASELINE
@@ -1033,11 +1082,15 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(int W, int H, int tiles_x, i
 // k_cam_reduce sums the partials deterministically.
 constexpr int kCamVals = 35;
 
-template <int DEG, bool RAW, bool CAM>
-__global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, int N, const float* __restrict__ means,
-                                                                const float* __restrict__ scales, const float* __restrict__ rots,
-                                                                const float* __restrict__ cov_pre, const float* __restrict__ shs,
-                                                                const float* __restrict__ shs_rest,
+// ADAM = true (needs RAW, shs + shs_rest, no cov_pre): optimizer-in-backward, see GsrFusedAdam in include/gsr.h.  The
+// parameter pointers are then read AND written by the block that owns the rows (no __restrict__ promises on them).
+constexpr int kSmallStride = 11;   // xyz 0-2 | opacity 3 | scaling 4-6 | rotation 7-10 (odd stride: conflict-free)
+
+template <int DEG, bool RAW, bool CAM, bool ADAM>
+__global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, int N, const float* means,
+                                                                const float* scales, const float* rots,
+                                                                const float* __restrict__ cov_pre, const float* shs,
+                                                                const float* shs_rest, const float* opac_raw, AdamDev ad,
                                                                 const Splat* __restrict__ splat, const float* __restrict__ ggrad,
                                                                 float* __restrict__ d_means, float* __restrict__ d_means2d,
                                                                 float* __restrict__ d_opac, float* __restrict__ d_colors,
@@ -1049,6 +1102,7 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, in
     constexpr int NC3 = 3 * (DEG + 1) * (DEG + 1);
     __shared__ float s_sh[kPreThreads * kShStride];
     __shared__ float s_cam[CAM ? (kPreThreads / 64) * kCamVals : 1];
+    __shared__ float s_small[ADAM ? kPreThreads * kSmallStride : 1];
     const int tid = threadIdx.x;
     const int base = blockIdx.x * kPreThreads;
     const int i = base + tid;
@@ -1144,9 +1198,17 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, in
         } else if (shs) {
             for (int e = 0; e < NC3; e++) s_sh[tid * kShStride + e] = 0.f;
         }
+        d_means2d[3 * (size_t)i] = m2d[0]; d_means2d[3 * (size_t)i + 1] = m2d[1]; d_means2d[3 * (size_t)i + 2] = 0.f;
+        if (ADAM) {
+            float* sm = &s_small[tid * kSmallStride];
+#pragma unroll
+            for (int k = 0; k < 3; k++) { sm[k] = dmean[k]; sm[4 + k] = dsc[k]; }
+            sm[3] = dop;
+#pragma unroll
+            for (int k = 0; k < 4; k++) sm[7 + k] = drq[k];
+        } else {
 #pragma unroll
         for (int k = 0; k < 3; k++) d_means[3 * (size_t)i + k] = dmean[k];
-        d_means2d[3 * (size_t)i] = m2d[0]; d_means2d[3 * (size_t)i + 1] = m2d[1]; d_means2d[3 * (size_t)i + 2] = 0.f;
         d_opac[i] = dop;
         if (d_colors) {
 #pragma unroll
@@ -1163,6 +1225,7 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, in
         if (d_cov) {
 #pragma unroll
             for (int k = 0; k < 6; k++) d_cov[6 * (size_t)i + k] = dcv[k];
+        }
         }
     }
     if (CAM) {
@@ -1183,7 +1246,21 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, in
             cam_partial[(size_t)blockIdx.x * kCamVals + tid] = t;
         }
     }
-    if (shs && d_shs) {
+    if (ADAM) {
+        __syncthreads();   // every thread's parameters are read, every gradient row is in LDS
+        const size_t b = (size_t)base;
+        const int rrow = cp.M * 3 - 3;
+        adam_rows(s_small, kSmallStride, 0, 3, 3, const_cast<float*>(means) + b * 3, ad.m[0] + b * 3, ad.v[0] + b * 3, nG, tid, ad.step_size[0], ad);
+        adam_rows(s_sh, kShStride, 0, 3, 3, const_cast<float*>(shs) + b * 3, ad.m[1] + b * 3, ad.v[1] + b * 3, nG, tid, ad.step_size[1], ad);
+        if (rrow == 45 && NC3 == 48)
+            adam_rows(s_sh, kShStride, 3, 45, 45, const_cast<float*>(shs_rest) + b * 45, ad.m[2] + b * 45, ad.v[2] + b * 45, nG, tid, ad.step_size[2], ad);
+        else if (rrow > 0)
+            adam_rows(s_sh, kShStride, 3, rrow, NC3 - 3, const_cast<float*>(shs_rest) + b * rrow, ad.m[2] + b * rrow, ad.v[2] + b * rrow, nG, tid,
+                      ad.step_size[2], ad);
+        adam_rows(s_small, kSmallStride, 3, 1, 1, const_cast<float*>(opac_raw) + b, ad.m[3] + b, ad.v[3] + b, nG, tid, ad.step_size[3], ad);
+        adam_rows(s_small, kSmallStride, 4, 3, 3, const_cast<float*>(scales) + b * 3, ad.m[4] + b * 3, ad.v[4] + b * 3, nG, tid, ad.step_size[4], ad);
+        adam_rows(s_small, kSmallStride, 7, 4, 4, const_cast<float*>(rots) + b * 4, ad.m[5] + b * 4, ad.v[5] + b * 4, nG, tid, ad.step_size[5], ad);
+    } else if (shs && d_shs) {
         __syncthreads();
         const int row = cp.M * 3;
         // rows are contiguous in memory, so when the active degree uses every stored coefficient the store is one
@@ -1534,7 +1611,7 @@ int gsr_backward(const GsrBackwardArgs* a, void* stream_)
         if (a->d_campos) GSR_HIP(hipMemsetAsync(a->d_campos, 0, 12, st));
         return GSR_OK;
     }
-    if (!a->geom || !a->image || !a->binning || !a->scratch || !a->d_means3D || !a->d_means2D || !a->d_opacities)
+    if (!a->geom || !a->image || !a->binning || !a->scratch || !a->d_means2D)
         return fail(GSR_ERR_ARG, "missing workspace / gradient pointer%s");
     const int tiles_x = (W + kTile - 1) / kTile, tiles_y = (H + kTile - 1) / kTile, T = tiles_x * tiles_y;
     const Splat* splat = static_cast<const Splat*>(a->geom);
@@ -1564,14 +1641,31 @@ int gsr_backward(const GsrBackwardArgs* a, void* stream_)
     const int grid = (N + kPreThreads - 1) / kPreThreads;
     const bool want_cam = a->d_viewmatrix || a->d_projmatrix || a->d_campos;
     float* cam_partial = reinterpret_cast<float*>(static_cast<uint8_t*>(a->scratch) + align256((size_t)N * kGG * 4));
-#define GSR_PREB_(DEG, RAW, CAM)                                                                                                             \
-    hipLaunchKernelGGL((k_preprocess_bwd<DEG, RAW, CAM>), dim3(grid), dim3(kPreThreads), 0, st, cp, N, a->means3D, a->scales, a->rotations, \
-                       a->cov3D_precomp, a->shs, a->shs_rest, splat, gg, a->d_means3D, a->d_means2D, a->d_opacities,                       \
-                       a->d_colors_precomp, a->d_shs, a->d_shs_rest, a->d_scales, a->d_rotations, a->d_cov3D_precomp, cam_partial)
+    AdamDev ad = {};
+    const GsrFusedAdam* fa = a->fused_adam;
+    if (fa) {
+        if (!a->raw_params || !a->shs || !a->shs_rest || a->cov3D_precomp || a->colors_precomp || !a->scales || !a->rotations || !a->opacities ||
+            a->M < 1 || fa->step <= 0)
+            return fail(GSR_ERR_ARG, "fused_adam needs raw_params with shs (f_dc) + shs_rest, scales, rotations and opacities%s");
+        for (int q = 0; q < 6; q++) {
+            if (!fa->exp_avg[q] || !fa->exp_avg_sq[q]) return fail(GSR_ERR_ARG, "fused_adam: missing moment buffer%s");
+            ad.m[q] = fa->exp_avg[q]; ad.v[q] = fa->exp_avg_sq[q];
+            ad.step_size[q] = fa->lr[q] / (float)(1.0 - pow((double)fa->beta1, (double)fa->step));
+        }
+        ad.b1 = fa->beta1; ad.b2 = fa->beta2; ad.eps = fa->eps;
+        ad.inv_bc2s = 1.f / (float)sqrt(1.0 - pow((double)fa->beta2, (double)fa->step));
+    } else if (!a->d_means3D || !a->d_opacities)
+        return fail(GSR_ERR_ARG, "missing workspace / gradient pointer%s");
+#define GSR_PREB_(DEG, RAW, CAM, ADAM)                                                                                                      \
+    hipLaunchKernelGGL((k_preprocess_bwd<DEG, RAW, CAM, ADAM>), dim3(grid), dim3(kPreThreads), 0, st, cp, N, a->means3D, a->scales,        \
+                       a->rotations, a->cov3D_precomp, a->shs, a->shs_rest, a->opacities, ad, splat, gg, a->d_means3D, a->d_means2D,        \
+                       a->d_opacities, a->d_colors_precomp, a->d_shs, a->d_shs_rest, a->d_scales, a->d_rotations, a->d_cov3D_precomp,      \
+                       cam_partial)
 #define GSR_PREB(DEG)                                                     \
     do {                                                                  \
-        if (a->raw_params) { if (want_cam) GSR_PREB_(DEG, true, true); else GSR_PREB_(DEG, true, false); }   \
-        else { if (want_cam) GSR_PREB_(DEG, false, true); else GSR_PREB_(DEG, false, false); }               \
+        if (fa) { if (want_cam) GSR_PREB_(DEG, true, true, true); else GSR_PREB_(DEG, true, false, true); }                 \
+        else if (a->raw_params) { if (want_cam) GSR_PREB_(DEG, true, true, false); else GSR_PREB_(DEG, true, false, false); }   \
+        else { if (want_cam) GSR_PREB_(DEG, false, true, false); else GSR_PREB_(DEG, false, false, false); }               \
     } while (0)
     {
         ProfScope ps(P_PRE_BWD, st);

@@ -10,6 +10,7 @@
 #include <stdint.h>
 
 #include "../../include/gsr.h"
+#include "adam_math.h"
 
 namespace gsr {
 
@@ -23,15 +24,6 @@ struct AdamBatch {
     int count;
     float beta1, beta2, eps, bc1, bc2_sqrt;
 };
-
-__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float b1, float b2, float eps, float step_size,
-                                         float inv_bc2s)
-{
-    m = fmaf(g - m, 1.f - b1, m);
-    v = fmaf(v, b2, (1.f - b2) * g * g);
-    const float denom = sqrtf(v) * inv_bc2s + eps;
-    p -= step_size * (m / denom);
-}
 
 __global__ __launch_bounds__(kAdamThreads) void k_adam(AdamBatch B)
 {

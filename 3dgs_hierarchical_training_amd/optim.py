@@ -35,6 +35,35 @@ class FusedAdam:
             elif p.grad is not None:
                 p.grad.zero_()
 
+    FUSED_ORDER = ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation")
+
+    def _state(self, p):
+        st = self.state.get(id(p))
+        if st is None:
+            st = self.state[id(p)] = {"exp_avg": torch.zeros_like(p), "exp_avg_sq": torch.zeros_like(p)}
+        return st
+
+    def fused_backward_args(self, tensors: Dict[str, torch.Tensor]) -> "L.GsrFusedAdam":
+        """GsrFusedAdam for the optimizer-in-backward mode of gsr_backward: counts as this optimizer's next step.
+        `tensors` are the parameter tensors the rasterizer saved, by group name; they must be the optimizer's own."""
+        by_name = {g.get("name"): g for g in self.param_groups}
+        if set(by_name) != set(self.FUSED_ORDER):
+            raise RuntimeError(f"fused_adam: optimizer groups must be named {self.FUSED_ORDER}, got {tuple(by_name)}")
+        fa = L.GsrFusedAdam()
+        fa.beta1, fa.beta2, fa.eps = float(self.betas[0]), float(self.betas[1]), float(self.eps)
+        for k, name in enumerate(self.FUSED_ORDER):
+            g = by_name[name]
+            p = g["params"][0]
+            t = tensors[name]
+            if t.data_ptr() != p.data_ptr() or t.numel() != p.numel() or p.dtype != torch.float32 or not p.is_contiguous():
+                raise RuntimeError(f"fused_adam: group '{name}' is not the contiguous float32 tensor that was rasterized")
+            st = self._state(p)
+            fa.lr[k] = float(g["lr"])
+            fa.exp_avg[k], fa.exp_avg_sq[k] = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+        self.step_count += 1
+        fa.step = self.step_count
+        return fa
+
     @torch.no_grad()
     def step(self):
         lib = L.load()
@@ -50,9 +79,7 @@ class FusedAdam:
         for k, g in enumerate(live):
             p = g["params"][0]
             assert p.is_contiguous() and p.dtype == torch.float32
-            st = self.state.get(id(p))
-            if st is None:
-                st = self.state[id(p)] = {"exp_avg": torch.zeros_like(p), "exp_avg_sq": torch.zeros_like(p)}
+            st = self._state(p)
             grad = p.grad.contiguous()
             keep.append(grad)
             arr[k].param, arr[k].grad = p.data_ptr(), grad.data_ptr()

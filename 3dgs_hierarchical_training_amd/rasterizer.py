@@ -94,7 +94,7 @@ class _Workspace:
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
-                sh_rest=None, raw_params=False, viewmatrix=None, projmatrix=None, campos=None):
+                sh_rest=None, raw_params=False, viewmatrix=None, projmatrix=None, campos=None, fused_adam=None):
         # viewmatrix / projmatrix / campos are ALSO passed as explicit tensor inputs (same objects as in
         # raster_settings) so that autograd can return their gradients: a NamedTuple cannot carry grads.
         lib = L.load()
@@ -147,6 +147,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.dims = (N, M, H, W)
         ctx.has = (sh is not None, colors_precomp is not None, scales is not None, cov3Ds_precomp is not None)
         ctx.raw = (sh_rest is not None, bool(raw_params))
+        ctx.fused_adam = fused_adam
         z = means3D.new_empty(0)
         # NOTE: depth is deliberately NOT saved -- the caller mutates it in place (ht3dgs_trainer.py:1290-1292).
         ctx.save_for_backward(means3D, opacities, sh if sh is not None else z, colors_precomp if colors_precomp is not None else z,
@@ -169,21 +170,32 @@ class _RasterizeGaussians(torch.autograd.Function):
         dev = means3D.device
         grad_color, grad_depth, grad_alpha = _f32c(grad_color), _f32c(grad_depth), _f32c(grad_alpha)
         if grad_color is None and grad_depth is None and grad_alpha is None:
-            return (None,) * 14
+            return (None,) * 15
         need_vm, need_pm, need_cp = ctx.needs_input_grad[11], ctx.needs_input_grad[12], ctx.needs_input_grad[13]
         d_vm = torch.empty((4, 4), dtype=torch.float32, device=dev) if need_vm else None
         d_pm = torch.empty((4, 4), dtype=torch.float32, device=dev) if need_pm else None
         d_cp = torch.empty((3,), dtype=torch.float32, device=dev) if need_cp else None
 
-        d_means3D = torch.empty((N, 3), dtype=torch.float32, device=dev)
+        fused = ctx.fused_adam
         d_means2D = torch.empty((N, 3), dtype=torch.float32, device=dev)
-        d_opac = torch.empty((N, 1), dtype=torch.float32, device=dev)
-        d_sh = torch.empty((N, 1 if has_rest else M, 3), dtype=torch.float32, device=dev) if has_sh else None
-        d_sh_rest = torch.empty((N, M - 1, 3), dtype=torch.float32, device=dev) if (has_sh and has_rest) else None
-        d_col = torch.empty((N, 3), dtype=torch.float32, device=dev) if has_col else None
-        d_scales = torch.empty((N, 3), dtype=torch.float32, device=dev) if has_scale else None
-        d_rot = torch.empty((N, 4), dtype=torch.float32, device=dev) if has_scale else None
-        d_cov = torch.empty((N, 6), dtype=torch.float32, device=dev) if has_cov else None
+        d_means3D = d_opac = d_sh = d_sh_rest = d_col = d_scales = d_rot = d_cov = None
+        fa = None
+        if fused is not None:
+            # optimizer-in-backward: the kernel applies the Adam step to the raw parameters in place; their gradients
+            # are never materialised (the corresponding .grad stay None and optimizer.step() has nothing left to do)
+            if not (raw_params and has_rest and has_sh and has_scale):
+                raise RuntimeError("fused_adam needs the raw-parameter path (rasterize_gaussians_raw)")
+            fa = fused.fused_backward_args({"xyz": means3D, "f_dc": sh, "f_rest": sh_rest, "opacity": opacities,
+                                            "scaling": scales, "rotation": rotations})
+        else:
+            d_means3D = torch.empty((N, 3), dtype=torch.float32, device=dev)
+            d_opac = torch.empty((N, 1), dtype=torch.float32, device=dev)
+            d_sh = torch.empty((N, 1 if has_rest else M, 3), dtype=torch.float32, device=dev) if has_sh else None
+            d_sh_rest = torch.empty((N, M - 1, 3), dtype=torch.float32, device=dev) if (has_sh and has_rest) else None
+            d_col = torch.empty((N, 3), dtype=torch.float32, device=dev) if has_col else None
+            d_scales = torch.empty((N, 3), dtype=torch.float32, device=dev) if has_scale else None
+            d_rot = torch.empty((N, 4), dtype=torch.float32, device=dev) if has_scale else None
+            d_cov = torch.empty((N, 6), dtype=torch.float32, device=dev) if has_cov else None
         scratch = torch.empty(lib.gsr_backward_scratch_bytes(N), dtype=torch.uint8, device=dev)
 
         a = L.GsrBackwardArgs()
@@ -204,10 +216,11 @@ class _RasterizeGaussians(torch.autograd.Function):
         a.shs_rest = _ptr(sh_rest) if has_rest else None
         a.d_shs_rest, a.raw_params = _ptr(d_sh_rest), int(raw_params)
         a.d_viewmatrix, a.d_projmatrix, a.d_campos = _ptr(d_vm), _ptr(d_pm), _ptr(d_cp)
+        a.fused_adam = C.addressof(fa) if fa is not None else None
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
             L.check(lib.gsr_backward(C.byref(a), C.c_void_p(stream)), "gsr_backward")
-        return (d_means3D, d_means2D, d_sh, d_col, d_opac, d_scales, d_rot, d_cov, None, d_sh_rest, None, d_vm, d_pm, d_cp)
+        return (d_means3D, d_means2D, d_sh, d_col, d_opac, d_scales, d_rot, d_cov, None, d_sh_rest, None, d_vm, d_pm, d_cp, None)
 
 
 def _cam_inputs(rs):
@@ -219,17 +232,22 @@ def _cam_inputs(rs):
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                                     raster_settings, None, False, *_cam_inputs(raster_settings))
+                                     raster_settings, None, False, *_cam_inputs(raster_settings), None)
 
 
 def rasterize_gaussians_raw(means3D, means2D, features_dc, features_rest, opacity_logit, log_scales, rotations_raw,
-                            raster_settings):
+                            raster_settings, fused_adam=None):
     """Extension ("next" row f-2): rasterize straight from HTGaussianModel's raw parameters (_xyz, _features_dc,
     _features_rest, _opacity, _scaling, _rotation; /root/reference/scene/gaussian_model_ht.py:74-82) with the
-    activations of :49-65,128-133,176-188 fused into the HIP kernels; gradients are w.r.t. the raw tensors."""
+    activations of :49-65,128-133,176-188 fused into the HIP kernels; gradients are w.r.t. the raw tensors.
+
+    fused_adam = a `FusedAdam` whose groups are exactly these six tensors (names xyz, f_dc, f_rest, opacity, scaling,
+    rotation as at gaussian_model_ht.py:275-286): backward() then applies that optimizer's step inside the
+    per-Gaussian backward kernel (include/gsr.h GsrFusedAdam) and leaves the parameter .grad unset; means2D.grad is
+    still produced.  Same result as backward() followed by optimizer.step()."""
     e = torch.Tensor([])
     return _RasterizeGaussians.apply(means3D, means2D, features_dc, e, opacity_logit, log_scales, rotations_raw, e,
-                                     raster_settings, features_rest, True, *_cam_inputs(raster_settings))
+                                     raster_settings, features_rest, True, *_cam_inputs(raster_settings), fused_adam)
 
 
 class GaussianRasterizer(nn.Module):

@@ -125,7 +125,7 @@ def make_settings(scene: Dict, device, sh_degree: int, bg=None) -> GaussianRaste
 
 
 def render(params: GaussianParams, settings: GaussianRasterizationSettings, clamp: bool = True,
-           fused_activations: bool = False) -> Dict:
+           fused_activations: bool = False, fused_adam=None) -> Dict:
     """CF3DGS_Render.render with compute_cov3D_python = convert_SHs_python = False.
     fused_activations=True hands the raw parameters to the kernels (exp / sigmoid / normalize / cat in-kernel)."""
     xyz = params.get_xyz
@@ -136,7 +136,7 @@ def render(params: GaussianParams, settings: GaussianRasterizationSettings, clam
         pass
     if fused_activations:
         out = rasterize_gaussians_raw(xyz, screenspace_points, params._features_dc, params._features_rest, params._opacity,
-                                      params._scaling, params._rotation, settings)
+                                      params._scaling, params._rotation, settings, fused_adam=fused_adam)
     else:
         rasterizer = GaussianRasterizer(raster_settings=settings)
         out = rasterizer(means3D=xyz, means2D=screenspace_points, shs=params.get_features, colors_precomp=None,
@@ -148,11 +148,16 @@ def render(params: GaussianParams, settings: GaussianRasterizationSettings, clam
 
 
 def train_step(params: GaussianParams, settings: GaussianRasterizationSettings, gt: torch.Tensor,
-               lambda_dssim: float = 0.2, fused_loss: bool = True, fused_activations: bool = True) -> Dict:
+               lambda_dssim: float = 0.2, fused_loss: bool = True, fused_activations: bool = True,
+               fused_optimizer: bool = True) -> Dict:
     """render -> loss -> backward -> Adam step (ht3dgs_trainer.py:102-166 without densification).
     fused_loss=True evaluates clamp + L1 + SSIM in the HIP loss kernels; False uses the torch restatement.
-    fused_activations=True runs exp / sigmoid / normalize / cat inside the rasterizer kernels."""
-    pkg = render(params, settings, clamp=not fused_loss, fused_activations=fused_activations)
+    fused_activations=True runs exp / sigmoid / normalize / cat inside the rasterizer kernels.
+    fused_optimizer=True (needs fused_activations and the "hip" optimizer) applies the Adam step inside the
+    per-Gaussian backward kernel -- same update, the gradients just never travel through HBM; optimizer.step()
+    then finds no .grad and is a no-op."""
+    fused_adam = params.optimizer if (fused_optimizer and fused_activations and isinstance(params.optimizer, FusedAdam)) else None
+    pkg = render(params, settings, clamp=not fused_loss, fused_activations=fused_activations, fused_adam=fused_adam)
     if fused_loss:
         loss = fused_photometric_loss(pkg["raw_image"], gt, lambda_dssim, clamp=True)
     else:

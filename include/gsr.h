@@ -82,6 +82,24 @@ typedef struct GsrForwardOut {
     size_t binning_bytes;
 } GsrForwardOut;
 
+/* Optimizer-in-backward: with raw_params = 1, shs (= _features_dc) + shs_rest given and this struct attached,
+ * gsr_backward applies the Adam step of /root/reference/scene/gaussian_model_ht.py:275-289 (torch.optim.Adam, no
+ * amsgrad / weight decay; ht3dgs_trainer.py:159-166 calls step() right after backward()) to the six parameter tensors
+ * IN PLACE inside the per-Gaussian backward kernel, instead of writing their gradients: the gradient never makes
+ * the round trip through HBM (2228 -> ~1530 bytes per Gaussian for backward + optimizer).  The parameter pointers of
+ * GsrBackwardArgs (means3D, shs, shs_rest, opacities, scales, rotations) are then written through; d_means3D,
+ * d_opacities, d_shs, d_shs_rest, d_scales, d_rotations are ignored (may be NULL); d_means2D is still produced
+ * (densification statistics, gaussian_model_ht.py:718-721).  Group order of lr / exp_avg / exp_avg_sq:
+ * 0 xyz, 1 f_dc, 2 f_rest, 3 opacity, 4 scaling, 5 rotation.  `step` is the 1-based step count. */
+typedef struct GsrFusedAdam {
+    float beta1, beta2, eps;
+    int32_t reserved;
+    int64_t step;
+    float lr[6];
+    float* exp_avg[6];
+    float* exp_avg_sq[6];
+} GsrFusedAdam;
+
 typedef struct GsrBackwardArgs {
     int32_t N, M, D, W, H;
     float scale_modifier, tanfovx, tanfovy;
@@ -112,6 +130,8 @@ typedef struct GsrBackwardArgs {
     float* d_viewmatrix;     /* 16 */
     float* d_projmatrix;     /* 16 */
     float* d_campos;         /* 3 */
+    /* ---- optimizer-in-backward (extension f-2, see GsrFusedAdam below).  NULL = plain backward. */
+    const struct GsrFusedAdam* fused_adam;
 } GsrBackwardArgs;
 
 size_t gsr_geom_bytes(int32_t N);

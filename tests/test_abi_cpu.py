@@ -31,7 +31,8 @@ def test_struct_layout_matches_header():
     """ctypes mirrors of the argument structs have the field order of include/gsr.h."""
     L = importlib.import_module("3dgs_hierarchical_training_amd._lib")
     hdr = open(os.path.join(REPO, "include", "gsr.h")).read()
-    for name, cls in [("GsrForwardArgs", L.GsrForwardArgs), ("GsrBackwardArgs", L.GsrBackwardArgs), ("GsrForwardOut", L.GsrForwardOut)]:
+    for name, cls in [("GsrForwardArgs", L.GsrForwardArgs), ("GsrBackwardArgs", L.GsrBackwardArgs), ("GsrForwardOut", L.GsrForwardOut),
+                      ("GsrFusedAdam", L.GsrFusedAdam)]:
         body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), hdr, re.S).group(1)
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         fields = []
@@ -40,7 +41,7 @@ def test_struct_layout_matches_header():
             if not stmt:
                 continue
             for part in stmt.split(","):
-                fields.append(re.findall(r"([A-Za-z_][A-Za-z0-9_]*)\s*$", part.strip())[0])
+                fields.append(re.findall(r"([A-Za-z_][A-Za-z0-9_]*)\s*(?:\[\d+\])?$", part.strip())[0])
         assert fields == [f[0] for f in cls._fields_], name
 
 

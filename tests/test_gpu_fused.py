@@ -80,6 +80,58 @@ def test_train_step_variants_agree():
     assert np.allclose(la, lb, rtol=2e-4), (la, lb)
 
 
+@pytest.mark.parametrize("n,deg", [(30000, 3), (30001, 3), (20011, 1), (4099, 0)])
+def test_optimizer_in_backward_equals_backward_then_step(n, deg):
+    """GsrFusedAdam (Adam applied inside the per-Gaussian backward kernel) == backward() + gsr_adam_step: same
+    gradient arithmetic, same update arithmetic, only the HBM round trip of the gradient is gone.  Two runs of the
+    blend backward differ in the last bits (float atomics across tiles commit in any order), and Adam with eps = 1e-15
+    turns the relative noise of a nearly cancelled gradient into a visible fraction of an lr step, so the comparison
+    is: all but 1e-3 of the elements agree to 5% of one learning-rate step + 4 ulp (parameters; a wrong group, column
+    or learning rate moves most elements by a whole step) / 1e-3 relative (moments).  Covers the 16-byte streams (n
+    multiple of 128), the ragged last block, and SH bands above the active degree (deg < 3 with 16 stored
+    coefficients: zero gradient, moments still decay)."""
+    dev = torch.device("cuda:0")
+    sc = parity.syn.make_scene(n, 320, 240, sh_degree=3, seed=9)
+    sc["sh_degree"] = deg
+    gt = parity.syn.target_image(320, 240).to(dev)
+    settings = ts.make_settings(sc, dev, deg)
+    pa, pb = ts.GaussianParams(sc, dev, optimizer="hip"), ts.GaussianParams(sc, dev, optimizer="hip")
+    names = ["_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation"]
+    lrs = {id(g["params"][0]): g["lr"] for g in pa.optimizer.param_groups}
+
+    def bad_frac(a, b, rtol, atol):
+        return ((a - b).abs() > atol + rtol * b.abs()).float().mean().item()
+
+    for it in range(3):
+        ka = ts.train_step(pa, settings, gt, fused_optimizer=True)
+        kb = ts.train_step(pb, settings, gt, fused_optimizer=False)
+        assert all(getattr(pa, k).grad is None for k in names)
+        ga, gb = ka["viewspace_points"].grad, kb["viewspace_points"].grad
+        assert bad_frac(ga, gb, 1e-3, 1e-3 * gb.abs().max().item() * 1e-3) < 1e-4
+        for k in names:
+            a, b = getattr(pa, k).detach(), getattr(pb, k).detach()
+            assert bad_frac(a, b, 5e-7, 0.05 * lrs[id(getattr(pa, k))]) < 1e-3, (it, k, (a - b).abs().max().item())
+            assert (a - b).abs().max().item() <= 2.5 * (it + 1) * lrs[id(getattr(pa, k))] + 1e-6 * b.abs().max().item()
+            sa, sb = pa.optimizer.state[id(getattr(pa, k))], pb.optimizer.state[id(getattr(pb, k))]
+            for mom in ("exp_avg", "exp_avg_sq"):
+                scale = sb[mom].abs().max().item()
+                assert bad_frac(sa[mom], sb[mom], 1e-3, 1e-6 * scale) < 1e-3, (it, k, mom)
+    assert pa.optimizer.step_count == pb.optimizer.step_count == 3
+    if deg < 3:   # bands above the active degree: no gradient, so both routes must agree exactly (and stay put)
+        hi = 3 * ((deg + 1) ** 2 - 1) // 3
+        assert torch.equal(pa._features_rest[:, hi:], pb._features_rest[:, hi:])
+
+
+def test_optimizer_in_backward_refuses_foreign_tensors():
+    dev = torch.device("cuda:0")
+    sc = parity.syn.make_scene(2000, 128, 96, sh_degree=3, seed=2)
+    settings = ts.make_settings(sc, dev, 3)
+    pa, pb = ts.GaussianParams(sc, dev, optimizer="hip"), ts.GaussianParams(sc, dev, optimizer="hip")
+    pkg = ts.render(pa, settings, clamp=False, fused_activations=True, fused_adam=pb.optimizer)   # someone else's optimizer
+    with pytest.raises(RuntimeError, match="fused_adam"):
+        pkg["raw_image"].sum().backward()
+
+
 def test_calc_importance_matches_oracle():
     """Merge-time pruning score (ht3dgs_trainer.py:1427-1462): |dL/dSH| with grad_out = 1 through clamp(0,1),
     summed over views, / num_pixels -- against the float64 oracle's backward."""
