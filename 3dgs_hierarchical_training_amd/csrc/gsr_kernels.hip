@@ -33,7 +33,7 @@ static int g_blend_ppt = 0;   // 0 = default
 static int g_bwd_ppt = 0;
 // 1 (default) = onesweep (decoupled look-back) for the depth sort over N, histogram+scan+scatter for the tile
 // sort over R (measured: 115 vs 140 us and 164 vs 157 us); 0 = three-kernel passes everywhere; 2 = onesweep everywhere
-static int g_sort_algo = 1;
+static int g_sort_algo = 2;   // 2: onesweep for both sorts; 1: onesweep depth sort + hist/scan/scatter tile sort; 0: hist/scan/scatter
 
 static int fail(int code, const char* fmt, const char* detail = "")
 {

@@ -4,10 +4,11 @@
 // keys over the R instances.  One pass = 8 bits = three launches:
 //   k_radix_hist     per-block digit histogram (block = 4096 keys)        -> hist[digit][block]
 //   k_radix_scan     one workgroup per digit: exclusive scan over blocks + digit base
-//   k_radix_scatter  stable in-block ranking with wave64 match-any ballots, LDS-staged so that the
-//                    global writes of one digit run are consecutive lanes -> coalesced
-// Stability inside a block comes from an explicit (round, wave, lane) order: the count matrix
-// cnt[round][wave][digit] is prefix-summed in that order, no atomics are involved in ranking.
+//   k_radix_scatter  stable in-block ranking (wave_rank below), LDS-staged so that the global writes of one
+//                    digit run are consecutive lanes -> coalesced
+// Stability inside a block comes from an explicit (wave, round, lane) order: wave w owns keys
+// [w*1024, (w+1)*1024) of the tile, ranks them round by round against its own running per-digit count, and the
+// per-wave counts are prefix-summed in wave order.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -23,6 +24,64 @@ __device__ __forceinline__ unsigned long long lanemask_lt()
 {
     const unsigned lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     return (1ull << lane) - 1ull;
+}
+
+// ---- in-wave ranking -------------------------------------------------------------------------------------------
+// "Which lanes of my wave hold my digit" without the 8 ballots + 8 per-lane selects of the classic match-any loop
+// (that loop was ~60 VALU instructions per key and made the scatter kernels issue-bound at 2 waves per SIMD): every
+// lane XORs its lane bit into a per-wave 64-bit LDS word of its digit and reads the word before and after; the
+// difference is exactly the set of lanes that toggled it this round.  XOR commutes, so the outcome does not depend
+// on the order in which the LDS unit serialises same-address atomics; LDS instructions of one wave execute in issue
+// order, so "read, xor, read" needs no barrier; nothing is ever reset (a round only looks at the difference).
+// s_cnt[digit] is the wave's running count of the digit over the rounds done so far.
+// rnk[r] = number of this wave's keys with the same digit that precede key r in (round, lane) order.
+__device__ __forceinline__ void wave_rank(unsigned long long* s_mask, uint32_t* s_cnt, const uint32_t (&dig)[kSortIPT],
+                                          uint32_t (&rnk)[kSortIPT], int lane)
+{
+#pragma unroll
+    for (int k = 0; k < 4; k++) { s_mask[k * 64 + lane] = 0ull; s_cnt[k * 64 + lane] = 0u; }
+    __builtin_amdgcn_wave_barrier();
+    const unsigned long long bit = 1ull << lane, lt = bit - 1ull;
+    volatile unsigned long long* vmask = s_mask;
+    volatile uint32_t* vcnt = s_cnt;
+#pragma unroll
+    for (int r = 0; r < kSortIPT; r++) {
+        const uint32_t d = dig[r];
+        uint32_t below, group;
+        const uint32_t base = vcnt[d];
+        if (__all(d == (uint32_t)__builtin_amdgcn_readfirstlane((int)d))) {   // one digit in the whole wave (high passes)
+            below = (uint32_t)lane; group = 64u;
+        } else {
+            const unsigned long long before = vmask[d];
+            atomicXor(&s_mask[d], bit);
+            const unsigned long long peers = before ^ vmask[d];
+            below = (uint32_t)__popcll(peers & lt);
+            group = (uint32_t)__popcll(peers);
+        }
+        rnk[r] = base + below;
+        __builtin_amdgcn_wave_barrier();
+        if (below == 0u) vcnt[d] = base + group;
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// exclusive scan of one value per thread over the 256 threads of the block (two barriers)
+__device__ __forceinline__ uint32_t block_scan_excl_256(uint32_t v, uint32_t* s_wsum /*[4]*/, int tid)
+{
+    const int lane = tid & 63, wave = tid >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)inc, off, 64);
+        if (lane >= off) inc += t;
+    }
+    if (lane == 63) s_wsum[wave] = inc;
+    __syncthreads();
+    uint32_t add = 0;
+#pragma unroll
+    for (int w = 0; w < kSortWaves; w++) add += (w < wave) ? s_wsum[w] : 0u;
+    __syncthreads();
+    return add + inc - v;
 }
 
 template <typename KeyT>
@@ -103,27 +162,24 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const KeyT* __re
                                                                 KeyT* __restrict__ kout, uint32_t* __restrict__ vout, uint32_t n,
                                                                 int shift, const uint32_t* __restrict__ hist, uint32_t nblocks)
 {
-    __shared__ uint16_t cnt[kSortIPT][kSortWaves][256];   // 32 KiB
+    __shared__ unsigned long long s_mask[kSortWaves][256];
+    __shared__ uint32_t s_cnt[kSortWaves][256];
     __shared__ KeyT s_keys[kSortTile];
     __shared__ uint32_t s_vals[kSortTile];
     __shared__ uint32_t s_start[256];    // block-local exclusive start of each digit
     __shared__ uint32_t s_gbase[256];    // global base of each digit for this block minus s_start
-    const int tid = threadIdx.x, wave = tid >> 6;
+    __shared__ uint32_t s_wsum[kSortWaves];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const uint32_t base = blockIdx.x * (uint32_t)kSortTile;
     const uint32_t valid = min((uint32_t)kSortTile, n - base);
 
-    {   // zero the count matrix (16384 u16 = 8192 u32)
-        uint32_t* z = reinterpret_cast<uint32_t*>(&cnt[0][0][0]);
-#pragma unroll
-        for (int k = 0; k < (kSortIPT * kSortWaves * 256 / 2) / kSortThreads; k++) z[k * kSortThreads + tid] = 0u;
-    }
     KeyT key[kSortIPT];
     uint32_t val[kSortIPT];
     uint32_t dig[kSortIPT];
     uint32_t rnk[kSortIPT];
 #pragma unroll
     for (int r = 0; r < kSortIPT; r++) {
-        const uint32_t p = r * kSortThreads + tid;
+        const uint32_t p = (uint32_t)(wave * (kSortIPT * 64) + r * 64 + lane);   // wave-major: see wave_rank
         if (p < valid) {
             key[r] = kin[base + p];
             val[r] = vin[base + p];
@@ -132,51 +188,22 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const KeyT* __re
             key[r] = (KeyT)~(KeyT)0; val[r] = 0u; dig[r] = 255u;   // padding sorts behind every real item
         }
     }
+    wave_rank(s_mask[wave], s_cnt[wave], dig, rnk, lane);
     __syncthreads();
-    const unsigned long long lt = lanemask_lt();
+    uint32_t mine = 0;   // thread = digit: exclusive prefix of the per-wave counts in wave order
 #pragma unroll
-    for (int r = 0; r < kSortIPT; r++) {
-        unsigned long long peers = ~0ull;
-#pragma unroll
-        for (int b = 0; b < 8; b++) {
-            const bool bit = (dig[r] >> b) & 1u;
-            const unsigned long long m = __ballot(bit);
-            peers &= bit ? m : ~m;
-        }
-        rnk[r] = (uint32_t)__popcll(peers & lt);
-        if (rnk[r] == 0) cnt[r][wave][dig[r]] = (uint16_t)__popcll(peers);
+    for (int w = 0; w < kSortWaves; w++) {
+        const uint32_t c = s_cnt[w][tid];
+        s_cnt[w][tid] = mine;
+        mine += c;
     }
-    __syncthreads();
-    {   // thread = digit: exclusive prefix over (round, wave) in stable order
-        uint32_t run = 0;
-#pragma unroll
-        for (int r = 0; r < kSortIPT; r++)
-#pragma unroll
-            for (int w = 0; w < kSortWaves; w++) {
-                const uint32_t c = cnt[r][w][tid];
-                cnt[r][w][tid] = (uint16_t)run;
-                run += c;
-            }
-        s_start[tid] = run;   // digit total, scanned below
-    }
-    __syncthreads();
-    {   // exclusive scan of the digit totals
-        const uint32_t mine = s_start[tid];
-        for (int off = 1; off < 256; off <<= 1) {
-            const uint32_t v = (tid >= off) ? s_start[tid - off] : 0u;
-            __syncthreads();
-            s_start[tid] += v;
-            __syncthreads();
-        }
-        const uint32_t excl = s_start[tid] - mine;
-        __syncthreads();
-        s_start[tid] = excl;
-        s_gbase[tid] = hist[(size_t)tid * nblocks + blockIdx.x] - excl;
-    }
+    const uint32_t excl = block_scan_excl_256(mine, s_wsum, tid);
+    s_start[tid] = excl;
+    s_gbase[tid] = hist[(size_t)tid * nblocks + blockIdx.x] - excl;
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < kSortIPT; r++) {
-        const uint32_t lp = s_start[dig[r]] + cnt[r][wave][dig[r]] + rnk[r];
+        const uint32_t lp = s_start[dig[r]] + s_cnt[wave][dig[r]] + rnk[r];
         s_keys[lp] = key[r];
         s_vals[lp] = val[r];
     }
@@ -215,7 +242,23 @@ __global__ __launch_bounds__(256) void k_radix_ghist(const KeyT* __restrict__ ke
 #pragma unroll
     for (int p = 0; p < PASSES; p++) h[p][tid] = 0;
     __syncthreads();
-    for (uint32_t i = blockIdx.x * 256 + tid; i < n; i += gridDim.x * 256) {
+    constexpr int KPV = 16 / (int)sizeof(KeyT);   // keys per 16-byte load
+    const uint32_t nv = (((uintptr_t)keys & 15) == 0) ? n / KPV : 0u;
+    const uint4* k4 = reinterpret_cast<const uint4*>(keys);
+    for (uint32_t i = blockIdx.x * 256 + tid; i < nv; i += gridDim.x * 256) {
+        const uint4 q = k4[i];
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+#pragma unroll
+            for (int e = 0; e < KPV / 4; e++) {
+                const uint32_t k = (sizeof(KeyT) == 4 ? w[c] : ((w[c] >> (16 * e)) & 0xffffu)) >> begin_bit;
+#pragma unroll
+                for (int p = 0; p < PASSES; p++) atomicAdd(&h[p][(k >> (8 * p)) & 0xffu], 1u);
+            }
+        }
+    }
+    for (uint32_t i = nv * KPV + blockIdx.x * 256 + tid; i < n; i += gridDim.x * 256) {
         const uint32_t k = (uint32_t)keys[i] >> begin_bit;
 #pragma unroll
         for (int p = 0; p < PASSES; p++) atomicAdd(&h[p][(k >> (8 * p)) & 0xffu], 1u);
@@ -233,29 +276,30 @@ __global__ __launch_bounds__(kSortThreads) void k_onesweep(const KeyT* __restric
                                                            uint32_t* __restrict__ status /*[nblocks][256]*/,
                                                            uint32_t* __restrict__ ticket)
 {
-    __shared__ uint16_t cnt[kSortIPT][kSortWaves][256];
+    __shared__ unsigned long long s_mask[kSortWaves][256];
+    __shared__ uint32_t s_cnt[kSortWaves][256];
     __shared__ KeyT s_keys[kSortTile];
     __shared__ uint32_t s_vals[kSortTile];
     __shared__ uint32_t s_start[256];
     __shared__ uint32_t s_gbase[256];
-    __shared__ uint32_t s_scan[256];
+    __shared__ uint32_t s_wsum[kSortWaves];
     __shared__ uint32_t s_tile;
-    const int tid = threadIdx.x, wave = tid >> 6;
-    if (tid == 0) s_tile = atomicAdd(ticket, 1u);
-    {
-        uint32_t* z = reinterpret_cast<uint32_t*>(&cnt[0][0][0]);
-#pragma unroll
-        for (int k = 0; k < (kSortIPT * kSortWaves * 256 / 2) / kSortThreads; k++) z[k * kSortThreads + tid] = 0u;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // ticket == nullptr: the whole grid is co-resident (host checked), so blockIdx order is as good as ticket order and
+    // the ~2 us global-atomic round trip at the head of every block's latency chain is saved
+    uint32_t tile = blockIdx.x;
+    if (ticket) {
+        if (tid == 0) s_tile = atomicAdd(ticket, 1u);
+        __syncthreads();
+        tile = s_tile;
     }
-    __syncthreads();
-    const uint32_t tile = s_tile;
     const uint32_t base = tile * (uint32_t)kSortTile;
     const uint32_t valid = min((uint32_t)kSortTile, n - base);
     KeyT key[kSortIPT];
     uint32_t val[kSortIPT], dig[kSortIPT], rnk[kSortIPT];
 #pragma unroll
     for (int r = 0; r < kSortIPT; r++) {
-        const uint32_t p = r * kSortThreads + tid;
+        const uint32_t p = (uint32_t)(wave * (kSortIPT * 64) + r * 64 + lane);   // wave-major: see wave_rank
         if (p < valid) {
             key[r] = kin[base + p];
             val[r] = vin[base + p];
@@ -264,67 +308,48 @@ __global__ __launch_bounds__(kSortThreads) void k_onesweep(const KeyT* __restric
             key[r] = (KeyT)~(KeyT)0; val[r] = 0u; dig[r] = 255u;
         }
     }
-    const unsigned long long lt = lanemask_lt();
-#pragma unroll
-    for (int r = 0; r < kSortIPT; r++) {
-        unsigned long long peers = ~0ull;
-#pragma unroll
-        for (int b = 0; b < 8; b++) {
-            const bool bit = (dig[r] >> b) & 1u;
-            const unsigned long long m = __ballot(bit);
-            peers &= bit ? m : ~m;
-        }
-        rnk[r] = (uint32_t)__popcll(peers & lt);
-        if (rnk[r] == 0) cnt[r][wave][dig[r]] = (uint16_t)__popcll(peers);
-    }
+    wave_rank(s_mask[wave], s_cnt[wave], dig, rnk, lane);
     __syncthreads();
-    uint32_t mine;   // this tile's count of digit `tid` (padding counted in digit 255; removed below)
-    {
-        uint32_t run = 0;
+    uint32_t mine = 0;   // this tile's count of digit `tid` (padding counted in digit 255; removed below)
 #pragma unroll
-        for (int r = 0; r < kSortIPT; r++)
-#pragma unroll
-            for (int w = 0; w < kSortWaves; w++) {
-                const uint32_t c = cnt[r][w][tid];
-                cnt[r][w][tid] = (uint16_t)run;
-                run += c;
-            }
-        mine = run;
+    for (int w = 0; w < kSortWaves; w++) {
+        const uint32_t c = s_cnt[w][tid];
+        s_cnt[w][tid] = mine;
+        mine += c;
     }
     const uint32_t real = (tid == 255) ? mine - ((uint32_t)kSortTile - valid) : mine;   // real keys of this digit
     uint32_t* my_status = status + (size_t)tile * 256 + tid;
     __hip_atomic_store(my_status, kOsLocal | real, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // local exclusive start of each digit (block scan of `mine`) and digit base (block scan of the global histogram)
-    s_start[tid] = mine;
-    s_scan[tid] = ghist[tid];
-    __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {
-        const uint32_t v = (tid >= off) ? s_start[tid - off] : 0u;
-        const uint32_t g = (tid >= off) ? s_scan[tid - off] : 0u;
-        __syncthreads();
-        s_start[tid] += v; s_scan[tid] += g;
-        __syncthreads();
-    }
-    const uint32_t lstart = s_start[tid] - mine;
-    const uint32_t dbase = s_scan[tid] - ghist[tid];
+    const uint32_t lstart = block_scan_excl_256(mine, s_wsum, tid);
+    const uint32_t dbase = block_scan_excl_256(ghist[tid], s_wsum, tid);
     // decoupled look-back over earlier tiles
+    // (windows of 4 independent loads: the walk is a chain of L2 round trips, and the chain is what a block waits on)
     uint32_t excl = 0;
     for (int t = (int)tile - 1; t >= 0;) {
-        const uint32_t v = __hip_atomic_load(status + (size_t)t * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t f = v & ~kOsMask;
-        if (f == 0u) { __builtin_amdgcn_s_sleep(1); continue; }
-        excl += v & kOsMask;
-        if (f == kOsIncl) break;
-        t--;
+        uint32_t v[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            v[q] = (t - q >= 0) ? __hip_atomic_load(status + (size_t)(t - q) * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kOsIncl;
+        bool done = false;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (done) break;
+            const uint32_t f = v[q] & ~kOsMask;
+            if (f == 0u) { done = true; break; }   // not published yet: re-poll from here
+            excl += v[q] & kOsMask;
+            t--;
+            if (f == kOsIncl) { t = -1; done = true; }
+        }
+        if (t >= 0 && done) __builtin_amdgcn_s_sleep(1);
     }
     __hip_atomic_store(my_status, kOsIncl | (excl + real), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
     s_start[tid] = lstart;
     s_gbase[tid] = dbase + excl - lstart;
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < kSortIPT; r++) {
-        const uint32_t lp = s_start[dig[r]] + cnt[r][wave][dig[r]] + rnk[r];
+        const uint32_t lp = s_start[dig[r]] + s_cnt[wave][dig[r]] + rnk[r];
         s_keys[lp] = key[r];
         s_vals[lp] = val[r];
     }
@@ -364,7 +389,7 @@ inline hipError_t onesweep_sort_pairs(KeyT* keys, uint32_t* vals, KeyT* keys_alt
     uint32_t* status = tickets + 64;
     hipError_t e = hipMemsetAsync(scratch, 0, (4 * 256 + 64 + (size_t)passes * nblocks * 256) * sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
-    const uint32_t hgrid = nblocks < 128u ? nblocks : 128u;
+    const uint32_t hgrid = nblocks < 256u ? nblocks : 256u;
     switch (passes) {
         case 1: hipLaunchKernelGGL((k_radix_ghist<KeyT, 1>), dim3(hgrid), dim3(256), 0, stream, keys, n, begin_bit, ghist); break;
         case 2: hipLaunchKernelGGL((k_radix_ghist<KeyT, 2>), dim3(hgrid), dim3(256), 0, stream, keys, n, begin_bit, ghist); break;
@@ -375,7 +400,7 @@ inline hipError_t onesweep_sort_pairs(KeyT* keys, uint32_t* vals, KeyT* keys_alt
     uint32_t *vin = vals, *vout = vals_alt;
     for (int p = 0; p < passes; p++) {
         hipLaunchKernelGGL(k_onesweep<KeyT>, dim3(nblocks), dim3(kSortThreads), 0, stream, kin, vin, kout, vout, n, begin_bit + 8 * p,
-                           ghist + p * 256, status + (size_t)p * nblocks * 256, tickets + p);
+                           ghist + p * 256, status + (size_t)p * nblocks * 256, nblocks <= 512u ? (uint32_t*)nullptr : tickets + p);
         KeyT* tk = kin; kin = kout; kout = tk;
         uint32_t* tv = vin; vin = vout; vout = tv;
         *in_alt ^= 1;

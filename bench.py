@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fwd-ppt", type=int, default=0)
     ap.add_argument("--bwd-ppt", type=int, default=0)
-    ap.add_argument("--sort-algo", type=int, default=-1, help="1 = onesweep (default), 0 = hist+scan+scatter per pass")
+    ap.add_argument("--sort-algo", type=int, default=-1, help="2 = onesweep for both sorts (default), 1 = onesweep depth sort only, 0 = hist+scan+scatter per pass")
     return ap.parse_args()
 
 

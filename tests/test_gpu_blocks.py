@@ -15,7 +15,7 @@ def sort_algo(request):
     lib = L.load()
     lib.gsr_set_option(b"sort_algo", request.param)
     yield request.param
-    lib.gsr_set_option(b"sort_algo", 1)
+    lib.gsr_set_option(b"sort_algo", 2)
 
 
 def _sort(keys, vals, bits, u16=False):
