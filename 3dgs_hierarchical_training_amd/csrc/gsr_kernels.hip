@@ -61,7 +61,7 @@ struct ProfScope {
     int id; hipStream_t st; hipEvent_t a = nullptr, b = nullptr;
     ProfScope(int id_, hipStream_t st_) : id(id_), st(st_)
     {
-        if (!g_profile) return;
+        if (!g_profile || (g_profile == 2 && id != P_BLEND_FWD)) return;
         if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
         (void)hipEventRecord(a, st);
     }
@@ -1460,7 +1460,7 @@ int gsr_set_option(const char* name, int value)
     if (!name) return GSR_ERR_ARG;
     // 1 / 3 / 4 = one workgroup per tile with 1 / 2 / 4 pixels per lane (scalar), 2 = packed 2-pixel, 5 = one wave per 8x8 sub-tile
     if (!strcmp(name, "blend_fwd_ppt")) { if (value < 0 || value > 5) return GSR_ERR_ARG; g_blend_ppt = value; return GSR_OK; }
-    if (!strcmp(name, "profile")) { g_profile = value ? 1 : 0; return GSR_OK; }
+    if (!strcmp(name, "profile")) { g_profile = (value == 2) ? 2 : (value ? 1 : 0); return GSR_OK; }
     if (!strcmp(name, "sort_algo")) { if (value < 0 || value > 2) return GSR_ERR_ARG; g_sort_algo = value; return GSR_OK; }
     // 2 = packed-math kernel (default), 3 = scalar 2-pixel kernel (kept for A/B), 1 / 4 = scalar 1 / 4 pixels
     if (!strcmp(name, "blend_bwd_ppt")) { if (value < 0 || value > 4) return GSR_ERR_ARG; g_bwd_ppt = value; return GSR_OK; }

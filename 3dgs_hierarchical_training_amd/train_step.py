@@ -129,11 +129,14 @@ def render(params: GaussianParams, settings: GaussianRasterizationSettings, clam
     """CF3DGS_Render.render with compute_cov3D_python = convert_SHs_python = False.
     fused_activations=True hands the raw parameters to the kernels (exp / sigmoid / normalize / cat in-kernel)."""
     xyz = params.get_xyz
-    screenspace_points = torch.zeros_like(xyz, requires_grad=True) + 0
-    try:
-        screenspace_points.retain_grad()
-    except Exception:
-        pass
+    # gaussian_model_ht.py:800-805 builds `zeros_like(xyz, requires_grad=True) + 0` every render only to receive
+    # the 2D positional gradient; its VALUES are never read by the rasterizer.  One zero leaf per model does the same
+    # job without a fill + add over N x 3 floats per step: its .grad is reset here and filled by backward().
+    screenspace_points = getattr(params, "_screenspace_zero", None)
+    if screenspace_points is None or screenspace_points.shape != xyz.shape or screenspace_points.device != xyz.device:
+        screenspace_points = torch.zeros_like(xyz, requires_grad=True)
+        params._screenspace_zero = screenspace_points
+    screenspace_points.grad = None
     if fused_activations:
         out = rasterize_gaussians_raw(xyz, screenspace_points, params._features_dc, params._features_rest, params._opacity,
                                       params._scaling, params._rotation, settings, fused_adam=fused_adam)

@@ -153,7 +153,8 @@ const char* gsr_last_error(void);
 int gsr_version(void);
 
 /* Process-wide knobs: "blend_fwd_ppt" / "blend_bwd_ppt" = pixels per thread of the blend kernels (1, 2, 4;
- * 0 = default); "profile" = 1 records HIP events around every stage on the caller's stream. */
+ * 0 = default); "profile" = 1 records HIP events around every stage on the caller's stream, 2 around the forward blend
+ * kernel only (an event pair costs ~10 us of stream bubble per stage). */
 int gsr_set_option(const char* name, int value);
 /* Sum of the recorded durations of stage `name` ("preprocess_fwd", "sort_depth", "scan", "emit", "sort_tile",
  * "ranges", "blend_fwd", "blend_bwd", "preprocess_bwd") since the last read; synchronises on the events. */
