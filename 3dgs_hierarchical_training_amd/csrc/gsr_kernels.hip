@@ -15,6 +15,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -375,7 +377,7 @@ __global__ __launch_bounds__(1024) void k_block_scan(uint32_t* __restrict__ bloc
 __global__ __launch_bounds__(kEmitThreads) void k_emit(int N, int W, int H, int tiles_x, int tiles_y,
                                                        const uint32_t* __restrict__ sorted_gid, const Splat* __restrict__ splat,
                                                        const uint32_t* __restrict__ block_offsets, uint16_t* __restrict__ out_tile,
-                                                       uint32_t* __restrict__ out_gid)
+                                                       uint32_t* __restrict__ out_gid, uint32_t cap)
 {
     __shared__ uint32_t s_wave[4];
     __shared__ uint32_t s_incl[kEmitThreads];
@@ -432,8 +434,10 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit(int N, int W, int H, int 
         for (int k = 0; k < 4; k++) { const uint32_t c = s_cnt[k]; pre += (k < wave) ? c : 0u; chunk += c; }
         if (ok) {
             const uint32_t pos = run + pre + (uint32_t)__popcll(m & lt);
-            out_tile[pos] = (uint16_t)tile;
-            out_gid[pos] = gg;
+            if (pos < cap) {   // cap = R, or the speculative capacity of gsr_forward (then an overflow is re-run)
+                out_tile[pos] = (uint16_t)tile;
+                out_gid[pos] = gg;
+            }
         }
         run += chunk;
         __syncthreads();
@@ -441,8 +445,10 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit(int N, int W, int H, int 
 }
 
 // K6: per-tile [start, end) from the tile-sorted keys (ranges pre-zeroed)
-__global__ void k_tile_ranges(uint32_t R, const uint16_t* __restrict__ keys, uint2* __restrict__ ranges)
+__global__ void k_tile_ranges(uint32_t R, const uint16_t* __restrict__ keys, uint2* __restrict__ ranges,
+                              const unsigned long long* __restrict__ n_dev)
 {
+    if (n_dev) R = (uint32_t)min((unsigned long long)R, *n_dev);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= R) return;
     const uint32_t t = keys[i];
@@ -1382,6 +1388,10 @@ static BinScratch bin_scratch_layout(int64_t R)
 
 static std::mutex g_pin_mutex;
 static unsigned long long* g_pinned = nullptr;
+static hipEvent_t g_pin_event = nullptr;
+static std::atomic<uint64_t> g_r_hint{0};   // capacity for the next speculative binning (0 = none yet: exact flow)
+static int g_speculate = 1;
+static std::atomic<int> g_spec_overflows{0};
 
 static int check_common(int32_t N, int32_t M, int32_t D, int32_t W, int32_t H)
 {
@@ -1460,6 +1470,8 @@ int gsr_set_option(const char* name, int value)
     if (!name) return GSR_ERR_ARG;
     // 1 / 3 / 4 = one workgroup per tile with 1 / 2 / 4 pixels per lane (scalar), 2 = packed 2-pixel, 5 = one wave per 8x8 sub-tile
     if (!strcmp(name, "blend_fwd_ppt")) { if (value < 0 || value > 5) return GSR_ERR_ARG; g_blend_ppt = value; return GSR_OK; }
+    if (!strcmp(name, "speculative_binning")) { g_speculate = value ? 1 : 0; return GSR_OK; }
+    if (!strcmp(name, "binning_capacity_hint")) { g_r_hint.store(value > 0 ? (uint64_t)value : 0); return GSR_OK; }   // tests: force an overflow
     if (!strcmp(name, "profile")) { g_profile = (value == 2) ? 2 : (value ? 1 : 0); return GSR_OK; }
     if (!strcmp(name, "sort_algo")) { if (value < 0 || value > 2) return GSR_ERR_ARG; g_sort_algo = value; return GSR_OK; }
     // 2 = packed-math kernel (default), 3 = scalar 2-pixel kernel (kept for A/B), 1 / 4 = scalar 1 / 4 pixels
@@ -1479,6 +1491,7 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
     const int tiles_x = (W + kTile - 1) / kTile, tiles_y = (H + kTile - 1) / kTile, T = tiles_x * tiles_y;
     out->num_rendered = 0; out->binning = nullptr; out->binning_bytes = 0;
     uint64_t R = 0;
+    unsigned long long* total_dev = nullptr;
     Splat* splat = static_cast<Splat*>(a->geom);
     uint32_t* sorted_gid = nullptr;
     uint8_t* fs = nullptr;
@@ -1529,23 +1542,50 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
             hipLaunchKernelGGL(k_block_scan, dim3(1), dim3(1024), 0, st, block_sums, nb, total);
         }
         GSR_HIP(hipGetLastError());
-        {
-            std::lock_guard<std::mutex> lk(g_pin_mutex);
-            if (!g_pinned) GSR_HIP(hipHostMalloc((void**)&g_pinned, 64, hipHostMallocDefault));
-            GSR_HIP(hipMemcpyAsync(g_pinned, total, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        total_dev = total;
+    }
+    // ---- the instance count R lives on the device.  Classic flow: read it back, synchronise, size the R-dependent
+    // buffers and grids exactly.  That puts a host round trip (~35 us of idle GPU per frame) in the middle of every
+    // forward, so by default the binning is launched SPECULATIVELY against a capacity (1.25x the recent frames' R):
+    // kernels take the true count from device memory, the read-back is only waited for after everything is enqueued,
+    // and in the rare overflow (R > capacity) the binning is simply launched again with the exact size. ----
+    std::unique_lock<std::mutex> pin_lock(g_pin_mutex, std::defer_lock);
+    uint64_t cap = 0;
+    bool speculative = false;
+    if (N > 0) {
+        pin_lock.lock();
+        if (!g_pinned) {
+            GSR_HIP(hipHostMalloc((void**)&g_pinned, 64, hipHostMallocDefault));
+            GSR_HIP(hipEventCreateWithFlags(&g_pin_event, hipEventDisableTiming));
+        }
+        GSR_HIP(hipMemcpyAsync(g_pinned, total_dev, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        const uint64_t hint = g_r_hint.load();
+        speculative = g_speculate && g_sort_algo == 2 && hint > 0;
+        if (speculative) {
+            GSR_HIP(hipEventRecord(g_pin_event, st));
+            cap = hint;
+        } else {
             GSR_HIP(hipStreamSynchronize(st));
             R = *g_pinned;
+            pin_lock.unlock();
+            if (R > 0xfffffff0ull) return fail(GSR_ERR_RANGE, "more than 2^32 instances%s");
+            cap = R;
         }
-        if (R > 0xfffffff0ull) return fail(GSR_ERR_RANGE, "more than 2^32 instances%s");
     }
-    BinLayout B = bin_layout((int64_t)R, W, H);
-    uint8_t* bin = static_cast<uint8_t*>(a->alloc(B.bytes, GSR_ALLOC_BINNING, a->alloc_user));
-    if (!bin) return fail(GSR_ERR_ALLOC, "binning allocation failed%s");
-    uint2* ranges = reinterpret_cast<uint2*>(bin + B.ranges);
-    uint32_t* list = reinterpret_cast<uint32_t*>(bin + B.list);
-    GSR_HIP(hipMemsetAsync(ranges, 0, (size_t)T * sizeof(uint2), st));
-    if (R > 0) {
-        BinScratch S = bin_scratch_layout((int64_t)R);
+    uint2* ranges = nullptr;
+    uint32_t* list = nullptr;
+    uint8_t* bin = nullptr;
+    BinLayout B = bin_layout(0, W, H);
+    // binning for `capacity` instances; n_dev != nullptr: the real count is read on the device
+    auto run_binning = [&](uint64_t capacity, const unsigned long long* n_dev) -> int {
+        B = bin_layout((int64_t)capacity, W, H);
+        bin = static_cast<uint8_t*>(a->alloc(B.bytes, GSR_ALLOC_BINNING, a->alloc_user));
+        if (!bin) return fail(GSR_ERR_ALLOC, "binning allocation failed%s");
+        ranges = reinterpret_cast<uint2*>(bin + B.ranges);
+        list = reinterpret_cast<uint32_t*>(bin + B.list);
+        GSR_HIP(hipMemsetAsync(ranges, 0, (size_t)T * sizeof(uint2), st));
+        if (capacity == 0) return GSR_OK;
+        BinScratch S = bin_scratch_layout((int64_t)capacity);
         uint8_t* bs = static_cast<uint8_t*>(a->alloc(S.bytes, GSR_ALLOC_SCRATCH, a->alloc_user));
         if (!bs) return fail(GSR_ERR_ALLOC, "binning scratch allocation failed%s");
         uint16_t* tkey = reinterpret_cast<uint16_t*>(bs + S.tile);
@@ -1561,20 +1601,25 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
         uint32_t* v1 = (passes & 1) ? list : gid_alt2;
         {
             ProfScope ps(P_EMIT, st);
-            hipLaunchKernelGGL(k_emit, dim3(nb), dim3(kEmitThreads), 0, st, N, W, H, tiles_x, tiles_y, sorted_gid, splat, block_sums, tkey, v0);
+            hipLaunchKernelGGL(k_emit, dim3(nb), dim3(kEmitThreads), 0, st, N, W, H, tiles_x, tiles_y, sorted_gid, splat, block_sums, tkey, v0,
+                               (uint32_t)capacity);
         }
         int in_alt = 0;
         {
             ProfScope ps(P_SORT_TILE, st);
-            GSR_HIP(g_sort_algo == 2 ? onesweep_sort_pairs<uint16_t>(tkey, v0, tkey_alt, v1, (uint32_t)R, 0, passes * 8, bs + S.sort, &in_alt, st)
-                                : radix_sort_pairs<uint16_t>(tkey, v0, tkey_alt, v1, (uint32_t)R, 0, passes * 8, bs + S.sort, &in_alt, st));
+            GSR_HIP(g_sort_algo == 2 ? onesweep_sort_pairs<uint16_t>(tkey, v0, tkey_alt, v1, (uint32_t)capacity, 0, passes * 8, bs + S.sort, &in_alt, st, n_dev)
+                                : radix_sort_pairs<uint16_t>(tkey, v0, tkey_alt, v1, (uint32_t)capacity, 0, passes * 8, bs + S.sort, &in_alt, st));
         }
         const uint16_t* skey = in_alt ? tkey_alt : tkey;
         {
             ProfScope ps(P_RANGES, st);
-            hipLaunchKernelGGL(k_tile_ranges, dim3(((uint32_t)R + 255) / 256), dim3(256), 0, st, (uint32_t)R, skey, ranges);
+            hipLaunchKernelGGL(k_tile_ranges, dim3(((uint32_t)capacity + 255) / 256), dim3(256), 0, st, (uint32_t)capacity, skey, ranges, n_dev);
         }
-    }
+        return GSR_OK;
+    };
+    rc = run_binning(cap, speculative ? total_dev : nullptr);
+    if (rc) return rc;
+    auto run_blend = [&]() -> int {
     const int ppt = g_blend_ppt ? g_blend_ppt : 5;   // default: one wave per 8x8 sub-tile
     float* img = static_cast<float*>(a->image);
     uint32_t* staged = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(a->image) + gsr_image_staged_offset(W, H));
@@ -1592,6 +1637,29 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
         else launch_blend_fwd<4>(W, H, tiles_x, T, ranges, list, splat, a->bg, a->out_color, a->out_depth, a->out_alpha, img, staged, st);
     }
     GSR_HIP(hipGetLastError());
+        return GSR_OK;
+    };
+    rc = run_blend();
+    if (rc) return rc;
+    if (speculative) {
+        GSR_HIP(hipEventSynchronize(g_pin_event));   // long past by the time the host gets here
+        R = *g_pinned;
+        pin_lock.unlock();
+        if (R > 0xfffffff0ull) return fail(GSR_ERR_RANGE, "more than 2^32 instances%s");
+        if (R > cap) {   // the capacity was too small: what was just enqueued binned a truncated list -- do it again, exactly
+            g_spec_overflows++;
+            rc = run_binning(R, nullptr);
+            if (rc) return rc;
+            rc = run_blend();
+            if (rc) return rc;
+        }
+    }
+    if (N > 0) {
+        // next capacity: 1.25x this frame's count, but never much below what recent frames needed (views alternate in
+        // training, so the hint decays slowly instead of following every small frame down)
+        const uint64_t prev = g_r_hint.load();
+        g_r_hint.store(std::max<uint64_t>(std::max<uint64_t>(R + R / 4, prev - prev / 32), 1u << 16));
+    }
     out->num_rendered = (int64_t)R;
     out->binning = bin;
     out->binning_bytes = B.bytes;

@@ -235,8 +235,10 @@ constexpr uint32_t kOsLocal = 1u << 30, kOsIncl = 2u << 30, kOsMask = (1u << 30)
 
 template <typename KeyT, int PASSES>
 __global__ __launch_bounds__(256) void k_radix_ghist(const KeyT* __restrict__ keys, uint32_t n, int begin_bit,
-                                                     uint32_t* __restrict__ ghist /*[PASSES][256]*/)
+                                                     uint32_t* __restrict__ ghist /*[PASSES][256]*/,
+                                                     const unsigned long long* __restrict__ n_dev)
 {
+    if (n_dev) n = (uint32_t)min((unsigned long long)n, *n_dev);   // device-side count (grid sized for a capacity)
     __shared__ uint32_t h[PASSES][256];
     const int tid = threadIdx.x;
 #pragma unroll
@@ -274,8 +276,10 @@ __global__ __launch_bounds__(kSortThreads) void k_onesweep(const KeyT* __restric
                                                            KeyT* __restrict__ kout, uint32_t* __restrict__ vout, uint32_t n, int shift,
                                                            const uint32_t* __restrict__ ghist /*[256] this pass*/,
                                                            uint32_t* __restrict__ status /*[nblocks][256]*/,
-                                                           uint32_t* __restrict__ ticket)
+                                                           uint32_t* __restrict__ ticket,
+                                                           const unsigned long long* __restrict__ n_dev)
 {
+    if (n_dev) n = (uint32_t)min((unsigned long long)n, *n_dev);   // device-side count: tiles past it exit at once
     __shared__ unsigned long long s_mask[kSortWaves][256];
     __shared__ uint32_t s_cnt[kSortWaves][256];
     __shared__ KeyT s_keys[kSortTile];
@@ -294,6 +298,7 @@ __global__ __launch_bounds__(kSortThreads) void k_onesweep(const KeyT* __restric
         tile = s_tile;
     }
     const uint32_t base = tile * (uint32_t)kSortTile;
+    if (base >= n) return;   // (uniform) only when the grid was sized for a capacity above the device-side count
     const uint32_t valid = min((uint32_t)kSortTile, n - base);
     KeyT key[kSortIPT];
     uint32_t val[kSortIPT], dig[kSortIPT], rnk[kSortIPT];
@@ -374,10 +379,12 @@ inline size_t onesweep_scratch_bytes(uint32_t n)
     return ((4 * 256 + 64 + 4 * (nblocks ? nblocks : 1) * 256) * sizeof(uint32_t) + 255) & ~(size_t)255;
 }
 
-// begin_bit..end_bit in 8-bit passes (at most 4).  Same contract as radix_sort_pairs.
+// begin_bit..end_bit in 8-bit passes (at most 4).  Same contract as radix_sort_pairs.  n_dev != nullptr: `n` is only a
+// capacity (it sizes the grid and the scratch); the number of pairs is min(n, *n_dev), read on the device.
 template <typename KeyT>
 inline hipError_t onesweep_sort_pairs(KeyT* keys, uint32_t* vals, KeyT* keys_alt, uint32_t* vals_alt, uint32_t n, int begin_bit,
-                                      int end_bit, void* scratch, int* in_alt, hipStream_t stream)
+                                      int end_bit, void* scratch, int* in_alt, hipStream_t stream,
+                                      const unsigned long long* n_dev = nullptr)
 {
     *in_alt = 0;
     if (n == 0) return hipSuccess;
@@ -391,16 +398,16 @@ inline hipError_t onesweep_sort_pairs(KeyT* keys, uint32_t* vals, KeyT* keys_alt
     if (e != hipSuccess) return e;
     const uint32_t hgrid = nblocks < 256u ? nblocks : 256u;
     switch (passes) {
-        case 1: hipLaunchKernelGGL((k_radix_ghist<KeyT, 1>), dim3(hgrid), dim3(256), 0, stream, keys, n, begin_bit, ghist); break;
-        case 2: hipLaunchKernelGGL((k_radix_ghist<KeyT, 2>), dim3(hgrid), dim3(256), 0, stream, keys, n, begin_bit, ghist); break;
-        case 3: hipLaunchKernelGGL((k_radix_ghist<KeyT, 3>), dim3(hgrid), dim3(256), 0, stream, keys, n, begin_bit, ghist); break;
-        default: hipLaunchKernelGGL((k_radix_ghist<KeyT, 4>), dim3(hgrid), dim3(256), 0, stream, keys, n, begin_bit, ghist); break;
+        case 1: hipLaunchKernelGGL((k_radix_ghist<KeyT, 1>), dim3(hgrid), dim3(256), 0, stream, keys, n, begin_bit, ghist, n_dev); break;
+        case 2: hipLaunchKernelGGL((k_radix_ghist<KeyT, 2>), dim3(hgrid), dim3(256), 0, stream, keys, n, begin_bit, ghist, n_dev); break;
+        case 3: hipLaunchKernelGGL((k_radix_ghist<KeyT, 3>), dim3(hgrid), dim3(256), 0, stream, keys, n, begin_bit, ghist, n_dev); break;
+        default: hipLaunchKernelGGL((k_radix_ghist<KeyT, 4>), dim3(hgrid), dim3(256), 0, stream, keys, n, begin_bit, ghist, n_dev); break;
     }
     KeyT *kin = keys, *kout = keys_alt;
     uint32_t *vin = vals, *vout = vals_alt;
     for (int p = 0; p < passes; p++) {
         hipLaunchKernelGGL(k_onesweep<KeyT>, dim3(nblocks), dim3(kSortThreads), 0, stream, kin, vin, kout, vout, n, begin_bit + 8 * p,
-                           ghist + p * 256, status + (size_t)p * nblocks * 256, nblocks <= 512u ? (uint32_t*)nullptr : tickets + p);
+                           ghist + p * 256, status + (size_t)p * nblocks * 256, nblocks <= 512u ? (uint32_t*)nullptr : tickets + p, n_dev);
         KeyT* tk = kin; kin = kout; kout = tk;
         uint32_t* tv = vin; vin = vout; vout = tv;
         *in_alt ^= 1;

@@ -114,6 +114,34 @@ def test_blend_variants_agree(ppt):
         lib.gsr_set_option(b"blend_bwd_ppt", 0)
 
 
+@pytest.mark.parametrize("hint", [0, 1000, 1 << 26], ids=["exact-flow", "overflow-rerun", "roomy"])
+def test_speculative_binning(hint):
+    """gsr_forward launches the binning against a capacity (1.25x the recent calls' R) and reads R back late; a
+    capacity that turns out too small is re-run with the exact size.  All three routes (no hint = classic
+    read-back-then-launch, capacity far too small, capacity far too large) must give the parity result, and an
+    identical image."""
+    import importlib
+    L = importlib.import_module("3dgs_hierarchical_training_amd._lib")
+    lib = L.load()
+    case = (20000, 330, 250, 3, True, "sh", (0.2, 0.3, 0.1))
+    try:
+        assert lib.gsr_set_option(b"speculative_binning", 0) == 0
+        sc = parity.syn.make_scene(case[0], case[1], case[2], sh_degree=case[3], seed=4, posed=case[4])
+        kw = parity.scene_kwargs(sc, case[5], bg=case[6])
+        import hip_runner
+        ref = hip_runner.run_hip(kw)["fwd"]
+        assert lib.gsr_set_option(b"speculative_binning", 1) == 0
+        assert lib.gsr_set_option(b"binning_capacity_hint", hint) == 0
+        got = hip_runner.run_hip(kw)["fwd"]
+        for r, g in zip(ref, got):
+            assert np.array_equal(r, g)
+        assert lib.gsr_set_option(b"binning_capacity_hint", hint) == 0
+        _run_case(*case)
+    finally:
+        lib.gsr_set_option(b"speculative_binning", 1)
+        lib.gsr_set_option(b"binning_capacity_hint", 0)
+
+
 @pytest.mark.parametrize("case", [CASES[1], CASES[2], CASES[3], (300000, 980, 545, 3, True, "sh", (0.0, 0.0, 0.0))],
                          ids=lambda c: f"{c[0]}-{c[1]}x{c[2]}-d{c[3]}-{c[5]}")
 def test_camera_gradients(case):
