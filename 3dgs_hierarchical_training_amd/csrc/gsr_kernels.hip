@@ -224,13 +224,17 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess(CamParams cp, int N,
                                                             const float* __restrict__ shs, const float* __restrict__ shs_rest,
                                                             const float* __restrict__ colors,
                                                             Splat* __restrict__ splat, int32_t* __restrict__ radii,
-                                                            uint32_t* __restrict__ dkey, uint32_t* __restrict__ gid)
+                                                            uint32_t* __restrict__ dkey, uint32_t* __restrict__ gid,
+                                                            uint32_t* __restrict__ ntiles, uint32_t* __restrict__ zero_words,
+                                                            int zero_count)
 {
     constexpr int NC3 = 3 * (DEG + 1) * (DEG + 1);
     __shared__ float s_sh[kPreThreads * kShStride];
     const int tid = threadIdx.x;
     const int base = blockIdx.x * kPreThreads;
     const int i = base + tid;
+    if (blockIdx.x == 0)   // rides along: clear the head of the depth sort's scratch (saves a fill launch)
+        for (int q = tid; q < zero_count; q += kPreThreads) zero_words[q] = 0u;
     if (shs) {
         const int nG = min(kPreThreads, N - base);
         if (shs_rest) {   // split storage: dc [N,1,3] + rest [N,M-1,3]; two straight, divergence-free streams
@@ -294,6 +298,7 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess(CamParams cp, int N,
     radii[i] = s.radius;
     dkey[i] = s.tiles > 0 ? __float_as_uint(s.depth) : 0xffffffffu;
     gid[i] = (uint32_t)i;
+    ntiles[i] = s.tiles;   // compact copy for k_tile_counts (a 4 B gather from 4N bytes instead of from the 48 B records)
 }
 
 __global__ void k_mark_visible(int N, const float* __restrict__ means, const float* __restrict__ vm, uint8_t* __restrict__ present)
@@ -329,22 +334,34 @@ __device__ __forceinline__ uint32_t block_inclusive_scan_256(uint32_t v, uint32_
 }
 
 __global__ __launch_bounds__(kEmitThreads) void k_tile_counts(int N, const uint32_t* __restrict__ sorted_gid,
-                                                              const Splat* __restrict__ splat, uint32_t* __restrict__ block_sums)
+                                                              const uint32_t* __restrict__ ntiles, uint32_t* __restrict__ block_sums)
 {
     __shared__ uint32_t s_wave[4];
     const int j = blockIdx.x * kEmitThreads + threadIdx.x;
     uint32_t t = 0;
-    if (j < N) t = splat[sorted_gid[j]].tiles;
+    if (j < N) t = ntiles[sorted_gid[j]];
     uint32_t total;
     block_inclusive_scan_256(t, s_wave, total);
     if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
 }
 
+// small clears that ride in k_block_scan (4-byte words; see gsr_forward)
+struct ZeroJobs {
+    void* p[3];
+    uint32_t words[3];
+};
+
 // single workgroup: exclusive scan of block_sums[nb] in place; total (64-bit) -> *total_out
-__global__ __launch_bounds__(1024) void k_block_scan(uint32_t* __restrict__ block_sums, int nb, unsigned long long* __restrict__ total_out)
+__global__ __launch_bounds__(1024) void k_block_scan(uint32_t* __restrict__ block_sums, int nb, unsigned long long* __restrict__ total_out,
+                                                     ZeroJobs zj)
 {
     __shared__ unsigned long long s_part[1024];
     const int tid = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        uint32_t* z = static_cast<uint32_t*>(zj.p[j]);
+        for (uint32_t q = tid; q < zj.words[j]; q += 1024) z[q] = 0u;
+    }
     const int chunk = (nb + 1023) / 1024;
     const int lo = min(nb, tid * chunk), hi = min(nb, lo + chunk);
     unsigned long long sum = 0;
@@ -1338,7 +1355,7 @@ static GeomLayout geom_layout(int32_t N)
 }
 
 struct FwdScratch {   // N-sized scratch of the forward
-    size_t dkey, gid, dkey_alt, gid_alt, block_sums, total, sort;
+    size_t dkey, gid, dkey_alt, gid_alt, ntiles, block_sums, total, sort;
     size_t bytes;
 };
 static FwdScratch fwd_scratch_layout(int32_t N)
@@ -1350,6 +1367,7 @@ static FwdScratch fwd_scratch_layout(int32_t N)
     s.gid = o; o += align256(n * 4);
     s.dkey_alt = o; o += align256(n * 4);
     s.gid_alt = o; o += align256(n * 4);
+    s.ntiles = o; o += align256(n * 4);
     s.block_sums = o; o += align256(((n + kEmitThreads - 1) / kEmitThreads) * 4);
     s.total = o; o += 256;
     s.sort = o; o += radix_scratch_bytes((uint32_t)n);
@@ -1491,114 +1509,48 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
     const int tiles_x = (W + kTile - 1) / kTile, tiles_y = (H + kTile - 1) / kTile, T = tiles_x * tiles_y;
     out->num_rendered = 0; out->binning = nullptr; out->binning_bytes = 0;
     uint64_t R = 0;
-    unsigned long long* total_dev = nullptr;
     Splat* splat = static_cast<Splat*>(a->geom);
-    uint32_t* sorted_gid = nullptr;
+    float* img = static_cast<float*>(a->image);
+    uint32_t* staged = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(a->image) + gsr_image_staged_offset(W, H));
+    const FwdScratch L = fwd_scratch_layout(N);
     uint8_t* fs = nullptr;
-    FwdScratch L = fwd_scratch_layout(N);
-    if (N > 0) {
-        if (!a->means3D || !a->opacities || !a->geom || !a->radii || !a->viewmatrix || !a->projmatrix)
-            return fail(GSR_ERR_ARG, "missing input pointer%s");
-        if ((a->shs == nullptr) == (a->colors_precomp == nullptr)) return fail(GSR_ERR_ARG, "provide exactly one of shs / colors_precomp%s");
-        if ((a->cov3D_precomp == nullptr) == (a->scales == nullptr || a->rotations == nullptr))
-            return fail(GSR_ERR_ARG, "provide exactly one of (scales, rotations) / cov3D_precomp%s");
-        if (a->shs && (!a->campos || a->M < (a->D + 1) * (a->D + 1))) return fail(GSR_ERR_ARG, "shs needs campos and M >= (D+1)^2%s");
-        fs = static_cast<uint8_t*>(a->alloc(L.bytes, GSR_ALLOC_SCRATCH, a->alloc_user));
-        if (!fs) return fail(GSR_ERR_ALLOC, "scratch allocation failed%s");
-        uint32_t* dkey = reinterpret_cast<uint32_t*>(fs + L.dkey);
-        uint32_t* gid = reinterpret_cast<uint32_t*>(fs + L.gid);
-        uint32_t* dkey_alt = reinterpret_cast<uint32_t*>(fs + L.dkey_alt);
-        uint32_t* gid_alt = reinterpret_cast<uint32_t*>(fs + L.gid_alt);
-        uint32_t* block_sums = reinterpret_cast<uint32_t*>(fs + L.block_sums);
-        unsigned long long* total = reinterpret_cast<unsigned long long*>(fs + L.total);
-        CamParams cp = {a->viewmatrix, a->projmatrix, a->campos, a->tanfovx, a->tanfovy, a->scale_modifier, W, H, a->D, a->M};
-        const int grid = (N + kPreThreads - 1) / kPreThreads;
-#define GSR_PRE_(DEG, RAW)                                                                                                          \
-    hipLaunchKernelGGL((k_preprocess<DEG, RAW>), dim3(grid), dim3(kPreThreads), 0, st, cp, N, a->means3D, a->scales, a->rotations, \
-                       a->cov3D_precomp, a->opacities, a->shs, a->shs_rest, a->colors_precomp, splat, a->radii, dkey, gid)
-#define GSR_PRE(DEG) do { if (a->raw_params) GSR_PRE_(DEG, true); else GSR_PRE_(DEG, false); } while (0)
-        {
-            ProfScope ps(P_PRE_FWD, st);
-            switch (a->shs ? a->D : 0) {
-                case 0: GSR_PRE(0); break;
-                case 1: GSR_PRE(1); break;
-                case 2: GSR_PRE(2); break;
-                default: GSR_PRE(3); break;
-            }
-        }
-#undef GSR_PRE
-#undef GSR_PRE_
-        int in_alt = 0;
-        {
-            ProfScope ps(P_SORT_DEPTH, st);
-            GSR_HIP(g_sort_algo ? onesweep_sort_pairs<uint32_t>(dkey, gid, dkey_alt, gid_alt, (uint32_t)N, 0, 32, fs + L.sort, &in_alt, st)
-                                : radix_sort_pairs<uint32_t>(dkey, gid, dkey_alt, gid_alt, (uint32_t)N, 0, 32, fs + L.sort, &in_alt, st));
-        }
-        sorted_gid = in_alt ? gid_alt : gid;
-        const int nb = (N + kEmitThreads - 1) / kEmitThreads;
-        {
-            ProfScope ps(P_SCAN, st);
-            hipLaunchKernelGGL(k_tile_counts, dim3(nb), dim3(kEmitThreads), 0, st, N, sorted_gid, splat, block_sums);
-            hipLaunchKernelGGL(k_block_scan, dim3(1), dim3(1024), 0, st, block_sums, nb, total);
-        }
-        GSR_HIP(hipGetLastError());
-        total_dev = total;
-    }
-    // ---- the instance count R lives on the device.  Classic flow: read it back, synchronise, size the R-dependent
-    // buffers and grids exactly.  That puts a host round trip (~35 us of idle GPU per frame) in the middle of every
-    // forward, so by default the binning is launched SPECULATIVELY against a capacity (1.25x the recent frames' R):
-    // kernels take the true count from device memory, the read-back is only waited for after everything is enqueued,
-    // and in the rare overflow (R > capacity) the binning is simply launched again with the exact size. ----
-    std::unique_lock<std::mutex> pin_lock(g_pin_mutex, std::defer_lock);
-    uint64_t cap = 0;
-    bool speculative = false;
-    if (N > 0) {
-        pin_lock.lock();
-        if (!g_pinned) {
-            GSR_HIP(hipHostMalloc((void**)&g_pinned, 64, hipHostMallocDefault));
-            GSR_HIP(hipEventCreateWithFlags(&g_pin_event, hipEventDisableTiming));
-        }
-        GSR_HIP(hipMemcpyAsync(g_pinned, total_dev, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-        const uint64_t hint = g_r_hint.load();
-        speculative = g_speculate && g_sort_algo == 2 && hint > 0;
-        if (speculative) {
-            GSR_HIP(hipEventRecord(g_pin_event, st));
-            cap = hint;
-        } else {
-            GSR_HIP(hipStreamSynchronize(st));
-            R = *g_pinned;
-            pin_lock.unlock();
-            if (R > 0xfffffff0ull) return fail(GSR_ERR_RANGE, "more than 2^32 instances%s");
-            cap = R;
-        }
-    }
+    uint32_t* sorted_gid = nullptr;
+    int bits = 1;
+    while ((1 << bits) < T) bits++;
+    const int tile_passes = (bits + 7) / 8;
+    const int nb = (N + kEmitThreads - 1) / kEmitThreads;
+
+    // ---- R-sized state (binning result + tile-sort scratch) and the stages that need it --------------------------
+    BinLayout B = bin_layout(0, W, H);
+    BinScratch S = bin_scratch_layout(0);
+    uint8_t *bin = nullptr, *bs = nullptr;
     uint2* ranges = nullptr;
     uint32_t* list = nullptr;
-    uint8_t* bin = nullptr;
-    BinLayout B = bin_layout(0, W, H);
-    // binning for `capacity` instances; n_dev != nullptr: the real count is read on the device
-    auto run_binning = [&](uint64_t capacity, const unsigned long long* n_dev) -> int {
+    auto alloc_binning = [&](uint64_t capacity) -> int {
         B = bin_layout((int64_t)capacity, W, H);
         bin = static_cast<uint8_t*>(a->alloc(B.bytes, GSR_ALLOC_BINNING, a->alloc_user));
         if (!bin) return fail(GSR_ERR_ALLOC, "binning allocation failed%s");
         ranges = reinterpret_cast<uint2*>(bin + B.ranges);
         list = reinterpret_cast<uint32_t*>(bin + B.list);
-        GSR_HIP(hipMemsetAsync(ranges, 0, (size_t)T * sizeof(uint2), st));
+        bs = nullptr;
         if (capacity == 0) return GSR_OK;
-        BinScratch S = bin_scratch_layout((int64_t)capacity);
-        uint8_t* bs = static_cast<uint8_t*>(a->alloc(S.bytes, GSR_ALLOC_SCRATCH, a->alloc_user));
+        S = bin_scratch_layout((int64_t)capacity);
+        bs = static_cast<uint8_t*>(a->alloc(S.bytes, GSR_ALLOC_SCRATCH, a->alloc_user));
         if (!bs) return fail(GSR_ERR_ALLOC, "binning scratch allocation failed%s");
+        return GSR_OK;
+    };
+    // emit + tile sort + ranges for `capacity` instances; n_dev != nullptr: the real count is read on the device.
+    // prezeroed: ranges, the staged counters and the head of the sort scratch were cleared by k_block_scan.
+    auto launch_binning = [&](uint64_t capacity, const unsigned long long* n_dev, bool prezeroed) -> int {
+        if (!prezeroed) GSR_HIP(hipMemsetAsync(ranges, 0, (size_t)T * sizeof(uint2), st));
+        if (capacity == 0) return GSR_OK;
         uint16_t* tkey = reinterpret_cast<uint16_t*>(bs + S.tile);
         uint16_t* tkey_alt = reinterpret_cast<uint16_t*>(bs + S.tile_alt);
         uint32_t* gid_alt2 = reinterpret_cast<uint32_t*>(bs + S.gid_alt);
         uint32_t* block_sums = reinterpret_cast<uint32_t*>(fs + L.block_sums);
-        const int nb = (N + kEmitThreads - 1) / kEmitThreads;
-        int bits = 1;
-        while ((1 << bits) < T) bits++;
-        const int passes = (bits + 7) / 8;
         // arrange the ping-pong so that the sorted gids land directly in `list`
-        uint32_t* v0 = (passes & 1) ? gid_alt2 : list;
-        uint32_t* v1 = (passes & 1) ? list : gid_alt2;
+        uint32_t* v0 = (tile_passes & 1) ? gid_alt2 : list;
+        uint32_t* v1 = (tile_passes & 1) ? list : gid_alt2;
         {
             ProfScope ps(P_EMIT, st);
             hipLaunchKernelGGL(k_emit, dim3(nb), dim3(kEmitThreads), 0, st, N, W, H, tiles_x, tiles_y, sorted_gid, splat, block_sums, tkey, v0,
@@ -1607,8 +1559,10 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
         int in_alt = 0;
         {
             ProfScope ps(P_SORT_TILE, st);
-            GSR_HIP(g_sort_algo == 2 ? onesweep_sort_pairs<uint16_t>(tkey, v0, tkey_alt, v1, (uint32_t)capacity, 0, passes * 8, bs + S.sort, &in_alt, st, n_dev)
-                                : radix_sort_pairs<uint16_t>(tkey, v0, tkey_alt, v1, (uint32_t)capacity, 0, passes * 8, bs + S.sort, &in_alt, st));
+            GSR_HIP(g_sort_algo == 2 ? onesweep_sort_pairs<uint16_t>(tkey, v0, tkey_alt, v1, (uint32_t)capacity, 0, tile_passes * 8, bs + S.sort,
+                                                                     &in_alt, st, n_dev, prezeroed)
+                                     : radix_sort_pairs<uint16_t>(tkey, v0, tkey_alt, v1, (uint32_t)capacity, 0, tile_passes * 8, bs + S.sort,
+                                                                  &in_alt, st));
         }
         const uint16_t* skey = in_alt ? tkey_alt : tkey;
         {
@@ -1617,44 +1571,142 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
         }
         return GSR_OK;
     };
-    rc = run_binning(cap, speculative ? total_dev : nullptr);
-    if (rc) return rc;
-    auto run_blend = [&]() -> int {
-    const int ppt = g_blend_ppt ? g_blend_ppt : 5;   // default: one wave per 8x8 sub-tile
-    float* img = static_cast<float*>(a->image);
-    uint32_t* staged = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(a->image) + gsr_image_staged_offset(W, H));
-    GSR_HIP(hipMemsetAsync(staged, 0, (size_t)T * 16, st));
-    {
-        ProfScope ps(P_BLEND_FWD, st);
-        if (ppt == 5)
-            hipLaunchKernelGGL(k_blend_fwd_w, dim3(8 * 4 * ((T + 7) / 8)), dim3(64), 0, st, W, H, tiles_x, T, ranges, list, splat, a->bg,
-                               a->out_color, a->out_depth, a->out_alpha, img, staged);
-        else if (ppt == 1) launch_blend_fwd<1>(W, H, tiles_x, T, ranges, list, splat, a->bg, a->out_color, a->out_depth, a->out_alpha, img, staged, st);
-        else if (ppt == 2)
-            hipLaunchKernelGGL(k_blend_fwd2, dim3(8 * ((T + 7) / 8)), dim3(128), 0, st, W, H, tiles_x, T, ranges, list, splat, a->bg,
-                               a->out_color, a->out_depth, a->out_alpha, img, staged);
-        else if (ppt == 3) launch_blend_fwd<2>(W, H, tiles_x, T, ranges, list, splat, a->bg, a->out_color, a->out_depth, a->out_alpha, img, staged, st);
-        else launch_blend_fwd<4>(W, H, tiles_x, T, ranges, list, splat, a->bg, a->out_color, a->out_depth, a->out_alpha, img, staged, st);
-    }
-    GSR_HIP(hipGetLastError());
+    auto launch_blend = [&](bool prezeroed) -> int {
+        const int ppt = g_blend_ppt ? g_blend_ppt : 5;   // default: one wave per 8x8 sub-tile
+        if (!prezeroed) GSR_HIP(hipMemsetAsync(staged, 0, (size_t)T * 16, st));
+        {
+            ProfScope ps(P_BLEND_FWD, st);
+            if (ppt == 5)
+                hipLaunchKernelGGL(k_blend_fwd_w, dim3(8 * 4 * ((T + 7) / 8)), dim3(64), 0, st, W, H, tiles_x, T, ranges, list, splat, a->bg,
+                                   a->out_color, a->out_depth, a->out_alpha, img, staged);
+            else if (ppt == 1) launch_blend_fwd<1>(W, H, tiles_x, T, ranges, list, splat, a->bg, a->out_color, a->out_depth, a->out_alpha, img, staged, st);
+            else if (ppt == 2)
+                hipLaunchKernelGGL(k_blend_fwd2, dim3(8 * ((T + 7) / 8)), dim3(128), 0, st, W, H, tiles_x, T, ranges, list, splat, a->bg,
+                                   a->out_color, a->out_depth, a->out_alpha, img, staged);
+            else if (ppt == 3) launch_blend_fwd<2>(W, H, tiles_x, T, ranges, list, splat, a->bg, a->out_color, a->out_depth, a->out_alpha, img, staged, st);
+            else launch_blend_fwd<4>(W, H, tiles_x, T, ranges, list, splat, a->bg, a->out_color, a->out_depth, a->out_alpha, img, staged, st);
+        }
+        GSR_HIP(hipGetLastError());
         return GSR_OK;
     };
-    rc = run_blend();
-    if (rc) return rc;
+
+    if (N == 0) {
+        rc = alloc_binning(0);
+        if (rc) return rc;
+        rc = launch_binning(0, nullptr, false);
+        if (rc) return rc;
+        rc = launch_blend(false);
+        if (rc) return rc;
+        out->binning = bin;
+        out->binning_bytes = B.bytes;
+        return GSR_OK;
+    }
+
+    if (!a->means3D || !a->opacities || !a->geom || !a->radii || !a->viewmatrix || !a->projmatrix)
+        return fail(GSR_ERR_ARG, "missing input pointer%s");
+    if ((a->shs == nullptr) == (a->colors_precomp == nullptr)) return fail(GSR_ERR_ARG, "provide exactly one of shs / colors_precomp%s");
+    if ((a->cov3D_precomp == nullptr) == (a->scales == nullptr || a->rotations == nullptr))
+        return fail(GSR_ERR_ARG, "provide exactly one of (scales, rotations) / cov3D_precomp%s");
+    if (a->shs && (!a->campos || a->M < (a->D + 1) * (a->D + 1))) return fail(GSR_ERR_ARG, "shs needs campos and M >= (D+1)^2%s");
+
+    // ---- the instance count R only exists on the device.  Classic flow: read it back, synchronise, size the
+    // R-dependent buffers and grids exactly.  That puts a host round trip (~35 us of idle GPU per frame) in the middle
+    // of every forward, so by default the binning is launched SPECULATIVELY against a capacity (1.25x the recent
+    // frames' R): kernels take the true count from device memory, the read-back is only waited for after everything
+    // is enqueued, and in the rare overflow (R > capacity) the binning is simply launched again with the exact size.
+    // Knowing the capacity up front also lets the small clears (ranges, staged counters, sort-scratch heads) ride in
+    // kernels that run anyway instead of five separate fill launches. ----
+    const uint64_t hint = g_r_hint.load();
+    const bool speculative = g_speculate && g_sort_algo == 2 && hint > 0;
+    const uint64_t cap = speculative ? hint : 0;
+
+    fs = static_cast<uint8_t*>(a->alloc(L.bytes, GSR_ALLOC_SCRATCH, a->alloc_user));
+    if (!fs) return fail(GSR_ERR_ALLOC, "scratch allocation failed%s");
     if (speculative) {
+        rc = alloc_binning(cap);
+        if (rc) return rc;
+    }
+    uint32_t* dkey = reinterpret_cast<uint32_t*>(fs + L.dkey);
+    uint32_t* gid = reinterpret_cast<uint32_t*>(fs + L.gid);
+    uint32_t* dkey_alt = reinterpret_cast<uint32_t*>(fs + L.dkey_alt);
+    uint32_t* gid_alt = reinterpret_cast<uint32_t*>(fs + L.gid_alt);
+    uint32_t* ntiles = reinterpret_cast<uint32_t*>(fs + L.ntiles);
+    uint32_t* block_sums = reinterpret_cast<uint32_t*>(fs + L.block_sums);
+    unsigned long long* total = reinterpret_cast<unsigned long long*>(fs + L.total);
+    const bool depth_onesweep = g_sort_algo != 0;
+    CamParams cp = {a->viewmatrix, a->projmatrix, a->campos, a->tanfovx, a->tanfovy, a->scale_modifier, W, H, a->D, a->M};
+    const int grid = (N + kPreThreads - 1) / kPreThreads;
+    // block 0 of k_preprocess clears the head (digit histograms + tickets) of the depth sort's scratch
+    uint32_t* zero_words = depth_onesweep ? reinterpret_cast<uint32_t*>(fs + L.sort) : nullptr;
+    const int zero_count = depth_onesweep ? (int)kOnesweepHeadWords : 0;
+#define GSR_PRE_(DEG, RAW)                                                                                                          \
+    hipLaunchKernelGGL((k_preprocess<DEG, RAW>), dim3(grid), dim3(kPreThreads), 0, st, cp, N, a->means3D, a->scales, a->rotations, \
+                       a->cov3D_precomp, a->opacities, a->shs, a->shs_rest, a->colors_precomp, splat, a->radii, dkey, gid, ntiles,  \
+                       zero_words, zero_count)
+#define GSR_PRE(DEG) do { if (a->raw_params) GSR_PRE_(DEG, true); else GSR_PRE_(DEG, false); } while (0)
+    {
+        ProfScope ps(P_PRE_FWD, st);
+        switch (a->shs ? a->D : 0) {
+            case 0: GSR_PRE(0); break;
+            case 1: GSR_PRE(1); break;
+            case 2: GSR_PRE(2); break;
+            default: GSR_PRE(3); break;
+        }
+    }
+#undef GSR_PRE
+#undef GSR_PRE_
+    int in_alt = 0;
+    {
+        ProfScope ps(P_SORT_DEPTH, st);
+        GSR_HIP(depth_onesweep ? onesweep_sort_pairs<uint32_t>(dkey, gid, dkey_alt, gid_alt, (uint32_t)N, 0, 32, fs + L.sort, &in_alt, st, nullptr, true)
+                               : radix_sort_pairs<uint32_t>(dkey, gid, dkey_alt, gid_alt, (uint32_t)N, 0, 32, fs + L.sort, &in_alt, st));
+    }
+    sorted_gid = in_alt ? gid_alt : gid;
+    {
+        ProfScope ps(P_SCAN, st);
+        ZeroJobs zj = {};
+        if (speculative) {   // the single-workgroup scan also clears what the binning / blend expect to be zero
+            zj.p[0] = ranges; zj.words[0] = (uint32_t)((size_t)T * sizeof(uint2) / 4);
+            zj.p[1] = staged; zj.words[1] = (uint32_t)T * 4u;
+            if (bs) { zj.p[2] = bs + S.sort; zj.words[2] = kOnesweepHeadWords; }
+        }
+        hipLaunchKernelGGL(k_tile_counts, dim3(nb), dim3(kEmitThreads), 0, st, N, sorted_gid, ntiles, block_sums);
+        hipLaunchKernelGGL(k_block_scan, dim3(1), dim3(1024), 0, st, block_sums, nb, total, zj);
+    }
+    GSR_HIP(hipGetLastError());
+
+    std::unique_lock<std::mutex> pin_lock(g_pin_mutex);
+    if (!g_pinned) {
+        GSR_HIP(hipHostMalloc((void**)&g_pinned, 64, hipHostMallocDefault));
+        GSR_HIP(hipEventCreateWithFlags(&g_pin_event, hipEventDisableTiming));
+    }
+    GSR_HIP(hipMemcpyAsync(g_pinned, total, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    if (speculative) {
+        GSR_HIP(hipEventRecord(g_pin_event, st));
+        rc = launch_binning(cap, total, true);
+        if (rc) return rc;
+        rc = launch_blend(true);
+        if (rc) return rc;
         GSR_HIP(hipEventSynchronize(g_pin_event));   // long past by the time the host gets here
         R = *g_pinned;
         pin_lock.unlock();
         if (R > 0xfffffff0ull) return fail(GSR_ERR_RANGE, "more than 2^32 instances%s");
-        if (R > cap) {   // the capacity was too small: what was just enqueued binned a truncated list -- do it again, exactly
-            g_spec_overflows++;
-            rc = run_binning(R, nullptr);
-            if (rc) return rc;
-            rc = run_blend();
-            if (rc) return rc;
-        }
+    } else {
+        GSR_HIP(hipStreamSynchronize(st));
+        R = *g_pinned;
+        pin_lock.unlock();
+        if (R > 0xfffffff0ull) return fail(GSR_ERR_RANGE, "more than 2^32 instances%s");
     }
-    if (N > 0) {
+    if (!speculative || R > cap) {   // exact flow, or the capacity was too small (the truncated result is overwritten)
+        if (speculative) g_spec_overflows++;
+        rc = alloc_binning(R);
+        if (rc) return rc;
+        rc = launch_binning(R, nullptr, false);
+        if (rc) return rc;
+        rc = launch_blend(false);
+        if (rc) return rc;
+    }
+    {
         // next capacity: 1.25x this frame's count, but never much below what recent frames needed (views alternate in
         // training, so the hint decays slowly instead of following every small frame down)
         const uint64_t prev = g_r_hint.load();

@@ -232,13 +232,18 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const KeyT* __re
 // no circular wait.  Versus hist+scan+scatter this reads the keys once per pass and saves two launches.
 // ------------------------------------------------------------------------------------------------
 constexpr uint32_t kOsLocal = 1u << 30, kOsIncl = 2u << 30, kOsMask = (1u << 30) - 1u;
+constexpr uint32_t kOnesweepHeadWords = 4 * 256 + 64;   // scratch head: ghist[4][256] + tickets (padded); status follows
 
 template <typename KeyT, int PASSES>
 __global__ __launch_bounds__(256) void k_radix_ghist(const KeyT* __restrict__ keys, uint32_t n, int begin_bit,
                                                      uint32_t* __restrict__ ghist /*[PASSES][256]*/,
-                                                     const unsigned long long* __restrict__ n_dev)
+                                                     const unsigned long long* __restrict__ n_dev,
+                                                     uint32_t* __restrict__ status, uint32_t status_words)
 {
     if (n_dev) n = (uint32_t)min((unsigned long long)n, *n_dev);   // device-side count (grid sized for a capacity)
+    // clear the look-back status words of all passes (they are first touched by the pass kernels that follow)
+    for (uint32_t q = blockIdx.x * 256 + threadIdx.x; q < status_words / 4; q += gridDim.x * 256)
+        reinterpret_cast<uint4*>(status)[q] = make_uint4(0u, 0u, 0u, 0u);
     __shared__ uint32_t h[PASSES][256];
     const int tid = threadIdx.x;
 #pragma unroll
@@ -384,7 +389,7 @@ inline size_t onesweep_scratch_bytes(uint32_t n)
 template <typename KeyT>
 inline hipError_t onesweep_sort_pairs(KeyT* keys, uint32_t* vals, KeyT* keys_alt, uint32_t* vals_alt, uint32_t n, int begin_bit,
                                       int end_bit, void* scratch, int* in_alt, hipStream_t stream,
-                                      const unsigned long long* n_dev = nullptr)
+                                      const unsigned long long* n_dev = nullptr, bool head_prezeroed = false)
 {
     *in_alt = 0;
     if (n == 0) return hipSuccess;
@@ -394,14 +399,19 @@ inline hipError_t onesweep_sort_pairs(KeyT* keys, uint32_t* vals, KeyT* keys_alt
     uint32_t* ghist = static_cast<uint32_t*>(scratch);
     uint32_t* tickets = ghist + 4 * 256;
     uint32_t* status = tickets + 64;
-    hipError_t e = hipMemsetAsync(scratch, 0, (4 * 256 + 64 + (size_t)passes * nblocks * 256) * sizeof(uint32_t), stream);
-    if (e != hipSuccess) return e;
+    // the head (histograms + tickets) must be zero before the histogram kernel; callers that can clear it in a kernel
+    // of their own say so.  The status words are cleared by the histogram kernel itself.
+    if (!head_prezeroed) {
+        hipError_t e = hipMemsetAsync(scratch, 0, kOnesweepHeadWords * sizeof(uint32_t), stream);
+        if (e != hipSuccess) return e;
+    }
+    const uint32_t status_words = (uint32_t)((size_t)passes * nblocks * 256);
     const uint32_t hgrid = nblocks < 256u ? nblocks : 256u;
     switch (passes) {
-        case 1: hipLaunchKernelGGL((k_radix_ghist<KeyT, 1>), dim3(hgrid), dim3(256), 0, stream, keys, n, begin_bit, ghist, n_dev); break;
-        case 2: hipLaunchKernelGGL((k_radix_ghist<KeyT, 2>), dim3(hgrid), dim3(256), 0, stream, keys, n, begin_bit, ghist, n_dev); break;
-        case 3: hipLaunchKernelGGL((k_radix_ghist<KeyT, 3>), dim3(hgrid), dim3(256), 0, stream, keys, n, begin_bit, ghist, n_dev); break;
-        default: hipLaunchKernelGGL((k_radix_ghist<KeyT, 4>), dim3(hgrid), dim3(256), 0, stream, keys, n, begin_bit, ghist, n_dev); break;
+        case 1: hipLaunchKernelGGL((k_radix_ghist<KeyT, 1>), dim3(hgrid), dim3(256), 0, stream, keys, n, begin_bit, ghist, n_dev, status, status_words); break;
+        case 2: hipLaunchKernelGGL((k_radix_ghist<KeyT, 2>), dim3(hgrid), dim3(256), 0, stream, keys, n, begin_bit, ghist, n_dev, status, status_words); break;
+        case 3: hipLaunchKernelGGL((k_radix_ghist<KeyT, 3>), dim3(hgrid), dim3(256), 0, stream, keys, n, begin_bit, ghist, n_dev, status, status_words); break;
+        default: hipLaunchKernelGGL((k_radix_ghist<KeyT, 4>), dim3(hgrid), dim3(256), 0, stream, keys, n, begin_bit, ghist, n_dev, status, status_words); break;
     }
     KeyT *kin = keys, *kout = keys_alt;
     uint32_t *vin = vals, *vout = vals_alt;
