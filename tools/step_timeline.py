@@ -2,7 +2,8 @@ import sqlite3, sys
 cur=sqlite3.connect(sys.argv[1]).cursor()
 rows=cur.execute("select name,start,end from kernels order by start").fetchall()
 idx=[i for i,r in enumerate(rows) if 'k_preprocess<3, true>' in r[0]]
-a,b=idx[-4],idx[-3]
+k=int(sys.argv[2]) if len(sys.argv)>2 else -4
+a,b=idx[k],idx[k+1]
 t0=rows[a][1]
 prev_end=None; gaps=0
 for r in rows[a:b]:
