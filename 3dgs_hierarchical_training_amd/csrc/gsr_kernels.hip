@@ -670,6 +670,14 @@ __global__ __launch_bounds__(64) void k_blend_fwd_w(int W, int H, int tiles_x, i
 // k_blend_bwd2 so forward and backward agree on every skip decision bit for bit.
 // ------------------------------------------------------------------------------------------------
 typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c)   // per-component fused multiply-add (v_pk_fma_f32)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_elementwise_fma(a, b, c);
+#else
+    return f2{fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)};
+#endif
+}
 
 __global__ __launch_bounds__(128) void k_blend_fwd2(int W, int H, int tiles_x, int T, const uint2* __restrict__ ranges,
                                                     const uint32_t* __restrict__ list, const Splat* __restrict__ splat,
@@ -962,10 +970,15 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(int W, int H, int tiles_x, i
 
     float4 ra = {0, 0, 0, 0}, rb = ra, rc = ra;
     uint32_t rg_id = 0;
+    // the staged copy carries the conic pre-multiplied for the exponent in base 2, exactly as k_blend_fwd_w stages it
+    // (A' = -log2(e)/2 A, B' = -log2(e) B, C' = -log2(e)/2 C), and log2(G) is evaluated with the same fma nesting, so
+    // forward and backward agree on every skip decision bit for bit
+    constexpr float kL2E = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
     if (tid < n) {
         rg_id = list[rg.x + tid];
         const float4* sp = reinterpret_cast<const float4*>(splat + rg_id);
         ra = sp[0]; rb = sp[1]; rc = sp[2];
+        ra.z *= -0.5f * kL2E; ra.w *= -kL2E; rb.x *= -0.5f * kL2E;
     }
 #pragma unroll
     for (int w = 0; w < NW; w++)
@@ -981,22 +994,28 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(int W, int H, int tiles_x, i
             rg_id = list[rg.x + nxt];
             const float4* sp = reinterpret_cast<const float4*>(splat + rg_id);
             ra = sp[0]; rb = sp[1]; rc = sp[2];
+            ra.z *= -0.5f * kL2E; ra.w *= -kL2E; rb.x *= -0.5f * kL2E;
         }
         const int cnt = min(NT, n - b * NT);
         for (int j = 0; j < cnt; j++) {
             const float4 A = s_a[buf][j], B = s_b[buf][j], C = s_c[buf][j];   // (manual LDS prefetch measured slower)
             const uint32_t idx = (uint32_t)(b * NT + j + 1);
-            const float ca = A.z, cb = A.w, cc = B.x, op = B.y, zd = B.z, cr = B.w, cg = C.x, cbl = C.y;
+            const float ca = A.z, cb = A.w, cc = B.x, op = B.y, zd = B.z, cr = B.w, cg = C.x, cbl = C.y;   // ca/cb/cc: A', B', C'
             const float dx = A.x - pxf;
             const f2 dy = A.y - pyf;
-            const float hx = ca * dx * dx, bx = cb * dx;
-            const f2 power = -0.5f * (cc * dy * dy + hx) - bx * dy;
-            f2 G = {fast_exp(power.x), fast_exp(power.y)};
+            const float adx = ca * dx;
+            const f2 cdy = cc * dy;
+            const f2 p2 = fma2(cdy, dy, fma2(f2{cb, cb}, dy, f2{adx, adx}) * dx);   // log2 of the Gaussian weight (= k_blend_fwd_w)
+#if defined(__HIP_DEVICE_COMPILE__)
+            f2 G = {__builtin_amdgcn_exp2f(p2.x), __builtin_amdgcn_exp2f(p2.y)};
+#else
+            f2 G = {exp2f(p2.x), exp2f(p2.y)};
+#endif
             f2 alpha = op * G;
             alpha.x = fminf(kAlphaMax, alpha.x); alpha.y = fminf(kAlphaMax, alpha.y);
-            const bool v0 = !(power.x > 0.f || alpha.x < kAlphaMin) && idx <= ncon[0];
-            const bool v1 = !(power.y > 0.f || alpha.y < kAlphaMin) && idx <= ncon[1];
-            if (__any(v0 || v1)) {   // wave-uniform
+            const bool v0 = !(p2.x > 0.f || alpha.x < kAlphaMin) && idx <= ncon[0];
+            const bool v1 = !(p2.y > 0.f || alpha.y < kAlphaMin) && idx <= ncon[1];
+            if (__ballot(v0 || v1) != 0ull) {   // wave-uniform (scalar compare; __any materialises a VGPR)
                 alpha.x = v0 ? alpha.x : 0.f; alpha.y = v1 ? alpha.y : 0.f;
                 G.x = v0 ? G.x : 0.f; G.y = v1 ? G.y : 0.f;
                 const f2 w = alpha * Tt;
@@ -1007,8 +1026,9 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(int W, int H, int tiles_x, i
                 const f2 inv = {fast_rcp(om.x), fast_rcp(om.y)};
                 const f2 dLda = gc * Tt - S * inv;
                 const f2 dLdpow = G * (op * dLda);
-                const f2 ex = -(ca * dx) - cb * dy;     // d power / d dx
-                const f2 ey = -(cc * dy) - bx;           // d power / d dy
+                // d log2(G) / d dx, d dy (the 1/log2(e) back to natural units is applied once per record in the flush)
+                const f2 ex = fma2(f2{cb, cb}, dy, f2{2.f * adx, 2.f * adx});
+                const f2 ey = fma2(cdy, f2{2.f, 2.f}, f2{cb * dx, cb * dx});
                 const f2 t_gx = dLdpow * ex, t_gy = dLdpow * ey;
                 const f2 t_gB = dLdpow * dy;
                 const f2 t_gC = t_gB * dy;
@@ -1042,7 +1062,7 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(int W, int H, int tiles_x, i
                 if (r < NV) {
                     const float v = s_part[0][jj][r] + s_part[1][jj][r];
                     s_part[0][jj][r] = 0.f; s_part[1][jj][r] = 0.f;   // ready for the next batch (its writers sit behind a barrier)
-                    if (v != 0.f) atomicAdd(ggrad + (size_t)s_gid[buf][jj] * kGG + r, v);
+                    if (v != 0.f) atomicAdd(ggrad + (size_t)s_gid[buf][jj] * kGG + r, r < 2 ? v * kLn2 : v);
                 }
             }
         }
