@@ -1,9 +1,21 @@
 """Multi-tensor Adam on top of gsr_adam_step (one HIP launch for all parameter groups).
 
-Mirror of how the reference drives its optimizer: `torch.optim.Adam(l, lr=0.0, eps=1e-15)` with one group
-per parameter tensor and per-group learning rates (/root/reference/scene/gaussian_model_ht.py:275-289);
-`step()` / `zero_grad(set_to_none=True)` as called at /root/reference/trainer/ht3dgs_trainer.py:159-166.
-Same update rule (no amsgrad, no weight decay).  No CPU path.
+Stands where the reference builds `torch.optim.Adam(l, lr=0.0, eps=1e-15)` with one group per parameter tensor
+and per-group learning rates (/root/reference/scene/gaussian_model_ht.py:275-289), and keeps the object protocol the
+reference's model code relies on, so that its densification / pruning / opacity-reset surgery works on it
+unchanged (densification-aware state):
+
+  * `param_groups`: list of dicts with "params" (one tensor), "lr", "name" -- `update_learning_rate` rewrites
+    `group["lr"]` every iteration (gaussian_model_ht.py:388-395); the value is read at each step;
+  * `state`: dict keyed by the parameter tensor, entries {"step", "exp_avg", "exp_avg_sq"} -- exactly what
+    `replace_tensor_to_optimizer` / `_prune_optimizer` / `cat_tensors_to_optimizer` (:532-607) get, slice,
+    concatenate, delete and re-insert under a new nn.Parameter;
+  * `step()` / `zero_grad(set_to_none=True)` as called at /root/reference/trainer/ht3dgs_trainer.py:159-166;
+  * `state_dict()` / `load_state_dict()` in torch.optim's layout (capture / restore, gaussian_model_ht.py:102,124),
+    interchangeable with a torch.optim.Adam checkpoint.
+
+Same update rule as torch (no amsgrad, no weight decay); the bias corrections use each tensor's own step count.
+No CPU path: `step()` needs the parameters on a ROCm/HIP device.
 """
 import ctypes as C
 from typing import Dict, List
@@ -13,20 +25,26 @@ import torch
 from . import _lib as L
 
 
+def _step_int(v) -> int:
+    return int(v.item()) if torch.is_tensor(v) else int(v)
+
+
 class FusedAdam:
+    FUSED_ORDER = ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation")
+
     def __init__(self, param_groups: List[Dict], lr: float = 0.0, betas=(0.9, 0.999), eps: float = 1e-15):
+        self.defaults = {"lr": lr, "betas": tuple(betas), "eps": eps}
         self.param_groups = []
         for g in param_groups:
             g = dict(g)
+            g["params"] = list(g["params"])
             g.setdefault("lr", lr)
             assert len(g["params"]) == 1, "one tensor per group, as the reference builds them"
             self.param_groups.append(g)
-        n = sum(1 for _ in self.param_groups)
-        assert n <= 8, "gsr_adam_step handles up to 8 tensors per launch"
-        self.betas, self.eps = betas, eps
+        self.betas, self.eps = tuple(betas), eps
         self.state = {}
-        self.step_count = 0
 
+    # ---- torch.optim protocol ------------------------------------------------------------------------------
     def zero_grad(self, set_to_none: bool = True):
         for g in self.param_groups:
             p = g["params"][0]
@@ -35,14 +53,69 @@ class FusedAdam:
             elif p.grad is not None:
                 p.grad.zero_()
 
-    FUSED_ORDER = ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation")
-
     def _state(self, p):
-        st = self.state.get(id(p))
+        st = self.state.get(p)
         if st is None:
-            st = self.state[id(p)] = {"exp_avg": torch.zeros_like(p), "exp_avg_sq": torch.zeros_like(p)}
+            st = self.state[p] = {}
+        # entries may have been rebuilt by the caller's surgery; anything missing starts from zero like torch does
+        if "step" not in st:
+            st["step"] = 0
+        if "exp_avg" not in st:
+            st["exp_avg"] = torch.zeros_like(p)
+        if "exp_avg_sq" not in st:
+            st["exp_avg_sq"] = torch.zeros_like(p)
+        for k in ("exp_avg", "exp_avg_sq"):
+            m = st[k]
+            if m.shape != p.shape or m.device != p.device or m.dtype != torch.float32:
+                raise RuntimeError(f"FusedAdam: state '{k}' {tuple(m.shape)} does not match its parameter {tuple(p.shape)}")
+            if not m.is_contiguous():      # e.g. a boolean-mask slice is contiguous, a strided view is not
+                st[k] = m.contiguous()
         return st
 
+    @property
+    def step_count(self) -> int:
+        """Largest per-tensor step count (all groups advance together in the reference's loop)."""
+        return max([_step_int(st.get("step", 0)) for st in self.state.values()], default=0)
+
+    def state_dict(self) -> Dict:
+        index, packed = {}, []
+        for g in self.param_groups:
+            ids = []
+            for p in g["params"]:
+                index.setdefault(id(p), len(index))
+                ids.append(index[id(p)])
+            packed.append({**{k: v for k, v in g.items() if k != "params"}, "betas": self.betas, "eps": self.eps,
+                           "params": ids})
+        st = {}
+        for g in self.param_groups:
+            for p in g["params"]:
+                if p in self.state:
+                    s = self.state[p]
+                    st[index[id(p)]] = {k: (torch.tensor(float(_step_int(v))) if k == "step" else v) for k, v in s.items()}
+        return {"state": st, "param_groups": packed}
+
+    def load_state_dict(self, sd: Dict):
+        groups = sd["param_groups"]
+        if len(groups) != len(self.param_groups):
+            raise ValueError("loaded state dict has a different number of parameter groups")
+        params = []
+        for g, saved in zip(self.param_groups, groups):
+            if len(saved["params"]) != len(g["params"]):
+                raise ValueError("loaded state dict contains a parameter group that doesn't match the size of optimizer's group")
+            for k, v in saved.items():
+                if k not in ("params", "betas", "eps"):
+                    g[k] = v
+            params += list(zip(saved["params"], g["params"]))
+        self.state = {}
+        for idx, p in params:
+            s = sd["state"].get(idx)
+            if s is None:
+                continue
+            self.state[p] = {"step": _step_int(s.get("step", 0)),
+                             "exp_avg": s["exp_avg"].to(device=p.device, dtype=torch.float32).clone(),
+                             "exp_avg_sq": s["exp_avg_sq"].to(device=p.device, dtype=torch.float32).clone()}
+
+    # ---- the two ways a step is taken ----------------------------------------------------------------------
     def fused_backward_args(self, tensors: Dict[str, torch.Tensor]) -> "L.GsrFusedAdam":
         """GsrFusedAdam for the optimizer-in-backward mode of gsr_backward: counts as this optimizer's next step.
         `tensors` are the parameter tensors the rasterizer saved, by group name; they must be the optimizer's own."""
@@ -51,6 +124,7 @@ class FusedAdam:
             raise RuntimeError(f"fused_adam: optimizer groups must be named {self.FUSED_ORDER}, got {tuple(by_name)}")
         fa = L.GsrFusedAdam()
         fa.beta1, fa.beta2, fa.eps = float(self.betas[0]), float(self.betas[1]), float(self.eps)
+        states, steps = [], set()
         for k, name in enumerate(self.FUSED_ORDER):
             g = by_name[name]
             p = g["params"][0]
@@ -58,10 +132,15 @@ class FusedAdam:
             if t.data_ptr() != p.data_ptr() or t.numel() != p.numel() or p.dtype != torch.float32 or not p.is_contiguous():
                 raise RuntimeError(f"fused_adam: group '{name}' is not the contiguous float32 tensor that was rasterized")
             st = self._state(p)
+            states.append(st)
+            steps.add(_step_int(st["step"]))
             fa.lr[k] = float(g["lr"])
             fa.exp_avg[k], fa.exp_avg_sq[k] = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
-        self.step_count += 1
-        fa.step = self.step_count
+        if len(steps) != 1:
+            raise RuntimeError(f"fused_adam: the six groups are at different step counts {sorted(steps)}; use step()")
+        fa.step = steps.pop() + 1
+        for st in states:
+            st["step"] = int(fa.step)
         return fa
 
     @torch.no_grad()
@@ -70,22 +149,29 @@ class FusedAdam:
         live = [g for g in self.param_groups if g["params"][0].grad is not None]
         if not live:
             return
-        self.step_count += 1
-        arr = (L.GsrAdamTensor * len(live))()
-        keep = []
         dev = live[0]["params"][0].device
         if dev.type != "cuda":
             raise RuntimeError("FusedAdam: parameters must be on a ROCm/HIP device (no CPU fallback)")
-        for k, g in enumerate(live):
+        by_step = {}
+        for g in live:
             p = g["params"][0]
-            assert p.is_contiguous() and p.dtype == torch.float32
+            if not (p.is_contiguous() and p.dtype == torch.float32):
+                raise RuntimeError("FusedAdam: parameters must be contiguous float32")
             st = self._state(p)
-            grad = p.grad.contiguous()
-            keep.append(grad)
-            arr[k].param, arr[k].grad = p.data_ptr(), grad.data_ptr()
-            arr[k].exp_avg, arr[k].exp_avg_sq = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
-            arr[k].n, arr[k].lr = p.numel(), float(g["lr"])
+            st["step"] = _step_int(st["step"]) + 1
+            by_step.setdefault(st["step"], []).append((g, p, st))
+        keep = []
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
-            L.check(lib.gsr_adam_step(arr, len(live), float(self.betas[0]), float(self.betas[1]), float(self.eps),
-                                      self.step_count, C.c_void_p(stream)), "gsr_adam_step")
+            for step, items in by_step.items():      # one launch; several only if tensors joined the optimizer at different times
+                for lo in range(0, len(items), 8):     # GSR_ADAM_MAX_TENSORS
+                    chunk = items[lo:lo + 8]
+                    arr = (L.GsrAdamTensor * len(chunk))()
+                    for k, (g, p, st) in enumerate(chunk):
+                        grad = p.grad.contiguous()
+                        keep.append(grad)
+                        arr[k].param, arr[k].grad = p.data_ptr(), grad.data_ptr()
+                        arr[k].exp_avg, arr[k].exp_avg_sq = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+                        arr[k].n, arr[k].lr = p.numel(), float(g["lr"])
+                    L.check(lib.gsr_adam_step(arr, len(chunk), float(self.betas[0]), float(self.betas[1]), float(self.eps),
+                                              int(step), C.c_void_p(stream)), "gsr_adam_step")

@@ -94,6 +94,47 @@ class GaussianParams:
     def num_points(self):
         return self._xyz.shape[0]
 
+    # ---- optimizer-state surgery of densification / pruning / opacity reset -----------------------------------------
+    # Same protocol as HTGaussianModel (/root/reference/scene/gaussian_model_ht.py:532-629): the parameter tensor of a
+    # group is replaced by a new leaf and its Adam moments are sliced / zero-extended / zeroed with it.  Works on
+    # torch.optim.Adam and on FusedAdam alike (both key `state` by the parameter tensor).
+    _GROUP_ATTR = {"xyz": "_xyz", "f_dc": "_features_dc", "f_rest": "_features_rest", "opacity": "_opacity",
+                   "scaling": "_scaling", "rotation": "_rotation"}
+
+    def _swap_group_tensor(self, group, new_tensor, moments):
+        """moments: callable(old_state_tensor) -> new state tensor (shape of new_tensor)."""
+        old = group["params"][0]
+        st = self.optimizer.state.pop(old, None)
+        new = new_tensor.detach().contiguous().requires_grad_(True)
+        if st is not None:
+            st["exp_avg"], st["exp_avg_sq"] = moments(st["exp_avg"]), moments(st["exp_avg_sq"])
+            self.optimizer.state[new] = st
+        group["params"][0] = new
+        setattr(self, self._GROUP_ATTR[group["name"]], new)
+        return new
+
+    def prune_points(self, mask: torch.Tensor):
+        """Remove the Gaussians where mask is True (gaussian_model_ht.py:568-582)."""
+        keep = ~mask
+        for g in self.optimizer.param_groups:
+            self._swap_group_tensor(g, g["params"][0][keep], lambda m: m[keep].contiguous())
+        self._screenspace_zero = None
+
+    def densification_postfix(self, new: Dict[str, torch.Tensor]):
+        """Append Gaussians; `new` maps group name -> tensor of new rows (gaussian_model_ht.py:584-629)."""
+        for g in self.optimizer.param_groups:
+            ext = new[g["name"]]
+            self._swap_group_tensor(g, torch.cat((g["params"][0].detach(), ext), dim=0),
+                                    lambda m, ext=ext: torch.cat((m, torch.zeros_like(ext)), dim=0))
+        self._screenspace_zero = None
+
+    def reset_opacity(self, ceiling: float = 0.01):
+        """opacity <- min(opacity, ceiling) with zeroed moments (gaussian_model_ht.py:468-474, 532-546)."""
+        for g in self.optimizer.param_groups:
+            if g["name"] == "opacity":
+                new = inverse_sigmoid(torch.min(self.get_opacity.detach(), torch.full_like(self._opacity, ceiling)))
+                self._swap_group_tensor(g, new, torch.zeros_like)
+
     @property
     def get_xyz(self):
         return self._xyz

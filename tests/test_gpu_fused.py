@@ -112,7 +112,7 @@ def test_optimizer_in_backward_equals_backward_then_step(n, deg):
             a, b = getattr(pa, k).detach(), getattr(pb, k).detach()
             assert bad_frac(a, b, 5e-7, 0.05 * lrs[id(getattr(pa, k))]) < 1e-3, (it, k, (a - b).abs().max().item())
             assert (a - b).abs().max().item() <= 2.5 * (it + 1) * lrs[id(getattr(pa, k))] + 1e-6 * b.abs().max().item()
-            sa, sb = pa.optimizer.state[id(getattr(pa, k))], pb.optimizer.state[id(getattr(pb, k))]
+            sa, sb = pa.optimizer.state[getattr(pa, k)], pb.optimizer.state[getattr(pb, k)]
             for mom in ("exp_avg", "exp_avg_sq"):
                 scale = sb[mom].abs().max().item()
                 assert bad_frac(sa[mom], sb[mom], 1e-3, 1e-6 * scale) < 1e-3, (it, k, mom)
@@ -120,6 +120,57 @@ def test_optimizer_in_backward_equals_backward_then_step(n, deg):
     if deg < 3:   # bands above the active degree: no gradient, so both routes must agree exactly (and stay put)
         hi = 3 * ((deg + 1) ** 2 - 1) // 3
         assert torch.equal(pa._features_rest[:, hi:], pb._features_rest[:, hi:])
+
+
+@pytest.mark.parametrize("fused_optimizer", [False, True], ids=["step", "in-backward"])
+def test_fused_adam_through_densification_matches_torch_adam(fused_optimizer):
+    """Train, prune, train, append (densify), reset opacity, train -- FusedAdam (stepped normally or inside the
+    backward kernel) against torch.optim.Adam with the same optimizer-state surgery (gaussian_model_ht.py:532-629).
+    Moments must be sliced / zero-extended with the parameters and the bias correction must keep counting."""
+    dev = torch.device("cuda:0")
+    sc = parity.syn.make_scene(12000, 256, 192, sh_degree=3, seed=21)
+    gt = parity.syn.target_image(256, 192).to(dev)
+    settings = ts.make_settings(sc, dev, 3)
+    pa, pb = ts.GaussianParams(sc, dev, optimizer="hip"), ts.GaussianParams(sc, dev, optimizer="torch")
+    names = ["_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation"]
+    gen = torch.Generator().manual_seed(5)
+
+    def steps(k):
+        for _ in range(k):
+            ts.train_step(pa, settings, gt, fused_optimizer=fused_optimizer)
+            ts.train_step(pb, settings, gt, fused_loss=True, fused_activations=True, fused_optimizer=False)
+
+    def compare(tag):
+        for k in names:
+            a, b = getattr(pa, k).detach(), getattr(pb, k).detach()
+            lr = next(g["lr"] for g in pa.optimizer.param_groups if g["params"][0] is getattr(pa, k))
+            bad = ((a - b).abs() > 0.05 * lr + 5e-7 * b.abs()).float().mean().item()
+            assert a.shape == b.shape and bad < 2e-3, (tag, k, bad)
+            sa, sb = pa.optimizer.state[getattr(pa, k)], pb.optimizer.state[getattr(pb, k)]
+            assert int(sa["step"]) == int(sb["step"]), (tag, k)
+            for mom in ("exp_avg", "exp_avg_sq"):
+                scale = sb[mom].abs().max().item()
+                bad = ((sa[mom] - sb[mom]).abs() > 1e-3 * sb[mom].abs() + 1e-6 * scale).float().mean().item()
+                assert bad < 2e-3, (tag, k, mom, bad)
+
+    steps(2)
+    compare("start")
+    mask = (torch.rand(pa.num_points, generator=gen) < 0.3).to(dev)
+    pa.prune_points(mask); pb.prune_points(mask)
+    steps(2)
+    compare("after prune")
+    idx = torch.randperm(pa.num_points, generator=gen)[:1500].to(dev)
+    for p in (pa, pb):
+        new = {n: getattr(p, a).detach()[idx].clone() for n, a in p._GROUP_ATTR.items()}
+        new["xyz"] = new["xyz"] + 0.01
+        p.densification_postfix(new)
+    assert pa.num_points == pb.num_points
+    steps(2)
+    compare("after densify")
+    pa.reset_opacity(); pb.reset_opacity()
+    steps(2)
+    compare("after opacity reset")
+    assert pa.optimizer.step_count == 8
 
 
 def test_optimizer_in_backward_refuses_foreign_tensors():
