@@ -24,6 +24,7 @@ class GsrForwardArgs(C.Structure):
         ("geom", C.c_void_p), ("image", C.c_void_p),
         ("alloc", ALLOC_FN), ("alloc_user", C.c_void_p),
         ("shs_rest", C.c_void_p), ("raw_params", C.c_int32),
+        ("points_transform", C.c_void_p),
     ]
 
 
@@ -46,6 +47,7 @@ class GsrBackwardArgs(C.Structure):
         ("shs_rest", C.c_void_p), ("d_shs_rest", C.c_void_p), ("raw_params", C.c_int32),
         ("d_viewmatrix", C.c_void_p), ("d_projmatrix", C.c_void_p), ("d_campos", C.c_void_p),
         ("fused_adam", C.c_void_p),
+        ("points_transform", C.c_void_p), ("d_points_transform", C.c_void_p),
     ]
 
 

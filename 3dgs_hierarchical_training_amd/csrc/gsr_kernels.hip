@@ -80,7 +80,17 @@ struct CamParams {
     const float *vm, *pm, *campos;
     float tanfovx, tanfovy, scale_mod;
     int W, H, D, M;
+    const float* xf;   // optional rigid / affine transform of the means (3x4 row-major), see GsrForwardArgs::points_transform
 };
+
+// p' = M [p; 1]: the in-kernel form of `P.retr().act(xyz)` (/root/reference/scene/gaussian_model_ht.py:135-148)
+__device__ __forceinline__ void apply_points_transform(const float* __restrict__ xf, float m[3])
+{
+    if (!xf) return;
+    const float x = m[0], y = m[1], z = m[2];
+#pragma unroll
+    for (int r = 0; r < 3; r++) m[r] = fmaf(xf[4 * r], x, fmaf(xf[4 * r + 1], y, fmaf(xf[4 * r + 2], z, xf[4 * r + 3])));
+}
 
 __device__ __forceinline__ Camera load_camera(const CamParams& p)
 {
@@ -265,7 +275,8 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess(CamParams cp, int N,
     if (i >= N) return;
     Camera cam = load_camera(cp);
     cam.D = DEG;
-    const float mean[3] = {means[3 * (size_t)i], means[3 * (size_t)i + 1], means[3 * (size_t)i + 2]};
+    float mean[3] = {means[3 * (size_t)i], means[3 * (size_t)i + 1], means[3 * (size_t)i + 2]};
+    apply_points_transform(cp.xf, mean);
     float sc[3] = {0, 0, 0}, rq[4] = {1, 0, 0, 0}, cv[6], colp[3];
     if (cov_pre) {
 #pragma unroll
@@ -1123,7 +1134,7 @@ __device__ __forceinline__ void adam_rows(const float* s_g, int stride, int col0
 // CAM = true additionally produces dL/d(viewmatrix, projmatrix, campos) (north_star's dL/dviewmatrix; BASELINE
 // config 5): per-thread contributions are reduced over the block and written as one 35-float partial per block;
 // k_cam_reduce sums the partials deterministically.
-constexpr int kCamVals = 35;
+constexpr int kCamVals = 47;   // viewmatrix 16 + projmatrix 16 + campos 3 + points_transform 12
 
 // ADAM = true (needs RAW, shs + shs_rest, no cov_pre): optimizer-in-backward, see GsrFusedAdam in include/gsr.h.  The
 // parameter pointers are then read AND written by the block that owns the rows (no __restrict__ promises on them).
@@ -1151,10 +1162,13 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, in
     const int i = base + tid;
     const int nG = min(kPreThreads, N - base);
     CamGrads cg;
+    float xg[12];   // dL/d(points_transform) share of this thread
     if (CAM) {
 #pragma unroll
         for (int q = 0; q < 16; q++) { cg.vm[q] = 0.f; cg.pm[q] = 0.f; }
         cg.cam[0] = cg.cam[1] = cg.cam[2] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 12; q++) xg[q] = 0.f;
     }
     if (shs) {
         if (shs_rest) {
@@ -1192,7 +1206,9 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, in
         if (s.radius > 0) {
             const float4* gp = reinterpret_cast<const float4*>(ggrad + (size_t)i * kGG);
             const float4 g0 = gp[0], g1 = gp[1], g2 = gp[2];   // gx gy gA gB | gC gop gr gg | gb gz - -
-            const float mean[3] = {means[3 * (size_t)i], means[3 * (size_t)i + 1], means[3 * (size_t)i + 2]};
+            const float mraw[3] = {means[3 * (size_t)i], means[3 * (size_t)i + 1], means[3 * (size_t)i + 2]};
+            float mean[3] = {mraw[0], mraw[1], mraw[2]};
+            apply_points_transform(cp.xf, mean);
             float sc[3] = {0, 0, 0}, rq[4] = {1, 0, 0, 0}, cv[6];
             if (cov_pre) {
 #pragma unroll
@@ -1238,6 +1254,18 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, in
                     cg.cam[0] = o.mean[0] - dmean[0]; cg.cam[1] = o.mean[1] - dmean[1]; cg.cam[2] = o.mean[2] - dmean[2];
                 }
             }
+            if (cp.xf) {   // chain through p' = M [p; 1]: dL/dM = dL/dp' [p; 1]^T, dL/dp = R^T dL/dp'
+                if (CAM) {
+#pragma unroll
+                    for (int r = 0; r < 3; r++) {
+                        xg[4 * r] = dmean[r] * mraw[0]; xg[4 * r + 1] = dmean[r] * mraw[1]; xg[4 * r + 2] = dmean[r] * mraw[2];
+                        xg[4 * r + 3] = dmean[r];
+                    }
+                }
+                const float d0 = dmean[0], d1 = dmean[1], d2 = dmean[2];
+#pragma unroll
+                for (int c = 0; c < 3; c++) dmean[c] = fmaf(cp.xf[c], d0, fmaf(cp.xf[4 + c], d1, cp.xf[8 + c] * d2));
+            }
         } else if (shs) {
             for (int e = 0; e < NC3; e++) s_sh[tid * kShStride + e] = 0.f;
         }
@@ -1277,6 +1305,8 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, in
 #pragma unroll
         for (int q = 0; q < 16; q++) { cv35[q] = cg.vm[q]; cv35[16 + q] = cg.pm[q]; }
         cv35[32] = cg.cam[0]; cv35[33] = cg.cam[1]; cv35[34] = cg.cam[2];
+#pragma unroll
+        for (int q = 0; q < 12; q++) cv35[35 + q] = xg[q];
 #pragma unroll
         for (int q = 0; q < kCamVals; q++) {
             const float t = wave_sum_to_lane63(cv35[q]);
@@ -1339,7 +1369,7 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, in
 
 // one block per camera entry: deterministic sum of the per-block partials
 __global__ __launch_bounds__(256) void k_cam_reduce(const float* __restrict__ partial, int nblocks, float* __restrict__ d_vm,
-                                                    float* __restrict__ d_pm, float* __restrict__ d_campos)
+                                                    float* __restrict__ d_pm, float* __restrict__ d_campos, float* __restrict__ d_xf)
 {
     __shared__ double s[256];
     const int q = blockIdx.x;
@@ -1355,7 +1385,8 @@ __global__ __launch_bounds__(256) void k_cam_reduce(const float* __restrict__ pa
         const float v = (float)s[0];
         if (q < 16) { if (d_vm) d_vm[q] = v; }
         else if (q < 32) { if (d_pm) d_pm[q - 16] = v; }
-        else if (d_campos) d_campos[q - 32] = v;
+        else if (q < 35) { if (d_campos) d_campos[q - 32] = v; }
+        else if (d_xf) d_xf[q - 35] = v;
     }
 }
 
@@ -1654,7 +1685,7 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
     uint32_t* block_sums = reinterpret_cast<uint32_t*>(fs + L.block_sums);
     unsigned long long* total = reinterpret_cast<unsigned long long*>(fs + L.total);
     const bool depth_onesweep = g_sort_algo != 0;
-    CamParams cp = {a->viewmatrix, a->projmatrix, a->campos, a->tanfovx, a->tanfovy, a->scale_modifier, W, H, a->D, a->M};
+    CamParams cp = {a->viewmatrix, a->projmatrix, a->campos, a->tanfovx, a->tanfovy, a->scale_modifier, W, H, a->D, a->M, a->points_transform};
     const int grid = (N + kPreThreads - 1) / kPreThreads;
     // block 0 of k_preprocess clears the head (digit histograms + tickets) of the depth sort's scratch
     uint32_t* zero_words = depth_onesweep ? reinterpret_cast<uint32_t*>(fs + L.sort) : nullptr;
@@ -1749,6 +1780,7 @@ int gsr_backward(const GsrBackwardArgs* a, void* stream_)
         if (a->d_viewmatrix) GSR_HIP(hipMemsetAsync(a->d_viewmatrix, 0, 64, st));
         if (a->d_projmatrix) GSR_HIP(hipMemsetAsync(a->d_projmatrix, 0, 64, st));
         if (a->d_campos) GSR_HIP(hipMemsetAsync(a->d_campos, 0, 12, st));
+        if (a->d_points_transform) GSR_HIP(hipMemsetAsync(a->d_points_transform, 0, 48, st));
         return GSR_OK;
     }
     if (!a->geom || !a->image || !a->binning || !a->scratch || !a->d_means2D)
@@ -1777,9 +1809,9 @@ int gsr_backward(const GsrBackwardArgs* a, void* stream_)
         } else if (ppt == 3) launch_blend_bwd<2>(W, H, tiles_x, T, ranges, list, splat, a->bg, img, a->grad_color, a->grad_depth, a->grad_alpha, gg, st);
         else launch_blend_bwd<4>(W, H, tiles_x, T, ranges, list, splat, a->bg, img, a->grad_color, a->grad_depth, a->grad_alpha, gg, st);
     }
-    CamParams cp = {a->viewmatrix, a->projmatrix, a->campos, a->tanfovx, a->tanfovy, a->scale_modifier, W, H, a->D, a->M};
+    CamParams cp = {a->viewmatrix, a->projmatrix, a->campos, a->tanfovx, a->tanfovy, a->scale_modifier, W, H, a->D, a->M, a->points_transform};
     const int grid = (N + kPreThreads - 1) / kPreThreads;
-    const bool want_cam = a->d_viewmatrix || a->d_projmatrix || a->d_campos;
+    const bool want_cam = a->d_viewmatrix || a->d_projmatrix || a->d_campos || a->d_points_transform;
     float* cam_partial = reinterpret_cast<float*>(static_cast<uint8_t*>(a->scratch) + align256((size_t)N * kGG * 4));
     AdamDev ad = {};
     const GsrFusedAdam* fa = a->fused_adam;
@@ -1819,7 +1851,8 @@ int gsr_backward(const GsrBackwardArgs* a, void* stream_)
 #undef GSR_PREB
 #undef GSR_PREB_
     if (want_cam)
-        hipLaunchKernelGGL(k_cam_reduce, dim3(kCamVals), dim3(256), 0, st, cam_partial, grid, a->d_viewmatrix, a->d_projmatrix, a->d_campos);
+        hipLaunchKernelGGL(k_cam_reduce, dim3(kCamVals), dim3(256), 0, st, cam_partial, grid, a->d_viewmatrix, a->d_projmatrix, a->d_campos,
+                           a->d_points_transform);
     GSR_HIP(hipGetLastError());
     return GSR_OK;
 }

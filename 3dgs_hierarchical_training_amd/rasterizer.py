@@ -94,7 +94,8 @@ class _Workspace:
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
-                sh_rest=None, raw_params=False, viewmatrix=None, projmatrix=None, campos=None, fused_adam=None):
+                sh_rest=None, raw_params=False, viewmatrix=None, projmatrix=None, campos=None, fused_adam=None,
+                points_transform=None):
         # viewmatrix / projmatrix / campos are ALSO passed as explicit tensor inputs (same objects as in
         # raster_settings) so that autograd can return their gradients: a NamedTuple cannot carry grads.
         lib = L.load()
@@ -114,6 +115,11 @@ class _RasterizeGaussians(torch.autograd.Function):
         bg = _f32c(rs.bg.to(dev))
         H, W = int(rs.image_height), int(rs.image_width)
         sh_rest = _f32c(_empty_to_none(sh_rest))
+        xf = None
+        if points_transform is not None:       # [3,4] or [4,4] rigid / affine transform applied to the means in-kernel
+            if tuple(points_transform.shape) not in ((3, 4), (4, 4)):
+                raise RuntimeError("points_transform must be a [3,4] or [4,4] tensor")
+            xf = _f32c(points_transform.to(dev)[:3])
         M = (int(sh.shape[1]) + (int(sh_rest.shape[1]) if sh_rest is not None else 0)) if sh is not None else 0
 
         color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
@@ -135,6 +141,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         a.geom, a.image = geom.data_ptr(), image.data_ptr()
         a.alloc, a.alloc_user = ws.cb, None
         a.shs_rest, a.raw_params = _ptr(sh_rest), int(bool(raw_params))
+        a.points_transform = _ptr(xf)
         out = L.GsrForwardOut()
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
@@ -148,12 +155,13 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.has = (sh is not None, colors_precomp is not None, scales is not None, cov3Ds_precomp is not None)
         ctx.raw = (sh_rest is not None, bool(raw_params))
         ctx.fused_adam = fused_adam
+        ctx.xf_shape = tuple(points_transform.shape) if points_transform is not None else None
         z = means3D.new_empty(0)
         # NOTE: depth is deliberately NOT saved -- the caller mutates it in place (ht3dgs_trainer.py:1290-1292).
         ctx.save_for_backward(means3D, opacities, sh if sh is not None else z, colors_precomp if colors_precomp is not None else z,
                               scales if scales is not None else z, rotations if rotations is not None else z,
                               cov3Ds_precomp if cov3Ds_precomp is not None else z, vm, pm, campos, bg, geom, image,
-                              ws.binning, sh_rest if sh_rest is not None else z)
+                              ws.binning, sh_rest if sh_rest is not None else z, xf if xf is not None else z)
         ctx.mark_non_differentiable(radii)
         ctx.set_materialize_grads(False)   # unused depth / alpha outputs arrive as None -> specialised backward
         return color, radii, depth, alpha
@@ -163,18 +171,20 @@ class _RasterizeGaussians(torch.autograd.Function):
         lib = L.load()
         rs = ctx.raster_settings
         (means3D, opacities, sh, colors_precomp, scales, rotations, cov3Ds_precomp, vm, pm, campos, bg, geom, image,
-         binning, sh_rest) = ctx.saved_tensors
+         binning, sh_rest, xf) = ctx.saved_tensors
         has_rest, raw_params = ctx.raw
         N, M, H, W = ctx.dims
         has_sh, has_col, has_scale, has_cov = ctx.has
         dev = means3D.device
         grad_color, grad_depth, grad_alpha = _f32c(grad_color), _f32c(grad_depth), _f32c(grad_alpha)
         if grad_color is None and grad_depth is None and grad_alpha is None:
-            return (None,) * 15
+            return (None,) * 16
         need_vm, need_pm, need_cp = ctx.needs_input_grad[11], ctx.needs_input_grad[12], ctx.needs_input_grad[13]
         d_vm = torch.empty((4, 4), dtype=torch.float32, device=dev) if need_vm else None
         d_pm = torch.empty((4, 4), dtype=torch.float32, device=dev) if need_pm else None
         d_cp = torch.empty((3,), dtype=torch.float32, device=dev) if need_cp else None
+        has_xf = ctx.xf_shape is not None
+        d_xf = torch.zeros(ctx.xf_shape, dtype=torch.float32, device=dev) if (has_xf and ctx.needs_input_grad[15]) else None
 
         fused = ctx.fused_adam
         d_means2D = torch.empty((N, 3), dtype=torch.float32, device=dev)
@@ -217,10 +227,12 @@ class _RasterizeGaussians(torch.autograd.Function):
         a.d_shs_rest, a.raw_params = _ptr(d_sh_rest), int(raw_params)
         a.d_viewmatrix, a.d_projmatrix, a.d_campos = _ptr(d_vm), _ptr(d_pm), _ptr(d_cp)
         a.fused_adam = C.addressof(fa) if fa is not None else None
+        a.points_transform = _ptr(xf) if has_xf else None
+        a.d_points_transform = _ptr(d_xf)       # first 12 floats = rows 0..2 (a [4,4] input keeps a zero last row)
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
             L.check(lib.gsr_backward(C.byref(a), C.c_void_p(stream)), "gsr_backward")
-        return (d_means3D, d_means2D, d_sh, d_col, d_opac, d_scales, d_rot, d_cov, None, d_sh_rest, None, d_vm, d_pm, d_cp, None)
+        return (d_means3D, d_means2D, d_sh, d_col, d_opac, d_scales, d_rot, d_cov, None, d_sh_rest, None, d_vm, d_pm, d_cp, None, d_xf)
 
 
 def _cam_inputs(rs):
@@ -230,13 +242,14 @@ def _cam_inputs(rs):
     return None, None, None
 
 
-def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
+                        points_transform=None):
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                                     raster_settings, None, False, *_cam_inputs(raster_settings), None)
+                                     raster_settings, None, False, *_cam_inputs(raster_settings), None, points_transform)
 
 
 def rasterize_gaussians_raw(means3D, means2D, features_dc, features_rest, opacity_logit, log_scales, rotations_raw,
-                            raster_settings, fused_adam=None):
+                            raster_settings, fused_adam=None, points_transform=None):
     """Extension ("next" row f-2): rasterize straight from HTGaussianModel's raw parameters (_xyz, _features_dc,
     _features_rest, _opacity, _scaling, _rotation; /root/reference/scene/gaussian_model_ht.py:74-82) with the
     activations of :49-65,128-133,176-188 fused into the HIP kernels; gradients are w.r.t. the raw tensors.
@@ -244,10 +257,14 @@ def rasterize_gaussians_raw(means3D, means2D, features_dc, features_rest, opacit
     fused_adam = a `FusedAdam` whose groups are exactly these six tensors (names xyz, f_dc, f_rest, opacity, scaling,
     rotation as at gaussian_model_ht.py:275-286): backward() then applies that optimizer's step inside the
     per-Gaussian backward kernel (include/gsr.h GsrFusedAdam) and leaves the parameter .grad unset; means2D.grad is
-    still produced.  Same result as backward() followed by optimizer.step()."""
+    still produced.  Same result as backward() followed by optimizer.step().
+
+    points_transform = [3,4] / [4,4] tensor M: every mean is replaced by M[:3,:3] p + M[:3,3] inside the kernels -- the
+    fused form of `get_xyz` under pose fitting (`self.P[k].retr().act(xyz)`, gaussian_model_ht.py:135-148); its
+    gradient comes back through autograd (see pose.py for the SE3 parametrisation)."""
     e = torch.Tensor([])
     return _RasterizeGaussians.apply(means3D, means2D, features_dc, e, opacity_logit, log_scales, rotations_raw, e,
-                                     raster_settings, features_rest, True, *_cam_inputs(raster_settings), fused_adam)
+                                     raster_settings, features_rest, True, *_cam_inputs(raster_settings), fused_adam, points_transform)
 
 
 class GaussianRasterizer(nn.Module):
@@ -275,7 +292,8 @@ class GaussianRasterizer(nn.Module):
         return present.bool()
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
-                cov3D_precomp=None):
+                cov3D_precomp=None, points_transform=None):
+        # points_transform is an extension (fused pose action, pose.py); None = the reference's signature
         rs = self.raster_settings
         if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
             raise Exception("Please provide excatly one of either SHs or precomputed colors!")
@@ -286,4 +304,4 @@ class GaussianRasterizer(nn.Module):
         return rasterize_gaussians(means3D, means2D, shs if shs is not None else e,
                                    colors_precomp if colors_precomp is not None else e, opacities,
                                    scales if scales is not None else e, rotations if rotations is not None else e,
-                                   cov3D_precomp if cov3D_precomp is not None else e, rs)
+                                   cov3D_precomp if cov3D_precomp is not None else e, rs, points_transform)

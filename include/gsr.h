@@ -74,6 +74,11 @@ typedef struct GsrForwardArgs {
                                     (gaussian_model_ht.py:176-179 concatenates them every call) */
     int32_t raw_params;          /* 1: scales = log-scales, rotations un-normalised, opacities = logits; the
                                     activations of gaussian_model_ht.py:49-65,128-133,187-188 run in-kernel */
+    /* ---- extension, "next" row f-4: fused pose action.  NULL = none.  12 floats, row-major 3x4 [R | t], device.
+     * Every mean is replaced by R p + t before anything else is computed -- the in-kernel form of
+     * `xyz = self.P[k].retr().act(self._xyz.clone())` (gaussian_model_ht.py:135-148): positions move, the Gaussians'
+     * own rotations / scales / SH do not, exactly as the reference's get_xyz has it. */
+    const float* points_transform;
 } GsrForwardArgs;
 
 typedef struct GsrForwardOut {
@@ -132,6 +137,10 @@ typedef struct GsrBackwardArgs {
     float* d_campos;         /* 3 */
     /* ---- optimizer-in-backward (extension f-2, see GsrFusedAdam below).  NULL = plain backward. */
     const struct GsrFusedAdam* fused_adam;
+    /* ---- fused pose action (f-4): the transform given to the forward, and where dL/d(transform) (12 floats, same
+     * layout) goes; d_means3D is then the gradient w.r.t. the UNtransformed means (R^T dL/dp'). */
+    const float* points_transform;
+    float* d_points_transform;
 } GsrBackwardArgs;
 
 size_t gsr_geom_bytes(int32_t N);

@@ -1,0 +1,79 @@
+"""GPU: the fused pose action (`points_transform`) against the route the reference takes today --
+transform the N centres with torch ops (`P.retr().act(xyz)`, gaussian_model_ht.py:135-148), then rasterize -- for
+the image and for every gradient, including dL/d(delta) of the SE(3) tangent parameter.  Tolerances as everywhere:
+1e-5 abs on the image (the two routes round R p + t differently in the last bit, so a small fraction of pixels may
+exceed it by a dropped / added marginal contribution), 1e-4 relative (norm-wise) on gradients."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+import parity
+
+pytestmark = pytest.mark.gpu
+ts = importlib.import_module("3dgs_hierarchical_training_amd.train_step")
+pose = importlib.import_module("3dgs_hierarchical_training_amd.pose")
+R = importlib.import_module("3dgs_hierarchical_training_amd.rasterizer")
+
+
+def _rel(a, b):
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+@pytest.mark.parametrize("raw", [False, True], ids=["activated", "raw"])
+def test_fused_pose_action_matches_explicit_act(raw):
+    dev = torch.device("cuda:0")
+    sc = parity.syn.make_scene(20000, 320, 240, sh_degree=3, seed=13, posed=True)
+    settings = ts.make_settings(sc, dev, 3, bg=torch.tensor([0.2, 0.1, 0.3]))
+    G = torch.tensor([0.05, -0.03, 0.08, 0.02, -0.015, 0.01, 1.0], device=dev)
+    G = torch.cat((G[:3], G[3:] / G[3:].norm()))
+    w = torch.linspace(0.5, 1.5, 3 * 240 * 320, device=dev).view(3, 240, 320)
+    res = {}
+    for fused in (False, True):
+        p = ts.GaussianParams(sc, dev, optimizer="torch")
+        delta = torch.zeros(6, device=dev, requires_grad=True)
+        Mx = pose.retr_matrix(delta, G)
+        m2d = torch.zeros_like(p._xyz, requires_grad=True)
+        xyz = p._xyz if fused else pose.act(Mx, p._xyz)
+        xf = Mx if fused else None
+        if raw:
+            out = R.rasterize_gaussians_raw(xyz, m2d, p._features_dc, p._features_rest, p._opacity, p._scaling, p._rotation,
+                                            settings, points_transform=xf)
+        else:
+            out = R.GaussianRasterizer(settings)(means3D=xyz, means2D=m2d, shs=p.get_features, opacities=p.get_opacity,
+                                                 scales=p.get_scaling, rotations=p.get_rotation, points_transform=xf)
+        color, radii, depth, alpha = out
+        ((color * w).sum() + 0.1 * depth.sum() + 0.1 * alpha.sum()).backward()
+        res[fused] = dict(img=color.detach(), radii=radii, delta=delta.grad.clone(), m2d=m2d.grad.clone(),
+                          grads={k: getattr(p, k).grad.clone() for k in ("_xyz", "_features_dc", "_features_rest", "_opacity",
+                                                                         "_scaling", "_rotation")})
+    assert (res[True]["radii"] != res[False]["radii"]).float().mean().item() < 1e-3
+    d = (res[True]["img"] - res[False]["img"]).abs()
+    assert (d > 1e-5).float().mean().item() < 2e-3 and d.max().item() < 2e-2
+    assert _rel(res[True]["delta"], res[False]["delta"]) < 1e-3          # a sum over all N contributions
+    assert float(res[False]["delta"].abs().max()) > 0
+    assert _rel(res[True]["m2d"], res[False]["m2d"]) < 1e-3
+    for k, ref in res[False]["grads"].items():
+        assert _rel(res[True]["grads"][k], ref) < 1e-3, k
+
+
+def test_identity_transform_is_a_no_op_and_4x4_grad_has_zero_last_row():
+    dev = torch.device("cuda:0")
+    sc = parity.syn.make_scene(5000, 160, 120, sh_degree=3, seed=3, posed=True)
+    settings = ts.make_settings(sc, dev, 3)
+    p = ts.GaussianParams(sc, dev, optimizer="torch")
+    m2d = torch.zeros_like(p._xyz)
+    with torch.no_grad():
+        a = R.rasterize_gaussians_raw(p._xyz, m2d, p._features_dc, p._features_rest, p._opacity, p._scaling, p._rotation, settings)
+        b = R.rasterize_gaussians_raw(p._xyz, m2d, p._features_dc, p._features_rest, p._opacity, p._scaling, p._rotation, settings,
+                                      points_transform=torch.eye(4, device=dev))
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    Mx = torch.eye(4, device=dev, requires_grad=True)
+    out = R.rasterize_gaussians_raw(p._xyz, m2d, p._features_dc, p._features_rest, p._opacity, p._scaling, p._rotation, settings,
+                                    points_transform=Mx)
+    out[0].sum().backward()
+    assert Mx.grad.shape == (4, 4) and float(Mx.grad[3].abs().max()) == 0.0 and float(Mx.grad[:3].abs().max()) > 0
+    with pytest.raises(RuntimeError, match="points_transform"):
+        R.rasterize_gaussians_raw(p._xyz, m2d, p._features_dc, p._features_rest, p._opacity, p._scaling, p._rotation, settings,
+                                  points_transform=torch.eye(3, device=dev))

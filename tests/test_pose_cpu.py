@@ -1,0 +1,45 @@
+"""CPU: the SE(3) maps of pose.py against independent statements (scipy rotations, numerical integration, autograd)."""
+import importlib
+
+import numpy as np
+import torch
+from scipy.spatial.transform import Rotation
+
+pose = importlib.import_module("3dgs_hierarchical_training_amd.pose")
+
+
+def test_exp_of_zero_and_inverse():
+    assert torch.allclose(pose.se3_exp(torch.zeros(6, dtype=torch.float64)), torch.eye(4, dtype=torch.float64))
+    d = torch.tensor([0.3, -0.2, 0.5, 0.4, -0.7, 0.2], dtype=torch.float64)
+    assert torch.allclose(pose.se3_exp(d) @ pose.se3_exp(-d), torch.eye(4, dtype=torch.float64), atol=1e-12)
+
+
+def test_rotation_block_is_rodrigues_and_translation_is_integral():
+    rng = np.random.default_rng(0)
+    for scale in (1e-6, 1e-3, 0.5, 2.5):
+        d = rng.normal(size=6) * scale
+        M = pose.se3_exp(torch.from_numpy(d)).numpy()
+        assert np.allclose(M[:3, :3], Rotation.from_rotvec(d[3:]).as_matrix(), atol=1e-12)
+        # t = (integral_0^1 exp(s phi^) ds) tau
+        s = np.linspace(0.0, 1.0, 4001)
+        Rs = Rotation.from_rotvec(np.outer(s, d[3:])).as_matrix()
+        V = np.trapezoid(Rs, s, axis=0)
+        assert np.allclose(M[:3, 3], V @ d[:3], atol=1e-6 * max(1.0, scale))
+
+
+def test_pose7_matches_scipy_quaternion_convention():
+    q = Rotation.from_euler("xyz", [0.3, -0.4, 1.1]).as_quat()          # scipy: (x, y, z, w)
+    p7 = torch.tensor([0.1, 0.2, 0.3, *q], dtype=torch.float64)
+    M = pose.pose7_to_matrix(p7).numpy()
+    assert np.allclose(M[:3, :3], Rotation.from_quat(q).as_matrix(), atol=1e-12) and np.allclose(M[:3, 3], [0.1, 0.2, 0.3])
+
+
+def test_tangent_derivative_at_zero_is_translation_and_cross_product():
+    """d/d delta of act(Exp(delta) G, p) at delta = 0 is [I | -[p']x] with p' = G p (left perturbation)."""
+    G = torch.tensor([0.2, -0.1, 0.4, *Rotation.from_rotvec([0.2, 0.5, -0.3]).as_quat()], dtype=torch.float64)
+    p = torch.tensor([[0.7, -1.2, 2.0]], dtype=torch.float64)
+    delta = torch.zeros(6, dtype=torch.float64, requires_grad=True)
+    J = torch.autograd.functional.jacobian(lambda d: pose.act(pose.retr_matrix(d, G), p)[0], delta)
+    pp = pose.act(pose.pose7_to_matrix(G), p)[0]
+    expect = torch.cat((torch.eye(3, dtype=torch.float64), -pose._hat(pp)), dim=1)
+    assert torch.allclose(J, expect, atol=1e-9)
