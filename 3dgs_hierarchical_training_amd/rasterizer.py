@@ -292,8 +292,9 @@ class GaussianRasterizer(nn.Module):
         return present.bool()
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
-                cov3D_precomp=None, points_transform=None):
-        # points_transform is an extension (fused pose action, pose.py); None = the reference's signature
+                cov3D_precomp=None):
+        # (the keyword set is exactly the reference's; extensions such as points_transform live on the functions
+        #  rasterize_gaussians / rasterize_gaussians_raw)
         rs = self.raster_settings
         if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
             raise Exception("Please provide excatly one of either SHs or precomputed colors!")
@@ -304,4 +305,4 @@ class GaussianRasterizer(nn.Module):
         return rasterize_gaussians(means3D, means2D, shs if shs is not None else e,
                                    colors_precomp if colors_precomp is not None else e, opacities,
                                    scales if scales is not None else e, rotations if rotations is not None else e,
-                                   cov3D_precomp if cov3D_precomp is not None else e, rs, points_transform)
+                                   cov3D_precomp if cov3D_precomp is not None else e, rs)

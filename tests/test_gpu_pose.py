@@ -41,8 +41,9 @@ def test_fused_pose_action_matches_explicit_act(raw):
             out = R.rasterize_gaussians_raw(xyz, m2d, p._features_dc, p._features_rest, p._opacity, p._scaling, p._rotation,
                                             settings, points_transform=xf)
         else:
-            out = R.GaussianRasterizer(settings)(means3D=xyz, means2D=m2d, shs=p.get_features, opacities=p.get_opacity,
-                                                 scales=p.get_scaling, rotations=p.get_rotation, points_transform=xf)
+            e = torch.Tensor([])
+            out = R.rasterize_gaussians(xyz, m2d, p.get_features, e, p.get_opacity, p.get_scaling, p.get_rotation, e, settings,
+                                        points_transform=xf)
         color, radii, depth, alpha = out
         ((color * w).sum() + 0.1 * depth.sum() + 0.1 * alpha.sum()).backward()
         res[fused] = dict(img=color.detach(), radii=radii, delta=delta.grad.clone(), m2d=m2d.grad.clone(),
