@@ -35,8 +35,9 @@ __device__ __forceinline__ unsigned long long lanemask_lt()
 // order, so "read, xor, read" needs no barrier; nothing is ever reset (a round only looks at the difference).
 // s_cnt[digit] is the wave's running count of the digit over the rounds done so far.
 // rnk[r] = number of this wave's keys with the same digit that precede key r in (round, lane) order.
-__device__ __forceinline__ void wave_rank(unsigned long long* s_mask, uint32_t* s_cnt, const uint32_t (&dig)[kSortIPT],
-                                          uint32_t (&rnk)[kSortIPT], int lane)
+template <int IPT>
+__device__ __forceinline__ void wave_rank(unsigned long long* s_mask, uint32_t* s_cnt, const uint32_t (&dig)[IPT],
+                                          uint32_t (&rnk)[IPT], int lane)
 {
 #pragma unroll
     for (int k = 0; k < 4; k++) { s_mask[k * 64 + lane] = 0ull; s_cnt[k * 64 + lane] = 0u; }
@@ -45,7 +46,7 @@ __device__ __forceinline__ void wave_rank(unsigned long long* s_mask, uint32_t* 
     volatile unsigned long long* vmask = s_mask;
     volatile uint32_t* vcnt = s_cnt;
 #pragma unroll
-    for (int r = 0; r < kSortIPT; r++) {
+    for (int r = 0; r < IPT; r++) {
         const uint32_t d = dig[r];
         uint32_t below, group;
         const uint32_t base = vcnt[d];
@@ -65,8 +66,9 @@ __device__ __forceinline__ void wave_rank(unsigned long long* s_mask, uint32_t* 
     }
 }
 
-// exclusive scan of one value per thread over the 256 threads of the block (two barriers)
-__device__ __forceinline__ uint32_t block_scan_excl_256(uint32_t v, uint32_t* s_wsum /*[4]*/, int tid)
+// exclusive scan of one value per thread over the block's WAVES * 64 threads (two barriers)
+template <int WAVES>
+__device__ __forceinline__ uint32_t block_scan_excl(uint32_t v, uint32_t* s_wsum /*[WAVES]*/, int tid)
 {
     const int lane = tid & 63, wave = tid >> 6;
     uint32_t inc = v;
@@ -79,7 +81,7 @@ __device__ __forceinline__ uint32_t block_scan_excl_256(uint32_t v, uint32_t* s_
     __syncthreads();
     uint32_t add = 0;
 #pragma unroll
-    for (int w = 0; w < kSortWaves; w++) add += (w < wave) ? s_wsum[w] : 0u;
+    for (int w = 0; w < WAVES; w++) add += (w < wave) ? s_wsum[w] : 0u;
     __syncthreads();
     return add + inc - v;
 }
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const KeyT* __re
             key[r] = (KeyT)~(KeyT)0; val[r] = 0u; dig[r] = 255u;   // padding sorts behind every real item
         }
     }
-    wave_rank(s_mask[wave], s_cnt[wave], dig, rnk, lane);
+    wave_rank<kSortIPT>(s_mask[wave], s_cnt[wave], dig, rnk, lane);
     __syncthreads();
     uint32_t mine = 0;   // thread = digit: exclusive prefix of the per-wave counts in wave order
 #pragma unroll
@@ -197,7 +199,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const KeyT* __re
         s_cnt[w][tid] = mine;
         mine += c;
     }
-    const uint32_t excl = block_scan_excl_256(mine, s_wsum, tid);
+    const uint32_t excl = block_scan_excl<kSortWaves>(mine, s_wsum, tid);
     s_start[tid] = excl;
     s_gbase[tid] = hist[(size_t)tid * nblocks + blockIdx.x] - excl;
     __syncthreads();
@@ -276,22 +278,32 @@ __global__ __launch_bounds__(256) void k_radix_ghist(const KeyT* __restrict__ ke
         if (h[p][tid]) atomicAdd(&ghist[p * 256 + tid], h[p][tid]);
 }
 
+// 512 threads x 8 keys per tile: the same 4096-key tile as the three-kernel path, but half the ranking rounds per
+// wave and twice the waves to hide the LDS / look-back latency behind (a workgroup's latency chain, not bandwidth,
+// is what a pass costs)
+// Measured (1 M depth keys / 4.5 M tile keys): 256x16 0.100 / 0.111 ms, 512x8 0.084 / 0.103, 1024x4 0.081 / 0.116,
+// 512x4 (2048-key tiles) 0.086 / 0.127 -> the small latency-bound depth sort takes 1024 threads, the tile sort 512.
+constexpr int kOsTile = 4096;
+template <typename KeyT> struct OsCfg { static constexpr int kThreads = 512; };
+template <> struct OsCfg<uint32_t> { static constexpr int kThreads = 1024; };
+
 template <typename KeyT>
-__global__ __launch_bounds__(kSortThreads) void k_onesweep(const KeyT* __restrict__ kin, const uint32_t* __restrict__ vin,
-                                                           KeyT* __restrict__ kout, uint32_t* __restrict__ vout, uint32_t n, int shift,
-                                                           const uint32_t* __restrict__ ghist /*[256] this pass*/,
-                                                           uint32_t* __restrict__ status /*[nblocks][256]*/,
-                                                           uint32_t* __restrict__ ticket,
-                                                           const unsigned long long* __restrict__ n_dev)
+__global__ __launch_bounds__(OsCfg<KeyT>::kThreads) void k_onesweep(const KeyT* __restrict__ kin, const uint32_t* __restrict__ vin,
+                                                         KeyT* __restrict__ kout, uint32_t* __restrict__ vout, uint32_t n, int shift,
+                                                         const uint32_t* __restrict__ ghist /*[256] this pass*/,
+                                                         uint32_t* __restrict__ status /*[nblocks][256]*/,
+                                                         uint32_t* __restrict__ ticket,
+                                                         const unsigned long long* __restrict__ n_dev)
 {
+    constexpr int kOsThreads = OsCfg<KeyT>::kThreads, kOsIPT = kOsTile / kOsThreads, kOsWaves = kOsThreads / 64;
     if (n_dev) n = (uint32_t)min((unsigned long long)n, *n_dev);   // device-side count: tiles past it exit at once
-    __shared__ unsigned long long s_mask[kSortWaves][256];
-    __shared__ uint32_t s_cnt[kSortWaves][256];
-    __shared__ KeyT s_keys[kSortTile];
-    __shared__ uint32_t s_vals[kSortTile];
+    __shared__ unsigned long long s_mask[kOsWaves][256];
+    __shared__ uint32_t s_cnt[kOsWaves][256];
+    __shared__ KeyT s_keys[kOsTile];
+    __shared__ uint32_t s_vals[kOsTile];
     __shared__ uint32_t s_start[256];
     __shared__ uint32_t s_gbase[256];
-    __shared__ uint32_t s_wsum[kSortWaves];
+    __shared__ uint32_t s_wsum[kOsWaves];
     __shared__ uint32_t s_tile;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     // ticket == nullptr: the whole grid is co-resident (host checked), so blockIdx order is as good as ticket order and
@@ -302,14 +314,14 @@ __global__ __launch_bounds__(kSortThreads) void k_onesweep(const KeyT* __restric
         __syncthreads();
         tile = s_tile;
     }
-    const uint32_t base = tile * (uint32_t)kSortTile;
+    const uint32_t base = tile * (uint32_t)kOsTile;
     if (base >= n) return;   // (uniform) only when the grid was sized for a capacity above the device-side count
-    const uint32_t valid = min((uint32_t)kSortTile, n - base);
-    KeyT key[kSortIPT];
-    uint32_t val[kSortIPT], dig[kSortIPT], rnk[kSortIPT];
+    const uint32_t valid = min((uint32_t)kOsTile, n - base);
+    KeyT key[kOsIPT];
+    uint32_t val[kOsIPT], dig[kOsIPT], rnk[kOsIPT];
 #pragma unroll
-    for (int r = 0; r < kSortIPT; r++) {
-        const uint32_t p = (uint32_t)(wave * (kSortIPT * 64) + r * 64 + lane);   // wave-major: see wave_rank
+    for (int r = 0; r < kOsIPT; r++) {
+        const uint32_t p = (uint32_t)(wave * (kOsIPT * 64) + r * 64 + lane);   // wave-major: see wave_rank
         if (p < valid) {
             key[r] = kin[base + p];
             val[r] = vin[base + p];
@@ -318,55 +330,61 @@ __global__ __launch_bounds__(kSortThreads) void k_onesweep(const KeyT* __restric
             key[r] = (KeyT)~(KeyT)0; val[r] = 0u; dig[r] = 255u;
         }
     }
-    wave_rank(s_mask[wave], s_cnt[wave], dig, rnk, lane);
+    wave_rank<kOsIPT>(s_mask[wave], s_cnt[wave], dig, rnk, lane);
     __syncthreads();
+    // threads 0..255 = digits (the upper half of the block only takes part in the barriers of the scans)
+    const bool is_digit = tid < 256;
     uint32_t mine = 0;   // this tile's count of digit `tid` (padding counted in digit 255; removed below)
+    if (is_digit) {
 #pragma unroll
-    for (int w = 0; w < kSortWaves; w++) {
-        const uint32_t c = s_cnt[w][tid];
-        s_cnt[w][tid] = mine;
-        mine += c;
-    }
-    const uint32_t real = (tid == 255) ? mine - ((uint32_t)kSortTile - valid) : mine;   // real keys of this digit
-    uint32_t* my_status = status + (size_t)tile * 256 + tid;
-    __hip_atomic_store(my_status, kOsLocal | real, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // local exclusive start of each digit (block scan of `mine`) and digit base (block scan of the global histogram)
-    const uint32_t lstart = block_scan_excl_256(mine, s_wsum, tid);
-    const uint32_t dbase = block_scan_excl_256(ghist[tid], s_wsum, tid);
-    // decoupled look-back over earlier tiles
-    // (windows of 4 independent loads: the walk is a chain of L2 round trips, and the chain is what a block waits on)
-    uint32_t excl = 0;
-    for (int t = (int)tile - 1; t >= 0;) {
-        uint32_t v[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++)
-            v[q] = (t - q >= 0) ? __hip_atomic_load(status + (size_t)(t - q) * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kOsIncl;
-        bool done = false;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            if (done) break;
-            const uint32_t f = v[q] & ~kOsMask;
-            if (f == 0u) { done = true; break; }   // not published yet: re-poll from here
-            excl += v[q] & kOsMask;
-            t--;
-            if (f == kOsIncl) { t = -1; done = true; }
+        for (int w = 0; w < kOsWaves; w++) {
+            const uint32_t c = s_cnt[w][tid];
+            s_cnt[w][tid] = mine;
+            mine += c;
         }
-        if (t >= 0 && done) __builtin_amdgcn_s_sleep(1);
     }
-    __hip_atomic_store(my_status, kOsIncl | (excl + real), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_start[tid] = lstart;
-    s_gbase[tid] = dbase + excl - lstart;
+    const uint32_t real = (tid == 255) ? mine - ((uint32_t)kOsTile - valid) : mine;   // real keys of this digit
+    uint32_t* my_status = status + (size_t)tile * 256 + (tid & 255);
+    if (is_digit) __hip_atomic_store(my_status, kOsLocal | real, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // local exclusive start of each digit (block scan of `mine`) and digit base (block scan of the global histogram)
+    const uint32_t lstart = block_scan_excl<kOsWaves>(mine, s_wsum, tid);
+    const uint32_t dbase = block_scan_excl<kOsWaves>(is_digit ? ghist[tid] : 0u, s_wsum, tid);
+    if (is_digit) {
+        // decoupled look-back over earlier tiles
+        // (windows of 4 independent loads: the walk is a chain of L2 round trips, and the chain is what a block waits on)
+        uint32_t excl = 0;
+        for (int t = (int)tile - 1; t >= 0;) {
+            uint32_t v[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                v[q] = (t - q >= 0) ? __hip_atomic_load(status + (size_t)(t - q) * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kOsIncl;
+            bool done = false;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                if (done) break;
+                const uint32_t f = v[q] & ~kOsMask;
+                if (f == 0u) { done = true; break; }   // not published yet: re-poll from here
+                excl += v[q] & kOsMask;
+                t--;
+                if (f == kOsIncl) { t = -1; done = true; }
+            }
+            if (t >= 0 && done) __builtin_amdgcn_s_sleep(1);
+        }
+        __hip_atomic_store(my_status, kOsIncl | (excl + real), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_start[tid] = lstart;
+        s_gbase[tid] = dbase + excl - lstart;
+    }
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < kSortIPT; r++) {
+    for (int r = 0; r < kOsIPT; r++) {
         const uint32_t lp = s_start[dig[r]] + s_cnt[wave][dig[r]] + rnk[r];
         s_keys[lp] = key[r];
         s_vals[lp] = val[r];
     }
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < kSortIPT; r++) {
-        const uint32_t p = r * kSortThreads + tid;
+    for (int r = 0; r < kOsIPT; r++) {
+        const uint32_t p = r * kOsThreads + tid;
         if (p < valid) {
             const KeyT k = s_keys[p];
             const uint32_t d = ((uint32_t)k >> shift) & 0xffu;
@@ -379,7 +397,7 @@ __global__ __launch_bounds__(kSortThreads) void k_onesweep(const KeyT* __restric
 
 inline size_t onesweep_scratch_bytes(uint32_t n)
 {
-    const size_t nblocks = ((size_t)n + kSortTile - 1) / kSortTile;
+    const size_t nblocks = ((size_t)n + kOsTile - 1) / kOsTile;
     // ghist[4][256] + tickets[4] (padded) + status[4 passes][nblocks][256]
     return ((4 * 256 + 64 + 4 * (nblocks ? nblocks : 1) * 256) * sizeof(uint32_t) + 255) & ~(size_t)255;
 }
@@ -395,7 +413,7 @@ inline hipError_t onesweep_sort_pairs(KeyT* keys, uint32_t* vals, KeyT* keys_alt
     if (n == 0) return hipSuccess;
     const int passes = (end_bit - begin_bit + 7) / 8;
     if (passes < 1 || passes > 4) return hipErrorInvalidValue;
-    const uint32_t nblocks = (n + kSortTile - 1) / kSortTile;
+    const uint32_t nblocks = (n + kOsTile - 1) / kOsTile;
     uint32_t* ghist = static_cast<uint32_t*>(scratch);
     uint32_t* tickets = ghist + 4 * 256;
     uint32_t* status = tickets + 64;
@@ -416,7 +434,7 @@ inline hipError_t onesweep_sort_pairs(KeyT* keys, uint32_t* vals, KeyT* keys_alt
     KeyT *kin = keys, *kout = keys_alt;
     uint32_t *vin = vals, *vout = vals_alt;
     for (int p = 0; p < passes; p++) {
-        hipLaunchKernelGGL(k_onesweep<KeyT>, dim3(nblocks), dim3(kSortThreads), 0, stream, kin, vin, kout, vout, n, begin_bit + 8 * p,
+        hipLaunchKernelGGL(k_onesweep<KeyT>, dim3(nblocks), dim3(OsCfg<KeyT>::kThreads), 0, stream, kin, vin, kout, vout, n, begin_bit + 8 * p,
                            ghist + p * 256, status + (size_t)p * nblocks * 256, nblocks <= 512u ? (uint32_t*)nullptr : tickets + p, n_dev);
         KeyT* tk = kin; kin = kout; kout = tk;
         uint32_t* tv = vin; vin = vout; vout = tv;
@@ -428,8 +446,9 @@ inline hipError_t onesweep_sort_pairs(KeyT* keys, uint32_t* vals, KeyT* keys_alt
 inline size_t radix_scratch_bytes(uint32_t n)
 {
     const size_t nblocks = ((size_t)n + kSortTile - 1) / kSortTile;
+    const size_t osblocks = ((size_t)n + kOsTile - 1) / kOsTile;
     const size_t three_kernel = ((256 * (nblocks ? nblocks : 1) + 8 * 256) * sizeof(uint32_t) + 255) & ~(size_t)255;   // hist + totals
-    const size_t onesweep = ((4 * 256 + 64 + 4 * (nblocks ? nblocks : 1) * 256) * sizeof(uint32_t) + 255) & ~(size_t)255;
+    const size_t onesweep = ((4 * 256 + 64 + 4 * (osblocks ? osblocks : 1) * 256) * sizeof(uint32_t) + 255) & ~(size_t)255;
     return three_kernel > onesweep ? three_kernel : onesweep;
 }
 
