@@ -206,7 +206,11 @@ def train_step(params: GaussianParams, settings: GaussianRasterizationSettings, 
         loss = fused_photometric_loss(pkg["raw_image"], gt, lambda_dssim, clamp=True)
     else:
         loss = photometric_loss(pkg["image"], gt, lambda_dssim)
-    loss.backward()
+    # same as loss.backward(); the upstream "1" is kept on the device instead of being filled by a launch every step
+    one = getattr(params, "_grad_one", None)
+    if one is None or one.device != loss.device:
+        one = params._grad_one = torch.ones((), dtype=loss.dtype, device=loss.device)
+    loss.backward(gradient=one)
     params.optimizer.step()
     params.optimizer.zero_grad(set_to_none=True)
     pkg["loss"] = loss.detach()
