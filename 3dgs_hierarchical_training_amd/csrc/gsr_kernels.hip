@@ -235,7 +235,7 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess(CamParams cp, int N,
                                                             const float* __restrict__ colors,
                                                             Splat* __restrict__ splat, int32_t* __restrict__ radii,
                                                             uint32_t* __restrict__ dkey, uint32_t* __restrict__ gid,
-                                                            uint32_t* __restrict__ ntiles, uint32_t* __restrict__ zero_words,
+                                                            TileRec* __restrict__ tilerec, uint32_t* __restrict__ zero_words,
                                                             int zero_count)
 {
     constexpr int NC3 = 3 * (DEG + 1) * (DEG + 1);
@@ -303,13 +303,14 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess(CamParams cp, int N,
         op = 1.0f / (1.0f + expf(-op));
     }
     Splat s;
+    TileRec rec;
     preprocess_one(cam, mean, sc, rq, cov_pre ? cv : nullptr, op, shs ? &s_sh[tid * kShStride] : nullptr, 3, 1,
-                   colors ? colp : nullptr, s);
+                   colors ? colp : nullptr, s, &rec);
     splat[i] = s;
+    tilerec[i] = rec;   // compact emission record: k_tile_counts / k_emit never touch the 48 B splats
     radii[i] = s.radius;
     dkey[i] = s.tiles > 0 ? __float_as_uint(s.depth) : 0xffffffffu;
     gid[i] = (uint32_t)i;
-    ntiles[i] = s.tiles;   // compact copy for k_tile_counts (a 4 B gather from 4N bytes instead of from the 48 B records)
 }
 
 __global__ void k_mark_visible(int N, const float* __restrict__ means, const float* __restrict__ vm, uint8_t* __restrict__ present)
@@ -345,12 +346,12 @@ __device__ __forceinline__ uint32_t block_inclusive_scan_256(uint32_t v, uint32_
 }
 
 __global__ __launch_bounds__(kEmitThreads) void k_tile_counts(int N, const uint32_t* __restrict__ sorted_gid,
-                                                              const uint32_t* __restrict__ ntiles, uint32_t* __restrict__ block_sums)
+                                                              const TileRec* __restrict__ tilerec, uint32_t* __restrict__ block_sums)
 {
     __shared__ uint32_t s_wave[4];
     const int j = blockIdx.x * kEmitThreads + threadIdx.x;
     uint32_t t = 0;
-    if (j < N) t = ntiles[sorted_gid[j]];
+    if (j < N) t = tilerec_count(tilerec[sorted_gid[j]]);
     uint32_t total;
     block_inclusive_scan_256(t, s_wave, total);
     if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
@@ -395,80 +396,98 @@ __global__ __launch_bounds__(1024) void k_block_scan(uint32_t* __restrict__ bloc
 }
 
 // ------------------------------------------------------------------------------------------------
-// K4: emit (tile, gid) instances in depth order, dropping the instances the exact tile test rejects.
-// A block owns 256 depth-sorted Gaussians; it enumerates the candidate (Gaussian, tile) slots of their
-// bounding rects 256 at a time (lanes take consecutive slots and find their Gaussian by binary search in the
-// block's LDS scan), tests each, and compacts the survivors IN ORDER with a ballot/popcount block scan, so the
-// output stays (depth, id)-ordered and the stores of one chunk are consecutive addresses.  The block's output
-// base is the exclusive scan of Splat::tiles (the exact counts k_preprocess made with the same test).
+// K4: emit (tile, gid) instances in depth order.  A block owns 256 depth-sorted Gaussians; its output base is the
+// exclusive scan of the exact per-Gaussian tile counts.  The decisions of the exact tile test were recorded by
+// k_preprocess as a bit mask over the rect (TileRec), so every output slot is a hit: lanes take consecutive output
+// slots, find their Gaussian by binary search in the block's LDS scan and the tile by selecting the k-th set bit --
+// no second evaluation of the test, no compaction, no 48-byte splat gather, consecutive addresses stored.
+// Gaussians whose rect exceeds 32 tiles carry no mask: those are emitted one per wave with the test evaluated 64
+// candidates at a time and a ballot compaction (same order: row-major over the rect).
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int select_kth_bit(uint32_t m, uint32_t k)   // position of the k-th (0-based) set bit
+{
+    for (uint32_t i = 0; i < k; i++) m &= m - 1u;
+    return __ffs((int)m) - 1;
+}
+
 __global__ __launch_bounds__(kEmitThreads) void k_emit(int N, int W, int H, int tiles_x, int tiles_y,
                                                        const uint32_t* __restrict__ sorted_gid, const Splat* __restrict__ splat,
+                                                       const TileRec* __restrict__ tilerec,
                                                        const uint32_t* __restrict__ block_offsets, uint16_t* __restrict__ out_tile,
                                                        uint32_t* __restrict__ out_gid, uint32_t cap)
 {
     __shared__ uint32_t s_wave[4];
     __shared__ uint32_t s_incl[kEmitThreads];
     __shared__ uint32_t s_gid[kEmitThreads];
-    __shared__ int s_x0[kEmitThreads], s_y0[kEmitThreads], s_w[kEmitThreads];
-    __shared__ TileTest s_tt[kEmitThreads];
-    __shared__ uint32_t s_cnt[4];
+    __shared__ TileRec s_rec[kEmitThreads];
+    __shared__ uint32_t s_big[kEmitThreads];
+    __shared__ uint32_t s_nbig;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = blockIdx.x * kEmitThreads + tid;
-    uint32_t full = 0, g = 0;
-    int x0 = 0, y0 = 0, w = 1;
-    TileTest tt = make_tile_test(0.f, 0.f, 1.f, 0.f, 1.f, 0.f);
+    if (tid == 0) s_nbig = 0u;
+    uint32_t g = 0;
+    TileRec r;
+    r.mask = 0u; r.rect = 1u << 24;
     if (j < N) {
         g = sorted_gid[j];
-        const Splat s = splat[g];
-        if (s.tiles) {
-            int x1, y1;
-            tile_rect(s.px + 0.5f * (float)W, s.py + 0.5f * (float)H, s.radius, tiles_x, tiles_y, x0, y0, x1, y1);
-            w = x1 - x0;
-            full = (uint32_t)(w * (y1 - y0));
-            tt = make_tile_test(s.px, s.py, s.ca, s.cb, s.cc, s.op);
+        r = tilerec[g];
+    }
+    const uint32_t cnt = tilerec_count(r);
+    uint32_t total;
+    const uint32_t incl = block_inclusive_scan_256(cnt, s_wave, total);   // (has a barrier: s_nbig is visible)
+    s_incl[tid] = incl; s_gid[tid] = g; s_rec[tid] = r;
+    if ((r.rect & kTileRecBig) && cnt) s_big[atomicAdd(&s_nbig, 1u)] = (uint32_t)tid;   // order irrelevant: positions are absolute
+    __syncthreads();
+    const uint32_t base = block_offsets[blockIdx.x];
+    for (uint32_t q = tid; q < total; q += kEmitThreads) {
+        int lo = 0, hi = kEmitThreads - 1;   // first index with s_incl > q
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (s_incl[mid] > q) hi = mid; else lo = mid + 1;
+        }
+        const TileRec rr = s_rec[lo];
+        if (rr.rect & kTileRecBig) continue;    // emitted below
+        const uint32_t excl = lo ? s_incl[lo - 1] : 0u;
+        const int pos = select_kth_bit(rr.mask, q - excl);
+        const int ww = (int)((rr.rect >> 24) & 63u), rx0 = (int)(rr.rect & 0xfffu), ry0 = (int)((rr.rect >> 12) & 0xfffu);
+        const int ty = pos / ww, tx = pos - ty * ww;
+        const uint32_t o = base + q;
+        if (o < cap) {   // cap = R, or the speculative capacity of gsr_forward (then an overflow is re-run)
+            out_tile[o] = (uint16_t)((ry0 + ty) * tiles_x + rx0 + tx);
+            out_gid[o] = s_gid[lo];
         }
     }
-    uint32_t total;
-    const uint32_t incl = block_inclusive_scan_256(full, s_wave, total);
-    s_incl[tid] = incl; s_gid[tid] = g; s_x0[tid] = x0; s_y0[tid] = y0; s_w[tid] = w; s_tt[tid] = tt;
-    __syncthreads();
-    uint32_t run = block_offsets[blockIdx.x];
+    // large rects: one wave per Gaussian, the exact test on 64 candidate tiles at a time, survivors compacted in order
+    const uint32_t nbig = s_nbig;
     const unsigned long long lt = lanemask_lt();
-    for (uint32_t base = 0; base < total; base += kEmitThreads) {
-        const uint32_t q = base + tid;
-        bool ok = false;
-        uint32_t tile = 0, gg = 0;
-        if (q < total) {
-            int lo = 0, hi = kEmitThreads - 1;   // first index with s_incl > q
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                if (s_incl[mid] > q) hi = mid; else lo = mid + 1;
+    for (uint32_t bi = wave; bi < nbig; bi += kEmitThreads / 64) {
+        const int idx = (int)s_big[bi];
+        const uint32_t gg = s_gid[idx];
+        const Splat s = splat[gg];
+        int x0, y0, x1, y1;
+        tile_rect(s.px + 0.5f * (float)W, s.py + 0.5f * (float)H, s.radius, tiles_x, tiles_y, x0, y0, x1, y1);
+        const int ww = x1 - x0, full = ww * (y1 - y0);
+        const TileTest tt = make_tile_test(s.px, s.py, s.ca, s.cb, s.cc, s.op);
+        uint32_t run = base + (idx ? s_incl[idx - 1] : 0u);
+        for (int c0 = 0; c0 < full; c0 += 64) {
+            const int c = c0 + lane;
+            bool ok = false;
+            int gx = 0, gy = 0;
+            if (c < full) {
+                const int ty = c / ww, tx = c - ty * ww;
+                gx = x0 + tx; gy = y0 + ty;
+                ok = tile_accept(tt, gx, gy, W, H);
             }
-            const uint32_t excl = lo ? s_incl[lo - 1] : 0u;
-            const int k = (int)(q - excl);
-            const int ww = s_w[lo];
-            const int ty = k / ww, tx = k - ty * ww;
-            const int gx = s_x0[lo] + tx, gy = s_y0[lo] + ty;
-            ok = tile_accept(s_tt[lo], gx, gy, W, H);
-            tile = (uint32_t)(gy * tiles_x + gx);
-            gg = s_gid[lo];
-        }
-        const unsigned long long m = __ballot(ok);
-        if (lane == 0) s_cnt[wave] = (uint32_t)__popcll(m);
-        __syncthreads();
-        uint32_t pre = 0, chunk = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) { const uint32_t c = s_cnt[k]; pre += (k < wave) ? c : 0u; chunk += c; }
-        if (ok) {
-            const uint32_t pos = run + pre + (uint32_t)__popcll(m & lt);
-            if (pos < cap) {   // cap = R, or the speculative capacity of gsr_forward (then an overflow is re-run)
-                out_tile[pos] = (uint16_t)tile;
-                out_gid[pos] = gg;
+            const unsigned long long m = __ballot(ok);
+            if (ok) {
+                const uint32_t o = run + (uint32_t)__popcll(m & lt);
+                if (o < cap) {
+                    out_tile[o] = (uint16_t)(gy * tiles_x + gx);
+                    out_gid[o] = gg;
+                }
             }
+            run += (uint32_t)__popcll(m);
         }
-        run += chunk;
-        __syncthreads();
     }
 }
 
@@ -1418,7 +1437,7 @@ static FwdScratch fwd_scratch_layout(int32_t N)
     s.gid = o; o += align256(n * 4);
     s.dkey_alt = o; o += align256(n * 4);
     s.gid_alt = o; o += align256(n * 4);
-    s.ntiles = o; o += align256(n * 4);
+    s.ntiles = o; o += align256(n * sizeof(TileRec));
     s.block_sums = o; o += align256(((n + kEmitThreads - 1) / kEmitThreads) * 4);
     s.total = o; o += 256;
     s.sort = o; o += radix_scratch_bytes((uint32_t)n);
@@ -1469,6 +1488,7 @@ static int check_common(int32_t N, int32_t M, int32_t D, int32_t W, int32_t H)
     if (M < 0 || M > 16) return fail(GSR_ERR_ARG, "at most 16 SH coefficients per Gaussian%s");
     const long long T = (long long)((W + kTile - 1) / kTile) * ((H + kTile - 1) / kTile);
     if (T > 65535) return fail(GSR_ERR_RANGE, "image has more than 65535 tiles%s");
+    if (W > 4095 * kTile || H > 4095 * kTile) return fail(GSR_ERR_RANGE, "image side longer than 65520 pixels%s");
     return GSR_OK;
 }
 
@@ -1604,7 +1624,8 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
         uint32_t* v1 = (tile_passes & 1) ? list : gid_alt2;
         {
             ProfScope ps(P_EMIT, st);
-            hipLaunchKernelGGL(k_emit, dim3(nb), dim3(kEmitThreads), 0, st, N, W, H, tiles_x, tiles_y, sorted_gid, splat, block_sums, tkey, v0,
+            hipLaunchKernelGGL(k_emit, dim3(nb), dim3(kEmitThreads), 0, st, N, W, H, tiles_x, tiles_y, sorted_gid, splat,
+                               reinterpret_cast<const TileRec*>(fs + L.ntiles), block_sums, tkey, v0,
                                (uint32_t)capacity);
         }
         int in_alt = 0;
@@ -1681,7 +1702,7 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
     uint32_t* gid = reinterpret_cast<uint32_t*>(fs + L.gid);
     uint32_t* dkey_alt = reinterpret_cast<uint32_t*>(fs + L.dkey_alt);
     uint32_t* gid_alt = reinterpret_cast<uint32_t*>(fs + L.gid_alt);
-    uint32_t* ntiles = reinterpret_cast<uint32_t*>(fs + L.ntiles);
+    TileRec* ntiles = reinterpret_cast<TileRec*>(fs + L.ntiles);
     uint32_t* block_sums = reinterpret_cast<uint32_t*>(fs + L.block_sums);
     unsigned long long* total = reinterpret_cast<unsigned long long*>(fs + L.total);
     const bool depth_onesweep = g_sort_algo != 0;

@@ -52,6 +52,28 @@ struct alignas(16) Splat {
 };
 static_assert(sizeof(Splat) == 48, "Splat must be 48 bytes");
 
+GSR_HD int gsr_popc(uint32_t v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __popc(v);
+#else
+    return __builtin_popcount(v);
+#endif
+}
+
+// What the emission (k_emit) needs of one Gaussian, 8 bytes: the tile rect and -- when the rect has at most 32 tiles
+// -- the outcome of the exact tile test as one bit per tile (row-major inside the rect), so that the emission copies
+// the decisions k_preprocess already made instead of evaluating the test a second time.
+struct alignas(8) TileRec {
+    uint32_t mask;   // small rect: bit (ty - y0) * w + (tx - x0) set = tile accepted (count = popcount);
+                     // big rect (more than 32 tiles): the NUMBER of accepted tiles, the test is re-run at emission
+    uint32_t rect;   // x0 [0:12) | y0 [12:24) | w [24:30) | big [31]
+};
+static_assert(sizeof(TileRec) == 8, "TileRec must be 8 bytes");
+constexpr uint32_t kTileRecBig = 0x80000000u;
+constexpr int kTileRecMaskTiles = 32;
+GSR_HD uint32_t tilerec_count(const TileRec& r) { return (r.rect & kTileRecBig) ? r.mask : (uint32_t)gsr_popc(r.mask); }
+
 struct Camera {
     float vm[16], pm[16];
     float cam[3];
@@ -240,12 +262,21 @@ GSR_HD bool tile_accept(const TileTest& t, int tx, int ty, int W, int H)
 }
 
 GSR_HD uint32_t count_accepted_tiles(float px, float py, float ca, float cb, float cc, float op, int x0, int y0, int x1, int y1,
-                                     int W, int H)
+                                     int W, int H, uint32_t* mask_out = nullptr)
 {
     const TileTest t = make_tile_test(px, py, ca, cb, cc, op);
-    uint32_t n = 0;
-    for (int ty = y0; ty < y1; ty++)
-        for (int tx = x0; tx < x1; tx++) n += tile_accept(t, tx, ty, W, H) ? 1u : 0u;
+    uint32_t n = 0, mask = 0u;   // an OR-reduction over an affine bit index (NOT a running `bit <<= 1`): the loop stays a plain
+                                 // reduction loop and the compiler evaluates two tiles per iteration with packed math
+    const int w = x1 - x0;
+    for (int ty = y0; ty < y1; ty++) {
+        const int row = (ty - y0) * w - x0;
+        for (int tx = x0; tx < x1; tx++) {
+            const bool ok = tile_accept(t, tx, ty, W, H);
+            n += ok ? 1u : 0u;
+            mask |= (ok ? 1u : 0u) << ((row + tx) & 31);   // only meaningful for rects of at most kTileRecMaskTiles tiles
+        }
+    }
+    if (mask_out) *mask_out = mask;
     return n;
 }
 
@@ -285,9 +316,10 @@ GSR_HD RT sh_channel(int deg, const float* sh, int stride, RT x, RT y, RT z)
 // sh[k*sh_kstride + ch*sh_cstride] (lets the caller hand either the global [M][3] row or an LDS copy).
 GSR_HD void preprocess_one(const Camera& c, const float mean[3], const float* scale, const float* rot,
                            const float* cov_pre, float opacity, const float* sh, int sh_kstride, int sh_cstride,
-                           const float* color_pre, Splat& out)
+                           const float* color_pre, Splat& out, TileRec* rec = nullptr)
 {
     typedef double RT;   // see the note above quat_to_rot
+    if (rec) { rec->mask = 0u; rec->rect = 1u << 24; }
     out.px = 0.f; out.py = 0.f; out.ca = 0.f; out.cb = 0.f; out.cc = 0.f; out.op = 0.f; out.depth = 0.f;
     out.r = 0.f; out.g = 0.f; out.b = 0.f; out.radius = 0; out.tiles = 0;
     const float zk = depth_key(c.vm, mean[0], mean[1], mean[2]);
@@ -343,7 +375,13 @@ GSR_HD void preprocess_one(const Camera& c, const float mean[3], const float* sc
     out.op = opacity;
     out.r = col[0]; out.g = col[1]; out.b = col[2];
     out.radius = radius;
-    out.tiles = count_accepted_tiles(out.px, out.py, out.ca, out.cb, out.cc, out.op, x0, y0, x1, y1, c.W, c.H);
+    uint32_t mask = 0u;
+    out.tiles = count_accepted_tiles(out.px, out.py, out.ca, out.cb, out.cc, out.op, x0, y0, x1, y1, c.W, c.H, rec ? &mask : nullptr);
+    if (rec) {   // (tile coordinates fit 12 bits: check_common limits the image to 65535 tiles)
+        const bool big = nt > kTileRecMaskTiles;
+        rec->mask = big ? out.tiles : mask;
+        rec->rect = (uint32_t)x0 | ((uint32_t)y0 << 12) | ((uint32_t)((x1 - x0) & 63) << 24) | (big ? kTileRecBig : 0u);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

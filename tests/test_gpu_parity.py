@@ -202,6 +202,27 @@ def test_scale_modifier():
     parity.check_grads(out["grads"], ref, "scale_modifier")
 
 
+@pytest.mark.parametrize("scale", [4.0, 12.0])
+def test_large_splats_take_the_per_wave_emission_path(scale):
+    """Rects of more than 32 tiles carry no decision mask (TileRec): k_emit re-runs the exact tile test for them, one
+    wave per Gaussian.  scale_modifier 4 mixes both paths in one block, 12 makes nearly every visible splat large."""
+    import hip_runner
+    N, W, H = 3000, 320, 240
+    sc = parity.syn.make_scene(N, W, H, sh_degree=3, seed=41, posed=True)
+    sc["scale_modifier"] = scale
+    kw = parity.scene_kwargs(sc, "sh")
+    o = binding.OracleRender(**kw)
+    o.forward()
+    gc, gd, ga = parity.upstream_grads(H, W, seed=4)
+    keep = o.px_ambig == 0
+    gc *= keep[None]; gd *= keep; ga *= keep
+    ref = o.backward(gc, gd, ga)
+    out = hip_runner.run_hip(kw, (gc, gd, ga))
+    assert (out["fwd"][1] * 2 > 6 * 16).mean() > (0.05 if scale < 10 else 0.5)     # radii: rects beyond 6 tiles across exist
+    parity.check_forward(out["fwd"], o, f"large splats x{scale}", ambig_max_frac=0.2)
+    parity.check_grads(out["grads"], ref, f"large splats x{scale}")
+
+
 def test_mark_visible():
     import hip_runner
     from diff_gaussian_rasterization import GaussianRasterizer
