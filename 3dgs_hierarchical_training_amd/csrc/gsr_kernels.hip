@@ -996,6 +996,7 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(int W, int H, int tiles_x, i
     if (lane == 0) s_max[wave] = nmax;
     __syncthreads();
     const int n = (int)max(s_max[0], s_max[1]);
+    const int nw = (int)s_max[wave];
     const int nb = (n + NT - 1) / NT;
 
     float4 ra = {0, 0, 0, 0}, rb = ra, rc = ra;
@@ -1004,12 +1005,25 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(int W, int H, int tiles_x, i
     // (A' = -log2(e)/2 A, B' = -log2(e) B, C' = -log2(e)/2 C), and log2(G) is evaluated with the same fma nesting, so
     // forward and backward agree on every skip decision bit for bit
     constexpr float kL2E = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
-    if (tid < n) {
-        rg_id = list[rg.x + tid];
+    // Per staged instance the staging thread also decides, once, which of the two waves (16x8 pixel halves of the tile)
+    // the Gaussian can reach at all: the exact box test of the tile culling (gsr_math.h box_accept: minimum of the conic
+    // form over the half's pixel box against 2 ln(255 o) + slack) on each half.  A wave skips an instance whose bit is
+    // clear for the cost of one LDS read instead of evaluating 128 alphas to find that none passes (36 % of the
+    // (wave, instance) iterations were such misses).  rc.w (Splat::tiles, unused by the blend) carries the two bits.
+    const float hbx0 = (float)(tx * kTile) - 0.5f * (float)W, hbx1 = fminf(hbx0 + (float)(kTile - 1), (float)(W - 1) - 0.5f * (float)W);
+    const float hby0 = (float)(ty * kTile) - cyf, hbyL = (float)(H - 1) - cyf;
+    auto stage = [&](int idx) {
+        rg_id = list[rg.x + idx];
         const float4* sp = reinterpret_cast<const float4*>(splat + rg_id);
         ra = sp[0]; rb = sp[1]; rc = sp[2];
+        const TileTest tt = make_tile_test(ra.x, ra.y, ra.z, ra.w, rb.x, rb.y);
+        uint32_t fl = 0u;
+        if (hby0 <= hbyL) fl |= box_accept(tt, hbx0, hby0, hbx1, fminf(hby0 + 7.f, hbyL)) ? 1u : 0u;
+        if (hby0 + 8.f <= hbyL) fl |= box_accept(tt, hbx0, hby0 + 8.f, hbx1, fminf(hby0 + 15.f, hbyL)) ? 2u : 0u;
+        rc.w = __uint_as_float(fl);
         ra.z *= -0.5f * kL2E; ra.w *= -kL2E; rb.x *= -0.5f * kL2E;
-    }
+    };
+    if (tid < n) stage(tid);
 #pragma unroll
     for (int w = 0; w < NW; w++)
 #pragma unroll
@@ -1020,14 +1034,20 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(int W, int H, int tiles_x, i
         s_a[buf][tid] = ra; s_b[buf][tid] = rb; s_c[buf][tid] = rc; s_gid[buf][tid] = rg_id;
         __syncthreads();
         const int nxt = (b + 1) * NT + tid;
-        if (nxt < n) {
-            rg_id = list[rg.x + nxt];
-            const float4* sp = reinterpret_cast<const float4*>(splat + rg_id);
-            ra = sp[0]; rb = sp[1]; rc = sp[2];
-            ra.z *= -0.5f * kL2E; ra.w *= -kL2E; rb.x *= -0.5f * kL2E;
-        }
+        if (nxt < n) stage(nxt);
         const int cnt = min(NT, n - b * NT);
-        for (int j = 0; j < cnt; j++) {
+        // a wave only walks as far as ITS pixels' last contributor (the tile-wide n bounds the staging and the barriers)
+        const int cntw = min(cnt, nw - b * NT);
+        // the reach bits of the batch as two wave-uniform 64-bit masks: the loop below visits set bits only, so an
+        // instance this half cannot reach costs nothing at all
+        const uint32_t wbit = 1u << wave;
+        const bool r0 = lane < cntw && (__float_as_uint(s_c[buf][lane].w) & wbit);
+        const bool r1 = lane + 64 < cntw && (__float_as_uint(s_c[buf][lane + 64].w) & wbit);
+        const unsigned long long reach[2] = {__ballot(r0), __ballot(r1)};
+#pragma unroll 1
+        for (int half = 0; half < 2; half++)
+        for (unsigned long long rm = reach[half]; rm != 0ull; rm &= rm - 1ull) {
+            const int j = half * 64 + (int)__builtin_ctzll(rm);
             const float4 A = s_a[buf][j], B = s_b[buf][j], C = s_c[buf][j];   // (manual LDS prefetch measured slower)
             const uint32_t idx = (uint32_t)(b * NT + j + 1);
             const float ca = A.z, cb = A.w, cc = B.x, op = B.y, zd = B.z, cr = B.w, cg = C.x, cbl = C.y;   // ca/cb/cc: A', B', C'
