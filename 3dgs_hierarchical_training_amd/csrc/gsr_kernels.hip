@@ -1238,13 +1238,18 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, in
     if (i < N) {
         Camera cam = load_camera(cp);
         cam.D = DEG;
-        const Splat s = splat[i];
         float dmean[3] = {0.f, 0.f, 0.f}, m2d[2] = {0.f, 0.f}, dop = 0.f;
         float dsc[3] = {0.f, 0.f, 0.f}, drq[4] = {0.f, 0.f, 0.f, 0.f}, dcv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         float grgb[3] = {0.f, 0.f, 0.f};
-        if (s.radius > 0) {
-            const float4* gp = reinterpret_cast<const float4*>(ggrad + (size_t)i * kGG);
-            const float4 g0 = gp[0], g1 = gp[1], g2 = gp[2];   // gx gy gA gB | gC gop gr gg | gb gz - -
+        // A Gaussian that was culled or fully occluded received nothing from the blend backward: its ggrad row is still
+        // the zeros of the memset and every gradient below would come out zero -- so "row is non-zero" replaces the
+        // radius > 0 test, and the 48-byte splat record is not read by this kernel at all (the activated opacity the
+        // sigmoid chain needs is recomputed from the logit exactly as the forward computed it).
+        const float4* gp = reinterpret_cast<const float4*>(ggrad + (size_t)i * kGG);
+        const float4 g0 = gp[0], g1 = gp[1], g2 = gp[2];   // gx gy gA gB | gC gop gr gg | gb gz - -
+        const bool live = g0.x != 0.f || g0.y != 0.f || g0.z != 0.f || g0.w != 0.f || g1.x != 0.f || g1.y != 0.f || g1.z != 0.f ||
+                          g1.w != 0.f || g2.x != 0.f || g2.y != 0.f;
+        if (live) {
             const float mraw[3] = {means[3 * (size_t)i], means[3 * (size_t)i + 1], means[3 * (size_t)i + 2]};
             float mean[3] = {mraw[0], mraw[1], mraw[2]};
             apply_points_transform(cp.xf, mean);
@@ -1273,7 +1278,7 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, in
             dop = g1.y;
             grgb[0] = g1.z; grgb[1] = g1.w; grgb[2] = g2.x;
             if (RAW) {   // chain through exp / normalize / sigmoid
-                const float sg = s.op;   // the activated opacity stored by the forward
+                const float sg = 1.0f / (1.0f + expf(-opac_raw[i]));   // the activated opacity, as k_preprocess computes it
                 dop *= sg * (1.f - sg);
 #pragma unroll
                 for (int k = 0; k < 3; k++) o.scale[k] *= sc[k];
