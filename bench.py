@@ -203,7 +203,7 @@ def main():
                        "unit": "GB/s", "frac": ab / (bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": ab,
                        "avg_launch_ms": bwd_ms, "note": "VALU-bound (packed f32 math + cross-lane reduction), see DESIGN.md"})
     if preb_ms:
-        ab = 1524.0 * N   # params 236 + ggrad 48 + splat 48 + moments 472 in; params + moments 708 + means2D grad 12 out
+        ab = 1476.0 * N   # params 236 + ggrad 48 + moments 472 in; params + moments 708 + means2D grad 12 out
         others.append({"kernel": "k_preprocess_bwd (per-Gaussian backward + in-kernel Adam)", "bound": "hbm",
                        "achieved": ab / (preb_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": ab / (preb_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": ab,

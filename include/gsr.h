@@ -91,7 +91,7 @@ typedef struct GsrForwardOut {
  * gsr_backward applies the Adam step of /root/reference/scene/gaussian_model_ht.py:275-289 (torch.optim.Adam, no
  * amsgrad / weight decay; ht3dgs_trainer.py:159-166 calls step() right after backward()) to the six parameter tensors
  * IN PLACE inside the per-Gaussian backward kernel, instead of writing their gradients: the gradient never makes
- * the round trip through HBM (2228 -> ~1530 bytes per Gaussian for backward + optimizer).  The parameter pointers of
+ * the round trip through HBM (2180 -> ~1480 bytes per Gaussian for backward + optimizer).  The parameter pointers of
  * GsrBackwardArgs (means3D, shs, shs_rest, opacities, scales, rotations) are then written through; d_means3D,
  * d_opacities, d_shs, d_shs_rest, d_scales, d_rotations are ignored (may be NULL); d_means2D is still produced
  * (densification statistics, gaussian_model_ht.py:718-721).  Group order of lr / exp_avg / exp_avg_sq:
