@@ -27,12 +27,18 @@ __device__ __constant__ float kGauss[11] = {0.0010283801f, 0.0075987581f, 0.0360
 
 __device__ __forceinline__ float clamp01(float v) { return fminf(fmaxf(v, 0.f), 1.f); }
 
+// Two moments per register pair: (x, y) and (x^2, y^2) ride through the separable window as float2, so a tap is one
+// 8-byte LDS read and v_pk_fma_f32 instead of two reads and two fmas (per-component fma: same rounding as scalar code).
+typedef float lf2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ lf2 lfma2(float w, lf2 v, lf2 acc) { return __builtin_elementwise_fma(lf2{w, w}, v, acc); }
+
 // grid (ceil(W/16), ceil(H/16), C); block 16x16.  maps: [3][C][H][W] = dS/dmu_x, dS/dE[x^2], dS/dE[xy]
 __global__ __launch_bounds__(256) void k_loss_fwd(const float* __restrict__ raw, const float* __restrict__ gt, int H, int W,
                                                   int do_clamp, float* __restrict__ maps, float* __restrict__ partial)
 {
-    __shared__ float sx[kLIn][kLIn + 1], sy[kLIn][kLIn + 1];
-    __shared__ float sh[5][kLIn][kLB + 1];
+    __shared__ lf2 sxy[kLIn][kLIn + 1];                       // (x, y) interleaved
+    __shared__ lf2 shA[kLIn][kLB + 1], shB[kLIn][kLB + 1];     // row-filtered (x, y) and (x^2, y^2)
+    __shared__ float shC[kLIn][kLB + 1];                       // row-filtered x y
     __shared__ float s_red[2][4];
     const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * kLB + tx;
     const int c = blockIdx.z;
@@ -49,29 +55,31 @@ __global__ __launch_bounds__(256) void k_loss_fwd(const float* __restrict__ raw,
             if (do_clamp) xv = clamp01(xv);
             yv = y[(size_t)gy * W + gx];
         }
-        sx[iy][ix] = xv; sy[iy][ix] = yv;
+        sxy[iy][ix] = lf2{xv, yv};
     }
     __syncthreads();
     for (int i = tid; i < kLIn * kLB; i += 256) {
         const int r = i / kLB, cc = i - r * kLB;
-        float h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f, h4 = 0.f;
+        lf2 hA = {0.f, 0.f}, hB = {0.f, 0.f};
+        float hC = 0.f;
 #pragma unroll
         for (int k = 0; k < 11; k++) {
-            const float w = kGauss[k], xv = sx[r][cc + k], yv = sy[r][cc + k];
-            h0 = fmaf(w, xv, h0); h1 = fmaf(w, yv, h1);
-            h2 = fmaf(w, xv * xv, h2); h3 = fmaf(w, yv * yv, h3); h4 = fmaf(w, xv * yv, h4);
+            const float w = kGauss[k];
+            const lf2 v = sxy[r][cc + k];
+            hA = lfma2(w, v, hA); hB = lfma2(w, v * v, hB); hC = fmaf(w, v.x * v.y, hC);
         }
-        sh[0][r][cc] = h0; sh[1][r][cc] = h1; sh[2][r][cc] = h2; sh[3][r][cc] = h3; sh[4][r][cc] = h4;
+        shA[r][cc] = hA; shB[r][cc] = hB; shC[r][cc] = hC;
     }
     __syncthreads();
-    float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+    lf2 mA = {0.f, 0.f}, mB = {0.f, 0.f};
+    float e12 = 0.f;
 #pragma unroll
     for (int k = 0; k < 11; k++) {
         const float w = kGauss[k];
-        mu1 = fmaf(w, sh[0][ty + k][tx], mu1); mu2 = fmaf(w, sh[1][ty + k][tx], mu2);
-        e11 = fmaf(w, sh[2][ty + k][tx], e11); e22 = fmaf(w, sh[3][ty + k][tx], e22);
-        e12 = fmaf(w, sh[4][ty + k][tx], e12);
+        mA = lfma2(w, shA[ty + k][tx], mA); mB = lfma2(w, shB[ty + k][tx], mB);
+        e12 = fmaf(w, shC[ty + k][tx], e12);
     }
+    const float mu1 = mA.x, mu2 = mA.y, e11 = mB.x, e22 = mB.y;
     const int gx = blockIdx.x * kLB + tx, gy = blockIdx.y * kLB + ty;
     float ssim = 0.f, l1 = 0.f;
     if (gx < W && gy < H) {
@@ -86,7 +94,8 @@ __global__ __launch_bounds__(256) void k_loss_fwd(const float* __restrict__ raw,
         const float dS_de12 = 2.f * A * iCD;
         const size_t CP = (size_t)gridDim.z * P, pid = (size_t)c * P + (size_t)gy * W + gx;
         maps[pid] = dS_dmu; maps[CP + pid] = dS_de11; maps[2 * CP + pid] = dS_de12;
-        l1 = fabsf(sx[ty + kHalo][tx + kHalo] - sy[ty + kHalo][tx + kHalo]);
+        const lf2 ctr = sxy[ty + kHalo][tx + kHalo];
+        l1 = fabsf(ctr.x - ctr.y);
     }
     // block reduction (wave shuffles, then 4 partials)
 #pragma unroll
@@ -124,8 +133,10 @@ __global__ __launch_bounds__(256) void k_loss_bwd(const float* __restrict__ raw,
                                                   int do_clamp, const float* __restrict__ maps, const float* __restrict__ gscale,
                                                   float inv_count, float lambda, float* __restrict__ d_raw)
 {
-    __shared__ float sm[3][kLIn][kLIn + 1];
-    __shared__ float sh[3][kLIn][kLB + 1];
+    __shared__ lf2 smA[kLIn][kLIn + 1];     // (dS/dmu_x, dS/dE[x^2])
+    __shared__ float smC[kLIn][kLIn + 1];   // dS/dE[xy]
+    __shared__ lf2 shA[kLIn][kLB + 1];
+    __shared__ float shC[kLIn][kLB + 1];
     const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * kLB + tx;
     const int c = blockIdx.z;
     const size_t P = (size_t)H * W, CP = (size_t)gridDim.z * P;
@@ -138,28 +149,31 @@ __global__ __launch_bounds__(256) void k_loss_bwd(const float* __restrict__ raw,
             const size_t pid = (size_t)c * P + (size_t)gy * W + gx;
             a = maps[pid]; b = maps[CP + pid]; d = maps[2 * CP + pid];
         }
-        sm[0][iy][ix] = a; sm[1][iy][ix] = b; sm[2][iy][ix] = d;
+        smA[iy][ix] = lf2{a, b}; smC[iy][ix] = d;
     }
     __syncthreads();
     for (int i = tid; i < kLIn * kLB; i += 256) {
         const int r = i / kLB, cc = i - r * kLB;
-        float h0 = 0.f, h1 = 0.f, h2 = 0.f;
+        lf2 hA = {0.f, 0.f};
+        float hC = 0.f;
 #pragma unroll
         for (int k = 0; k < 11; k++) {
             const float w = kGauss[k];
-            h0 = fmaf(w, sm[0][r][cc + k], h0); h1 = fmaf(w, sm[1][r][cc + k], h1); h2 = fmaf(w, sm[2][r][cc + k], h2);
+            hA = lfma2(w, smA[r][cc + k], hA); hC = fmaf(w, smC[r][cc + k], hC);
         }
-        sh[0][r][cc] = h0; sh[1][r][cc] = h1; sh[2][r][cc] = h2;
+        shA[r][cc] = hA; shC[r][cc] = hC;
     }
     __syncthreads();
     const int gx = blockIdx.x * kLB + tx, gy = blockIdx.y * kLB + ty;
     if (gx >= W || gy >= H) return;
-    float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+    lf2 cA = {0.f, 0.f};
+    float c2 = 0.f;
 #pragma unroll
     for (int k = 0; k < 11; k++) {
         const float w = kGauss[k];
-        c0 = fmaf(w, sh[0][ty + k][tx], c0); c1 = fmaf(w, sh[1][ty + k][tx], c1); c2 = fmaf(w, sh[2][ty + k][tx], c2);
+        cA = lfma2(w, shA[ty + k][tx], cA); c2 = fmaf(w, shC[ty + k][tx], c2);
     }
+    const float c0 = cA.x, c1 = cA.y;
     const size_t pid = (size_t)c * P + (size_t)gy * W + gx;
     const float r = raw[pid], yv = gt[pid];
     const float xv = do_clamp ? clamp01(r) : r;
