@@ -220,6 +220,40 @@ __device__ __forceinline__ void stage_out_vec(const float* s_sh, int col0, float
 }
 __device__ __forceinline__ bool vec_ok(const void* p, int nfloats) { return (((uintptr_t)p & 15) == 0) && ((nfloats & 3) == 0); }
 
+// stage_in_vec split in two: the 16-byte loads are issued into registers first, the per-Gaussian arithmetic that does
+// not need the rows runs while they are in flight, and only then are they scattered into the padded LDS tile.
+template <int ROW>
+constexpr int stage_regs() { return (ROW * kPreThreads / 4 + kPreThreads - 1) / kPreThreads; }
+template <int ROW, int KN>
+__device__ __forceinline__ void stage_load(float4 (&r)[KN], const float* __restrict__ src, int nG, int tid)
+{
+    static_assert(KN >= stage_regs<ROW>(), "register file too small for the rows");
+    const float4* s4 = reinterpret_cast<const float4*>(src);
+#pragma unroll
+    for (int q = 0; q < stage_regs<ROW>(); q++) {
+        const int v = tid + q * kPreThreads;
+        r[q] = v < (nG * ROW) / 4 ? s4[v] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+template <int ROW, int KN>
+__device__ __forceinline__ void stage_store(const float4 (&r)[KN], float* s_sh, int col0, int nG, int tid)
+{
+#pragma unroll
+    for (int q = 0; q < stage_regs<ROW>(); q++) {
+        const int v = tid + q * kPreThreads;
+        if (v < (nG * ROW) / 4) {
+            const int f = 4 * v;
+            int g = f / ROW, e = f - g * ROW;
+            const float xs[4] = {r[q].x, r[q].y, r[q].z, r[q].w};
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                s_sh[g * kShStride + col0 + e] = xs[c];
+                if (++e == ROW) { e = 0; g++; }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // K1: per-Gaussian projection.  SH rows are staged through LDS with coalesced loads.
 // ------------------------------------------------------------------------------------------------
@@ -245,17 +279,24 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess(CamParams cp, int N,
     const int i = base + tid;
     if (blockIdx.x == 0)   // rides along: clear the head of the depth sort's scratch (saves a fill launch)
         for (int q = tid; q < zero_count; q += kPreThreads) zero_words[q] = 0u;
+    // ---- phase 0: SH rows.  Dense, aligned rows (the normal case) are only LOADED here -- into registers; the geometry
+    // below does not need them, so the 180-192 bytes per Gaussian stream in underneath ~1500 instructions of float64
+    // projection instead of in front of them (K1 was the sum of its HBM time and its VALU time: 0.073 ms without
+    // SH rows, 0.125 ms with).  Odd layouts (partial last block, stored degree above the active one) stage directly.
+    constexpr int NR = NC3 > 3 ? NC3 - 3 : 1;
+    float4 r_dc[1];                        // 128 x 3 floats = 96 float4
+    float4 r_rows[stage_regs<NC3>()];      // the rest rows OR the full rows (one register file for either layout)
+    bool pend_dc = false, pend_rest = false, pend_full = false;
+    const int nG = min(kPreThreads, N - base);
     if (shs) {
-        const int nG = min(kPreThreads, N - base);
         if (shs_rest) {   // split storage: dc [N,1,3] + rest [N,M-1,3]; two straight, divergence-free streams
             const size_t row = (size_t)(cp.M - 1) * 3;
             const float* dc0 = shs + (size_t)base * 3;
-            if (vec_ok(dc0, nG * 3)) stage_in_vec<3>(s_sh, 0, dc0, nG, tid);
+            if (vec_ok(dc0, nG * 3)) { stage_load<3>(r_dc, dc0, nG, tid); pend_dc = true; }
             else for (int f = tid; f < nG * 3; f += kPreThreads) s_sh[(f / 3) * kShStride + (f % 3)] = dc0[f];
             if (NC3 > 3) {
-                constexpr int NR = NC3 > 3 ? NC3 - 3 : 1;
                 const float* r0 = shs_rest + (size_t)base * row;
-                if (row == NR && vec_ok(r0, nG * NR)) stage_in_vec<NR>(s_sh, 3, r0, nG, tid);
+                if (row == NR && vec_ok(r0, nG * NR)) { stage_load<NR>(r_rows, r0, nG, tid); pend_rest = true; }
                 else for (int f = tid; f < nG * NR; f += kPreThreads) {
                     const int g = f / NR, e = f - g * NR;
                     s_sh[g * kShStride + 3 + e] = shs_rest[(size_t)(base + g) * row + e];
@@ -264,48 +305,63 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess(CamParams cp, int N,
         } else {
             const size_t row = (size_t)cp.M * 3;
             const float* r0 = shs + (size_t)base * row;
-            if (row == NC3 && vec_ok(r0, nG * NC3)) stage_in_vec<NC3>(s_sh, 0, r0, nG, tid);
+            if (row == NC3 && vec_ok(r0, nG * NC3)) { stage_load<NC3>(r_rows, r0, nG, tid); pend_full = true; }
             else for (int f = tid; f < nG * NC3; f += kPreThreads) {
                 const int g = f / NC3, e = f - g * NC3;
                 s_sh[g * kShStride + e] = shs[(size_t)(base + g) * row + e];
             }
         }
-        __syncthreads();
     }
-    if (i >= N) return;
+    // ---- phase 1: geometry (+ precomputed colour), no SH
+    const bool act = i < N;
     Camera cam = load_camera(cp);
     cam.D = DEG;
-    float mean[3] = {means[3 * (size_t)i], means[3 * (size_t)i + 1], means[3 * (size_t)i + 2]};
-    apply_points_transform(cp.xf, mean);
-    float sc[3] = {0, 0, 0}, rq[4] = {1, 0, 0, 0}, cv[6], colp[3];
-    if (cov_pre) {
-#pragma unroll
-        for (int k = 0; k < 6; k++) cv[k] = cov_pre[6 * (size_t)i + k];
-    } else {
-#pragma unroll
-        for (int k = 0; k < 3; k++) sc[k] = scales[3 * (size_t)i + k];
-#pragma unroll
-        for (int k = 0; k < 4; k++) rq[k] = rots[4 * (size_t)i + k];
-    }
-    if (colors) {
-#pragma unroll
-        for (int k = 0; k < 3; k++) colp[k] = colors[3 * (size_t)i + k];
-    }
-    float op = opac[i];
-    if (RAW) {
-        if (!cov_pre) {
-#pragma unroll
-            for (int k = 0; k < 3; k++) sc[k] = expf(sc[k]);
-            const float inv = 1.0f / fmaxf(sqrtf(rq[0] * rq[0] + rq[1] * rq[1] + rq[2] * rq[2] + rq[3] * rq[3]), 1e-12f);
-#pragma unroll
-            for (int k = 0; k < 4; k++) rq[k] *= inv;
-        }
-        op = 1.0f / (1.0f + expf(-op));
-    }
+    float mean[3] = {0.f, 0.f, 0.f};
     Splat s;
     TileRec rec;
-    preprocess_one(cam, mean, sc, rq, cov_pre ? cv : nullptr, op, shs ? &s_sh[tid * kShStride] : nullptr, 3, 1,
-                   colors ? colp : nullptr, s, &rec);
+    if (act) {
+        mean[0] = means[3 * (size_t)i]; mean[1] = means[3 * (size_t)i + 1]; mean[2] = means[3 * (size_t)i + 2];
+        apply_points_transform(cp.xf, mean);
+        float sc[3] = {0, 0, 0}, rq[4] = {1, 0, 0, 0}, cv[6], colp[3];
+        if (cov_pre) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) cv[k] = cov_pre[6 * (size_t)i + k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 3; k++) sc[k] = scales[3 * (size_t)i + k];
+#pragma unroll
+            for (int k = 0; k < 4; k++) rq[k] = rots[4 * (size_t)i + k];
+        }
+        if (colors) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) colp[k] = colors[3 * (size_t)i + k];
+        }
+        float op = opac[i];
+        if (RAW) {
+            if (!cov_pre) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) sc[k] = expf(sc[k]);
+                const float inv = 1.0f / fmaxf(sqrtf(rq[0] * rq[0] + rq[1] * rq[1] + rq[2] * rq[2] + rq[3] * rq[3]), 1e-12f);
+#pragma unroll
+                for (int k = 0; k < 4; k++) rq[k] *= inv;
+            }
+            op = 1.0f / (1.0f + expf(-op));
+        }
+        preprocess_one(cam, mean, sc, rq, cov_pre ? cv : nullptr, op, nullptr, 3, 1, colors ? colp : nullptr, s, &rec);
+    }
+    // ---- phase 2: rows into the LDS tile, then the colour of the Gaussians that survived the culls
+    if (shs) {
+        if (pend_dc) stage_store<3>(r_dc, s_sh, 0, nG, tid);
+        if (pend_rest) stage_store<NR>(r_rows, s_sh, 3, nG, tid);
+        if (pend_full) stage_store<NC3>(r_rows, s_sh, 0, nG, tid);
+        __syncthreads();
+        if (act && s.radius > 0) {
+            float col[3];
+            splat_sh_color(cam, mean, &s_sh[tid * kShStride], 3, 1, col);
+            s.r = col[0]; s.g = col[1]; s.b = col[2];
+        }
+    }
+    if (!act) return;
     splat[i] = s;
     tilerec[i] = rec;   // compact emission record: k_tile_counts / k_emit never touch the 48 B splats
     radii[i] = s.radius;

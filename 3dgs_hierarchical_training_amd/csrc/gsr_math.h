@@ -311,6 +311,20 @@ GSR_HD RT sh_channel(int deg, const float* sh, int stride, RT x, RT y, RT z)
     return res;
 }
 
+// SH colour of one Gaussian seen from the camera centre: max(SH(dir) + 0.5, 0) per channel.
+// Colour enters the image linearly, so binary32 is enough here (relative error ~1e-7); only the geometry of
+// preprocess_one (conic = inverse of a nearly singular 2x2, pixel position) needs the float64 evaluation.
+GSR_HD void splat_sh_color(const Camera& c, const float mean[3], const float* sh, int sh_kstride, int sh_cstride, float col[3])
+{
+    float dx = mean[0] - c.cam[0], dy = mean[1] - c.cam[1], dz = mean[2] - c.cam[2];
+    const float inv_n = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+    dx *= inv_n; dy *= inv_n; dz *= inv_n;
+    for (int ch = 0; ch < 3; ch++) {
+        const float v = sh_channel<float>(c.D, sh + ch * sh_cstride, sh_kstride, dx, dy, dz) + 0.5f;
+        col[ch] = v < 0.f ? 0.f : v;
+    }
+}
+
 // Forward projection of one Gaussian.  `sh` may be null when `color_pre` is given (and vice versa);
 // `cov_pre` null means build Sigma from scale/rot.  sh coefficient k of channel ch is at
 // sh[k*sh_kstride + ch*sh_cstride] (lets the caller hand either the global [M][3] row or an LDS copy).
@@ -356,19 +370,11 @@ GSR_HD void preprocess_one(const Camera& c, const float mean[3], const float* sc
     tile_rect(px + 0.5f * (float)c.W, py + 0.5f * (float)c.H, radius, c.tiles_x, c.tiles_y, x0, y0, x1, y1);
     const int nt = (x1 - x0) * (y1 - y0);
     if (nt == 0) return;
-    float col[3];
+    float col[3] = {0.f, 0.f, 0.f};   // neither colour source given: geometry only, the caller adds the colour (k_preprocess)
     if (color_pre) {
         col[0] = color_pre[0]; col[1] = color_pre[1]; col[2] = color_pre[2];
-    } else {
-        // colour enters the image linearly, so binary32 is enough here (relative error ~1e-7); only the geometry
-        // above (conic = inverse of a nearly singular 2x2, pixel position) needs the float64 evaluation
-        float dx = mean[0] - c.cam[0], dy = mean[1] - c.cam[1], dz = mean[2] - c.cam[2];
-        const float inv_n = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
-        dx *= inv_n; dy *= inv_n; dz *= inv_n;
-        for (int ch = 0; ch < 3; ch++) {
-            const float v = sh_channel<float>(c.D, sh + ch * sh_cstride, sh_kstride, dx, dy, dz) + 0.5f;
-            col[ch] = v < 0.f ? 0.f : v;
-        }
+    } else if (sh) {
+        splat_sh_color(c, mean, sh, sh_kstride, sh_cstride, col);
     }
     out.px = px; out.py = py;
     out.ca = (float)(cc * dinv); out.cb = (float)(-b * dinv); out.cc = (float)(a * dinv);
