@@ -678,13 +678,17 @@ __global__ __launch_bounds__(64) void k_blend_fwd_w(int W, int H, int tiles_x, i
                                                     const uint32_t* __restrict__ list, const Splat* __restrict__ splat,
                                                     const float* __restrict__ bg, float* __restrict__ out_color,
                                                     float* __restrict__ out_depth, float* __restrict__ out_alpha,
-                                                    float* __restrict__ img, uint32_t* __restrict__ staged4)
+                                                    float* __restrict__ img, uint32_t* __restrict__ staged4, int interleave)
 {
     constexpr int NT = 64;
     __shared__ float4 s_a[2][NT], s_b[2][NT], s_c[2][NT];
     const int per = (T + 7) >> 3;
     const int kslot = blockIdx.x >> 3;
-    const int tile = (blockIdx.x & 7) * per + (kslot >> 2), sub = kslot & 3;
+    // interleaved (default): tile t lives on XCD t % 8, so a spatially coherent hot region -- real scenes concentrate
+    // their Gaussians on a few hundred tiles -- is spread over all eight XCDs; banded: XCD x owns tiles
+    // [x per, (x+1) per) (neighbours share an L2).  A tile's four waves share an XCD either way.
+    const int tile = interleave ? (kslot >> 2) * 8 + (int)(blockIdx.x & 7) : (int)(blockIdx.x & 7) * per + (kslot >> 2);
+    const int sub = kslot & 3;
     if (tile >= T || (kslot >> 2) >= per) return;
     const int lane = threadIdx.x;
     const int tx = tile % tiles_x, ty = tile / tiles_x;
@@ -1002,7 +1006,7 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(int W, int H, int tiles_x, i
                                                     const uint32_t* __restrict__ list, const Splat* __restrict__ splat,
                                                     const float* __restrict__ bg, const float* __restrict__ img,
                                                     const float* __restrict__ g_color, const float* __restrict__ g_depth,
-                                                    const float* __restrict__ g_alpha, float* __restrict__ ggrad)
+                                                    const float* __restrict__ g_alpha, float* __restrict__ ggrad, int interleave)
 {
     constexpr int NT = 128, NW = 2, NV = HAS_DA ? 10 : 9;
     // single staging buffer: a batch is ~10^4 cycles of compute, so the second barrier per batch is free, and the
@@ -1011,7 +1015,7 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(int W, int H, int tiles_x, i
     __shared__ uint32_t s_gid[1][NT];
     __shared__ float s_part[NW][NT][NV];
     __shared__ uint32_t s_max[NW];
-    const int tile = xcd_tile(blockIdx.x, T);
+    const int tile = interleave ? (int)blockIdx.x : xcd_tile(blockIdx.x, T);   // see k_blend_fwd_w
     if (tile >= T) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tx = tile % tiles_x, ty = tile / tiles_x;
@@ -1560,6 +1564,7 @@ static unsigned long long* g_pinned = nullptr;
 static hipEvent_t g_pin_event = nullptr;
 static std::atomic<uint64_t> g_r_hint{0};   // capacity for the next speculative binning (0 = none yet: exact flow)
 static int g_speculate = 1;
+static int g_tile_map = 1;   // 1: interleaved tile -> XCD map (tile t on XCD t % 8), 0: banded
 static std::atomic<int> g_spec_overflows{0};
 
 static int check_common(int32_t N, int32_t M, int32_t D, int32_t W, int32_t H)
@@ -1640,6 +1645,7 @@ int gsr_set_option(const char* name, int value)
     if (!name) return GSR_ERR_ARG;
     // 1 / 3 / 4 = one workgroup per tile with 1 / 2 / 4 pixels per lane (scalar), 2 = packed 2-pixel, 5 = one wave per 8x8 sub-tile
     if (!strcmp(name, "blend_fwd_ppt")) { if (value < 0 || value > 5) return GSR_ERR_ARG; g_blend_ppt = value; return GSR_OK; }
+    if (!strcmp(name, "tile_map")) { g_tile_map = value ? 1 : 0; return GSR_OK; }
     if (!strcmp(name, "speculative_binning")) { g_speculate = value ? 1 : 0; return GSR_OK; }
     if (!strcmp(name, "binning_capacity_hint")) { g_r_hint.store(value > 0 ? (uint64_t)value : 0); return GSR_OK; }   // tests: force an overflow
     if (!strcmp(name, "profile")) { g_profile = (value == 2) ? 2 : (value ? 1 : 0); return GSR_OK; }
@@ -1731,7 +1737,7 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
             ProfScope ps(P_BLEND_FWD, st);
             if (ppt == 5)
                 hipLaunchKernelGGL(k_blend_fwd_w, dim3(8 * 4 * ((T + 7) / 8)), dim3(64), 0, st, W, H, tiles_x, T, ranges, list, splat, a->bg,
-                                   a->out_color, a->out_depth, a->out_alpha, img, staged);
+                                   a->out_color, a->out_depth, a->out_alpha, img, staged, g_tile_map);
             else if (ppt == 1) launch_blend_fwd<1>(W, H, tiles_x, T, ranges, list, splat, a->bg, a->out_color, a->out_depth, a->out_alpha, img, staged, st);
             else if (ppt == 2)
                 hipLaunchKernelGGL(k_blend_fwd2, dim3(8 * ((T + 7) / 8)), dim3(128), 0, st, W, H, tiles_x, T, ranges, list, splat, a->bg,
@@ -1904,10 +1910,10 @@ int gsr_backward(const GsrBackwardArgs* a, void* stream_)
             const int grid = 8 * ((T + 7) / 8);
             if (a->grad_depth || a->grad_alpha)
                 hipLaunchKernelGGL(k_blend_bwd2<true>, dim3(grid), dim3(128), 0, st, W, H, tiles_x, T, ranges, list, splat, a->bg, img,
-                                   a->grad_color, a->grad_depth, a->grad_alpha, gg);
+                                   a->grad_color, a->grad_depth, a->grad_alpha, gg, g_tile_map);
             else
                 hipLaunchKernelGGL(k_blend_bwd2<false>, dim3(grid), dim3(128), 0, st, W, H, tiles_x, T, ranges, list, splat, a->bg, img,
-                                   a->grad_color, a->grad_depth, a->grad_alpha, gg);
+                                   a->grad_color, a->grad_depth, a->grad_alpha, gg, g_tile_map);
         } else if (ppt == 3) launch_blend_bwd<2>(W, H, tiles_x, T, ranges, list, splat, a->bg, img, a->grad_color, a->grad_depth, a->grad_alpha, gg, st);
         else launch_blend_bwd<4>(W, H, tiles_x, T, ranges, list, splat, a->bg, img, a->grad_color, a->grad_depth, a->grad_alpha, gg, st);
     }

@@ -161,9 +161,18 @@ int gsr_mark_visible(int32_t N, const float* means3D, const float* viewmatrix, c
 const char* gsr_last_error(void);
 int gsr_version(void);
 
-/* Process-wide knobs: "blend_fwd_ppt" / "blend_bwd_ppt" = pixels per thread of the blend kernels (1, 2, 4;
- * 0 = default); "profile" = 1 records HIP events around every stage on the caller's stream, 2 around the forward blend
- * kernel only (an event pair costs ~10 us of stream bubble per stage). */
+/* Process-wide knobs (value 0 = default unless stated):
+ *   "blend_fwd_ppt"        forward blend kernel: 5 = one wave per 8x8 sub-tile (default); 1, 3, 4 = 256 / 128 / 64-thread
+ *                          tile kernels (1, 2, 4 pixels per thread); 2 = packed two-pixel kernel
+ *   "blend_bwd_ppt"        backward blend kernel: 2 = packed two-pixel kernel (default); 1, 3, 4 = scalar variants
+ *   "sort_algo"            2 = onesweep for both sorts (default); 1 = onesweep depth sort only; 0 = hist + scan + scatter
+ *   "tile_map"             1 (default) = tiles interleaved over the eight XCDs (tile t on XCD t % 8); 0 = one contiguous
+ *                          band of tiles per XCD
+ *   "speculative_binning"  1 (default) = R-dependent stages launched against a capacity, R read back late;
+ *                          0 = read R, then launch
+ *   "binning_capacity_hint" capacity for the next speculative forward (tests: force the overflow re-run)
+ *   "profile"              1 = HIP events around every stage on the caller's stream, 2 = around the forward blend kernel
+ *                          only (an event pair costs ~10 us of stream bubble per stage) */
 int gsr_set_option(const char* name, int value);
 /* Sum of the recorded durations of stage `name` ("preprocess_fwd", "sort_depth", "scan", "emit", "sort_tile",
  * "ranges", "blend_fwd", "blend_bwd", "preprocess_bwd") since the last read; synchronises on the events. */
