@@ -29,7 +29,8 @@ class GsrForwardArgs(C.Structure):
 
 
 class GsrForwardOut(C.Structure):
-    _fields_ = [("num_rendered", C.c_int64), ("binning", C.c_void_p), ("binning_bytes", C.c_size_t)]
+    _fields_ = [("num_rendered", C.c_int64), ("binning", C.c_void_p), ("binning_bytes", C.c_size_t),
+                ("binning_capacity", C.c_int64)]
 
 
 class GsrBackwardArgs(C.Structure):
@@ -48,6 +49,7 @@ class GsrBackwardArgs(C.Structure):
         ("d_viewmatrix", C.c_void_p), ("d_projmatrix", C.c_void_p), ("d_campos", C.c_void_p),
         ("fused_adam", C.c_void_p),
         ("points_transform", C.c_void_p), ("d_points_transform", C.c_void_p),
+        ("binning_capacity", C.c_int64),
     ]
 
 

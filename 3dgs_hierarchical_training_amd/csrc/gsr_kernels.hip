@@ -571,6 +571,11 @@ __global__ void k_tile_ranges(uint32_t R, const uint16_t* __restrict__ keys, uin
 // image state planes (floats): 0 final_T, 1 n_contrib(u32), 2..4 C, 5 D, 6 A
 // ------------------------------------------------------------------------------------------------
 constexpr int kImgPlanes = 7;
+// Long lists are split over several workgroups in the backward: past the first kCkptFirst 128-instance batches of a tile
+// the forward leaves a checkpoint of every pixel's running state (T, C.rgb, D, A) at each batch boundary, so a later
+// workgroup can start its replay there instead of at instance 0.  Slot of (tile, batch k >= kCkptFirst):
+// (ranges[tile].x >> 7) + tile + k - kCkptFirst (non-overlapping: floor(a) + floor(b) + 1 <= floor(a + b) + 1).
+constexpr int kCkptFirst = 4, kCkptPlanes = 6, kCkptFloats = kCkptPlanes * kTile * kTile;
 
 __device__ __forceinline__ int xcd_tile(int b, int T)
 {
@@ -678,7 +683,8 @@ __global__ __launch_bounds__(64) void k_blend_fwd_w(int W, int H, int tiles_x, i
                                                     const uint32_t* __restrict__ list, const Splat* __restrict__ splat,
                                                     const float* __restrict__ bg, float* __restrict__ out_color,
                                                     float* __restrict__ out_depth, float* __restrict__ out_alpha,
-                                                    float* __restrict__ img, uint32_t* __restrict__ staged4, int interleave)
+                                                    float* __restrict__ img, uint32_t* __restrict__ staged4, int interleave,
+                                                    float* __restrict__ ckpt)
 {
     constexpr int NT = 64;
     __shared__ float4 s_a[2][NT], s_b[2][NT], s_c[2][NT];
@@ -714,6 +720,10 @@ __global__ __launch_bounds__(64) void k_blend_fwd_w(int W, int H, int tiles_x, i
     for (int b = 0; b < nb; b++) {
         const int buf = b & 1;
         if (__all(done)) break;
+        if (ckpt && !(b & 1) && (b >> 1) >= kCkptFirst) {   // 128-instance boundary deep in a long list: checkpoint
+            float* c = ckpt + ((size_t)(rg.x >> 7) + tile + (b >> 1) - kCkptFirst) * kCkptFloats + sub * 64 + lane;
+            c[0] = acc.T; c[256] = acc.C0; c[512] = acc.C1; c[768] = acc.C2; c[1024] = acc.D; c[1280] = acc.A;
+        }
         s_a[buf][lane] = ra; s_b[buf][lane] = rb; s_c[buf][lane] = rc;
         __syncthreads();   // single-wave workgroup: just orders the LDS writes before the broadcast reads
         batches = b + 1;
@@ -1006,7 +1016,8 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(int W, int H, int tiles_x, i
                                                     const uint32_t* __restrict__ list, const Splat* __restrict__ splat,
                                                     const float* __restrict__ bg, const float* __restrict__ img,
                                                     const float* __restrict__ g_color, const float* __restrict__ g_depth,
-                                                    const float* __restrict__ g_alpha, float* __restrict__ ggrad, int interleave)
+                                                    const float* __restrict__ g_alpha, float* __restrict__ ggrad, int interleave,
+                                                    const float* __restrict__ ckpt, int split)
 {
     constexpr int NT = 128, NW = 2, NV = HAS_DA ? 10 : 9;
     // single staging buffer: a batch is ~10^4 cycles of compute, so the second barrier per batch is free, and the
@@ -1015,7 +1026,10 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(int W, int H, int tiles_x, i
     __shared__ uint32_t s_gid[1][NT];
     __shared__ float s_part[NW][NT][NV];
     __shared__ uint32_t s_max[NW];
-    const int tile = interleave ? (int)blockIdx.x : xcd_tile(blockIdx.x, T);   // see k_blend_fwd_w
+    // grid = split x Tpad workgroups: part `spart` of tile `tile` (parts beyond what the tile's depth needs exit)
+    const int tpad = 8 * ((T + 7) / 8);
+    const int spart = (int)blockIdx.x / tpad, tb = (int)blockIdx.x - spart * tpad;
+    const int tile = interleave ? tb : xcd_tile(tb, T);   // see k_blend_fwd_w
     if (tile >= T) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tx = tile % tiles_x, ty = tile / tiles_x;
@@ -1058,6 +1072,36 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(int W, int H, int tiles_x, i
     const int n = (int)max(s_max[0], s_max[1]);
     const int nw = (int)s_max[wave];
     const int nb = (n + NT - 1) / NT;
+    // this workgroup's share of the tile's batches: everything when the list is short or splitting is off; otherwise
+    // part 0 takes the first kCkptFirst batches and the rest is divided evenly over parts 1..split-1, each of which
+    // starts from the checkpoint the forward left at its first batch
+    int b0 = 0, b1 = nb;
+    if (split > 1 && ckpt) {
+        if (nb <= kCkptFirst) { if (spart) return; }
+        else if (spart == 0) b1 = kCkptFirst;
+        else {
+            const int q = (nb - kCkptFirst + split - 2) / (split - 1);
+            b0 = kCkptFirst + (spart - 1) * q;
+            b1 = min(nb, b0 + q);
+            if (b0 >= b1) return;
+        }
+    } else if (spart) return;
+    if (b0 > 0) {   // resume from the forward's checkpoint at batch b0: T there, S = what is still to come
+        const float* c = ckpt + ((size_t)(rg.x >> 7) + tile + b0 - kCkptFirst) * kCkptFloats;
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            const int ly = (tid >> 4) * 2 + p, lx = tid & 15;
+            const int pi = ((ly >> 3) * 2 + (lx >> 3)) * 64 + (ly & 7) * 8 + (lx & 7);   // k_blend_fwd_w's (sub-tile, lane)
+            if (ncon[p] > (uint32_t)(b0 * NT)) {   // the pixel was still blending at this boundary: its wave wrote the slot
+                Tt[p] = c[pi];
+                float s = gC0[p] * c[256 + pi] + gC1[p] * c[512 + pi] + gC2[p] * c[768 + pi];
+                if (HAS_DA) s += gD[p] * c[1024 + pi] + gA[p] * c[1280 + pi];
+                S[p] -= s;
+            } else {                                // finished earlier: takes no part here (and its slot may be unwritten)
+                Tt[p] = 0.f; S[p] = 0.f; ncon[p] = 0u;
+            }
+        }
+    }
 
     float4 ra = {0, 0, 0, 0}, rb = ra, rc = ra;
     uint32_t rg_id = 0;
@@ -1083,18 +1127,18 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(int W, int H, int tiles_x, i
         rc.w = __uint_as_float(fl);
         ra.z *= -0.5f * kL2E; ra.w *= -kL2E; rb.x *= -0.5f * kL2E;
     };
-    if (tid < n) stage(tid);
+    if (b0 * NT + tid < n) stage(b0 * NT + tid);
 #pragma unroll
     for (int w = 0; w < NW; w++)
 #pragma unroll
         for (int k = 0; k < NV; k++) s_part[w][tid][k] = 0.f;   // the flush below re-zeroes what it consumes
-    for (int b = 0; b < nb; b++) {
+    for (int b = b0; b < b1; b++) {
         const int buf = 0;
-        if (b) __syncthreads();   // everyone is done reading the previous batch (and its flush read s_gid)
+        if (b > b0) __syncthreads();   // everyone is done reading the previous batch (and its flush read s_gid)
         s_a[buf][tid] = ra; s_b[buf][tid] = rb; s_c[buf][tid] = rc; s_gid[buf][tid] = rg_id;
         __syncthreads();
         const int nxt = (b + 1) * NT + tid;
-        if (nxt < n) stage(nxt);
+        if (nxt < n && b + 1 < b1) stage(nxt);
         const int cnt = min(NT, n - b * NT);
         // a wave only walks as far as ITS pixels' last contributor (the tile-wide n bounds the staging and the barriers)
         const int cntw = min(cnt, nw - b * NT);
@@ -1530,8 +1574,8 @@ static FwdScratch fwd_scratch_layout(int32_t N)
     return s;
 }
 
-struct BinLayout {   // persistent: list + ranges
-    size_t list, ranges, bytes;
+struct BinLayout {   // persistent: list + ranges + checkpoints of long lists
+    size_t list, ranges, ckpt, bytes;
 };
 static BinLayout bin_layout(int64_t R, int32_t W, int32_t H)
 {
@@ -1539,7 +1583,8 @@ static BinLayout bin_layout(int64_t R, int32_t W, int32_t H)
     BinLayout b;
     b.ranges = 0;
     b.list = align256((T ? T : 1) * sizeof(uint2));
-    b.bytes = b.list + align256((size_t)(R > 0 ? R : 1) * 4);
+    b.ckpt = b.list + align256((size_t)(R > 0 ? R : 1) * 4);
+    b.bytes = b.ckpt + align256((((size_t)(R > 0 ? R : 0) >> 7) + T + 1) * kCkptFloats * sizeof(float));
     return b;
 }
 
@@ -1564,6 +1609,7 @@ static unsigned long long* g_pinned = nullptr;
 static hipEvent_t g_pin_event = nullptr;
 static std::atomic<uint64_t> g_r_hint{0};   // capacity for the next speculative binning (0 = none yet: exact flow)
 static int g_speculate = 1;
+static int g_bwd_split = 8;  // workgroups a long tile's backward is split over (checkpoints from the forward); 1 = off
 static int g_tile_map = 1;   // 1: interleaved tile -> XCD map (tile t on XCD t % 8), 0: banded
 static std::atomic<int> g_spec_overflows{0};
 
@@ -1645,6 +1691,7 @@ int gsr_set_option(const char* name, int value)
     if (!name) return GSR_ERR_ARG;
     // 1 / 3 / 4 = one workgroup per tile with 1 / 2 / 4 pixels per lane (scalar), 2 = packed 2-pixel, 5 = one wave per 8x8 sub-tile
     if (!strcmp(name, "blend_fwd_ppt")) { if (value < 0 || value > 5) return GSR_ERR_ARG; g_blend_ppt = value; return GSR_OK; }
+    if (!strcmp(name, "bwd_split")) { if (value < 0 || value > 16) return GSR_ERR_ARG; g_bwd_split = value ? value : 8; return GSR_OK; }
     if (!strcmp(name, "tile_map")) { g_tile_map = value ? 1 : 0; return GSR_OK; }
     if (!strcmp(name, "speculative_binning")) { g_speculate = value ? 1 : 0; return GSR_OK; }
     if (!strcmp(name, "binning_capacity_hint")) { g_r_hint.store(value > 0 ? (uint64_t)value : 0); return GSR_OK; }   // tests: force an overflow
@@ -1665,7 +1712,7 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
         return fail(GSR_ERR_ARG, "missing output / workspace pointer%s");
     const int N = a->N, W = a->W, H = a->H;
     const int tiles_x = (W + kTile - 1) / kTile, tiles_y = (H + kTile - 1) / kTile, T = tiles_x * tiles_y;
-    out->num_rendered = 0; out->binning = nullptr; out->binning_bytes = 0;
+    out->num_rendered = 0; out->binning = nullptr; out->binning_bytes = 0; out->binning_capacity = 0;
     uint64_t R = 0;
     Splat* splat = static_cast<Splat*>(a->geom);
     float* img = static_cast<float*>(a->image);
@@ -1737,7 +1784,8 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
             ProfScope ps(P_BLEND_FWD, st);
             if (ppt == 5)
                 hipLaunchKernelGGL(k_blend_fwd_w, dim3(8 * 4 * ((T + 7) / 8)), dim3(64), 0, st, W, H, tiles_x, T, ranges, list, splat, a->bg,
-                                   a->out_color, a->out_depth, a->out_alpha, img, staged, g_tile_map);
+                                   a->out_color, a->out_depth, a->out_alpha, img, staged, g_tile_map,
+                                   reinterpret_cast<float*>(bin + B.ckpt));
             else if (ppt == 1) launch_blend_fwd<1>(W, H, tiles_x, T, ranges, list, splat, a->bg, a->out_color, a->out_depth, a->out_alpha, img, staged, st);
             else if (ppt == 2)
                 hipLaunchKernelGGL(k_blend_fwd2, dim3(8 * ((T + 7) / 8)), dim3(128), 0, st, W, H, tiles_x, T, ranges, list, splat, a->bg,
@@ -1874,6 +1922,7 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
     out->num_rendered = (int64_t)R;
     out->binning = bin;
     out->binning_bytes = B.bytes;
+    out->binning_capacity = (int64_t)((speculative && R <= cap) ? cap : R);
     return GSR_OK;
 }
 
@@ -1895,7 +1944,7 @@ int gsr_backward(const GsrBackwardArgs* a, void* stream_)
         return fail(GSR_ERR_ARG, "missing workspace / gradient pointer%s");
     const int tiles_x = (W + kTile - 1) / kTile, tiles_y = (H + kTile - 1) / kTile, T = tiles_x * tiles_y;
     const Splat* splat = static_cast<const Splat*>(a->geom);
-    BinLayout B = bin_layout(a->num_rendered, W, H);
+    BinLayout B = bin_layout(a->binning_capacity > 0 ? a->binning_capacity : a->num_rendered, W, H);
     const uint8_t* bin = static_cast<const uint8_t*>(a->binning);
     const uint2* ranges = reinterpret_cast<const uint2*>(bin + B.ranges);
     const uint32_t* list = reinterpret_cast<const uint32_t*>(bin + B.list);
@@ -1907,13 +1956,16 @@ int gsr_backward(const GsrBackwardArgs* a, void* stream_)
         ProfScope ps(P_BLEND_BWD, st);
         if (ppt == 1) launch_blend_bwd<1>(W, H, tiles_x, T, ranges, list, splat, a->bg, img, a->grad_color, a->grad_depth, a->grad_alpha, gg, st);
                 else if (ppt == 2) {
-            const int grid = 8 * ((T + 7) / 8);
+            // (checkpoints are written by k_blend_fwd_w only)
+            const int split = (g_bwd_split > 1 && (g_blend_ppt == 0 || g_blend_ppt == 5)) ? g_bwd_split : 1;
+            const int grid = split * 8 * ((T + 7) / 8);
+            const float* ckpt = reinterpret_cast<const float*>(bin + B.ckpt);
             if (a->grad_depth || a->grad_alpha)
                 hipLaunchKernelGGL(k_blend_bwd2<true>, dim3(grid), dim3(128), 0, st, W, H, tiles_x, T, ranges, list, splat, a->bg, img,
-                                   a->grad_color, a->grad_depth, a->grad_alpha, gg, g_tile_map);
+                                   a->grad_color, a->grad_depth, a->grad_alpha, gg, g_tile_map, ckpt, split);
             else
                 hipLaunchKernelGGL(k_blend_bwd2<false>, dim3(grid), dim3(128), 0, st, W, H, tiles_x, T, ranges, list, splat, a->bg, img,
-                                   a->grad_color, a->grad_depth, a->grad_alpha, gg, g_tile_map);
+                                   a->grad_color, a->grad_depth, a->grad_alpha, gg, g_tile_map, ckpt, split);
         } else if (ppt == 3) launch_blend_bwd<2>(W, H, tiles_x, T, ranges, list, splat, a->bg, img, a->grad_color, a->grad_depth, a->grad_alpha, gg, st);
         else launch_blend_bwd<4>(W, H, tiles_x, T, ranges, list, splat, a->bg, img, a->grad_color, a->grad_depth, a->grad_alpha, gg, st);
     }

@@ -151,6 +151,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         _LAST.update(num_rendered=int(out.num_rendered), image=image, W=W, H=H)
         ctx.raster_settings = rs
         ctx.num_rendered = int(out.num_rendered)
+        ctx.binning_capacity = int(out.binning_capacity)
         ctx.dims = (N, M, H, W)
         ctx.has = (sh is not None, colors_precomp is not None, scales is not None, cov3Ds_precomp is not None)
         ctx.raw = (sh_rest is not None, bool(raw_params))
@@ -218,6 +219,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         a.colors_precomp = _ptr(colors_precomp) if has_col else None
         a.viewmatrix, a.projmatrix, a.campos, a.bg = _ptr(vm), _ptr(pm), _ptr(campos), _ptr(bg)
         a.geom, a.image, a.binning, a.num_rendered = geom.data_ptr(), image.data_ptr(), binning.data_ptr(), ctx.num_rendered
+        a.binning_capacity = ctx.binning_capacity
         a.grad_color, a.grad_depth, a.grad_alpha = _ptr(grad_color), _ptr(grad_depth), _ptr(grad_alpha)
         a.d_means3D, a.d_means2D, a.d_opacities = _ptr(d_means3D), _ptr(d_means2D), _ptr(d_opac)
         a.d_colors_precomp, a.d_shs = _ptr(d_col), _ptr(d_sh)

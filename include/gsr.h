@@ -85,6 +85,8 @@ typedef struct GsrForwardOut {
     int64_t num_rendered; /* R: (tile, Gaussian) instances */
     void* binning;        /* pointer returned by alloc(GSR_ALLOC_BINNING); pass to gsr_backward */
     size_t binning_bytes;
+    int64_t binning_capacity; /* instances the binning buffer was laid out for (>= R when the forward ran speculatively);
+                                 pass to gsr_backward together with `binning` */
 } GsrForwardOut;
 
 /* Optimizer-in-backward: with raw_params = 1, shs (= _features_dc) + shs_rest given and this struct attached,
@@ -141,6 +143,7 @@ typedef struct GsrBackwardArgs {
      * layout) goes; d_means3D is then the gradient w.r.t. the UNtransformed means (R^T dL/dp'). */
     const float* points_transform;
     float* d_points_transform;
+    int64_t binning_capacity; /* GsrForwardOut::binning_capacity of the forward (0 = num_rendered) */
 } GsrBackwardArgs;
 
 size_t gsr_geom_bytes(int32_t N);
@@ -166,6 +169,8 @@ int gsr_version(void);
  *                          tile kernels (1, 2, 4 pixels per thread); 2 = packed two-pixel kernel
  *   "blend_bwd_ppt"        backward blend kernel: 2 = packed two-pixel kernel (default); 1, 3, 4 = scalar variants
  *   "sort_algo"            2 = onesweep for both sorts (default); 1 = onesweep depth sort only; 0 = hist + scan + scatter
+ *   "bwd_split"            workgroups the backward of one long tile is split over, resuming from per-pixel checkpoints
+ *                          the forward leaves every 128 instances beyond the first 512 (default 8; 1 = off)
  *   "tile_map"             1 (default) = tiles interleaved over the eight XCDs (tile t on XCD t % 8); 0 = one contiguous
  *                          band of tiles per XCD
  *   "speculative_binning"  1 (default) = R-dependent stages launched against a capacity, R read back late;

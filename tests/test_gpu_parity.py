@@ -223,6 +223,44 @@ def test_large_splats_take_the_per_wave_emission_path(scale):
     parity.check_grads(out["grads"], ref, f"large splats x{scale}")
 
 
+def test_deep_lists_split_backward():
+    """Tiles whose lists are processed deeper than 512 instances: the forward leaves per-pixel checkpoints every 128
+    instances and the backward of such a tile is split over several workgroups that resume from them
+    (gsr_set_option "bwd_split").  Same gradients as the unsplit replay (1e-5 relative; the suffix scalar is formed
+    from a checkpoint instead of by running subtraction) and parity with the oracle."""
+    import importlib
+    import hip_runner
+    L = importlib.import_module("3dgs_hierarchical_training_amd._lib")
+    lib = L.load()
+    N, W, H = 60000, 128, 96
+    sc = parity.syn.make_scene(N, W, H, sh_degree=3, seed=77, posed=True)
+    g = torch.Generator().manual_seed(3)
+    sc["opacities"] = torch.sigmoid(-3.8 + 0.5 * torch.randn(N, 1, generator=g))      # faint: transmittance decays slowly
+    kw = parity.scene_kwargs(sc, "sh", bg=(0.3, 0.1, 0.2))
+    o = binding.OracleRender(**kw)
+    o.forward()
+    gc, gd, ga = parity.upstream_grads(H, W, seed=6)
+    keep = o.px_ambig == 0
+    gc *= keep[None]; gd *= keep; ga *= keep
+    ref = o.backward(gc, gd, ga)
+    outs = {}
+    try:
+        for split in (1, 4, 7):
+            assert lib.gsr_set_option(b"bwd_split", split) == 0
+            outs[split] = hip_runner.run_hip(kw, (gc, gd, ga))
+    finally:
+        lib.gsr_set_option(b"bwd_split", 0)
+    ncon = np.asarray(o.n_contrib) if hasattr(o, "n_contrib") else None
+    R = importlib.import_module("3dgs_hierarchical_training_amd.rasterizer")
+    assert R.last_call_info()["staged"] > 48 * 600, "scene not deep enough to exercise the split"
+    parity.check_forward(outs[4]["fwd"], o, "deep lists", ambig_max_frac=0.2)
+    parity.check_grads(outs[4]["grads"], ref, "deep lists, split 4")
+    for split in (4, 7):
+        for k_, v in outs[1]["grads"].items():
+            d = np.abs(outs[split]["grads"][k_] - v).max()
+            assert d <= 1e-5 * np.abs(v).max() + 1e-12, (split, k_, d)
+
+
 def test_mark_visible():
     import hip_runner
     from diff_gaussian_rasterization import GaussianRasterizer
