@@ -571,11 +571,13 @@ __global__ void k_tile_ranges(uint32_t R, const uint16_t* __restrict__ keys, uin
 // image state planes (floats): 0 final_T, 1 n_contrib(u32), 2..4 C, 5 D, 6 A
 // ------------------------------------------------------------------------------------------------
 constexpr int kImgPlanes = 7;
-// Long lists are split over several workgroups in the backward: past the first kCkptFirst 128-instance batches of a tile
-// the forward leaves a checkpoint of every pixel's running state (T, C.rgb, D, A) at each batch boundary, so a later
-// workgroup can start its replay there instead of at instance 0.  Slot of (tile, batch k >= kCkptFirst):
-// (ranges[tile].x >> 7) + tile + k - kCkptFirst (non-overlapping: floor(a) + floor(b) + 1 <= floor(a + b) + 1).
-constexpr int kCkptFirst = 4, kCkptPlanes = 6, kCkptFloats = kCkptPlanes * kTile * kTile;
+// The backward of a tile is split over several workgroups: at every 128-instance boundary of a tile's list (from batch
+// `first` on; first = 1 by default, i.e. every boundary) the forward leaves a checkpoint of every pixel's running state
+// (T, C.rgb, D, A), so a workgroup can start its front-to-back replay there instead of at instance 0 -- (tile, batch)
+// pieces are independent, which both balances long lists and puts three to four times more waves in flight on a
+// 2 170-tile frame.  Slot of (tile, batch k >= first): (ranges[tile].x >> 7) + tile + k - first (non-overlapping:
+// floor(a) + floor(b) + 1 <= floor(a + b) + 1).
+constexpr int kCkptPlanes = 6, kCkptFloats = kCkptPlanes * kTile * kTile;
 
 __device__ __forceinline__ int xcd_tile(int b, int T)
 {
@@ -684,7 +686,7 @@ __global__ __launch_bounds__(64) void k_blend_fwd_w(int W, int H, int tiles_x, i
                                                     const float* __restrict__ bg, float* __restrict__ out_color,
                                                     float* __restrict__ out_depth, float* __restrict__ out_alpha,
                                                     float* __restrict__ img, uint32_t* __restrict__ staged4, int interleave,
-                                                    float* __restrict__ ckpt)
+                                                    float* __restrict__ ckpt, int kCkptFirst)
 {
     constexpr int NT = 64;
     __shared__ float4 s_a[2][NT], s_b[2][NT], s_c[2][NT];
@@ -1017,7 +1019,8 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(int W, int H, int tiles_x, i
                                                     const float* __restrict__ bg, const float* __restrict__ img,
                                                     const float* __restrict__ g_color, const float* __restrict__ g_depth,
                                                     const float* __restrict__ g_alpha, float* __restrict__ ggrad, int interleave,
-                                                    const float* __restrict__ ckpt, int split)
+                                                    const float* __restrict__ ckpt, int split, int kCkptFirst,
+                                                    const uint32_t* __restrict__ staged4)
 {
     constexpr int NT = 128, NW = 2, NV = HAS_DA ? 10 : 9;
     // single staging buffer: a batch is ~10^4 cycles of compute, so the second barrier per batch is free, and the
@@ -1040,6 +1043,23 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(int W, int H, int tiles_x, i
     const f2 pyf = {(float)py0 - cyf, (float)(py0 + 1) - cyf};
     const uint2 rg = ranges[tile];
     const size_t P = (size_t)W * H;
+    // this workgroup's share of the tile's 128-instance batches, decided from the forward's per-sub-tile staged depths
+    // (an upper bound of every pixel's last contributor that all parts of the tile see alike) before anything else is
+    // loaded: part 0 takes the first kCkptFirst batches, the rest is divided evenly over parts 1..split-1, each of
+    // which resumes from the checkpoint the forward left at its first batch; surplus parts leave at once
+    int b0 = 0, b1 = 0x7fffffff;
+    if (split > 1 && ckpt) {
+        const uint4 sd = *reinterpret_cast<const uint4*>(staged4 + 4 * tile);
+        const int nbs = ((int)max(max(sd.x, sd.y), max(sd.z, sd.w)) + NT - 1) / NT;
+        if (nbs <= kCkptFirst) { if (spart) return; }
+        else if (spart == 0) b1 = kCkptFirst;
+        else {
+            const int q = (nbs - kCkptFirst + split - 2) / (split - 1);
+            b0 = kCkptFirst + (spart - 1) * q;
+            b1 = b0 + q;
+            if (b0 >= nbs) return;
+        }
+    } else if (spart) return;
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
 
     // S = <gC, suffix colour> + gD * suffix depth + gA * suffix alpha + T_final <bg, gC>: the only combination of the
@@ -1072,20 +1092,8 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(int W, int H, int tiles_x, i
     const int n = (int)max(s_max[0], s_max[1]);
     const int nw = (int)s_max[wave];
     const int nb = (n + NT - 1) / NT;
-    // this workgroup's share of the tile's batches: everything when the list is short or splitting is off; otherwise
-    // part 0 takes the first kCkptFirst batches and the rest is divided evenly over parts 1..split-1, each of which
-    // starts from the checkpoint the forward left at its first batch
-    int b0 = 0, b1 = nb;
-    if (split > 1 && ckpt) {
-        if (nb <= kCkptFirst) { if (spart) return; }
-        else if (spart == 0) b1 = kCkptFirst;
-        else {
-            const int q = (nb - kCkptFirst + split - 2) / (split - 1);
-            b0 = kCkptFirst + (spart - 1) * q;
-            b1 = min(nb, b0 + q);
-            if (b0 >= b1) return;
-        }
-    } else if (spart) return;
+    b1 = min(b1, nb);
+    if (b0 >= b1) return;   // (uniform) the staged depth over-estimated the deepest contributor
     if (b0 > 0) {   // resume from the forward's checkpoint at batch b0: T there, S = what is still to come
         const float* c = ckpt + ((size_t)(rg.x >> 7) + tile + b0 - kCkptFirst) * kCkptFloats;
 #pragma unroll
@@ -1609,7 +1617,8 @@ static unsigned long long* g_pinned = nullptr;
 static hipEvent_t g_pin_event = nullptr;
 static std::atomic<uint64_t> g_r_hint{0};   // capacity for the next speculative binning (0 = none yet: exact flow)
 static int g_speculate = 1;
-static int g_bwd_split = 8;  // workgroups a long tile's backward is split over (checkpoints from the forward); 1 = off
+static int g_bwd_split = 16; // workgroups a long tile's backward is split over (checkpoints from the forward); 1 = off
+static int g_ckpt_first = 1;  // 128-instance batches of a tile before the forward starts leaving checkpoints
 static int g_tile_map = 1;   // 1: interleaved tile -> XCD map (tile t on XCD t % 8), 0: banded
 static std::atomic<int> g_spec_overflows{0};
 
@@ -1691,7 +1700,8 @@ int gsr_set_option(const char* name, int value)
     if (!name) return GSR_ERR_ARG;
     // 1 / 3 / 4 = one workgroup per tile with 1 / 2 / 4 pixels per lane (scalar), 2 = packed 2-pixel, 5 = one wave per 8x8 sub-tile
     if (!strcmp(name, "blend_fwd_ppt")) { if (value < 0 || value > 5) return GSR_ERR_ARG; g_blend_ppt = value; return GSR_OK; }
-    if (!strcmp(name, "bwd_split")) { if (value < 0 || value > 16) return GSR_ERR_ARG; g_bwd_split = value ? value : 8; return GSR_OK; }
+    if (!strcmp(name, "bwd_split")) { if (value < 0 || value > 64) return GSR_ERR_ARG; g_bwd_split = value ? value : 16; return GSR_OK; }
+    if (!strcmp(name, "ckpt_first")) { if (value < 1 || value > 64) return GSR_ERR_ARG; g_ckpt_first = value; return GSR_OK; }
     if (!strcmp(name, "tile_map")) { g_tile_map = value ? 1 : 0; return GSR_OK; }
     if (!strcmp(name, "speculative_binning")) { g_speculate = value ? 1 : 0; return GSR_OK; }
     if (!strcmp(name, "binning_capacity_hint")) { g_r_hint.store(value > 0 ? (uint64_t)value : 0); return GSR_OK; }   // tests: force an overflow
@@ -1785,7 +1795,7 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
             if (ppt == 5)
                 hipLaunchKernelGGL(k_blend_fwd_w, dim3(8 * 4 * ((T + 7) / 8)), dim3(64), 0, st, W, H, tiles_x, T, ranges, list, splat, a->bg,
                                    a->out_color, a->out_depth, a->out_alpha, img, staged, g_tile_map,
-                                   reinterpret_cast<float*>(bin + B.ckpt));
+                                   reinterpret_cast<float*>(bin + B.ckpt), g_ckpt_first);
             else if (ppt == 1) launch_blend_fwd<1>(W, H, tiles_x, T, ranges, list, splat, a->bg, a->out_color, a->out_depth, a->out_alpha, img, staged, st);
             else if (ppt == 2)
                 hipLaunchKernelGGL(k_blend_fwd2, dim3(8 * ((T + 7) / 8)), dim3(128), 0, st, W, H, tiles_x, T, ranges, list, splat, a->bg,
@@ -1960,12 +1970,13 @@ int gsr_backward(const GsrBackwardArgs* a, void* stream_)
             const int split = (g_bwd_split > 1 && (g_blend_ppt == 0 || g_blend_ppt == 5)) ? g_bwd_split : 1;
             const int grid = split * 8 * ((T + 7) / 8);
             const float* ckpt = reinterpret_cast<const float*>(bin + B.ckpt);
+            const uint32_t* staged4 = reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(a->image) + gsr_image_staged_offset(W, H));
             if (a->grad_depth || a->grad_alpha)
                 hipLaunchKernelGGL(k_blend_bwd2<true>, dim3(grid), dim3(128), 0, st, W, H, tiles_x, T, ranges, list, splat, a->bg, img,
-                                   a->grad_color, a->grad_depth, a->grad_alpha, gg, g_tile_map, ckpt, split);
+                                   a->grad_color, a->grad_depth, a->grad_alpha, gg, g_tile_map, ckpt, split, g_ckpt_first, staged4);
             else
                 hipLaunchKernelGGL(k_blend_bwd2<false>, dim3(grid), dim3(128), 0, st, W, H, tiles_x, T, ranges, list, splat, a->bg, img,
-                                   a->grad_color, a->grad_depth, a->grad_alpha, gg, g_tile_map, ckpt, split);
+                                   a->grad_color, a->grad_depth, a->grad_alpha, gg, g_tile_map, ckpt, split, g_ckpt_first, staged4);
         } else if (ppt == 3) launch_blend_bwd<2>(W, H, tiles_x, T, ranges, list, splat, a->bg, img, a->grad_color, a->grad_depth, a->grad_alpha, gg, st);
         else launch_blend_bwd<4>(W, H, tiles_x, T, ranges, list, splat, a->bg, img, a->grad_color, a->grad_depth, a->grad_alpha, gg, st);
     }

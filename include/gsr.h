@@ -169,8 +169,9 @@ int gsr_version(void);
  *                          tile kernels (1, 2, 4 pixels per thread); 2 = packed two-pixel kernel
  *   "blend_bwd_ppt"        backward blend kernel: 2 = packed two-pixel kernel (default); 1, 3, 4 = scalar variants
  *   "sort_algo"            2 = onesweep for both sorts (default); 1 = onesweep depth sort only; 0 = hist + scan + scatter
- *   "bwd_split"            workgroups the backward of one long tile is split over, resuming from per-pixel checkpoints
- *                          the forward leaves every 128 instances beyond the first 512 (default 8; 1 = off)
+ *   "bwd_split"            workgroups the backward of one tile is split over (default 16; 1 = off): each part replays a
+ *                          run of 128-instance batches, resuming from the per-pixel checkpoints the forward leaves at
+ *                          every 128-instance boundary from batch "ckpt_first" (default 1) on
  *   "tile_map"             1 (default) = tiles interleaved over the eight XCDs (tile t on XCD t % 8); 0 = one contiguous
  *                          band of tiles per XCD
  *   "speculative_binning"  1 (default) = R-dependent stages launched against a capacity, R read back late;
