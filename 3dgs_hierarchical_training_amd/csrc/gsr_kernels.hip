@@ -423,8 +423,8 @@ struct ZeroJobs {
 __global__ __launch_bounds__(1024) void k_block_scan(uint32_t* __restrict__ block_sums, int nb, unsigned long long* __restrict__ total_out,
                                                      ZeroJobs zj)
 {
-    __shared__ unsigned long long s_part[1024];
-    const int tid = threadIdx.x;
+    __shared__ unsigned long long s_wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #pragma unroll
     for (int j = 0; j < 3; j++) {
         uint32_t* z = static_cast<uint32_t*>(zj.p[j]);
@@ -434,21 +434,25 @@ __global__ __launch_bounds__(1024) void k_block_scan(uint32_t* __restrict__ bloc
     const int lo = min(nb, tid * chunk), hi = min(nb, lo + chunk);
     unsigned long long sum = 0;
     for (int b = lo; b < hi; b++) sum += block_sums[b];
-    s_part[tid] = sum;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        const unsigned long long v = (tid >= off) ? s_part[tid - off] : 0ull;
-        __syncthreads();
-        s_part[tid] += v;
-        __syncthreads();
+    // inclusive scan over the 1024 partial sums: wave shuffles, then the 16 wave totals (one barrier)
+    unsigned long long inc = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned long long y = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += y;
     }
-    unsigned long long run = s_part[tid] - sum;
+    if (lane == 63) s_wsum[wave] = inc;
+    __syncthreads();
+    unsigned long long add = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) { const unsigned long long t = s_wsum[w]; add += (w < wave) ? t : 0ull; all += t; }
+    unsigned long long run = add + inc - sum;
     for (int b = lo; b < hi; b++) {
         const uint32_t c = block_sums[b];
         block_sums[b] = (uint32_t)run;
         run += c;
     }
-    if (tid == 1023) *total_out = s_part[1023];
+    if (tid == 0) *total_out = all;
 }
 
 // ------------------------------------------------------------------------------------------------
