@@ -6,7 +6,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libgsr_hip.so")
 SOURCES = ["gsr_kernels.hip", "loss_kernels.hip", "optim_kernels.hip", "knn_kernels.hip"]
-HEADERS = ["gsr_math.h", "radix_sort.h", os.path.join("..", "..", "include", "gsr.h")]
+HEADERS = ["gsr_math.h", "adam_math.h", "radix_sort.h", os.path.join("..", "..", "include", "gsr.h")]
 
 
 def _stale():
