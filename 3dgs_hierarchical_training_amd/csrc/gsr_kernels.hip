@@ -1779,7 +1779,7 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
         int in_alt = 0;
         {
             ProfScope ps(P_SORT_TILE, st);
-            GSR_HIP(g_sort_algo == 2 ? onesweep_sort_pairs<uint16_t>(tkey, v0, tkey_alt, v1, (uint32_t)capacity, 0, tile_passes * 8, bs + S.sort,
+            GSR_HIP(g_sort_algo == 2 ? onesweep_sort_pairs<uint16_t>(tkey, v0, tkey_alt, v1, (uint32_t)capacity, 0, bits, bs + S.sort,
                                                                      &in_alt, st, n_dev, prezeroed)
                                      : radix_sort_pairs<uint16_t>(tkey, v0, tkey_alt, v1, (uint32_t)capacity, 0, tile_passes * 8, bs + S.sort,
                                                                   &in_alt, st));

@@ -240,8 +240,12 @@ template <typename KeyT, int PASSES>
 __global__ __launch_bounds__(256) void k_radix_ghist(const KeyT* __restrict__ keys, uint32_t n, int begin_bit,
                                                      uint32_t* __restrict__ ghist /*[PASSES][256]*/,
                                                      const unsigned long long* __restrict__ n_dev,
-                                                     uint32_t* __restrict__ status, uint32_t status_words)
+                                                     uint32_t* __restrict__ status, uint32_t status_words, int dbits, int bits)
 {
+    // digit p covers key bits [dbits p, min(dbits (p + 1), bits)) above begin_bit (<= 8 wide: the tables keep 256 entries)
+    uint32_t dmask[PASSES];
+#pragma unroll
+    for (int p = 0; p < PASSES; p++) dmask[p] = (1u << min(dbits, bits - dbits * p)) - 1u;
     if (n_dev) n = (uint32_t)min((unsigned long long)n, *n_dev);   // device-side count (grid sized for a capacity)
     // clear the look-back status words of all passes (they are first touched by the pass kernels that follow)
     for (uint32_t q = blockIdx.x * 256 + threadIdx.x; q < status_words / 4; q += gridDim.x * 256)
@@ -263,14 +267,14 @@ __global__ __launch_bounds__(256) void k_radix_ghist(const KeyT* __restrict__ ke
             for (int e = 0; e < KPV / 4; e++) {
                 const uint32_t k = (sizeof(KeyT) == 4 ? w[c] : ((w[c] >> (16 * e)) & 0xffffu)) >> begin_bit;
 #pragma unroll
-                for (int p = 0; p < PASSES; p++) atomicAdd(&h[p][(k >> (8 * p)) & 0xffu], 1u);
+                for (int p = 0; p < PASSES; p++) atomicAdd(&h[p][(k >> (dbits * p)) & dmask[p]], 1u);
             }
         }
     }
     for (uint32_t i = nv * KPV + blockIdx.x * 256 + tid; i < n; i += gridDim.x * 256) {
         const uint32_t k = (uint32_t)keys[i] >> begin_bit;
 #pragma unroll
-        for (int p = 0; p < PASSES; p++) atomicAdd(&h[p][(k >> (8 * p)) & 0xffu], 1u);
+        for (int p = 0; p < PASSES; p++) atomicAdd(&h[p][(k >> (dbits * p)) & dmask[p]], 1u);
     }
     __syncthreads();
 #pragma unroll
@@ -293,7 +297,7 @@ __global__ __launch_bounds__(OsCfg<KeyT>::kThreads) void k_onesweep(const KeyT* 
                                                          const uint32_t* __restrict__ ghist /*[256] this pass*/,
                                                          uint32_t* __restrict__ status /*[nblocks][256]*/,
                                                          uint32_t* __restrict__ ticket,
-                                                         const unsigned long long* __restrict__ n_dev)
+                                                         const unsigned long long* __restrict__ n_dev, uint32_t dmask)
 {
     constexpr int kOsThreads = OsCfg<KeyT>::kThreads, kOsIPT = kOsTile / kOsThreads, kOsWaves = kOsThreads / 64;
     if (n_dev) n = (uint32_t)min((unsigned long long)n, *n_dev);   // device-side count: tiles past it exit at once
@@ -325,7 +329,7 @@ __global__ __launch_bounds__(OsCfg<KeyT>::kThreads) void k_onesweep(const KeyT* 
         if (p < valid) {
             key[r] = kin[base + p];
             val[r] = vin[base + p];
-            dig[r] = ((uint32_t)key[r] >> shift) & 0xffu;
+            dig[r] = ((uint32_t)key[r] >> shift) & dmask;
         } else {
             key[r] = (KeyT)~(KeyT)0; val[r] = 0u; dig[r] = 255u;
         }
@@ -387,7 +391,7 @@ __global__ __launch_bounds__(OsCfg<KeyT>::kThreads) void k_onesweep(const KeyT* 
         const uint32_t p = r * kOsThreads + tid;
         if (p < valid) {
             const KeyT k = s_keys[p];
-            const uint32_t d = ((uint32_t)k >> shift) & 0xffu;
+            const uint32_t d = ((uint32_t)k >> shift) & dmask;
             const uint32_t g = s_gbase[d] + p;
             kout[g] = k;
             vout[g] = s_vals[p];
@@ -411,8 +415,12 @@ inline hipError_t onesweep_sort_pairs(KeyT* keys, uint32_t* vals, KeyT* keys_alt
 {
     *in_alt = 0;
     if (n == 0) return hipSuccess;
-    const int passes = (end_bit - begin_bit + 7) / 8;
+    const int bits = end_bit - begin_bit;
+    const int passes = (bits + 7) / 8;
     if (passes < 1 || passes > 4) return hipErrorInvalidValue;
+    // balanced digits: 12 key bits sort as 6 + 6 rather than 8 + 4 (fewer same-digit collisions in the ranking, longer
+    // runs per digit in the scatter); the last digit is narrower when the bits do not divide evenly
+    const int dbits = (bits + passes - 1) / passes;
     const uint32_t nblocks = (n + kOsTile - 1) / kOsTile;
     uint32_t* ghist = static_cast<uint32_t*>(scratch);
     uint32_t* tickets = ghist + 4 * 256;
@@ -426,16 +434,17 @@ inline hipError_t onesweep_sort_pairs(KeyT* keys, uint32_t* vals, KeyT* keys_alt
     const uint32_t status_words = (uint32_t)((size_t)passes * nblocks * 256);
     const uint32_t hgrid = nblocks < 256u ? nblocks : 256u;
     switch (passes) {
-        case 1: hipLaunchKernelGGL((k_radix_ghist<KeyT, 1>), dim3(hgrid), dim3(256), 0, stream, keys, n, begin_bit, ghist, n_dev, status, status_words); break;
-        case 2: hipLaunchKernelGGL((k_radix_ghist<KeyT, 2>), dim3(hgrid), dim3(256), 0, stream, keys, n, begin_bit, ghist, n_dev, status, status_words); break;
-        case 3: hipLaunchKernelGGL((k_radix_ghist<KeyT, 3>), dim3(hgrid), dim3(256), 0, stream, keys, n, begin_bit, ghist, n_dev, status, status_words); break;
-        default: hipLaunchKernelGGL((k_radix_ghist<KeyT, 4>), dim3(hgrid), dim3(256), 0, stream, keys, n, begin_bit, ghist, n_dev, status, status_words); break;
+        case 1: hipLaunchKernelGGL((k_radix_ghist<KeyT, 1>), dim3(hgrid), dim3(256), 0, stream, keys, n, begin_bit, ghist, n_dev, status, status_words, dbits, bits); break;
+        case 2: hipLaunchKernelGGL((k_radix_ghist<KeyT, 2>), dim3(hgrid), dim3(256), 0, stream, keys, n, begin_bit, ghist, n_dev, status, status_words, dbits, bits); break;
+        case 3: hipLaunchKernelGGL((k_radix_ghist<KeyT, 3>), dim3(hgrid), dim3(256), 0, stream, keys, n, begin_bit, ghist, n_dev, status, status_words, dbits, bits); break;
+        default: hipLaunchKernelGGL((k_radix_ghist<KeyT, 4>), dim3(hgrid), dim3(256), 0, stream, keys, n, begin_bit, ghist, n_dev, status, status_words, dbits, bits); break;
     }
     KeyT *kin = keys, *kout = keys_alt;
     uint32_t *vin = vals, *vout = vals_alt;
     for (int p = 0; p < passes; p++) {
-        hipLaunchKernelGGL(k_onesweep<KeyT>, dim3(nblocks), dim3(OsCfg<KeyT>::kThreads), 0, stream, kin, vin, kout, vout, n, begin_bit + 8 * p,
-                           ghist + p * 256, status + (size_t)p * nblocks * 256, nblocks <= 512u ? (uint32_t*)nullptr : tickets + p, n_dev);
+        hipLaunchKernelGGL(k_onesweep<KeyT>, dim3(nblocks), dim3(OsCfg<KeyT>::kThreads), 0, stream, kin, vin, kout, vout, n, begin_bit + dbits * p,
+                           ghist + p * 256, status + (size_t)p * nblocks * 256, nblocks <= 512u ? (uint32_t*)nullptr : tickets + p, n_dev,
+                           (1u << (dbits < bits - dbits * p ? dbits : bits - dbits * p)) - 1u);
         KeyT* tk = kin; kin = kout; kout = tk;
         uint32_t* tv = vin; vin = vout; vout = tv;
         *in_alt ^= 1;
