@@ -35,12 +35,12 @@ __device__ __forceinline__ unsigned long long lanemask_lt()
 // order, so "read, xor, read" needs no barrier; nothing is ever reset (a round only looks at the difference).
 // s_cnt[digit] is the wave's running count of the digit over the rounds done so far.
 // rnk[r] = number of this wave's keys with the same digit that precede key r in (round, lane) order.
-template <int IPT>
+template <int IPT, int NB = 256>
 __device__ __forceinline__ void wave_rank(unsigned long long* s_mask, uint32_t* s_cnt, const uint32_t (&dig)[IPT],
                                           uint32_t (&rnk)[IPT], int lane)
 {
 #pragma unroll
-    for (int k = 0; k < 4; k++) { s_mask[k * 64 + lane] = 0ull; s_cnt[k * 64 + lane] = 0u; }
+    for (int k = 0; k < NB / 64; k++) { s_mask[k * 64 + lane] = 0ull; s_cnt[k * 64 + lane] = 0u; }
     __builtin_amdgcn_wave_barrier();
     const unsigned long long bit = 1ull << lane, lt = bit - 1ull;
     volatile unsigned long long* vmask = s_mask;
@@ -291,7 +291,9 @@ constexpr int kOsTile = 4096;
 template <typename KeyT> struct OsCfg { static constexpr int kThreads = 512; };
 template <> struct OsCfg<uint32_t> { static constexpr int kThreads = 1024; };
 
-template <typename KeyT>
+// NB = digit table size: 256, or 64 when the digits of the sort are at most 6 bits wide (a quarter of the LDS tables:
+// five instead of three workgroups per CU for 16-bit keys).  Status words keep their 256-word stride in memory.
+template <typename KeyT, int NB>
 __global__ __launch_bounds__(OsCfg<KeyT>::kThreads) void k_onesweep(const KeyT* __restrict__ kin, const uint32_t* __restrict__ vin,
                                                          KeyT* __restrict__ kout, uint32_t* __restrict__ vout, uint32_t n, int shift,
                                                          const uint32_t* __restrict__ ghist /*[256] this pass*/,
@@ -301,12 +303,12 @@ __global__ __launch_bounds__(OsCfg<KeyT>::kThreads) void k_onesweep(const KeyT* 
 {
     constexpr int kOsThreads = OsCfg<KeyT>::kThreads, kOsIPT = kOsTile / kOsThreads, kOsWaves = kOsThreads / 64;
     if (n_dev) n = (uint32_t)min((unsigned long long)n, *n_dev);   // device-side count: tiles past it exit at once
-    __shared__ unsigned long long s_mask[kOsWaves][256];
-    __shared__ uint32_t s_cnt[kOsWaves][256];
+    __shared__ unsigned long long s_mask[kOsWaves][NB];
+    __shared__ uint32_t s_cnt[kOsWaves][NB];
     __shared__ KeyT s_keys[kOsTile];
     __shared__ uint32_t s_vals[kOsTile];
-    __shared__ uint32_t s_start[256];
-    __shared__ uint32_t s_gbase[256];
+    __shared__ uint32_t s_start[NB];
+    __shared__ uint32_t s_gbase[NB];
     __shared__ uint32_t s_wsum[kOsWaves];
     __shared__ uint32_t s_tile;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -331,13 +333,13 @@ __global__ __launch_bounds__(OsCfg<KeyT>::kThreads) void k_onesweep(const KeyT* 
             val[r] = vin[base + p];
             dig[r] = ((uint32_t)key[r] >> shift) & dmask;
         } else {
-            key[r] = (KeyT)~(KeyT)0; val[r] = 0u; dig[r] = 255u;
+            key[r] = (KeyT)~(KeyT)0; val[r] = 0u; dig[r] = (uint32_t)(NB - 1);
         }
     }
-    wave_rank<kOsIPT>(s_mask[wave], s_cnt[wave], dig, rnk, lane);
+    wave_rank<kOsIPT, NB>(s_mask[wave], s_cnt[wave], dig, rnk, lane);
     __syncthreads();
     // threads 0..255 = digits (the upper half of the block only takes part in the barriers of the scans)
-    const bool is_digit = tid < 256;
+    const bool is_digit = tid < NB;
     uint32_t mine = 0;   // this tile's count of digit `tid` (padding counted in digit 255; removed below)
     if (is_digit) {
 #pragma unroll
@@ -347,8 +349,8 @@ __global__ __launch_bounds__(OsCfg<KeyT>::kThreads) void k_onesweep(const KeyT* 
             mine += c;
         }
     }
-    const uint32_t real = (tid == 255) ? mine - ((uint32_t)kOsTile - valid) : mine;   // real keys of this digit
-    uint32_t* my_status = status + (size_t)tile * 256 + (tid & 255);
+    const uint32_t real = (tid == NB - 1) ? mine - ((uint32_t)kOsTile - valid) : mine;   // real keys of this digit
+    uint32_t* my_status = status + (size_t)tile * 256 + (tid & (NB - 1));
     if (is_digit) __hip_atomic_store(my_status, kOsLocal | real, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // local exclusive start of each digit (block scan of `mine`) and digit base (block scan of the global histogram)
     const uint32_t lstart = block_scan_excl<kOsWaves>(mine, s_wsum, tid);
@@ -442,9 +444,14 @@ inline hipError_t onesweep_sort_pairs(KeyT* keys, uint32_t* vals, KeyT* keys_alt
     KeyT *kin = keys, *kout = keys_alt;
     uint32_t *vin = vals, *vout = vals_alt;
     for (int p = 0; p < passes; p++) {
-        hipLaunchKernelGGL(k_onesweep<KeyT>, dim3(nblocks), dim3(OsCfg<KeyT>::kThreads), 0, stream, kin, vin, kout, vout, n, begin_bit + dbits * p,
-                           ghist + p * 256, status + (size_t)p * nblocks * 256, nblocks <= 512u ? (uint32_t*)nullptr : tickets + p, n_dev,
-                           (1u << (dbits < bits - dbits * p ? dbits : bits - dbits * p)) - 1u);
+        const uint32_t pmask = (1u << (dbits < bits - dbits * p ? dbits : bits - dbits * p)) - 1u;
+        uint32_t* tk_p = nblocks <= 512u ? (uint32_t*)nullptr : tickets + p;
+        if (dbits <= 6)
+            hipLaunchKernelGGL((k_onesweep<KeyT, 64>), dim3(nblocks), dim3(OsCfg<KeyT>::kThreads), 0, stream, kin, vin, kout, vout, n,
+                               begin_bit + dbits * p, ghist + p * 256, status + (size_t)p * nblocks * 256, tk_p, n_dev, pmask);
+        else
+            hipLaunchKernelGGL((k_onesweep<KeyT, 256>), dim3(nblocks), dim3(OsCfg<KeyT>::kThreads), 0, stream, kin, vin, kout, vout, n,
+                               begin_bit + dbits * p, ghist + p * 256, status + (size_t)p * nblocks * 256, tk_p, n_dev, pmask);
         KeyT* tk = kin; kin = kout; kout = tk;
         uint32_t* tv = vin; vin = vout; vout = tv;
         *in_alt ^= 1;
