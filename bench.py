@@ -214,7 +214,7 @@ def main():
                 "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": blend_ms,
                 "launches_timed": prof["blend_fwd"][1], "R": R, "R_eff": R_eff, "P": P, "T": T}
     res = {
-        "metric": "train-step images/sec @1M Gaussians, 980x545 (fwd+bwd ms alongside)",
+        "metric": "train-step images/sec + fwd+bwd ms @1M Gaussians, 980x545; 1/2/4/8 GPU",   # BASELINE.json's metric
         "value": world * args.steps / elapsed, "unit": "images/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
