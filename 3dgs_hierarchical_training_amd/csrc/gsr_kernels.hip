@@ -347,7 +347,33 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess(CamParams cp, int N,
             }
             op = 1.0f / (1.0f + expf(-op));
         }
-        preprocess_one(cam, mean, sc, rq, cov_pre ? cv : nullptr, op, nullptr, 3, 1, colors ? colp : nullptr, s, &rec);
+        preprocess_one(cam, mean, sc, rq, cov_pre ? cv : nullptr, op, nullptr, 3, 1, colors ? colp : nullptr, s, &rec, true);
+    }
+    // large rects (more than 32 candidate tiles): counted by the whole wave, 64 candidate tiles per step, so one
+    // screen-filling splat costs its wave rect/64 steps instead of rect steps of a single lane
+    {
+        const int lane = tid & 63;
+        for (unsigned long long pm = __ballot(act && s.tiles == kTilesPending); pm != 0ull; pm &= pm - 1ull) {
+            const int src = (int)__builtin_ctzll(pm);
+            const float bpx = __shfl(s.px, src, 64), bpy = __shfl(s.py, src, 64), bca = __shfl(s.ca, src, 64);
+            const float bcb = __shfl(s.cb, src, 64), bcc = __shfl(s.cc, src, 64), bop = __shfl(s.op, src, 64);
+            const int brad = __shfl(s.radius, src, 64);
+            int x0, y0, x1, y1;
+            tile_rect_tight(bpx, bpy, brad, bca, bcb, bcc, bop, cp.W, cp.H, cam.tiles_x, cam.tiles_y, x0, y0, x1, y1);
+            const int ww = x1 - x0, full = ww * (y1 - y0);
+            const TileTest tt = make_tile_test(bpx, bpy, bca, bcb, bcc, bop);
+            uint32_t cnt = 0;
+            for (int c0 = 0; c0 < full; c0 += 64) {
+                const int c = c0 + lane;
+                bool ok = false;
+                if (c < full) {
+                    const int ty = c / ww, tx = c - ty * ww;
+                    ok = tile_accept(tt, x0 + tx, y0 + ty, cp.W, cp.H);
+                }
+                cnt += (uint32_t)__popcll(__ballot(ok));
+            }
+            if (lane == src) { s.tiles = cnt; rec.mask = cnt; }
+        }
     }
     // ---- phase 2: rows into the LDS tile, then the colour of the Gaussians that survived the culls
     if (shs) {
@@ -525,7 +551,7 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit(int N, int W, int H, int 
         const uint32_t gg = s_gid[idx];
         const Splat s = splat[gg];
         int x0, y0, x1, y1;
-        tile_rect(s.px + 0.5f * (float)W, s.py + 0.5f * (float)H, s.radius, tiles_x, tiles_y, x0, y0, x1, y1);
+        tile_rect_tight(s.px, s.py, s.radius, s.ca, s.cb, s.cc, s.op, W, H, tiles_x, tiles_y, x0, y0, x1, y1);   // as k_preprocess
         const int ww = x1 - x0, full = ww * (y1 - y0);
         const TileTest tt = make_tile_test(s.px, s.py, s.ca, s.cb, s.cc, s.op);
         uint32_t run = base + (idx ? s_incl[idx - 1] : 0u);

@@ -72,6 +72,7 @@ struct alignas(8) TileRec {
 static_assert(sizeof(TileRec) == 8, "TileRec must be 8 bytes");
 constexpr uint32_t kTileRecBig = 0x80000000u;
 constexpr int kTileRecMaskTiles = 32;
+constexpr uint32_t kTilesPending = 0xffffffffu;   // Splat::tiles of a large rect whose count the caller still has to fill in
 GSR_HD uint32_t tilerec_count(const TileRec& r) { return (r.rect & kTileRecBig) ? r.mask : (uint32_t)gsr_popc(r.mask); }
 
 struct Camera {
@@ -261,6 +262,30 @@ GSR_HD bool tile_accept(const TileTest& t, int tx, int ty, int W, int H)
     return box_accept(t, bx0, by0, bx1, by1);
 }
 
+// The 3-sigma tile rect of the reference, shrunk to the axis-aligned bounding box of the region where the Gaussian can
+// contribute at all: { q <= tau + slack } is an ellipse with half extents sqrt((tau + slack) cov_xx), sqrt(.. cov_yy)
+// (cov = inverse of the conic), which is much smaller than ceil(3 sqrt(lambda_max)) for faint or elongated splats.
+// Only tiles inside the intersection can pass the exact test, so the set of accepted tiles is unchanged -- the count
+// loop and the per-wave emission of large rects just visit fewer candidates.  Everything is computed from the Splat's
+// own binary32 fields with explicit fmaf so that k_preprocess and k_emit derive the same rect bit for bit.
+GSR_HD void tile_rect_tight(float px, float py, int radius, float ca, float cb, float cc, float op, int W, int H, int tiles_x,
+                            int tiles_y, int& x0, int& y0, int& x1, int& y1)
+{
+    const float ux = px + 0.5f * (float)W, uy = py + 0.5f * (float)H;   // un-centred pixel coordinates
+    tile_rect(ux, uy, radius, tiles_x, tiles_y, x0, y0, x1, y1);
+    const float tau = splat_tau(op);
+    const float hi = tau + 1e-3f * (1.0f + fabsf(tau));
+    const float det = fmaf(ca, cc, -(cb * cb));
+    if (!(hi > 0.f) || !(det > 0.f)) return;   // contributes nowhere (the test rejects every tile) / degenerate conic
+    const float s = hi / det;
+    const float hx = sqrtf(s * cc) * 1.0001f + 1.0f, hy = sqrtf(s * ca) * 1.0001f + 1.0f;   // + a pixel of margin
+    const float inv = 1.0f / kTile;
+    const int bx0 = (int)floorf((ux - hx) * inv), bx1 = (int)floorf((ux + hx) * inv) + 1;
+    const int by0 = (int)floorf((uy - hy) * inv), by1 = (int)floorf((uy + hy) * inv) + 1;
+    x0 = imax(x0, imin(bx0, x1)); x1 = imin(x1, imax(bx1, x0));
+    y0 = imax(y0, imin(by0, y1)); y1 = imin(y1, imax(by1, y0));
+}
+
 GSR_HD uint32_t count_accepted_tiles(float px, float py, float ca, float cb, float cc, float op, int x0, int y0, int x1, int y1,
                                      int W, int H, uint32_t* mask_out = nullptr)
 {
@@ -330,7 +355,7 @@ GSR_HD void splat_sh_color(const Camera& c, const float mean[3], const float* sh
 // sh[k*sh_kstride + ch*sh_cstride] (lets the caller hand either the global [M][3] row or an LDS copy).
 GSR_HD void preprocess_one(const Camera& c, const float mean[3], const float* scale, const float* rot,
                            const float* cov_pre, float opacity, const float* sh, int sh_kstride, int sh_cstride,
-                           const float* color_pre, Splat& out, TileRec* rec = nullptr)
+                           const float* color_pre, Splat& out, TileRec* rec = nullptr, bool defer_big = false)
 {
     typedef double RT;   // see the note above quat_to_rot
     if (rec) { rec->mask = 0u; rec->rect = 1u << 24; }
@@ -368,8 +393,7 @@ GSR_HD void preprocess_one(const Camera& c, const float mean[3], const float* sc
     const float py = (float)((hy * pw * c.H - 1) * (RT)0.5);
     int x0, y0, x1, y1;
     tile_rect(px + 0.5f * (float)c.W, py + 0.5f * (float)c.H, radius, c.tiles_x, c.tiles_y, x0, y0, x1, y1);
-    const int nt = (x1 - x0) * (y1 - y0);
-    if (nt == 0) return;
+    if ((x1 - x0) * (y1 - y0) == 0) return;   // the reference's visibility rule: 3-sigma rect touches no tile
     float col[3] = {0.f, 0.f, 0.f};   // neither colour source given: geometry only, the caller adds the colour (k_preprocess)
     if (color_pre) {
         col[0] = color_pre[0]; col[1] = color_pre[1]; col[2] = color_pre[2];
@@ -382,7 +406,17 @@ GSR_HD void preprocess_one(const Camera& c, const float mean[3], const float* sc
     out.r = col[0]; out.g = col[1]; out.b = col[2];
     out.radius = radius;
     uint32_t mask = 0u;
-    out.tiles = count_accepted_tiles(out.px, out.py, out.ca, out.cb, out.cc, out.op, x0, y0, x1, y1, c.W, c.H, rec ? &mask : nullptr);
+    tile_rect_tight(out.px, out.py, radius, out.ca, out.cb, out.cc, out.op, c.W, c.H, c.tiles_x, c.tiles_y, x0, y0, x1, y1);
+    const int nt = (x1 - x0) * (y1 - y0);
+    if (defer_big && nt > kTileRecMaskTiles) {
+        // a rect of hundreds of tiles in ONE lane's loop stalls its whole wave: the caller (k_preprocess) counts these
+        // with all 64 lanes instead; kTilesPending marks them
+        out.tiles = kTilesPending;
+        if (rec) { rec->mask = 0u; rec->rect = (uint32_t)x0 | ((uint32_t)y0 << 12) | kTileRecBig; }
+        return;
+    }
+    out.tiles = nt ? count_accepted_tiles(out.px, out.py, out.ca, out.cb, out.cc, out.op, x0, y0, x1, y1, c.W, c.H, rec ? &mask : nullptr)
+                   : 0u;
     if (rec) {   // (tile coordinates fit 12 bits: check_common limits the image to 65535 tiles)
         const bool big = nt > kTileRecMaskTiles;
         rec->mask = big ? out.tiles : mask;
