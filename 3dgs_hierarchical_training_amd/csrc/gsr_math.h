@@ -567,106 +567,119 @@ struct CamGrads {
     float vm[16], pm[16], cam[3];
 };
 
-GSR_HD void gauss_backward(const Camera& c, const float mean[3], const float* scale, const float* rot,
-                           const float* cov_pre, float g_px, float g_py, float gA, float gB, float gC, float g_z,
-                           GaussGrads& o, CamGrads* cg = nullptr)
+// RT = arithmetic of the chain.  The conic -> cov2D step cancels catastrophically for needle-shaped splats
+// (-C^2 gA + B C gB - B^2 gC over det^2 with det << A C): in binary32 a 20:1 splat loses three digits of dL/dmean, so the
+// kernels run the chain in float64 like the forward projection (K9 is HBM-bound; the extra VALU time hides under it).
+template <typename RT>
+GSR_HD void gauss_backward_t(const Camera& c, const float mean[3], const float* scale, const float* rot,
+                             const float* cov_pre, float g_px, float g_py, float gA_, float gB_, float gC_, float g_z_,
+                             GaussGrads& o, CamGrads* cg)
 {
-    const float X = mean[0], Y = mean[1], Z = mean[2];
-    float cov[6];
+    const RT gA = gA_, gB = gB_, gC = gC_, g_z = g_z_;
+    const RT X = mean[0], Y = mean[1], Z = mean[2];
+    RT cov[6];
     if (cov_pre) {
         for (int k = 0; k < 6; k++) cov[k] = cov_pre[k];
     } else {
-        cov3d_from_scale_rot<float>(scale, c.scale_mod, rot, cov);
+        cov3d_from_scale_rot<RT>(scale, c.scale_mod, rot, cov);
     }
-    ProjFrame<float> f;
-    proj_frame<float>(c, X, Y, Z, f);
-    float a, b, cc, Sm0[3], Sm1[3];
-    cov2d_from_frame<float>(f, cov, a, b, cc, Sm0, Sm1);
+    ProjFrame<RT> f;
+    proj_frame<RT>(c, X, Y, Z, f);
+    RT a, b, cc, Sm0[3], Sm1[3];
+    cov2d_from_frame<RT>(f, cov, a, b, cc, Sm0, Sm1);
     // conic -> cov2D (guard 1e-7 recalled from the public module)
-    const float det = a * cc - b * b;
-    const float d2i = 1.0f / (det * det + 1e-7f);
-    const float ga = d2i * (-cc * cc * gA + b * cc * gB - b * b * gC);
-    const float gb = d2i * (2.f * b * cc * gA - (det + 2.f * b * b) * gB + 2.f * a * b * gC);
-    const float gc = d2i * (-b * b * gA + a * b * gB - a * a * gC);
+    const RT det = a * cc - b * b;
+    const RT d2i = (RT)1.0 / (det * det + (RT)1e-7);
+    const RT ga = d2i * (-cc * cc * gA + b * cc * gB - b * b * gC);
+    const RT gb = d2i * ((RT)2. * b * cc * gA - (det + (RT)2. * b * b) * gB + (RT)2. * a * b * gC);
+    const RT gc = d2i * (-b * b * gA + a * b * gB - a * a * gC);
     // cov2D -> Sigma (6 unique entries)
-    const float* m0 = f.m0; const float* m1 = f.m1;
-    float gS[6];
+    const RT* m0 = f.m0; const RT* m1 = f.m1;
+    RT gS[6];
     gS[0] = ga * m0[0] * m0[0] + gb * m0[0] * m1[0] + gc * m1[0] * m1[0];
     gS[3] = ga * m0[1] * m0[1] + gb * m0[1] * m1[1] + gc * m1[1] * m1[1];
     gS[5] = ga * m0[2] * m0[2] + gb * m0[2] * m1[2] + gc * m1[2] * m1[2];
-    gS[1] = 2.f * ga * m0[0] * m0[1] + gb * (m0[0] * m1[1] + m0[1] * m1[0]) + 2.f * gc * m1[0] * m1[1];
-    gS[2] = 2.f * ga * m0[0] * m0[2] + gb * (m0[0] * m1[2] + m0[2] * m1[0]) + 2.f * gc * m1[0] * m1[2];
-    gS[4] = 2.f * ga * m0[1] * m0[2] + gb * (m0[1] * m1[2] + m0[2] * m1[1]) + 2.f * gc * m1[1] * m1[2];
+    gS[1] = (RT)2. * ga * m0[0] * m0[1] + gb * (m0[0] * m1[1] + m0[1] * m1[0]) + (RT)2. * gc * m1[0] * m1[1];
+    gS[2] = (RT)2. * ga * m0[0] * m0[2] + gb * (m0[0] * m1[2] + m0[2] * m1[0]) + (RT)2. * gc * m1[0] * m1[2];
+    gS[4] = (RT)2. * ga * m0[1] * m0[2] + gb * (m0[1] * m1[2] + m0[2] * m1[1]) + (RT)2. * gc * m1[1] * m1[2];
     // cov2D -> M rows -> J -> view-space mean
-    float gm0[3], gm1[3];
-    for (int r = 0; r < 3; r++) { gm0[r] = 2.f * ga * Sm0[r] + gb * Sm1[r]; gm1[r] = 2.f * gc * Sm1[r] + gb * Sm0[r]; }
+    RT gm0[3], gm1[3];
+    for (int r = 0; r < 3; r++) { gm0[r] = (RT)2. * ga * Sm0[r] + gb * Sm1[r]; gm1[r] = (RT)2. * gc * Sm1[r] + gb * Sm0[r]; }
     const float* vm = c.vm;
-    float gJ00 = 0.f, gJ02 = 0.f, gJ11 = 0.f, gJ12 = 0.f;
+    RT gJ00 = (RT)0., gJ02 = (RT)0., gJ11 = (RT)0., gJ12 = (RT)0.;
     for (int k = 0; k < 3; k++) {
         gJ00 += gm0[k] * vm[k * 4 + 0]; gJ02 += gm0[k] * vm[k * 4 + 2];
         gJ11 += gm1[k] * vm[k * 4 + 1]; gJ12 += gm1[k] * vm[k * 4 + 2];
     }
-    const float iz = 1.0f / f.t2, tz2 = iz * iz, tz3 = tz2 * iz;
-    const float gt0 = f.xmul * -c.fx * tz2 * gJ02;
-    const float gt1 = f.ymul * -c.fy * tz2 * gJ12;
-    const float gt2 = -c.fx * tz2 * gJ00 - c.fy * tz2 * gJ11 + 2.f * c.fx * f.t0 * tz3 * gJ02 + 2.f * c.fy * f.t1 * tz3 * gJ12;
+    const RT iz = (RT)1.0 / f.t2, tz2 = iz * iz, tz3 = tz2 * iz;
+    const RT gt0 = f.xmul * -c.fx * tz2 * gJ02;
+    const RT gt1 = f.ymul * -c.fy * tz2 * gJ12;
+    const RT gt2 = -c.fx * tz2 * gJ00 - c.fy * tz2 * gJ11 + (RT)2. * c.fx * f.t0 * tz3 * gJ02 + (RT)2. * c.fy * f.t1 * tz3 * gJ12;
     // screen position -> mean
     const float* pm = c.pm;
-    const float hx = pm[0] * X + pm[4] * Y + pm[8] * Z + pm[12];
-    const float hy = pm[1] * X + pm[5] * Y + pm[9] * Z + pm[13];
-    const float hw = pm[3] * X + pm[7] * Y + pm[11] * Z + pm[15];
-    const float mw = 1.0f / (hw + 1e-7f);
-    const float gnx = g_px * 0.5f * c.W, gny = g_py * 0.5f * c.H;
-    o.mean2d[0] = gnx; o.mean2d[1] = gny;
+    const RT hx = pm[0] * X + pm[4] * Y + pm[8] * Z + pm[12];
+    const RT hy = pm[1] * X + pm[5] * Y + pm[9] * Z + pm[13];
+    const RT hw = pm[3] * X + pm[7] * Y + pm[11] * Z + pm[15];
+    const RT mw = (RT)1.0 / (hw + (RT)1e-7);
+    const RT gnx = g_px * (RT)0.5 * c.W, gny = g_py * (RT)0.5 * c.H;
+    o.mean2d[0] = (float)gnx; o.mean2d[1] = (float)gny;
     for (int k = 0; k < 3; k++) {
-        float d = vm[k * 4 + 0] * gt0 + vm[k * 4 + 1] * gt1 + vm[k * 4 + 2] * (gt2 + g_z);
+        RT d = vm[k * 4 + 0] * gt0 + vm[k * 4 + 1] * gt1 + vm[k * 4 + 2] * (gt2 + g_z);
         d += (pm[k * 4 + 0] * mw - pm[k * 4 + 3] * hx * mw * mw) * gnx + (pm[k * 4 + 1] * mw - pm[k * 4 + 3] * hy * mw * mw) * gny;
-        o.mean[k] = d;
+        o.mean[k] = (float)d;
     }
     if (cg) {
-        const float ph[4] = {X, Y, Z, 1.f};
-        const float gtv[3] = {gt0, gt1, gt2 + g_z};
+        const RT ph[4] = {X, Y, Z, (RT)1.};
+        const RT gtv[3] = {gt0, gt1, gt2 + g_z};
         for (int k = 0; k < 4; k++) {
             // view-space position t = V p_h (rows 0..2) and the depth feature (row 2, folded into gtv[2])
-            cg->vm[k * 4 + 0] = gtv[0] * ph[k]; cg->vm[k * 4 + 1] = gtv[1] * ph[k]; cg->vm[k * 4 + 2] = gtv[2] * ph[k];
-            cg->vm[k * 4 + 3] = 0.f;
+            cg->vm[k * 4 + 0] = (float)(gtv[0] * ph[k]); cg->vm[k * 4 + 1] = (float)(gtv[1] * ph[k]); cg->vm[k * 4 + 2] = (float)(gtv[2] * ph[k]);
+            cg->vm[k * 4 + 3] = (float)((RT)0.);
             // homogeneous clip position (rows 0, 1, 3 of the full projection; row 2 is unused by the rasterizer)
-            cg->pm[k * 4 + 0] = gnx * mw * ph[k]; cg->pm[k * 4 + 1] = gny * mw * ph[k]; cg->pm[k * 4 + 2] = 0.f;
-            cg->pm[k * 4 + 3] = -(gnx * hx + gny * hy) * mw * mw * ph[k];
+            cg->pm[k * 4 + 0] = (float)(gnx * mw * ph[k]); cg->pm[k * 4 + 1] = (float)(gny * mw * ph[k]); cg->pm[k * 4 + 2] = (float)((RT)0.);
+            cg->pm[k * 4 + 3] = (float)(-(gnx * hx + gny * hy) * mw * mw * ph[k]);
         }
         for (int k = 0; k < 3; k++) {   // rotation block through M = J Wr
-            cg->vm[k * 4 + 0] += gm0[k] * f.J00;
-            cg->vm[k * 4 + 1] += gm1[k] * f.J11;
-            cg->vm[k * 4 + 2] += gm0[k] * f.J02 + gm1[k] * f.J12;
+            cg->vm[k * 4 + 0] += (float)(gm0[k] * f.J00);
+            cg->vm[k * 4 + 1] += (float)(gm1[k] * f.J11);
+            cg->vm[k * 4 + 2] += (float)(gm0[k] * f.J02 + gm1[k] * f.J12);
         }
-        cg->cam[0] = 0.f; cg->cam[1] = 0.f; cg->cam[2] = 0.f;
+        cg->cam[0] = (RT)0.; cg->cam[1] = (RT)0.; cg->cam[2] = (RT)0.;
     }
-    for (int k = 0; k < 6; k++) o.cov[k] = gS[k];
-    for (int k = 0; k < 3; k++) o.scale[k] = 0.f;
-    for (int k = 0; k < 4; k++) o.rot[k] = 0.f;
+    for (int k = 0; k < 6; k++) o.cov[k] = (float)gS[k];
+    for (int k = 0; k < 3; k++) o.scale[k] = (RT)0.;
+    for (int k = 0; k < 4; k++) o.rot[k] = (RT)0.;
     if (!cov_pre) {
-        float R[9];
-        quat_to_rot<float>(rot, R);
-        const float sv[3] = {c.scale_mod * scale[0], c.scale_mod * scale[1], c.scale_mod * scale[2]};
-        const float Gf[9] = {gS[0], 0.5f * gS[1], 0.5f * gS[2], 0.5f * gS[1], gS[3], 0.5f * gS[4], 0.5f * gS[2], 0.5f * gS[4], gS[5]};
-        float gR[9];
+        RT R[9];
+        quat_to_rot<RT>(rot, R);
+        const RT sv[3] = {c.scale_mod * scale[0], c.scale_mod * scale[1], c.scale_mod * scale[2]};
+        const RT Gf[9] = {gS[0], (RT)0.5 * gS[1], (RT)0.5 * gS[2], (RT)0.5 * gS[1], gS[3], (RT)0.5 * gS[4], (RT)0.5 * gS[2], (RT)0.5 * gS[4], gS[5]};
+        RT gR[9];
         for (int bcol = 0; bcol < 3; bcol++) {
-            float gs = 0.f;
+            RT gs = (RT)0.;
             for (int arow = 0; arow < 3; arow++) {
-                float acc = 0.f;
+                RT acc = (RT)0.;
                 for (int k = 0; k < 3; k++) acc += Gf[arow * 3 + k] * R[k * 3 + bcol];
-                const float gL = 2.f * acc * sv[bcol];   // dL/dL[arow][bcol]
+                const RT gL = (RT)2. * acc * sv[bcol];   // dL/dL[arow][bcol]
                 gs += gL * R[arow * 3 + bcol];
                 gR[arow * 3 + bcol] = gL * sv[bcol];
             }
-            o.scale[bcol] = gs * c.scale_mod;
+            o.scale[bcol] = (float)(gs * c.scale_mod);
         }
-        const float r = rot[0], x = rot[1], y = rot[2], z = rot[3];
-        o.rot[0] = 2.f * (-z * gR[1] + y * gR[2] + z * gR[3] - x * gR[5] - y * gR[6] + x * gR[7]);
-        o.rot[1] = 2.f * (y * gR[1] + z * gR[2] + y * gR[3] - 2.f * x * gR[4] - r * gR[5] + z * gR[6] + r * gR[7] - 2.f * x * gR[8]);
-        o.rot[2] = 2.f * (-2.f * y * gR[0] + x * gR[1] + r * gR[2] + x * gR[3] + z * gR[5] - r * gR[6] + z * gR[7] - 2.f * y * gR[8]);
-        o.rot[3] = 2.f * (-2.f * z * gR[0] - r * gR[1] + x * gR[2] + r * gR[3] - 2.f * z * gR[4] + y * gR[5] + x * gR[6] + y * gR[7]);
+        const RT r = rot[0], x = rot[1], y = rot[2], z = rot[3];
+        o.rot[0] = (RT)2. * (-z * gR[1] + y * gR[2] + z * gR[3] - x * gR[5] - y * gR[6] + x * gR[7]);
+        o.rot[1] = (RT)2. * (y * gR[1] + z * gR[2] + y * gR[3] - (RT)2. * x * gR[4] - r * gR[5] + z * gR[6] + r * gR[7] - (RT)2. * x * gR[8]);
+        o.rot[2] = (RT)2. * (-(RT)2. * y * gR[0] + x * gR[1] + r * gR[2] + x * gR[3] + z * gR[5] - r * gR[6] + z * gR[7] - (RT)2. * y * gR[8]);
+        o.rot[3] = (RT)2. * (-(RT)2. * z * gR[0] - r * gR[1] + x * gR[2] + r * gR[3] - (RT)2. * z * gR[4] + y * gR[5] + x * gR[6] + y * gR[7]);
     }
+}
+
+
+GSR_HD void gauss_backward(const Camera& c, const float mean[3], const float* scale, const float* rot,
+                           const float* cov_pre, float g_px, float g_py, float gA, float gB, float gC, float g_z,
+                           GaussGrads& o, CamGrads* cg = nullptr)
+{
+    gauss_backward_t<double>(c, mean, scale, rot, cov_pre, g_px, g_py, gA, gB, gC, g_z, o, cg);
 }
 
 }  // namespace gsr
