@@ -428,12 +428,17 @@ __device__ __forceinline__ uint32_t block_inclusive_scan_256(uint32_t v, uint32_
 }
 
 __global__ __launch_bounds__(kEmitThreads) void k_tile_counts(int N, const uint32_t* __restrict__ sorted_gid,
-                                                              const TileRec* __restrict__ tilerec, uint32_t* __restrict__ block_sums)
+                                                              const TileRec* __restrict__ tilerec, uint32_t* __restrict__ block_sums,
+                                                              TileRec* __restrict__ sorted_rec)
 {
     __shared__ uint32_t s_wave[4];
     const int j = blockIdx.x * kEmitThreads + threadIdx.x;
     uint32_t t = 0;
-    if (j < N) t = tilerec_count(tilerec[sorted_gid[j]]);
+    if (j < N) {   // the one random gather of the records: k_emit reads them back in depth order, coalesced
+        const TileRec r = tilerec[sorted_gid[j]];
+        sorted_rec[j] = r;
+        t = tilerec_count(r);
+    }
     uint32_t total;
     block_inclusive_scan_256(t, s_wave, total);
     if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
@@ -516,7 +521,7 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit(int N, int W, int H, int 
     r.mask = 0u; r.rect = 1u << 24;
     if (j < N) {
         g = sorted_gid[j];
-        r = tilerec[g];
+        r = tilerec[j];   // already in depth order (k_tile_counts)
     }
     const uint32_t cnt = tilerec_count(r);
     uint32_t total;
@@ -1592,7 +1597,7 @@ static GeomLayout geom_layout(int32_t N)
 }
 
 struct FwdScratch {   // N-sized scratch of the forward
-    size_t dkey, gid, dkey_alt, gid_alt, ntiles, block_sums, total, sort;
+    size_t dkey, gid, dkey_alt, gid_alt, ntiles, srec, block_sums, total, sort;
     size_t bytes;
 };
 static FwdScratch fwd_scratch_layout(int32_t N)
@@ -1605,6 +1610,7 @@ static FwdScratch fwd_scratch_layout(int32_t N)
     s.dkey_alt = o; o += align256(n * 4);
     s.gid_alt = o; o += align256(n * 4);
     s.ntiles = o; o += align256(n * sizeof(TileRec));
+    s.srec = o; o += align256(n * sizeof(TileRec));
     s.block_sums = o; o += align256(((n + kEmitThreads - 1) / kEmitThreads) * 4);
     s.total = o; o += 256;
     s.sort = o; o += radix_scratch_bytes((uint32_t)n);
@@ -1799,7 +1805,7 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
         {
             ProfScope ps(P_EMIT, st);
             hipLaunchKernelGGL(k_emit, dim3(nb), dim3(kEmitThreads), 0, st, N, W, H, tiles_x, tiles_y, sorted_gid, splat,
-                               reinterpret_cast<const TileRec*>(fs + L.ntiles), block_sums, tkey, v0,
+                               reinterpret_cast<const TileRec*>(fs + L.srec), block_sums, tkey, v0,
                                (uint32_t)capacity);
         }
         int in_alt = 0;
@@ -1917,7 +1923,8 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
             zj.p[1] = staged; zj.words[1] = (uint32_t)T * 4u;
             if (bs) { zj.p[2] = bs + S.sort; zj.words[2] = kOnesweepHeadWords; }
         }
-        hipLaunchKernelGGL(k_tile_counts, dim3(nb), dim3(kEmitThreads), 0, st, N, sorted_gid, ntiles, block_sums);
+        hipLaunchKernelGGL(k_tile_counts, dim3(nb), dim3(kEmitThreads), 0, st, N, sorted_gid, ntiles, block_sums,
+                           reinterpret_cast<TileRec*>(fs + L.srec));
         hipLaunchKernelGGL(k_block_scan, dim3(1), dim3(1024), 0, st, block_sums, nb, total, zj);
     }
     GSR_HIP(hipGetLastError());
