@@ -191,4 +191,41 @@ void hostemu_backward(EmuCtx* c, const float* g_color, const float* g_depth, con
 }
 
 void hostemu_free(EmuCtx* c) { delete c; }
+
+// Property check for tile_rect_tight (gsr_math.h): for `count` pseudo-random splats -- including needle-shaped, faint,
+// huge and off-screen ones -- every tile of the reference's 3-sigma rect that passes the exact test must lie inside the
+// tight rect.  Returns the number of accepted tiles found OUTSIDE the tight rect (must be 0); *checked = accepted tiles.
+long long hostemu_check_tight_rect(int count, unsigned seed, int W, int H, long long* checked)
+{
+    const int tiles_x = (W + kTile - 1) / kTile, tiles_y = (H + kTile - 1) / kTile;
+    unsigned long long st = seed * 6364136223846793005ull + 1442695040888963407ull;
+    auto rnd = [&]() { st = st * 6364136223846793005ull + 1442695040888963407ull; return (float)((st >> 40) & 0xffffff) / 16777216.0f; };
+    long long bad = 0, seen = 0;
+    for (int i = 0; i < count; i++) {
+        const float px = (rnd() * 1.4f - 0.2f) * W - 0.5f * W, py = (rnd() * 1.4f - 0.2f) * H - 0.5f * H;   // centred, some off-screen
+        const float s1 = expf(rnd() * 7.0f - 1.0f), ratio = expf(rnd() * 4.0f);                         // sigma 0.4 .. 400 px, up to 55:1
+        const float s2 = s1 / ratio, th = rnd() * 3.14159265f;
+        const float c = cosf(th), sn = sinf(th);
+        const float a = c * c * s1 * s1 + sn * sn * s2 * s2 + 0.3f, d = sn * sn * s1 * s1 + c * c * s2 * s2 + 0.3f, b = c * sn * (s1 * s1 - s2 * s2);
+        const float det = a * d - b * b;
+        const float ca = d / det, cb = -b / det, cc = a / det;   // conic = inverse covariance
+        const float mid = 0.5f * (a + d), disc = sqrtf(fmaxf(0.1f, mid * mid - det));
+        const int radius = (int)ceilf(3.0f * sqrtf(mid + disc));
+        const float r3 = rnd();
+        const float op = r3 < 0.2f ? 0.0039f + 0.002f * rnd() : (r3 < 0.6f ? 0.01f + 0.1f * rnd() : rnd());
+        int x0, y0, x1, y1, tx0, ty0, tx1, ty1;
+        tile_rect(px + 0.5f * W, py + 0.5f * H, radius, tiles_x, tiles_y, x0, y0, x1, y1);
+        tile_rect_tight(px, py, radius, ca, cb, cc, op, W, H, tiles_x, tiles_y, tx0, ty0, tx1, ty1);
+        const TileTest tt = make_tile_test(px, py, ca, cb, cc, op);
+        for (int y = y0; y < y1; y++)
+            for (int x = x0; x < x1; x++)
+                if (tile_accept(tt, x, y, W, H)) {
+                    seen++;
+                    if (!(x >= tx0 && x < tx1 && y >= ty0 && y < ty1)) bad++;
+                }
+    }
+    if (checked) *checked = seen;
+    return bad;
+}
+
 }
