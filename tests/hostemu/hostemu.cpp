@@ -228,4 +228,45 @@ long long hostemu_check_tight_rect(int count, unsigned seed, int W, int H, long 
     return bad;
 }
 
+
+// Property check for the exact tile culling (gsr_math.h box_accept): whenever ANY pixel centre of a box receives a
+// contribution from the splat by the blend's own rule (pair_alpha: power <= 0 and o exp(power) >= 1/255), box_accept must
+// say yes -- for tiles (the culling of the binning), 16x8 halves (reach bits of the backward) and arbitrary sub-boxes.
+// Returns the number of violations (must be 0); *checked = boxes that had a contributing pixel.
+long long hostemu_check_box_accept(int count, unsigned seed, long long* checked)
+{
+    unsigned long long st = seed * 6364136223846793005ull + 1442695040888963407ull;
+    auto rnd = [&]() { st = st * 6364136223846793005ull + 1442695040888963407ull; return (float)((st >> 40) & 0xffffff) / 16777216.0f; };
+    long long bad = 0, seen = 0;
+    for (int i = 0; i < count; i++) {
+        const float px = (rnd() - 0.5f) * 400.f, py = (rnd() - 0.5f) * 400.f;
+        const float s1 = expf(rnd() * 5.0f - 1.0f), ratio = expf(rnd() * 3.5f), s2 = s1 / ratio, th = rnd() * 3.14159265f;
+        const float c = cosf(th), sn = sinf(th);
+        const float a = c * c * s1 * s1 + sn * sn * s2 * s2 + 0.3f, d = sn * sn * s1 * s1 + c * c * s2 * s2 + 0.3f, b = c * sn * (s1 * s1 - s2 * s2);
+        const float det = a * d - b * b;
+        const float ca = d / det, cb = -b / det, cc = a / det;
+        const float r3 = rnd();
+        const float op = r3 < 0.3f ? 0.0039f + 0.004f * rnd() : (r3 < 0.6f ? 0.01f + 0.1f * rnd() : rnd());
+        const TileTest tt = make_tile_test(px, py, ca, cb, cc, op);
+        // a box near the 1/255 contour of the splat (that is where a wrong reject would hide)
+        const float reach = sqrtf(fmaxf(0.f, 2.f * logf(255.f * op))) * s1;
+        const float ang = rnd() * 6.2831853f, dist = reach * (0.6f + 0.8f * rnd());
+        const int bw = 1 + (int)(rnd() * 16.f), bh = 1 + (int)(rnd() * 16.f);
+        const float bx0 = floorf(px + dist * cosf(ang)) + 0.5f, by0 = floorf(py + dist * sinf(ang)) + 0.5f;   // pixel centres at k + 0.5
+        const float bx1 = bx0 + (float)(bw - 1), by1 = by0 + (float)(bh - 1);
+        bool any = false;
+        for (int y = 0; y < bh && !any; y++)
+            for (int x = 0; x < bw; x++) {
+                float G, dx, dy;
+                if (pair_alpha(bx0 + (float)x, by0 + (float)y, px, py, ca, cb, cc, op, G, dx, dy) > 0.f) { any = true; break; }
+            }
+        if (any) {
+            seen++;
+            if (!box_accept(tt, bx0, by0, bx1, by1)) bad++;
+        }
+    }
+    if (checked) *checked = seen;
+    return bad;
+}
+
 }
