@@ -20,8 +20,8 @@ W = H = 17          # odd: the principal point falls exactly on the centre of pi
 CX = CY = 8
 
 
-def _render(z, scale, opacity, color, bg=(0.0, 0.0, 0.0), order=None):
-    """Isotropic Gaussians on the optical axis of the identity-pose camera of synthetic.make_camera."""
+def axis_kwargs(z, scale, opacity, color, bg=(0.0, 0.0, 0.0)):
+    """kwargs (+ camera) of isotropic Gaussians on the optical axis of the identity-pose camera of synthetic.make_camera."""
     cam = parity.syn.make_camera(W, H)
     n = len(z)
     means = torch.tensor([[0.0, 0.0, zi] for zi in z], dtype=torch.float32)
@@ -31,6 +31,11 @@ def _render(z, scale, opacity, color, bg=(0.0, 0.0, 0.0), order=None):
               colors_precomp=torch.tensor(color, dtype=torch.float32).view(n, 3),
               scales=torch.tensor([[s, s, s] for s in scale], dtype=torch.float32),
               rotations=torch.tensor([[1.0, 0.0, 0.0, 0.0]] * n, dtype=torch.float32))
+    return kw, cam
+
+
+def _render(z, scale, opacity, color, bg=(0.0, 0.0, 0.0)):
+    kw, cam = axis_kwargs(z, scale, opacity, color, bg)
     o = binding.OracleRender(**kw)
     o.forward()
     return o, cam
@@ -91,14 +96,17 @@ def test_front_to_back_compositing_order():
 
 
 def test_transmittance_stop():
-    """With alpha clamped to 0.99, T = 1 -> 1e-2 -> 1e-4; the third splat would leave T (1 - a) = 1e-6 < 1e-4, so it (and
-    everything behind it) is not blended: the pixel keeps T = 1e-4 and shows nothing of splats 3 and 4."""
-    z = [1.0, 2.0, 3.0, 4.0]
-    cols = [(1.0, 0.0, 0.0), (0.0, 1.0, 0.0), (0.0, 0.0, 1.0), (0.0, 0.0, 1.0)]
-    o, _ = _render(z, [0.3] * 4, [1.0] * 4, cols)
-    assert abs(o.alpha[0, CY, CX] - (0.99 + 0.99 * 0.01)) < 1e-7
+    """alpha = 0.95 each: T = 1 -> 5e-2 -> 2.5e-3 -> 1.25e-4; the fourth splat would leave T (1 - a) = 6.25e-6 < 1e-4, so it
+    (and everything behind it) is not blended: the pixel keeps T = 1.25e-4 and shows nothing of splats 4 and 5.
+    (0.95 on purpose: with the clamp value 0.99 the second product is 1e-4 in exact arithmetic and 9.99998e-5 in
+    binary32 -- a knife edge on which a float64 and a binary32 implementation legitimately disagree.)"""
+    z = [1.0, 2.0, 3.0, 4.0, 5.0]
+    cols = [(1.0, 0.0, 0.0), (0.0, 1.0, 0.0), (1.0, 1.0, 0.0), (0.0, 0.0, 1.0), (0.0, 0.0, 1.0)]
+    o, _ = _render(z, [0.3] * 5, [0.95] * 5, cols)
+    w = [0.95, 0.95 * 0.05, 0.95 * 0.0025]
+    assert abs(o.alpha[0, CY, CX] - sum(w)) < 1e-6
     assert o.color[2, CY, CX] == 0.0
-    assert abs(o.color[0, CY, CX] - 0.99) < 1e-7 and abs(o.color[1, CY, CX] - 0.0099) < 1e-7
+    assert abs(o.color[0, CY, CX] - (w[0] + w[2])) < 1e-6 and abs(o.color[1, CY, CX] - (w[1] + w[2])) < 1e-6
 
 
 def test_pixel_coordinate_convention():
