@@ -211,8 +211,9 @@ def main():
     roofline = {"kernel": "k_blend_fwd_w", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                 "traffic_source": "profiles/r01_pmc_blend.json (rocprofv3 --pmc, separate passes)" if traffic else None,
-                "traffic_note": "includes ~105 MB of per-pixel checkpoint writes (every 128 instances) that let the backward "
-                                "blend run one workgroup per (tile, batch); 81 MB without them" if traffic else None,
+                "traffic_note": "81 MB with one band of tiles per XCD; the interleaved tile map (load balance) lets several XCD "
+                                "L2s fetch the same splat records (+~80 MB of reads), and the per-pixel checkpoints for the "
+                                "split backward add ~25 MB of writes; the kernel is VALU-bound either way" if traffic else None,
                 "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": blend_ms,
                 "launches_timed": prof["blend_fwd"][1], "R": R, "R_eff": R_eff, "P": P, "T": T}
     res = {
