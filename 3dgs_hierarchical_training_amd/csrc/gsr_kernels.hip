@@ -708,6 +708,28 @@ __global__ __launch_bounds__(256 / PPT) void k_blend_fwd(int W, int H, int tiles
     }
 }
 
+// tile handled by slot `s` of XCD `x` (0..7).  map 0 "banded": XCD x owns the contiguous tiles [x per, (x+1) per);
+// map 1 "interleaved": tile t lives on XCD t % 8; map 2 "block-interleaved": 2x2 blocks of tiles are dealt round-robin to
+// the XCDs (block j on XCD j % 8), which still spreads a spatially coherent hot region over all XCDs but keeps most of
+// the tiles a splat touches behind one L2.  Returns -1 for a slot beyond the image.
+__device__ __forceinline__ int slot_tile(int map, int x, int s, int T, int tiles_x)
+{
+    if (map == 0) { const int per = (T + 7) >> 3; const int t = x * per + s; return (s < per && t < T) ? t : -1; }
+    if (map == 1) { const int t = s * 8 + x; return t < T ? t : -1; }
+    const int tiles_y = T / tiles_x, bx_n = (tiles_x + 1) >> 1, by_n = (tiles_y + 1) >> 1;
+    const int j = (s >> 2) * 8 + x, w = s & 3;
+    if (j >= bx_n * by_n) return -1;
+    const int tx = 2 * (j % bx_n) + (w & 1), ty = 2 * (j / bx_n) + (w >> 1);
+    return (tx < tiles_x && ty < tiles_y) ? ty * tiles_x + tx : -1;
+}
+// slots per XCD that cover every tile under `map`
+static inline int slots_per_xcd(int map, int T, int tiles_x)
+{
+    if (map != 2) return (T + 7) / 8;
+    const int tiles_y = T / tiles_x, nblk = ((tiles_x + 1) / 2) * ((tiles_y + 1) / 2);
+    return 4 * ((nblk + 7) / 8);
+}
+
 // ------------------------------------------------------------------------------------------------
 // K7 (wave-per-sub-tile variant).  One 64-lane wave = one workgroup = one 8x8 pixel block; the four waves of a
 // tile are independent: each stages the tile's list itself in batches of 64 (the gathers of the other three hit
@@ -727,12 +749,10 @@ __global__ __launch_bounds__(64) void k_blend_fwd_w(int W, int H, int tiles_x, i
     __shared__ float4 s_a[2][NT], s_b[2][NT], s_c[2][NT];
     const int per = (T + 7) >> 3;
     const int kslot = blockIdx.x >> 3;
-    // interleaved (default): tile t lives on XCD t % 8, so a spatially coherent hot region -- real scenes concentrate
-    // their Gaussians on a few hundred tiles -- is spread over all eight XCDs; banded: XCD x owns tiles
-    // [x per, (x+1) per) (neighbours share an L2).  A tile's four waves share an XCD either way.
-    const int tile = interleave ? (kslot >> 2) * 8 + (int)(blockIdx.x & 7) : (int)(blockIdx.x & 7) * per + (kslot >> 2);
+    // which tile this XCD slot works on: see slot_tile (a tile's four waves share an XCD under every map)
+    const int tile = slot_tile(interleave, (int)(blockIdx.x & 7), kslot >> 2, T, tiles_x);
     const int sub = kslot & 3;
-    if (tile >= T || (kslot >> 2) >= per) return;
+    if (tile < 0) return;
     const int lane = threadIdx.x;
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int px = tx * kTile + (sub & 1) * 8 + (lane & 7);
@@ -1055,7 +1075,7 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(int W, int H, int tiles_x, i
                                                     const float* __restrict__ g_color, const float* __restrict__ g_depth,
                                                     const float* __restrict__ g_alpha, float* __restrict__ ggrad, int interleave,
                                                     const float* __restrict__ ckpt, int split, int kCkptFirst,
-                                                    const uint32_t* __restrict__ staged4)
+                                                    const uint32_t* __restrict__ staged4, int tpad)
 {
     constexpr int NT = 128, NW = 2, NV = HAS_DA ? 10 : 9;
     // single staging buffer: a batch is ~10^4 cycles of compute, so the second barrier per batch is free, and the
@@ -1065,10 +1085,9 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(int W, int H, int tiles_x, i
     __shared__ float s_part[NW][NT][NV];
     __shared__ uint32_t s_max[NW];
     // grid = split x Tpad workgroups: part `spart` of tile `tile` (parts beyond what the tile's depth needs exit)
-    const int tpad = 8 * ((T + 7) / 8);
     const int spart = (int)blockIdx.x / tpad, tb = (int)blockIdx.x - spart * tpad;
-    const int tile = interleave ? tb : xcd_tile(tb, T);   // see k_blend_fwd_w
-    if (tile >= T) return;
+    const int tile = slot_tile(interleave, tb & 7, tb >> 3, T, tiles_x);   // see k_blend_fwd_w
+    if (tile < 0) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int px = tx * kTile + (tid & 15);
@@ -1655,7 +1674,7 @@ static std::atomic<uint64_t> g_r_hint{0};   // capacity for the next speculative
 static int g_speculate = 1;
 static int g_bwd_split = 16; // workgroups a long tile's backward is split over (checkpoints from the forward); 1 = off
 static int g_ckpt_first = 1;  // 128-instance batches of a tile before the forward starts leaving checkpoints
-static int g_tile_map = 1;   // 1: interleaved tile -> XCD map (tile t on XCD t % 8), 0: banded
+static int g_tile_map = 2;   // tile -> XCD map: 2 = 2x2 tile blocks interleaved (default), 1 = tiles interleaved, 0 = banded
 static std::atomic<int> g_spec_overflows{0};
 
 static int check_common(int32_t N, int32_t M, int32_t D, int32_t W, int32_t H)
@@ -1738,7 +1757,7 @@ int gsr_set_option(const char* name, int value)
     if (!strcmp(name, "blend_fwd_ppt")) { if (value < 0 || value > 5) return GSR_ERR_ARG; g_blend_ppt = value; return GSR_OK; }
     if (!strcmp(name, "bwd_split")) { if (value < 0 || value > 64) return GSR_ERR_ARG; g_bwd_split = value ? value : 16; return GSR_OK; }
     if (!strcmp(name, "ckpt_first")) { if (value < 1 || value > 64) return GSR_ERR_ARG; g_ckpt_first = value; return GSR_OK; }
-    if (!strcmp(name, "tile_map")) { g_tile_map = value ? 1 : 0; return GSR_OK; }
+    if (!strcmp(name, "tile_map")) { if (value < 0 || value > 2) return GSR_ERR_ARG; g_tile_map = value; return GSR_OK; }
     if (!strcmp(name, "speculative_binning")) { g_speculate = value ? 1 : 0; return GSR_OK; }
     if (!strcmp(name, "binning_capacity_hint")) { g_r_hint.store(value > 0 ? (uint64_t)value : 0); return GSR_OK; }   // tests: force an overflow
     if (!strcmp(name, "profile")) { g_profile = (value == 2) ? 2 : (value ? 1 : 0); return GSR_OK; }
@@ -1829,7 +1848,7 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
         {
             ProfScope ps(P_BLEND_FWD, st);
             if (ppt == 5)
-                hipLaunchKernelGGL(k_blend_fwd_w, dim3(8 * 4 * ((T + 7) / 8)), dim3(64), 0, st, W, H, tiles_x, T, ranges, list, splat, a->bg,
+                hipLaunchKernelGGL(k_blend_fwd_w, dim3(8 * 4 * slots_per_xcd(g_tile_map, T, tiles_x)), dim3(64), 0, st, W, H, tiles_x, T, ranges, list, splat, a->bg,
                                    a->out_color, a->out_depth, a->out_alpha, img, staged, g_tile_map,
                                    reinterpret_cast<float*>(bin + B.ckpt), g_ckpt_first);
             else if (ppt == 1) launch_blend_fwd<1>(W, H, tiles_x, T, ranges, list, splat, a->bg, a->out_color, a->out_depth, a->out_alpha, img, staged, st);
@@ -2005,15 +2024,16 @@ int gsr_backward(const GsrBackwardArgs* a, void* stream_)
                 else if (ppt == 2) {
             // (checkpoints are written by k_blend_fwd_w only)
             const int split = (g_bwd_split > 1 && (g_blend_ppt == 0 || g_blend_ppt == 5)) ? g_bwd_split : 1;
-            const int grid = split * 8 * ((T + 7) / 8);
+            const int tpad = 8 * slots_per_xcd(g_tile_map, T, tiles_x);
+            const int grid = split * tpad;
             const float* ckpt = reinterpret_cast<const float*>(bin + B.ckpt);
             const uint32_t* staged4 = reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(a->image) + gsr_image_staged_offset(W, H));
             if (a->grad_depth || a->grad_alpha)
                 hipLaunchKernelGGL(k_blend_bwd2<true>, dim3(grid), dim3(128), 0, st, W, H, tiles_x, T, ranges, list, splat, a->bg, img,
-                                   a->grad_color, a->grad_depth, a->grad_alpha, gg, g_tile_map, ckpt, split, g_ckpt_first, staged4);
+                                   a->grad_color, a->grad_depth, a->grad_alpha, gg, g_tile_map, ckpt, split, g_ckpt_first, staged4, tpad);
             else
                 hipLaunchKernelGGL(k_blend_bwd2<false>, dim3(grid), dim3(128), 0, st, W, H, tiles_x, T, ranges, list, splat, a->bg, img,
-                                   a->grad_color, a->grad_depth, a->grad_alpha, gg, g_tile_map, ckpt, split, g_ckpt_first, staged4);
+                                   a->grad_color, a->grad_depth, a->grad_alpha, gg, g_tile_map, ckpt, split, g_ckpt_first, staged4, tpad);
         } else if (ppt == 3) launch_blend_bwd<2>(W, H, tiles_x, T, ranges, list, splat, a->bg, img, a->grad_color, a->grad_depth, a->grad_alpha, gg, st);
         else launch_blend_bwd<4>(W, H, tiles_x, T, ranges, list, splat, a->bg, img, a->grad_color, a->grad_depth, a->grad_alpha, gg, st);
     }

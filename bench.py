@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fwd-ppt", type=int, default=0)
     ap.add_argument("--bwd-ppt", type=int, default=0)
+    ap.add_argument("--tile-map", type=int, default=-1, help="2 = 2x2 tile blocks interleaved over the XCDs (default), 1 = single tiles "
+                    "interleaved, 0 = one band of tiles per XCD")
     ap.add_argument("--sort-algo", type=int, default=-1, help="2 = onesweep for both sorts (default), 1 = onesweep depth sort only, 0 = hist+scan+scatter per pass")
     return ap.parse_args()
 
@@ -115,6 +117,8 @@ def main():
         lib.gsr_set_option(b"blend_bwd_ppt", args.bwd_ppt)
     if args.sort_algo >= 0:
         lib.gsr_set_option(b"sort_algo", args.sort_algo)
+    if args.tile_map >= 0:
+        lib.gsr_set_option(b"tile_map", args.tile_map)
 
     N, W, H, deg = args.gaussians, args.width, args.height, args.sh_degree
     scene = syn.make_scene(N, W, H, sh_degree=deg, seed=rank)
@@ -211,9 +215,9 @@ def main():
     roofline = {"kernel": "k_blend_fwd_w", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                 "traffic_source": "profiles/r01_pmc_blend.json (rocprofv3 --pmc, separate passes)" if traffic else None,
-                "traffic_note": "81 MB with one band of tiles per XCD; the interleaved tile map (load balance) lets several XCD "
-                                "L2s fetch the same splat records (+~80 MB of reads), and the per-pixel checkpoints for the "
-                                "split backward add ~25 MB of writes; the kernel is VALU-bound either way" if traffic else None,
+                "traffic_note": "81 MB with one band of tiles per XCD; dealing 2x2 tile blocks round-robin to the XCDs (load "
+                                "balance) lets neighbouring L2s fetch some splat records twice (+~25 MB of reads), and the "
+                                "per-pixel checkpoints for the split backward add ~25 MB of writes" if traffic else None,
                 "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": blend_ms,
                 "launches_timed": prof["blend_fwd"][1], "R": R, "R_eff": R_eff, "P": P, "T": T}
     res = {

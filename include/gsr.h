@@ -172,8 +172,8 @@ int gsr_version(void);
  *   "bwd_split"            workgroups the backward of one tile is split over (default 16; 1 = off): each part replays a
  *                          run of 128-instance batches, resuming from the per-pixel checkpoints the forward leaves at
  *                          every 128-instance boundary from batch "ckpt_first" (default 1) on
- *   "tile_map"             1 (default) = tiles interleaved over the eight XCDs (tile t on XCD t % 8); 0 = one contiguous
- *                          band of tiles per XCD
+ *   "tile_map"             how tiles are dealt to the eight XCDs: 2 (default) = 2x2 blocks of tiles round-robin, 1 = single
+ *                          tiles round-robin (tile t on XCD t % 8), 0 = one contiguous band of tiles per XCD
  *   "speculative_binning"  1 (default) = R-dependent stages launched against a capacity, R read back late;
  *                          0 = read R, then launch
  *   "binning_capacity_hint" capacity for the next speculative forward (tests: force the overflow re-run)
