@@ -223,6 +223,20 @@ def test_large_splats_take_the_per_wave_emission_path(scale):
     parity.check_grads(out["grads"], ref, f"large splats x{scale}")
 
 
+@pytest.mark.parametrize("tile_map", [0, 1, 2], ids=["banded", "interleaved", "blocks"])
+def test_tile_to_xcd_maps_agree(tile_map):
+    """The three tile -> XCD maps only change which workgroup processes which tile: identical image, parity gradients
+    (335x250: 21 x 16 tiles, odd counts in both directions exercise the padding slots of the 2x2-block map)."""
+    import importlib
+    L = importlib.import_module("3dgs_hierarchical_training_amd._lib")
+    lib = L.load()
+    try:
+        assert lib.gsr_set_option(b"tile_map", tile_map) == 0
+        _run_case(20000, 335, 250, 3, True, "sh", (0.2, 0.3, 0.1))
+    finally:
+        lib.gsr_set_option(b"tile_map", 2)
+
+
 def test_faint_elongated_splats():
     """Needle-shaped (20:1), faint splats: the candidate rect (bounding box of the contribution ellipse inside the
     3-sigma rect) is far smaller than the 3-sigma square; the set of accepted tiles -- and therefore the image and the
