@@ -16,4 +16,18 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
     p -= step_size * (m / denom);
 }
 
+// Streaming accesses: parameters and moments are touched once per step (1.4 kB per Gaussian), so they carry the `nt` bit and
+// do not displace the splats, lists and checkpoints the neighbouring kernels keep in L2 / MALL.
+typedef float nt_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 nt_load4(const float4* a)
+{
+    const nt_f4 r = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(a));
+    return make_float4(r.x, r.y, r.z, r.w);
+}
+__device__ __forceinline__ void nt_store4(float4* a, const float4& x)
+{
+    nt_f4 r = {x.x, x.y, x.z, x.w};
+    __builtin_nontemporal_store(r, reinterpret_cast<nt_f4*>(a));
+}
+
 }  // namespace gsr

@@ -1308,7 +1308,7 @@ __device__ __forceinline__ void adam_rows(const float* s_g, int stride, int col0
         float4* m4 = reinterpret_cast<float4*>(m);
         float4* v4 = reinterpret_cast<float4*>(v);
         for (int q = tid; q < total / 4; q += kPreThreads) {
-            float4 pp = p4[q], mm = m4[q], vv = v4[q];
+            float4 pp = p4[q], mm = nt_load4(m4 + q), vv = nt_load4(v4 + q);   // moments are touched once per step: keep them out of L2
             const int f = 4 * q;
             int g = f / row, e = f - g * row;
             float gs[4];
@@ -1321,7 +1321,7 @@ __device__ __forceinline__ void adam_rows(const float* s_g, int stride, int col0
             adam_one(pp.y, gs[1], mm.y, vv.y, ad.b1, ad.b2, ad.eps, step_size, ad.inv_bc2s);
             adam_one(pp.z, gs[2], mm.z, vv.z, ad.b1, ad.b2, ad.eps, step_size, ad.inv_bc2s);
             adam_one(pp.w, gs[3], mm.w, vv.w, ad.b1, ad.b2, ad.eps, step_size, ad.inv_bc2s);
-            p4[q] = pp; m4[q] = mm; v4[q] = vv;
+            nt_store4(p4 + q, pp); nt_store4(m4 + q, mm); nt_store4(v4 + q, vv);
         }
     } else {
         for (int f = tid; f < total; f += kPreThreads) {

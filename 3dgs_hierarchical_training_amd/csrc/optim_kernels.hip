@@ -40,17 +40,17 @@ __global__ __launch_bounds__(kAdamThreads) void k_adam(AdamBatch B)
         const uint64_t i = base + (uint64_t)(r * kAdamThreads + threadIdx.x) * kAdamVec;
         if (i >= t.n) break;
         if (aligned && i + kAdamVec <= t.n) {
-            float4 p = *reinterpret_cast<float4*>(t.param + i);
-            const float4 g = *reinterpret_cast<const float4*>(t.grad + i);
-            float4 m = *reinterpret_cast<float4*>(t.exp_avg + i);
-            float4 v = *reinterpret_cast<float4*>(t.exp_avg_sq + i);
+            float4 p = nt_load4(reinterpret_cast<const float4*>(t.param + i));
+            const float4 g = nt_load4(reinterpret_cast<const float4*>(t.grad + i));
+            float4 m = nt_load4(reinterpret_cast<const float4*>(t.exp_avg + i));
+            float4 v = nt_load4(reinterpret_cast<const float4*>(t.exp_avg_sq + i));
             adam_one(p.x, g.x, m.x, v.x, B.beta1, B.beta2, B.eps, step_size, inv_bc2s);
             adam_one(p.y, g.y, m.y, v.y, B.beta1, B.beta2, B.eps, step_size, inv_bc2s);
             adam_one(p.z, g.z, m.z, v.z, B.beta1, B.beta2, B.eps, step_size, inv_bc2s);
             adam_one(p.w, g.w, m.w, v.w, B.beta1, B.beta2, B.eps, step_size, inv_bc2s);
-            *reinterpret_cast<float4*>(t.param + i) = p;
-            *reinterpret_cast<float4*>(t.exp_avg + i) = m;
-            *reinterpret_cast<float4*>(t.exp_avg_sq + i) = v;
+            nt_store4(reinterpret_cast<float4*>(t.param + i), p);
+            nt_store4(reinterpret_cast<float4*>(t.exp_avg + i), m);
+            nt_store4(reinterpret_cast<float4*>(t.exp_avg_sq + i), v);
         } else {
             for (uint64_t k = i; k < t.n && k < i + kAdamVec; k++) {
                 float p = t.param[k], m = t.exp_avg[k], v = t.exp_avg_sq[k];
