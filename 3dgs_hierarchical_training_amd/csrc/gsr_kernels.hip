@@ -1333,6 +1333,37 @@ __device__ __forceinline__ void adam_rows(const float* s_g, int stride, int col0
     }
 }
 
+// The four small groups (mean 3, opacity 1, scaling 3, rotation 4 floats) are updated by the thread that owns the Gaussian,
+// straight from its registers: neighbouring lanes touch neighbouring rows, so every fetched line is fully used, and the
+// block keeps no LDS copy of these gradients (25 instead of 30.7 kB per block: one more block per CU).
+template <int K>
+__device__ __forceinline__ void adam_own(float* p, float* m, float* v, const float* g, float step_size, const AdamDev& ad)
+{
+    if (K == 4 && ((((uintptr_t)p | (uintptr_t)m | (uintptr_t)v) & 15) == 0)) {
+        float4 pp = *reinterpret_cast<const float4*>(p);
+        float4 mm = nt_load4(reinterpret_cast<const float4*>(m)), vv = nt_load4(reinterpret_cast<const float4*>(v));
+        adam_one(pp.x, g[0], mm.x, vv.x, ad.b1, ad.b2, ad.eps, step_size, ad.inv_bc2s);
+        adam_one(pp.y, g[1], mm.y, vv.y, ad.b1, ad.b2, ad.eps, step_size, ad.inv_bc2s);
+        adam_one(pp.z, g[2], mm.z, vv.z, ad.b1, ad.b2, ad.eps, step_size, ad.inv_bc2s);
+        adam_one(pp.w, g[3], mm.w, vv.w, ad.b1, ad.b2, ad.eps, step_size, ad.inv_bc2s);
+        nt_store4(reinterpret_cast<float4*>(p), pp);
+        nt_store4(reinterpret_cast<float4*>(m), mm);
+        nt_store4(reinterpret_cast<float4*>(v), vv);
+        return;
+    }
+    float pp[K], mm[K], vv[K];
+#pragma unroll
+    for (int c = 0; c < K; c++) { pp[c] = p[c]; mm[c] = __builtin_nontemporal_load(m + c); vv[c] = __builtin_nontemporal_load(v + c); }
+#pragma unroll
+    for (int c = 0; c < K; c++) adam_one(pp[c], g[c], mm[c], vv[c], ad.b1, ad.b2, ad.eps, step_size, ad.inv_bc2s);
+#pragma unroll
+    for (int c = 0; c < K; c++) {
+        __builtin_nontemporal_store(pp[c], p + c);
+        __builtin_nontemporal_store(mm[c], m + c);
+        __builtin_nontemporal_store(vv[c], v + c);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // K9: per-Gaussian backward.  SH rows in, dSH rows out through the same LDS tile (coalesced both ways).
 // ------------------------------------------------------------------------------------------------
@@ -1343,7 +1374,6 @@ constexpr int kCamVals = 47;   // viewmatrix 16 + projmatrix 16 + campos 3 + poi
 
 // ADAM = true (needs RAW, shs + shs_rest, no cov_pre): optimizer-in-backward, see GsrFusedAdam in include/gsr.h.  The
 // parameter pointers are then read AND written by the block that owns the rows (no __restrict__ promises on them).
-constexpr int kSmallStride = 11;   // xyz 0-2 | opacity 3 | scaling 4-6 | rotation 7-10 (odd stride: conflict-free)
 
 template <int DEG, bool RAW, bool CAM, bool ADAM>
 __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, int N, const float* means,
@@ -1361,7 +1391,6 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, in
     constexpr int NC3 = 3 * (DEG + 1) * (DEG + 1);
     __shared__ float s_sh[kPreThreads * kShStride];
     __shared__ float s_cam[CAM ? (kPreThreads / 64) * kCamVals : 1];
-    __shared__ float s_small[ADAM ? kPreThreads * kSmallStride : 1];
     const int tid = threadIdx.x;
     const int base = blockIdx.x * kPreThreads;
     const int i = base + tid;
@@ -1480,13 +1509,12 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, in
             for (int e = 0; e < NC3; e++) s_sh[tid * kShStride + e] = 0.f;
         }
         d_means2d[3 * (size_t)i] = m2d[0]; d_means2d[3 * (size_t)i + 1] = m2d[1]; d_means2d[3 * (size_t)i + 2] = 0.f;
-        if (ADAM) {
-            float* sm = &s_small[tid * kSmallStride];
-#pragma unroll
-            for (int k = 0; k < 3; k++) { sm[k] = dmean[k]; sm[4 + k] = dsc[k]; }
-            sm[3] = dop;
-#pragma unroll
-            for (int k = 0; k < 4; k++) sm[7 + k] = drq[k];
+        if (ADAM) {   // this thread is the only reader of its Gaussian's small rows, and it has read them
+            const size_t gi = (size_t)i;
+            adam_own<3>(const_cast<float*>(means) + 3 * gi, ad.m[0] + 3 * gi, ad.v[0] + 3 * gi, dmean, ad.step_size[0], ad);
+            adam_own<1>(const_cast<float*>(opac_raw) + gi, ad.m[3] + gi, ad.v[3] + gi, &dop, ad.step_size[3], ad);
+            adam_own<3>(const_cast<float*>(scales) + 3 * gi, ad.m[4] + 3 * gi, ad.v[4] + 3 * gi, dsc, ad.step_size[4], ad);
+            adam_own<4>(const_cast<float*>(rots) + 4 * gi, ad.m[5] + 4 * gi, ad.v[5] + 4 * gi, drq, ad.step_size[5], ad);
         } else {
 #pragma unroll
         for (int k = 0; k < 3; k++) d_means[3 * (size_t)i + k] = dmean[k];
@@ -1533,16 +1561,12 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, in
         __syncthreads();   // every thread's parameters are read, every gradient row is in LDS
         const size_t b = (size_t)base;
         const int rrow = cp.M * 3 - 3;
-        adam_rows(s_small, kSmallStride, 0, 3, 3, const_cast<float*>(means) + b * 3, ad.m[0] + b * 3, ad.v[0] + b * 3, nG, tid, ad.step_size[0], ad);
         adam_rows(s_sh, kShStride, 0, 3, 3, const_cast<float*>(shs) + b * 3, ad.m[1] + b * 3, ad.v[1] + b * 3, nG, tid, ad.step_size[1], ad);
         if (rrow == 45 && NC3 == 48)
             adam_rows(s_sh, kShStride, 3, 45, 45, const_cast<float*>(shs_rest) + b * 45, ad.m[2] + b * 45, ad.v[2] + b * 45, nG, tid, ad.step_size[2], ad);
         else if (rrow > 0)
             adam_rows(s_sh, kShStride, 3, rrow, NC3 - 3, const_cast<float*>(shs_rest) + b * rrow, ad.m[2] + b * rrow, ad.v[2] + b * rrow, nG, tid,
                       ad.step_size[2], ad);
-        adam_rows(s_small, kSmallStride, 3, 1, 1, const_cast<float*>(opac_raw) + b, ad.m[3] + b, ad.v[3] + b, nG, tid, ad.step_size[3], ad);
-        adam_rows(s_small, kSmallStride, 4, 3, 3, const_cast<float*>(scales) + b * 3, ad.m[4] + b * 3, ad.v[4] + b * 3, nG, tid, ad.step_size[4], ad);
-        adam_rows(s_small, kSmallStride, 7, 4, 4, const_cast<float*>(rots) + b * 4, ad.m[5] + b * 4, ad.v[5] + b * 4, nG, tid, ad.step_size[5], ad);
     } else if (shs && d_shs) {
         __syncthreads();
         const int row = cp.M * 3;
