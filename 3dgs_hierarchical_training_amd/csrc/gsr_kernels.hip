@@ -746,7 +746,8 @@ __global__ __launch_bounds__(64) void k_blend_fwd_w(int W, int H, int tiles_x, i
                                                     float* __restrict__ ckpt, int kCkptFirst)
 {
     constexpr int NT = 64;
-    __shared__ float4 s_a[2][NT], s_b[2][NT], s_c[2][NT];
+    __shared__ float4 s_a[2][NT], s_b[2][NT];
+    __shared__ float2 s_c[2][NT];   // 10 of the record's 12 floats are used: 5120 B per wave = 32 waves per CU
     const int per = (T + 7) >> 3;
     const int kslot = blockIdx.x >> 3;
     // which tile this XCD slot works on: see slot_tile (a tile's four waves share an XCD under every map)
@@ -781,7 +782,7 @@ __global__ __launch_bounds__(64) void k_blend_fwd_w(int W, int H, int tiles_x, i
             float* c = ckpt + ((size_t)(rg.x >> 7) + tile + (b >> 1) - kCkptFirst) * kCkptFloats + sub * 64 + lane;
             c[0] = acc.T; c[256] = acc.C0; c[512] = acc.C1; c[768] = acc.C2; c[1024] = acc.D; c[1280] = acc.A;
         }
-        s_a[buf][lane] = ra; s_b[buf][lane] = rb; s_c[buf][lane] = rc;
+        s_a[buf][lane] = ra; s_b[buf][lane] = rb; s_c[buf][lane] = make_float2(rc.x, rc.y);
         __syncthreads();   // single-wave workgroup: just orders the LDS writes before the broadcast reads
         batches = b + 1;
         const int nxt = (b + 1) * NT + lane;
@@ -792,7 +793,8 @@ __global__ __launch_bounds__(64) void k_blend_fwd_w(int W, int H, int tiles_x, i
         }
         const int cnt = min(NT, n - b * NT);
         for (int j = 0; j < cnt; j++) {
-            const float4 A = s_a[buf][j], B = s_b[buf][j], C = s_c[buf][j];
+            const float4 A = s_a[buf][j], B = s_b[buf][j];
+            const float2 C = s_c[buf][j];
             if (done) continue;
             const float dx = A.x - pxf, dy = A.y - pyf;
             const float p2 = fmaf(B.x * dy, dy, fmaf(A.w, dy, A.z * dx) * dx);   // log2 of the Gaussian weight
