@@ -218,6 +218,24 @@ __device__ __forceinline__ void stage_out_vec(const float* s_sh, int col0, float
         d4[v] = make_float4(xs[0], xs[1], xs[2], xs[3]);
     }
 }
+// Linear tiles: with split dc / rest storage and every stored coefficient active, a block's rows are copied into LDS in
+// their memory order (16-byte LDS accesses, no index arithmetic, no bank conflicts on the streaming side); the owning
+// thread walks its row at stride ROW, which is conflict-free when ROW is odd (3 and 45).  The padded stride-49 tile above
+// stays for every other layout.
+template <int ROW>
+__device__ __forceinline__ void stage_in_lin(float* tile, const float* __restrict__ src, int nG, int tid)
+{
+    const float4* s4 = reinterpret_cast<const float4*>(src);
+    float4* t4 = reinterpret_cast<float4*>(tile);
+    for (int v = tid; v < (nG * ROW) / 4; v += kPreThreads) t4[v] = s4[v];
+}
+template <int ROW>
+__device__ __forceinline__ void stage_out_lin(const float* tile, float* __restrict__ dst, int nG, int tid)
+{
+    const float4* t4 = reinterpret_cast<const float4*>(tile);
+    float4* d4 = reinterpret_cast<float4*>(dst);
+    for (int v = tid; v < (nG * ROW) / 4; v += kPreThreads) d4[v] = t4[v];
+}
 __device__ __forceinline__ bool vec_ok(const void* p, int nfloats) { return (((uintptr_t)p & 15) == 0) && ((nfloats & 3) == 0); }
 
 // stage_in_vec split in two: the 16-byte loads are issued into registers first, the per-Gaussian arithmetic that does
@@ -259,6 +277,17 @@ __device__ __forceinline__ void stage_store(const float4 (&r)[KN], float* s_sh, 
 // ------------------------------------------------------------------------------------------------
 // RAW = true ("next" row f-2): the kernel consumes the model's raw parameters and applies the activations of
 // /root/reference/scene/gaussian_model_ht.py:49-65,128-133,176-188 itself -- scale = exp(_scaling),
+template <int ROW, int KN>
+__device__ __forceinline__ void stage_store_lin(const float4 (&r)[KN], float* tile, int nG, int tid)
+{
+    float4* t4 = reinterpret_cast<float4*>(tile);
+#pragma unroll
+    for (int q = 0; q < stage_regs<ROW>(); q++) {
+        const int v = tid + q * kPreThreads;
+        if (v < (nG * ROW) / 4) t4[v] = r[q];
+    }
+}
+
 // q = normalize(_rotation), opacity = sigmoid(_opacity), SH = cat(_features_dc, _features_rest) -- so the
 // torch exp / sigmoid / normalize / cat kernels (and their backward) disappear from the train step.
 template <int DEG, bool RAW>
@@ -377,13 +406,23 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess(CamParams cp, int N,
     }
     // ---- phase 2: rows into the LDS tile, then the colour of the Gaussians that survived the culls
     if (shs) {
-        if (pend_dc) stage_store<3>(r_dc, s_sh, 0, nG, tid);
-        if (pend_rest) stage_store<NR>(r_rows, s_sh, 3, nG, tid);
-        if (pend_full) stage_store<NC3>(r_rows, s_sh, 0, nG, tid);
+        constexpr bool kLinOk = NC3 > 3 && (NR & 1);
+        const bool lin = kLinOk && pend_dc && pend_rest;   // block-uniform: linear tiles (see stage_in_lin)
+        float* s_dc = s_sh;
+        float* s_rest = s_sh + kPreThreads * 3;
+        if (lin) {
+            stage_store_lin<3>(r_dc, s_dc, nG, tid);
+            stage_store_lin<NR>(r_rows, s_rest, nG, tid);
+        } else {
+            if (pend_dc) stage_store<3>(r_dc, s_sh, 0, nG, tid);
+            if (pend_rest) stage_store<NR>(r_rows, s_sh, 3, nG, tid);
+            if (pend_full) stage_store<NC3>(r_rows, s_sh, 0, nG, tid);
+        }
         __syncthreads();
         if (act && s.radius > 0) {
             float col[3];
-            splat_sh_color(cam, mean, &s_sh[tid * kShStride], 3, 1, col);
+            if (lin) splat_sh_color(cam, mean, s_rest + tid * NR - 3, 3, 1, col, s_dc + tid * 3);
+            else splat_sh_color(cam, mean, &s_sh[tid * kShStride], 3, 1, col);
             s.r = col[0]; s.g = col[1]; s.b = col[2];
         }
     }
@@ -1335,6 +1374,33 @@ __device__ __forceinline__ void adam_rows(const float* s_g, int stride, int col0
     }
 }
 
+// the same update when the gradient tile is a linear copy of the rows (stage_in_lin): one 16-byte LDS read per 16-byte stream element
+__device__ __forceinline__ void adam_rows_lin(const float* s_g, int total, float* __restrict__ p, float* __restrict__ m,
+                                              float* __restrict__ v, int tid, float step_size, const AdamDev& ad)
+{
+    float4* p4 = reinterpret_cast<float4*>(p);
+    float4* m4 = reinterpret_cast<float4*>(m);
+    float4* v4 = reinterpret_cast<float4*>(v);
+    const float4* g4 = reinterpret_cast<const float4*>(s_g);
+    if ((((uintptr_t)m | (uintptr_t)v) & 15) == 0) {
+        for (int q = tid; q < total / 4; q += kPreThreads) {
+            float4 pp = p4[q], mm = nt_load4(m4 + q), vv = nt_load4(v4 + q);
+            const float4 g = g4[q];
+            adam_one(pp.x, g.x, mm.x, vv.x, ad.b1, ad.b2, ad.eps, step_size, ad.inv_bc2s);
+            adam_one(pp.y, g.y, mm.y, vv.y, ad.b1, ad.b2, ad.eps, step_size, ad.inv_bc2s);
+            adam_one(pp.z, g.z, mm.z, vv.z, ad.b1, ad.b2, ad.eps, step_size, ad.inv_bc2s);
+            adam_one(pp.w, g.w, mm.w, vv.w, ad.b1, ad.b2, ad.eps, step_size, ad.inv_bc2s);
+            nt_store4(p4 + q, pp); nt_store4(m4 + q, mm); nt_store4(v4 + q, vv);
+        }
+    } else {
+        for (int f = tid; f < total; f += kPreThreads) {
+            float pp = p[f], mm = m[f], vv = v[f];
+            adam_one(pp, s_g[f], mm, vv, ad.b1, ad.b2, ad.eps, step_size, ad.inv_bc2s);
+            p[f] = pp; m[f] = mm; v[f] = vv;
+        }
+    }
+}
+
 // The four small groups (mean 3, opacity 1, scaling 3, rotation 4 floats) are updated by the thread that owns the Gaussian,
 // straight from its registers: neighbouring lanes touch neighbouring rows, so every fetched line is fully used, and the
 // block keeps no LDS copy of these gradients (25 instead of 30.7 kB per block: one more block per CU).
@@ -1406,7 +1472,18 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, in
 #pragma unroll
         for (int q = 0; q < 12; q++) xg[q] = 0.f;
     }
-    if (shs) {
+    // linear tiles (see stage_in_lin): split storage, every stored coefficient active, aligned full rows
+    constexpr int NRL = NC3 > 3 ? NC3 - 3 : 1;
+    constexpr bool kLinOk = NC3 > 3 && (NRL & 1);
+    float* s_dc = s_sh;
+    float* s_rest = s_sh + kPreThreads * 3;
+    const bool lin = kLinOk && shs && shs_rest && (cp.M - 1) * 3 == NRL && vec_ok(shs + (size_t)base * 3, nG * 3) &&
+                     vec_ok(shs_rest + (size_t)base * NRL, nG * NRL);   // block-uniform
+    if (lin) {
+        stage_in_lin<3>(s_dc, shs + (size_t)base * 3, nG, tid);
+        stage_in_lin<NRL>(s_rest, shs_rest + (size_t)base * NRL, nG, tid);
+        __syncthreads();
+    } else if (shs) {
         if (shs_rest) {
             const size_t row = (size_t)(cp.M - 1) * 3;
             const float* dc0 = shs + (size_t)base * 3;
@@ -1490,7 +1567,8 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, in
 #pragma unroll
             for (int k = 0; k < 6; k++) dcv[k] = o.cov[k];
             if (shs) {
-                sh_backward(cam, mean, &s_sh[tid * kShStride], 3, 1, grgb, &s_sh[tid * kShStride], 3, 1, dmean);
+                if (lin) sh_backward(cam, mean, s_rest + tid * NRL - 3, 3, 1, grgb, s_rest + tid * NRL - 3, 3, 1, dmean, s_dc + tid * 3, s_dc + tid * 3);
+                else sh_backward(cam, mean, &s_sh[tid * kShStride], 3, 1, grgb, &s_sh[tid * kShStride], 3, 1, dmean);
                 if (CAM) {   // the view direction is (p - campos)/|.|: d/dcampos = -(its share of d/dp)
                     cg.cam[0] = o.mean[0] - dmean[0]; cg.cam[1] = o.mean[1] - dmean[1]; cg.cam[2] = o.mean[2] - dmean[2];
                 }
@@ -1507,6 +1585,9 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, in
 #pragma unroll
                 for (int c = 0; c < 3; c++) dmean[c] = fmaf(cp.xf[c], d0, fmaf(cp.xf[4 + c], d1, cp.xf[8 + c] * d2));
             }
+        } else if (lin) {
+            for (int e = 0; e < 3; e++) s_dc[tid * 3 + e] = 0.f;
+            for (int e = 0; e < NRL; e++) s_rest[tid * NRL + e] = 0.f;
         } else if (shs) {
             for (int e = 0; e < NC3; e++) s_sh[tid * kShStride + e] = 0.f;
         }
@@ -1563,12 +1644,21 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, in
         __syncthreads();   // every thread's parameters are read, every gradient row is in LDS
         const size_t b = (size_t)base;
         const int rrow = cp.M * 3 - 3;
+        if (lin) {
+            adam_rows_lin(s_dc, nG * 3, const_cast<float*>(shs) + b * 3, ad.m[1] + b * 3, ad.v[1] + b * 3, tid, ad.step_size[1], ad);
+            adam_rows_lin(s_rest, nG * NRL, const_cast<float*>(shs_rest) + b * NRL, ad.m[2] + b * NRL, ad.v[2] + b * NRL, tid, ad.step_size[2], ad);
+            return;
+        }
         adam_rows(s_sh, kShStride, 0, 3, 3, const_cast<float*>(shs) + b * 3, ad.m[1] + b * 3, ad.v[1] + b * 3, nG, tid, ad.step_size[1], ad);
         if (rrow == 45 && NC3 == 48)
             adam_rows(s_sh, kShStride, 3, 45, 45, const_cast<float*>(shs_rest) + b * 45, ad.m[2] + b * 45, ad.v[2] + b * 45, nG, tid, ad.step_size[2], ad);
         else if (rrow > 0)
             adam_rows(s_sh, kShStride, 3, rrow, NC3 - 3, const_cast<float*>(shs_rest) + b * rrow, ad.m[2] + b * rrow, ad.v[2] + b * rrow, nG, tid,
                       ad.step_size[2], ad);
+    } else if (lin && d_shs && d_shs_rest) {
+        __syncthreads();
+        stage_out_lin<3>(s_dc, d_shs + (size_t)base * 3, nG, tid);
+        stage_out_lin<NRL>(s_rest, d_shs_rest + (size_t)base * NRL, nG, tid);
     } else if (shs && d_shs) {
         __syncthreads();
         const int row = cp.M * 3;

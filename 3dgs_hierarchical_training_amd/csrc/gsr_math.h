@@ -307,8 +307,10 @@ GSR_HD uint32_t count_accepted_tiles(float px, float py, float ca, float cb, flo
 
 // SH colour (before +0.5 / clamp) for one channel; sh points at coefficient 0 of that channel,
 // consecutive coefficients are `stride` floats apart.
+// `sh0` (optional) points at coefficient 0 when it is stored apart from the others (split dc / rest storage); the
+// coefficients k >= 1 are then still addressed as sh[k * stride].
 template <typename RT>
-GSR_HD RT sh_channel(int deg, const float* sh, int stride, RT x, RT y, RT z)
+GSR_HD RT sh_channel(int deg, const float* sh, int stride, RT x, RT y, RT z, const float* sh0 = nullptr)
 {
     constexpr RT SH_C0 = (RT)0.28209479177387814, SH_C1 = (RT)0.4886025119029199;
     constexpr RT SH_C2_0 = (RT)1.0925484305920792, SH_C2_1 = (RT)-1.0925484305920792, SH_C2_2 = (RT)0.31539156525252005,
@@ -316,7 +318,7 @@ GSR_HD RT sh_channel(int deg, const float* sh, int stride, RT x, RT y, RT z)
     constexpr RT SH_C3_0 = (RT)-0.5900435899266435, SH_C3_1 = (RT)2.890611442640554, SH_C3_2 = (RT)-0.4570457994644658,
                  SH_C3_3 = (RT)0.3731763325901154, SH_C3_4 = (RT)-0.4570457994644658, SH_C3_5 = (RT)1.445305721320277,
                  SH_C3_6 = (RT)-0.5900435899266435;
-    RT res = SH_C0 * sh[0];
+    RT res = SH_C0 * (sh0 ? sh0[0] : sh[0]);
     if (deg > 0) {
         res = res - SH_C1 * y * sh[1 * stride] + SH_C1 * z * sh[2 * stride] - SH_C1 * x * sh[3 * stride];
         if (deg > 1) {
@@ -339,13 +341,14 @@ GSR_HD RT sh_channel(int deg, const float* sh, int stride, RT x, RT y, RT z)
 // SH colour of one Gaussian seen from the camera centre: max(SH(dir) + 0.5, 0) per channel.
 // Colour enters the image linearly, so binary32 is enough here (relative error ~1e-7); only the geometry of
 // preprocess_one (conic = inverse of a nearly singular 2x2, pixel position) needs the float64 evaluation.
-GSR_HD void splat_sh_color(const Camera& c, const float mean[3], const float* sh, int sh_kstride, int sh_cstride, float col[3])
+GSR_HD void splat_sh_color(const Camera& c, const float mean[3], const float* sh, int sh_kstride, int sh_cstride, float col[3],
+                           const float* sh0 = nullptr)
 {
     float dx = mean[0] - c.cam[0], dy = mean[1] - c.cam[1], dz = mean[2] - c.cam[2];
     const float inv_n = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
     dx *= inv_n; dy *= inv_n; dz *= inv_n;
     for (int ch = 0; ch < 3; ch++) {
-        const float v = sh_channel<float>(c.D, sh + ch * sh_cstride, sh_kstride, dx, dy, dz) + 0.5f;
+        const float v = sh_channel<float>(c.D, sh + ch * sh_cstride, sh_kstride, dx, dy, dz, sh0 ? sh0 + ch * sh_cstride : nullptr) + 0.5f;
         col[ch] = v < 0.f ? 0.f : v;
     }
 }
@@ -503,15 +506,16 @@ struct GaussGrads {
 
 // accumulates dL/d(mean) through the colour and writes dL/dsh (coefficient k, channel ch at
 // dsh[k*dk + ch*dc]).  Coefficients >= (deg+1)^2 are written as zero up to M.
+// `sh0` / `dsh0` (optional): where coefficient 0 lives when it is stored apart from the rest (channel ch at sh0[ch*sc], dsh0[ch*dc]).
 GSR_HD void sh_backward(const Camera& c, const float mean[3], const float* sh, int sk, int sc, const float g_rgb_in[3],
-                        float* dsh, int dk, int dc, float dmean[3])
+                        float* dsh, int dk, int dc, float dmean[3], const float* sh0 = nullptr, float* dsh0 = nullptr)
 {
     float dx = mean[0] - c.cam[0], dy = mean[1] - c.cam[1], dz = mean[2] - c.cam[2];
     const float inv_n = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
     const float x = dx * inv_n, y = dy * inv_n, z = dz * inv_n;
     float gr[3];
     for (int ch = 0; ch < 3; ch++) {
-        const float v = sh_channel<float>(c.D, sh + ch * sc, sk, x, y, z) + 0.5f;
+        const float v = sh_channel<float>(c.D, sh + ch * sc, sk, x, y, z, sh0 ? sh0 + ch * sc : nullptr) + 0.5f;
         gr[ch] = v < 0.f ? 0.f : g_rgb_in[ch];
     }
     float basis[16], bx[16], by[16], bz[16];
@@ -547,8 +551,9 @@ GSR_HD void sh_backward(const Camera& c, const float mean[3], const float* sh, i
     for (int k = 0; k < 16; k++) {
         if (k < nc) {
             for (int ch = 0; ch < 3; ch++) {
-                const float s = sh[k * sk + ch * sc];
-                dsh[k * dk + ch * dc] = basis[k] * gr[ch];
+                const float s = (k == 0 && sh0) ? sh0[ch * sc] : sh[k * sk + ch * sc];
+                if (k == 0 && dsh0) dsh0[ch * dc] = basis[k] * gr[ch];
+                else dsh[k * dk + ch * dc] = basis[k] * gr[ch];
                 gdx += bx[k] * s * gr[ch]; gdy += by[k] * s * gr[ch]; gdz += bz[k] * s * gr[ch];
             }
         } else if (k < c.M) {
