@@ -1383,6 +1383,7 @@ __device__ __forceinline__ void adam_rows_lin(const float* s_g, int total, float
     float4* v4 = reinterpret_cast<float4*>(v);
     const float4* g4 = reinterpret_cast<const float4*>(s_g);
     if ((((uintptr_t)m | (uintptr_t)v) & 15) == 0) {
+#pragma unroll 2
         for (int q = tid; q < total / 4; q += kPreThreads) {
             float4 pp = p4[q], mm = nt_load4(m4 + q), vv = nt_load4(v4 + q);
             const float4 g = g4[q];
