@@ -286,10 +286,13 @@ __global__ __launch_bounds__(256) void k_radix_ghist(const KeyT* __restrict__ ke
 // wave and twice the waves to hide the LDS / look-back latency behind (a workgroup's latency chain, not bandwidth,
 // is what a pass costs)
 // Measured (1 M depth keys / 4.5 M tile keys): 256x16 0.100 / 0.111 ms, 512x8 0.084 / 0.103, 1024x4 0.081 / 0.116,
-// 512x4 (2048-key tiles) 0.086 / 0.127 -> the small latency-bound depth sort takes 1024 threads, the tile sort 512.
+// 512x4 (2048-key tiles) 0.086 / 0.127 -> the small latency-bound depth sort takes 1024 threads, the tile sort 512;
+// 512x10 (5120-key tiles) for the tile sort: 0.096 -> 0.094 (its 4.5 M keys then fit the 1024 resident workgroups at once).
+// One wave per 8 digits reading 64 predecessors per round trip (instead of one thread per digit reading 4): 3.7x SLOWER --
+// the look-back is bound by the status traffic in L2, not by the length of the walk.
 constexpr int kOsTile = 4096;
-template <typename KeyT> struct OsCfg { static constexpr int kThreads = 512; };
-template <> struct OsCfg<uint32_t> { static constexpr int kThreads = 1024; };
+template <typename KeyT> struct OsCfg { static constexpr int kThreads = 512, kTile = 5120; };
+template <> struct OsCfg<uint32_t> { static constexpr int kThreads = 1024, kTile = 4096; };
 
 // NB = digit table size: 256, or 64 when the digits of the sort are at most 6 bits wide (a quarter of the LDS tables:
 // five instead of three workgroups per CU for 16-bit keys).  Status words keep their 256-word stride in memory.
@@ -301,7 +304,7 @@ __global__ __launch_bounds__(OsCfg<KeyT>::kThreads) void k_onesweep(const KeyT* 
                                                          uint32_t* __restrict__ ticket,
                                                          const unsigned long long* __restrict__ n_dev, uint32_t dmask)
 {
-    constexpr int kOsThreads = OsCfg<KeyT>::kThreads, kOsIPT = kOsTile / kOsThreads, kOsWaves = kOsThreads / 64;
+    constexpr int kOsThreads = OsCfg<KeyT>::kThreads, kOsTile = OsCfg<KeyT>::kTile, kOsIPT = kOsTile / kOsThreads, kOsWaves = kOsThreads / 64;
     if (n_dev) n = (uint32_t)min((unsigned long long)n, *n_dev);   // device-side count: tiles past it exit at once
     __shared__ unsigned long long s_mask[kOsWaves][NB];
     __shared__ uint32_t s_cnt[kOsWaves][NB];
@@ -360,13 +363,14 @@ __global__ __launch_bounds__(OsCfg<KeyT>::kThreads) void k_onesweep(const KeyT* 
         // (windows of 4 independent loads: the walk is a chain of L2 round trips, and the chain is what a block waits on)
         uint32_t excl = 0;
         for (int t = (int)tile - 1; t >= 0;) {
-            uint32_t v[4];
+            constexpr int kWin = 4;   // (8: same speed, 16: +20 % per pass -- the polls compete for the status lines in L2)
+            uint32_t v[kWin];
 #pragma unroll
-            for (int q = 0; q < 4; q++)
+            for (int q = 0; q < kWin; q++)
                 v[q] = (t - q >= 0) ? __hip_atomic_load(status + (size_t)(t - q) * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kOsIncl;
             bool done = false;
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
+            for (int q = 0; q < kWin; q++) {
                 if (done) break;
                 const uint32_t f = v[q] & ~kOsMask;
                 if (f == 0u) { done = true; break; }   // not published yet: re-poll from here
@@ -423,7 +427,7 @@ inline hipError_t onesweep_sort_pairs(KeyT* keys, uint32_t* vals, KeyT* keys_alt
     // balanced digits: 12 key bits sort as 6 + 6 rather than 8 + 4 (fewer same-digit collisions in the ranking, longer
     // runs per digit in the scatter); the last digit is narrower when the bits do not divide evenly
     const int dbits = (bits + passes - 1) / passes;
-    const uint32_t nblocks = (n + kOsTile - 1) / kOsTile;
+    const uint32_t nblocks = (n + OsCfg<KeyT>::kTile - 1) / OsCfg<KeyT>::kTile;   // (the scratch is sized for 4096-key tiles: never fewer words)
     uint32_t* ghist = static_cast<uint32_t*>(scratch);
     uint32_t* tickets = ghist + 4 * 256;
     uint32_t* status = tickets + 64;
