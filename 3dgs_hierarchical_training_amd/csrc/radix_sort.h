@@ -438,6 +438,7 @@ inline hipError_t onesweep_sort_pairs(KeyT* keys, uint32_t* vals, KeyT* keys_alt
         if (e != hipSuccess) return e;
     }
     const uint32_t status_words = (uint32_t)((size_t)passes * nblocks * 256);
+    // (64 blocks of 1024 threads, to shorten the per-address chains of the closing global atomics: +5 us per sort)
     const uint32_t hgrid = nblocks < 256u ? nblocks : 256u;
     switch (passes) {
         case 1: hipLaunchKernelGGL((k_radix_ghist<KeyT, 1>), dim3(hgrid), dim3(256), 0, stream, keys, n, begin_bit, ghist, n_dev, status, status_words, dbits, bits); break;

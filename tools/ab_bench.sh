@@ -11,7 +11,7 @@ for r in $(seq 1 ${1:-3}); do
     python bench.py --steps ${STEPS:-30} --warmup ${WARM:-5} --no-cpu-baseline 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
-print('$w', round(d['value'], 1), round(d['ms_per_step'], 4), {k: round(v * 1000) for k, v in d.get('stage_ms', {}).items()})"
+print('$w', round(d['value'], 1), round(d['ms_per_step'], 4), round(d.get('fwd_bwd_ms', 0), 3), {k: round(v * 1000) for k, v in d.get('stage_ms', {}).items()})"
   done
 done
 cp /tmp/new.so $D/libgsr_hip.so
