@@ -147,8 +147,10 @@ def main():
     read_profile(lib, names)  # drop anything recorded so far
     sync_all()
     t0 = time.perf_counter()
+    stamps = [t0]
     for _ in range(args.steps):
         ts.train_step(params, settings, gt)
+        stamps.append(time.perf_counter())   # host clock only (each step already waits for the forward's instance count)
     sync_all()
     elapsed = time.perf_counter() - t0
     lib.gsr_set_option(b"profile", 0)
@@ -179,6 +181,9 @@ def main():
     P = W * H
     T = ((W + 15) // 16) * ((H + 15) // 16)
     ms_per_step = 1000.0 * elapsed / args.steps
+    # host-side enqueue intervals of the timed steps (a stall of the launching thread shows up as max >> median)
+    gaps = sorted(1e3 * (b - a) for a, b in zip(stamps[:-1], stamps[1:]))
+    step_host = {"median": gaps[len(gaps) // 2], "p90": gaps[min(len(gaps) - 1, (9 * len(gaps)) // 10)], "max": gaps[-1]} if gaps else {}
     stage_ms = {k: (v[0] / v[1] if v[1] else None) for k, v in prof.items()}
     fwd_stages = ["preprocess_fwd", "sort_depth", "scan", "emit", "sort_tile", "ranges", "blend_fwd"]
     bwd_stages = ["blend_bwd", "preprocess_bwd"]
@@ -232,7 +237,7 @@ def main():
                    "train_step": "activations + rasterize fwd + 0.8*L1+0.2*(1-SSIM) + backward + Adam(eps=1e-15) on all 59 floats "
                                  "per Gaussian (update applied inside the per-Gaussian backward kernel)"},
         "fwd_bwd_ms": fwd_ms + bwd_ms, "rasterizer_fwd_ms": fwd_ms, "rasterizer_bwd_ms": bwd_ms,
-        "stage_ms": stage_ms, "roofline": roofline, "roofline_other_kernels": others,
+        "stage_ms": stage_ms, "step_host_ms": step_host, "roofline": roofline, "roofline_other_kernels": others,
     }
     if world == 1 and not args.no_cpu_baseline:
         threads = os.cpu_count() or 1
