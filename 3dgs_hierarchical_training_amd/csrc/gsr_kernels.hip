@@ -540,10 +540,12 @@ __device__ __forceinline__ int select_kth_bit(uint32_t m, uint32_t k)   // posit
     return __ffs((int)m) - 1;
 }
 
+// KeyT = uint16_t up to 65536 tiles (the tile sort then moves 6-byte records), uint32_t above
+template <typename KeyT>
 __global__ __launch_bounds__(kEmitThreads) void k_emit(int N, int W, int H, int tiles_x, int tiles_y,
                                                        const uint32_t* __restrict__ sorted_gid, const Splat* __restrict__ splat,
                                                        const TileRec* __restrict__ tilerec,
-                                                       const uint32_t* __restrict__ block_offsets, uint16_t* __restrict__ out_tile,
+                                                       const uint32_t* __restrict__ block_offsets, KeyT* __restrict__ out_tile,
                                                        uint32_t* __restrict__ out_gid, uint32_t cap)
 {
     __shared__ uint32_t s_wave[4];
@@ -583,7 +585,7 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit(int N, int W, int H, int 
         const int ty = pos / ww, tx = pos - ty * ww;
         const uint32_t o = base + q;
         if (o < cap) {   // cap = R, or the speculative capacity of gsr_forward (then an overflow is re-run)
-            out_tile[o] = (uint16_t)((ry0 + ty) * tiles_x + rx0 + tx);
+            out_tile[o] = (KeyT)((ry0 + ty) * tiles_x + rx0 + tx);
             out_gid[o] = s_gid[lo];
         }
     }
@@ -612,7 +614,7 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit(int N, int W, int H, int 
             if (ok) {
                 const uint32_t o = run + (uint32_t)__popcll(m & lt);
                 if (o < cap) {
-                    out_tile[o] = (uint16_t)(gy * tiles_x + gx);
+                    out_tile[o] = (KeyT)(gy * tiles_x + gx);
                     out_gid[o] = gg;
                 }
             }
@@ -622,7 +624,8 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit(int N, int W, int H, int 
 }
 
 // K6: per-tile [start, end) from the tile-sorted keys (ranges pre-zeroed)
-__global__ void k_tile_ranges(uint32_t R, const uint16_t* __restrict__ keys, uint2* __restrict__ ranges,
+template <typename KeyT>
+__global__ void k_tile_ranges(uint32_t R, const KeyT* __restrict__ keys, uint2* __restrict__ ranges,
                               const unsigned long long* __restrict__ n_dev)
 {
     if (n_dev) R = (uint32_t)min((unsigned long long)R, *n_dev);
@@ -1771,13 +1774,13 @@ static BinLayout bin_layout(int64_t R, int32_t W, int32_t H)
 struct BinScratch {
     size_t tile, tile_alt, gid_alt, sort, bytes;
 };
-static BinScratch bin_scratch_layout(int64_t R)
+static BinScratch bin_scratch_layout(int64_t R, int key_bytes = 4)
 {
     const size_t r = (size_t)(R > 0 ? R : 1);
     BinScratch s;
     size_t o = 0;
-    s.tile = o; o += align256(r * 2);
-    s.tile_alt = o; o += align256(r * 2);
+    s.tile = o; o += align256(r * (size_t)key_bytes);
+    s.tile_alt = o; o += align256(r * (size_t)key_bytes);
     s.gid_alt = o; o += align256(r * 4);
     s.sort = o; o += radix_scratch_bytes((uint32_t)r);
     s.bytes = o;
@@ -1800,7 +1803,6 @@ static int check_common(int32_t N, int32_t M, int32_t D, int32_t W, int32_t H)
     if (D < 0 || D > 3) return fail(GSR_ERR_ARG, "sh_degree must be 0..3%s");
     if (M < 0 || M > 16) return fail(GSR_ERR_ARG, "at most 16 SH coefficients per Gaussian%s");
     const long long T = (long long)((W + kTile - 1) / kTile) * ((H + kTile - 1) / kTile);
-    if (T > 65535) return fail(GSR_ERR_RANGE, "image has more than 65535 tiles%s");
     if (W > 4095 * kTile || H > 4095 * kTile) return fail(GSR_ERR_RANGE, "image side longer than 65520 pixels%s");
     return GSR_OK;
 }
@@ -1905,6 +1907,7 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
     int bits = 1;
     while ((1 << bits) < T) bits++;
     const int tile_passes = (bits + 7) / 8;
+    const bool wide_keys = T > 65536;   // tile ids beyond 16 bits: 32-bit keys in the instance stream
     const int nb = (N + kEmitThreads - 1) / kEmitThreads;
 
     // ---- R-sized state (binning result + tile-sort scratch) and the stages that need it --------------------------
@@ -1921,18 +1924,19 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
         list = reinterpret_cast<uint32_t*>(bin + B.list);
         bs = nullptr;
         if (capacity == 0) return GSR_OK;
-        S = bin_scratch_layout((int64_t)capacity);
+        S = bin_scratch_layout((int64_t)capacity, wide_keys ? 4 : 2);
         bs = static_cast<uint8_t*>(a->alloc(S.bytes, GSR_ALLOC_SCRATCH, a->alloc_user));
         if (!bs) return fail(GSR_ERR_ALLOC, "binning scratch allocation failed%s");
         return GSR_OK;
     };
     // emit + tile sort + ranges for `capacity` instances; n_dev != nullptr: the real count is read on the device.
     // prezeroed: ranges, the staged counters and the head of the sort scratch were cleared by k_block_scan.
-    auto launch_binning = [&](uint64_t capacity, const unsigned long long* n_dev, bool prezeroed) -> int {
+    auto launch_binning_t = [&](auto key_tag, uint64_t capacity, const unsigned long long* n_dev, bool prezeroed) -> int {
+        using KeyT = decltype(key_tag);
         if (!prezeroed) GSR_HIP(hipMemsetAsync(ranges, 0, (size_t)T * sizeof(uint2), st));
         if (capacity == 0) return GSR_OK;
-        uint16_t* tkey = reinterpret_cast<uint16_t*>(bs + S.tile);
-        uint16_t* tkey_alt = reinterpret_cast<uint16_t*>(bs + S.tile_alt);
+        KeyT* tkey = reinterpret_cast<KeyT*>(bs + S.tile);
+        KeyT* tkey_alt = reinterpret_cast<KeyT*>(bs + S.tile_alt);
         uint32_t* gid_alt2 = reinterpret_cast<uint32_t*>(bs + S.gid_alt);
         uint32_t* block_sums = reinterpret_cast<uint32_t*>(fs + L.block_sums);
         // arrange the ping-pong so that the sorted gids land directly in `list`
@@ -1940,24 +1944,27 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
         uint32_t* v1 = (tile_passes & 1) ? list : gid_alt2;
         {
             ProfScope ps(P_EMIT, st);
-            hipLaunchKernelGGL(k_emit, dim3(nb), dim3(kEmitThreads), 0, st, N, W, H, tiles_x, tiles_y, sorted_gid, splat,
+            hipLaunchKernelGGL(k_emit<KeyT>, dim3(nb), dim3(kEmitThreads), 0, st, N, W, H, tiles_x, tiles_y, sorted_gid, splat,
                                reinterpret_cast<const TileRec*>(fs + L.srec), block_sums, tkey, v0,
                                (uint32_t)capacity);
         }
         int in_alt = 0;
         {
             ProfScope ps(P_SORT_TILE, st);
-            GSR_HIP(g_sort_algo == 2 ? onesweep_sort_pairs<uint16_t>(tkey, v0, tkey_alt, v1, (uint32_t)capacity, 0, bits, bs + S.sort,
-                                                                     &in_alt, st, n_dev, prezeroed)
-                                     : radix_sort_pairs<uint16_t>(tkey, v0, tkey_alt, v1, (uint32_t)capacity, 0, tile_passes * 8, bs + S.sort,
-                                                                  &in_alt, st));
+            GSR_HIP(g_sort_algo == 2 ? onesweep_sort_pairs<KeyT>(tkey, v0, tkey_alt, v1, (uint32_t)capacity, 0, bits, bs + S.sort,
+                                                                 &in_alt, st, n_dev, prezeroed)
+                                     : radix_sort_pairs<KeyT>(tkey, v0, tkey_alt, v1, (uint32_t)capacity, 0, tile_passes * 8, bs + S.sort,
+                                                              &in_alt, st));
         }
-        const uint16_t* skey = in_alt ? tkey_alt : tkey;
+        const KeyT* skey = in_alt ? tkey_alt : tkey;
         {
             ProfScope ps(P_RANGES, st);
-            hipLaunchKernelGGL(k_tile_ranges, dim3(((uint32_t)capacity + 255) / 256), dim3(256), 0, st, (uint32_t)capacity, skey, ranges, n_dev);
+            hipLaunchKernelGGL(k_tile_ranges<KeyT>, dim3(((uint32_t)capacity + 255) / 256), dim3(256), 0, st, (uint32_t)capacity, skey, ranges, n_dev);
         }
         return GSR_OK;
+    };
+    auto launch_binning = [&](uint64_t capacity, const unsigned long long* n_dev, bool prezeroed) -> int {
+        return wide_keys ? launch_binning_t(uint32_t{}, capacity, n_dev, prezeroed) : launch_binning_t(uint16_t{}, capacity, n_dev, prezeroed);
     };
     auto launch_blend = [&](bool prezeroed) -> int {
         const int ppt = g_blend_ppt ? g_blend_ppt : 5;   // default: one wave per 8x8 sub-tile

@@ -291,8 +291,10 @@ __global__ __launch_bounds__(256) void k_radix_ghist(const KeyT* __restrict__ ke
 // One wave per 8 digits reading 64 predecessors per round trip (instead of one thread per digit reading 4): 3.7x SLOWER --
 // the look-back is bound by the status traffic in L2, not by the length of the walk.
 constexpr int kOsTile = 4096;
-template <typename KeyT> struct OsCfg { static constexpr int kThreads = 512, kTile = 5120; };
-template <> struct OsCfg<uint32_t> { static constexpr int kThreads = 1024, kTile = 4096; };
+// kResident: workgroups of the pass kernel the chip holds at once (LDS-bound: 4 per CU for 16-bit keys, 1 per CU for 32-bit),
+// below which the grid runs without tickets
+template <typename KeyT> struct OsCfg { static constexpr int kThreads = 512, kTile = 5120, kResident = 512; };
+template <> struct OsCfg<uint32_t> { static constexpr int kThreads = 1024, kTile = 4096, kResident = 256; };
 
 // NB = digit table size: 256, or 64 when the digits of the sort are at most 6 bits wide (a quarter of the LDS tables:
 // five instead of three workgroups per CU for 16-bit keys).  Status words keep their 256-word stride in memory.
@@ -450,7 +452,7 @@ inline hipError_t onesweep_sort_pairs(KeyT* keys, uint32_t* vals, KeyT* keys_alt
     uint32_t *vin = vals, *vout = vals_alt;
     for (int p = 0; p < passes; p++) {
         const uint32_t pmask = (1u << (dbits < bits - dbits * p ? dbits : bits - dbits * p)) - 1u;
-        uint32_t* tk_p = nblocks <= 512u ? (uint32_t*)nullptr : tickets + p;
+        uint32_t* tk_p = nblocks <= (uint32_t)OsCfg<KeyT>::kResident ? (uint32_t*)nullptr : tickets + p;
         if (dbits <= 6)
             hipLaunchKernelGGL((k_onesweep<KeyT, 64>), dim3(nblocks), dim3(OsCfg<KeyT>::kThreads), 0, stream, kin, vin, kout, vout, n,
                                begin_bit + dbits * p, ghist + p * 256, status + (size_t)p * nblocks * 256, tk_p, n_dev, pmask);

@@ -153,6 +153,8 @@ size_t gsr_image_bytes(int32_t W, int32_t H);
 size_t gsr_image_staged_offset(int32_t W, int32_t H);
 size_t gsr_forward_scratch_bytes(int32_t N);
 size_t gsr_binning_bytes(int64_t R, int32_t W, int32_t H);
+/* upper bound of what the forward asks its allocator for (GSR_ALLOC_SCRATCH): sized for 32-bit tile keys, which images
+ * above 65 536 tiles use; smaller images carry 16-bit keys and ask for 4 R bytes less */
 size_t gsr_binning_scratch_bytes(int64_t R);
 size_t gsr_backward_scratch_bytes(int32_t N);
 

@@ -24,7 +24,7 @@ CASES = [
 ]
 
 
-def _run_case(N, W, H, deg, posed, mode, bg, ppt=None, noncontig=False, color_only=False, ambig_max_frac=None):
+def _run_case(N, W, H, deg, posed, mode, bg, ppt=None, noncontig=False, color_only=False, ambig_max_frac=None, fwd_atol=None):
     import hip_runner
     sc = parity.syn.make_scene(N, W, H, sh_degree=deg, seed=N % 97, posed=posed)
     kw = parity.scene_kwargs(sc, mode, bg=bg)
@@ -37,7 +37,7 @@ def _run_case(N, W, H, deg, posed, mode, bg, ppt=None, noncontig=False, color_on
         gd = ga = None
     ref = o.backward(gc, gd, ga)
     out = hip_runner.run_hip(kw, (gc, gd, ga), noncontig=noncontig)
-    rep = parity.check_forward(out["fwd"], o, f"hip fwd {N}/{W}x{H}/deg{deg}/{mode}", ambig_max_frac)
+    rep = parity.check_forward(out["fwd"], o, f"hip fwd {N}/{W}x{H}/deg{deg}/{mode}", ambig_max_frac, fwd_atol)
     grep = parity.check_grads(out["grads"], ref, f"hip bwd {N}/{W}x{H}/deg{deg}/{mode}")
     print(rep, {k: "%.1e" % v for k, v in grep.items()})
     o.close()
@@ -46,6 +46,15 @@ def _run_case(N, W, H, deg, posed, mode, bg, ppt=None, noncontig=False, color_on
 @pytest.mark.parametrize("case", CASES, ids=lambda c: f"{c[0]}-{c[1]}x{c[2]}-d{c[3]}-{c[5]}")
 def test_parity_vs_oracle(case):
     _run_case(*case)
+
+
+def test_more_than_65536_tiles():
+    """4112 x 4112 pixels = 257 x 257 = 66 049 tiles: tile ids no longer fit 16 bits, so the instance stream carries 32-bit
+    keys (three 6-bit passes of the wide onesweep).  The public module this replaces has no image-size limit.
+    Forward tolerance 4e-5 instead of 1e-5: the blend works on binary32 pixel coordinates, and 2 056 px from the image centre
+    one ulp is 2.4e-4 px -- a relative error of a * dx * ulp ~ 1e-4 in a splat's weight three sigma out (the public module
+    keeps ABSOLUTE binary32 pixel coordinates, twice that).  The float64 oracle does not round there."""
+    _run_case(30000, 4112, 4112, 1, True, "sh", (0.2, 0.1, 0.0), fwd_atol=4e-5)
 
 
 # BASELINE.json configs at FULL size, straight against the oracle (it is OpenMP C: seconds on the GPU box's host)
