@@ -48,7 +48,21 @@ def test_radix_sort_u32_stable(n, bits, few):
     assert torch.equal(got_keys, keys[order])
 
 
-@pytest.mark.parametrize("n", [5, 4096, 300001])
+@pytest.mark.parametrize("n,bits", [(1_500_000, 32), (5_000_000, 32), (2_000_003, 17), (700_001, 20), (3_000_000, 24)])
+def test_radix_sort_u32_large_and_odd_widths(n, bits):
+    """More workgroups than the chip holds at once (ticketed order; 1.5 M keys sit between one and two residencies of the
+    1024-thread pass kernel) and the digit splits of wide tile keys: 17 bits = 3 x 6 (64-entry tables), 20 bits = 3 x 7,
+    24 bits = 3 x 8."""
+    g = torch.Generator().manual_seed(n + bits)
+    keys = torch.randint(0, 1 << bits, (n,), generator=g, dtype=torch.int64)
+    vals = torch.arange(n, dtype=torch.int64)
+    sk, sv = _sort((keys - (keys >= 2**31) * 2**32).to(torch.int32), vals.to(torch.int32), bits)
+    order = torch.sort(keys, stable=True).indices
+    assert torch.equal(sv.cpu().to(torch.int64), order), "values not in stable sorted order"
+    assert torch.equal(sk.cpu().to(torch.int64) & 0xFFFFFFFF, keys[order])
+
+
+@pytest.mark.parametrize("n", [5, 4096, 300001, 6_000_000])
 @pytest.mark.parametrize("T", [200, 2170, 40000])
 def test_radix_sort_u16_stable(n, T):
     g = torch.Generator().manual_seed(n + T)
