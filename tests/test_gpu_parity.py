@@ -392,3 +392,52 @@ def test_under_no_grad_and_depth_mutation():
     depth[depth < 5.0] = 5.0   # in-place on an output
     g2 = torch.autograd.grad(color.sum(), t["means3D"])[0]
     assert torch.allclose(g_ref, g2, rtol=1e-3, atol=1e-5 * float(g_ref.abs().max()))
+
+
+def test_two_host_threads_two_streams():
+    """Two host threads render different scenes on their own streams at the same time (the library keeps process-wide state:
+    the capacity hint of the speculative binning and the pinned read-back slot of the instance count).  Forward results must be
+    bit-identical to the same renders done one after the other."""
+    import threading
+    import hip_runner
+    from diff_gaussian_rasterization import GaussianRasterizer
+    dev = torch.device("cuda:0")
+    jobs = []
+    for seed, (N, W, H) in enumerate([(40000, 640, 360), (15000, 330, 250)]):
+        sc = parity.syn.make_scene(N, W, H, sh_degree=2, seed=seed + 11)
+        kw = parity.scene_kwargs(sc, "sh")
+        t = {k: kw[k].to(dev) for k in ["means3D", "shs", "opacities", "scales", "rotations"]}
+        jobs.append((GaussianRasterizer(hip_runner.settings_from(kw, dev)), t, N))
+
+    def render(job):
+        rast, t, N = job
+        m2d = torch.zeros(N, 3, device=dev)
+        with torch.no_grad():
+            c, r, d, a = rast(means3D=t["means3D"], means2D=m2d, shs=t["shs"], colors_precomp=None, opacities=t["opacities"],
+                              scales=t["scales"], rotations=t["rotations"], cov3D_precomp=None)
+        return c, r, d, a
+
+    ref = [render(j) for j in jobs]
+    torch.cuda.synchronize()
+    errors = []
+
+    def worker(i):
+        try:
+            s = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(s):
+                for _ in range(25):
+                    out = render(jobs[i])
+                    s.synchronize()
+                    for got, want in zip(out, ref[i]):
+                        if not torch.equal(got, want):
+                            errors.append(f"thread {i}: output differs from the sequential render")
+                            return
+        except Exception as e:   # noqa: BLE001
+            errors.append(f"thread {i}: {e!r}")
+
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t_ in th:
+        t_.start()
+    for t_ in th:
+        t_.join()
+    assert not errors, errors
