@@ -1,0 +1,39 @@
+"""Stability soak: training steps over six alternating views with densification surgery (clone 3 %, prune ~3 %, opacity reset)
+every 500 / 3000 steps, checking for non-finite parameters.  Needs a GPU:  gpurun -- 'python tools/soak.py [steps] [gaussians]'
+(round 1: 12 000 steps at 300 k in 9 s and 40 000 steps at 1 M -> 2.9 M Gaussians in 73 s, no non-finite value, no hang)."""
+import sys, time, importlib, torch
+sys.path.insert(0, '.')   # run from the repository root
+syn = importlib.import_module('3dgs_hierarchical_training_amd.synthetic')
+ts = importlib.import_module('3dgs_hierarchical_training_amd.train_step')
+dev = torch.device('cuda:0')
+N, W, H = int(sys.argv[2]) if len(sys.argv) > 2 else 300000, 980, 545
+scene = syn.make_scene(N, W, H, sh_degree=3, seed=3)
+gen = torch.Generator().manual_seed(0)
+views = []
+for k in range(6):
+    c = syn.make_camera(W, H, R=syn.random_rotation(gen, 0.2), t=0.2 * torch.randn(3, generator=gen))
+    s = dict(scene); s.update(c); views.append(ts.make_settings(s, dev, 3))
+gts = [syn.target_image(W, H, seed=10 + k).to(dev) * 0.5 + 0.25 for k in range(6)]
+params = ts.GaussianParams(scene, dev)
+t0 = time.time()
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 6000
+for it in range(steps):
+    v = it % 6
+    pkg = ts.train_step(params, views[v], gts[v])
+    if it % 500 == 499:
+        n = params._xyz.shape[0]
+        # densify: clone 3 % (random), prune 3 % (lowest opacity), like the reference's cadence
+        idx = torch.randperm(n, device=dev)[: n // 33]
+        new = {g["name"]: g["params"][0].detach()[idx].clone() for g in params.optimizer.param_groups}
+        params.densification_postfix(new)
+        op = params.get_opacity.detach().squeeze(1)
+        thr = torch.quantile(op[torch.randperm(op.numel(), device=dev)[:100000]], 0.03)
+        params.prune_points(op < thr)
+        if it % 3000 == 2999:
+            params.reset_opacity()
+        l = float(pkg["loss"])
+        bad = any(not torch.isfinite(g["params"][0]).all() for g in params.optimizer.param_groups)
+        print(it + 1, "N", params._xyz.shape[0], "loss %.5f" % l, "nonfinite", bad, "%.1f s" % (time.time() - t0), flush=True)
+        assert not bad and l == l
+torch.cuda.synchronize()
+print("done", steps, "steps in %.1f s" % (time.time() - t0))
