@@ -233,12 +233,17 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const KeyT* __re
 // publishes its LOCAL count before it waits on anything, so the look-back can always walk back to tile 0:
 // no circular wait.  Versus hist+scan+scatter this reads the keys once per pass and saves two launches.
 // ------------------------------------------------------------------------------------------------
+// kResident: workgroups of the pass kernel the chip holds at once (LDS-bound: 4 per CU for 16-bit keys, 1 per CU for 32-bit),
+// below which the grid runs without tickets
+template <typename KeyT> struct OsCfg { static constexpr int kThreads = 512, kTile = 5120, kResident = 512; };
+template <> struct OsCfg<uint32_t> { static constexpr int kThreads = 1024, kTile = 4096, kResident = 256; };
+constexpr int kOsRanges = 8;
 constexpr uint32_t kOsLocal = 1u << 30, kOsIncl = 2u << 30, kOsMask = (1u << 30) - 1u;
-constexpr uint32_t kOnesweepHeadWords = 4 * 256 + 64;   // scratch head: ghist[4][256] + tickets (padded); status follows
+constexpr uint32_t kOnesweepHeadWords = 4 * kOsRanges * 256 + 64;   // scratch head: ghist[4][256] + tickets (padded); status follows
 
 template <typename KeyT, int PASSES>
 __global__ __launch_bounds__(256) void k_radix_ghist(const KeyT* __restrict__ keys, uint32_t n, int begin_bit,
-                                                     uint32_t* __restrict__ ghist /*[PASSES][256]*/,
+                                                     uint32_t* __restrict__ ghist /*[PASSES][8][256]*/,
                                                      const unsigned long long* __restrict__ n_dev,
                                                      uint32_t* __restrict__ status, uint32_t status_words, int dbits, int bits)
 {
@@ -255,10 +260,16 @@ __global__ __launch_bounds__(256) void k_radix_ghist(const KeyT* __restrict__ ke
 #pragma unroll
     for (int p = 0; p < PASSES; p++) h[p][tid] = 0;
     __syncthreads();
+    constexpr uint64_t kT = (uint64_t)OsCfg<KeyT>::kTile;
+    const uint64_t ntiles = ((uint64_t)n + kT - 1) / kT, per = (ntiles + kOsRanges - 1) / kOsRanges;
+    const uint32_t bpr = gridDim.x / kOsRanges, x = blockIdx.x / bpr, sub = blockIdx.x - x * bpr;
+    const uint64_t lo = min((uint64_t)n, (uint64_t)x * per * kT), hi = min((uint64_t)n, (uint64_t)(x + 1) * per * kT);
     constexpr int KPV = 16 / (int)sizeof(KeyT);   // keys per 16-byte load
-    const uint32_t nv = (((uintptr_t)keys & 15) == 0) ? n / KPV : 0u;
-    const uint4* k4 = reinterpret_cast<const uint4*>(keys);
-    for (uint32_t i = blockIdx.x * 256 + tid; i < nv; i += gridDim.x * 256) {
+    const KeyT* kr = keys + lo;
+    const uint32_t len = (uint32_t)(hi - lo);
+    const uint32_t nv = (((uintptr_t)kr & 15) == 0) ? len / KPV : 0u;
+    const uint4* k4 = reinterpret_cast<const uint4*>(kr);
+    for (uint32_t i = sub * 256 + tid; i < nv; i += bpr * 256) {
         const uint4 q = k4[i];
         const uint32_t w[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
@@ -271,15 +282,15 @@ __global__ __launch_bounds__(256) void k_radix_ghist(const KeyT* __restrict__ ke
             }
         }
     }
-    for (uint32_t i = nv * KPV + blockIdx.x * 256 + tid; i < n; i += gridDim.x * 256) {
-        const uint32_t k = (uint32_t)keys[i] >> begin_bit;
+    for (uint32_t i = nv * KPV + sub * 256 + tid; i < len; i += bpr * 256) {
+        const uint32_t k = (uint32_t)kr[i] >> begin_bit;
 #pragma unroll
         for (int p = 0; p < PASSES; p++) atomicAdd(&h[p][(k >> (dbits * p)) & dmask[p]], 1u);
     }
     __syncthreads();
 #pragma unroll
     for (int p = 0; p < PASSES; p++)
-        if (h[p][tid]) atomicAdd(&ghist[p * 256 + tid], h[p][tid]);
+        if (h[p][tid]) atomicAdd(&ghist[(p * kOsRanges + x) * 256 + tid], h[p][tid]);
 }
 
 // 512 threads x 8 keys per tile: the same 4096-key tile as the three-kernel path, but half the ranking rounds per
@@ -291,10 +302,6 @@ __global__ __launch_bounds__(256) void k_radix_ghist(const KeyT* __restrict__ ke
 // One wave per 8 digits reading 64 predecessors per round trip (instead of one thread per digit reading 4): 3.7x SLOWER --
 // the look-back is bound by the status traffic in L2, not by the length of the walk.
 constexpr int kOsTile = 4096;
-// kResident: workgroups of the pass kernel the chip holds at once (LDS-bound: 4 per CU for 16-bit keys, 1 per CU for 32-bit),
-// below which the grid runs without tickets
-template <typename KeyT> struct OsCfg { static constexpr int kThreads = 512, kTile = 5120, kResident = 512; };
-template <> struct OsCfg<uint32_t> { static constexpr int kThreads = 1024, kTile = 4096, kResident = 256; };
 
 // NB = digit table size: 256, or 64 when the digits of the sort are at most 6 bits wide (a quarter of the LDS tables:
 // five instead of three workgroups per CU for 16-bit keys).  Status words keep their 256-word stride in memory.
@@ -304,7 +311,7 @@ __global__ __launch_bounds__(OsCfg<KeyT>::kThreads) void k_onesweep(const KeyT* 
                                                          const uint32_t* __restrict__ ghist /*[256] this pass*/,
                                                          uint32_t* __restrict__ status /*[nblocks][256]*/,
                                                          uint32_t* __restrict__ ticket,
-                                                         const unsigned long long* __restrict__ n_dev, uint32_t dmask)
+                                                         const unsigned long long* __restrict__ n_dev, uint32_t dmask, int runs)
 {
     constexpr int kOsThreads = OsCfg<KeyT>::kThreads, kOsTile = OsCfg<KeyT>::kTile, kOsIPT = kOsTile / kOsThreads, kOsWaves = kOsThreads / 64;
     if (n_dev) n = (uint32_t)min((unsigned long long)n, *n_dev);   // device-side count: tiles past it exit at once
@@ -319,14 +326,22 @@ __global__ __launch_bounds__(OsCfg<KeyT>::kThreads) void k_onesweep(const KeyT* 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     // ticket == nullptr: the whole grid is co-resident (host checked), so blockIdx order is as good as ticket order and
     // the ~2 us global-atomic round trip at the head of every block's latency chain is saved
-    uint32_t tile = blockIdx.x;
+    // The FIRST pass cuts the key array into eight runs of tiles with their own look-back chains (run = blockIdx & 7): the
+    // histogram kernel counted its digits per run, so a run's digit base is known up front.  Later passes see the keys in
+    // the order the previous pass produced, for which no per-run counts exist: one chain (runs = 1).
+    const uint32_t ntiles = (uint32_t)(((uint64_t)n + kOsTile - 1) / kOsTile);
+    const uint32_t per = runs > 1 ? (ntiles + kOsRanges - 1) / kOsRanges : ntiles;
+    const uint32_t run = runs > 1 ? (blockIdx.x & (kOsRanges - 1)) : 0u;
+    uint32_t krun = runs > 1 ? blockIdx.x / kOsRanges : blockIdx.x;
     if (ticket) {
-        if (tid == 0) s_tile = atomicAdd(ticket, 1u);
+        if (tid == 0) s_tile = atomicAdd(ticket + run, 1u);
         __syncthreads();
-        tile = s_tile;
+        krun = s_tile;
     }
+    const uint32_t run_start = run * per;
+    const uint32_t tile = run_start + krun;
+    if (krun >= per || tile >= ntiles) return;   // (uniform) the grid covers the capacity, the runs the device-side count
     const uint32_t base = tile * (uint32_t)kOsTile;
-    if (base >= n) return;   // (uniform) only when the grid was sized for a capacity above the device-side count
     const uint32_t valid = min((uint32_t)kOsTile, n - base);
     KeyT key[kOsIPT];
     uint32_t val[kOsIPT], dig[kOsIPT], rnk[kOsIPT];
@@ -359,17 +374,27 @@ __global__ __launch_bounds__(OsCfg<KeyT>::kThreads) void k_onesweep(const KeyT* 
     if (is_digit) __hip_atomic_store(my_status, kOsLocal | real, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // local exclusive start of each digit (block scan of `mine`) and digit base (block scan of the global histogram)
     const uint32_t lstart = block_scan_excl<kOsWaves>(mine, s_wsum, tid);
-    const uint32_t dbase = block_scan_excl<kOsWaves>(is_digit ? ghist[tid] : 0u, s_wsum, tid);
+    uint32_t gtot = 0u, gpre = 0u;   // keys of this digit in all runs / in the runs in front of this one
+    if (is_digit) {
+#pragma unroll
+        for (int x = 0; x < kOsRanges; x++) {
+            const uint32_t c = ghist[x * 256 + tid];
+            gtot += c;
+            gpre += (uint32_t)x < run ? c : 0u;
+        }
+    }
+    const uint32_t dbase = block_scan_excl<kOsWaves>(gtot, s_wsum, tid) + gpre;
     if (is_digit) {
         // decoupled look-back over earlier tiles
         // (windows of 4 independent loads: the walk is a chain of L2 round trips, and the chain is what a block waits on)
         uint32_t excl = 0;
-        for (int t = (int)tile - 1; t >= 0;) {
+        const int t_lo = (int)run_start;   // the chain ends at the head of the run: what lies in front is in the digit base
+        for (int t = (int)tile - 1; t >= t_lo;) {
             constexpr int kWin = 4;   // (8: same speed, 16: +20 % per pass -- the polls compete for the status lines in L2)
             uint32_t v[kWin];
 #pragma unroll
             for (int q = 0; q < kWin; q++)
-                v[q] = (t - q >= 0) ? __hip_atomic_load(status + (size_t)(t - q) * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kOsIncl;
+                v[q] = (t - q >= t_lo) ? __hip_atomic_load(status + (size_t)(t - q) * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kOsIncl;
             bool done = false;
 #pragma unroll
             for (int q = 0; q < kWin; q++) {
@@ -378,9 +403,9 @@ __global__ __launch_bounds__(OsCfg<KeyT>::kThreads) void k_onesweep(const KeyT* 
                 if (f == 0u) { done = true; break; }   // not published yet: re-poll from here
                 excl += v[q] & kOsMask;
                 t--;
-                if (f == kOsIncl) { t = -1; done = true; }
+                if (f == kOsIncl) { t = t_lo - 1; done = true; }
             }
-            if (t >= 0 && done) __builtin_amdgcn_s_sleep(1);
+            if (t >= t_lo && done) __builtin_amdgcn_s_sleep(1);
         }
         __hip_atomic_store(my_status, kOsIncl | (excl + real), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_start[tid] = lstart;
@@ -411,7 +436,7 @@ inline size_t onesweep_scratch_bytes(uint32_t n)
 {
     const size_t nblocks = ((size_t)n + kOsTile - 1) / kOsTile;
     // ghist[4][256] + tickets[4] (padded) + status[4 passes][nblocks][256]
-    return ((4 * 256 + 64 + 4 * (nblocks ? nblocks : 1) * 256) * sizeof(uint32_t) + 255) & ~(size_t)255;
+    return ((kOnesweepHeadWords + 4 * (nblocks ? nblocks : 1) * 256) * sizeof(uint32_t) + 255) & ~(size_t)255;
 }
 
 // begin_bit..end_bit in 8-bit passes (at most 4).  Same contract as radix_sort_pairs.  n_dev != nullptr: `n` is only a
@@ -431,7 +456,7 @@ inline hipError_t onesweep_sort_pairs(KeyT* keys, uint32_t* vals, KeyT* keys_alt
     const int dbits = (bits + passes - 1) / passes;
     const uint32_t nblocks = (n + OsCfg<KeyT>::kTile - 1) / OsCfg<KeyT>::kTile;   // (the scratch is sized for 4096-key tiles: never fewer words)
     uint32_t* ghist = static_cast<uint32_t*>(scratch);
-    uint32_t* tickets = ghist + 4 * 256;
+    uint32_t* tickets = ghist + 4 * kOsRanges * 256;   // [pass][run]
     uint32_t* status = tickets + 64;
     // the head (histograms + tickets) must be zero before the histogram kernel; callers that can clear it in a kernel
     // of their own say so.  The status words are cleared by the histogram kernel itself.
@@ -441,7 +466,8 @@ inline hipError_t onesweep_sort_pairs(KeyT* keys, uint32_t* vals, KeyT* keys_alt
     }
     const uint32_t status_words = (uint32_t)((size_t)passes * nblocks * 256);
     // (64 blocks of 1024 threads, to shorten the per-address chains of the closing global atomics: +5 us per sort)
-    const uint32_t hgrid = nblocks < 256u ? nblocks : 256u;
+    const uint32_t per_cap = (nblocks + kOsRanges - 1) / kOsRanges;
+    const uint32_t hgrid = kOsRanges * (per_cap < 32u ? per_cap : 32u);   // histogram blocks: up to 32 per run
     switch (passes) {
         case 1: hipLaunchKernelGGL((k_radix_ghist<KeyT, 1>), dim3(hgrid), dim3(256), 0, stream, keys, n, begin_bit, ghist, n_dev, status, status_words, dbits, bits); break;
         case 2: hipLaunchKernelGGL((k_radix_ghist<KeyT, 2>), dim3(hgrid), dim3(256), 0, stream, keys, n, begin_bit, ghist, n_dev, status, status_words, dbits, bits); break;
@@ -452,13 +478,15 @@ inline hipError_t onesweep_sort_pairs(KeyT* keys, uint32_t* vals, KeyT* keys_alt
     uint32_t *vin = vals, *vout = vals_alt;
     for (int p = 0; p < passes; p++) {
         const uint32_t pmask = (1u << (dbits < bits - dbits * p ? dbits : bits - dbits * p)) - 1u;
-        uint32_t* tk_p = nblocks <= (uint32_t)OsCfg<KeyT>::kResident ? (uint32_t*)nullptr : tickets + p;
+        const int runs = p == 0 ? kOsRanges : 1;
+        const uint32_t pgrid = runs > 1 ? kOsRanges * per_cap : nblocks;
+        uint32_t* tk_p = pgrid <= (uint32_t)OsCfg<KeyT>::kResident ? (uint32_t*)nullptr : tickets + p * kOsRanges;
         if (dbits <= 6)
-            hipLaunchKernelGGL((k_onesweep<KeyT, 64>), dim3(nblocks), dim3(OsCfg<KeyT>::kThreads), 0, stream, kin, vin, kout, vout, n,
-                               begin_bit + dbits * p, ghist + p * 256, status + (size_t)p * nblocks * 256, tk_p, n_dev, pmask);
+            hipLaunchKernelGGL((k_onesweep<KeyT, 64>), dim3(pgrid), dim3(OsCfg<KeyT>::kThreads), 0, stream, kin, vin, kout, vout, n,
+                               begin_bit + dbits * p, ghist + p * kOsRanges * 256, status + (size_t)p * nblocks * 256, tk_p, n_dev, pmask, runs);
         else
-            hipLaunchKernelGGL((k_onesweep<KeyT, 256>), dim3(nblocks), dim3(OsCfg<KeyT>::kThreads), 0, stream, kin, vin, kout, vout, n,
-                               begin_bit + dbits * p, ghist + p * 256, status + (size_t)p * nblocks * 256, tk_p, n_dev, pmask);
+            hipLaunchKernelGGL((k_onesweep<KeyT, 256>), dim3(pgrid), dim3(OsCfg<KeyT>::kThreads), 0, stream, kin, vin, kout, vout, n,
+                               begin_bit + dbits * p, ghist + p * kOsRanges * 256, status + (size_t)p * nblocks * 256, tk_p, n_dev, pmask, runs);
         KeyT* tk = kin; kin = kout; kout = tk;
         uint32_t* tv = vin; vin = vout; vout = tv;
         *in_alt ^= 1;
@@ -471,7 +499,7 @@ inline size_t radix_scratch_bytes(uint32_t n)
     const size_t nblocks = ((size_t)n + kSortTile - 1) / kSortTile;
     const size_t osblocks = ((size_t)n + kOsTile - 1) / kOsTile;
     const size_t three_kernel = ((256 * (nblocks ? nblocks : 1) + 8 * 256) * sizeof(uint32_t) + 255) & ~(size_t)255;   // hist + totals
-    const size_t onesweep = ((4 * 256 + 64 + 4 * (osblocks ? osblocks : 1) * 256) * sizeof(uint32_t) + 255) & ~(size_t)255;
+    const size_t onesweep = ((kOnesweepHeadWords + 4 * (osblocks ? osblocks : 1) * 256) * sizeof(uint32_t) + 255) & ~(size_t)255;
     return three_kernel > onesweep ? three_kernel : onesweep;
 }
 
