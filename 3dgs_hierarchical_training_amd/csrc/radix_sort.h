@@ -237,9 +237,10 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const KeyT* __re
 // below which the grid runs without tickets
 template <typename KeyT> struct OsCfg { static constexpr int kThreads = 512, kTile = 5120, kResident = 512; };
 template <> struct OsCfg<uint32_t> { static constexpr int kThreads = 1024, kTile = 4096, kResident = 256; };
-constexpr int kOsRanges = 8;
+constexpr int kOsRanges = 32;
 constexpr uint32_t kOsLocal = 1u << 30, kOsIncl = 2u << 30, kOsMask = (1u << 30) - 1u;
-constexpr uint32_t kOnesweepHeadWords = 4 * kOsRanges * 256 + 64;   // scratch head: ghist[4][256] + tickets (padded); status follows
+constexpr uint32_t kOsTicketWords = (4 * kOsRanges + 63) / 64 * 64;   // tickets[pass][run], padded
+constexpr uint32_t kOnesweepHeadWords = 4 * kOsRanges * 256 + kOsTicketWords;   // scratch head: ghist[4][256] + tickets (padded); status follows
 
 template <typename KeyT, int PASSES>
 __global__ __launch_bounds__(256) void k_radix_ghist(const KeyT* __restrict__ keys, uint32_t n, int begin_bit,
@@ -453,11 +454,11 @@ inline hipError_t onesweep_sort_pairs(KeyT* keys, uint32_t* vals, KeyT* keys_alt
     if (passes < 1 || passes > 4) return hipErrorInvalidValue;
     // balanced digits: 12 key bits sort as 6 + 6 rather than 8 + 4 (fewer same-digit collisions in the ranking, longer
     // runs per digit in the scatter); the last digit is narrower when the bits do not divide evenly
-    const int dbits = (bits + passes - 1) / passes;
+    const int dbits = (bits + passes - 1) / passes;   // (12 tile-key bits as 7 + 5 or 8 + 4: +2 / +5 us)
     const uint32_t nblocks = (n + OsCfg<KeyT>::kTile - 1) / OsCfg<KeyT>::kTile;   // (the scratch is sized for 4096-key tiles: never fewer words)
     uint32_t* ghist = static_cast<uint32_t*>(scratch);
     uint32_t* tickets = ghist + 4 * kOsRanges * 256;   // [pass][run]
-    uint32_t* status = tickets + 64;
+    uint32_t* status = tickets + kOsTicketWords;
     // the head (histograms + tickets) must be zero before the histogram kernel; callers that can clear it in a kernel
     // of their own say so.  The status words are cleared by the histogram kernel itself.
     if (!head_prezeroed) {
@@ -481,7 +482,8 @@ inline hipError_t onesweep_sort_pairs(KeyT* keys, uint32_t* vals, KeyT* keys_alt
         const int runs = p == 0 ? kOsRanges : 1;
         const uint32_t pgrid = runs > 1 ? kOsRanges * per_cap : nblocks;
         uint32_t* tk_p = pgrid <= (uint32_t)OsCfg<KeyT>::kResident ? (uint32_t*)nullptr : tickets + p * kOsRanges;
-        if (dbits <= 6)
+        const int wbits = dbits < bits - dbits * p ? dbits : bits - dbits * p;   // this pass's digit width
+        if (wbits <= 6)
             hipLaunchKernelGGL((k_onesweep<KeyT, 64>), dim3(pgrid), dim3(OsCfg<KeyT>::kThreads), 0, stream, kin, vin, kout, vout, n,
                                begin_bit + dbits * p, ghist + p * kOsRanges * 256, status + (size_t)p * nblocks * 256, tk_p, n_dev, pmask, runs);
         else
