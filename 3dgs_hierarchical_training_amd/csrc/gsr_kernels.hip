@@ -624,20 +624,36 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit(int N, int W, int H, int 
 }
 
 // K6: per-tile [start, end) from the tile-sorted keys (ranges pre-zeroed)
+// one 16-byte load (8 or 4 keys) + the key in front of it per thread
 template <typename KeyT>
-__global__ void k_tile_ranges(uint32_t R, const KeyT* __restrict__ keys, uint2* __restrict__ ranges,
-                              const unsigned long long* __restrict__ n_dev)
+__global__ __launch_bounds__(256) void k_tile_ranges(uint32_t R, const KeyT* __restrict__ keys, uint2* __restrict__ ranges,
+                                                     const unsigned long long* __restrict__ n_dev)
 {
     if (n_dev) R = (uint32_t)min((unsigned long long)R, *n_dev);
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= R) return;
-    const uint32_t t = keys[i];
-    if (i == 0) ranges[t].x = 0;
-    else {
-        const uint32_t p = keys[i - 1];
-        if (p != t) { ranges[p].y = i; ranges[t].x = i; }
+    constexpr uint32_t KPV = 16 / (uint32_t)sizeof(KeyT);
+    const uint32_t i0 = (blockIdx.x * 256u + threadIdx.x) * KPV;
+    if (i0 >= R) return;
+    uint32_t t[KPV];
+    if (i0 + KPV <= R && (((uintptr_t)keys & 15) == 0)) {
+        const uint4 q = *reinterpret_cast<const uint4*>(keys + i0);
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (uint32_t c = 0; c < KPV; c++) t[c] = sizeof(KeyT) == 4 ? w[c] : ((w[c / 2] >> (16 * (c & 1))) & 0xffffu);
+    } else {
+#pragma unroll
+        for (uint32_t c = 0; c < KPV; c++) t[c] = i0 + c < R ? (uint32_t)keys[i0 + c] : 0u;
     }
-    if (i == R - 1) ranges[t].y = R;
+    uint32_t prev = i0 ? (uint32_t)keys[i0 - 1] : 0xffffffffu;
+#pragma unroll
+    for (uint32_t c = 0; c < KPV; c++) {
+        const uint32_t i = i0 + c;
+        if (i < R) {
+            if (i == 0) ranges[t[c]].x = 0;
+            else if (prev != t[c]) { ranges[prev].y = i; ranges[t[c]].x = i; }
+            if (i == R - 1) ranges[t[c]].y = R;
+            prev = t[c];
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1959,7 +1975,8 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
         const KeyT* skey = in_alt ? tkey_alt : tkey;
         {
             ProfScope ps(P_RANGES, st);
-            hipLaunchKernelGGL(k_tile_ranges<KeyT>, dim3(((uint32_t)capacity + 255) / 256), dim3(256), 0, st, (uint32_t)capacity, skey, ranges, n_dev);
+            constexpr uint32_t kpb = 256u * (16u / (uint32_t)sizeof(KeyT));   // keys per block
+            hipLaunchKernelGGL(k_tile_ranges<KeyT>, dim3(((uint32_t)capacity + kpb - 1) / kpb), dim3(256), 0, st, (uint32_t)capacity, skey, ranges, n_dev);
         }
         return GSR_OK;
     };
