@@ -64,3 +64,30 @@ def retr_matrix(delta: torch.Tensor, pose7: torch.Tensor) -> torch.Tensor:
 def act(matrix: torch.Tensor, xyz: torch.Tensor) -> torch.Tensor:
     """R p + t on [N,3] points: the torch statement of what the kernels do with `points_transform`."""
     return xyz @ matrix[:3, :3].t() + matrix[:3, 3]
+
+
+def so3_log(R: torch.Tensor) -> torch.Tensor:
+    """Rotation vector phi with exp(phi^) = R (angle in [0, pi)); series near 0."""
+    cos = ((R[0, 0] + R[1, 1] + R[2, 2] - 1.0) * 0.5).clamp(-1.0, 1.0)
+    th = torch.acos(cos)
+    w = torch.stack((R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1])) * 0.5      # sin(th) * axis
+    small = th < 1e-4
+    ths = torch.where(small, torch.ones_like(th), th)
+    k = torch.where(small, 1.0 + th * th / 6.0, ths / torch.sin(ths))
+    return k * w
+
+
+def se3_log(M: torch.Tensor) -> torch.Tensor:
+    """Inverse of se3_exp: [4,4] rigid transform -> tangent (tau[3], phi[3])."""
+    phi = so3_log(M[:3, :3])
+    _, V = so3_exp_and_v(phi)
+    tau = torch.linalg.solve(V, M[:3, 3])
+    return torch.cat((tau, phi))
+
+
+def interpolate_pose(pose0: torch.Tensor, pose1: torch.Tensor, alpha: float) -> torch.Tensor:
+    """Virtual view between two poses, pose0 * Exp(alpha * Log(pose0^-1 * pose1)) -- what `get_virtual_view`
+    (/root/reference/trainer/ht3dgs_trainer.py:462-479) evaluates with lietorch; alpha = 0 / 1 give pose0 / pose1."""
+    assert 0.0 <= alpha <= 1.0
+    p0, p1 = pose0.double(), pose1.double()
+    return (p0 @ se3_exp(alpha * se3_log(torch.linalg.inv(p0) @ p1))).to(pose0.dtype)

@@ -1,0 +1,329 @@
+#!/usr/bin/env python3
+"""BASELINE config 4: hierarchical training with one leaf segment per GPU and a point-to-point exchange at each merge.
+
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \
+         3dgs_hierarchical_training_amd/run_segments.py --frames 40 --leaf-gaussians 200000
+  python 3dgs_hierarchical_training_amd/run_segments.py --local --segments 8      # whole tree on one GPU, in order
+
+Stage B of `HTGaussianTrainer.hierarchical_training` (/root/reference/trainer/ht3dgs_trainer.py:710-813) re-cut for
+eight GPUs:
+
+  reference (one GPU, sequential)                       here (rank r = leaf r)
+  ------------------------------------------------      ---------------------------------------------------------------
+  for each leaf: init_leaf_3DGS + train_leaf_3DGS       every rank trains its own leaf at the same time, no communication
+    :729-753
+  after every second segment: merge_two_3DGS            level k: ranks (2^(k+1) j, 2^(k+1) j + 2^k) pair up; both compute
+    (importance of both, prune both, move the             their own child's importance at the same time, the source ships
+    source by inverse(get_RT(src.start_fidx)),            the UN-PRUNED child + drop mask + frames + poses over its own
+    append) :767-780, :214-272                            xGMI link, the destination applies the masks, moves, appends
+  poses of the source's frames chained on :783-790      same, from the (replicated) relative-pose table of stage A
+  train_nonleaf_3DGS_phase1 with the two frozen         same, on the destination rank; the teachers are the two un-pruned
+    children as teachers for virtual views :757,          children it now holds (its own snapshot + the received one)
+    :815-900
+  train_nonleaf_3DGS_phase2 on the real frames :762     same
+
+Source ranks are idle after their send (tree reduction: 8 -> 4 -> 2 -> 1 busy GPUs).  Frames, targets and relative
+poses are synthetic (sequence.py); the relative-pose table stands for stage A's result (stage_a.py shards that stage).
+
+`RankRunner` holds one rank's state; `run_local` plays all ranks in turn on one device through `LocalTransport`
+(senders of a level before its receivers) -- the same code path, and the reference's own execution order.
+Every rank prints one JSON line per phase: leaf, and per level {importance_ms, send_ms | recv_ms, bytes, ...}.
+"""
+import argparse
+import importlib
+import json
+import os
+import random
+import sys
+import time
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional
+
+import torch
+
+if __package__ in (None, ""):      # executed as a script: make the oddly named package importable
+    _root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if _root not in sys.path:
+        sys.path.insert(0, _root)
+    _pkg = importlib.import_module("3dgs_hierarchical_training_amd")
+    hierarchy = importlib.import_module("3dgs_hierarchical_training_amd.hierarchy")
+    segments = importlib.import_module("3dgs_hierarchical_training_amd.segments")
+    sequence = importlib.import_module("3dgs_hierarchical_training_amd.sequence")
+    ts = importlib.import_module("3dgs_hierarchical_training_amd.train_step")
+    densify = importlib.import_module("3dgs_hierarchical_training_amd.densify")
+    pose_mod = importlib.import_module("3dgs_hierarchical_training_amd.pose")
+else:
+    from . import densify, hierarchy, segments, sequence
+    from . import pose as pose_mod
+    from . import train_step as ts
+
+
+@dataclass
+class HTConfig:
+    """Iteration counts follow /root/reference/arguments/full/Tanks/Ballroom.yml:5-16 in meaning; the defaults are
+    shortened so the harness finishes in minutes."""
+    frames: int = 40
+    width: int = 980
+    height: int = 545
+    sh_degree: int = 3
+    gt_gaussians: int = 400_000
+    leaf_gaussians: int = 200_000
+    leaf_iters_per_frame: int = 30              # single_step
+    phase1_iters_per_frame: int = 5             # mss_phase1_iteration_per_frame (50 in Ballroom.yml)
+    phase1_ratio: float = 0.5                   # mss_phase1_ratio
+    phase2_iters_per_frame: List[int] = field(default_factory=lambda: [10, 10, 10])   # num_iterations_per_frame_each_level
+    prune_ratio: float = 0.5                    # Ballroom.yml:44
+    importance_views: int = 0                   # 0 = all of the child's frames (the reference), k = every (len/k)-th
+    densify: bool = False
+    seed: int = 0
+    optimizer: str = "hip"
+    fused: bool = True
+
+
+class Segment:
+    """One 3DGS model and what the trainer keeps next to it (`gs_render.start_fidx / to_visit_frames /
+    global_iteration`, :733-735, :766; `get_RT`, gaussian_model_ht.py:150-160)."""
+
+    def __init__(self, params, frames: List[int], start_fidx: int, poses: Dict[int, torch.Tensor], global_iteration: int = 0):
+        self.params, self.frames, self.start_fidx, self.poses, self.global_iteration = params, list(frames), start_fidx, dict(poses), global_iteration
+        self.densifier = None
+
+    def pose_tensor(self) -> torch.Tensor:
+        return torch.stack([self.poses[f] for f in self.frames])
+
+
+class RankRunner:
+    def __init__(self, rank: int, world: int, transport, seq, cfg: HTConfig, device, log=None, importance_fn=None,
+                 step_fn=None, teacher_render_fn=None):
+        """importance_fn / step_fn / teacher_render_fn replace the three places that reach the HIP rasterizer; the
+        GPU-less gloo tests pass stand-ins so that the tree walk, the messages and the bookkeeping run on CPU."""
+        self.rank, self.world, self.tr, self.seq, self.cfg, self.dev = rank, world, transport, seq, cfg, device
+        self.importance_fn = importance_fn or hierarchy.calc_importance
+        self.step_fn = step_fn
+        self.teacher_render_fn = teacher_render_fn or hierarchy.render_raw
+        self.level = world.bit_length() - 1
+        self.parts = sequence.partition(cfg.frames, self.level)
+        self.schedule = segments.merge_schedule(world)
+        self.rng = random.Random(cfg.seed * 1000 + rank)
+        self.seg: Optional[Segment] = None
+        self.teachers = None
+        self.log = log if log is not None else (lambda rec: print(json.dumps(rec), flush=True))
+        self.report = []
+
+    def _emit(self, rec):
+        rec = {"rank": self.rank, **rec}
+        self.report.append(rec)
+        self.log(rec)
+
+    # ---- helpers ---------------------------------------------------------------------------------------------------
+    def _settings(self, seg: Segment, f: int):
+        return self.seq.settings_for_pose(seg.poses[f])
+
+    def _importance_views(self, seg: Segment):
+        fr = seg.frames
+        k = self.cfg.importance_views
+        if k and len(fr) > k:
+            fr = fr[::max(1, len(fr) // k)][:k]
+        return [self._settings(seg, f) for f in fr]
+
+    def _step(self, seg: Segment, settings, target):
+        seg.global_iteration += 1
+        if self.step_fn is not None:
+            return self.step_fn(seg, settings, target)
+        ts.train_step(seg.params, settings, target, fused_optimizer=self.cfg.fused, densifier=seg.densifier,
+                      iteration=seg.global_iteration)
+
+    def _new_densifier(self, seg: Segment):
+        if self.cfg.densify:
+            seg.densifier = densify.Densifier(seg.params, scene_extent=5.0, cfg=densify.DensifyConfig(
+                densify_from_iter=50, densification_interval=100, opacity_reset_interval=3000,
+                max_points=4 * seg.params.num_points), seed=self.rank)
+
+    # ---- leaf (:729-753) ---------------------------------------------------------------------------------------------
+    def train_leaf(self):
+        cfg = self.cfg
+        frames = self.parts[self.level][self.rank]
+        start = frames[0]
+        scene = self.seq.leaf_scene(start, cfg.leaf_gaussians, seed=cfg.seed + 17 * self.rank)
+        params = ts.GaussianParams(scene, self.dev, optimizer=cfg.optimizer)
+        seg = Segment(params, frames, start, {start: torch.eye(4)})
+        self._new_densifier(seg)
+        t0 = time.perf_counter()
+        visited, steps = [start], 0
+        for f in frames[1:]:
+            seg.poses[f] = self.seq.rel_pose(f - 1, f) @ seg.poses[f - 1]          # :739-741
+            visited.append(f)
+            for _ in range(cfg.leaf_iters_per_frame):
+                v = self.rng.choice(visited)                                         # sample_a_training_frame, :482-505
+                self._step(seg, self._settings(seg, v), self.seq.target(v))
+                steps += 1
+        if self.dev.type == "cuda":
+            torch.cuda.synchronize(self.dev)
+        self.seg = seg
+        self._emit({"phase": "leaf", "frames": [frames[0], frames[-1]], "steps": steps, "gaussians": params.num_points,
+                    "ms": 1e3 * (time.perf_counter() - t0)})
+
+    # ---- merge (:767-793, :214-272) ----------------------------------------------------------------------------------
+    def role(self, k: int):
+        return segments.partner(self.rank, self.schedule[k])
+
+    def merge_send(self, k: int):
+        seg, self.tr.rank = self.seg, self.rank
+        st = hierarchy.merge_send(self.tr, self.role(k)[1], seg.params.raw(), self._importance_views(seg), self.cfg.prune_ratio,
+                                  frames=seg.frames, poses=seg.pose_tensor(), start_fidx=seg.start_fidx,
+                                  global_iteration=seg.global_iteration, importance_fn=self.importance_fn)
+        self.seg = None          # this GPU is free from here on
+        self._emit({"phase": "merge", "level": k, **st})
+
+    def merge_recv(self, k: int):
+        seg, self.tr.rank = self.seg, self.rank
+        # child coordinates -> this model's coordinates: inverse of get_RT(child.start_fidx), :778-780.  The child's
+        # start frame is one of this model's own frames (the partitions overlap by two frames).
+        src_to_dst = lambda msg: torch.linalg.inv(seg.poses[msg["start_fidx"]])
+        out = hierarchy.merge_recv(self.tr, self.role(k)[1], seg.params.raw(), self._importance_views(seg),
+                                   self.cfg.prune_ratio, src_to_dst, importance_fn=self.importance_fn)
+        child = out["child"]
+        own_teacher = {"seg": {kk: v.clone() for kk, v in out["teachers"][0].items()}, "start_fidx": seg.start_fidx,
+                       "frames": list(seg.frames)}
+        child_teacher = {"seg": out["teachers"][1], "start_fidx": child["start_fidx"], "frames": list(child["frames"])}
+        self.teachers = [own_teacher, child_teacher]
+        for f in child["frames"]:                                                    # :783-790
+            if f not in seg.poses:
+                seg.poses[f] = self.seq.rel_pose(f - 1, f) @ seg.poses[f - 1]
+        frames = sorted(set(seg.frames + child["frames"]))                           # :796
+        params = ts.GaussianParams.from_raw(out["merged"], self.dev, sh_degree=self.cfg.sh_degree, optimizer=self.cfg.optimizer)
+        self.seg = Segment(params, frames, seg.start_fidx, seg.poses, global_iteration=0)   # :792-793
+        self._new_densifier(self.seg)
+        self._emit({"phase": "merge", "level": k, **{kk: v for kk, v in out.items() if kk not in ("merged", "teachers", "child")}})
+
+    # ---- non-leaf training (:757-764, :815-900) ------------------------------------------------------------------------
+    def train_nonleaf(self, k: int):
+        cfg, seg = self.cfg, self.seg
+        frames = seg.frames
+        t0 = time.perf_counter()
+        n1 = cfg.phase1_iters_per_frame * len(frames)
+        virtual = 0
+        for _ in range(n1):
+            f = self.rng.choice(frames)
+            if self.rng.random() < cfg.phase1_ratio:
+                alpha = self.rng.random()
+                if f == frames[-1]:
+                    f -= 1
+                if f + 1 not in seg.poses:
+                    continue
+                p = pose_mod.interpolate_pose(seg.poses[f], seg.poses[f + 1], alpha)     # get_virtual_view, :462-479
+                teacher = next((t for t in self.teachers[::-1] if f >= t["start_fidx"] and f in t["frames"]), None)
+                if teacher is None:
+                    raise ValueError(f"frame {f} belongs to no child")
+                p_wrt_teacher = p @ torch.linalg.inv(seg.poses[teacher["start_fidx"]])    # :874
+                pseudo = self.teacher_render_fn(teacher["seg"], self.seq.settings_for_pose(p_wrt_teacher))
+                self._step(seg, self.seq.settings_for_pose(p), pseudo)
+                virtual += 1
+            else:
+                self._step(seg, self._settings(seg, f), self.seq.target(f))
+        self.teachers = None                                                               # :758-760
+        lvl = self.level - 1 - k
+        per = cfg.phase2_iters_per_frame[min(lvl, len(cfg.phase2_iters_per_frame) - 1)]
+        n2 = per * len(frames)
+        for _ in range(n2):
+            f = self.rng.choice(frames)
+            self._step(seg, self._settings(seg, f), self.seq.target(f))
+        if self.dev.type == "cuda":
+            torch.cuda.synchronize(self.dev)
+        self._emit({"phase": "nonleaf", "level": k, "phase1_steps": n1, "virtual_views": virtual, "phase2_steps": n2,
+                    "gaussians": seg.params.num_points, "ms": 1e3 * (time.perf_counter() - t0)})
+
+    def evaluate(self) -> float:
+        """Mean PSNR of the final model over its frames."""
+        seg, tot = self.seg, 0.0
+        with torch.no_grad():
+            for f in seg.frames:
+                img = ts.render(seg.params, self._settings(seg, f))["image"]
+                mse = ((img - self.seq.target(f)) ** 2).mean().clamp_min(1e-12)
+                tot += float(-10.0 * torch.log10(mse))
+        return tot / len(seg.frames)
+
+    # ---- one rank's whole run (distributed) ----------------------------------------------------------------------------
+    def run(self, barrier=None):
+        self.train_leaf()
+        for k in range(len(self.schedule)):
+            if barrier is not None:
+                barrier()
+            if self.seg is None:
+                continue
+            r = self.role(k)
+            if r is None:
+                continue
+            if r[0] == "send":
+                self.merge_send(k)
+            else:
+                self.merge_recv(k)
+                self.train_nonleaf(k)
+        return self.seg
+
+
+def run_local(world: int, seq, cfg: HTConfig, device, log=None):
+    """All ranks in turn on one device (the reference's execution order).  Returns (root RankRunner, report)."""
+    tr = segments.LocalTransport(world)
+    runners = [RankRunner(r, world, tr, seq, cfg, device, log=log) for r in range(world)]
+    for rr in runners:
+        rr.train_leaf()
+    for k in range(len(runners[0].schedule)):
+        pairs = runners[0].schedule[k]
+        for dst, src in pairs:
+            runners[src].merge_send(k)
+        for dst, src in pairs:
+            runners[dst].merge_recv(k)
+            runners[dst].train_nonleaf(k)
+    return runners[0], [rec for rr in runners for rec in rr.report]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--local", action="store_true", help="walk the whole tree on one GPU (no process group)")
+    ap.add_argument("--segments", type=int, default=8, help="leaf segments for --local (otherwise WORLD_SIZE)")
+    ap.add_argument("--frames", type=int, default=40)
+    ap.add_argument("--width", type=int, default=980)
+    ap.add_argument("--height", type=int, default=545)
+    ap.add_argument("--gt-gaussians", type=int, default=400_000)
+    ap.add_argument("--leaf-gaussians", type=int, default=200_000)
+    ap.add_argument("--leaf-iters", type=int, default=30)
+    ap.add_argument("--phase1-iters", type=int, default=5)
+    ap.add_argument("--phase2-iters", type=int, default=10)
+    ap.add_argument("--importance-views", type=int, default=0)
+    ap.add_argument("--densify", action="store_true")
+    ap.add_argument("--backend", default="nccl")
+    a = ap.parse_args()
+    cfg = HTConfig(frames=a.frames, width=a.width, height=a.height, gt_gaussians=a.gt_gaussians, leaf_gaussians=a.leaf_gaussians,
+                   leaf_iters_per_frame=a.leaf_iters, phase1_iters_per_frame=a.phase1_iters, phase2_iters_per_frame=[a.phase2_iters] * 3,
+                   importance_views=a.importance_views, densify=a.densify)
+    if not torch.cuda.is_available():
+        raise SystemExit("run_segments.py needs a ROCm GPU (no CPU fallback in the product path)")
+    if a.local:
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        seq = sequence.FrameSequence(cfg.frames, cfg.gt_gaussians, cfg.width, cfg.height, dev, seed=cfg.seed)
+        t0 = time.perf_counter()
+        root, _ = run_local(a.segments, seq, cfg, dev)
+        print(json.dumps({"phase": "done", "world": a.segments, "mode": "local", "gaussians": root.seg.params.num_points,
+                          "psnr": root.evaluate(), "total_s": time.perf_counter() - t0}), flush=True)
+        return
+    import torch.distributed as dist
+    rank, world, local_rank = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(a.backend, device_id=dev if a.backend == "nccl" else None)
+    seq = sequence.FrameSequence(cfg.frames, cfg.gt_gaussians, cfg.width, cfg.height, dev, seed=cfg.seed)
+    rr = RankRunner(rank, world, segments.DistTransport(), seq, cfg, dev)
+    t0 = time.perf_counter()
+    rr.run(barrier=dist.barrier)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"phase": "done", "world": world, "mode": a.backend, "gaussians": rr.seg.params.num_points,
+                          "psnr": rr.evaluate(), "total_s": time.perf_counter() - t0}), flush=True)
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -3,11 +3,22 @@
 The reference trains 2^level leaf segments one after another on cuda:0 and merges neighbours pairwise
 (/root/reference/trainer/ht3dgs_trainer.py:710-804; merge_two_3DGS :214-272).  Leaf segments are independent
 (:729-753), so here rank r owns leaf segment r; the ONLY data exchange is at a merge, where the source
-segment's Gaussian tensors (59 fp32 = 236 B per Gaussian: _xyz, _features_dc, _features_rest, _opacity,
-_scaling, _rotation -- :257-267) travel src -> dst point-to-point.  xGMI is a full mesh of point-to-point
-links, so each pair of a merge level uses its own link; no ring collective is involved.  Backend "nccl" is
-RCCL on ROCm; the same code runs over gloo on CPU for the world_size-2 tests.
+child travels src -> dst point-to-point:
+
+  * the Gaussian tensors, 59 fp32 = 236 B per Gaussian (_xyz, _features_dc, _features_rest, _opacity, _scaling,
+    _rotation -- :257-267), **un-pruned**: with the 'base' multi-source supervision the child is the frozen teacher
+    of the parent's phase 1 (:757, :866-883), so the whole child is sent once and the importance mask (:247-253,
+    computed on the child's home rank, in parallel with the destination's own) is applied at the destination;
+  * the drop mask, one byte per Gaussian;
+  * the child's frames and their poses (`to_visit_frames`, `start_fidx`, the pose list P -- :734-735, :766 and
+    /root/reference/scene/gaussian_model_ht.py:363-377; 4x4 matrices here) and `global_iteration`.
+
+xGMI is a full mesh of point-to-point links, so each pair of a merge level uses its own link; no ring collective
+is involved.  Backend "nccl" is RCCL on ROCm; the same code runs over gloo on CPU for the world_size-2/4 tests, and
+through `LocalTransport` when one process walks the whole tree on one device (the reference's own execution order).
 """
+import time
+from collections import deque
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -16,6 +27,7 @@ import torch.distributed as dist
 SEGMENT_KEYS = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation")
 _TRAILING = {"_xyz": (3,), "_features_dc": (1, 3), "_features_rest": (15, 3), "_opacity": (1,), "_scaling": (3,),
              "_rotation": (4,)}
+FLOATS_PER_GAUSSIAN = 59
 
 
 def merge_schedule(world: int) -> List[List[Tuple[int, int]]]:
@@ -38,14 +50,135 @@ def partner(rank: int, level_pairs: List[Tuple[int, int]]) -> Optional[Tuple[str
     return None
 
 
+# ---- transports -------------------------------------------------------------------------------------------------------
+class DistTransport:
+    """torch.distributed point-to-point (RCCL on the GPUs, gloo in the CPU tests)."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+
+    def send(self, t: torch.Tensor, dst: int):
+        dist.send(t, dst, group=self.group)
+
+    def recv(self, t: torch.Tensor, src: int):
+        dist.recv(t, src, group=self.group)
+
+
+class LocalTransport:
+    """In-process mailboxes: one process plays every rank in turn on one device (senders of a level run before its
+    receivers).  A send is a device copy, so the 'wire' time it reports is an HBM copy, not a link."""
+
+    def __init__(self, world: int):
+        self.world = world
+        self.rank = 0           # set by the driver before each virtual rank acts
+        self.box: Dict[Tuple[int, int], deque] = {}
+
+    def send(self, t: torch.Tensor, dst: int):
+        self.box.setdefault((self.rank, dst), deque()).append(t.detach().clone())
+
+    def recv(self, t: torch.Tensor, src: int):
+        q = self.box.get((src, self.rank))
+        if not q:
+            raise RuntimeError(f"LocalTransport: rank {self.rank} receives from {src} before it sent")
+        m = q.popleft()
+        if m.shape != t.shape or m.dtype != t.dtype:
+            raise RuntimeError(f"LocalTransport: message {tuple(m.shape)} {m.dtype} does not match the receive buffer "
+                               f"{tuple(t.shape)} {t.dtype}")
+        t.copy_(m)
+
+
+def _sync(t: torch.Tensor):
+    if t.is_cuda:
+        torch.cuda.synchronize(t.device)
+
+
+# ---- the child message -----------------------------------------------------------------------------------------------
+def pack_segment(seg: Dict[str, torch.Tensor]) -> torch.Tensor:
+    n = seg["_xyz"].shape[0]
+    return torch.cat([seg[key].detach().reshape(n, -1).float() for key in SEGMENT_KEYS], dim=1).contiguous()
+
+
+def unpack_segment(flat: torch.Tensor) -> Dict[str, torch.Tensor]:
+    n = flat.shape[0]
+    seg, o = {}, 0
+    for key in SEGMENT_KEYS:
+        w = 1
+        for d in _TRAILING[key]:
+            w *= d
+        seg[key] = flat[:, o:o + w].reshape((n,) + _TRAILING[key]).contiguous()
+        o += w
+    return seg
+
+
+def send_child(tr, dst: int, seg: Dict[str, torch.Tensor], drop: Optional[torch.Tensor] = None,
+               frames: Optional[List[int]] = None, poses: Optional[torch.Tensor] = None, start_fidx: int = 0,
+               global_iteration: int = 0) -> Dict:
+    """Header (sizes, variable N), then the un-pruned 59-float rows, then mask / frames / poses.  Returns
+    {'bytes', 'ms'} (ms includes the wait for the receiver)."""
+    dev = seg["_xyz"].device
+    n = seg["_xyz"].shape[0]
+    frames = list(frames or [])
+    t0 = time.perf_counter()
+    hdr = torch.tensor([n, len(frames), int(start_fidx), int(global_iteration), 0 if drop is None else 1],
+                       dtype=torch.int64, device=dev)
+    tr.send(hdr, dst)
+    nbytes = hdr.numel() * 8
+    flat = pack_segment(seg)
+    tr.send(flat, dst)
+    nbytes += flat.numel() * 4
+    if drop is not None:
+        m = drop.to(device=dev, dtype=torch.uint8).contiguous()
+        tr.send(m, dst)
+        nbytes += m.numel()
+    if frames:
+        tr.send(torch.tensor(frames, dtype=torch.int64, device=dev), dst)
+        p = poses.detach().to(device=dev, dtype=torch.float32).reshape(len(frames), 16).contiguous()
+        tr.send(p, dst)
+        nbytes += len(frames) * (8 + 64)
+    _sync(flat)
+    return {"bytes": nbytes, "ms": 1e3 * (time.perf_counter() - t0)}
+
+
+def recv_child(tr, src: int, device) -> Dict:
+    """Counterpart of send_child: {'seg', 'drop', 'frames', 'poses', 'start_fidx', 'global_iteration', 'bytes', 'ms'}."""
+    t0 = time.perf_counter()
+    hdr = torch.zeros(5, dtype=torch.int64, device=device)
+    tr.recv(hdr, src)
+    n, nf, start_fidx, giter, has_mask = (int(v) for v in hdr.tolist())
+    nbytes = 40
+    flat = torch.empty((n, FLOATS_PER_GAUSSIAN), dtype=torch.float32, device=device)
+    tr.recv(flat, src)
+    nbytes += flat.numel() * 4
+    drop = None
+    if has_mask:
+        m = torch.empty(n, dtype=torch.uint8, device=device)
+        tr.recv(m, src)
+        drop = m.bool()
+        nbytes += n
+    frames, poses = [], None
+    if nf:
+        f = torch.empty(nf, dtype=torch.int64, device=device)
+        tr.recv(f, src)
+        frames = [int(v) for v in f.tolist()]
+        poses = torch.empty((nf, 16), dtype=torch.float32, device=device)
+        tr.recv(poses, src)
+        poses = poses.reshape(nf, 4, 4)
+        nbytes += nf * (8 + 64)
+    _sync(flat)
+    return {"seg": unpack_segment(flat), "drop": drop, "frames": frames, "poses": poses, "start_fidx": start_fidx,
+            "global_iteration": giter, "bytes": nbytes, "ms": 1e3 * (time.perf_counter() - t0)}
+
+
+# ---- round-1 names (kept: the world_size-2 exchange test and external callers use them) ---------------------------------
 def send_segment(seg: Dict[str, torch.Tensor], dst: int, extra: Optional[torch.Tensor] = None, group=None) -> None:
-    """Count first (N differs per segment), then one flat 59-float-per-Gaussian message."""
+    """Count first (N differs per segment), then one flat 59-float-per-Gaussian message (+ an optional float vector)."""
     n = seg["_xyz"].shape[0]
     dev = seg["_xyz"].device
     k = 0 if extra is None else extra.numel()
     dist.send(torch.tensor([n, k], dtype=torch.int64, device=dev), dst, group=group)
-    flat = torch.cat([seg[key].detach().reshape(n, -1).float() for key in SEGMENT_KEYS], dim=1).contiguous()
-    dist.send(flat, dst, group=group)
+    dist.send(pack_segment(seg), dst, group=group)
     if k:
         dist.send(extra.detach().float().contiguous().reshape(-1), dst, group=group)
 
@@ -54,31 +187,27 @@ def recv_segment(src: int, device, group=None) -> Tuple[Dict[str, torch.Tensor],
     hdr = torch.zeros(2, dtype=torch.int64, device=device)
     dist.recv(hdr, src, group=group)
     n, k = int(hdr[0].item()), int(hdr[1].item())
-    flat = torch.empty((n, 59), dtype=torch.float32, device=device)
+    flat = torch.empty((n, FLOATS_PER_GAUSSIAN), dtype=torch.float32, device=device)
     dist.recv(flat, src, group=group)
-    seg, o = {}, 0
-    for key in SEGMENT_KEYS:
-        w = 1
-        for d in _TRAILING[key]:
-            w *= d
-        seg[key] = flat[:, o:o + w].reshape((n,) + _TRAILING[key]).contiguous()
-        o += w
     extra = None
     if k:
         extra = torch.empty(k, dtype=torch.float32, device=device)
         dist.recv(extra, src, group=group)
-    return seg, extra
+    return unpack_segment(flat), extra
 
 
 def merge_segments(dst_seg: Dict[str, torch.Tensor], src_seg: Dict[str, torch.Tensor], dst_keep: torch.Tensor,
                    src_keep: torch.Tensor, src_to_dst: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
     """merge_two_3DGS (:233-271): prune both by their importance masks, move the source points by the 4x4
-    relative transform, append."""
+    relative transform (homogeneous, with the divide of :252-254), append."""
     out = {}
-    xyz = src_seg["_xyz"][src_keep]
+    xyz = src_seg["_xyz"]
     if src_to_dst is not None:
         T = src_to_dst.to(xyz)
-        xyz = xyz @ T[:3, :3].t() + T[:3, 3]
+        h = xyz @ T[:3, :3].t() + T[:3, 3]
+        w = xyz @ T[3, :3] + T[3, 3]
+        xyz = h / w.unsqueeze(1)
+    xyz = xyz[src_keep]
     for key in SEGMENT_KEYS:
         s = xyz if key == "_xyz" else src_seg[key][src_keep]
         out[key] = torch.cat([dst_seg[key][dst_keep], s], dim=0)

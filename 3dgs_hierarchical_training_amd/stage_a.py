@@ -1,0 +1,112 @@
+"""Stage A of the hierarchical trainer, sharded: relative-pose fits of consecutive frame pairs.
+
+Reference: `for fidx in range(1, seq_len): compute_relative_pose(fidx, fidx-1)`
+(/root/reference/trainer/ht3dgs_trainer.py:697-698).  Each call trains a single-image 3DGS on frame f-1 (<= 1000
+iterations, :274-305, :352-365) and then fits the SE(3) pose that makes it explain frame f (300 iterations,
+:308-333, :367-378); nothing is shared between pairs, and the results land in `pose_dict` under
+`rel_pose_{a}_to_{b}` (+ `rel_pose_{a}_to_{a}.5`, `rel_pose_{a}.5_to_{b}` in the interpolated-frame mode, :427-429).
+That is ~70 % of all render calls of a scene and embarrassingly parallel:
+
+  * pair p = (p, p+1) goes to rank p % world (round-robin keeps the ranks' loads equal when frames vary smoothly);
+  * every rank writes its results into a [P, 3, 4, 4] table (slot 0 = a -> b, slots 1 / 2 = the two half steps, identity
+    when unused), the only collective is ONE `all_gather` of the ranks' own rows (<= 192 B per pair);
+  * every rank ends with the full `pose_dict`, which stage B needs replicated (leaf pose chains :739-741, merge pose
+    chains :783-790).
+
+`fit_pair` is the per-pair work on the MI355X rasterizer: single-image training with the fused train step, then Adam on
+the six tangent numbers through the fused pose action (`points_transform`, pose.py) -- the means never leave the kernels.
+"""
+from typing import Callable, Dict, List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+def pairs_of_rank(n_frames: int, rank: int, world: int) -> List[int]:
+    """Pair indices p (frames p -> p+1) owned by `rank`."""
+    return list(range(rank, n_frames - 1, world))
+
+
+def gather_pose_table(local: Dict[int, torch.Tensor], n_frames: int, rank: int, world: int, device, group=None) -> torch.Tensor:
+    """local: {pair index -> [3,4,4]} for this rank's pairs.  Returns the full [P,3,4,4] table on every rank."""
+    P = n_frames - 1
+    rows = (P + world - 1) // world                   # every rank contributes the same number of rows (padding = identity)
+    mine = torch.eye(4, dtype=torch.float32).repeat(rows, 3, 1, 1)
+    for j, p in enumerate(pairs_of_rank(n_frames, rank, world)):
+        mine[j] = local[p].detach().float().cpu()
+    mine = mine.to(device).contiguous()
+    if world == 1:
+        return mine[:P]
+    out = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(out, mine, group=group)
+    table = torch.empty((P, 3, 4, 4), dtype=torch.float32, device=device)
+    for r in range(world):
+        idx = pairs_of_rank(n_frames, r, world)
+        if idx:
+            table[torch.tensor(idx, device=device)] = out[r][:len(idx)]
+    return table
+
+
+def pose_dict_from_table(table: torch.Tensor, vfi: bool = False) -> Dict[str, torch.Tensor]:
+    """The reference's `pose_dict` keys (:378, :427-429)."""
+    d = {}
+    for p in range(table.shape[0]):
+        d[f"rel_pose_{p}_to_{p + 1}"] = table[p, 0]
+        if vfi:
+            d[f"rel_pose_{p}_to_{p}.5"] = table[p, 1]
+            d[f"rel_pose_{p}.5_to_{p + 1}"] = table[p, 2]
+    return d
+
+
+def run_stage_a(n_frames: int, fit_fn: Callable[[int], torch.Tensor], device, rank: Optional[int] = None,
+                world: Optional[int] = None, group=None, vfi: bool = False) -> Dict[str, torch.Tensor]:
+    """fit_fn(p) -> [4,4] (or [3,4,4]) relative pose(s) of pair p.  Every rank returns the complete pose_dict."""
+    if world is None:
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+    local = {}
+    for p in pairs_of_rank(n_frames, rank, world):
+        r = fit_fn(p)
+        if r.dim() == 2:
+            eye = torch.eye(4, dtype=r.dtype, device=r.device)
+            r = torch.stack((r, eye, eye))
+        local[p] = r
+    return pose_dict_from_table(gather_pose_table(local, n_frames, rank, world, device, group), vfi)
+
+
+def fit_pair(seq, p: int, device, n_points: int = 100_000, single_image_iters: int = 1000, pose_iters: int = 300,
+             pose_lr: float = 2e-3, seed: int = 0) -> torch.Tensor:
+    """compute_relative_pose(p+1, p) on the HIP rasterizer (:336-380): returns rel_pose_{p}_to_{p+1} [4,4] (CPU).
+
+    1. single-image 3DGS of frame p in that frame's own camera coordinates (identity pose), fused train step, no
+       densification (:352-365; early exit on PSNR > 35 after 500 iterations as :300-301);
+    2. freeze the Gaussians, fit delta in Exp(delta) (tangent at the identity, `init_RT(None)` :370) on frame p+1 with
+       Adam through `points_transform` (pose.py): loss = the same photometric loss."""
+    from . import pose as pose_mod
+    from . import train_step as ts
+    from .loss import fused_photometric_loss
+    from .rasterizer import rasterize_gaussians_raw
+    scene = seq.leaf_scene(p, n_points, seed=seed + p)
+    params = ts.GaussianParams(scene, device)
+    ident = seq.settings_for_pose(torch.eye(4))
+    tgt0, tgt1 = seq.target(p), seq.target(p + 1)
+    for it in range(1, single_image_iters + 1):
+        pkg = ts.train_step(params, ident, tgt0)
+        if it > 500 and it % 50 == 0:
+            with torch.no_grad():
+                mse = ((pkg["raw_image"].clamp(0, 1) - tgt0) ** 2).mean()
+            if float(-10 * torch.log10(mse.clamp_min(1e-12))) > 35:
+                break
+    raw = params.raw()
+    delta = torch.zeros(6, device=device, requires_grad=True)
+    opt = torch.optim.Adam([delta], lr=pose_lr)
+    pose7 = torch.tensor([0, 0, 0, 0, 0, 0, 1.0], device=device)
+    m2d = torch.zeros_like(raw["_xyz"])
+    for _ in range(pose_iters):
+        opt.zero_grad(set_to_none=True)
+        M = pose_mod.retr_matrix(delta, pose7)
+        img = rasterize_gaussians_raw(raw["_xyz"], m2d, raw["_features_dc"], raw["_features_rest"], raw["_opacity"],
+                                      raw["_scaling"], raw["_rotation"], ident, points_transform=M)[0]
+        fused_photometric_loss(img, tgt1, 0.2, clamp=True).backward()
+        opt.step()
+    return pose_mod.retr_matrix(delta.detach(), pose7).cpu()

@@ -46,11 +46,13 @@ def random_rotation(gen: torch.Generator, max_angle: float = 0.3) -> torch.Tenso
 
 
 def make_scene(N: int, W: int, H: int, sh_degree: int = 3, seed: int = 0, fovx: float = FOVX_FRANCIS,
-               sigma_px: float = 3.0, posed: bool = False, frac_behind: float = 0.02) -> Dict:
+               sigma_px: float = 3.0, posed: bool = False, frac_behind: float = 0.02, clustered: bool = False) -> Dict:
     """syn-N: z~U[1,10] filling the frustum with 5% overscan, `frac_behind` of the points near/behind the
     near plane, ~sigma_px anisotropic Gaussians, random unit quaternions, opacity = sigmoid(N(0,2)),
     SH dc ~ 0.5 N(0,1), rest ~ 0.1 N(0,1).  With posed=True the same cloud is seen from a rotated and
-    translated camera (exercises the matrix conventions)."""
+    translated camera (exercises the matrix conventions).  clustered=True is the load-imbalance variant: screen positions
+    ~ N(centre, 0.13 of the frame) and low opacities sigmoid(N(-2.5, 1)), so a few hundred tiles carry long,
+    non-saturating lists (what real scenes look like early in training)."""
     g = torch.Generator().manual_seed(seed)
     if posed:
         Rm = random_rotation(g)
@@ -64,6 +66,9 @@ def make_scene(N: int, W: int, H: int, sh_degree: int = 3, seed: int = 0, fovx: 
     if nb:
         z[:nb] = -1 + 1.2 * torch.rand(nb, generator=g)
     u, v = torch.rand(N, generator=g), torch.rand(N, generator=g)
+    if clustered:
+        u = (0.5 + 0.13 * torch.randn(N, generator=g)).clamp(-0.02, 1.02)
+        v = (0.5 + 0.13 * torch.randn(N, generator=g)).clamp(-0.02, 1.02)
     pc = torch.stack([(2 * u - 1) * 1.05 * tfx * z, (2 * v - 1) * 1.05 * tfy * z, z], 1)
     # camera-space points -> world: p_w = R^T (p_c - t)
     w2c = cam["viewmatrix"].t()
@@ -75,6 +80,8 @@ def make_scene(N: int, W: int, H: int, sh_degree: int = 3, seed: int = 0, fovx: 
     q = torch.randn(N, 4, generator=g)
     q = q / q.norm(dim=1, keepdim=True)
     op = torch.sigmoid(2.0 * torch.randn(N, 1, generator=g))
+    if clustered:
+        op = torch.sigmoid(-2.5 + torch.randn(N, 1, generator=g))
     M = 16
     shs = torch.zeros(N, M, 3)
     shs[:, 0] = 0.5 * torch.randn(N, 3, generator=g)

@@ -73,6 +73,9 @@ class GaussianParams:
         self._scaling = torch.log(scene["scales"].to(d)).requires_grad_(True)
         self._rotation = scene["rotations"].to(d).clone().requires_grad_(True)
         self._opacity = inverse_sigmoid(scene["opacities"].to(d).clamp(1e-4, 1 - 1e-4)).requires_grad_(True)
+        self._build_optimizer(spatial_lr_scale, optimizer)
+
+    def _build_optimizer(self, spatial_lr_scale: float, optimizer: str):
         groups = [
             {"params": [self._xyz], "lr": 0.00016 * spatial_lr_scale, "name": "xyz"},
             {"params": [self._features_dc], "lr": 0.0025, "name": "f_dc"},
@@ -89,6 +92,24 @@ class GaussianParams:
             self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15, fused=self._xyz.is_cuda)
         else:                         # the reference's own construction (foreach implementation)
             self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
+
+    @classmethod
+    def from_raw(cls, seg: Dict[str, torch.Tensor], device, sh_degree: int = 3, spatial_lr_scale: float = 1.0,
+                 optimizer: str = "hip") -> "GaussianParams":
+        """Model from the six raw tensors (`_xyz`, `_features_dc`, ... as HTGaussianModel.capture() holds them,
+        gaussian_model_ht.py:92-104) with a fresh optimizer -- what `training_setup` does after a merge
+        (/root/reference/trainer/ht3dgs_trainer.py:793)."""
+        self = cls.__new__(cls)
+        self.max_sh_degree = int(round(math.sqrt(seg["_features_rest"].shape[1] + 1))) - 1
+        self.active_sh_degree = int(sh_degree)
+        for k in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation"):
+            setattr(self, k, seg[k].detach().to(device=device, dtype=torch.float32).contiguous().clone().requires_grad_(True))
+        self._build_optimizer(spatial_lr_scale, optimizer)
+        return self
+
+    def raw(self) -> Dict[str, torch.Tensor]:
+        """The six raw tensors, detached (no copy)."""
+        return {k: getattr(self, k).detach() for k in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation")}
 
     @property
     def num_points(self):
@@ -193,13 +214,15 @@ def render(params: GaussianParams, settings: GaussianRasterizationSettings, clam
 
 def train_step(params: GaussianParams, settings: GaussianRasterizationSettings, gt: torch.Tensor,
                lambda_dssim: float = 0.2, fused_loss: bool = True, fused_activations: bool = True,
-               fused_optimizer: bool = True) -> Dict:
+               fused_optimizer: bool = True, densifier=None, iteration: int = 0) -> Dict:
     """render -> loss -> backward -> Adam step (ht3dgs_trainer.py:102-166 without densification).
     fused_loss=True evaluates clamp + L1 + SSIM in the HIP loss kernels; False uses the torch restatement.
     fused_activations=True runs exp / sigmoid / normalize / cat inside the rasterizer kernels.
     fused_optimizer=True (needs fused_activations and the "hip" optimizer) applies the Adam step inside the
     per-Gaussian backward kernel -- same update, the gradients just never travel through HBM; optimizer.step()
-    then finds no .grad and is a no-op."""
+    then finds no .grad and is a no-op.
+    densifier (densify.Densifier) + iteration: the adaptive density control of ht3dgs_trainer.py:137-155 runs between
+    backward() and optimizer.step(), as in the reference (see densify.py for the ordering note of the fused mode)."""
     fused_adam = params.optimizer if (fused_optimizer and fused_activations and isinstance(params.optimizer, FusedAdam)) else None
     pkg = render(params, settings, clamp=not fused_loss, fused_activations=fused_activations, fused_adam=fused_adam)
     if fused_loss:
@@ -211,6 +234,8 @@ def train_step(params: GaussianParams, settings: GaussianRasterizationSettings, 
     if one is None or one.device != loss.device:
         one = params._grad_one = torch.ones((), dtype=loss.dtype, device=loss.device)
     loss.backward(gradient=one)
+    if densifier is not None:
+        densifier.after_backward(iteration, pkg)
     params.optimizer.step()
     params.optimizer.zero_grad(set_to_none=True)
     pkg["loss"] = loss.detach()

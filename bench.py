@@ -12,11 +12,20 @@ densification.  Inputs are resident in HBM before the timed region.  N>1 = one i
 per GPU ("one segment per GPU"): weak scaling, no data-path collective; value = images of all
 ranks / max-over-ranks time.
 
-Rank 0 prints ONE JSON line.  `roofline` describes the per-tile forward blend kernel (the kernel
-BASELINE.json's north_star names): achieved = algorithmic bytes (44 R_eff + 28 P + 8 T) /
-average launch duration measured with HIP events on the launch stream inside the timed region.
-`cpu_baseline` times oracle/ (the CPU restatement, kind "port") on the host cores -- reported beside the GPU
-number, never part of it.
+Rank 0 prints ONE JSON line.  Besides the contract's keys:
+  `roofline`       the per-tile forward blend kernel (the kernel BASELINE.json's north_star names): achieved =
+                   algorithmic bytes (44 R_eff + 28 P + 8 T) / average launch duration measured with HIP
+                   events on the launch stream inside the timed region; `peak` = 8 TB/s (vendor), `peak_measured` = the
+                   device-to-device copy rate measured on this box.
+  `cpu_baseline`   oracle/ (the CPU restatement, kind "port") on the host cores: all threads and ONE thread -- reported
+                   beside the GPU number, never part of it.
+  `dropin`         the same workload through what the UNMODIFIED reference trainer can reach: `GaussianRasterizer(...)`
+                   behind torch activations + cat, torch SSIM / L1, `torch.optim.Adam(eps=1e-15)` (gaussian_model_ht.py:
+                   824-880, :289; trainer/losses.py:98-136).  `value` is the build's own fused step (see config.train_step).
+  `merge`          one level of the merge tree (BASELINE config 4) timed AFTER the timed steps, never part of `value`:
+                   importance of each child on its home rank, un-pruned child + mask point-to-point (RCCL for N > 1; a
+                   device copy at N = 1), masks applied and appended at the destination.
+  `other_workloads` the other BASELINE configs on the same code (N = 1 only; `--no-extras` skips them).
 """
 import argparse
 import ctypes as C
@@ -33,6 +42,7 @@ if REPO not in sys.path:
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+STAGES = ["preprocess_fwd", "sort_depth", "scan", "emit", "sort_tile", "ranges", "blend_fwd", "blend_bwd", "preprocess_bwd"]
 
 
 def parse():
@@ -44,7 +54,9 @@ def parse():
     ap.add_argument("--width", type=int, default=980)
     ap.add_argument("--height", type=int, default=545)
     ap.add_argument("--sh-degree", type=int, default=3)
+    ap.add_argument("--clustered", action="store_true", help="load-imbalance variant of the scene (synthetic.make_scene)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip dropin / other_workloads / merge / copy ceiling")
     ap.add_argument("--fwd-ppt", type=int, default=0)
     ap.add_argument("--bwd-ppt", type=int, default=0)
     ap.add_argument("--tile-map", type=int, default=-1, help="2 = 2x2 tile blocks interleaved over the XCDs (default), 1 = single tiles "
@@ -63,15 +75,15 @@ def read_profile(lib, names):
 
 
 def cpu_baseline(scene, threads):
-    """oracle/ restatement (binary32 build) on the host cores: one full forward (K1-K6) of the same workload,
-    plus the K1-K5 (preprocess + duplicate + sort + ranges) leg on its own."""
+    """oracle/ restatement (binary32 build) on the host cores: full forwards (K1-K6) of the same workload plus the
+    K1-K5 (preprocess + duplicate + sort + ranges) leg on its own -- on all host threads (bounded to ~10 s) and on ONE
+    thread (one repetition, ~8 s)."""
     from oracle import binding
     o = binding.OracleRender(means3D=scene["means3D"], opacities=scene["opacities"], viewmatrix=scene["viewmatrix"],
                              projmatrix=scene["projmatrix"], campos=scene["campos"], bg=scene["bg"],
                              image_height=scene["image_height"], image_width=scene["image_width"],
                              tanfovx=scene["tanfovx"], tanfovy=scene["tanfovy"], sh_degree=scene["sh_degree"],
                              shs=scene["shs"], scales=scene["scales"], rotations=scene["rotations"], precision="f32")
-    # bounded sample: repeat the forward until ~10 s of wall time (all host threads busy) have been spent
     t_pre, t_full, reps, R = 0.0, 0.0, 0, 0
     while t_pre + t_full < 10.0 and reps < 64:
         t0 = time.perf_counter()
@@ -84,11 +96,159 @@ def cpu_baseline(scene, threads):
         reps += 1
     t_pre /= reps
     t_full /= reps
-    return {"value": 1.0 / t_full, "unit": "images/s", "cores": threads, "kind": "port",
-            "sample": f"{reps} forward renders (K1-K6: preprocess+duplicate+sort+ranges+blend; no backward / loss / Adam) of the "
-                      f"same syn workload, R={R} before exact tile culling, OpenMP over {threads} host threads, binary32 "
-                      f"oracle/gsr_oracle.c; about {reps * (t_pre + t_full):.0f} s of wall time",
-            "k1_k5_preprocess_sort_images_per_s": 1.0 / t_pre, "k1_k5_seconds": t_pre, "k1_k6_seconds": t_full}
+    res = {"value": 1.0 / t_full, "unit": "images/s", "cores": threads, "kind": "port",
+           "sample": f"{reps} forward renders (K1-K6: preprocess+duplicate+sort+ranges+blend; no backward / loss / Adam) of the "
+                     f"same syn workload, R={R} before exact tile culling, OpenMP over {threads} host threads, binary32 "
+                     f"oracle/gsr_oracle.c; about {reps * (t_pre + t_full):.0f} s of wall time",
+           "k1_k5_preprocess_sort_images_per_s": 1.0 / t_pre, "k1_k5_seconds": t_pre, "k1_k6_seconds": t_full}
+    try:        # the single-thread leg (SURVEY.md 8d "(a) single-thread"): same code, OpenMP team of one
+        gomp = C.CDLL("libgomp.so.1")
+        gomp.omp_set_num_threads(1)
+        t0 = time.perf_counter()
+        binding.run_stages(o, False)
+        t1 = time.perf_counter()
+        binding.run_stages(o, True)
+        t2 = time.perf_counter()
+        gomp.omp_set_num_threads(threads)
+        res["single_thread"] = {"value": 1.0 / (t2 - t1), "unit": "images/s", "cores": 1, "k1_k5_seconds": t1 - t0,
+                                "k1_k6_seconds": t2 - t1, "sample": "1 forward render of the same workload on one host thread"}
+    except Exception as e:
+        res["single_thread"] = {"value": None, "sample": f"failed: {e}"}
+    return res
+
+
+def copy_ceiling(dev, nbytes=1 << 30, reps=10):
+    """Measured device-to-device copy rate (read + write bytes / time): the practical HBM ceiling of this box."""
+    a = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    b = torch.empty_like(a)
+    for _ in range(2):
+        b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(dev)
+    e0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    ms = e0.elapsed_time(e1) / reps
+    return 2.0 * nbytes / (ms * 1e-3) / 1e9
+
+
+def timed_steps(step, steps, dev):
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(i)
+    torch.cuda.synchronize(dev)
+    return (time.perf_counter() - t0) / steps
+
+
+def dropin_leg(ts, scene, settings, gt, dev, steps, warmup):
+    """The path the unmodified reference trainer reaches: torch activations + cat -> GaussianRasterizer(...) -> clamp ->
+    torch L1 + SSIM (F.conv2d) -> backward -> torch.optim.Adam(l, lr=0.0, eps=1e-15).step()."""
+    p = ts.GaussianParams(scene, dev, optimizer="torch")
+    f = lambda i: ts.train_step(p, settings, gt, fused_loss=False, fused_activations=False, fused_optimizer=False)
+    for i in range(warmup):
+        f(i)
+    sec = timed_steps(f, steps, dev)
+    # the rasterizer alone on this path (forward + backward of GaussianRasterizer, grads to the activated tensors)
+    def fb(i):
+        pkg = ts.render(p, settings, clamp=False, fused_activations=False)
+        pkg["raw_image"].backward(gt)
+        p.optimizer.zero_grad(set_to_none=True)
+    for i in range(2):
+        fb(i)
+    sec_r = timed_steps(fb, steps, dev)
+    del p
+    return {"value": 1.0 / sec, "unit": "images/s", "ms_per_step": 1e3 * sec, "steps": steps,
+            "rasterizer_fwd_bwd_ms": 1e3 * sec_r,
+            "path": "GaussianRasterizer(raster_settings)(means3D, means2D, shs, opacities, scales, rotations) behind torch exp / "
+                    "sigmoid / normalize / cat, torch clamp + L1 + 11x11 SSIM (F.conv2d), torch.optim.Adam(eps=1e-15, foreach) -- "
+                    "no fused extension entry point is used"}
+
+
+def workload_leg(syn, ts, raster, dev, N, W, H, deg, steps, warmup, clustered=False, densify_every=0, seed=0):
+    dm = importlib.import_module("3dgs_hierarchical_training_amd.densify")
+    scene = syn.make_scene(N, W, H, sh_degree=deg, seed=seed, clustered=clustered)
+    gt = syn.target_image(W, H, seed=1).to(dev)
+    p = ts.GaussianParams(scene, dev)
+    st = ts.make_settings(scene, dev, deg)
+    den = None
+    if densify_every:
+        den = dm.Densifier(p, scene_extent=5.0, cfg=dm.DensifyConfig(densify_from_iter=0, densification_interval=densify_every,
+                                                                    densify_grad_threshold=2e-4, opacity_reset_interval=10 ** 9,
+                                                                    max_points=2 * N))
+    it = [0]
+
+    def f(i):
+        it[0] += 1
+        ts.train_step(p, st, gt, densifier=den, iteration=it[0])
+    for i in range(warmup):
+        f(i)
+    sec = timed_steps(f, steps, dev)
+    with torch.no_grad():
+        ts.render(p, st)
+    info = raster.last_call_info()
+    out = {"gaussians_start": N, "gaussians_end": p.num_points, "width": W, "height": H, "sh_degree": deg, "steps": steps,
+           "images_per_s": 1.0 / sec, "ms_per_step": 1e3 * sec, "num_rendered_R": info["num_rendered"], "R_eff": info["staged"]}
+    if densify_every:
+        out["densification"] = f"every {densify_every} steps, grad threshold 2e-4 (clone + split + prune inside the timed region)"
+    del p, den
+    torch.cuda.empty_cache()
+    return out
+
+
+def merge_leg(dev, dist, world, rank, params, scene, ts, syn, deg):
+    """One level of the merge tree, level 0 pairs (2k <- 2k+1).  N = 1: the segment merges with a copy of itself through
+    the in-process transport (a device copy stands for the link)."""
+    hier = importlib.import_module("3dgs_hierarchical_training_amd.hierarchy")
+    seg_mod = importlib.import_module("3dgs_hierarchical_training_amd.segments")
+    W, H = int(scene["image_width"]), int(scene["image_height"])
+    views = [ts.make_settings(scene, dev, deg)]
+    cam = syn.make_scene(8, W, H, sh_degree=deg, seed=77, posed=True)
+    sc2 = dict(scene)
+    for k in ("viewmatrix", "projmatrix", "campos"):
+        sc2[k] = cam[k]
+    views.append(ts.make_settings(sc2, dev, deg))
+    raw = params.raw()
+    T = torch.eye(4)
+    hier.calc_importance(raw, views[:1])      # warm the non-fused backward variant
+    if world == 1:
+        tr = seg_mod.LocalTransport(2)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        tr.rank = 1
+        s = hier.merge_send(tr, 0, raw, views, 0.5)
+        tr.rank = 0
+        d = hier.merge_recv(tr, 1, raw, views, 0.5, T)
+        torch.cuda.synchronize(dev)
+        total = 1e3 * (time.perf_counter() - t0)
+        return {"merge_ms": total, "merge_bytes": s["bytes"], "pairs": 1, "transport": "in-process device copy (N = 1)",
+                "importance_views": len(views), "importance_ms_src": s["importance_ms"], "importance_ms_dst": d["importance_ms"],
+                "send_ms": s["send_ms"], "recv_ms": d["recv_ms"], "append_ms": d["append_ms"], "gaussians_child": s["n"],
+                "gaussians_merged": d["n_merged"], "note": "both children's importance run back to back on the one GPU"}
+    tr = seg_mod.DistTransport()
+    pairs = seg_mod.merge_schedule(world)[0]
+    role = seg_mod.partner(rank, pairs)
+    torch.cuda.synchronize(dev)
+    dist.barrier()
+    t0 = time.perf_counter()
+    st = {"importance_ms": 0.0, "xfer_ms": 0.0, "bytes": 0.0, "append_ms": 0.0, "n_merged": 0.0}
+    if role is not None and role[0] == "send":
+        s = hier.merge_send(tr, role[1], raw, views, 0.5)
+        st.update(importance_ms=s["importance_ms"], xfer_ms=s["send_ms"], bytes=float(s["bytes"]))
+    elif role is not None:
+        d = hier.merge_recv(tr, role[1], raw, views, 0.5, T)
+        st.update(importance_ms=d["importance_ms"], xfer_ms=d["recv_ms"], append_ms=d["append_ms"], n_merged=float(d["n_merged"]))
+    torch.cuda.synchronize(dev)
+    local = 1e3 * (time.perf_counter() - t0)
+    v = torch.tensor([local, st["importance_ms"], st["xfer_ms"], st["append_ms"], st["n_merged"]], device=dev, dtype=torch.float64)
+    dist.all_reduce(v, op=dist.ReduceOp.MAX)
+    b = torch.tensor([st["bytes"]], device=dev, dtype=torch.float64)
+    dist.all_reduce(b, op=dist.ReduceOp.SUM)
+    return {"merge_ms": float(v[0]), "merge_bytes": float(b[0]), "pairs": len(pairs), "transport": "RCCL send/recv, one xGMI link per pair",
+            "importance_views": len(views), "importance_ms_max": float(v[1]), "xfer_ms_max": float(v[2]), "append_ms_max": float(v[3]),
+            "gaussians_merged_max": int(v[4]), "link_GBps": (float(b[0]) / len(pairs)) / (float(v[2]) * 1e-3) / 1e9 if float(v[2]) > 0 else None}
 
 
 def main():
@@ -110,6 +270,7 @@ def main():
     syn = importlib.import_module("3dgs_hierarchical_training_amd.synthetic")
     ts = importlib.import_module("3dgs_hierarchical_training_amd.train_step")
     L = importlib.import_module("3dgs_hierarchical_training_amd._lib")
+    raster = importlib.import_module("3dgs_hierarchical_training_amd.rasterizer")
     lib = L.load()
     if args.fwd_ppt:
         lib.gsr_set_option(b"blend_fwd_ppt", args.fwd_ppt)
@@ -121,12 +282,10 @@ def main():
         lib.gsr_set_option(b"tile_map", args.tile_map)
 
     N, W, H, deg = args.gaussians, args.width, args.height, args.sh_degree
-    scene = syn.make_scene(N, W, H, sh_degree=deg, seed=rank)
+    scene = syn.make_scene(N, W, H, sh_degree=deg, seed=rank, clustered=args.clustered)
     gt = syn.target_image(W, H, seed=1).to(dev)
     params = ts.GaussianParams(scene, dev)
     settings = ts.make_settings(scene, dev, deg)
-    names = ["preprocess_fwd", "sort_depth", "scan", "emit", "sort_tile", "ranges", "blend_fwd", "blend_bwd",
-             "preprocess_bwd"]
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -144,7 +303,7 @@ def main():
     # timed region: HIP events only around the forward blend kernel (the roofline kernel); an event pair is a ~10 us
     # stream bubble, so the per-stage breakdown is taken from a few extra UNTIMED steps afterwards
     lib.gsr_set_option(b"profile", 2)
-    read_profile(lib, names)  # drop anything recorded so far
+    read_profile(lib, STAGES)  # drop anything recorded so far
     sync_all()
     t0 = time.perf_counter()
     stamps = [t0]
@@ -160,7 +319,7 @@ def main():
         ts.train_step(params, settings, gt)
     torch.cuda.synchronize(dev)
     lib.gsr_set_option(b"profile", 0)
-    prof = read_profile(lib, names)
+    prof = read_profile(lib, STAGES)
     prof["blend_fwd"] = prof_blend   # the figure the roofline uses: measured inside the timed region
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -168,11 +327,18 @@ def main():
         elapsed = float(t.item())
 
     # R and R_eff of the final state (one extra forward outside the timed region)
-    raster = importlib.import_module("3dgs_hierarchical_training_amd.rasterizer")
     with torch.no_grad():
         ts.render(params, settings)
     info = raster.last_call_info()
     R, R_eff = info["num_rendered"], info["staged"]
+
+    # one merge level (config 4), outside the timed region; every rank takes part
+    merge = None
+    if not args.no_extras:
+        try:
+            merge = merge_leg(dev, dist, world, rank, params, scene, ts, syn, deg)
+        except Exception as e:   # a diagnostic must never take the bench line down
+            merge = {"merge_ms": None, "error": repr(e)}
 
     if rank != 0:
         if dist is not None:
@@ -188,29 +354,34 @@ def main():
     fwd_stages = ["preprocess_fwd", "sort_depth", "scan", "emit", "sort_tile", "ranges", "blend_fwd"]
     bwd_stages = ["blend_bwd", "preprocess_bwd"]
     fwd_ms = sum(stage_ms[k] or 0.0 for k in fwd_stages)
-    bwd_ms = sum(stage_ms[k] or 0.0 for k in bwd_stages)
+    bwd_ms = sum(stage_ms[k] or 0.0 for k in bwd_stages)      # both backward stages (the in-kernel Adam rides in the second)
     blend_ms = stage_ms["blend_fwd"]
     alg_bytes = 44.0 * R_eff + 28.0 * P + 8.0 * T
     achieved = (alg_bytes / (blend_ms * 1e-3) / 1e9) if blend_ms else None
-    # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950
-    # read-side x2 correction; tools/pmc_profile.sh + tools/pmc_summary.py).  PMC collection cannot run inside this
-    # process, so the figure is taken from the committed summary when it was measured on this very workload.
-    traffic = None
-    pmc_file = os.path.join(REPO, "profiles", "r01_pmc_blend.json")
-    if (N, W, H, deg) == (1_000_000, 980, 545, 3) and os.path.exists(pmc_file):
-        try:
-            ks = json.load(open(pmc_file))["kernels"]
-            traffic = next(v["hbm_traffic_bytes"] for k, v in ks.items() if "k_blend_fwd" in k)
-        except Exception:
-            traffic = None
+    # HBM bytes per launch and the issue counters from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+    # runs, gfx950 read-side x2 correction; tools/pmc_profile.sh + tools/pmc_summary.py).  PMC collection cannot run inside
+    # this process, so the figures are taken from the newest committed summary measured on this very workload.
+    traffic = valu_issue = pmc_src = None
+    if (N, W, H, deg, args.clustered) == (1_000_000, 980, 545, 3, False):
+        for name in ("r02_pmc_blend.json", "r01_pmc_blend.json"):
+            pmc_file = os.path.join(REPO, "profiles", name)
+            if not os.path.exists(pmc_file):
+                continue
+            try:
+                ks = json.load(open(pmc_file))["kernels"]
+                kv = next(v for k, v in ks.items() if "k_blend_fwd" in k)
+                traffic, valu_issue, pmc_src = kv["hbm_traffic_bytes"], kv.get("valu_issue_frac_est"), f"profiles/{name}"
+                break
+            except Exception:
+                continue
     V = n_visible
-    bwd_ms, preb_ms = stage_ms["blend_bwd"], stage_ms["preprocess_bwd"]
+    blend_bwd_ms, preb_ms = stage_ms["blend_bwd"], stage_ms["preprocess_bwd"]
     others = []
-    if bwd_ms:
+    if blend_bwd_ms:
         ab = 44.0 * R_eff + 36.0 * P + 40.0 * V
-        others.append({"kernel": "k_blend_bwd2", "bound": "hbm", "achieved": ab / (bwd_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                       "unit": "GB/s", "frac": ab / (bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": ab,
-                       "avg_launch_ms": bwd_ms, "note": "VALU-bound (packed f32 math + cross-lane reduction), see DESIGN.md"})
+        others.append({"kernel": "k_blend_bwd2", "bound": "hbm", "achieved": ab / (blend_bwd_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                       "unit": "GB/s", "frac": ab / (blend_bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": ab,
+                       "avg_launch_ms": blend_bwd_ms, "note": "VALU-bound (packed f32 math + cross-lane reduction), see DESIGN.md"})
     if preb_ms:
         ab = 1476.0 * N   # params 236 + ggrad 48 + moments 472 in; params + moments 708 + means2D grad 12 out
         others.append({"kernel": "k_preprocess_bwd (per-Gaussian backward + in-kernel Adam)", "bound": "hbm",
@@ -219,10 +390,10 @@ def main():
                        "avg_launch_ms": preb_ms, "note": "durations from the untimed stage-profiling steps"})
     roofline = {"kernel": "k_blend_fwd_w", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
-                "traffic_source": "profiles/r01_pmc_blend.json (rocprofv3 --pmc, separate passes)" if traffic else None,
-                "traffic_note": "81 MB with one band of tiles per XCD; dealing 2x2 tile blocks round-robin to the XCDs (load "
-                                "balance) lets neighbouring L2s fetch some splat records twice (+~25 MB of reads), and the "
-                                "per-pixel checkpoints for the split backward add ~25 MB of writes" if traffic else None,
+                "traffic_source": f"{pmc_src} (rocprofv3 --pmc, separate passes)" if traffic else None,
+                "valu_issue_frac": valu_issue,
+                "second_bound": "the kernel is VALU/SALU-issue bound, not HBM-bound: valu_issue_frac = SQ_INSTS_VALU x 4 cycles / 1024 SIMDs / "
+                                "busy cycles from the same PMC passes (DESIGN.md section 5)",
                 "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": blend_ms,
                 "launches_timed": prof["blend_fwd"][1], "R": R, "R_eff": R_eff, "P": P, "T": T}
     res = {
@@ -230,15 +401,48 @@ def main():
         "value": world * args.steps / elapsed, "unit": "images/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"syn-{N} Gaussians, {W}x{H}, SH degree {deg}, identity-pose pinhole camera "
+        "config": {"workload": f"syn-{N} Gaussians{' (clustered)' if args.clustered else ''}, {W}x{H}, SH degree {deg}, identity-pose pinhole camera "
                                f"(FoVx {syn.FOVX_FRANCIS}), U[0,1] target, one view per step per GPU",
                    "gaussians": N, "width": W, "height": H, "sh_degree": deg, "visible": n_visible,
                    "num_rendered_R": R, "parallelism": f"{world} independent segment replica(s), no data-path collective",
                    "train_step": "activations + rasterize fwd + 0.8*L1+0.2*(1-SSIM) + backward + Adam(eps=1e-15) on all 59 floats "
-                                 "per Gaussian (update applied inside the per-Gaussian backward kernel)"},
+                                 "per Gaussian (update applied inside the per-Gaussian backward kernel); the unmodified "
+                                 "reference trainer reaches the `dropin` path instead"},
         "fwd_bwd_ms": fwd_ms + bwd_ms, "rasterizer_fwd_ms": fwd_ms, "rasterizer_bwd_ms": bwd_ms,
         "stage_ms": stage_ms, "step_host_ms": step_host, "roofline": roofline, "roofline_other_kernels": others,
     }
+    if merge is not None:
+        res["merge"] = merge
+    if world == 1 and not args.no_extras:
+        try:
+            roofline["peak_measured"] = copy_ceiling(dev)
+            roofline["frac_of_measured"] = (achieved / roofline["peak_measured"]) if achieved else None
+            for o in others:
+                o["peak_measured"] = roofline["peak_measured"]
+                o["frac_of_measured"] = o["achieved"] / roofline["peak_measured"]
+        except Exception as e:
+            roofline["peak_measured"] = None
+            roofline["peak_measured_error"] = repr(e)
+        try:
+            res["dropin"] = dropin_leg(ts, scene, settings, gt, dev, steps=min(args.steps, 10), warmup=2)
+        except Exception as e:
+            res["dropin"] = {"value": None, "error": repr(e)}
+        del params
+        torch.cuda.empty_cache()
+        extra = {}
+        if (N, W, H) == (1_000_000, 980, 545) and not args.clustered:
+            legs = [("C2 300k @980x545", dict(N=300_000, W=980, H=545, steps=20)),
+                    ("C3 1M @1920x1080, densification every 100 steps", dict(N=1_000_000, W=1920, H=1080, steps=300, densify_every=100)),
+                    ("C5 4M @980x545", dict(N=4_000_000, W=980, H=545, steps=10)),
+                    ("syn-1M clustered @980x545", dict(N=1_000_000, W=980, H=545, steps=20, clustered=True)),
+                    ("stage-A size 50k @980x545", dict(N=50_000, W=980, H=545, steps=50)),
+                    ("stage-A size 20k @980x545", dict(N=20_000, W=980, H=545, steps=50))]
+            for name, kw in legs:
+                try:
+                    extra[name] = workload_leg(syn, ts, raster, dev, deg=deg, warmup=3, **kw)
+                except Exception as e:
+                    extra[name] = {"error": repr(e)}
+        res["other_workloads"] = extra
     if world == 1 and not args.no_cpu_baseline:
         threads = os.cpu_count() or 1
         try:

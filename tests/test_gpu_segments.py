@@ -1,0 +1,136 @@
+"""BASELINE config 4 on one GPU: the 8-leaf hierarchical run walked sequentially on cuda:0 through the SAME code the
+one-process-per-GPU launcher runs (run_segments.RankRunner), with the in-process LocalTransport standing for the RCCL
+point-to-point exchange.  The merge is checked against merge_two_3DGS semantics
+(/root/reference/trainer/ht3dgs_trainer.py:233-271) with the float64 oracle's importance."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+import parity
+from oracle import binding
+
+pytestmark = pytest.mark.gpu
+
+rs = importlib.import_module("3dgs_hierarchical_training_amd.run_segments")
+hier = importlib.import_module("3dgs_hierarchical_training_amd.hierarchy")
+seg_mod = importlib.import_module("3dgs_hierarchical_training_amd.segments")
+sequence = importlib.import_module("3dgs_hierarchical_training_amd.sequence")
+ts = importlib.import_module("3dgs_hierarchical_training_amd.train_step")
+
+
+def _oracle_importance(raw, views):
+    """calc_importance (:1427-1462) from the float64 oracle: sum over views of |dL/dSH| with dL/dimage = 1 inside the
+    clamp's pass-through range, / pixels."""
+    cpu = {k: v.detach().cpu() for k, v in raw.items()}
+    N = cpu["_xyz"].shape[0]
+    acc, npix = np.zeros((N, 16, 3)), 0
+    for rs_ in views:
+        kw = dict(means3D=cpu["_xyz"], opacities=torch.sigmoid(cpu["_opacity"]), viewmatrix=rs_.viewmatrix.cpu(),
+                  projmatrix=rs_.projmatrix.cpu(), campos=rs_.campos.cpu(), bg=rs_.bg.cpu(), image_height=rs_.image_height,
+                  image_width=rs_.image_width, tanfovx=rs_.tanfovx, tanfovy=rs_.tanfovy, sh_degree=rs_.sh_degree, scale_modifier=1.0,
+                  shs=torch.cat((cpu["_features_dc"], cpu["_features_rest"]), 1).contiguous(), scales=torch.exp(cpu["_scaling"]),
+                  rotations=torch.nn.functional.normalize(cpu["_rotation"]))
+        o = binding.OracleRender(**kw)
+        color = o.forward()[0]
+        g = ((color >= 0) & (color <= 1)).astype(np.float32)
+        acc += np.abs(o.backward(g, None, None)["shs"])
+        npix += rs_.image_height * rs_.image_width
+        o.close()
+    return acc.reshape(N, 48) / npix
+
+
+def test_eight_leaf_tree_on_one_gpu():
+    dev = torch.device("cuda:0")
+    cfg = rs.HTConfig(frames=40, width=192, height=144, gt_gaussians=6000, leaf_gaussians=2500, leaf_iters_per_frame=12,
+                      phase1_iters_per_frame=3, phase2_iters_per_frame=[6, 6, 6], prune_ratio=0.5)
+    seq = sequence.FrameSequence(cfg.frames, cfg.gt_gaussians, cfg.width, cfg.height, dev, seed=4)
+    tr = seg_mod.LocalTransport(8)
+    captured = {}
+
+    def importance(seg, views):                       # the product's, recorded for the first pair
+        imp = hier.calc_importance(seg, views)
+        captured.setdefault(len(captured), ({k: v.detach().clone() for k, v in seg.items()}, list(views), imp.clone()))
+        return imp
+
+    log = []
+    runners = [rs.RankRunner(r, 8, tr, seq, cfg, dev, log=log.append, importance_fn=importance) for r in range(8)]
+    for rr in runners:
+        rr.train_leaf()
+    psnr_leaf0 = runners[0].evaluate()
+    pre = {r: {k: v.clone() for k, v in runners[r].seg.params.raw().items()} for r in (0, 1)}
+    pose01 = runners[0].seg.poses[runners[1].seg.start_fidx].clone()
+    for k, pairs in enumerate(runners[0].schedule):
+        for dst, src in pairs:
+            runners[src].merge_send(k)
+        for dst, src in pairs:
+            runners[dst].merge_recv(k)
+            if k == 0 and dst == 0:
+                merged01 = {kk: v.clone() for kk, v in runners[0].seg.params.raw().items()}
+                t_own, t_child = runners[0].teachers       # both UN-pruned children are held as the frozen teachers
+                assert torch.equal(t_own["seg"]["_xyz"], pre[0]["_xyz"]) and torch.equal(t_child["seg"]["_xyz"], pre[1]["_xyz"])
+                assert t_child["start_fidx"] == runners[0].parts[3][1][0]
+            runners[dst].train_nonleaf(k)
+
+    # ---- structure of the walk -----------------------------------------------------------------------------------------
+    root = runners[0]
+    assert all(r.seg is None for r in runners[1:])
+    assert root.seg.frames == list(range(cfg.frames)) and sorted(root.seg.poses) == list(range(cfg.frames))
+    n = cfg.leaf_gaussians
+    for _ in range(3):
+        n = 2 * (n - n // 2)
+    assert root.seg.params.num_points == n
+    merges = [r for r in log if r["phase"] == "merge"]
+    assert len(merges) == 14 and sum(1 for m in merges if m["role"] == "src") == 7
+    for m in merges:
+        assert m["importance_ms"] > 0 and m["bytes"] >= (m["n"] if m["role"] == "src" else m["n_child"]) * 237
+    for f in (0, 17, 39):                                # chained poses equal the ground-truth camera track
+        assert torch.allclose(root.seg.poses[f], seq.w2c[f] @ torch.linalg.inv(seq.w2c[0]), atol=1e-5)
+
+    # ---- merge (0 <- 1) against merge_two_3DGS semantics with the ORACLE's importance ---------------------------------------
+    # level 0 runs the four senders (ranks 1, 3, 5, 7) first, then the four receivers (0, 2, 4, 6)
+    (raw1, views1, imp1), (raw0, views0, imp0) = captured[0], captured[4]
+    assert torch.equal(raw0["_xyz"], pre[0]["_xyz"]) and torch.equal(raw1["_xyz"], pre[1]["_xyz"])
+    keep_rows = []
+    for raw, views, imp in ((raw0, views0, imp0), (raw1, views1, imp1)):
+        ref = _oracle_importance(raw, views)
+        assert np.abs(imp.cpu().numpy() - ref).max() <= 2e-3 * ref.max()
+        score = ref.max(1)
+        N = score.shape[0]
+        kdrop = int(N * cfg.prune_ratio)
+        order = np.argsort(score, kind="stable")
+        thr = score[order[kdrop - 1]]
+        drop_ref = np.zeros(N, bool); drop_ref[order[:kdrop]] = True
+        drop_hip = hier.prune_mask(imp, cfg.prune_ratio).cpu().numpy()
+        assert drop_hip.sum() == kdrop
+        diff = drop_ref != drop_hip                        # only Gaussians whose score sits at the threshold may swap sides
+        assert diff.mean() < 0.01
+        assert np.all(np.abs(score[diff] - thr) <= 5e-3 * max(thr, 1e-12))
+        keep_rows.append(~drop_hip)
+    T = torch.linalg.inv(pose01).to(dev)
+    xyz1 = pre[1]["_xyz"] @ T[:3, :3].t() + T[:3, 3]
+    k0, k1 = torch.from_numpy(keep_rows[0]).to(dev), torch.from_numpy(keep_rows[1]).to(dev)
+    assert torch.allclose(merged01["_xyz"], torch.cat((pre[0]["_xyz"][k0], xyz1[k1])), atol=1e-6)
+    for key in ("_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation"):
+        assert torch.equal(merged01[key], torch.cat((pre[0][key][k0], pre[1][key][k1])))
+
+    # ---- the merged, fine-tuned root explains ALL frames (a leaf only saw an eighth of the track) -------------------------
+    psnr_root = root.evaluate()
+    print(f"PSNR leaf 0 over its {len(runners[0].parts[3][0])} frames {psnr_leaf0:.2f} dB; root over all {cfg.frames} frames {psnr_root:.2f} dB")
+    assert psnr_root > 17.0
+
+
+def test_stage_a_pair_fit_recovers_the_relative_pose():
+    """compute_relative_pose (:336-380) on the HIP rasterizer for one frame pair: single-image 3DGS, then the SE(3) fit."""
+    sa = importlib.import_module("3dgs_hierarchical_training_amd.stage_a")
+    dev = torch.device("cuda:0")
+    seq = sequence.FrameSequence(6, 5000, 256, 192, dev, seed=2, step_angle=0.015, step_shift=0.02)
+    rel = sa.fit_pair(seq, 2, dev, n_points=5000, single_image_iters=150, pose_iters=250, pose_lr=1e-3)
+    gt = seq.rel_pose(2, 3)
+    err0 = (torch.eye(4) - gt)[:3].abs().max().item()
+    err = (rel - gt)[:3].abs().max().item()
+    print(f"relative pose error {err:.4f} (identity start {err0:.4f})")
+    assert err < 0.35 * err0
+    d = sa.run_stage_a(3, lambda p: gt if p == 0 else torch.eye(4), dev, rank=0, world=1)
+    assert sorted(d) == ["rel_pose_0_to_1", "rel_pose_1_to_2"] and torch.allclose(d["rel_pose_0_to_1"].cpu(), gt)

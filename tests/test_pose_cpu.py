@@ -43,3 +43,23 @@ def test_tangent_derivative_at_zero_is_translation_and_cross_product():
     pp = pose.act(pose.pose7_to_matrix(G), p)[0]
     expect = torch.cat((torch.eye(3, dtype=torch.float64), -pose._hat(pp)), dim=1)
     assert torch.allclose(J, expect, atol=1e-9)
+
+
+def test_log_inverts_exp_and_interpolation_hits_both_ends():
+    rng = np.random.default_rng(3)
+    for scale in (1e-7, 1e-3, 0.4, 2.0):
+        d = torch.from_numpy(rng.normal(size=6) * scale)
+        M = pose.se3_exp(d)
+        if scale < 1.0:      # rotation angle below pi: the log is unique
+            assert torch.allclose(pose.se3_log(M), d, atol=1e-9)
+        assert torch.allclose(pose.se3_exp(pose.se3_log(M)), M, atol=1e-9)
+    a, b = pose.se3_exp(torch.from_numpy(rng.normal(size=6) * 0.3)), pose.se3_exp(torch.from_numpy(rng.normal(size=6) * 0.3))
+    assert torch.allclose(pose.interpolate_pose(a, b, 0.0), a, atol=1e-12)
+    assert torch.allclose(pose.interpolate_pose(a, b, 1.0), b, atol=1e-10)
+    h = pose.interpolate_pose(a, b, 0.5)        # the geodesic midpoint is equidistant from both ends
+    da, db = pose.se3_log(torch.linalg.inv(a) @ h), pose.se3_log(torch.linalg.inv(h) @ b)
+    assert torch.allclose(da, db, atol=1e-9)
+    # rotation part agrees with scipy's slerp
+    from scipy.spatial.transform import Slerp
+    sl = Slerp([0, 1], Rotation.from_matrix(np.stack([a[:3, :3].numpy(), b[:3, :3].numpy()])))
+    assert np.allclose(h[:3, :3].numpy(), sl(0.5).as_matrix(), atol=1e-9)

@@ -110,3 +110,170 @@ def test_merge_schedule_tree():
     assert lv == [[(0, 1), (2, 3), (4, 5), (6, 7)], [(0, 2), (4, 6)], [(0, 4)]]
     assert seg_mod.partner(3, lv[0]) == ("send", 2) and seg_mod.partner(4, lv[2]) == ("send", 0)
     assert seg_mod.partner(1, lv[1]) is None
+
+
+# ---- config 4 tree walk (run_segments.RankRunner) over gloo, world 2 and 4 ----------------------------------------------
+# The three places that reach the HIP rasterizer are replaced by CPU stand-ins; everything else -- partition, pose chains,
+# un-pruned child + mask messages, masks applied at the destination, teachers, frame unions -- is the product code.
+def _fake_importance(s, views):
+    return s["_xyz"].abs().sum(1, keepdim=True).repeat(1, 48) + 0.01 * len(views)
+
+
+def _tree_worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rs = importlib.import_module("3dgs_hierarchical_training_amd.run_segments")
+    seg_mod = importlib.import_module("3dgs_hierarchical_training_amd.segments")
+    sequence = importlib.import_module("3dgs_hierarchical_training_amd.sequence")
+
+    class Seq(sequence.FrameSequence):
+        def target(self, f):
+            return torch.zeros(3, self.H, self.W)
+
+    cfg = rs.HTConfig(frames=24, width=64, height=48, gt_gaussians=600, leaf_gaussians=200 + 10 * rank, leaf_iters_per_frame=2,
+                      phase1_iters_per_frame=2, phase2_iters_per_frame=[1, 1, 1], optimizer="torch", fused=False)
+    seq = Seq(cfg.frames, cfg.gt_gaussians, cfg.width, cfg.height, torch.device("cpu"))
+    log, steps, renders = [], [0], [0]
+
+    def step_fn(seg, settings, target):
+        steps[0] += 1
+
+    def teacher_render(seg, settings):
+        renders[0] += 1
+        return torch.zeros(3, cfg.height, cfg.width)
+
+    rr = rs.RankRunner(rank, world, seg_mod.DistTransport(), seq, cfg, torch.device("cpu"), log=log.append,
+                       importance_fn=_fake_importance, step_fn=step_fn, teacher_render_fn=teacher_render)
+    final = rr.run(barrier=dist.barrier)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, None if final is None else (final.params.num_points, final.frames, final.start_fidx, sorted(final.poses)),
+           log, steps[0], renders[0]))
+
+
+def _run_tree(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tree_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(60)
+    return res
+
+
+def _check_tree(world):
+    res = _run_tree(world)
+    n_leaf = [200 + 10 * r for r in range(world)]
+    # expected Gaussian counts up the tree: both children lose int(N * 0.5) at every merge
+    counts, step = list(n_leaf), 1
+    while step < world:
+        for k in range(0, world, 2 * step):
+            counts[k] = (counts[k] - counts[k] // 2) + (counts[k + step] - counts[k + step] // 2)
+        step *= 2
+    rank0 = res[0]
+    assert rank0[1][0] == counts[0]
+    assert rank0[1][1] == list(range(24)) and rank0[1][2] == 0 and rank0[1][3] == list(range(24))   # all frames, all poses chained
+    for rank, final, log, steps, renders in res[1:]:
+        assert final is None                           # every other rank handed its model up the tree
+    for rank, final, log, steps, renders in res:
+        merges = [r for r in log if r["phase"] == "merge"]
+        for m in merges:
+            if m["role"] == "src":                     # the child travels UN-pruned: 59 floats per Gaussian + 1 mask byte
+                assert m["bytes"] >= m["n"] * (59 * 4 + 1) and m["n_dropped"] == m["n"] // 2
+            else:
+                assert m["bytes"] >= m["n_child"] * (59 * 4 + 1)
+                assert m["n_merged"] == (m["n"] - m["n_dropped"]) + (m["n_child"] - m["n_child_dropped"])
+                assert m["n_child_dropped"] == m["n_child"] // 2
+        non = [r for r in log if r["phase"] == "nonleaf"]
+        assert len(non) == sum(1 for m in merges if m["role"] == "dst")
+        if non:
+            assert renders == sum(r["virtual_views"] for r in non) and renders > 0    # phase 1 asked the frozen children
+            assert steps > 0
+
+
+def test_segment_tree_world2():
+    _check_tree(2)
+
+
+def test_segment_tree_world4():
+    _check_tree(4)
+
+
+def test_local_transport_walks_the_same_tree():
+    """One process, LocalTransport: the same RankRunner code yields the same counts as the distributed walk."""
+    rs = importlib.import_module("3dgs_hierarchical_training_amd.run_segments")
+    sequence = importlib.import_module("3dgs_hierarchical_training_amd.sequence")
+
+    class Seq(sequence.FrameSequence):
+        def target(self, f):
+            return torch.zeros(3, self.H, self.W)
+
+    cfg = rs.HTConfig(frames=40, width=64, height=48, gt_gaussians=600, leaf_gaussians=300, leaf_iters_per_frame=1,
+                      phase1_iters_per_frame=1, phase2_iters_per_frame=[1], optimizer="torch", fused=False)
+    seq = Seq(cfg.frames, cfg.gt_gaussians, cfg.width, cfg.height, torch.device("cpu"))
+    seg_mod = importlib.import_module("3dgs_hierarchical_training_amd.segments")
+    tr = seg_mod.LocalTransport(8)
+    runners = [rs.RankRunner(r, 8, tr, seq, cfg, torch.device("cpu"), log=lambda rec: None, importance_fn=_fake_importance,
+                             step_fn=lambda *a: None, teacher_render_fn=lambda s, st: torch.zeros(3, 48, 64)) for r in range(8)]
+    for rr in runners:
+        rr.train_leaf()
+    for k, pairs in enumerate(runners[0].schedule):
+        for dst, src in pairs:
+            runners[src].merge_send(k)
+        for dst, src in pairs:
+            runners[dst].merge_recv(k)
+            # the destination holds both UN-pruned children as teachers
+            t_own, t_child = runners[dst].teachers
+            msgs = [r for r in runners[dst].report if r["phase"] == "merge" and r["level"] == k]
+            assert t_own["seg"]["_xyz"].shape[0] == msgs[-1]["n"] and t_child["seg"]["_xyz"].shape[0] == msgs[-1]["n_child"]
+            runners[dst].train_nonleaf(k)
+    assert runners[0].seg.frames == list(range(40))
+    assert all(r.seg is None for r in runners[1:])
+    n = 300
+    for _ in range(3):
+        n = 2 * (n - n // 2)
+    assert runners[0].seg.params.num_points == n
+
+
+def _stage_a_worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sa = importlib.import_module("3dgs_hierarchical_training_amd.stage_a")
+    fitted = []
+
+    def fit(p):            # stands in for stage_a.fit_pair (HIP): a pose that encodes the pair index
+        fitted.append(p)
+        M = torch.eye(4)
+        M[:3, 3] = torch.tensor([p, 10.0 * p, -p])
+        return M
+
+    d = sa.run_stage_a(11, fit, torch.device("cpu"))
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, fitted, {k: v[:3, 3].tolist() for k, v in d.items()}))
+
+
+def test_stage_a_round_robin_all_gather_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_stage_a_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert res[0][1] == [0, 2, 4, 6, 8] and res[1][1] == [1, 3, 5, 7, 9]          # pairs dealt round-robin
+    for rank, fitted, d in res:                                                     # every rank ends with the whole table
+        assert sorted(d) == sorted(f"rel_pose_{p}_to_{p + 1}" for p in range(10))
+        for p in range(10):
+            assert d[f"rel_pose_{p}_to_{p + 1}"] == [float(p), 10.0 * p, float(-p)]
