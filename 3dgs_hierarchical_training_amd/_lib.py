@@ -30,7 +30,7 @@ class GsrForwardArgs(C.Structure):
 
 class GsrForwardOut(C.Structure):
     _fields_ = [("num_rendered", C.c_int64), ("binning", C.c_void_p), ("binning_bytes", C.c_size_t),
-                ("binning_capacity", C.c_int64)]
+                ("binning_capacity", C.c_int64), ("forward_flags", C.c_int64)]
 
 
 class GsrBackwardArgs(C.Structure):
@@ -49,7 +49,7 @@ class GsrBackwardArgs(C.Structure):
         ("d_viewmatrix", C.c_void_p), ("d_projmatrix", C.c_void_p), ("d_campos", C.c_void_p),
         ("fused_adam", C.c_void_p),
         ("points_transform", C.c_void_p), ("d_points_transform", C.c_void_p),
-        ("binning_capacity", C.c_int64),
+        ("binning_capacity", C.c_int64), ("forward_flags", C.c_int64),
     ]
 
 
@@ -69,7 +69,7 @@ EXPORTS = [
     "gsr_mark_visible", "gsr_last_error", "gsr_version", "gsr_set_option", "gsr_sort_pairs_u32",
     "gsr_sort_pairs_u16", "gsr_sort_scratch_bytes", "gsr_image_staged_offset", "gsr_profile_read",
     "gsr_loss_workspace_bytes", "gsr_loss_forward", "gsr_loss_backward", "gsr_adam_step",
-    "gsr_knn_scratch_bytes", "gsr_knn_mean_dist2",
+    "gsr_knn_scratch_bytes", "gsr_knn_mean_dist2", "gsr_get_counter", "gsr_debug_read_binning",
 ]
 
 _lib = None
@@ -124,6 +124,10 @@ def load():
     lib.gsr_version.restype = C.c_int
     lib.gsr_set_option.restype = C.c_int
     lib.gsr_set_option.argtypes = [C.c_char_p, C.c_int]
+    lib.gsr_get_counter.restype = C.c_int64
+    lib.gsr_get_counter.argtypes = [C.c_char_p]
+    lib.gsr_debug_read_binning.restype = C.c_int
+    lib.gsr_debug_read_binning.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     for fn in ["gsr_sort_pairs_u32", "gsr_sort_pairs_u16"]:
         getattr(lib, fn).restype = C.c_int
         getattr(lib, fn).argtypes = [C.c_void_p] * 4 + [C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_size_t,

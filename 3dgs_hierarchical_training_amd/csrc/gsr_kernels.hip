@@ -17,7 +17,10 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cmath>
+#include <map>
 #include <mutex>
+#include <tuple>
 #include <vector>
 
 #include "../../include/gsr.h"
@@ -1803,15 +1806,53 @@ static BinScratch bin_scratch_layout(int64_t R, int key_bytes = 4)
     return s;
 }
 
-static std::mutex g_pin_mutex;
-static unsigned long long* g_pinned = nullptr;
-static hipEvent_t g_pin_event = nullptr;
-static std::atomic<uint64_t> g_r_hint{0};   // capacity for the next speculative binning (0 = none yet: exact flow)
+// ---- speculation state, keyed per caller ----------------------------------------------------------------------------
+// The capacity hint of the speculative binning is kept per (device, image size, Gaussian-count bucket): the reference
+// alternates models of very different size on one process -- teacher and student (ht3dgs_trainer.py:877-883), the
+// single-image models of stage A next to a leaf -- and one process-wide hint would thrash between over-allocation and
+// the overflow re-run.  Buckets are half octaves of N, so a model that densifies keeps its entry.
+// The pinned read-back slot and its event belong to ONE device (an event recorded on another device's stream is an
+// invalid-handle error), and a slot is held by one call at a time: callers on several threads / devices do not serialise
+// on each other while they enqueue or wait.
+struct PinSlot { unsigned long long* host = nullptr; hipEvent_t ev = nullptr; bool busy = false; };
+static std::mutex g_state_mutex;
+static std::map<int, std::vector<PinSlot*>> g_pin_slots;                     // device -> slots
+static std::map<std::tuple<int, int, int, int>, uint64_t> g_hints;         // (device, W, H, bucket of N) -> capacity
+static long long g_hint_override = -1;                                      // tests: capacity of the NEXT forward (one shot)
 static int g_speculate = 1;
 static int g_bwd_split = 16; // workgroups a long tile's backward is split over (checkpoints from the forward); 1 = off
 static int g_ckpt_first = 1;  // 128-instance batches of a tile before the forward starts leaving checkpoints
 static int g_tile_map = 2;   // tile -> XCD map: 2 = 2x2 tile blocks interleaved (default), 1 = tiles interleaved, 0 = banded
-static std::atomic<int> g_spec_overflows{0};
+static std::atomic<long long> g_spec_overflows{0}, g_spec_forwards{0}, g_exact_forwards{0};
+
+static int n_bucket(int N) { return N > 0 ? (int)std::floor(2.0 * std::log2((double)N)) : 0; }
+
+static PinSlot* acquire_pin_slot(int dev)
+{
+    std::lock_guard<std::mutex> lk(g_state_mutex);
+    auto& v = g_pin_slots[dev];
+    for (PinSlot* s : v)
+        if (!s->busy) { s->busy = true; return s; }
+    PinSlot* s = new PinSlot();
+    if (hipHostMalloc((void**)&s->host, 64, hipHostMallocDefault) != hipSuccess ||
+        hipEventCreateWithFlags(&s->ev, hipEventDisableTiming) != hipSuccess) { delete s; return nullptr; }
+    s->busy = true;
+    v.push_back(s);
+    return s;
+}
+struct PinLease {   // releases the slot on every exit path
+    PinSlot* s;
+    explicit PinLease(PinSlot* s_) : s(s_) {}
+    ~PinLease() { if (s) { std::lock_guard<std::mutex> lk(g_state_mutex); s->busy = false; } }
+};
+
+// What the forward fixed for its backward (GsrForwardOut::forward_flags): the blend kernel variant, the tile -> XCD map,
+// the first checkpointed batch and whether checkpoints were written at all.  gsr_backward reads them from the flags
+// instead of the process-wide options as they happen to be at backward time.
+static inline int64_t pack_fwd_flags(int ppt, int tile_map, int ckpt_first)
+{
+    return 1 | ((int64_t)ppt << 1) | ((int64_t)tile_map << 4) | ((int64_t)ckpt_first << 6) | ((int64_t)(ppt == 5) << 13);
+}
 
 static int check_common(int32_t N, int32_t M, int32_t D, int32_t W, int32_t H)
 {
@@ -1894,7 +1935,17 @@ int gsr_set_option(const char* name, int value)
     if (!strcmp(name, "ckpt_first")) { if (value < 1 || value > 64) return GSR_ERR_ARG; g_ckpt_first = value; return GSR_OK; }
     if (!strcmp(name, "tile_map")) { if (value < 0 || value > 2) return GSR_ERR_ARG; g_tile_map = value; return GSR_OK; }
     if (!strcmp(name, "speculative_binning")) { g_speculate = value ? 1 : 0; return GSR_OK; }
-    if (!strcmp(name, "binning_capacity_hint")) { g_r_hint.store(value > 0 ? (uint64_t)value : 0); return GSR_OK; }   // tests: force an overflow
+    if (!strcmp(name, "binning_capacity_hint")) {   // tests: capacity of the next forward (one shot; forces an overflow re-run)
+        std::lock_guard<std::mutex> lk(g_state_mutex);
+        g_hint_override = value > 0 ? value : -1;
+        return GSR_OK;
+    }
+    if (!strcmp(name, "reset_speculation")) {       // forget every capacity hint and zero the counters
+        std::lock_guard<std::mutex> lk(g_state_mutex);
+        g_hints.clear(); g_hint_override = -1;
+        g_spec_overflows = 0; g_spec_forwards = 0; g_exact_forwards = 0;
+        return GSR_OK;
+    }
     if (!strcmp(name, "profile")) { g_profile = (value == 2) ? 2 : (value ? 1 : 0); return GSR_OK; }
     if (!strcmp(name, "sort_algo")) { if (value < 0 || value > 2) return GSR_ERR_ARG; g_sort_algo = value; return GSR_OK; }
     // 2 = packed-math kernel (default), 3 = scalar 2-pixel kernel (kept for A/B), 1 / 4 = scalar 1 / 4 pixels
@@ -1911,8 +1962,11 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
     if (!a->out_color || !a->out_depth || !a->out_alpha || !a->image || !a->bg || !a->alloc)
         return fail(GSR_ERR_ARG, "missing output / workspace pointer%s");
     const int N = a->N, W = a->W, H = a->H;
+    // the process-wide options as they are NOW: one forward uses one consistent set and hands it to its backward
+    const int opt_ppt = g_blend_ppt ? g_blend_ppt : 5, opt_map = g_tile_map, opt_ckpt = g_ckpt_first;
     const int tiles_x = (W + kTile - 1) / kTile, tiles_y = (H + kTile - 1) / kTile, T = tiles_x * tiles_y;
     out->num_rendered = 0; out->binning = nullptr; out->binning_bytes = 0; out->binning_capacity = 0;
+    out->forward_flags = pack_fwd_flags(opt_ppt, opt_map, opt_ckpt);
     uint64_t R = 0;
     Splat* splat = static_cast<Splat*>(a->geom);
     float* img = static_cast<float*>(a->image);
@@ -1984,14 +2038,14 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
         return wide_keys ? launch_binning_t(uint32_t{}, capacity, n_dev, prezeroed) : launch_binning_t(uint16_t{}, capacity, n_dev, prezeroed);
     };
     auto launch_blend = [&](bool prezeroed) -> int {
-        const int ppt = g_blend_ppt ? g_blend_ppt : 5;   // default: one wave per 8x8 sub-tile
+        const int ppt = opt_ppt;   // default 5: one wave per 8x8 sub-tile
         if (!prezeroed) GSR_HIP(hipMemsetAsync(staged, 0, (size_t)T * 16, st));
         {
             ProfScope ps(P_BLEND_FWD, st);
             if (ppt == 5)
-                hipLaunchKernelGGL(k_blend_fwd_w, dim3(8 * 4 * slots_per_xcd(g_tile_map, T, tiles_x)), dim3(64), 0, st, W, H, tiles_x, T, ranges, list, splat, a->bg,
-                                   a->out_color, a->out_depth, a->out_alpha, img, staged, g_tile_map,
-                                   reinterpret_cast<float*>(bin + B.ckpt), g_ckpt_first);
+                hipLaunchKernelGGL(k_blend_fwd_w, dim3(8 * 4 * slots_per_xcd(opt_map, T, tiles_x)), dim3(64), 0, st, W, H, tiles_x, T, ranges, list, splat, a->bg,
+                                   a->out_color, a->out_depth, a->out_alpha, img, staged, opt_map,
+                                   reinterpret_cast<float*>(bin + B.ckpt), opt_ckpt);
             else if (ppt == 1) launch_blend_fwd<1>(W, H, tiles_x, T, ranges, list, splat, a->bg, a->out_color, a->out_depth, a->out_alpha, img, staged, st);
             else if (ppt == 2)
                 hipLaunchKernelGGL(k_blend_fwd2, dim3(8 * ((T + 7) / 8)), dim3(128), 0, st, W, H, tiles_x, T, ranges, list, splat, a->bg,
@@ -2029,7 +2083,15 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
     // is enqueued, and in the rare overflow (R > capacity) the binning is simply launched again with the exact size.
     // Knowing the capacity up front also lets the small clears (ranges, staged counters, sort-scratch heads) ride in
     // kernels that run anyway instead of five separate fill launches. ----
-    const uint64_t hint = g_r_hint.load();
+    int dev_id = 0;
+    GSR_HIP(hipGetDevice(&dev_id));
+    const auto hint_key = std::make_tuple(dev_id, W, H, n_bucket(N));
+    uint64_t hint = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_state_mutex);
+        if (g_hint_override > 0) { hint = (uint64_t)g_hint_override; g_hint_override = -1; }
+        else { auto it = g_hints.find(hint_key); if (it != g_hints.end()) hint = it->second; }
+    }
     const bool speculative = g_speculate && g_sort_algo == 2 && hint > 0;
     const uint64_t cap = speculative ? hint : 0;
 
@@ -2089,28 +2151,23 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
     }
     GSR_HIP(hipGetLastError());
 
-    std::unique_lock<std::mutex> pin_lock(g_pin_mutex);
-    if (!g_pinned) {
-        GSR_HIP(hipHostMalloc((void**)&g_pinned, 64, hipHostMallocDefault));
-        GSR_HIP(hipEventCreateWithFlags(&g_pin_event, hipEventDisableTiming));
-    }
-    GSR_HIP(hipMemcpyAsync(g_pinned, total, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    PinLease pin(acquire_pin_slot(dev_id));
+    if (!pin.s) return fail(GSR_ERR_HIP, "pinned read-back slot allocation failed%s");
+    GSR_HIP(hipMemcpyAsync(pin.s->host, total, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     if (speculative) {
-        GSR_HIP(hipEventRecord(g_pin_event, st));
+        GSR_HIP(hipEventRecord(pin.s->ev, st));
         rc = launch_binning(cap, total, true);
         if (rc) return rc;
         rc = launch_blend(true);
         if (rc) return rc;
-        GSR_HIP(hipEventSynchronize(g_pin_event));   // long past by the time the host gets here
-        R = *g_pinned;
-        pin_lock.unlock();
-        if (R > 0xfffffff0ull) return fail(GSR_ERR_RANGE, "more than 2^32 instances%s");
+        GSR_HIP(hipEventSynchronize(pin.s->ev));   // long past by the time the host gets here
+        g_spec_forwards++;
     } else {
         GSR_HIP(hipStreamSynchronize(st));
-        R = *g_pinned;
-        pin_lock.unlock();
-        if (R > 0xfffffff0ull) return fail(GSR_ERR_RANGE, "more than 2^32 instances%s");
+        g_exact_forwards++;
     }
+    R = *pin.s->host;
+    if (R > 0xfffffff0ull) return fail(GSR_ERR_RANGE, "more than 2^32 instances%s");
     if (!speculative || R > cap) {   // exact flow, or the capacity was too small (the truncated result is overwritten)
         if (speculative) g_spec_overflows++;
         rc = alloc_binning(R);
@@ -2121,15 +2178,19 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
         if (rc) return rc;
     }
     {
-        // next capacity: 1.25x this frame's count, but never much below what recent frames needed (views alternate in
-        // training, so the hint decays slowly instead of following every small frame down)
-        const uint64_t prev = g_r_hint.load();
-        g_r_hint.store(std::max<uint64_t>(std::max<uint64_t>(R + R / 4, prev - prev / 32), 1u << 16));
+        // next capacity of THIS caller (device, image size, N bucket): 1.25x this frame's count, but never much below what
+        // its recent frames needed (views alternate in training, so the hint decays slowly instead of following every
+        // small frame down)
+        std::lock_guard<std::mutex> lk(g_state_mutex);
+        uint64_t& h = g_hints[hint_key];
+        h = std::max<uint64_t>(std::max<uint64_t>(R + R / 4, h - h / 32), 1u << 16);
+        if (g_hints.size() > 4096) g_hints.clear();   // (a runaway number of distinct callers: start over)
     }
     out->num_rendered = (int64_t)R;
     out->binning = bin;
     out->binning_bytes = B.bytes;
     out->binning_capacity = (int64_t)((speculative && R <= cap) ? cap : R);
+    out->forward_flags = pack_fwd_flags(opt_ppt, opt_map, opt_ckpt);
     return GSR_OK;
 }
 
@@ -2140,6 +2201,14 @@ int gsr_backward(const GsrBackwardArgs* a, void* stream_)
     int rc = check_common(a->N, a->M, a->D, a->W, a->H);
     if (rc) return rc;
     const int N = a->N, W = a->W, H = a->H;
+    // the forward's kernel variant / tile map / checkpoint layout travel with its output (forward_flags); a caller of the
+    // round-1 ABI (flags 0) gets the process-wide options as before
+    int f_ppt = g_blend_ppt ? g_blend_ppt : 5, f_map = g_tile_map, f_ckpt = g_ckpt_first;
+    if (a->forward_flags & 1) {
+        f_ppt = (int)((a->forward_flags >> 1) & 7); f_map = (int)((a->forward_flags >> 4) & 3); f_ckpt = (int)((a->forward_flags >> 6) & 127);
+        if (f_ppt < 1 || f_ppt > 5 || f_map > 2 || f_ckpt < 1) return fail(GSR_ERR_ARG, "forward_flags do not come from gsr_forward%s");
+    }
+    (void)f_ppt;
     if (N == 0) {
         if (a->d_viewmatrix) GSR_HIP(hipMemsetAsync(a->d_viewmatrix, 0, 64, st));
         if (a->d_projmatrix) GSR_HIP(hipMemsetAsync(a->d_projmatrix, 0, 64, st));
@@ -2164,17 +2233,17 @@ int gsr_backward(const GsrBackwardArgs* a, void* stream_)
         if (ppt == 1) launch_blend_bwd<1>(W, H, tiles_x, T, ranges, list, splat, a->bg, img, a->grad_color, a->grad_depth, a->grad_alpha, gg, st);
                 else if (ppt == 2) {
             // (checkpoints are written by k_blend_fwd_w only)
-            const int split = (g_bwd_split > 1 && (g_blend_ppt == 0 || g_blend_ppt == 5)) ? g_bwd_split : 1;
-            const int tpad = 8 * slots_per_xcd(g_tile_map, T, tiles_x);
+            const int split = (g_bwd_split > 1 && f_ppt == 5) ? g_bwd_split : 1;
+            const int tpad = 8 * slots_per_xcd(f_map, T, tiles_x);
             const int grid = split * tpad;
             const float* ckpt = reinterpret_cast<const float*>(bin + B.ckpt);
             const uint32_t* staged4 = reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(a->image) + gsr_image_staged_offset(W, H));
             if (a->grad_depth || a->grad_alpha)
                 hipLaunchKernelGGL(k_blend_bwd2<true>, dim3(grid), dim3(128), 0, st, W, H, tiles_x, T, ranges, list, splat, a->bg, img,
-                                   a->grad_color, a->grad_depth, a->grad_alpha, gg, g_tile_map, ckpt, split, g_ckpt_first, staged4, tpad);
+                                   a->grad_color, a->grad_depth, a->grad_alpha, gg, f_map, ckpt, split, f_ckpt, staged4, tpad);
             else
                 hipLaunchKernelGGL(k_blend_bwd2<false>, dim3(grid), dim3(128), 0, st, W, H, tiles_x, T, ranges, list, splat, a->bg, img,
-                                   a->grad_color, a->grad_depth, a->grad_alpha, gg, g_tile_map, ckpt, split, g_ckpt_first, staged4, tpad);
+                                   a->grad_color, a->grad_depth, a->grad_alpha, gg, f_map, ckpt, split, f_ckpt, staged4, tpad);
         } else if (ppt == 3) launch_blend_bwd<2>(W, H, tiles_x, T, ranges, list, splat, a->bg, img, a->grad_color, a->grad_depth, a->grad_alpha, gg, st);
         else launch_blend_bwd<4>(W, H, tiles_x, T, ranges, list, splat, a->bg, img, a->grad_color, a->grad_depth, a->grad_alpha, gg, st);
     }
@@ -2224,6 +2293,30 @@ int gsr_backward(const GsrBackwardArgs* a, void* stream_)
                            a->d_points_transform);
     GSR_HIP(hipGetLastError());
     return GSR_OK;
+}
+
+int gsr_debug_read_binning(const void* binning, int64_t binning_capacity, int64_t num_rendered, int32_t W, int32_t H,
+                            uint32_t* ranges_out, uint32_t* list_out, void* stream_)
+{
+    if (!binning || W <= 0 || H <= 0 || num_rendered < 0) return fail(GSR_ERR_ARG, "bad debug_read_binning args%s");
+    const BinLayout B = bin_layout(binning_capacity > 0 ? binning_capacity : num_rendered, W, H);
+    const size_t T = (size_t)((W + kTile - 1) / kTile) * ((H + kTile - 1) / kTile);
+    const uint8_t* bin = static_cast<const uint8_t*>(binning);
+    hipStream_t st = (hipStream_t)stream_;
+    if (ranges_out) GSR_HIP(hipMemcpyAsync(ranges_out, bin + B.ranges, T * sizeof(uint2), hipMemcpyDeviceToDevice, st));
+    if (list_out && num_rendered > 0)
+        GSR_HIP(hipMemcpyAsync(list_out, bin + B.list, (size_t)num_rendered * 4, hipMemcpyDeviceToDevice, st));
+    return GSR_OK;
+}
+
+int64_t gsr_get_counter(const char* name)
+{
+    if (!name) return -1;
+    if (!strcmp(name, "spec_overflows")) return g_spec_overflows.load();
+    if (!strcmp(name, "spec_forwards")) return g_spec_forwards.load();
+    if (!strcmp(name, "exact_forwards")) return g_exact_forwards.load();
+    if (!strcmp(name, "spec_callers")) { std::lock_guard<std::mutex> lk(g_state_mutex); return (int64_t)g_hints.size(); }
+    return -1;
 }
 
 int gsr_mark_visible(int32_t N, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present, void* stream_)

@@ -53,6 +53,23 @@ def last_call_info():
     return {"num_rendered": _LAST["num_rendered"], "staged": staged}
 
 
+def last_binning():
+    """Debug / test hook (gsr_debug_read_binning): (ranges[T,2] int64, list[R] int64) of the most recent forward on this
+    process -- per-tile [begin, end) into the (tile, depth, id)-ordered list of Gaussian ids."""
+    lib = L.load()
+    b, W, H, R = _LAST.get("binning"), _LAST["W"], _LAST["H"], _LAST["num_rendered"]
+    if b is None:
+        raise RuntimeError("no forward has run yet")
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    ranges = torch.empty((T, 2), dtype=torch.int32, device=b.device)
+    lst = torch.empty((max(R, 1),), dtype=torch.int32, device=b.device)
+    with torch.cuda.device(b.device):
+        st = torch.cuda.current_stream(b.device).cuda_stream
+        L.check(lib.gsr_debug_read_binning(b.data_ptr(), _LAST["binning_capacity"], R, W, H, ranges.data_ptr(), lst.data_ptr(),
+                                           C.c_void_p(st)), "gsr_debug_read_binning")
+    return ranges.long() & 0xffffffff, lst[:R].long() & 0xffffffff
+
+
 def _f32c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
     """float32 + contiguous (viewmatrix / campos arrive as non-contiguous views: SURVEY Appendix B)."""
     if t is None:
@@ -148,10 +165,12 @@ class _RasterizeGaussians(torch.autograd.Function):
             L.check(lib.gsr_forward(C.byref(a), C.byref(out), C.c_void_p(stream)), "gsr_forward")
         ws.scratch.clear()  # stream-ordered reuse by the caching allocator is safe: same stream
 
-        _LAST.update(num_rendered=int(out.num_rendered), image=image, W=W, H=H)
+        _LAST.update(num_rendered=int(out.num_rendered), image=image, W=W, H=H, binning=ws.binning,
+                     binning_capacity=int(out.binning_capacity))
         ctx.raster_settings = rs
         ctx.num_rendered = int(out.num_rendered)
         ctx.binning_capacity = int(out.binning_capacity)
+        ctx.forward_flags = int(out.forward_flags)
         ctx.dims = (N, M, H, W)
         ctx.has = (sh is not None, colors_precomp is not None, scales is not None, cov3Ds_precomp is not None)
         ctx.raw = (sh_rest is not None, bool(raw_params))
@@ -220,6 +239,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         a.viewmatrix, a.projmatrix, a.campos, a.bg = _ptr(vm), _ptr(pm), _ptr(campos), _ptr(bg)
         a.geom, a.image, a.binning, a.num_rendered = geom.data_ptr(), image.data_ptr(), binning.data_ptr(), ctx.num_rendered
         a.binning_capacity = ctx.binning_capacity
+        a.forward_flags = ctx.forward_flags
         a.grad_color, a.grad_depth, a.grad_alpha = _ptr(grad_color), _ptr(grad_depth), _ptr(grad_alpha)
         a.d_means3D, a.d_means2D, a.d_opacities = _ptr(d_means3D), _ptr(d_means2D), _ptr(d_opac)
         a.d_colors_precomp, a.d_shs = _ptr(d_col), _ptr(d_sh)

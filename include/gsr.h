@@ -87,6 +87,9 @@ typedef struct GsrForwardOut {
     size_t binning_bytes;
     int64_t binning_capacity; /* instances the binning buffer was laid out for (>= R when the forward ran speculatively);
                                  pass to gsr_backward together with `binning` */
+    int64_t forward_flags;    /* what this forward fixed for its backward (blend kernel variant, tile -> XCD map, checkpoint
+                                 layout): pass to gsr_backward unchanged.  gsr_set_option calls between the two then cannot
+                                 make the backward read checkpoints the forward never wrote */
 } GsrForwardOut;
 
 /* Optimizer-in-backward: with raw_params = 1, shs (= _features_dc) + shs_rest given and this struct attached,
@@ -144,6 +147,7 @@ typedef struct GsrBackwardArgs {
     const float* points_transform;
     float* d_points_transform;
     int64_t binning_capacity; /* GsrForwardOut::binning_capacity of the forward (0 = num_rendered) */
+    int64_t forward_flags;    /* GsrForwardOut::forward_flags of the forward (0 = round-1 caller: process-wide options) */
 } GsrBackwardArgs;
 
 size_t gsr_geom_bytes(int32_t N);
@@ -178,10 +182,21 @@ int gsr_version(void);
  *                          tiles round-robin (tile t on XCD t % 8), 0 = one contiguous band of tiles per XCD
  *   "speculative_binning"  1 (default) = R-dependent stages launched against a capacity, R read back late;
  *                          0 = read R, then launch
- *   "binning_capacity_hint" capacity for the next speculative forward (tests: force the overflow re-run)
+ *   "binning_capacity_hint" capacity of the NEXT forward, one shot (tests: force the overflow re-run).  The regular hints
+ *                          are kept per caller -- (device, image size, half-octave bucket of N) -- so models of different
+ *                          size alternating on one process (teacher / student, stage-A models) do not disturb each other
+ *   "reset_speculation"    forget every capacity hint and zero the counters of gsr_get_counter
  *   "profile"              1 = HIP events around every stage on the caller's stream, 2 = around the forward blend kernel
  *                          only (an event pair costs ~10 us of stream bubble per stage) */
 int gsr_set_option(const char* name, int value);
+/* Monotonic counters: "spec_forwards" (forwards launched against a capacity), "spec_overflows" (of those, how many had to
+ * re-run the binning because R exceeded the capacity), "exact_forwards" (read-then-launch forwards), "spec_callers"
+ * (distinct (device, size, N bucket) entries).  -1 for an unknown name. */
+int64_t gsr_get_counter(const char* name);
+/* Debug / test hook: copy the per-tile ranges (T x {begin, end} uint32) and the (tile, depth, id)-ordered Gaussian-id list
+ * (num_rendered uint32) out of a forward's binning buffer into device buffers of the caller (either may be NULL). */
+int gsr_debug_read_binning(const void* binning, int64_t binning_capacity, int64_t num_rendered, int32_t W, int32_t H,
+                           uint32_t* ranges_out, uint32_t* list_out, void* stream);
 /* Sum of the recorded durations of stage `name` ("preprocess_fwd", "sort_depth", "scan", "emit", "sort_tile",
  * "ranges", "blend_fwd", "blend_bwd", "preprocess_bwd") since the last read; synchronises on the events. */
 int gsr_profile_read(const char* name, double* total_ms, int64_t* count);

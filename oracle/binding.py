@@ -59,6 +59,8 @@ def _lib(precision="f64"):
         lib.gsr_oracle_sh_eval.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.gsr_oracle_cov3d.argtypes = [C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]
         lib.gsr_oracle_set_margins.argtypes = [C.c_double] * 3
+        lib.gsr_oracle_resolve_branches.restype = C.c_int64
+        lib.gsr_oracle_resolve_branches.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 5
         _LIBS[precision] = lib
     return _LIBS[precision]
 
@@ -124,6 +126,18 @@ class OracleRender:
         self.num_rendered = int(self.lib.gsr_oracle_num_rendered(self.ctx))
         self.pairs = int(self.lib.gsr_oracle_pairs(self.ctx))
         return self.color, self.radii, self.depth, self.alpha
+
+    def resolve_branches(self, got_color, got_alpha, max_events=8):
+        """Adopt, per pixel with rounding-edge decisions, the branch closest to the implementation under test (see
+        gsr_oracle_resolve_branches).  Replaces self.color / depth / alpha by the adopted branches' outputs; a later
+        backward() differentiates the same branches.  Returns dict(events[H,W] uint8, err[H,W] float32, changed)."""
+        gc = _f32(got_color, (3, self.H, self.W))
+        ga = _f32(got_alpha, (self.H, self.W))
+        ev = np.zeros((self.H, self.W), np.uint8)
+        err = np.zeros((self.H, self.W), np.float32)
+        changed = int(self.lib.gsr_oracle_resolve_branches(self.ctx, _ptr(gc), _ptr(ga), int(max_events), _ptr(ev), _ptr(err),
+                                                           _ptr(self.color), _ptr(self.depth), _ptr(self.alpha)))
+        return dict(events=ev, err=err, changed=changed)
 
     def binning(self):
         T = ((self.W + 15) // 16) * ((self.H + 15) // 16)

@@ -103,7 +103,8 @@ typedef struct {
     real *final_T;
     uint32_t *n_contrib;
     real *acc;            /* [P,5] C0,C1,C2,D,A without background */
-    uint8_t *px_ambig;
+    uint8_t *px_ambig;    /* bit 0: a blend decision of this pixel sits on a rounding edge; bit 1: a tile-rect edge */
+    uint32_t *px_flips;   /* [P] or NULL: which of those decisions this pixel takes the OTHER way (gsr_oracle_resolve_branches) */
     int64_t pairs_evaluated;
 } Ctx;
 
@@ -195,7 +196,7 @@ void gsr_oracle_free(Ctx *c)
     if (!c) return;
     free(c->radius); free(c->rect); free(c->rect_outer); free(c->rect_inner); free(c->depth); free(c->xy); free(c->conic); free(c->rgb);
     free(c->cov3d); free(c->cov2d); free(c->clamped); free(c->g_ambig); free(c->tile_start);
-    free(c->list); free(c->final_T); free(c->n_contrib); free(c->acc); free(c->px_ambig);
+    free(c->list); free(c->final_T); free(c->n_contrib); free(c->acc); free(c->px_ambig); free(c->px_flips);
     free(c);
 }
 
@@ -379,61 +380,108 @@ static void bin_all(Ctx *c)
 
 /* Stage 3: per-pixel front-to-back compositing (3DGS paper eq. 3; fork adds depth = sum z a T and
  * alpha = sum a T).  Constants recalled from the public module: alpha = min(0.99, o*exp(power)),
- * skip alpha<1/255, skip power>0, stop before T would drop below 1e-4. */
+ * skip alpha<1/255, skip power>0, stop before T would drop below 1e-4.
+ *
+ * walk_pixel is the ONE statement of these decisions: the forward, the branch resolution and the backward all
+ * go through it.  Three of the decisions are discrete (power > 0, alpha < 1/255, T(1-alpha) < 1e-4); an
+ * implementation in binary32 can take one the other way when the quantity sits within rounding of its
+ * threshold.  Each such rounding-edge decision met on the walk is an EVENT, numbered in order; bit j of `flips`
+ * takes event j the other way.  flips = 0 is the exact-arithmetic walk. */
+typedef struct {
+    real T, C[3], D, A;
+    uint32_t last;      /* 1-based list position of the last blended instance (n_contrib) */
+    int events;         /* rounding-edge decisions met */
+    int64_t pairs;
+} PixOut;
+
+typedef struct { uint32_t g; real alpha, G, T; } Kept;   /* one blended instance: id, clamped alpha, exp(power), T before it */
+
+static void walk_pixel(const Ctx *c, int64_t s, int64_t e, int px, int py, uint32_t flips, PixOut *out, Kept *kept, int *n_kept)
+{
+    const GsrOracleIn *I = &c->in;
+    const double coord_ulp = 6e-8 * (I->W > I->H ? I->W : I->H);
+    real T = 1, C[3] = {0, 0, 0}, Dp = 0, A = 0;
+    uint32_t contributor = 0, last = 0;
+    int ev = 0, nk = 0;
+    int64_t pairs = 0;
+    double relT = 0;
+    for (int64_t k = s; k < e; k++) {
+        contributor++;
+        pairs++;
+        uint32_t g = c->list[k];
+        real dx = c->xy[2 * (size_t)g] - px, dy = c->xy[2 * (size_t)g + 1] - py;
+        const real *co = c->conic + 3 * (size_t)g;
+        real o = I->opacities[g];
+        real power = (real)-0.5 * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+        /* binary32 error model of the HIP path: the pixel-space mean carries ~ulp(max(W,H)),
+         * so power carries |grad power| * ulp plus its own rounding; alpha = o*exp(power)
+         * inherits alpha * dpower.  The running T collects the relative errors of (1-alpha). */
+        double dpow = 4.0 * ((fabs((double)(co[0] * dx + co[1] * dy)) + fabs((double)(co[2] * dy + co[1] * dx))) * coord_ulp +
+                             6e-8 * (fabs((double)(co[0] * dx * dx)) + fabs((double)(co[2] * dy * dy)) + fabs((double)(co[1] * dx * dy)) + 1.0));
+        int skip = power > 0;
+        if (power > (real)-(g_margin_power + dpow) && o >= ALPHA_MIN) {
+            if (ev < 32 && ((flips >> ev) & 1u)) skip = !skip;
+            ev++;
+        }
+        if (skip) continue;
+        real G = R_EXP(power);
+        real alpha = o * G;
+        if (alpha > ALPHA_MAX) alpha = ALPHA_MAX;
+        double dalpha = (double)alpha * dpow + g_margin_alpha;
+        skip = alpha < ALPHA_MIN;
+        if (fabs((double)(alpha - ALPHA_MIN)) < dalpha) {
+            if (ev < 32 && ((flips >> ev) & 1u)) skip = !skip;
+            ev++;
+        }
+        if (skip) continue;
+        real test_T = T * (1 - alpha);
+        relT += dalpha / (1.0 - (double)alpha) + 1.2e-7;
+        int stop = test_T < T_STOP;
+        if (fabs((double)(test_T - T_STOP)) < (double)test_T * relT + g_margin_T) {
+            if (ev < 32 && ((flips >> ev) & 1u)) stop = !stop;
+            ev++;
+        }
+        if (stop) break;
+        real w = alpha * T;
+        const real *rgb = c->rgb + 3 * (size_t)g;
+        C[0] += rgb[0] * w; C[1] += rgb[1] * w; C[2] += rgb[2] * w;
+        Dp += (real)c->depth[g] * w;
+        A += w;
+        if (kept) { kept[nk].g = g; kept[nk].alpha = alpha; kept[nk].G = G; kept[nk].T = T; }
+        nk++;
+        T = test_T;
+        last = contributor;
+    }
+    out->T = T; out->C[0] = C[0]; out->C[1] = C[1]; out->C[2] = C[2]; out->D = Dp; out->A = A;
+    out->last = last; out->events = ev; out->pairs = pairs;
+    if (n_kept) *n_kept = nk;
+}
+
+static void store_pixel(Ctx *c, size_t pid, const PixOut *o)
+{
+    c->final_T[pid] = o->T;
+    c->n_contrib[pid] = o->last;
+    real *acc = c->acc + 5 * pid;
+    acc[0] = o->C[0]; acc[1] = o->C[1]; acc[2] = o->C[2]; acc[3] = o->D; acc[4] = o->A;
+}
+
 static void blend_all(Ctx *c)
 {
     const GsrOracleIn *I = &c->in;
     const int W = I->W, H = I->H, tx = c->tiles_x;
     int64_t pairs = 0;
-    const double coord_ulp = 6e-8 * (W > H ? W : H);
 #pragma omp parallel for schedule(dynamic, 4) reduction(+ : pairs)
     for (int t = 0; t < c->tiles_x * c->tiles_y; t++) {
         int ty0 = (t / tx) * TILE, tx0 = (t % tx) * TILE;
         int64_t s = c->tile_start[t], e = c->tile_start[t + 1];
         for (int py = ty0; py < ty0 + TILE && py < H; py++)
             for (int px = tx0; px < tx0 + TILE && px < W; px++) {
-                real T = 1, C[3] = {0, 0, 0}, Dp = 0, A = 0;
-                uint32_t contributor = 0, last = 0;
-                uint8_t amb = 0;
-                double relT = 0;
-                for (int64_t k = s; k < e; k++) {
-                    contributor++;
-                    pairs++;
-                    uint32_t g = c->list[k];
-                    real dx = c->xy[2 * (size_t)g] - px, dy = c->xy[2 * (size_t)g + 1] - py;
-                    const real *co = c->conic + 3 * (size_t)g;
-                    real o = I->opacities[g];
-                    real power = (real)-0.5 * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
-                    /* binary32 error model of the HIP path: the pixel-space mean carries ~ulp(max(W,H)),
-                     * so power carries |grad power| * ulp plus its own rounding; alpha = o*exp(power)
-                     * inherits alpha * dpower.  The running T collects the relative errors of (1-alpha). */
-                    double dpow = 4.0 * ((fabs((double)(co[0] * dx + co[1] * dy)) + fabs((double)(co[2] * dy + co[1] * dx))) * coord_ulp +
-                                         6e-8 * (fabs((double)(co[0] * dx * dx)) + fabs((double)(co[2] * dy * dy)) + fabs((double)(co[1] * dx * dy)) + 1.0));
-                    if (power > (real)-(g_margin_power + dpow) && o >= ALPHA_MIN) amb = 1;
-                    if (power > 0) continue;
-                    real alpha = o * R_EXP(power);
-                    if (alpha > ALPHA_MAX) alpha = ALPHA_MAX;
-                    double dalpha = (double)alpha * dpow + g_margin_alpha;
-                    if (fabs((double)(alpha - ALPHA_MIN)) < dalpha) amb = 1;
-                    if (alpha < ALPHA_MIN) continue;
-                    real test_T = T * (1 - alpha);
-                    relT += dalpha / (1.0 - (double)alpha) + 1.2e-7;
-                    if (fabs((double)(test_T - T_STOP)) < (double)test_T * relT + g_margin_T) amb = 1;
-                    if (test_T < T_STOP) break;
-                    real w = alpha * T;
-                    const real *rgb = c->rgb + 3 * (size_t)g;
-                    C[0] += rgb[0] * w; C[1] += rgb[1] * w; C[2] += rgb[2] * w;
-                    Dp += (real)c->depth[g] * w;
-                    A += w;
-                    T = test_T;
-                    last = contributor;
-                }
+                PixOut o;
+                walk_pixel(c, s, e, px, py, 0u, &o, NULL, NULL);
+                pairs += o.pairs;
                 size_t pid = (size_t)py * W + px;
-                c->final_T[pid] = T;
-                c->n_contrib[pid] = last;
-                real *acc = c->acc + 5 * pid;
-                acc[0] = C[0]; acc[1] = C[1]; acc[2] = C[2]; acc[3] = Dp; acc[4] = A;
-                c->px_ambig[pid] = amb;
+                store_pixel(c, pid, &o);
+                c->px_ambig[pid] = o.events ? 1 : 0;
             }
     }
     c->pairs_evaluated = pairs;
@@ -454,7 +502,7 @@ static void blend_all(Ctx *c)
                         real power = (real)-0.5 * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
                         if (power > (real)1e-3) continue;
                         real alpha = o_ * R_EXP(power > 0 ? 0 : power);
-                        if (alpha >= ALPHA_MIN * (real)0.999) c->px_ambig[(size_t)y * W + x] = 1;
+                        if (alpha >= ALPHA_MIN * (real)0.999) c->px_ambig[(size_t)y * W + x] |= 2;
                     }
             }
     }
@@ -510,6 +558,71 @@ Ctx *gsr_oracle_forward(const GsrOracleIn *in, float *out_color, float *out_dept
     return c;
 }
 
+/* Branch resolution against an implementation under test.
+ * A pixel whose walk met m >= 1 rounding-edge decisions has up to 2^m legitimate outcomes (each such decision may go
+ * either way under binary32 rounding).  For every such pixel try the combinations of its first `max_events` events
+ * and ADOPT the branch whose (colour, alpha) is closest to `got`: the pixel's stored state and px_flips are replaced,
+ * so the outputs returned here AND a following gsr_oracle_backward belong to that same branch.  The caller then
+ * holds the implementation to the ordinary tolerance on these pixels too; a pixel that matches none of its branches
+ * shows up with a large out_err.  out_events[p] = m of the exact walk (saturating at 255).  Returns the number of
+ * pixels whose adopted branch is not the exact-arithmetic one. */
+int64_t gsr_oracle_resolve_branches(Ctx *c, const float *got_color, const float *got_alpha, int max_events,
+                                    uint8_t *out_events, float *out_err, float *out_color, float *out_depth, float *out_alpha)
+{
+    const GsrOracleIn *I = &c->in;
+    const int W = I->W, H = I->H, tx = c->tiles_x;
+    const size_t P = (size_t)W * H;
+    if (max_events > 12) max_events = 12;
+    if (!c->px_flips) c->px_flips = (uint32_t *)calloc(P ? P : 1, sizeof(uint32_t));
+    int64_t changed = 0;
+#pragma omp parallel for schedule(dynamic, 4) reduction(+ : changed)
+    for (int t = 0; t < c->tiles_x * c->tiles_y; t++) {
+        int ty0 = (t / tx) * TILE, tx0 = (t % tx) * TILE;
+        int64_t s = c->tile_start[t], e = c->tile_start[t + 1];
+        for (int py = ty0; py < ty0 + TILE && py < H; py++)
+            for (int px = tx0; px < tx0 + TILE && px < W; px++) {
+                size_t pid = (size_t)py * W + px;
+                PixOut best, o;
+                walk_pixel(c, s, e, px, py, 0u, &best, NULL, NULL);
+                const int m0 = best.events;
+                uint32_t best_mask = 0;
+                double best_err = 0;
+                {
+                    double err = 0;
+                    for (int k = 0; k < 3; k++) {
+                        double d = fabs((double)(best.C[k] + best.T * I->bg[k]) - (double)got_color[k * P + pid]);
+                        if (d > err) err = d;
+                    }
+                    double d = fabs((double)best.A - (double)got_alpha[pid]);
+                    best_err = d > err ? d : err;
+                }
+                if (m0 > 0) {
+                    int E = m0 < max_events ? m0 : max_events;
+                    for (uint32_t mask = 1; mask < (1u << E); mask++) {
+                        walk_pixel(c, s, e, px, py, mask, &o, NULL, NULL);
+                        if (o.events > E && o.events <= max_events) E = o.events;   /* a flipped stop reveals later events */
+                        double err = 0;
+                        for (int k = 0; k < 3; k++) {
+                            double d = fabs((double)(o.C[k] + o.T * I->bg[k]) - (double)got_color[k * P + pid]);
+                            if (d > err) err = d;
+                        }
+                        double d = fabs((double)o.A - (double)got_alpha[pid]);
+                        if (d > err) err = d;
+                        if (err < best_err) { best_err = err; best = o; best_mask = mask; }
+                    }
+                }
+                if (best_mask) { changed++; store_pixel(c, pid, &best); }
+                c->px_flips[pid] = best_mask;
+                if (out_events) out_events[pid] = (uint8_t)(m0 > 255 ? 255 : m0);
+                if (out_err) out_err[pid] = (float)best_err;
+                if (out_color) for (int k = 0; k < 3; k++) out_color[k * P + pid] = (float)(best.C[k] + best.T * I->bg[k]);
+                if (out_depth) out_depth[pid] = (float)best.D;
+                if (out_alpha) out_alpha[pid] = (float)best.A;
+            }
+    }
+    return changed;
+}
+
 int64_t gsr_oracle_num_rendered(const Ctx *c) { return c->R; }
 int64_t gsr_oracle_pairs(const Ctx *c) { return c->pairs_evaluated; }
 
@@ -557,34 +670,37 @@ void gsr_oracle_backward(const Ctx *c, const float *g_color, const float *g_dept
     double *g_z = (double *)calloc((size_t)N + 1, sizeof(double));
     double *g_op = (double *)calloc((size_t)N + 1, sizeof(double));
 
-#pragma omp parallel for schedule(dynamic, 4)
+    int64_t longest = 1;
+    for (int t = 0; t < c->tiles_x * c->tiles_y; t++)
+        if (c->tile_start[t + 1] - c->tile_start[t] > longest) longest = c->tile_start[t + 1] - c->tile_start[t];
+#pragma omp parallel
+    {
+    Kept *kept = (Kept *)malloc(sizeof(Kept) * (size_t)longest);
+#pragma omp for schedule(dynamic, 4)
     for (int t = 0; t < c->tiles_x * c->tiles_y; t++) {
         int ty0 = (t / tx) * TILE, tx0 = (t % tx) * TILE;
-        int64_t s = c->tile_start[t];
+        int64_t s = c->tile_start[t], e = c->tile_start[t + 1];
         for (int py = ty0; py < ty0 + TILE && py < H; py++)
             for (int px = tx0; px < tx0 + TILE && px < W; px++) {
                 size_t pid = (size_t)py * W + px;
                 double gC[3] = {g_color ? g_color[pid] : 0, g_color ? g_color[P + pid] : 0,
                                 g_color ? g_color[2 * P + pid] : 0};
                 double gD = g_depth ? g_depth[pid] : 0, gA = g_alpha ? g_alpha[pid] : 0;
-                const real *acc = c->acc + 5 * pid;
-                double Tf = c->final_T[pid];
+                if (gC[0] == 0 && gC[1] == 0 && gC[2] == 0 && gD == 0 && gA == 0) continue;
+                /* the same walk as the forward took for this pixel (same branch of every rounding-edge decision) */
+                PixOut po;
+                int nk = 0;
+                walk_pixel(c, s, e, px, py, c->px_flips ? c->px_flips[pid] : 0u, &po, kept, &nk);
+                double Tf = po.T;
                 double bgdot = Tf * (I->bg[0] * gC[0] + I->bg[1] * gC[1] + I->bg[2] * gC[2]);
                 /* suffix sums start as the totals and shrink as we walk front to back */
-                double sufC[3] = {acc[0], acc[1], acc[2]}, sufD = acc[3], sufA = acc[4];
-                double T = 1;
-                uint32_t n = c->n_contrib[pid];
-                for (uint32_t k = 0; k < n; k++) {
-                    uint32_t g = c->list[s + k];
+                double sufC[3] = {po.C[0], po.C[1], po.C[2]}, sufD = po.D, sufA = po.A;
+                for (int q = 0; q < nk; q++) {
+                    uint32_t g = kept[q].g;
                     double dx = (double)c->xy[2 * (size_t)g] - px, dy = (double)c->xy[2 * (size_t)g + 1] - py;
                     const real *co = c->conic + 3 * (size_t)g;
                     double o = I->opacities[g];
-                    double power = -0.5 * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
-                    if (power > 0) continue;
-                    double G = exp(power);
-                    double alpha = o * G;
-                    if (alpha > 0.99) alpha = 0.99;
-                    if (alpha < (double)ALPHA_MIN) continue;
+                    double G = kept[q].G, alpha = kept[q].alpha, T = kept[q].T;
                     double w = alpha * T;
                     const real *rgb = c->rgb + 3 * (size_t)g;
                     double z = c->depth[g];
@@ -618,9 +734,10 @@ void gsr_oracle_backward(const Ctx *c, const float *g_color, const float *g_dept
                     }
 #pragma omp atomic
                     g_z[g] += w * gD;
-                    T *= (1 - alpha);
                 }
             }
+    }
+    free(kept);
     }
 
     const float *vm = I->viewmatrix, *pm = I->projmatrix;

@@ -61,12 +61,15 @@ def test_kernel_arithmetic_on_host_vs_oracle(N, W, H, deg, posed, mode):
     kw = parity.scene_kwargs(sc, mode, bg=(0.2, 0.1, 0.3))
     o = binding.OracleRender(**kw)
     o.forward()
+    n_amb = int((o.px_ambig != 0).sum())
+    emu = parity.hostemu_run(o)
+    rep = parity.check_forward(emu["fwd"], o, "hostemu")     # adopts, per rounding-edge pixel, the branch the kernels took
+    print({k: v for k, v in rep.items() if k != "grad_mask"}, "edge pixels", n_amb)
     gc, gd, ga = parity.upstream_grads(H, W)
-    keep = o.px_ambig == 0
+    keep = rep["grad_mask"]                                   # everything but the (few) unresolved pixels
     gc *= keep[None]; gd *= keep; ga *= keep
     ref = o.backward(gc, gd, ga)
     emu = parity.hostemu_run(o, (gc, gd, ga))
-    parity.check_forward(emu["fwd"], o, "hostemu")
     got = {k: v for k, v in emu["grads"].items() if kw.get(k) is not None or k in ("means2D", "opacities", "means3D")}
     got["viewmatrix"], got["projmatrix"] = emu["grads"]["viewmatrix"], emu["grads"]["projmatrix"]
     if mode == "sh":
@@ -83,7 +86,7 @@ def test_oracle_regression_vs_committed_golden(golden_dir):
     color, radii, depth, alpha = o.forward()
     assert o.num_rendered == int(g["num_rendered"])
     assert np.array_equal(radii, g["radii"].astype(np.int32))
-    assert np.abs(color - g["color"].astype(np.float32)).max() < 2e-3      # stored as float16
+    assert np.abs(color - g["color"]).max() == 0 and np.abs(depth - g["depth"]).max() == 0      # float32 fixture, same code
     assert abs(float(color.astype(np.float64).sum()) - float(g["color_sum"])) < 1e-6 * abs(float(g["color_sum"]))
 
 

@@ -256,8 +256,8 @@ def gen_oracle(out):
         grads = o.backward(gc, gd, ga)
         np.savez_compressed(
             os.path.join(out, name + ".npz"), N=np.int32(N), W=np.int32(W), H=np.int32(H), deg=np.int32(deg),
-            posed=np.bool_(posed), seed=np.int32(5), color=color.astype(np.float16), depth=depth.astype(np.float16),
-            alpha=alpha.astype(np.float16), color_sum=np.float64(color.astype(np.float64).sum()),
+            posed=np.bool_(posed), seed=np.int32(5), color=color.astype(np.float32), depth=depth.astype(np.float32),
+            alpha=alpha.astype(np.float32), color_sum=np.float64(color.astype(np.float64).sum()),
             radii=radii.astype(np.int16), px_ambig=np.packbits(o.px_ambig), g_ambig=np.packbits(o.g_ambig),
             num_rendered=np.int64(o.num_rendered), gc_seed=np.int32(6),
             **{"g_" + k: v.astype(np.float32) for k, v in grads.items() if k in ("means3D", "means2D", "opacities", "scales", "rotations")},
@@ -269,8 +269,12 @@ def gen_oracle(out):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
+    ap.add_argument("--only-oracle", action="store_true", help="regenerate the self-generated oracle_*.npz only (no reference needed)")
     args = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
+    if args.only_oracle:
+        gen_oracle(OUT)
+        return
     captured = install_shim(args.ref)
     gen_sh(OUT)
     gen_cov3d(OUT)
