@@ -1,0 +1,90 @@
+"""Loader of the PyTorch-ROCm extension (csrc/torch_ext.cpp -> csrc/torch_build/gsr_torch.so) and the fake kernels that
+make its ops traceable (torch.compile / FakeTensor).
+
+`torch.ops.gsr.*` is the product's binding: GaussianRasterizer, the fused loss, FusedAdam and simple_knn go through
+it.  The ctypes view of the same C ABI (_lib.py) stays as the plain-FFI example of INTEGRATION.md and for the debug /
+profiling hooks; `GSR_BINDING=ctypes` routes the rasterizer through it (one GPU test does, to keep it honest).
+No fallback: a missing gsr_torch.so raises.
+"""
+import os
+
+import torch
+
+from . import _lib as L
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+EXT_PATH = os.path.join(HERE, "csrc", "torch_build", "gsr_torch.so")
+_loaded = False
+
+
+def use_ctypes() -> bool:
+    return os.environ.get("GSR_BINDING", "") == "ctypes"
+
+
+def load():
+    """torch.ops.load_library(gsr_torch.so) once; returns torch.ops.gsr."""
+    global _loaded
+    if not _loaded:
+        L.load()        # libgsr_hip.so first (fails loudly when it is not built)
+        if not os.path.exists(EXT_PATH):
+            raise RuntimeError(f"{EXT_PATH} not found: the PyTorch extension is not built (run `python __graft_entry__.py` or "
+                               "`python 3dgs_hierarchical_training_amd/build.py`).  There is no CPU fallback.")
+        torch.ops.load_library(EXT_PATH)
+        _register_fakes()
+        _loaded = True
+    return torch.ops.gsr
+
+
+def _register_fakes():
+    lib = L.load()
+
+    @torch.library.register_fake("gsr::rasterize_forward")
+    def _(means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, sh_rest, viewmatrix, projmatrix, campos, bg,
+          points_transform, image_height, image_width, tanfovx, tanfovy, scale_modifier, sh_degree, raw_params, prefiltered, debug):
+        N, H, W = means3D.shape[0], image_height, image_width
+        f = lambda *s: means3D.new_empty(s, dtype=torch.float32)
+        b = lambda n: means3D.new_empty((n,), dtype=torch.uint8)
+        ctx = torch.library.get_ctx()
+        nbin = ctx.new_dynamic_size()          # the binning buffer is R-sized: data dependent
+        return (f(3, H, W), means3D.new_empty((N,), dtype=torch.int32), f(1, H, W), f(1, H, W), b(lib.gsr_geom_bytes(int(N))),
+                b(lib.gsr_image_bytes(int(W), int(H))), b(nbin), torch.empty((3,), dtype=torch.int64))
+
+    @torch.library.register_fake("gsr::rasterize")
+    def _(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, sh_rest, viewmatrix, projmatrix, campos,
+          bg, points_transform, image_height, image_width, tanfovx, tanfovy, scale_modifier, sh_degree, raw_params, prefiltered, debug,
+          cam_grad, adam_m, adam_v, adam_lr, beta1, beta2, eps, step):
+        N, H, W = means3D.shape[0], image_height, image_width
+        f = lambda *s: means3D.new_empty(s, dtype=torch.float32)
+        return f(3, H, W), means3D.new_empty((N,), dtype=torch.int32), f(1, H, W), f(1, H, W)
+
+    @torch.library.register_fake("gsr::rasterize_backward")
+    def _(means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, sh_rest, viewmatrix, projmatrix, campos, bg,
+          points_transform, geom, image, binning, meta, grad_color, grad_depth, grad_alpha, image_height, image_width, tanfovx, tanfovy,
+          scale_modifier, sh_degree, raw_params, need_viewmatrix, need_projmatrix, need_campos, need_points_transform):
+        N = means3D.shape[0]
+        f = lambda *s: means3D.new_empty(s, dtype=torch.float32)
+        has = lambda t: t.numel() > 0
+        M = (sh.shape[1] + (sh_rest.shape[1] if has(sh_rest) else 0)) if has(sh) else 0
+        none = f(0)
+        return [f(N, 3), f(N, 3), f(N, 1 if has(sh_rest) else M, 3) if has(sh) else none, f(N, 3) if has(colors_precomp) else none,
+                f(N, 1), f(N, 3) if has(scales) else none, f(N, 4) if has(scales) else none, f(N, 6) if has(cov3D_precomp) else none,
+                f(N, M - 1, 3) if (has(sh) and has(sh_rest)) else none, f(4, 4) if need_viewmatrix else none,
+                f(4, 4) if need_projmatrix else none, f(3) if need_campos else none,
+                f(3, 4) if (need_points_transform and has(points_transform)) else none]
+
+    @torch.library.register_fake("gsr::mark_visible")
+    def _(means3D, viewmatrix, projmatrix):
+        return means3D.new_empty((means3D.shape[0],), dtype=torch.bool)
+
+    @torch.library.register_fake("gsr::photometric_loss_forward")
+    def _(render, target, lambda_dssim, clamp):
+        C, H, W = render.shape
+        return render.new_empty((3,), dtype=torch.float32), render.new_empty((lib.gsr_loss_workspace_bytes(int(C), int(H), int(W)),), dtype=torch.uint8)
+
+    @torch.library.register_fake("gsr::photometric_loss_backward")
+    def _(render, target, workspace, grad_loss, lambda_dssim, clamp):
+        return torch.empty_like(render, dtype=torch.float32)
+
+    @torch.library.register_fake("gsr::knn_mean_dist2")
+    def _(points):
+        return points.new_empty((points.shape[0],), dtype=torch.float32)

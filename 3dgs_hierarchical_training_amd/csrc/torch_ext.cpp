@@ -1,0 +1,463 @@
+// torch_ext.cpp -- the PyTorch-ROCm extension over the C ABI of include/gsr.h (libgsr_hip.so).
+//
+// north_star: "Python host code calls HIP through a PyTorch-ROCm C++/HIP extension".  This file is that extension's host
+// side: plain C++ (no kernels -- they live in *.hip behind the C ABI), built by torch.utils.cpp_extension into
+// csrc/torch_build/gsr_torch.so and loaded with torch.ops.load_library.  It stands where the public module's
+// `rasterize_points.cu / ext.cpp` pair stands (RasterizeGaussiansCUDA / RasterizeGaussiansBackwardCUDA / markVisible,
+// called from diff_gaussian_rasterization/__init__.py as at /root/reference/scene/gaussian_model_ht.py:871-880):
+//
+//   gsr::rasterize            autograd-enabled entry (C++ torch::autograd::Function): what GaussianRasterizer.forward calls
+//   gsr::rasterize_forward    -> gsr_forward   (buffers come from at::empty inside the allocator callback: no Python)
+//   gsr::rasterize_backward   -> gsr_backward
+//   gsr::rasterize_backward_fused  -> gsr_backward with the in-kernel Adam step (parameters / moments updated in place)
+//   gsr::mark_visible         -> gsr_mark_visible
+//   gsr::photometric_loss_forward / _backward -> gsr_loss_forward / gsr_loss_backward
+//   gsr::adam_step            -> gsr_adam_step
+//   gsr::knn_mean_dist2       -> gsr_knn_mean_dist2
+//
+// Registered with TORCH_LIBRARY so the ops are visible to the dispatcher (torch.ops.gsr.*, fake kernels in _ext.py for
+// torch.compile).  An empty tensor (numel 0) stands for "None".  Everything runs on the current HIP stream of the
+// inputs' device under a device guard.  No CPU kernels are registered: CPU tensors fail in the dispatcher.
+#include <ATen/hip/HIPContext.h>
+#include <c10/hip/HIPGuard.h>
+#include <c10/hip/HIPStream.h>
+#include <torch/library.h>
+#include <torch/torch.h>
+
+#include <cmath>
+#include <mutex>
+#include <vector>
+
+#include "../../include/gsr.h"
+
+namespace {
+
+using at::Tensor;
+
+inline const float* fp(const Tensor& t) { return (t.defined() && t.numel() > 0) ? t.data_ptr<float>() : nullptr; }
+inline float* fpm(Tensor& t) { return (t.defined() && t.numel() > 0) ? t.data_ptr<float>() : nullptr; }
+inline bool has(const Tensor& t) { return t.defined() && t.numel() > 0; }
+
+inline Tensor f32c(const Tensor& t)
+{
+    if (!has(t)) return t;
+    return t.to(at::kFloat).contiguous();   // no-ops when already float32 + contiguous
+}
+
+void check(int rc, const char* what)
+{
+    TORCH_CHECK(rc == 0, what, " failed (code ", rc, "): ", gsr_last_error());
+}
+
+struct AllocCtx {
+    at::TensorOptions opts;
+    Tensor binning;
+    std::vector<Tensor> scratch;
+};
+void* alloc_cb(size_t bytes, int tag, void* user)
+{
+    AllocCtx* c = static_cast<AllocCtx*>(user);
+    try {
+        Tensor t = at::empty({(int64_t)bytes}, c->opts);
+        if (tag == GSR_ALLOC_BINNING) c->binning = t;
+        else c->scratch.push_back(t);
+        return t.data_ptr();
+    } catch (...) {
+        return nullptr;   // out of memory -> GSR_ERR_ALLOC
+    }
+}
+
+// diagnostics of the most recent forward of this process (bench.py reads R / R_eff from it, the binning test the list):
+// {image workspace, binning, meta, [W, H]}
+std::mutex g_last_mutex;
+std::vector<Tensor> g_last;
+
+std::vector<Tensor> debug_last()
+{
+    std::lock_guard<std::mutex> lk(g_last_mutex);
+    return g_last;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> rasterize_forward(
+    const Tensor& means3D_, const Tensor& sh_, const Tensor& colors_, const Tensor& opacities_, const Tensor& scales_,
+    const Tensor& rotations_, const Tensor& cov3D_, const Tensor& sh_rest_, const Tensor& viewmatrix_, const Tensor& projmatrix_,
+    const Tensor& campos_, const Tensor& bg_, const Tensor& xf_, int64_t H, int64_t W, double tanfovx, double tanfovy,
+    double scale_modifier, int64_t sh_degree, bool raw_params, bool prefiltered, bool debug)
+{
+    TORCH_CHECK(means3D_.is_cuda(), "GaussianRasterizer: tensors must be on a ROCm/HIP device (no CPU fallback)");
+    const c10::hip::HIPGuard guard(means3D_.device());
+    const Tensor means3D = f32c(means3D_), sh = f32c(sh_), colors = f32c(colors_), opac = f32c(opacities_), scales = f32c(scales_),
+                 rots = f32c(rotations_), cov = f32c(cov3D_), rest = f32c(sh_rest_), vm = f32c(viewmatrix_), pm = f32c(projmatrix_),
+                 campos = f32c(campos_), bg = f32c(bg_), xf = f32c(xf_);
+    const int64_t N = means3D.size(0);
+    const int64_t M = has(sh) ? sh.size(1) + (has(rest) ? rest.size(1) : 0) : 0;
+    const auto fo = means3D.options().dtype(at::kFloat);
+    const auto bo = means3D.options().dtype(at::kByte);
+    Tensor color = at::empty({3, H, W}, fo), depth = at::empty({1, H, W}, fo), alpha = at::empty({1, H, W}, fo);
+    Tensor radii = at::empty({N}, means3D.options().dtype(at::kInt));
+    Tensor geom = at::empty({(int64_t)gsr_geom_bytes((int32_t)N)}, bo);
+    Tensor image = at::empty({(int64_t)gsr_image_bytes((int32_t)W, (int32_t)H)}, bo);
+    AllocCtx actx{bo, Tensor(), {}};
+
+    GsrForwardArgs a{};
+    a.N = (int32_t)N; a.M = (int32_t)M; a.D = (int32_t)sh_degree; a.W = (int32_t)W; a.H = (int32_t)H;
+    a.prefiltered = prefiltered; a.debug = debug;
+    a.scale_modifier = (float)scale_modifier; a.tanfovx = (float)tanfovx; a.tanfovy = (float)tanfovy;
+    a.means3D = fp(means3D); a.scales = fp(scales); a.rotations = fp(rots); a.cov3D_precomp = fp(cov);
+    a.opacities = fp(opac); a.shs = fp(sh); a.colors_precomp = fp(colors);
+    a.viewmatrix = fp(vm); a.projmatrix = fp(pm); a.campos = fp(campos); a.bg = fp(bg);
+    a.out_color = color.data_ptr<float>(); a.out_depth = depth.data_ptr<float>(); a.out_alpha = alpha.data_ptr<float>();
+    a.radii = N ? radii.data_ptr<int32_t>() : nullptr;
+    a.geom = geom.data_ptr(); a.image = image.data_ptr();
+    a.alloc = alloc_cb; a.alloc_user = &actx;
+    a.shs_rest = fp(rest); a.raw_params = raw_params;
+    a.points_transform = fp(xf);
+    GsrForwardOut out{};
+    check(gsr_forward(&a, &out, c10::hip::getCurrentHIPStream().stream()), "gsr_forward");
+    // (scratch tensors die here: stream-ordered reuse by the caching allocator is safe, same stream)
+    Tensor meta = at::empty({3}, at::TensorOptions().dtype(at::kLong));   // CPU: R, capacity, flags
+    int64_t* mp = meta.data_ptr<int64_t>();
+    mp[0] = out.num_rendered; mp[1] = out.binning_capacity; mp[2] = out.forward_flags;
+    Tensor binning = actx.binning.defined() ? actx.binning : at::empty({0}, bo);
+    {
+        Tensor dims = at::empty({2}, at::TensorOptions().dtype(at::kLong));
+        dims.data_ptr<int64_t>()[0] = W; dims.data_ptr<int64_t>()[1] = H;
+        std::lock_guard<std::mutex> lk(g_last_mutex);
+        g_last = {image, binning, meta, dims};
+    }
+    return {color, radii, depth, alpha, geom, image, binning, meta};
+}
+
+struct BwdCommon {
+    Tensor means3D, sh, colors, opac, scales, rots, cov, rest, vm, pm, campos, bg, xf, gc, gd, ga;
+};
+
+void fill_backward_args(GsrBackwardArgs& a, const BwdCommon& b, const Tensor& geom, const Tensor& image, const Tensor& binning,
+                        const Tensor& meta, int64_t H, int64_t W, double tanfovx, double tanfovy, double scale_modifier,
+                        int64_t sh_degree, bool raw_params)
+{
+    const int64_t N = b.means3D.size(0);
+    const int64_t M = has(b.sh) ? b.sh.size(1) + (has(b.rest) ? b.rest.size(1) : 0) : 0;
+    const int64_t* mp = meta.data_ptr<int64_t>();
+    a.N = (int32_t)N; a.M = (int32_t)M; a.D = (int32_t)sh_degree; a.W = (int32_t)W; a.H = (int32_t)H;
+    a.scale_modifier = (float)scale_modifier; a.tanfovx = (float)tanfovx; a.tanfovy = (float)tanfovy;
+    a.means3D = fp(b.means3D); a.scales = fp(b.scales); a.rotations = fp(b.rots); a.cov3D_precomp = fp(b.cov);
+    a.opacities = fp(b.opac); a.shs = fp(b.sh); a.colors_precomp = fp(b.colors);
+    a.viewmatrix = fp(b.vm); a.projmatrix = fp(b.pm); a.campos = fp(b.campos); a.bg = fp(b.bg);
+    a.geom = geom.data_ptr(); a.image = image.data_ptr(); a.binning = has(binning) ? binning.data_ptr() : nullptr;
+    a.num_rendered = mp[0]; a.binning_capacity = mp[1]; a.forward_flags = mp[2];
+    a.grad_color = fp(b.gc); a.grad_depth = fp(b.gd); a.grad_alpha = fp(b.ga);
+    a.shs_rest = fp(b.rest); a.raw_params = raw_params;
+    a.points_transform = fp(b.xf);
+}
+
+// returns {d_means3D, d_means2D, d_sh, d_colors, d_opac, d_scales, d_rot, d_cov, d_sh_rest, d_vm, d_pm, d_campos, d_xf}
+std::vector<Tensor> rasterize_backward(
+    const Tensor& means3D, const Tensor& sh, const Tensor& colors, const Tensor& opac, const Tensor& scales, const Tensor& rots,
+    const Tensor& cov, const Tensor& rest, const Tensor& vm, const Tensor& pm, const Tensor& campos, const Tensor& bg, const Tensor& xf,
+    const Tensor& geom, const Tensor& image, const Tensor& binning, const Tensor& meta, const Tensor& grad_color, const Tensor& grad_depth,
+    const Tensor& grad_alpha, int64_t H, int64_t W, double tanfovx, double tanfovy, double scale_modifier, int64_t sh_degree,
+    bool raw_params, bool need_vm, bool need_pm, bool need_campos, bool need_xf)
+{
+    const c10::hip::HIPGuard guard(means3D.device());
+    BwdCommon b{means3D, sh, colors, opac, scales, rots, cov, rest, vm, pm, campos, bg, xf, f32c(grad_color), f32c(grad_depth), f32c(grad_alpha)};
+    const int64_t N = means3D.size(0);
+    const int64_t M = has(sh) ? sh.size(1) + (has(rest) ? rest.size(1) : 0) : 0;
+    const auto fo = means3D.options().dtype(at::kFloat);
+    Tensor none;
+    Tensor d_means3D = at::empty({N, 3}, fo), d_means2D = at::empty({N, 3}, fo), d_opac = at::empty({N, 1}, fo);
+    Tensor d_sh = has(sh) ? at::empty({N, has(rest) ? 1 : M, 3}, fo) : none;
+    Tensor d_rest = (has(sh) && has(rest)) ? at::empty({N, M - 1, 3}, fo) : none;
+    Tensor d_col = has(colors) ? at::empty({N, 3}, fo) : none;
+    Tensor d_scales = has(scales) ? at::empty({N, 3}, fo) : none, d_rot = has(scales) ? at::empty({N, 4}, fo) : none;
+    Tensor d_cov = has(cov) ? at::empty({N, 6}, fo) : none;
+    Tensor d_vm = need_vm ? at::empty({4, 4}, fo) : none, d_pm = need_pm ? at::empty({4, 4}, fo) : none;
+    Tensor d_cp = need_campos ? at::empty({3}, fo) : none;
+    Tensor d_xf = (need_xf && has(xf)) ? at::zeros({3, 4}, fo) : none;
+    Tensor scratch = at::empty({(int64_t)gsr_backward_scratch_bytes((int32_t)N)}, means3D.options().dtype(at::kByte));
+    GsrBackwardArgs a{};
+    fill_backward_args(a, b, geom, image, binning, meta, H, W, tanfovx, tanfovy, scale_modifier, sh_degree, raw_params);
+    a.d_means3D = fpm(d_means3D); a.d_means2D = fpm(d_means2D); a.d_opacities = fpm(d_opac);
+    a.d_colors_precomp = fpm(d_col); a.d_shs = fpm(d_sh); a.d_scales = fpm(d_scales); a.d_rotations = fpm(d_rot);
+    a.d_cov3D_precomp = fpm(d_cov); a.d_shs_rest = fpm(d_rest);
+    a.d_viewmatrix = fpm(d_vm); a.d_projmatrix = fpm(d_pm); a.d_campos = fpm(d_cp); a.d_points_transform = fpm(d_xf);
+    a.scratch = scratch.data_ptr();
+    check(gsr_backward(&a, c10::hip::getCurrentHIPStream().stream()), "gsr_backward");
+    return {d_means3D, d_means2D, d_sh, d_col, d_opac, d_scales, d_rot, d_cov, d_rest, d_vm, d_pm, d_cp, d_xf};
+}
+
+// Optimizer-in-backward (GsrFusedAdam): parameters (xyz, f_dc, f_rest, opacity, scaling, rotation) and their moments are
+// updated in place; returns {d_means2D, d_vm, d_pm, d_campos, d_xf}.
+std::vector<Tensor> rasterize_backward_fused(
+    Tensor means3D, Tensor sh, Tensor rest, Tensor opac, Tensor scales, Tensor rots, const Tensor& vm, const Tensor& pm, const Tensor& campos,
+    const Tensor& bg, const Tensor& xf, const Tensor& geom, const Tensor& image, const Tensor& binning, const Tensor& meta,
+    const Tensor& grad_color, const Tensor& grad_depth, const Tensor& grad_alpha, int64_t H, int64_t W, double tanfovx, double tanfovy,
+    double scale_modifier, int64_t sh_degree, bool need_vm, bool need_pm, bool need_campos, bool need_xf, at::TensorList adam_m,
+    at::TensorList adam_v, at::ArrayRef<double> adam_lr, double beta1, double beta2, double eps, int64_t step)
+{
+    const c10::hip::HIPGuard guard(means3D.device());
+    TORCH_CHECK(adam_m.size() == 6 && adam_v.size() == 6 && adam_lr.size() == 6, "fused_adam: six groups expected");
+    Tensor none;
+    BwdCommon b{means3D, sh, none, opac, scales, rots, none, rest, vm, pm, campos, bg, xf, f32c(grad_color), f32c(grad_depth), f32c(grad_alpha)};
+    const int64_t N = means3D.size(0);
+    const auto fo = means3D.options().dtype(at::kFloat);
+    Tensor d_means2D = at::empty({N, 3}, fo);
+    Tensor d_vm = need_vm ? at::empty({4, 4}, fo) : none, d_pm = need_pm ? at::empty({4, 4}, fo) : none;
+    Tensor d_cp = need_campos ? at::empty({3}, fo) : none;
+    Tensor d_xf = (need_xf && has(xf)) ? at::zeros({3, 4}, fo) : none;
+    Tensor scratch = at::empty({(int64_t)gsr_backward_scratch_bytes((int32_t)N)}, means3D.options().dtype(at::kByte));
+    GsrFusedAdam fa{};
+    fa.beta1 = (float)beta1; fa.beta2 = (float)beta2; fa.eps = (float)eps; fa.step = step;
+    for (int q = 0; q < 6; q++) {
+        TORCH_CHECK(adam_m[q].is_contiguous() && adam_v[q].is_contiguous() && adam_m[q].scalar_type() == at::kFloat, "fused_adam: moments must be contiguous float32");
+        fa.lr[q] = (float)adam_lr[q];
+        fa.exp_avg[q] = adam_m[q].data_ptr<float>();
+        fa.exp_avg_sq[q] = adam_v[q].data_ptr<float>();
+    }
+    GsrBackwardArgs a{};
+    fill_backward_args(a, b, geom, image, binning, meta, H, W, tanfovx, tanfovy, scale_modifier, sh_degree, true);
+    a.d_means2D = fpm(d_means2D);
+    a.d_viewmatrix = fpm(d_vm); a.d_projmatrix = fpm(d_pm); a.d_campos = fpm(d_cp); a.d_points_transform = fpm(d_xf);
+    a.scratch = scratch.data_ptr();
+    a.fused_adam = &fa;
+    check(gsr_backward(&a, c10::hip::getCurrentHIPStream().stream()), "gsr_backward");
+    return {d_means2D, d_vm, d_pm, d_cp, d_xf};
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// autograd
+// inputs (16 tensors): 0 means3D 1 means2D 2 sh 3 colors 4 opacities 5 scales 6 rotations 7 cov3D 8 sh_rest
+//                      9 viewmatrix 10 projmatrix 11 campos 12 bg 13 points_transform
+struct Cfg {
+    int64_t H, W, sh_degree, adam_step;
+    double tanfovx, tanfovy, scale_modifier, beta1, beta2, eps;
+    bool raw_params, prefiltered, debug, cam_grad;
+    std::vector<double> adam_lr;
+    std::vector<Tensor> adam_m, adam_v;   // optimizer moments: plain buffers, not autograd inputs
+};
+
+class RasterizeFn : public torch::autograd::Function<RasterizeFn> {
+   public:
+    static torch::autograd::variable_list forward(torch::autograd::AutogradContext* ctx, const Tensor& means3D, const Tensor& means2D,
+                                                  const Tensor& sh, const Tensor& colors, const Tensor& opac, const Tensor& scales,
+                                                  const Tensor& rots, const Tensor& cov, const Tensor& rest, const Tensor& vm,
+                                                  const Tensor& pm, const Tensor& campos, const Tensor& bg, const Tensor& xf,
+                                                  const Cfg& cfg)
+    {
+        (void)means2D;
+        static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("gsr::rasterize_forward", "").typed<decltype(rasterize_forward)>();
+        // float32 + contiguous once, here: the SAME tensors are saved for the backward
+        const Tensor m3 = f32c(means3D), s = f32c(sh), c = f32c(colors), o = f32c(opac), sc = f32c(scales), r = f32c(rots), cv = f32c(cov),
+                     rs = f32c(rest), v = f32c(vm), p = f32c(pm), cp = f32c(campos), b = f32c(bg), x = f32c(has(xf) ? xf.slice(0, 0, 3) : xf);
+        auto out = op.call(m3, s, c, o, sc, r, cv, rs, v, p, cp, b, x, cfg.H, cfg.W, cfg.tanfovx, cfg.tanfovy, cfg.scale_modifier,
+                           cfg.sh_degree, cfg.raw_params, cfg.prefiltered, cfg.debug);
+        // NOTE: depth is deliberately NOT saved -- the caller mutates it in place (ht3dgs_trainer.py:1290-1292)
+        std::vector<Tensor> saved = {m3, s, c, o, sc, r, cv, rs, v, p, cp, b, x, std::get<4>(out), std::get<5>(out), std::get<6>(out),
+                                     std::get<7>(out)};
+        ctx->save_for_backward(saved);
+        ctx->saved_data["adam_m"] = cfg.adam_m; ctx->saved_data["adam_v"] = cfg.adam_v;
+        ctx->saved_data["H"] = cfg.H; ctx->saved_data["W"] = cfg.W; ctx->saved_data["D"] = cfg.sh_degree;
+        ctx->saved_data["tfx"] = cfg.tanfovx; ctx->saved_data["tfy"] = cfg.tanfovy; ctx->saved_data["smod"] = cfg.scale_modifier;
+        ctx->saved_data["raw"] = cfg.raw_params; ctx->saved_data["cam_grad"] = cfg.cam_grad;
+        ctx->saved_data["n_adam"] = (int64_t)cfg.adam_m.size();
+        ctx->saved_data["lr"] = cfg.adam_lr; ctx->saved_data["b1"] = cfg.beta1; ctx->saved_data["b2"] = cfg.beta2;
+        ctx->saved_data["eps"] = cfg.eps; ctx->saved_data["step"] = cfg.adam_step;
+        ctx->saved_data["xf_rows"] = has(xf) ? xf.size(0) : (int64_t)0;
+        ctx->saved_data["done"] = false;
+        ctx->mark_non_differentiable({std::get<1>(out)});
+        ctx->set_materialize_grads(false);   // unused depth / alpha outputs arrive undefined -> specialised backward
+        return {std::get<0>(out), std::get<1>(out), std::get<2>(out), std::get<3>(out)};
+    }
+
+    static torch::autograd::variable_list backward(torch::autograd::AutogradContext* ctx, torch::autograd::variable_list g)
+    {
+        auto sv = ctx->get_saved_variables();
+        const int64_t n_adam = ctx->saved_data["n_adam"].toInt();
+        const Tensor &gc = g[0], &gd = g[2], &ga = g[3];
+        torch::autograd::variable_list out(15);   // 14 tensor inputs + the Cfg argument
+        if (!gc.defined() && !gd.defined() && !ga.defined()) return out;
+        const int64_t H = ctx->saved_data["H"].toInt(), W = ctx->saved_data["W"].toInt(), D = ctx->saved_data["D"].toInt();
+        const double tfx = ctx->saved_data["tfx"].toDouble(), tfy = ctx->saved_data["tfy"].toDouble(), smod = ctx->saved_data["smod"].toDouble();
+        const bool raw = ctx->saved_data["raw"].toBool(), cam = ctx->saved_data["cam_grad"].toBool();
+        const bool need_vm = cam && ctx->needs_input_grad(9), need_pm = cam && ctx->needs_input_grad(10), need_cp = cam && ctx->needs_input_grad(11);
+        const bool need_xf = ctx->needs_input_grad(13);
+        const int64_t xf_rows = ctx->saved_data["xf_rows"].toInt();
+        Tensor e;
+        auto orE = [&](const Tensor& t) { return t.defined() ? t : e; };
+        Tensor d_xf;
+        if (n_adam) {
+            // a second backward through the same forward would apply the optimizer step twice
+            TORCH_CHECK(!ctx->saved_data["done"].toBool(), "fused_adam: backward() ran twice on the same render (retain_graph); the in-kernel "
+                                                           "Adam step can be applied once per forward");
+            ctx->saved_data["done"] = true;
+            static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("gsr::rasterize_backward_fused", "").typed<decltype(rasterize_backward_fused)>();
+            std::vector<Tensor> m = ctx->saved_data["adam_m"].toTensorVector(), v = ctx->saved_data["adam_v"].toTensorVector();
+            auto lr = ctx->saved_data["lr"].toDoubleVector();
+            auto r = op.call(sv[0], sv[1], sv[7], sv[3], sv[4], sv[5], sv[8], sv[9], sv[10], sv[11], sv[12], sv[13], sv[14], sv[15], sv[16],
+                             orE(gc), orE(gd), orE(ga), H, W, tfx, tfy, smod, D, need_vm, need_pm, need_cp, need_xf, m, v, lr,
+                             ctx->saved_data["b1"].toDouble(), ctx->saved_data["b2"].toDouble(), ctx->saved_data["eps"].toDouble(),
+                             ctx->saved_data["step"].toInt());
+            out[1] = r[0]; out[9] = r[1]; out[10] = r[2]; out[11] = r[3]; d_xf = r[4];
+        } else {
+            static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("gsr::rasterize_backward", "").typed<decltype(rasterize_backward)>();
+            auto r = op.call(sv[0], sv[1], sv[2], sv[3], sv[4], sv[5], sv[6], sv[7], sv[8], sv[9], sv[10], sv[11], sv[12], sv[13], sv[14],
+                             sv[15], sv[16], orE(gc), orE(gd), orE(ga), H, W, tfx, tfy, smod, D, raw, need_vm, need_pm, need_cp, need_xf);
+            out[0] = r[0]; out[1] = r[1]; out[2] = r[2]; out[3] = r[3]; out[4] = r[4]; out[5] = r[5]; out[6] = r[6]; out[7] = r[7]; out[8] = r[8];
+            out[9] = r[9]; out[10] = r[10]; out[11] = r[11]; d_xf = r[12];
+        }
+        if (d_xf.defined() && xf_rows == 4) d_xf = at::cat({d_xf, at::zeros({1, 4}, d_xf.options())}, 0);   // a [4,4] input keeps a zero last row
+        out[13] = d_xf;
+        return out;
+    }
+};
+
+std::tuple<Tensor, Tensor, Tensor, Tensor> rasterize(
+    const Tensor& means3D, const Tensor& means2D, const Tensor& sh, const Tensor& colors, const Tensor& opac, const Tensor& scales,
+    const Tensor& rots, const Tensor& cov, const Tensor& rest, const Tensor& vm, const Tensor& pm, const Tensor& campos, const Tensor& bg,
+    const Tensor& xf, int64_t H, int64_t W, double tanfovx, double tanfovy, double scale_modifier, int64_t sh_degree, bool raw_params,
+    bool prefiltered, bool debug, bool cam_grad, at::TensorList adam_m, at::TensorList adam_v, at::ArrayRef<double> adam_lr, double beta1,
+    double beta2, double eps, int64_t step)
+{
+    Cfg cfg{H, W, sh_degree, step, tanfovx, tanfovy, scale_modifier, beta1, beta2, eps, raw_params, prefiltered, debug, cam_grad,
+            std::vector<double>(adam_lr.begin(), adam_lr.end()), adam_m.vec(), adam_v.vec()};
+    auto r = RasterizeFn::apply(means3D, means2D, sh, colors, opac, scales, rots, cov, rest, vm, pm, campos, bg, xf, cfg);
+    return {r[0], r[1], r[2], r[3]};
+}
+
+// tensors without an autograd key (torch.inference_mode): the forward alone
+std::tuple<Tensor, Tensor, Tensor, Tensor> rasterize_forward_only(
+    const Tensor& means3D, const Tensor& means2D, const Tensor& sh, const Tensor& colors, const Tensor& opac, const Tensor& scales,
+    const Tensor& rots, const Tensor& cov, const Tensor& rest, const Tensor& vm, const Tensor& pm, const Tensor& campos, const Tensor& bg,
+    const Tensor& xf, int64_t H, int64_t W, double tanfovx, double tanfovy, double scale_modifier, int64_t sh_degree, bool raw_params,
+    bool prefiltered, bool debug, bool cam_grad, at::TensorList adam_m, at::TensorList adam_v, at::ArrayRef<double> adam_lr, double beta1,
+    double beta2, double eps, int64_t step)
+{
+    (void)means2D; (void)cam_grad; (void)adam_m; (void)adam_v; (void)adam_lr; (void)beta1; (void)beta2; (void)eps; (void)step;
+    auto out = rasterize_forward(means3D, sh, colors, opac, scales, rots, cov, rest, vm, pm, campos, bg, has(xf) ? xf.slice(0, 0, 3) : xf, H, W,
+                                 tanfovx, tanfovy, scale_modifier, sh_degree, raw_params, prefiltered, debug);
+    return {std::get<0>(out), std::get<1>(out), std::get<2>(out), std::get<3>(out)};
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+Tensor mark_visible(const Tensor& means3D_, const Tensor& vm_, const Tensor& pm_)
+{
+    TORCH_CHECK(means3D_.is_cuda(), "markVisible: tensors must be on a ROCm/HIP device (no CPU fallback)");
+    const c10::hip::HIPGuard guard(means3D_.device());
+    const Tensor p = f32c(means3D_), vm = f32c(vm_), pm = f32c(pm_);
+    Tensor present = at::empty({p.size(0)}, p.options().dtype(at::kByte));
+    check(gsr_mark_visible((int32_t)p.size(0), fp(p), fp(vm), fp(pm), p.size(0) ? present.data_ptr<uint8_t>() : nullptr,
+                           c10::hip::getCurrentHIPStream().stream()), "gsr_mark_visible");
+    return present.to(at::kBool);
+}
+
+std::tuple<Tensor, Tensor> photometric_loss_forward(const Tensor& render_, const Tensor& target_, double lambda_dssim, bool clamp)
+{
+    TORCH_CHECK(render_.is_cuda(), "fused_photometric_loss: tensors must be on a ROCm/HIP device (no CPU fallback)");
+    const c10::hip::HIPGuard guard(render_.device());
+    const Tensor render = f32c(render_), target = f32c(target_);
+    const int32_t C = (int32_t)render.size(0), H = (int32_t)render.size(1), W = (int32_t)render.size(2);
+    Tensor ws = at::empty({(int64_t)gsr_loss_workspace_bytes(C, H, W)}, render.options().dtype(at::kByte));
+    Tensor out = at::empty({3}, render.options());
+    check(gsr_loss_forward(fp(render), fp(target), C, H, W, (float)lambda_dssim, clamp, ws.data_ptr(), out.data_ptr<float>(),
+                           c10::hip::getCurrentHIPStream().stream()), "gsr_loss_forward");
+    return {out, ws};
+}
+
+Tensor photometric_loss_backward(const Tensor& render_, const Tensor& target_, const Tensor& ws, const Tensor& grad_loss_, double lambda_dssim,
+                                 bool clamp)
+{
+    const c10::hip::HIPGuard guard(render_.device());
+    const Tensor render = f32c(render_), target = f32c(target_), g = f32c(grad_loss_);
+    const int32_t C = (int32_t)render.size(0), H = (int32_t)render.size(1), W = (int32_t)render.size(2);
+    Tensor d = at::empty_like(render);
+    check(gsr_loss_backward(fp(render), fp(target), C, H, W, (float)lambda_dssim, clamp, ws.data_ptr(), fp(g), d.data_ptr<float>(),
+                            c10::hip::getCurrentHIPStream().stream()), "gsr_loss_backward");
+    return d;
+}
+
+void adam_step(at::TensorList params, at::TensorList grads, at::TensorList exp_avg, at::TensorList exp_avg_sq, at::ArrayRef<double> lr,
+               double beta1, double beta2, double eps, int64_t step)
+{
+    if (params.empty()) return;
+    TORCH_CHECK(params[0].is_cuda(), "FusedAdam: parameters must be on a ROCm/HIP device (no CPU fallback)");
+    const c10::hip::HIPGuard guard(params[0].device());
+    std::vector<Tensor> keep;
+    for (size_t lo = 0; lo < params.size(); lo += GSR_ADAM_MAX_TENSORS) {
+        GsrAdamTensor arr[GSR_ADAM_MAX_TENSORS];
+        const size_t n = std::min<size_t>(GSR_ADAM_MAX_TENSORS, params.size() - lo);
+        for (size_t k = 0; k < n; k++) {
+            const Tensor& p = params[lo + k];
+            TORCH_CHECK(p.is_contiguous() && p.scalar_type() == at::kFloat, "FusedAdam: parameters must be contiguous float32");
+            Tensor g = grads[lo + k].contiguous();
+            keep.push_back(g);
+            arr[k].param = p.data_ptr<float>(); arr[k].grad = g.data_ptr<float>();
+            arr[k].exp_avg = exp_avg[lo + k].data_ptr<float>(); arr[k].exp_avg_sq = exp_avg_sq[lo + k].data_ptr<float>();
+            arr[k].n = (uint64_t)p.numel(); arr[k].lr = (float)lr[lo + k];
+        }
+        check(gsr_adam_step(arr, (int32_t)n, (float)beta1, (float)beta2, (float)eps, step, c10::hip::getCurrentHIPStream().stream()),
+              "gsr_adam_step");
+    }
+}
+
+Tensor knn_mean_dist2(const Tensor& points_)
+{
+    TORCH_CHECK(points_.is_cuda(), "distCUDA2: points must be on a ROCm/HIP device (no CPU fallback)");
+    const c10::hip::HIPGuard guard(points_.device());
+    const Tensor p = f32c(points_);
+    const int32_t N = (int32_t)p.size(0);
+    Tensor out = at::empty({N}, p.options());
+    const size_t sb = gsr_knn_scratch_bytes(N);
+    Tensor scratch = at::empty({(int64_t)sb}, p.options().dtype(at::kByte));
+    check(gsr_knn_mean_dist2(fp(p), N, N ? out.data_ptr<float>() : nullptr, scratch.data_ptr(), sb, c10::hip::getCurrentHIPStream().stream()),
+          "gsr_knn_mean_dist2");
+    return out;
+}
+
+}  // namespace
+
+TORCH_LIBRARY(gsr, m)
+{
+    m.def("rasterize_forward(Tensor means3D, Tensor sh, Tensor colors_precomp, Tensor opacities, Tensor scales, Tensor rotations, "
+          "Tensor cov3D_precomp, Tensor sh_rest, Tensor viewmatrix, Tensor projmatrix, Tensor campos, Tensor bg, Tensor points_transform, "
+          "int image_height, int image_width, float tanfovx, float tanfovy, float scale_modifier, int sh_degree, bool raw_params, "
+          "bool prefiltered, bool debug) -> (Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)");
+    m.def("rasterize_backward(Tensor means3D, Tensor sh, Tensor colors_precomp, Tensor opacities, Tensor scales, Tensor rotations, "
+          "Tensor cov3D_precomp, Tensor sh_rest, Tensor viewmatrix, Tensor projmatrix, Tensor campos, Tensor bg, Tensor points_transform, "
+          "Tensor geom, Tensor image, Tensor binning, Tensor meta, Tensor grad_color, Tensor grad_depth, Tensor grad_alpha, "
+          "int image_height, int image_width, float tanfovx, float tanfovy, float scale_modifier, int sh_degree, bool raw_params, "
+          "bool need_viewmatrix, bool need_projmatrix, bool need_campos, bool need_points_transform) -> Tensor[]");
+    m.def("rasterize_backward_fused(Tensor(a!) means3D, Tensor(b!) sh, Tensor(c!) sh_rest, Tensor(d!) opacities, Tensor(e!) scales, "
+          "Tensor(f!) rotations, Tensor viewmatrix, Tensor projmatrix, Tensor campos, Tensor bg, Tensor points_transform, Tensor geom, "
+          "Tensor image, Tensor binning, Tensor meta, Tensor grad_color, Tensor grad_depth, Tensor grad_alpha, int image_height, "
+          "int image_width, float tanfovx, float tanfovy, float scale_modifier, int sh_degree, bool need_viewmatrix, bool need_projmatrix, "
+          "bool need_campos, bool need_points_transform, Tensor(g!)[] adam_m, Tensor(h!)[] adam_v, float[] adam_lr, float beta1, "
+          "float beta2, float eps, int step) -> Tensor[]");
+    m.def("rasterize(Tensor means3D, Tensor means2D, Tensor sh, Tensor colors_precomp, Tensor opacities, Tensor scales, Tensor rotations, "
+          "Tensor cov3D_precomp, Tensor sh_rest, Tensor viewmatrix, Tensor projmatrix, Tensor campos, Tensor bg, Tensor points_transform, "
+          "int image_height, int image_width, float tanfovx, float tanfovy, float scale_modifier, int sh_degree, bool raw_params, "
+          "bool prefiltered, bool debug, bool cam_grad, Tensor[] adam_m, Tensor[] adam_v, float[] adam_lr, float beta1, float beta2, "
+          "float eps, int step) -> (Tensor, Tensor, Tensor, Tensor)");
+    m.def("mark_visible(Tensor means3D, Tensor viewmatrix, Tensor projmatrix) -> Tensor");
+    m.def("photometric_loss_forward(Tensor render, Tensor target, float lambda_dssim, bool clamp) -> (Tensor, Tensor)");
+    m.def("photometric_loss_backward(Tensor render, Tensor target, Tensor workspace, Tensor grad_loss, float lambda_dssim, bool clamp) -> Tensor");
+    m.def("adam_step(Tensor(a!)[] params, Tensor[] grads, Tensor(b!)[] exp_avg, Tensor(c!)[] exp_avg_sq, float[] lr, float beta1, "
+          "float beta2, float eps, int step) -> ()");
+    m.def("knn_mean_dist2(Tensor points) -> Tensor");
+    m.def("debug_last() -> Tensor[]", &debug_last);
+}
+
+TORCH_LIBRARY_IMPL(gsr, CUDA, m)   // the dispatch key of HIP tensors on a ROCm build
+{
+    m.impl("rasterize_forward", &rasterize_forward);
+    m.impl("rasterize_backward", &rasterize_backward);
+    m.impl("rasterize_backward_fused", &rasterize_backward_fused);
+    m.impl("mark_visible", &mark_visible);
+    m.impl("photometric_loss_forward", &photometric_loss_forward);
+    m.impl("photometric_loss_backward", &photometric_loss_backward);
+    m.impl("adam_step", &adam_step);
+    m.impl("knn_mean_dist2", &knn_mean_dist2);
+    m.impl("rasterize", &rasterize_forward_only);
+}
+
+TORCH_LIBRARY_IMPL(gsr, Autograd, m) { m.impl("rasterize", &rasterize); }

@@ -17,11 +17,11 @@ unchanged (densification-aware state):
 Same update rule as torch (no amsgrad, no weight decay); the bias corrections use each tensor's own step count.
 No CPU path: `step()` needs the parameters on a ROCm/HIP device.
 """
-import ctypes as C
 from typing import Dict, List
 
 import torch
 
+from . import _ext as E
 from . import _lib as L
 
 
@@ -43,6 +43,7 @@ class FusedAdam:
             self.param_groups.append(g)
         self.betas, self.eps = tuple(betas), eps
         self.state = {}
+        self._stepped_in_backward = False     # set when a backward applied this optimizer's step in-kernel
 
     # ---- torch.optim protocol ------------------------------------------------------------------------------
     def zero_grad(self, set_to_none: bool = True):
@@ -116,16 +117,15 @@ class FusedAdam:
                              "exp_avg_sq": s["exp_avg_sq"].to(device=p.device, dtype=torch.float32).clone()}
 
     # ---- the two ways a step is taken ----------------------------------------------------------------------
-    def fused_backward_args(self, tensors: Dict[str, torch.Tensor]) -> "L.GsrFusedAdam":
-        """GsrFusedAdam for the optimizer-in-backward mode of gsr_backward: counts as this optimizer's next step.
-        `tensors` are the parameter tensors the rasterizer saved, by group name; they must be the optimizer's own."""
+    def fused_step_plan(self, tensors: Dict[str, torch.Tensor]):
+        """(exp_avg[6], exp_avg_sq[6], lr[6], beta1, beta2, eps, step) for the optimizer-in-backward mode of gsr_backward:
+        counts as this optimizer's next step.  `tensors` are the parameter tensors being rasterized, by group name; they
+        must be the optimizer's own."""
         by_name = {g.get("name"): g for g in self.param_groups}
         if set(by_name) != set(self.FUSED_ORDER):
             raise RuntimeError(f"fused_adam: optimizer groups must be named {self.FUSED_ORDER}, got {tuple(by_name)}")
-        fa = L.GsrFusedAdam()
-        fa.beta1, fa.beta2, fa.eps = float(self.betas[0]), float(self.betas[1]), float(self.eps)
-        states, steps = [], set()
-        for k, name in enumerate(self.FUSED_ORDER):
+        states, steps, lrs = [], set(), []
+        for name in self.FUSED_ORDER:
             g = by_name[name]
             p = g["params"][0]
             t = tensors[name]
@@ -134,24 +134,41 @@ class FusedAdam:
             st = self._state(p)
             states.append(st)
             steps.add(_step_int(st["step"]))
-            fa.lr[k] = float(g["lr"])
-            fa.exp_avg[k], fa.exp_avg_sq[k] = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+            lrs.append(float(g["lr"]))
         if len(steps) != 1:
             raise RuntimeError(f"fused_adam: the six groups are at different step counts {sorted(steps)}; use step()")
-        fa.step = steps.pop() + 1
+        step = steps.pop() + 1
         for st in states:
-            st["step"] = int(fa.step)
+            st["step"] = int(step)
+        self._stepped_in_backward = True
+        return ([st["exp_avg"] for st in states], [st["exp_avg_sq"] for st in states], lrs, float(self.betas[0]),
+                float(self.betas[1]), float(self.eps), int(step))
+
+    def fused_backward_args(self, tensors: Dict[str, torch.Tensor]) -> "L.GsrFusedAdam":
+        """The same plan as a GsrFusedAdam struct (ctypes binding)."""
+        m, v, lrs, b1, b2, eps, step = self.fused_step_plan(tensors)
+        fa = L.GsrFusedAdam()
+        fa.beta1, fa.beta2, fa.eps, fa.step = b1, b2, eps, step
+        for k in range(6):
+            fa.lr[k] = lrs[k]
+            fa.exp_avg[k], fa.exp_avg_sq[k] = m[k].data_ptr(), v[k].data_ptr()
         return fa
 
     @torch.no_grad()
     def step(self):
-        lib = L.load()
         live = [g for g in self.param_groups if g["params"][0].grad is not None]
+        stepped, self._stepped_in_backward = self._stepped_in_backward, False
         if not live:
             return
+        if stepped and any(g.get("name") in self.FUSED_ORDER for g in live):
+            # the in-kernel step of this iteration has already been applied; a .grad on the same parameters (a second loss
+            # term, a second backward) would be a second Adam update with a second step count
+            raise RuntimeError("FusedAdam.step(): this iteration's step was already applied inside backward() (fused_adam), but "
+                               "the parameters also carry a .grad -- render without fused_adam when other loss terms reach them")
         dev = live[0]["params"][0].device
         if dev.type != "cuda":
             raise RuntimeError("FusedAdam: parameters must be on a ROCm/HIP device (no CPU fallback)")
+        ops = E.load()
         by_step = {}
         for g in live:
             p = g["params"][0]
@@ -160,18 +177,7 @@ class FusedAdam:
             st = self._state(p)
             st["step"] = _step_int(st["step"]) + 1
             by_step.setdefault(st["step"], []).append((g, p, st))
-        keep = []
-        with torch.cuda.device(dev):
-            stream = torch.cuda.current_stream(dev).cuda_stream
-            for step, items in by_step.items():      # one launch; several only if tensors joined the optimizer at different times
-                for lo in range(0, len(items), 8):     # GSR_ADAM_MAX_TENSORS
-                    chunk = items[lo:lo + 8]
-                    arr = (L.GsrAdamTensor * len(chunk))()
-                    for k, (g, p, st) in enumerate(chunk):
-                        grad = p.grad.contiguous()
-                        keep.append(grad)
-                        arr[k].param, arr[k].grad = p.data_ptr(), grad.data_ptr()
-                        arr[k].exp_avg, arr[k].exp_avg_sq = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
-                        arr[k].n, arr[k].lr = p.numel(), float(g["lr"])
-                    L.check(lib.gsr_adam_step(arr, len(chunk), float(self.betas[0]), float(self.betas[1]), float(self.eps),
-                                              int(step), C.c_void_p(stream)), "gsr_adam_step")
+        for step, items in by_step.items():      # one launch; several only if tensors joined the optimizer at different times
+            ops.adam_step([p for _, p, _ in items], [p.grad for _, p, _ in items], [st["exp_avg"] for _, _, st in items],
+                          [st["exp_avg_sq"] for _, _, st in items], [float(g["lr"]) for g, _, _ in items], float(self.betas[0]),
+                          float(self.betas[1]), float(self.eps), int(step))

@@ -8,7 +8,11 @@ gaussian_model_ht.py:809-880 and returning the 4-tuple unpacked at :881-894
 
 PyTorch is plumbing only: device memory (caching allocator), the current HIP stream and autograd.  All
 arithmetic happens in the hand-written HIP kernels of csrc/gsr_kernels.hip.  There is no CPU path: tensors
-must live on a ROCm device and libgsr_hip.so must be built, otherwise a RuntimeError is raised.
+must live on a ROCm device and the libraries must be built, otherwise a RuntimeError is raised.
+
+Binding: the PyTorch-ROCm C++ extension `torch.ops.gsr.rasterize` (csrc/torch_ext.cpp: C++ autograd function, buffers
+from at::empty, no Python in the allocator path).  `GSR_BINDING=ctypes` selects the plain-FFI route over the same C ABI
+(`_RasterizeGaussians` below: the example INTEGRATION.md walks through).
 """
 import ctypes as C
 from typing import NamedTuple, Optional
@@ -16,6 +20,7 @@ from typing import NamedTuple, Optional
 import torch
 import torch.nn as nn
 
+from . import _ext as E
 from . import _lib as L
 
 
@@ -39,9 +44,21 @@ class GaussianRasterizationSettings(NamedTuple):
 _LAST = {"num_rendered": 0, "image": None, "W": 0, "H": 0}
 
 
+def _sync_last():
+    """Pull the extension's record of the most recent forward into _LAST (the ctypes route fills _LAST itself)."""
+    if E.use_ctypes() or not E._loaded:
+        return
+    rec = torch.ops.gsr.debug_last()
+    if len(rec) == 4:
+        image, binning, meta, dims = rec
+        _LAST.update(num_rendered=int(meta[0]), binning_capacity=int(meta[1]), image=image, binning=binning if binning.numel() else None,
+                     W=int(dims[0]), H=int(dims[1]))
+
+
 def last_call_info():
     """{'num_rendered': R, 'staged': R_eff} of the most recent forward on this process."""
     lib = L.load()
+    _sync_last()
     img, W, H = _LAST["image"], _LAST["W"], _LAST["H"]
     staged = 0
     if img is not None:
@@ -57,6 +74,7 @@ def last_binning():
     """Debug / test hook (gsr_debug_read_binning): (ranges[T,2] int64, list[R] int64) of the most recent forward on this
     process -- per-tile [begin, end) into the (tile, depth, id)-ordered list of Gaussian ids."""
     lib = L.load()
+    _sync_last()
     b, W, H, R = _LAST.get("binning"), _LAST["W"], _LAST["H"], _LAST["num_rendered"]
     if b is None:
         raise RuntimeError("no forward has run yet")
@@ -264,8 +282,51 @@ def _cam_inputs(rs):
     return None, None, None
 
 
+_EMPTY = {}
+
+
+def _e(dev):
+    t = _EMPTY.get(dev)
+    if t is None:
+        t = _EMPTY[dev] = torch.empty(0, dtype=torch.float32, device=dev)
+    return t
+
+
+def _rasterize_ext(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, rs, sh_rest, raw_params,
+                   fused_adam, points_transform):
+    """torch.ops.gsr.rasterize: empty tensors stand for None; the camera tensors of the settings tuple are ordinary inputs
+    (their gradients are produced when one of them requires grad)."""
+    ops = E.load()
+    dev = means3D.device
+    if dev.type != "cuda":
+        raise RuntimeError("GaussianRasterizer: tensors must be on a ROCm/HIP device (no CPU fallback)")
+    e = _e(dev)
+    pick = lambda t: e if (t is None or t.numel() == 0) else t
+    vm, pm, cp = rs.viewmatrix, rs.projmatrix, rs.campos
+    cam_grad = vm.requires_grad or pm.requires_grad or cp.requires_grad
+    if vm.device != dev:
+        vm, pm, cp = vm.to(dev), pm.to(dev), cp.to(dev)
+    bg = rs.bg if rs.bg.device == dev else rs.bg.to(dev)
+    if points_transform is not None and tuple(points_transform.shape) not in ((3, 4), (4, 4)):
+        raise RuntimeError("points_transform must be a [3,4] or [4,4] tensor")
+    xf = e if points_transform is None else points_transform.to(dev)
+    m, v, lr, b1, b2, eps, step = [], [], [], 0.0, 0.0, 0.0, 0
+    if fused_adam is not None:
+        if not (raw_params and sh_rest is not None and sh is not None and scales is not None):
+            raise RuntimeError("fused_adam needs the raw-parameter path (rasterize_gaussians_raw)")
+        m, v, lr, b1, b2, eps, step = fused_adam.fused_step_plan({"xyz": means3D, "f_dc": sh, "f_rest": sh_rest, "opacity": opacities,
+                                                                  "scaling": scales, "rotation": rotations})
+    return ops.rasterize(means3D, means2D, pick(sh), pick(colors_precomp), opacities, pick(scales), pick(rotations), pick(cov3Ds_precomp),
+                         pick(sh_rest), vm, pm, cp, bg, xf, int(rs.image_height), int(rs.image_width), float(rs.tanfovx),
+                         float(rs.tanfovy), float(rs.scale_modifier), int(rs.sh_degree), bool(raw_params), bool(rs.prefiltered),
+                         bool(rs.debug), bool(cam_grad), m, v, lr, b1, b2, eps, step)
+
+
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
                         points_transform=None):
+    if not E.use_ctypes():
+        return _rasterize_ext(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
+                              None, False, None, points_transform)
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                                      raster_settings, None, False, *_cam_inputs(raster_settings), None, points_transform)
 
@@ -284,6 +345,9 @@ def rasterize_gaussians_raw(means3D, means2D, features_dc, features_rest, opacit
     points_transform = [3,4] / [4,4] tensor M: every mean is replaced by M[:3,:3] p + M[:3,3] inside the kernels -- the
     fused form of `get_xyz` under pose fitting (`self.P[k].retr().act(xyz)`, gaussian_model_ht.py:135-148); its
     gradient comes back through autograd (see pose.py for the SE3 parametrisation)."""
+    if not E.use_ctypes():
+        return _rasterize_ext(means3D, means2D, features_dc, None, opacity_logit, log_scales, rotations_raw, None, raster_settings,
+                              features_rest, True, fused_adam, points_transform)
     e = torch.Tensor([])
     return _RasterizeGaussians.apply(means3D, means2D, features_dc, e, opacity_logit, log_scales, rotations_raw, e,
                                      raster_settings, features_rest, True, *_cam_inputs(raster_settings), fused_adam, points_transform)
@@ -298,20 +362,12 @@ class GaussianRasterizer(nn.Module):
 
     def markVisible(self, positions: torch.Tensor) -> torch.Tensor:
         """Frustum (near-plane) visibility mask; present in the module's API, unused by the reference."""
-        lib = L.load()
         rs = self.raster_settings
         with torch.no_grad():
-            p = _f32c(positions)
-            dev = p.device
+            dev = positions.device
             if dev.type != "cuda":
                 raise RuntimeError("markVisible: tensors must be on a ROCm/HIP device (no CPU fallback)")
-            vm, pm = _f32c(rs.viewmatrix.to(dev)), _f32c(rs.projmatrix.to(dev))
-            present = torch.empty((p.shape[0],), dtype=torch.uint8, device=dev)
-            with torch.cuda.device(dev):
-                stream = torch.cuda.current_stream(dev).cuda_stream
-                L.check(lib.gsr_mark_visible(p.shape[0], _ptr(p), _ptr(vm), _ptr(pm), _ptr(present), C.c_void_p(stream)),
-                        "gsr_mark_visible")
-        return present.bool()
+            return E.load().mark_visible(positions, rs.viewmatrix.to(dev), rs.projmatrix.to(dev))
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
                 cov3D_precomp=None):

@@ -178,9 +178,47 @@ def test_optimizer_in_backward_refuses_foreign_tensors():
     sc = parity.syn.make_scene(2000, 128, 96, sh_degree=3, seed=2)
     settings = ts.make_settings(sc, dev, 3)
     pa, pb = ts.GaussianParams(sc, dev, optimizer="hip"), ts.GaussianParams(sc, dev, optimizer="hip")
-    pkg = ts.render(pa, settings, clamp=False, fused_activations=True, fused_adam=pb.optimizer)   # someone else's optimizer
-    with pytest.raises(RuntimeError, match="fused_adam"):
+    with pytest.raises(RuntimeError, match="fused_adam"):      # someone else's optimizer
+        pkg = ts.render(pa, settings, clamp=False, fused_activations=True, fused_adam=pb.optimizer)
         pkg["raw_image"].sum().backward()
+    assert pb.optimizer.step_count == 0
+
+
+def test_optimizer_in_backward_guards():
+    """(a) a second backward through the same fused render must not apply the step twice; (b) step() must refuse
+    to apply a second update when the in-kernel step already ran and the parameters also carry a .grad."""
+    dev = torch.device("cuda:0")
+    sc = parity.syn.make_scene(2000, 128, 96, sh_degree=3, seed=2)
+    settings = ts.make_settings(sc, dev, 3)
+    p = ts.GaussianParams(sc, dev, optimizer="hip")
+    pkg = ts.render(p, settings, clamp=False, fused_activations=True, fused_adam=p.optimizer)
+    loss = pkg["raw_image"].sum()
+    loss.backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="ran twice"):
+        loss.backward()
+    assert p.optimizer.step_count == 1
+    p.optimizer.step()                           # nothing carries a .grad: a no-op, as in train_step
+    assert p.optimizer.step_count == 1
+    pkg = ts.render(p, settings, clamp=False, fused_activations=True, fused_adam=p.optimizer)
+    (pkg["raw_image"].sum() + 1e-3 * p._xyz.sum()).backward()        # a second loss term reaches _xyz directly
+    with pytest.raises(RuntimeError, match="already applied inside backward"):
+        p.optimizer.step()
+
+
+def test_ctypes_binding_route_matches_the_extension(monkeypatch):
+    """GSR_BINDING=ctypes: the plain-FFI route over the same C ABI (the INTEGRATION.md example) renders and differentiates
+    exactly what torch.ops.gsr.rasterize does."""
+    import hip_runner
+    sc = parity.syn.make_scene(6000, 200, 150, sh_degree=3, seed=8, posed=True)
+    kw = parity.scene_kwargs(sc, "sh", bg=(0.2, 0.1, 0.0))
+    g = parity.upstream_grads(150, 200, seed=1)
+    a = hip_runner.run_hip(kw, g, cam_grad=True)
+    monkeypatch.setenv("GSR_BINDING", "ctypes")
+    b = hip_runner.run_hip(kw, g, cam_grad=True)
+    for x, y in zip(a["fwd"], b["fwd"]):
+        assert np.array_equal(x, y)
+    for k in a["grads"]:
+        assert np.abs(a["grads"][k] - b["grads"][k]).max() <= 2e-5 * np.abs(a["grads"][k]).max() + 1e-12, k
 
 
 def test_calc_importance_matches_oracle():
