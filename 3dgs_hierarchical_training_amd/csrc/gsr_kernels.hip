@@ -885,6 +885,113 @@ __global__ __launch_bounds__(64) void k_blend_fwd_w(int W, int H, int tiles_x, i
 }
 
 // ------------------------------------------------------------------------------------------------
+// K7, wave-per-sub-tile with a wave-uniform pre-test (variants 6 / 7).  Same decomposition and the SAME decisions as
+// k_blend_fwd_w; two changes to what an iteration costs:
+//  * the staging lane also stores thr = log2((1/255) / opacity) - 4e-3: a pixel whose exponent p2 lies below thr cannot
+//    reach alpha >= 1/255 (o 2^p2 < (1/255) 2^-0.004, far outside the rounding of exp2 / the product), so when NO live lane
+//    of the wave passes p2 >= thr the iteration ends after the six instructions of the quadratic form -- no v_exp_f32 (a
+//    quarter-rate op), product, clamp or compare pair.  With ~3 px splats about half of a tile's instances miss a given
+//    8x8 sub-tile entirely.  Lanes that pass go through the exact test of the original kernel, bit for bit;
+//  * the record is split so that the skip path reads 24 B of LDS (xy + A'B', C' + thr) instead of 40 B; with DEFER the
+//    remaining 20 B (opacity, depth, rgb) are only read once some lane has passed the pre-test.
+// One wave = one workgroup, so the LDS staging area needs no double buffer (a wave's LDS operations execute in order):
+// 44 B x 64 instances = 2.8 kB per wave.
+// ------------------------------------------------------------------------------------------------
+template <bool DEFER>
+__global__ __launch_bounds__(64) void k_blend_fwd_w6(int W, int H, int tiles_x, int T, const uint2* __restrict__ ranges,
+                                                     const uint32_t* __restrict__ list, const Splat* __restrict__ splat,
+                                                     const float* __restrict__ bg, float* __restrict__ out_color,
+                                                     float* __restrict__ out_depth, float* __restrict__ out_alpha,
+                                                     float* __restrict__ img, uint32_t* __restrict__ staged4, int interleave,
+                                                     float* __restrict__ ckpt, int kCkptFirst)
+{
+    constexpr int NT = 64;
+    __shared__ float4 s_a[NT];   // px, py, A', B'
+    __shared__ float2 s_t[NT];   // C', thr
+    __shared__ float4 s_b[NT];   // opacity, depth, r, g
+    __shared__ float s_c[NT];    // b
+    const int kslot = blockIdx.x >> 3;
+    const int tile = slot_tile(interleave, (int)(blockIdx.x & 7), kslot >> 2, T, tiles_x);
+    const int sub = kslot & 3;
+    if (tile < 0) return;
+    const int lane = threadIdx.x;
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const int px = tx * kTile + (sub & 1) * 8 + (lane & 7);
+    const int py = ty * kTile + (sub >> 1) * 8 + (lane >> 3);
+    const float pxf = (float)px - 0.5f * (float)W, pyf = (float)py - 0.5f * (float)H;
+    const uint2 rg = ranges[tile];
+    const int n = (int)(rg.y - rg.x);
+    const int nb = (n + NT - 1) / NT;
+    PixelAcc acc = {1.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    uint32_t last = 0;
+    bool done = !(px < W && py < H);
+    float4 ra = {0, 0, 0, 0}, rb = ra, rc = ra;
+    constexpr float kL2E = 1.4426950408889634f;
+    auto fetch = [&](int i) {
+        const float4* sp = reinterpret_cast<const float4*>(splat + list[rg.x + i]);
+        ra = sp[0]; rb = sp[1]; rc = sp[2];
+        ra.z *= -0.5f * kL2E; ra.w *= -kL2E; rb.x *= -0.5f * kL2E;
+        // thr: below it the exact test (o 2^p2 < 1/255) is certain to reject.  opacity <= 0 never contributes (thr = +big);
+        // a NaN opacity keeps the original kernel's behaviour (never pre-rejected)
+        const float op = rb.y;
+#if defined(__HIP_DEVICE_COMPILE__)
+        rc.z = op > 0.f ? __builtin_amdgcn_logf(kAlphaMin / op) - 4e-3f : (op == op ? 3.0e38f : -3.0e38f);
+#else
+        rc.z = op > 0.f ? log2f(kAlphaMin / op) - 4e-3f : (op == op ? 3.0e38f : -3.0e38f);
+#endif
+    };
+    if (lane < n) fetch(lane);
+    int batches = 0;
+    for (int b = 0; b < nb; b++) {
+        if (__all(done)) break;
+        if (ckpt && !(b & 1) && (b >> 1) >= kCkptFirst) {   // 128-instance boundary deep in a long list: checkpoint
+            float* c = ckpt + ((size_t)(rg.x >> 7) + tile + (b >> 1) - kCkptFirst) * kCkptFloats + sub * 64 + lane;
+            c[0] = acc.T; c[256] = acc.C0; c[512] = acc.C1; c[768] = acc.C2; c[1024] = acc.D; c[1280] = acc.A;
+        }
+        s_a[lane] = ra; s_t[lane] = make_float2(rb.x, rc.z);
+        s_b[lane] = make_float4(rb.y, rb.z, rb.w, rc.x); s_c[lane] = rc.y;
+        __syncthreads();   // single-wave workgroup: orders the LDS writes before the broadcast reads
+        batches = b + 1;
+        const int nxt = (b + 1) * NT + lane;
+        if (nxt < n) fetch(nxt);
+        const int cnt = min(NT, n - b * NT);
+        for (int j = 0; j < cnt; j++) {
+            const float4 A = s_a[j];
+            const float2 Tt = s_t[j];
+            float4 B; float Cb;
+            if (!DEFER) { B = s_b[j]; Cb = s_c[j]; }
+            if (done) continue;
+            const float dx = A.x - pxf, dy = A.y - pyf;
+            const float p2 = fmaf(Tt.x * dy, dy, fmaf(A.w, dy, A.z * dx) * dx);   // log2 of the Gaussian weight
+            if (!__any(p2 >= Tt.y)) continue;     // wave-uniform: no live pixel of this sub-tile can be reached
+            if (DEFER) { B = s_b[j]; Cb = s_c[j]; }
+#if defined(__HIP_DEVICE_COMPILE__)
+            const float alpha = fminf(kAlphaMax, B.x * __builtin_amdgcn_exp2f(p2));
+#else
+            const float alpha = fminf(kAlphaMax, B.x * exp2f(p2));
+#endif
+            if (p2 > 0.f || alpha < kAlphaMin) continue;
+            if (!blend_step_fwd(acc, alpha, B.z, B.w, Cb, B.y)) { done = true; continue; }
+            last = (uint32_t)(b * NT + j + 1);
+        }
+        __syncthreads();   // the next batch overwrites the staging area
+    }
+    if (lane == 0) staged4[tile * 4 + sub] = (uint32_t)min(n, batches * NT);
+    if (px < W && py < H) {
+        const size_t P = (size_t)W * H, pid = (size_t)py * W + px;
+        img[pid] = acc.T;
+        reinterpret_cast<uint32_t*>(img)[P + pid] = last;
+        img[2 * P + pid] = acc.C0; img[3 * P + pid] = acc.C1; img[4 * P + pid] = acc.C2;
+        img[5 * P + pid] = acc.D; img[6 * P + pid] = acc.A;
+        out_color[pid] = acc.C0 + acc.T * bg[0];
+        out_color[P + pid] = acc.C1 + acc.T * bg[1];
+        out_color[2 * P + pid] = acc.C2 + acc.T * bg[2];
+        out_depth[pid] = acc.D;
+        out_alpha[pid] = acc.A;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // K7 (packed variant): two vertically adjacent pixels per lane as float2 -> v_pk_* arithmetic, branch-free
 // per-pixel skip / stop (masked alpha), only the whole-wave skip is a branch.  Same power expression as
 // k_blend_bwd2 so forward and backward agree on every skip decision bit for bit.
@@ -1851,7 +1958,7 @@ struct PinLease {   // releases the slot on every exit path
 // instead of the process-wide options as they happen to be at backward time.
 static inline int64_t pack_fwd_flags(int ppt, int tile_map, int ckpt_first)
 {
-    return 1 | ((int64_t)ppt << 1) | ((int64_t)tile_map << 4) | ((int64_t)ckpt_first << 6) | ((int64_t)(ppt == 5) << 13);
+    return 1 | ((int64_t)ppt << 1) | ((int64_t)tile_map << 4) | ((int64_t)ckpt_first << 6) | ((int64_t)(ppt >= 5) << 13);
 }
 
 static int check_common(int32_t N, int32_t M, int32_t D, int32_t W, int32_t H)
@@ -1930,7 +2037,7 @@ int gsr_set_option(const char* name, int value)
 {
     if (!name) return GSR_ERR_ARG;
     // 1 / 3 / 4 = one workgroup per tile with 1 / 2 / 4 pixels per lane (scalar), 2 = packed 2-pixel, 5 = one wave per 8x8 sub-tile
-    if (!strcmp(name, "blend_fwd_ppt")) { if (value < 0 || value > 5) return GSR_ERR_ARG; g_blend_ppt = value; return GSR_OK; }
+    if (!strcmp(name, "blend_fwd_ppt")) { if (value < 0 || value > 7) return GSR_ERR_ARG; g_blend_ppt = value; return GSR_OK; }
     if (!strcmp(name, "bwd_split")) { if (value < 0 || value > 64) return GSR_ERR_ARG; g_bwd_split = value ? value : 16; return GSR_OK; }
     if (!strcmp(name, "ckpt_first")) { if (value < 1 || value > 64) return GSR_ERR_ARG; g_ckpt_first = value; return GSR_OK; }
     if (!strcmp(name, "tile_map")) { if (value < 0 || value > 2) return GSR_ERR_ARG; g_tile_map = value; return GSR_OK; }
@@ -2046,6 +2153,12 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
                 hipLaunchKernelGGL(k_blend_fwd_w, dim3(8 * 4 * slots_per_xcd(opt_map, T, tiles_x)), dim3(64), 0, st, W, H, tiles_x, T, ranges, list, splat, a->bg,
                                    a->out_color, a->out_depth, a->out_alpha, img, staged, opt_map,
                                    reinterpret_cast<float*>(bin + B.ckpt), opt_ckpt);
+            else if (ppt == 6)
+                hipLaunchKernelGGL(k_blend_fwd_w6<false>, dim3(8 * 4 * slots_per_xcd(opt_map, T, tiles_x)), dim3(64), 0, st, W, H, tiles_x, T, ranges, list, splat, a->bg,
+                                   a->out_color, a->out_depth, a->out_alpha, img, staged, opt_map, reinterpret_cast<float*>(bin + B.ckpt), opt_ckpt);
+            else if (ppt == 7)
+                hipLaunchKernelGGL(k_blend_fwd_w6<true>, dim3(8 * 4 * slots_per_xcd(opt_map, T, tiles_x)), dim3(64), 0, st, W, H, tiles_x, T, ranges, list, splat, a->bg,
+                                   a->out_color, a->out_depth, a->out_alpha, img, staged, opt_map, reinterpret_cast<float*>(bin + B.ckpt), opt_ckpt);
             else if (ppt == 1) launch_blend_fwd<1>(W, H, tiles_x, T, ranges, list, splat, a->bg, a->out_color, a->out_depth, a->out_alpha, img, staged, st);
             else if (ppt == 2)
                 hipLaunchKernelGGL(k_blend_fwd2, dim3(8 * ((T + 7) / 8)), dim3(128), 0, st, W, H, tiles_x, T, ranges, list, splat, a->bg,
@@ -2206,7 +2319,7 @@ int gsr_backward(const GsrBackwardArgs* a, void* stream_)
     int f_ppt = g_blend_ppt ? g_blend_ppt : 5, f_map = g_tile_map, f_ckpt = g_ckpt_first;
     if (a->forward_flags & 1) {
         f_ppt = (int)((a->forward_flags >> 1) & 7); f_map = (int)((a->forward_flags >> 4) & 3); f_ckpt = (int)((a->forward_flags >> 6) & 127);
-        if (f_ppt < 1 || f_ppt > 5 || f_map > 2 || f_ckpt < 1) return fail(GSR_ERR_ARG, "forward_flags do not come from gsr_forward%s");
+        if (f_ppt < 1 || f_ppt > 7 || f_map > 2 || f_ckpt < 1) return fail(GSR_ERR_ARG, "forward_flags do not come from gsr_forward%s");
     }
     (void)f_ppt;
     if (N == 0) {
@@ -2233,7 +2346,7 @@ int gsr_backward(const GsrBackwardArgs* a, void* stream_)
         if (ppt == 1) launch_blend_bwd<1>(W, H, tiles_x, T, ranges, list, splat, a->bg, img, a->grad_color, a->grad_depth, a->grad_alpha, gg, st);
                 else if (ppt == 2) {
             // (checkpoints are written by k_blend_fwd_w only)
-            const int split = (g_bwd_split > 1 && f_ppt == 5) ? g_bwd_split : 1;
+            const int split = (g_bwd_split > 1 && f_ppt >= 5) ? g_bwd_split : 1;
             const int tpad = 8 * slots_per_xcd(f_map, T, tiles_x);
             const int grid = split * tpad;
             const float* ckpt = reinterpret_cast<const float*>(bin + B.ckpt);

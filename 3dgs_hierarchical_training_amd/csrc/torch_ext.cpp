@@ -19,8 +19,8 @@
 // torch.compile).  An empty tensor (numel 0) stands for "None".  Everything runs on the current HIP stream of the
 // inputs' device under a device guard.  No CPU kernels are registered: CPU tensors fail in the dispatcher.
 #include <ATen/hip/HIPContext.h>
-#include <c10/hip/HIPGuard.h>
-#include <c10/hip/HIPStream.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>   // a ROCm build of torch presents its HIP devices under the "cuda"
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>      // device type: these are its guard and stream accessors for them
 #include <torch/library.h>
 #include <torch/torch.h>
 
@@ -86,7 +86,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> raste
     double scale_modifier, int64_t sh_degree, bool raw_params, bool prefiltered, bool debug)
 {
     TORCH_CHECK(means3D_.is_cuda(), "GaussianRasterizer: tensors must be on a ROCm/HIP device (no CPU fallback)");
-    const c10::hip::HIPGuard guard(means3D_.device());
+    const c10::hip::HIPGuardMasqueradingAsCUDA guard(means3D_.device());
     const Tensor means3D = f32c(means3D_), sh = f32c(sh_), colors = f32c(colors_), opac = f32c(opacities_), scales = f32c(scales_),
                  rots = f32c(rotations_), cov = f32c(cov3D_), rest = f32c(sh_rest_), vm = f32c(viewmatrix_), pm = f32c(projmatrix_),
                  campos = f32c(campos_), bg = f32c(bg_), xf = f32c(xf_);
@@ -114,7 +114,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> raste
     a.shs_rest = fp(rest); a.raw_params = raw_params;
     a.points_transform = fp(xf);
     GsrForwardOut out{};
-    check(gsr_forward(&a, &out, c10::hip::getCurrentHIPStream().stream()), "gsr_forward");
+    check(gsr_forward(&a, &out, c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()), "gsr_forward");
     // (scratch tensors die here: stream-ordered reuse by the caching allocator is safe, same stream)
     Tensor meta = at::empty({3}, at::TensorOptions().dtype(at::kLong));   // CPU: R, capacity, flags
     int64_t* mp = meta.data_ptr<int64_t>();
@@ -160,7 +160,7 @@ std::vector<Tensor> rasterize_backward(
     const Tensor& grad_alpha, int64_t H, int64_t W, double tanfovx, double tanfovy, double scale_modifier, int64_t sh_degree,
     bool raw_params, bool need_vm, bool need_pm, bool need_campos, bool need_xf)
 {
-    const c10::hip::HIPGuard guard(means3D.device());
+    const c10::hip::HIPGuardMasqueradingAsCUDA guard(means3D.device());
     BwdCommon b{means3D, sh, colors, opac, scales, rots, cov, rest, vm, pm, campos, bg, xf, f32c(grad_color), f32c(grad_depth), f32c(grad_alpha)};
     const int64_t N = means3D.size(0);
     const int64_t M = has(sh) ? sh.size(1) + (has(rest) ? rest.size(1) : 0) : 0;
@@ -183,7 +183,7 @@ std::vector<Tensor> rasterize_backward(
     a.d_cov3D_precomp = fpm(d_cov); a.d_shs_rest = fpm(d_rest);
     a.d_viewmatrix = fpm(d_vm); a.d_projmatrix = fpm(d_pm); a.d_campos = fpm(d_cp); a.d_points_transform = fpm(d_xf);
     a.scratch = scratch.data_ptr();
-    check(gsr_backward(&a, c10::hip::getCurrentHIPStream().stream()), "gsr_backward");
+    check(gsr_backward(&a, c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()), "gsr_backward");
     return {d_means3D, d_means2D, d_sh, d_col, d_opac, d_scales, d_rot, d_cov, d_rest, d_vm, d_pm, d_cp, d_xf};
 }
 
@@ -196,7 +196,7 @@ std::vector<Tensor> rasterize_backward_fused(
     double scale_modifier, int64_t sh_degree, bool need_vm, bool need_pm, bool need_campos, bool need_xf, at::TensorList adam_m,
     at::TensorList adam_v, at::ArrayRef<double> adam_lr, double beta1, double beta2, double eps, int64_t step)
 {
-    const c10::hip::HIPGuard guard(means3D.device());
+    const c10::hip::HIPGuardMasqueradingAsCUDA guard(means3D.device());
     TORCH_CHECK(adam_m.size() == 6 && adam_v.size() == 6 && adam_lr.size() == 6, "fused_adam: six groups expected");
     Tensor none;
     BwdCommon b{means3D, sh, none, opac, scales, rots, none, rest, vm, pm, campos, bg, xf, f32c(grad_color), f32c(grad_depth), f32c(grad_alpha)};
@@ -221,7 +221,7 @@ std::vector<Tensor> rasterize_backward_fused(
     a.d_viewmatrix = fpm(d_vm); a.d_projmatrix = fpm(d_pm); a.d_campos = fpm(d_cp); a.d_points_transform = fpm(d_xf);
     a.scratch = scratch.data_ptr();
     a.fused_adam = &fa;
-    check(gsr_backward(&a, c10::hip::getCurrentHIPStream().stream()), "gsr_backward");
+    check(gsr_backward(&a, c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()), "gsr_backward");
     return {d_means2D, d_vm, d_pm, d_cp, d_xf};
 }
 
@@ -343,36 +343,36 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> rasterize_forward_only(
 Tensor mark_visible(const Tensor& means3D_, const Tensor& vm_, const Tensor& pm_)
 {
     TORCH_CHECK(means3D_.is_cuda(), "markVisible: tensors must be on a ROCm/HIP device (no CPU fallback)");
-    const c10::hip::HIPGuard guard(means3D_.device());
+    const c10::hip::HIPGuardMasqueradingAsCUDA guard(means3D_.device());
     const Tensor p = f32c(means3D_), vm = f32c(vm_), pm = f32c(pm_);
     Tensor present = at::empty({p.size(0)}, p.options().dtype(at::kByte));
     check(gsr_mark_visible((int32_t)p.size(0), fp(p), fp(vm), fp(pm), p.size(0) ? present.data_ptr<uint8_t>() : nullptr,
-                           c10::hip::getCurrentHIPStream().stream()), "gsr_mark_visible");
+                           c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()), "gsr_mark_visible");
     return present.to(at::kBool);
 }
 
 std::tuple<Tensor, Tensor> photometric_loss_forward(const Tensor& render_, const Tensor& target_, double lambda_dssim, bool clamp)
 {
     TORCH_CHECK(render_.is_cuda(), "fused_photometric_loss: tensors must be on a ROCm/HIP device (no CPU fallback)");
-    const c10::hip::HIPGuard guard(render_.device());
+    const c10::hip::HIPGuardMasqueradingAsCUDA guard(render_.device());
     const Tensor render = f32c(render_), target = f32c(target_);
     const int32_t C = (int32_t)render.size(0), H = (int32_t)render.size(1), W = (int32_t)render.size(2);
     Tensor ws = at::empty({(int64_t)gsr_loss_workspace_bytes(C, H, W)}, render.options().dtype(at::kByte));
     Tensor out = at::empty({3}, render.options());
     check(gsr_loss_forward(fp(render), fp(target), C, H, W, (float)lambda_dssim, clamp, ws.data_ptr(), out.data_ptr<float>(),
-                           c10::hip::getCurrentHIPStream().stream()), "gsr_loss_forward");
+                           c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()), "gsr_loss_forward");
     return {out, ws};
 }
 
 Tensor photometric_loss_backward(const Tensor& render_, const Tensor& target_, const Tensor& ws, const Tensor& grad_loss_, double lambda_dssim,
                                  bool clamp)
 {
-    const c10::hip::HIPGuard guard(render_.device());
+    const c10::hip::HIPGuardMasqueradingAsCUDA guard(render_.device());
     const Tensor render = f32c(render_), target = f32c(target_), g = f32c(grad_loss_);
     const int32_t C = (int32_t)render.size(0), H = (int32_t)render.size(1), W = (int32_t)render.size(2);
     Tensor d = at::empty_like(render);
     check(gsr_loss_backward(fp(render), fp(target), C, H, W, (float)lambda_dssim, clamp, ws.data_ptr(), fp(g), d.data_ptr<float>(),
-                            c10::hip::getCurrentHIPStream().stream()), "gsr_loss_backward");
+                            c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()), "gsr_loss_backward");
     return d;
 }
 
@@ -381,7 +381,7 @@ void adam_step(at::TensorList params, at::TensorList grads, at::TensorList exp_a
 {
     if (params.empty()) return;
     TORCH_CHECK(params[0].is_cuda(), "FusedAdam: parameters must be on a ROCm/HIP device (no CPU fallback)");
-    const c10::hip::HIPGuard guard(params[0].device());
+    const c10::hip::HIPGuardMasqueradingAsCUDA guard(params[0].device());
     std::vector<Tensor> keep;
     for (size_t lo = 0; lo < params.size(); lo += GSR_ADAM_MAX_TENSORS) {
         GsrAdamTensor arr[GSR_ADAM_MAX_TENSORS];
@@ -395,7 +395,7 @@ void adam_step(at::TensorList params, at::TensorList grads, at::TensorList exp_a
             arr[k].exp_avg = exp_avg[lo + k].data_ptr<float>(); arr[k].exp_avg_sq = exp_avg_sq[lo + k].data_ptr<float>();
             arr[k].n = (uint64_t)p.numel(); arr[k].lr = (float)lr[lo + k];
         }
-        check(gsr_adam_step(arr, (int32_t)n, (float)beta1, (float)beta2, (float)eps, step, c10::hip::getCurrentHIPStream().stream()),
+        check(gsr_adam_step(arr, (int32_t)n, (float)beta1, (float)beta2, (float)eps, step, c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()),
               "gsr_adam_step");
     }
 }
@@ -403,13 +403,13 @@ void adam_step(at::TensorList params, at::TensorList grads, at::TensorList exp_a
 Tensor knn_mean_dist2(const Tensor& points_)
 {
     TORCH_CHECK(points_.is_cuda(), "distCUDA2: points must be on a ROCm/HIP device (no CPU fallback)");
-    const c10::hip::HIPGuard guard(points_.device());
+    const c10::hip::HIPGuardMasqueradingAsCUDA guard(points_.device());
     const Tensor p = f32c(points_);
     const int32_t N = (int32_t)p.size(0);
     Tensor out = at::empty({N}, p.options());
     const size_t sb = gsr_knn_scratch_bytes(N);
     Tensor scratch = at::empty({(int64_t)sb}, p.options().dtype(at::kByte));
-    check(gsr_knn_mean_dist2(fp(p), N, N ? out.data_ptr<float>() : nullptr, scratch.data_ptr(), sb, c10::hip::getCurrentHIPStream().stream()),
+    check(gsr_knn_mean_dist2(fp(p), N, N ? out.data_ptr<float>() : nullptr, scratch.data_ptr(), sb, c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()),
           "gsr_knn_mean_dist2");
     return out;
 }

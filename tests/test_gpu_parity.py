@@ -57,20 +57,23 @@ def test_more_than_65536_tiles():
     _run_case(30000, 4112, 4112, 1, True, "sh", (0.2, 0.1, 0.0), fwd_atol=4e-5)
 
 
-# BASELINE.json configs at FULL size, straight against the oracle (it is OpenMP C: seconds on the GPU box's host)
+# BASELINE.json configs at FULL size, straight against the oracle (it is OpenMP C: seconds on the GPU box's host).
+# Last entry: bound on the share of pixels with a rounding-edge decision = the share measured on MI355X (round 2:
+# 2.33 % / 2.35 % / 4.43 % / 2.52 %) + 20 %.  Those pixels are not excused: each must match one of its branches within 1e-5
+# (parity.check_forward); the bound only says how many go through that route.
 FULL = [
-    (300000, 980, 545, 3, True, "sh", (0.0, 0.0, 0.0)),      # configs[1]: ~300k Gaussians, 980x545, SH 3
-    (1000000, 980, 545, 3, False, "sh", (0.0, 0.0, 0.0)),    # the metric's workload
-    (1000000, 1920, 1080, 3, True, "sh", (0.0, 0.0, 0.0)),   # configs[2]: 1M, 1920x1080
-    (4000000, 980, 545, 3, True, "sh", (0.0, 0.0, 0.0)),     # configs[4]: 4M Gaussians
+    (300000, 980, 545, 3, True, "sh", (0.0, 0.0, 0.0), 0.0280),      # configs[1]: ~300k Gaussians, 980x545, SH 3
+    (1000000, 980, 545, 3, False, "sh", (0.0, 0.0, 0.0), 0.0283),    # the metric's workload
+    (1000000, 1920, 1080, 3, True, "sh", (0.0, 0.0, 0.0), 0.0532),   # configs[2]: 1M, 1920x1080
+    (4000000, 980, 545, 3, True, "sh", (0.0, 0.0, 0.0), 0.0303),     # configs[4]: 4M Gaussians
 ]
 
 
 @pytest.mark.parametrize("case", FULL, ids=lambda c: f"{c[0]}-{c[1]}x{c[2]}")
 def test_parity_full_size(case):
     # thousands of (pixel, Gaussian) evaluations per pixel: the share of pixels with at least one evaluation on a
-    # rounding edge grows with the list length; every unambiguous pixel still has to be within 1e-5
-    _run_case(*case, color_only=True, ambig_max_frac=0.35)
+    # rounding edge grows with the list length; every pixel still has to be within 1e-5 of one of its branches
+    _run_case(*case[:7], color_only=True, ambig_max_frac=case[7])
 
 
 def test_full_size_properties():
