@@ -885,19 +885,16 @@ __global__ __launch_bounds__(64) void k_blend_fwd_w(int W, int H, int tiles_x, i
 }
 
 // ------------------------------------------------------------------------------------------------
-// K7, wave-per-sub-tile with a wave-uniform pre-test (variants 6 / 7).  Same decomposition and the SAME decisions as
-// k_blend_fwd_w; two changes to what an iteration costs:
-//  * the staging lane also stores thr = log2((1/255) / opacity) - 4e-3: a pixel whose exponent p2 lies below thr cannot
-//    reach alpha >= 1/255 (o 2^p2 < (1/255) 2^-0.004, far outside the rounding of exp2 / the product), so when NO live lane
-//    of the wave passes p2 >= thr the iteration ends after the six instructions of the quadratic form -- no v_exp_f32 (a
-//    quarter-rate op), product, clamp or compare pair.  With ~3 px splats about half of a tile's instances miss a given
-//    8x8 sub-tile entirely.  Lanes that pass go through the exact test of the original kernel, bit for bit;
-//  * the record is split so that the skip path reads 24 B of LDS (xy + A'B', C' + thr) instead of 40 B; with DEFER the
-//    remaining 20 B (opacity, depth, rgb) are only read once some lane has passed the pre-test.
-// One wave = one workgroup, so the LDS staging area needs no double buffer (a wave's LDS operations execute in order):
-// 44 B x 64 instances = 2.8 kB per wave.
+// K7, wave-per-sub-tile, "sign-encoded done" (variant 6).  Same decomposition, staging and arithmetic as k_blend_fwd_w;
+// what changes is how a finished pixel is represented.  There `done` is a lane mask the compiler carries in SGPR pairs:
+// every iteration opens with xor / and_saveexec / branch on it and closes by merging the lanes that just stopped back in
+// -- about sixteen scalar instructions per (wave, instance), as many as the arithmetic (41.5 M SALU next to 46 M VALU
+// wave instructions per launch in profiles/r01_pmc_blend.json).  Here a pixel that stops keeps its transmittance with
+// the SIGN FLIPPED: T < 0 means done, |T| is the final value.  A done lane then needs no control flow at all:
+// T (1 - alpha) is negative, hence below the 1e-4 stop threshold, hence the lane never blends -- the stop test that
+// exists anyway masks it.  One divergent region per iteration remains (lanes whose alpha passes), inside it the stop is
+// a select, not a branch.  Decisions and results are bit-identical with k_blend_fwd_w for every live lane.
 // ------------------------------------------------------------------------------------------------
-template <bool DEFER>
 __global__ __launch_bounds__(64) void k_blend_fwd_w6(int W, int H, int tiles_x, int T, const uint2* __restrict__ ranges,
                                                      const uint32_t* __restrict__ list, const Splat* __restrict__ splat,
                                                      const float* __restrict__ bg, float* __restrict__ out_color,
@@ -906,10 +903,8 @@ __global__ __launch_bounds__(64) void k_blend_fwd_w6(int W, int H, int tiles_x, 
                                                      float* __restrict__ ckpt, int kCkptFirst)
 {
     constexpr int NT = 64;
-    __shared__ float4 s_a[NT];   // px, py, A', B'
-    __shared__ float2 s_t[NT];   // C', thr
-    __shared__ float4 s_b[NT];   // opacity, depth, r, g
-    __shared__ float s_c[NT];    // b
+    __shared__ float4 s_a[2][NT], s_b[2][NT];
+    __shared__ float2 s_c[2][NT];
     const int kslot = blockIdx.x >> 3;
     const int tile = slot_tile(interleave, (int)(blockIdx.x & 7), kslot >> 2, T, tiles_x);
     const int sub = kslot & 3;
@@ -922,72 +917,78 @@ __global__ __launch_bounds__(64) void k_blend_fwd_w6(int W, int H, int tiles_x, 
     const uint2 rg = ranges[tile];
     const int n = (int)(rg.y - rg.x);
     const int nb = (n + NT - 1) / NT;
-    PixelAcc acc = {1.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const bool inside = px < W && py < H;
+    float Tr = inside ? 1.f : -1.f;            // running transmittance; negative = this pixel is finished
+    float C0 = 0.f, C1 = 0.f, C2 = 0.f, Dd = 0.f, Aa = 0.f;
     uint32_t last = 0;
-    bool done = !(px < W && py < H);
     float4 ra = {0, 0, 0, 0}, rb = ra, rc = ra;
     constexpr float kL2E = 1.4426950408889634f;
-    auto fetch = [&](int i) {
-        const float4* sp = reinterpret_cast<const float4*>(splat + list[rg.x + i]);
+    if (lane < n) {
+        const float4* sp = reinterpret_cast<const float4*>(splat + list[rg.x + lane]);
         ra = sp[0]; rb = sp[1]; rc = sp[2];
         ra.z *= -0.5f * kL2E; ra.w *= -kL2E; rb.x *= -0.5f * kL2E;
-        // thr: below it the exact test (o 2^p2 < 1/255) is certain to reject.  opacity <= 0 never contributes (thr = +big);
-        // a NaN opacity keeps the original kernel's behaviour (never pre-rejected)
-        const float op = rb.y;
-#if defined(__HIP_DEVICE_COMPILE__)
-        rc.z = op > 0.f ? __builtin_amdgcn_logf(kAlphaMin / op) - 4e-3f : (op == op ? 3.0e38f : -3.0e38f);
-#else
-        rc.z = op > 0.f ? log2f(kAlphaMin / op) - 4e-3f : (op == op ? 3.0e38f : -3.0e38f);
-#endif
-    };
-    if (lane < n) fetch(lane);
+    }
     int batches = 0;
     for (int b = 0; b < nb; b++) {
-        if (__all(done)) break;
+        const int buf = b & 1;
+        if (__all(Tr < 0.f)) break;
         if (ckpt && !(b & 1) && (b >> 1) >= kCkptFirst) {   // 128-instance boundary deep in a long list: checkpoint
             float* c = ckpt + ((size_t)(rg.x >> 7) + tile + (b >> 1) - kCkptFirst) * kCkptFloats + sub * 64 + lane;
-            c[0] = acc.T; c[256] = acc.C0; c[512] = acc.C1; c[768] = acc.C2; c[1024] = acc.D; c[1280] = acc.A;
+            c[0] = fabsf(Tr); c[256] = C0; c[512] = C1; c[768] = C2; c[1024] = Dd; c[1280] = Aa;
         }
-        s_a[lane] = ra; s_t[lane] = make_float2(rb.x, rc.z);
-        s_b[lane] = make_float4(rb.y, rb.z, rb.w, rc.x); s_c[lane] = rc.y;
-        __syncthreads();   // single-wave workgroup: orders the LDS writes before the broadcast reads
+        s_a[buf][lane] = ra; s_b[buf][lane] = rb; s_c[buf][lane] = make_float2(rc.x, rc.y);
+        __syncthreads();   // single-wave workgroup: just orders the LDS writes before the broadcast reads
         batches = b + 1;
         const int nxt = (b + 1) * NT + lane;
-        if (nxt < n) fetch(nxt);
-        const int cnt = min(NT, n - b * NT);
-        for (int j = 0; j < cnt; j++) {
-            const float4 A = s_a[j];
-            const float2 Tt = s_t[j];
-            float4 B; float Cb;
-            if (!DEFER) { B = s_b[j]; Cb = s_c[j]; }
-            if (done) continue;
-            const float dx = A.x - pxf, dy = A.y - pyf;
-            const float p2 = fmaf(Tt.x * dy, dy, fmaf(A.w, dy, A.z * dx) * dx);   // log2 of the Gaussian weight
-            if (!__any(p2 >= Tt.y)) continue;     // wave-uniform: no live pixel of this sub-tile can be reached
-            if (DEFER) { B = s_b[j]; Cb = s_c[j]; }
-#if defined(__HIP_DEVICE_COMPILE__)
-            const float alpha = fminf(kAlphaMax, B.x * __builtin_amdgcn_exp2f(p2));
-#else
-            const float alpha = fminf(kAlphaMax, B.x * exp2f(p2));
-#endif
-            if (p2 > 0.f || alpha < kAlphaMin) continue;
-            if (!blend_step_fwd(acc, alpha, B.z, B.w, Cb, B.y)) { done = true; continue; }
-            last = (uint32_t)(b * NT + j + 1);
+        if (nxt < n) {
+            const float4* sp = reinterpret_cast<const float4*>(splat + list[rg.x + nxt]);
+            ra = sp[0]; rb = sp[1]; rc = sp[2];
+            ra.z *= -0.5f * kL2E; ra.w *= -kL2E; rb.x *= -0.5f * kL2E;
         }
-        __syncthreads();   // the next batch overwrites the staging area
+        const int cnt = min(NT, n - b * NT);
+        auto alpha_of = [&](int j, float& p2) {
+            const float4 A = s_a[buf][j];
+            const float2 Bq = *reinterpret_cast<const float2*>(&s_b[buf][j]);   // C', opacity
+            const float dx = A.x - pxf, dy = A.y - pyf;
+            p2 = fmaf(Bq.x * dy, dy, fmaf(A.w, dy, A.z * dx) * dx);   // log2 of the Gaussian weight
+#if defined(__HIP_DEVICE_COMPILE__)
+            return fminf(kAlphaMax, Bq.y * __builtin_amdgcn_exp2f(p2));
+#else
+            return fminf(kAlphaMax, Bq.y * exp2f(p2));
+#endif
+        };
+        auto blend = [&](int j, float p2, float alpha) {
+            if (p2 > 0.f || alpha < kAlphaMin) return;
+            const float4 B = s_b[buf][j];
+            const float2 C = s_c[buf][j];
+            const float test_T = Tr * (1.f - alpha);          // negative for a finished pixel: fails the stop test below
+            const bool pass = !(test_T < kTStop);
+            const float w = pass ? alpha * Tr : 0.f;
+            C0 = fmaf(B.w, w, C0); C1 = fmaf(C.x, w, C1); C2 = fmaf(C.y, w, C2);
+            Dd = fmaf(B.z, w, Dd); Aa += w;
+            Tr = pass ? test_T : -fabsf(Tr);                  // first failure flips the sign: done, |T| kept
+            last = pass ? (uint32_t)(b * NT + j + 1) : last;
+        };
+        // (evaluating two instances' alpha before either blend -- two v_exp_f32 in flight -- measured the same: 118 us)
+        for (int j = 0; j < cnt; j++) {
+            float p2;
+            const float a1 = alpha_of(j, p2);
+            blend(j, p2, a1);
+        }
     }
     if (lane == 0) staged4[tile * 4 + sub] = (uint32_t)min(n, batches * NT);
-    if (px < W && py < H) {
+    if (inside) {
         const size_t P = (size_t)W * H, pid = (size_t)py * W + px;
-        img[pid] = acc.T;
+        const float Tf = fabsf(Tr);
+        img[pid] = Tf;
         reinterpret_cast<uint32_t*>(img)[P + pid] = last;
-        img[2 * P + pid] = acc.C0; img[3 * P + pid] = acc.C1; img[4 * P + pid] = acc.C2;
-        img[5 * P + pid] = acc.D; img[6 * P + pid] = acc.A;
-        out_color[pid] = acc.C0 + acc.T * bg[0];
-        out_color[P + pid] = acc.C1 + acc.T * bg[1];
-        out_color[2 * P + pid] = acc.C2 + acc.T * bg[2];
-        out_depth[pid] = acc.D;
-        out_alpha[pid] = acc.A;
+        img[2 * P + pid] = C0; img[3 * P + pid] = C1; img[4 * P + pid] = C2;
+        img[5 * P + pid] = Dd; img[6 * P + pid] = Aa;
+        out_color[pid] = C0 + Tf * bg[0];
+        out_color[P + pid] = C1 + Tf * bg[1];
+        out_color[2 * P + pid] = C2 + Tf * bg[2];
+        out_depth[pid] = Dd;
+        out_alpha[pid] = Aa;
     }
 }
 
@@ -2037,7 +2038,7 @@ int gsr_set_option(const char* name, int value)
 {
     if (!name) return GSR_ERR_ARG;
     // 1 / 3 / 4 = one workgroup per tile with 1 / 2 / 4 pixels per lane (scalar), 2 = packed 2-pixel, 5 = one wave per 8x8 sub-tile
-    if (!strcmp(name, "blend_fwd_ppt")) { if (value < 0 || value > 7) return GSR_ERR_ARG; g_blend_ppt = value; return GSR_OK; }
+    if (!strcmp(name, "blend_fwd_ppt")) { if (value < 0 || value > 6) return GSR_ERR_ARG; g_blend_ppt = value; return GSR_OK; }
     if (!strcmp(name, "bwd_split")) { if (value < 0 || value > 64) return GSR_ERR_ARG; g_bwd_split = value ? value : 16; return GSR_OK; }
     if (!strcmp(name, "ckpt_first")) { if (value < 1 || value > 64) return GSR_ERR_ARG; g_ckpt_first = value; return GSR_OK; }
     if (!strcmp(name, "tile_map")) { if (value < 0 || value > 2) return GSR_ERR_ARG; g_tile_map = value; return GSR_OK; }
@@ -2070,7 +2071,7 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
         return fail(GSR_ERR_ARG, "missing output / workspace pointer%s");
     const int N = a->N, W = a->W, H = a->H;
     // the process-wide options as they are NOW: one forward uses one consistent set and hands it to its backward
-    const int opt_ppt = g_blend_ppt ? g_blend_ppt : 5, opt_map = g_tile_map, opt_ckpt = g_ckpt_first;
+    const int opt_ppt = g_blend_ppt ? g_blend_ppt : 6, opt_map = g_tile_map, opt_ckpt = g_ckpt_first;
     const int tiles_x = (W + kTile - 1) / kTile, tiles_y = (H + kTile - 1) / kTile, T = tiles_x * tiles_y;
     out->num_rendered = 0; out->binning = nullptr; out->binning_bytes = 0; out->binning_capacity = 0;
     out->forward_flags = pack_fwd_flags(opt_ppt, opt_map, opt_ckpt);
@@ -2145,7 +2146,7 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
         return wide_keys ? launch_binning_t(uint32_t{}, capacity, n_dev, prezeroed) : launch_binning_t(uint16_t{}, capacity, n_dev, prezeroed);
     };
     auto launch_blend = [&](bool prezeroed) -> int {
-        const int ppt = opt_ppt;   // default 5: one wave per 8x8 sub-tile
+        const int ppt = opt_ppt;   // default 6: one wave per 8x8 sub-tile, sign-encoded done (5 = the same with a lane mask)
         if (!prezeroed) GSR_HIP(hipMemsetAsync(staged, 0, (size_t)T * 16, st));
         {
             ProfScope ps(P_BLEND_FWD, st);
@@ -2154,10 +2155,7 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
                                    a->out_color, a->out_depth, a->out_alpha, img, staged, opt_map,
                                    reinterpret_cast<float*>(bin + B.ckpt), opt_ckpt);
             else if (ppt == 6)
-                hipLaunchKernelGGL(k_blend_fwd_w6<false>, dim3(8 * 4 * slots_per_xcd(opt_map, T, tiles_x)), dim3(64), 0, st, W, H, tiles_x, T, ranges, list, splat, a->bg,
-                                   a->out_color, a->out_depth, a->out_alpha, img, staged, opt_map, reinterpret_cast<float*>(bin + B.ckpt), opt_ckpt);
-            else if (ppt == 7)
-                hipLaunchKernelGGL(k_blend_fwd_w6<true>, dim3(8 * 4 * slots_per_xcd(opt_map, T, tiles_x)), dim3(64), 0, st, W, H, tiles_x, T, ranges, list, splat, a->bg,
+                hipLaunchKernelGGL(k_blend_fwd_w6, dim3(8 * 4 * slots_per_xcd(opt_map, T, tiles_x)), dim3(64), 0, st, W, H, tiles_x, T, ranges, list, splat, a->bg,
                                    a->out_color, a->out_depth, a->out_alpha, img, staged, opt_map, reinterpret_cast<float*>(bin + B.ckpt), opt_ckpt);
             else if (ppt == 1) launch_blend_fwd<1>(W, H, tiles_x, T, ranges, list, splat, a->bg, a->out_color, a->out_depth, a->out_alpha, img, staged, st);
             else if (ppt == 2)
@@ -2316,10 +2314,10 @@ int gsr_backward(const GsrBackwardArgs* a, void* stream_)
     const int N = a->N, W = a->W, H = a->H;
     // the forward's kernel variant / tile map / checkpoint layout travel with its output (forward_flags); a caller of the
     // round-1 ABI (flags 0) gets the process-wide options as before
-    int f_ppt = g_blend_ppt ? g_blend_ppt : 5, f_map = g_tile_map, f_ckpt = g_ckpt_first;
+    int f_ppt = g_blend_ppt ? g_blend_ppt : 6, f_map = g_tile_map, f_ckpt = g_ckpt_first;
     if (a->forward_flags & 1) {
         f_ppt = (int)((a->forward_flags >> 1) & 7); f_map = (int)((a->forward_flags >> 4) & 3); f_ckpt = (int)((a->forward_flags >> 6) & 127);
-        if (f_ppt < 1 || f_ppt > 7 || f_map > 2 || f_ckpt < 1) return fail(GSR_ERR_ARG, "forward_flags do not come from gsr_forward%s");
+        if (f_ppt < 1 || f_ppt > 6 || f_map > 2 || f_ckpt < 1) return fail(GSR_ERR_ARG, "forward_flags do not come from gsr_forward%s");
     }
     (void)f_ppt;
     if (N == 0) {

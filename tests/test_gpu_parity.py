@@ -112,7 +112,7 @@ def test_parity_color_loss_only(case):
     _run_case(*case, color_only=True)
 
 
-@pytest.mark.parametrize("ppt", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("ppt", [1, 2, 3, 4, 5, 6])
 def test_blend_variants_agree(ppt):
     import importlib
     L = importlib.import_module("3dgs_hierarchical_training_amd._lib")
@@ -678,3 +678,23 @@ def test_models_of_different_size_alternate_without_overflow_reruns():
     torch.cuda.synchronize()
     assert lib.gsr_get_counter(b"spec_forwards") == 20
     assert lib.gsr_get_counter(b"spec_overflows") == 0
+
+
+def test_sign_encoded_forward_is_bit_identical_with_the_lane_mask_kernel():
+    """k_blend_fwd_w6 (default) represents a finished pixel by the sign of its transmittance instead of a lane mask;
+    every decision and every accumulation of a live pixel is the same instruction sequence, so the images are EQUAL."""
+    import importlib
+    import hip_runner
+    L = importlib.import_module("3dgs_hierarchical_training_amd._lib")
+    lib = L.load()
+    sc = parity.syn.make_scene(300000, 980, 545, sh_degree=3, seed=5, posed=True)
+    kw = parity.scene_kwargs(sc, "sh", bg=(0.3, 0.2, 0.1))
+    outs = {}
+    try:
+        for v in (5, 6):
+            assert lib.gsr_set_option(b"blend_fwd_ppt", v) == 0
+            outs[v] = hip_runner.run_hip(kw)["fwd"]
+    finally:
+        lib.gsr_set_option(b"blend_fwd_ppt", 0)
+    for a, b in zip(outs[5], outs[6]):
+        assert np.array_equal(a, b)
