@@ -3,7 +3,7 @@
 // Pipeline (DESIGN.md has the byte accounting):
 //   forward   K1 k_preprocess      per Gaussian: cull, project, cov2D, conic, radius, SH colour -> 48-B Splat
 //             K2 radix sort        32-bit depth keys over N (4 passes)           -> depth order
-//             K3 k_tile_counts / k_block_scan  tiles-touched in depth order -> offsets, R (one D2H read)
+//             K3 k_tile_counts / k_block_scan  tiles-touched in depth order -> offsets, R (written to pinned host memory)
 //             K4 k_emit            cooperative, coalesced emission of (tile u16, gid u32) in depth order
 //             K5 radix sort        16-bit tile keys over R (<=2 passes, stable) -> (tile, depth, id) order
 //             K6 k_tile_ranges     per-tile [start,end)
@@ -469,6 +469,53 @@ __device__ __forceinline__ uint32_t block_inclusive_scan_256(uint32_t v, uint32_
     return x + add;
 }
 
+// small clears that ride in k_block_scan (4-byte words; see gsr_forward)
+struct ZeroJobs {
+    void* p[3];
+    uint32_t words[3];
+};
+
+// one workgroup of NTHR threads: exclusive scan of block_sums[nb] in place; total (64-bit) -> *total_out and, when
+// host_out is given, into pinned host memory (device-visible): the count reaches the host without a copy launch
+template <int NTHR>
+__device__ __forceinline__ void block_scan_body(uint32_t* block_sums, int nb, unsigned long long* total_out, const ZeroJobs& zj,
+                                                unsigned long long* host_out, unsigned long long* s_wsum /*[NTHR/64]*/)
+{
+    constexpr int NWV = NTHR / 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        uint32_t* z = static_cast<uint32_t*>(zj.p[j]);
+        for (uint32_t q = tid; q < zj.words[j]; q += NTHR) z[q] = 0u;
+    }
+    const int chunk = (nb + NTHR - 1) / NTHR;
+    const int lo = min(nb, tid * chunk), hi = min(nb, lo + chunk);
+    unsigned long long sum = 0;
+    for (int b = lo; b < hi; b++) sum += block_sums[b];
+    // inclusive scan over the NTHR partial sums: wave shuffles, then the wave totals (one barrier)
+    unsigned long long inc = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned long long y = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += y;
+    }
+    if (lane == 63) s_wsum[wave] = inc;
+    __syncthreads();
+    unsigned long long add = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < NWV; w++) { const unsigned long long t = s_wsum[w]; add += (w < wave) ? t : 0ull; all += t; }
+    unsigned long long run = add + inc - sum;
+    for (int b = lo; b < hi; b++) {
+        const uint32_t c = block_sums[b];
+        block_sums[b] = (uint32_t)run;
+        run += c;
+    }
+    if (tid == 0) {
+        *total_out = all;
+        if (host_out) { __atomic_store_n(host_out, all, __ATOMIC_RELAXED); __threadfence_system(); }
+    }
+}
+
 __global__ __launch_bounds__(kEmitThreads) void k_tile_counts(int N, const uint32_t* __restrict__ sorted_gid,
                                                               const TileRec* __restrict__ tilerec, uint32_t* __restrict__ block_sums,
                                                               TileRec* __restrict__ sorted_rec)
@@ -486,46 +533,14 @@ __global__ __launch_bounds__(kEmitThreads) void k_tile_counts(int N, const uint3
     if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
 }
 
-// small clears that ride in k_block_scan (4-byte words; see gsr_forward)
-struct ZeroJobs {
-    void* p[3];
-    uint32_t words[3];
-};
-
-// single workgroup: exclusive scan of block_sums[nb] in place; total (64-bit) -> *total_out
+// (letting the LAST workgroup of k_tile_counts do the scan -- a ticket, agent-scope loads of the other blocks' totals --
+//  saves the launch but measured 140 us at 1 M Gaussians and +2 us at 50 k: the totals of 3 907 blocks read through
+//  coherent loads by 256 threads are a long latency chain; the single-workgroup launch below stays)
 __global__ __launch_bounds__(1024) void k_block_scan(uint32_t* __restrict__ block_sums, int nb, unsigned long long* __restrict__ total_out,
-                                                     ZeroJobs zj)
+                                                     ZeroJobs zj, unsigned long long* __restrict__ host_out)
 {
     __shared__ unsigned long long s_wsum[16];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-#pragma unroll
-    for (int j = 0; j < 3; j++) {
-        uint32_t* z = static_cast<uint32_t*>(zj.p[j]);
-        for (uint32_t q = tid; q < zj.words[j]; q += 1024) z[q] = 0u;
-    }
-    const int chunk = (nb + 1023) / 1024;
-    const int lo = min(nb, tid * chunk), hi = min(nb, lo + chunk);
-    unsigned long long sum = 0;
-    for (int b = lo; b < hi; b++) sum += block_sums[b];
-    // inclusive scan over the 1024 partial sums: wave shuffles, then the 16 wave totals (one barrier)
-    unsigned long long inc = sum;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const unsigned long long y = __shfl_up(inc, off, 64);
-        if (lane >= off) inc += y;
-    }
-    if (lane == 63) s_wsum[wave] = inc;
-    __syncthreads();
-    unsigned long long add = 0, all = 0;
-#pragma unroll
-    for (int w = 0; w < 16; w++) { const unsigned long long t = s_wsum[w]; add += (w < wave) ? t : 0ull; all += t; }
-    unsigned long long run = add + inc - sum;
-    for (int b = lo; b < hi; b++) {
-        const uint32_t c = block_sums[b];
-        block_sums[b] = (uint32_t)run;
-        run += c;
-    }
-    if (tid == 0) *total_out = all;
+    block_scan_body<1024>(block_sums, nb, total_out, zj, host_out, s_wsum);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -963,9 +978,10 @@ __global__ __launch_bounds__(64) void k_blend_fwd_w6(int W, int H, int tiles_x, 
             const float2 C = s_c[buf][j];
             const float test_T = Tr * (1.f - alpha);          // negative for a finished pixel: fails the stop test below
             const bool pass = !(test_T < kTStop);
-            const float w = pass ? alpha * Tr : 0.f;
+            const float asel = pass ? alpha : 0.f;            // a lane that does not blend adds (+-)0 to everything below
+            const float w = asel * Tr;
             C0 = fmaf(B.w, w, C0); C1 = fmaf(C.x, w, C1); C2 = fmaf(C.y, w, C2);
-            Dd = fmaf(B.z, w, Dd); Aa += w;
+            Dd = fmaf(B.z, w, Dd); Aa = fmaf(Tr, asel, Aa);   // (k_blend_fwd_w's `A += alpha * T` is contracted to this fma)
             Tr = pass ? test_T : -fabsf(Tr);                  // first failure flips the sign: done, |T| kept
             last = pass ? (uint32_t)(b * NT + j + 1) : last;
         };
@@ -1922,7 +1938,7 @@ static BinScratch bin_scratch_layout(int64_t R, int key_bytes = 4)
 // The pinned read-back slot and its event belong to ONE device (an event recorded on another device's stream is an
 // invalid-handle error), and a slot is held by one call at a time: callers on several threads / devices do not serialise
 // on each other while they enqueue or wait.
-struct PinSlot { unsigned long long* host = nullptr; hipEvent_t ev = nullptr; bool busy = false; };
+struct PinSlot { unsigned long long* host = nullptr; unsigned long long* dev = nullptr; hipEvent_t ev = nullptr; bool busy = false; };
 static std::mutex g_state_mutex;
 static std::map<int, std::vector<PinSlot*>> g_pin_slots;                     // device -> slots
 static std::map<std::tuple<int, int, int, int>, uint64_t> g_hints;         // (device, W, H, bucket of N) -> capacity
@@ -1942,7 +1958,8 @@ static PinSlot* acquire_pin_slot(int dev)
     for (PinSlot* s : v)
         if (!s->busy) { s->busy = true; return s; }
     PinSlot* s = new PinSlot();
-    if (hipHostMalloc((void**)&s->host, 64, hipHostMallocDefault) != hipSuccess ||
+    if (hipHostMalloc((void**)&s->host, 64, hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&s->dev, s->host, 0) != hipSuccess ||
         hipEventCreateWithFlags(&s->ev, hipEventDisableTiming) != hipSuccess) { delete s; return nullptr; }
     s->busy = true;
     v.push_back(s);
@@ -2248,6 +2265,8 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
                                : radix_sort_pairs<uint32_t>(dkey, gid, dkey_alt, gid_alt, (uint32_t)N, 0, 32, fs + L.sort, &in_alt, st));
     }
     sorted_gid = in_alt ? gid_alt : gid;
+    PinLease pin(acquire_pin_slot(dev_id));
+    if (!pin.s) return fail(GSR_ERR_HIP, "pinned read-back slot allocation failed%s");
     {
         ProfScope ps(P_SCAN, st);
         ZeroJobs zj = {};
@@ -2258,13 +2277,11 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
         }
         hipLaunchKernelGGL(k_tile_counts, dim3(nb), dim3(kEmitThreads), 0, st, N, sorted_gid, ntiles, block_sums,
                            reinterpret_cast<TileRec*>(fs + L.srec));
-        hipLaunchKernelGGL(k_block_scan, dim3(1), dim3(1024), 0, st, block_sums, nb, total, zj);
+        // the scan writes R straight into the pinned slot (device-visible host memory): no copy launch behind it
+        hipLaunchKernelGGL(k_block_scan, dim3(1), dim3(1024), 0, st, block_sums, nb, total, zj, pin.s->dev);
     }
     GSR_HIP(hipGetLastError());
 
-    PinLease pin(acquire_pin_slot(dev_id));
-    if (!pin.s) return fail(GSR_ERR_HIP, "pinned read-back slot allocation failed%s");
-    GSR_HIP(hipMemcpyAsync(pin.s->host, total, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     if (speculative) {
         GSR_HIP(hipEventRecord(pin.s->ev, st));
         rc = launch_binning(cap, total, true);
@@ -2277,7 +2294,7 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
         GSR_HIP(hipStreamSynchronize(st));
         g_exact_forwards++;
     }
-    R = *pin.s->host;
+    R = *static_cast<volatile unsigned long long*>(pin.s->host);
     if (R > 0xfffffff0ull) return fail(GSR_ERR_RANGE, "more than 2^32 instances%s");
     if (!speculative || R > cap) {   // exact flow, or the capacity was too small (the truncated result is overwritten)
         if (speculative) g_spec_overflows++;

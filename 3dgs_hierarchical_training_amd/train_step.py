@@ -186,6 +186,17 @@ def make_settings(scene: Dict, device, sh_degree: int, bg=None) -> GaussianRaste
         sh_degree=sh_degree, campos=scene["campos"].to(device), prefiltered=False, debug=False)
 
 
+class _LazyVisibility(dict):
+    """The render package of CF3DGS_Render.render (gaussian_model_ht.py:886-894); `visibility_filter = radii > 0` is a kernel
+    launch nobody reads on most iterations, so it is evaluated on first access."""
+
+    def __missing__(self, key):
+        if key == "visibility_filter":
+            v = self["visibility_filter"] = self["radii"] > 0
+            return v
+        raise KeyError(key)
+
+
 def render(params: GaussianParams, settings: GaussianRasterizationSettings, clamp: bool = True,
            fused_activations: bool = False, fused_adam=None) -> Dict:
     """CF3DGS_Render.render with compute_cov3D_python = convert_SHs_python = False.
@@ -208,8 +219,8 @@ def render(params: GaussianParams, settings: GaussianRasterizationSettings, clam
                          opacities=params.get_opacity, scales=params.get_scaling, rotations=params.get_rotation,
                          cov3D_precomp=None)
     rendered_image, radii, rendered_depth, rendered_alpha = out
-    return {"image": rendered_image.clamp(0, 1) if clamp else None, "raw_image": rendered_image, "depth": rendered_depth,
-            "alpha": rendered_alpha, "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii}
+    return _LazyVisibility({"image": rendered_image.clamp(0, 1) if clamp else None, "raw_image": rendered_image,
+                            "depth": rendered_depth, "alpha": rendered_alpha, "viewspace_points": screenspace_points, "radii": radii})
 
 
 def train_step(params: GaussianParams, settings: GaussianRasterizationSettings, gt: torch.Tensor,

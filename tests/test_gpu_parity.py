@@ -696,5 +696,5 @@ def test_sign_encoded_forward_is_bit_identical_with_the_lane_mask_kernel():
             outs[v] = hip_runner.run_hip(kw)["fwd"]
     finally:
         lib.gsr_set_option(b"blend_fwd_ppt", 0)
-    for a, b in zip(outs[5], outs[6]):
-        assert np.array_equal(a, b)
+    for name, a, b in zip(("color", "radii", "depth", "alpha"), outs[5], outs[6]):
+        assert np.array_equal(a, b), (name, int((a != b).sum()), float(np.abs(a.astype(np.float64) - b).max()))
