@@ -910,6 +910,7 @@ __global__ __launch_bounds__(64) void k_blend_fwd_w(int W, int H, int tiles_x, i
 // exists anyway masks it.  One divergent region per iteration remains (lanes whose alpha passes), inside it the stop is
 // a select, not a branch.  Decisions and results are bit-identical with k_blend_fwd_w for every live lane.
 // ------------------------------------------------------------------------------------------------
+template <bool REACH>
 __global__ __launch_bounds__(64) void k_blend_fwd_w6(int W, int H, int tiles_x, int T, const uint2* __restrict__ ranges,
                                                      const uint32_t* __restrict__ list, const Splat* __restrict__ splat,
                                                      const float* __restrict__ bg, float* __restrict__ out_color,
@@ -938,11 +939,20 @@ __global__ __launch_bounds__(64) void k_blend_fwd_w6(int W, int H, int tiles_x, 
     uint32_t last = 0;
     float4 ra = {0, 0, 0, 0}, rb = ra, rc = ra;
     constexpr float kL2E = 1.4426950408889634f;
-    if (lane < n) {
-        const float4* sp = reinterpret_cast<const float4*>(splat + list[rg.x + lane]);
+    // REACH: the staging lane also runs the exact box test of the tile culling (gsr_math.h box_accept: the minimum of the conic
+    // form over the pixel box against 2 ln(255 o) + slack -- never rejects a box in which some pixel is reached) on THIS
+    // wave's 8x8 block; the blend loop then visits only the instances whose bit is set.  An instance the tile accepted but
+    // this sub-tile cannot see costs three scalar instructions instead of twelve vector ones.
+    const float sbx0 = (float)(tx * kTile + (sub & 1) * 8) - 0.5f * (float)W, sby0 = (float)(ty * kTile + (sub >> 1) * 8) - 0.5f * (float)H;
+    const float sbx1 = fminf(sbx0 + 7.f, (float)(W - 1) - 0.5f * (float)W), sby1 = fminf(sby0 + 7.f, (float)(H - 1) - 0.5f * (float)H);
+    bool reach_nxt = false;
+    auto fetch = [&](int i) {
+        const float4* sp = reinterpret_cast<const float4*>(splat + list[rg.x + i]);
         ra = sp[0]; rb = sp[1]; rc = sp[2];
+        if (REACH) reach_nxt = box_accept(make_tile_test(ra.x, ra.y, ra.z, ra.w, rb.x, rb.y), sbx0, sby0, sbx1, sby1);
         ra.z *= -0.5f * kL2E; ra.w *= -kL2E; rb.x *= -0.5f * kL2E;
-    }
+    };
+    if (lane < n) fetch(lane);
     int batches = 0;
     for (int b = 0; b < nb; b++) {
         const int buf = b & 1;
@@ -952,15 +962,13 @@ __global__ __launch_bounds__(64) void k_blend_fwd_w6(int W, int H, int tiles_x, 
             c[0] = fabsf(Tr); c[256] = C0; c[512] = C1; c[768] = C2; c[1024] = Dd; c[1280] = Aa;
         }
         s_a[buf][lane] = ra; s_b[buf][lane] = rb; s_c[buf][lane] = make_float2(rc.x, rc.y);
+        const int cnt = min(NT, n - b * NT);
+        const unsigned long long reach = REACH ? __ballot(reach_nxt && lane < cnt) : 0ull;
+        reach_nxt = false;
         __syncthreads();   // single-wave workgroup: just orders the LDS writes before the broadcast reads
         batches = b + 1;
         const int nxt = (b + 1) * NT + lane;
-        if (nxt < n) {
-            const float4* sp = reinterpret_cast<const float4*>(splat + list[rg.x + nxt]);
-            ra = sp[0]; rb = sp[1]; rc = sp[2];
-            ra.z *= -0.5f * kL2E; ra.w *= -kL2E; rb.x *= -0.5f * kL2E;
-        }
-        const int cnt = min(NT, n - b * NT);
+        if (nxt < n) fetch(nxt);
         auto alpha_of = [&](int j, float& p2) {
             const float4 A = s_a[buf][j];
             const float2 Bq = *reinterpret_cast<const float2*>(&s_b[buf][j]);   // C', opacity
@@ -986,10 +994,19 @@ __global__ __launch_bounds__(64) void k_blend_fwd_w6(int W, int H, int tiles_x, 
             last = pass ? (uint32_t)(b * NT + j + 1) : last;
         };
         // (evaluating two instances' alpha before either blend -- two v_exp_f32 in flight -- measured the same: 118 us)
-        for (int j = 0; j < cnt; j++) {
-            float p2;
-            const float a1 = alpha_of(j, p2);
-            blend(j, p2, a1);
+        if (REACH) {
+            for (unsigned long long rm = reach; rm != 0ull; rm &= rm - 1ull) {
+                const int j = (int)__builtin_ctzll(rm);
+                float p2;
+                const float a1 = alpha_of(j, p2);
+                blend(j, p2, a1);
+            }
+        } else {
+            for (int j = 0; j < cnt; j++) {
+                float p2;
+                const float a1 = alpha_of(j, p2);
+                blend(j, p2, a1);
+            }
         }
     }
     if (lane == 0) staged4[tile * 4 + sub] = (uint32_t)min(n, batches * NT);
@@ -2055,7 +2072,7 @@ int gsr_set_option(const char* name, int value)
 {
     if (!name) return GSR_ERR_ARG;
     // 1 / 3 / 4 = one workgroup per tile with 1 / 2 / 4 pixels per lane (scalar), 2 = packed 2-pixel, 5 = one wave per 8x8 sub-tile
-    if (!strcmp(name, "blend_fwd_ppt")) { if (value < 0 || value > 6) return GSR_ERR_ARG; g_blend_ppt = value; return GSR_OK; }
+    if (!strcmp(name, "blend_fwd_ppt")) { if (value < 0 || value > 7) return GSR_ERR_ARG; g_blend_ppt = value; return GSR_OK; }
     if (!strcmp(name, "bwd_split")) { if (value < 0 || value > 64) return GSR_ERR_ARG; g_bwd_split = value ? value : 16; return GSR_OK; }
     if (!strcmp(name, "ckpt_first")) { if (value < 1 || value > 64) return GSR_ERR_ARG; g_ckpt_first = value; return GSR_OK; }
     if (!strcmp(name, "tile_map")) { if (value < 0 || value > 2) return GSR_ERR_ARG; g_tile_map = value; return GSR_OK; }
@@ -2088,7 +2105,7 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
         return fail(GSR_ERR_ARG, "missing output / workspace pointer%s");
     const int N = a->N, W = a->W, H = a->H;
     // the process-wide options as they are NOW: one forward uses one consistent set and hands it to its backward
-    const int opt_ppt = g_blend_ppt ? g_blend_ppt : 6, opt_map = g_tile_map, opt_ckpt = g_ckpt_first;
+    const int opt_ppt = g_blend_ppt ? g_blend_ppt : 7, opt_map = g_tile_map, opt_ckpt = g_ckpt_first;
     const int tiles_x = (W + kTile - 1) / kTile, tiles_y = (H + kTile - 1) / kTile, T = tiles_x * tiles_y;
     out->num_rendered = 0; out->binning = nullptr; out->binning_bytes = 0; out->binning_capacity = 0;
     out->forward_flags = pack_fwd_flags(opt_ppt, opt_map, opt_ckpt);
@@ -2163,7 +2180,7 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
         return wide_keys ? launch_binning_t(uint32_t{}, capacity, n_dev, prezeroed) : launch_binning_t(uint16_t{}, capacity, n_dev, prezeroed);
     };
     auto launch_blend = [&](bool prezeroed) -> int {
-        const int ppt = opt_ppt;   // default 6: one wave per 8x8 sub-tile, sign-encoded done (5 = the same with a lane mask)
+        const int ppt = opt_ppt;   // default 7: one wave per 8x8 sub-tile, sign-encoded done + sub-tile reach bits (6: without the bits, 5: lane mask)
         if (!prezeroed) GSR_HIP(hipMemsetAsync(staged, 0, (size_t)T * 16, st));
         {
             ProfScope ps(P_BLEND_FWD, st);
@@ -2171,8 +2188,11 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
                 hipLaunchKernelGGL(k_blend_fwd_w, dim3(8 * 4 * slots_per_xcd(opt_map, T, tiles_x)), dim3(64), 0, st, W, H, tiles_x, T, ranges, list, splat, a->bg,
                                    a->out_color, a->out_depth, a->out_alpha, img, staged, opt_map,
                                    reinterpret_cast<float*>(bin + B.ckpt), opt_ckpt);
+            else if (ppt == 7)
+                hipLaunchKernelGGL(k_blend_fwd_w6<true>, dim3(8 * 4 * slots_per_xcd(opt_map, T, tiles_x)), dim3(64), 0, st, W, H, tiles_x, T, ranges, list, splat, a->bg,
+                                   a->out_color, a->out_depth, a->out_alpha, img, staged, opt_map, reinterpret_cast<float*>(bin + B.ckpt), opt_ckpt);
             else if (ppt == 6)
-                hipLaunchKernelGGL(k_blend_fwd_w6, dim3(8 * 4 * slots_per_xcd(opt_map, T, tiles_x)), dim3(64), 0, st, W, H, tiles_x, T, ranges, list, splat, a->bg,
+                hipLaunchKernelGGL(k_blend_fwd_w6<false>, dim3(8 * 4 * slots_per_xcd(opt_map, T, tiles_x)), dim3(64), 0, st, W, H, tiles_x, T, ranges, list, splat, a->bg,
                                    a->out_color, a->out_depth, a->out_alpha, img, staged, opt_map, reinterpret_cast<float*>(bin + B.ckpt), opt_ckpt);
             else if (ppt == 1) launch_blend_fwd<1>(W, H, tiles_x, T, ranges, list, splat, a->bg, a->out_color, a->out_depth, a->out_alpha, img, staged, st);
             else if (ppt == 2)
@@ -2331,10 +2351,10 @@ int gsr_backward(const GsrBackwardArgs* a, void* stream_)
     const int N = a->N, W = a->W, H = a->H;
     // the forward's kernel variant / tile map / checkpoint layout travel with its output (forward_flags); a caller of the
     // round-1 ABI (flags 0) gets the process-wide options as before
-    int f_ppt = g_blend_ppt ? g_blend_ppt : 6, f_map = g_tile_map, f_ckpt = g_ckpt_first;
+    int f_ppt = g_blend_ppt ? g_blend_ppt : 7, f_map = g_tile_map, f_ckpt = g_ckpt_first;
     if (a->forward_flags & 1) {
         f_ppt = (int)((a->forward_flags >> 1) & 7); f_map = (int)((a->forward_flags >> 4) & 3); f_ckpt = (int)((a->forward_flags >> 6) & 127);
-        if (f_ppt < 1 || f_ppt > 6 || f_map > 2 || f_ckpt < 1) return fail(GSR_ERR_ARG, "forward_flags do not come from gsr_forward%s");
+        if (f_ppt < 1 || f_ppt > 7 || f_map > 2 || f_ckpt < 1) return fail(GSR_ERR_ARG, "forward_flags do not come from gsr_forward%s");
     }
     (void)f_ppt;
     if (N == 0) {

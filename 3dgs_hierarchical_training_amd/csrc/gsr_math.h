@@ -40,6 +40,10 @@ constexpr float SH_C3_0 = -0.5900435899266435f, SH_C3_1 = 2.890611442640554f, SH
                 SH_C3_6 = -0.5900435899266435f;
 
 // Projected 2D Gaussian, 48 bytes, 16-byte aligned: what the blend kernels gather per instance.
+// (Measured in round 2: padding the record to one 64-byte, 64-byte-aligned line -- so that a gather never straddles two
+//  lines -- takes the counted HBM traffic of the forward / backward blend from 132 / 203 MB to 118 / 192 MB per launch but
+//  leaves their time unchanged (both are VALU-bound) and costs k_preprocess 5 us for the 16 more bytes it writes per
+//  Gaussian: kept at 48.)
 // px, py are stored RELATIVE TO THE IMAGE CENTRE (W/2, H/2): pixel centres minus the centre are exact in
 // binary32, so dx = px - pixel carries only the rounding of |px| <= W/2 instead of W (halves the dominant
 // coordinate error at 1920x1080: max image error vs the float64 oracle 1.24e-5 -> below 1e-5).

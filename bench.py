@@ -26,6 +26,7 @@ Rank 0 prints ONE JSON line.  Besides the contract's keys:
                    importance of each child on its home rank, un-pruned child + mask point-to-point (RCCL for N > 1; a
                    device copy at N = 1), masks applied and appended at the destination.
   `other_workloads` the other BASELINE configs on the same code (N = 1 only; `--no-extras` skips them).
+  `host_us`        host time of one forward + backward call through the PyTorch extension.
 """
 import argparse
 import ctypes as C
@@ -143,6 +144,47 @@ def timed_steps(step, steps, dev):
     return (time.perf_counter() - t0) / steps
 
 
+def host_leg(syn, ts, dev, calls=300):
+    """Cost of one forward + backward call through each binding on a scene so small (2 000 Gaussians @128x96) that the
+    ~20 kernels of a call are at their launch-latency floor: wall time per call through the PyTorch extension
+    (torch.ops.gsr.rasterize: C++ autograd function, at::empty allocator) and through the ctypes FFI route
+    (GSR_BINDING=ctypes: Python autograd.Function, struct marshalling, Python allocator callback).  The difference is host
+    work the extension removed; the extension's figure is an upper bound of its host cost (it contains the device's own
+    latency floor and the one wait for the instance count)."""
+    sc = syn.make_scene(2000, 128, 96, sh_degree=3, seed=0)
+    p = ts.GaussianParams(sc, dev, optimizer="torch")
+    st = ts.make_settings(sc, dev, 3)
+    g = torch.ones(3, 96, 128, device=dev)
+
+    def call():
+        pkg = ts.render(p, st, clamp=False, fused_activations=True)
+        pkg["raw_image"].backward(g)
+        p.optimizer.zero_grad(set_to_none=True)
+
+    def measure():
+        for _ in range(20):
+            call()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(calls):
+            call()
+        torch.cuda.synchronize(dev)
+        return 1e6 * (time.perf_counter() - t0) / calls
+    ext = measure()
+    prev = os.environ.get("GSR_BINDING")
+    os.environ["GSR_BINDING"] = "ctypes"
+    try:
+        ct = measure()
+    finally:
+        if prev is None:
+            os.environ.pop("GSR_BINDING", None)
+        else:
+            os.environ["GSR_BINDING"] = prev
+    return {"fwd_bwd_call_us": ext, "ctypes_fwd_bwd_call_us": ct, "calls": calls, "binding": "torch.ops.gsr.rasterize (csrc/torch_ext.cpp)",
+            "note": "wall time per forward + backward call at 2 000 Gaussians @128x96 (device at its launch-latency floor): an upper "
+                    "bound of the host cost per call; ctypes_* = the same through the plain-FFI route"}
+
+
 def dropin_leg(ts, scene, settings, gt, dev, steps, warmup):
     """The path the unmodified reference trainer reaches: torch activations + cat -> GaussianRasterizer(...) -> clamp ->
     torch L1 + SSIM (F.conv2d) -> backward -> torch.optim.Adam(l, lr=0.0, eps=1e-15).step()."""
@@ -214,34 +256,40 @@ def merge_leg(dev, dist, world, rank, params, scene, ts, syn, deg):
     T = torch.eye(4)
     hier.calc_importance(raw, views[:1])      # warm the non-fused backward variant
     if world == 1:
-        tr = seg_mod.LocalTransport(2)
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        tr.rank = 1
-        s = hier.merge_send(tr, 0, raw, views, 0.5)
-        tr.rank = 0
-        d = hier.merge_recv(tr, 1, raw, views, 0.5, T)
-        torch.cuda.synchronize(dev)
-        total = 1e3 * (time.perf_counter() - t0)
-        return {"merge_ms": total, "merge_bytes": s["bytes"], "pairs": 1, "transport": "in-process device copy (N = 1)",
-                "importance_views": len(views), "importance_ms_src": s["importance_ms"], "importance_ms_dst": d["importance_ms"],
-                "send_ms": s["send_ms"], "recv_ms": d["recv_ms"], "append_ms": d["append_ms"], "gaussians_child": s["n"],
-                "gaussians_merged": d["n_merged"], "note": "both children's importance run back to back on the one GPU"}
+        best = None
+        for rep in range(2):          # the first pass pays torch's one-time kernel loads (topk, masked gathers); report the second
+            tr = seg_mod.LocalTransport(2)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            tr.rank = 1
+            s = hier.merge_send(tr, 0, raw, views, 0.5)
+            tr.rank = 0
+            d = hier.merge_recv(tr, 1, raw, views, 0.5, T)
+            torch.cuda.synchronize(dev)
+            total = 1e3 * (time.perf_counter() - t0)
+            best = {"merge_ms": total, "merge_bytes": s["bytes"], "pairs": 1, "transport": "in-process device copy (N = 1)",
+                    "importance_views": len(views), "importance_ms_src": s["importance_ms"], "importance_ms_dst": d["importance_ms"],
+                    "send_ms": s["send_ms"], "recv_ms": d["recv_ms"], "append_ms": d["append_ms"], "gaussians_child": s["n"],
+                    "gaussians_merged": d["n_merged"], "note": "both children's importance run back to back on the one GPU"}
+            del d
+        return best
     tr = seg_mod.DistTransport()
     pairs = seg_mod.merge_schedule(world)[0]
     role = seg_mod.partner(rank, pairs)
-    torch.cuda.synchronize(dev)
-    dist.barrier()
-    t0 = time.perf_counter()
-    st = {"importance_ms": 0.0, "xfer_ms": 0.0, "bytes": 0.0, "append_ms": 0.0, "n_merged": 0.0}
-    if role is not None and role[0] == "send":
-        s = hier.merge_send(tr, role[1], raw, views, 0.5)
-        st.update(importance_ms=s["importance_ms"], xfer_ms=s["send_ms"], bytes=float(s["bytes"]))
-    elif role is not None:
-        d = hier.merge_recv(tr, role[1], raw, views, 0.5, T)
-        st.update(importance_ms=d["importance_ms"], xfer_ms=d["recv_ms"], append_ms=d["append_ms"], n_merged=float(d["n_merged"]))
-    torch.cuda.synchronize(dev)
-    local = 1e3 * (time.perf_counter() - t0)
+    for rep in range(2):              # first pass: torch's one-time kernel loads + RCCL's channel set-up; the second is reported
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        t0 = time.perf_counter()
+        st = {"importance_ms": 0.0, "xfer_ms": 0.0, "bytes": 0.0, "append_ms": 0.0, "n_merged": 0.0}
+        if role is not None and role[0] == "send":
+            s = hier.merge_send(tr, role[1], raw, views, 0.5)
+            st.update(importance_ms=s["importance_ms"], xfer_ms=s["send_ms"], bytes=float(s["bytes"]))
+        elif role is not None:
+            d = hier.merge_recv(tr, role[1], raw, views, 0.5, T)
+            st.update(importance_ms=d["importance_ms"], xfer_ms=d["recv_ms"], append_ms=d["append_ms"], n_merged=float(d["n_merged"]))
+            del d
+        torch.cuda.synchronize(dev)
+        local = 1e3 * (time.perf_counter() - t0)
     v = torch.tensor([local, st["importance_ms"], st["xfer_ms"], st["append_ms"], st["n_merged"]], device=dev, dtype=torch.float64)
     dist.all_reduce(v, op=dist.ReduceOp.MAX)
     b = torch.tensor([st["bytes"]], device=dev, dtype=torch.float64)
@@ -423,6 +471,10 @@ def main():
         except Exception as e:
             roofline["peak_measured"] = None
             roofline["peak_measured_error"] = repr(e)
+        try:
+            res["host_us"] = host_leg(syn, ts, dev)
+        except Exception as e:
+            res["host_us"] = {"fwd_bwd_call_us": None, "error": repr(e)}
         try:
             res["dropin"] = dropin_leg(ts, scene, settings, gt, dev, steps=min(args.steps, 10), warmup=2)
         except Exception as e:

@@ -12,7 +12,7 @@ for SET in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU S
            "TCC_HIT_sum TCC_MISS_sum" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum"; do
   i=$((i+1))
   timeout 300 rocprofv3 --pmc $SET --kernel-include-regex "$REGEX" --output-format csv -d $OUT/pass$i -o p -- \
-      python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > $OUT/pass$i.json 2> $OUT/pass$i.err || echo "pass $i failed: $SET" >> $OUT/failed.txt
+      python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras "$@" > $OUT/pass$i.json 2> $OUT/pass$i.err || echo "pass $i failed: $SET" >> $OUT/failed.txt
 done
 rocprofv3 -L > $OUT/counters_list.txt 2>&1 || true
 find $OUT -name "*.csv" | head -20
