@@ -10,6 +10,9 @@
 // [w*1024, (w+1)*1024) of the tile, ranks them round by round against its own running per-digit count, and the
 // per-wave counts are prefix-summed in wave order.
 #pragma once
+#include <map>
+#include <mutex>
+#include <utility>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -233,10 +236,32 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const KeyT* __re
 // publishes its LOCAL count before it waits on anything, so the look-back can always walk back to tile 0:
 // no circular wait.  Versus hist+scan+scatter this reads the keys once per pass and saves two launches.
 // ------------------------------------------------------------------------------------------------
-// kResident: workgroups of the pass kernel the chip holds at once (LDS-bound: 4 per CU for 16-bit keys, 1 per CU for 32-bit),
-// below which the grid runs without tickets
-template <typename KeyT> struct OsCfg { static constexpr int kThreads = 512, kTile = 5120, kResident = 512; };
-template <> struct OsCfg<uint32_t> { static constexpr int kThreads = 1024, kTile = 4096, kResident = 256; };
+// A pass runs WITHOUT tickets (blockIdx order = look-back order) when its whole grid is co-resident on the device; the
+// bound -- workgroups of this very kernel the device holds at once -- is asked of the runtime per device and kernel
+// (occupancy API x the device's CU count: a partitioned (CPX / NPS) device reports fewer CUs and gets a smaller bound),
+// never assumed.  Above it, workgroups take tickets, which is correct at any residency.
+template <typename KeyT> struct OsCfg { static constexpr int kThreads = 512, kTile = 5120; };
+template <> struct OsCfg<uint32_t> { static constexpr int kThreads = 1024, kTile = 4096; };
+
+template <typename KernelT>
+inline uint32_t onesweep_resident_blocks(KernelT kernel, int threads)
+{
+    static std::mutex mu;
+    static std::map<std::pair<int, const void*>, uint32_t> cache;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    const auto key = std::make_pair(dev, reinterpret_cast<const void*>(kernel));
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    int per_cu = 0, cus = 0;
+    uint32_t v = 0;   // unknown: always take tickets
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0) == hipSuccess &&
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && per_cu > 0 && cus > 0)
+        v = (uint32_t)per_cu * (uint32_t)cus;
+    cache[key] = v;
+    return v;
+}
 constexpr int kOsRanges = 32;
 constexpr uint32_t kOsLocal = 1u << 30, kOsIncl = 2u << 30, kOsMask = (1u << 30) - 1u;
 constexpr uint32_t kOsTicketWords = (4 * kOsRanges + 63) / 64 * 64;   // tickets[pass][run], padded
@@ -481,8 +506,10 @@ inline hipError_t onesweep_sort_pairs(KeyT* keys, uint32_t* vals, KeyT* keys_alt
         const uint32_t pmask = (1u << (dbits < bits - dbits * p ? dbits : bits - dbits * p)) - 1u;
         const int runs = p == 0 ? kOsRanges : 1;
         const uint32_t pgrid = runs > 1 ? kOsRanges * per_cap : nblocks;
-        uint32_t* tk_p = pgrid <= (uint32_t)OsCfg<KeyT>::kResident ? (uint32_t*)nullptr : tickets + p * kOsRanges;
         const int wbits = dbits < bits - dbits * p ? dbits : bits - dbits * p;   // this pass's digit width
+        const uint32_t resident = wbits <= 6 ? onesweep_resident_blocks(k_onesweep<KeyT, 64>, OsCfg<KeyT>::kThreads)
+                                             : onesweep_resident_blocks(k_onesweep<KeyT, 256>, OsCfg<KeyT>::kThreads);
+        uint32_t* tk_p = pgrid <= resident ? (uint32_t*)nullptr : tickets + p * kOsRanges;
         if (wbits <= 6)
             hipLaunchKernelGGL((k_onesweep<KeyT, 64>), dim3(pgrid), dim3(OsCfg<KeyT>::kThreads), 0, stream, kin, vin, kout, vout, n,
                                begin_bit + dbits * p, ghist + p * kOsRanges * 256, status + (size_t)p * nblocks * 256, tk_p, n_dev, pmask, runs);
