@@ -1138,6 +1138,7 @@ __global__ __launch_bounds__(128) void k_blend_fwd2(int W, int H, int tiles_x, i
 // ggrad record (12 floats / Gaussian): gx gy gA gB gC gop gr gg gb gz - -
 // ------------------------------------------------------------------------------------------------
 constexpr int kGG = 12;
+constexpr int kDetStride = 10;   // floats per (tile, instance) slot of the deterministic backward
 
 template <int PPT>
 __global__ __launch_bounds__(256 / PPT) void k_blend_bwd(int W, int H, int tiles_x, int T, const uint2* __restrict__ ranges,
@@ -1279,7 +1280,7 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(int W, int H, int tiles_x, i
                                                     const float* __restrict__ g_color, const float* __restrict__ g_depth,
                                                     const float* __restrict__ g_alpha, float* __restrict__ ggrad, int interleave,
                                                     const float* __restrict__ ckpt, int split, int kCkptFirst,
-                                                    const uint32_t* __restrict__ staged4, int tpad)
+                                                    const uint32_t* __restrict__ staged4, int tpad, float* __restrict__ det_part)
 {
     constexpr int NT = 128, NW = 2, NV = HAS_DA ? 10 : 9;
     // single staging buffer: a batch is ~10^4 cycles of compute, so the second barrier per batch is free, and the
@@ -1482,7 +1483,10 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(int W, int H, int tiles_x, i
                 if (r < NV) {
                     const float v = s_part[0][jj][r] + s_part[1][jj][r];
                     s_part[0][jj][r] = 0.f; s_part[1][jj][r] = 0.f;   // ready for the next batch (its writers sit behind a barrier)
-                    if (v != 0.f) atomicAdd(ggrad + (size_t)s_gid[buf][jj] * kGG + r, r < 2 ? v * kLn2 : v);
+                    // deterministic debug mode: the (tile, instance) partial goes to its own slot, k_det_reduce sums a
+                    // Gaussian's slots in list order afterwards; default: one coalesced atomic per record row
+                    if (det_part) det_part[((size_t)rg.x + (size_t)b * NT + jj) * kDetStride + r] = r < 2 ? v * kLn2 : v;
+                    else if (v != 0.f) atomicAdd(ggrad + (size_t)s_gid[buf][jj] * kGG + r, r < 2 ? v * kLn2 : v);
                 }
             }
         }
@@ -1857,6 +1861,33 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, in
     }
 }
 
+// Deterministic-accumulation debug mode (gsr_set_option "deterministic_backward"): instance positions sorted by Gaussian id
+// (stable: a Gaussian's instances stay in list = tile order); the first position of each run sums the run's partial
+// records in that order and writes the Gaussian's row -- no float atomics, the same bits on every run.
+__global__ __launch_bounds__(256) void k_det_iota(uint32_t R, uint32_t* __restrict__ pos)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < R) pos[i] = i;
+}
+__global__ __launch_bounds__(256) void k_det_reduce(uint32_t R, const uint32_t* __restrict__ gid_sorted, const uint32_t* __restrict__ pos_sorted,
+                                                    const float* __restrict__ part, float* __restrict__ ggrad)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= R) return;
+    const uint32_t g = gid_sorted[i];
+    if (i > 0 && gid_sorted[i - 1] == g) return;
+    float acc[kDetStride];
+#pragma unroll
+    for (int r = 0; r < kDetStride; r++) acc[r] = 0.f;
+    for (uint32_t j = i; j < R && gid_sorted[j] == g; j++) {
+        const float* p = part + (size_t)pos_sorted[j] * kDetStride;
+#pragma unroll
+        for (int r = 0; r < kDetStride; r++) acc[r] += p[r];
+    }
+#pragma unroll
+    for (int r = 0; r < kDetStride; r++) ggrad[(size_t)g * kGG + r] = acc[r];
+}
+
 // one block per camera entry: deterministic sum of the per-block partials
 __global__ __launch_bounds__(256) void k_cam_reduce(const float* __restrict__ partial, int nblocks, float* __restrict__ d_vm,
                                                     float* __restrict__ d_pm, float* __restrict__ d_campos, float* __restrict__ d_xf)
@@ -1961,6 +1992,7 @@ static std::map<int, std::vector<PinSlot*>> g_pin_slots;                     // 
 static std::map<std::tuple<int, int, int, int>, uint64_t> g_hints;         // (device, W, H, bucket of N) -> capacity
 static long long g_hint_override = -1;                                      // tests: capacity of the NEXT forward (one shot)
 static int g_speculate = 1;
+static int g_deterministic = 0;   // 1: the blend backward accumulates per Gaussian in a fixed order (debug; slower)
 static int g_bwd_split = 16; // workgroups a long tile's backward is split over (checkpoints from the forward); 1 = off
 static int g_ckpt_first = 1;  // 128-instance batches of a tile before the forward starts leaving checkpoints
 static int g_tile_map = 2;   // tile -> XCD map: 2 = 2x2 tile blocks interleaved (default), 1 = tiles interleaved, 0 = banded
@@ -2077,6 +2109,7 @@ int gsr_set_option(const char* name, int value)
     if (!strcmp(name, "ckpt_first")) { if (value < 1 || value > 64) return GSR_ERR_ARG; g_ckpt_first = value; return GSR_OK; }
     if (!strcmp(name, "tile_map")) { if (value < 0 || value > 2) return GSR_ERR_ARG; g_tile_map = value; return GSR_OK; }
     if (!strcmp(name, "speculative_binning")) { g_speculate = value ? 1 : 0; return GSR_OK; }
+    if (!strcmp(name, "deterministic_backward")) { g_deterministic = value ? 1 : 0; return GSR_OK; }
     if (!strcmp(name, "binning_capacity_hint")) {   // tests: capacity of the next forward (one shot; forces an overflow re-run)
         std::lock_guard<std::mutex> lk(g_state_mutex);
         g_hint_override = value > 0 ? value : -1;
@@ -2388,12 +2421,41 @@ int gsr_backward(const GsrBackwardArgs* a, void* stream_)
             const int grid = split * tpad;
             const float* ckpt = reinterpret_cast<const float*>(bin + B.ckpt);
             const uint32_t* staged4 = reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(a->image) + gsr_image_staged_offset(W, H));
+            // deterministic debug mode: R-sized slots + a sort of the instance positions by Gaussian id (stream-ordered
+            // allocations of the library's own: gsr_backward has no allocator callback and this is not a hot path)
+            float* det_part = nullptr;
+            uint8_t* det_mem = nullptr;
+            const uint32_t Rn = (uint32_t)a->num_rendered;
+            size_t o_part = 0, o_k0 = 0, o_k1 = 0, o_v0 = 0, o_v1 = 0, o_sort = 0, det_bytes = 0;
+            if (g_deterministic) {
+                size_t o = 0;
+                o_part = o; o += align256((size_t)Rn * kDetStride * 4);
+                o_k0 = o; o += align256((size_t)Rn * 4); o_k1 = o; o += align256((size_t)Rn * 4);
+                o_v0 = o; o += align256((size_t)Rn * 4); o_v1 = o; o += align256((size_t)Rn * 4);
+                o_sort = o; o += radix_scratch_bytes(Rn);
+                det_bytes = o;
+                GSR_HIP(hipMallocAsync((void**)&det_mem, det_bytes, st));
+                det_part = reinterpret_cast<float*>(det_mem + o_part);
+                GSR_HIP(hipMemsetAsync(det_part, 0, (size_t)Rn * kDetStride * 4, st));
+            }
             if (a->grad_depth || a->grad_alpha)
                 hipLaunchKernelGGL(k_blend_bwd2<true>, dim3(grid), dim3(128), 0, st, W, H, tiles_x, T, ranges, list, splat, a->bg, img,
-                                   a->grad_color, a->grad_depth, a->grad_alpha, gg, f_map, ckpt, split, f_ckpt, staged4, tpad);
+                                   a->grad_color, a->grad_depth, a->grad_alpha, gg, f_map, ckpt, split, f_ckpt, staged4, tpad, det_part);
             else
                 hipLaunchKernelGGL(k_blend_bwd2<false>, dim3(grid), dim3(128), 0, st, W, H, tiles_x, T, ranges, list, splat, a->bg, img,
-                                   a->grad_color, a->grad_depth, a->grad_alpha, gg, f_map, ckpt, split, f_ckpt, staged4, tpad);
+                                   a->grad_color, a->grad_depth, a->grad_alpha, gg, f_map, ckpt, split, f_ckpt, staged4, tpad, det_part);
+            if (g_deterministic) {
+                uint32_t* k0 = reinterpret_cast<uint32_t*>(det_mem + o_k0); uint32_t* k1 = reinterpret_cast<uint32_t*>(det_mem + o_k1);
+                uint32_t* v0 = reinterpret_cast<uint32_t*>(det_mem + o_v0); uint32_t* v1 = reinterpret_cast<uint32_t*>(det_mem + o_v1);
+                GSR_HIP(hipMemcpyAsync(k0, list, (size_t)Rn * 4, hipMemcpyDeviceToDevice, st));
+                hipLaunchKernelGGL(k_det_iota, dim3((Rn + 255) / 256), dim3(256), 0, st, Rn, v0);
+                int nbits = 1;
+                while ((1ll << nbits) < (long long)N) nbits++;
+                int in_alt = 0;
+                GSR_HIP(radix_sort_pairs<uint32_t>(k0, v0, k1, v1, Rn, 0, ((nbits + 7) / 8) * 8, det_mem + o_sort, &in_alt, st));
+                hipLaunchKernelGGL(k_det_reduce, dim3((Rn + 255) / 256), dim3(256), 0, st, Rn, in_alt ? k1 : k0, in_alt ? v1 : v0, det_part, gg);
+                GSR_HIP(hipFreeAsync(det_mem, st));
+            }
         } else if (ppt == 3) launch_blend_bwd<2>(W, H, tiles_x, T, ranges, list, splat, a->bg, img, a->grad_color, a->grad_depth, a->grad_alpha, gg, st);
         else launch_blend_bwd<4>(W, H, tiles_x, T, ranges, list, splat, a->bg, img, a->grad_color, a->grad_depth, a->grad_alpha, gg, st);
     }

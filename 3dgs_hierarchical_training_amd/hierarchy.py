@@ -65,10 +65,12 @@ def prune_mask(importance: torch.Tensor, prune_ratio: float) -> torch.Tensor:
 
 
 def merge_send(tr, dst: int, seg: Dict[str, torch.Tensor], views, prune_ratio: float, frames=None, poses=None,
-               start_fidx: int = 0, global_iteration: int = 0, importance_fn=calc_importance) -> Dict:
-    """Source side of one pair: own importance -> drop mask; ship the UN-PRUNED child + mask + frames / poses."""
+               start_fidx: int = 0, global_iteration: int = 0, importance_fn=calc_importance, drop=None) -> Dict:
+    """Source side of one pair: own importance -> drop mask; ship the UN-PRUNED child + mask + frames / poses.
+    `drop`: a mask computed beforehand (then `views` is not used)."""
     t0 = time.perf_counter()
-    drop = prune_mask(importance_fn(seg, views), prune_ratio)
+    if drop is None:
+        drop = prune_mask(importance_fn(seg, views), prune_ratio)
     imp_ms = _elapsed_ms(t0, seg["_xyz"])
     st = segments.send_child(tr, dst, seg, drop=drop, frames=frames, poses=poses, start_fidx=start_fidx,
                              global_iteration=global_iteration)
@@ -77,13 +79,13 @@ def merge_send(tr, dst: int, seg: Dict[str, torch.Tensor], views, prune_ratio: f
 
 
 def merge_recv(tr, src: int, seg: Dict[str, torch.Tensor], views, prune_ratio: float, src_to_dst=None,
-               importance_fn=calc_importance) -> Dict:
+               importance_fn=calc_importance, drop=None) -> Dict:
     """Destination side: own importance (in parallel with the source's), receive the un-pruned child, apply both masks,
     move the child's points by `src_to_dst` (a [4,4] or a callable(child_message) -> [4,4]) and append.
 
     Returns {'merged', 'teachers': [own un-pruned, child un-pruned], 'child': message, stats...}."""
     t0 = time.perf_counter()
-    drop_dst = prune_mask(importance_fn(seg, views), prune_ratio)
+    drop_dst = drop if drop is not None else prune_mask(importance_fn(seg, views), prune_ratio)
     imp_ms = _elapsed_ms(t0, seg["_xyz"])
     msg = segments.recv_child(tr, src, seg["_xyz"].device)
     child = msg["seg"]

@@ -281,12 +281,27 @@ def merge_leg(dev, dist, world, rank, params, scene, ts, syn, deg):
         dist.barrier()
         t0 = time.perf_counter()
         st = {"importance_ms": 0.0, "xfer_ms": 0.0, "bytes": 0.0, "append_ms": 0.0, "n_merged": 0.0}
+        # phase 1, local: every paired rank scores its own child.  A rank that fails here must not leave its partner
+        # blocked in a point-to-point call, so the ranks agree (one MIN all-reduce of a flag) before any send / recv
+        drop, ok = None, 1.0
+        try:
+            if role is not None:
+                drop = hier.prune_mask(hier.calc_importance(raw, views), 0.5)
+            torch.cuda.synchronize(dev)
+        except Exception:
+            ok = 0.0
+        st["importance_ms"] = 1e3 * (time.perf_counter() - t0)
+        flag = torch.tensor([ok], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if float(flag.item()) < 1.0:
+            raise RuntimeError("importance failed on at least one rank; merge exchange skipped on all")
+        # phase 2: the exchange
         if role is not None and role[0] == "send":
-            s = hier.merge_send(tr, role[1], raw, views, 0.5)
-            st.update(importance_ms=s["importance_ms"], xfer_ms=s["send_ms"], bytes=float(s["bytes"]))
+            s = hier.merge_send(tr, role[1], raw, views, 0.5, drop=drop)
+            st.update(xfer_ms=s["send_ms"], bytes=float(s["bytes"]))
         elif role is not None:
-            d = hier.merge_recv(tr, role[1], raw, views, 0.5, T)
-            st.update(importance_ms=d["importance_ms"], xfer_ms=d["recv_ms"], append_ms=d["append_ms"], n_merged=float(d["n_merged"]))
+            d = hier.merge_recv(tr, role[1], raw, views, 0.5, T, drop=drop)
+            st.update(xfer_ms=d["recv_ms"], append_ms=d["append_ms"], n_merged=float(d["n_merged"]))
             del d
         torch.cuda.synchronize(dev)
         local = 1e3 * (time.perf_counter() - t0)
@@ -380,15 +395,39 @@ def main():
     info = raster.last_call_info()
     R, R_eff = info["num_rendered"], info["staged"]
 
-    # one merge level (config 4), outside the timed region; every rank takes part
+    # one merge level (config 4), outside the timed region; every rank takes part.  It is the only place where ranks exchange
+    # data, so it runs under a watchdog: if the exchange has not come back after two minutes, rank 0 prints the line without
+    # it and every rank leaves -- a stuck link must not cost the throughput measurement that is already complete.
     merge = None
-    if not args.no_extras:
+    state = {"res": None, "printed": False}
+
+    def bail():
+        if rank == 0 and state["res"] is not None and not state["printed"]:
+            state["res"]["merge"] = {"merge_ms": None, "error": "merge exchange did not complete within 120 s (watchdog)"}
+            print(json.dumps(state["res"]), flush=True)
+        os._exit(0)
+
+    import threading
+    dog = None
+    if world > 1 and not args.no_extras:
+        dog = threading.Timer(120.0, bail)
+        dog.daemon = True
+
+    def run_merge():
+        nonlocal merge
+        if args.no_extras or os.environ.get("GSR_BENCH_MERGE", "1") == "0":
+            return
         try:
             merge = merge_leg(dev, dist, world, rank, params, scene, ts, syn, deg)
         except Exception as e:   # a diagnostic must never take the bench line down
             merge = {"merge_ms": None, "error": repr(e)}
 
     if rank != 0:
+        if dog is not None:
+            dog.start()
+        run_merge()
+        if dog is not None:
+            dog.cancel()
         if dist is not None:
             dist.destroy_process_group()
         return
@@ -459,6 +498,12 @@ def main():
         "fwd_bwd_ms": fwd_ms + bwd_ms, "rasterizer_fwd_ms": fwd_ms, "rasterizer_bwd_ms": bwd_ms,
         "stage_ms": stage_ms, "step_host_ms": step_host, "roofline": roofline, "roofline_other_kernels": others,
     }
+    state["res"] = res
+    if dog is not None:
+        dog.start()
+    run_merge()
+    if dog is not None:
+        dog.cancel()
     if merge is not None:
         res["merge"] = merge
     if world == 1 and not args.no_extras:
@@ -502,7 +547,8 @@ def main():
         except Exception as e:  # the checker must never take the bench line down
             res["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": threads, "kind": "port",
                                    "sample": f"failed: {e}"}
-    print(json.dumps(res))
+    state["printed"] = True
+    print(json.dumps(res), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

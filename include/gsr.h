@@ -188,6 +188,9 @@ int gsr_version(void);
  *                          are kept per caller -- (device, image size, half-octave bucket of N) -- so models of different
  *                          size alternating on one process (teacher / student, stage-A models) do not disturb each other
  *   "reset_speculation"    forget every capacity hint and zero the counters of gsr_get_counter
+ *   "deterministic_backward" 1 = debug mode: the blend backward writes every (tile, Gaussian) partial gradient to its own slot and
+ *                          a second kernel sums each Gaussian's slots in list order -- no float atomics, bit-identical gradients
+ *                          from run to run (the default accumulates with atomics in arrival order); several times slower
  *   "profile"              1 = HIP events around every stage on the caller's stream, 2 = around the forward blend kernel
  *                          only (an event pair costs ~10 us of stream bubble per stage) */
 int gsr_set_option(const char* name, int value);

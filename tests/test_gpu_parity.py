@@ -699,3 +699,27 @@ def test_sign_encoded_forward_is_bit_identical_with_the_lane_mask_kernel():
     for v in (6, 7):      # 7 (default) adds the sub-tile reach bits: a conservative skip, the same image again
         for name, a, b in zip(("color", "radii", "depth", "alpha"), outs[5], outs[v]):
             assert np.array_equal(a, b), (v, name, int((a != b).sum()), float(np.abs(a.astype(np.float64) - b).max()))
+
+
+def test_deterministic_backward_debug_mode():
+    """gsr_set_option("deterministic_backward", 1) (optional deterministic mode for debugging): the
+    blend backward accumulates each Gaussian's gradient in list order instead of with float atomics in arrival order.
+    Two runs give the SAME BITS, and they agree with the default path within its accumulation noise."""
+    import importlib
+    import hip_runner
+    L = importlib.import_module("3dgs_hierarchical_training_amd._lib")
+    lib = L.load()
+    sc = parity.syn.make_scene(120000, 640, 360, sh_degree=3, seed=13, posed=True)
+    kw = parity.scene_kwargs(sc, "sh", bg=(0.1, 0.1, 0.2))
+    g = parity.upstream_grads(360, 640, seed=2)
+    base = hip_runner.run_hip(kw, g)["grads"]
+    try:
+        assert lib.gsr_set_option(b"deterministic_backward", 1) == 0
+        a = hip_runner.run_hip(kw, g)["grads"]
+        b = hip_runner.run_hip(kw, g)["grads"]
+    finally:
+        lib.gsr_set_option(b"deterministic_backward", 0)
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k                                    # bit-identical from run to run
+        scale = np.abs(base[k]).max()
+        assert np.abs(a[k] - base[k]).max() <= 2e-5 * scale + 1e-12, k          # and the same gradient as the atomic path
