@@ -296,3 +296,31 @@ def test_training_recovers_a_perturbed_scene(fused):
     l1 = mean_loss()
     print(f"loss {l0:.5f} -> {l1:.5f}")
     assert l1 < 0.2 * l0, (l0, l1)
+
+
+def test_extension_ops_run_under_torch_compile():
+    """The rasterizer and the fused loss are dispatcher ops with fake kernels (_ext.py): a function built from them compiles
+    (torch.compile, graph breaks allowed) and gives the eager loss and gradients."""
+    R = importlib.import_module("3dgs_hierarchical_training_amd.rasterizer")
+    Ls = importlib.import_module("3dgs_hierarchical_training_amd.loss")
+    dev = torch.device("cuda:0")
+    sc = parity.syn.make_scene(5000, 160, 120, sh_degree=3, seed=1)
+    p = ts.GaussianParams(sc, dev, optimizer="torch")
+    st = ts.make_settings(sc, dev, 3)
+    gt = parity.syn.target_image(160, 120).to(dev)
+
+    def f(xyz, dc, rest, op, sca, rot, target):
+        color = R.rasterize_gaussians_raw(xyz, torch.zeros_like(xyz), dc, rest, op, sca, rot, st)[0]
+        return Ls.fused_photometric_loss(color, target, 0.2, True)
+
+    args = [p._xyz, p._features_dc, p._features_rest, p._opacity, p._scaling, p._rotation]
+    l0 = f(*args, gt)
+    l0.backward()
+    g0 = [a.grad.clone() for a in args]
+    for a in args:
+        a.grad = None
+    l1 = torch.compile(f)(*args, gt)
+    l1.backward()
+    assert abs(float(l0.detach()) - float(l1.detach())) < 1e-6
+    for a, b in zip(g0, [a.grad for a in args]):
+        assert (a - b).abs().max().item() <= 2e-5 * a.abs().max().item() + 1e-12
