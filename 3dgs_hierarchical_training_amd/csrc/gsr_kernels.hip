@@ -1447,20 +1447,17 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(int W, int H, int tiles_x, i
                 const f2 inv = {fast_rcp(om.x), fast_rcp(om.y)};
                 const f2 dLda = gc * Tt - S * inv;
                 const f2 dLdpow = G * (op * dLda);
-                // d log2(G) / d dx, d dy (the 1/log2(e) back to natural units is applied once per record in the flush)
-                const f2 ex = fma2(f2{cb, cb}, dy, f2{2.f * adx, 2.f * adx});
-                const f2 ey = fma2(cdy, f2{2.f, 2.f}, f2{cb * dx, cb * dx});
-                const f2 t_gx = dLdpow * ex, t_gy = dLdpow * ey;
-                const f2 t_gB = dLdpow * dy;
-                const f2 t_gC = t_gB * dy;
+                // The five geometric gradients are linear in the moments of dLdpow over the pixels:
+                //   gx = B' my + 2 A' mx, gy = 2 C' my + B' mx, gA = -mxx / 2, gB = -mxy, gC = -myy / 2
+                // with mx = sum dLdpow dx, my = sum dLdpow dy, mxx = sum dLdpow dx^2, ...  Only the moments are formed and
+                // reduced here (five packed products); the per-record combination happens once, in the flush.
+                const f2 t_mx = dLdpow * dx, t_my = dLdpow * dy;
+                const f2 t_mxx = t_mx * dx, t_mxy = t_mx * dy, t_myy = t_my * dy;
                 const f2 t_op = G * dLda;
                 const f2 t_r = w * gC0, t_g = w * gC1, t_b = w * gC2;
                 float v[10];
-                v[0] = t_gx.x + t_gx.y; v[1] = t_gy.x + t_gy.y;
-                const float sdl = dLdpow.x + dLdpow.y;
-                v[2] = -0.5f * dx * dx * sdl;                    // gA
-                v[3] = -dx * (t_gB.x + t_gB.y);                  // gB
-                v[4] = -0.5f * (t_gC.x + t_gC.y);                // gC
+                v[0] = t_mx.x + t_mx.y; v[1] = t_my.x + t_my.y;
+                v[2] = t_mxx.x + t_mxx.y; v[3] = t_mxy.x + t_mxy.y; v[4] = t_myy.x + t_myy.y;
                 v[5] = t_op.x + t_op.y;
                 v[6] = t_r.x + t_r.y; v[7] = t_g.x + t_g.y; v[8] = t_b.x + t_b.y;
                 if (HAS_DA) { const f2 t_z = w * gD; v[9] = t_z.x + t_z.y; }
@@ -1481,7 +1478,14 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(int W, int H, int tiles_x, i
             const int r = tid & 15, q = tid >> 4;   // 8 groups of 16 lanes
             for (int jj = q; jj < cnt; jj += NT / 16) {
                 if (r < NV) {
-                    const float v = s_part[0][jj][r] + s_part[1][jj][r];
+                    float v = s_part[0][jj][r] + s_part[1][jj][r];
+                    if (r < 2) {        // moments -> d/d(pixel-space mean): this lane also needs the OTHER first-order moment
+                        const float mo = s_part[0][jj][r ^ 1] + s_part[1][jj][r ^ 1];
+                        const float cb = s_a[buf][jj].w;                                 // B'
+                        const float c2 = 2.f * (r == 0 ? s_a[buf][jj].z : s_b[buf][jj].x);   // 2 A' (gx) or 2 C' (gy)
+                        v = fmaf(cb, mo, c2 * v);
+                    } else if (r < 5) v *= (r == 3 ? -1.f : -0.5f);                       // second moments -> conic gradients
+                    __builtin_amdgcn_wave_barrier();   // every lane of the group has read both first moments before any is cleared
                     s_part[0][jj][r] = 0.f; s_part[1][jj][r] = 0.f;   // ready for the next batch (its writers sit behind a barrier)
                     // deterministic debug mode: the (tile, instance) partial goes to its own slot, k_det_reduce sums a
                     // Gaussian's slots in list order afterwards; default: one coalesced atomic per record row
