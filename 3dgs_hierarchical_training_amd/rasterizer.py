@@ -316,10 +316,20 @@ def _rasterize_ext(means3D, means2D, sh, colors_precomp, opacities, scales, rota
             raise RuntimeError("fused_adam needs the raw-parameter path (rasterize_gaussians_raw)")
         m, v, lr, b1, b2, eps, step = fused_adam.fused_step_plan({"xyz": means3D, "f_dc": sh, "f_rest": sh_rest, "opacity": opacities,
                                                                   "scaling": scales, "rotation": rotations})
-    return ops.rasterize(means3D, means2D, pick(sh), pick(colors_precomp), opacities, pick(scales), pick(rotations), pick(cov3Ds_precomp),
-                         pick(sh_rest), vm, pm, cp, bg, xf, int(rs.image_height), int(rs.image_width), float(rs.tanfovx),
-                         float(rs.tanfovy), float(rs.scale_modifier), int(rs.sh_degree), bool(raw_params), bool(rs.prefiltered),
-                         bool(rs.debug), bool(cam_grad), m, v, lr, b1, b2, eps, step)
+    args = (means3D, means2D, pick(sh), pick(colors_precomp), opacities, pick(scales), pick(rotations), pick(cov3Ds_precomp),
+            pick(sh_rest), vm, pm, cp, bg, xf, int(rs.image_height), int(rs.image_width), float(rs.tanfovx),
+            float(rs.tanfovy), float(rs.scale_modifier), int(rs.sh_degree), bool(raw_params), bool(rs.prefiltered),
+            bool(rs.debug), bool(cam_grad), m, v, lr, b1, b2, eps, step)
+    if not rs.debug:
+        return ops.rasterize(*args)
+    # raster_settings.debug = True: what the public module does -- on an error in the native forward, dump the arguments to
+    # snapshot_fw.dump for offline inspection and re-raise (the reference always passes debug=False, gaussian_model_ht.py:821)
+    try:
+        return ops.rasterize(*args)
+    except Exception:
+        torch.save([a.detach().cpu() if torch.is_tensor(a) else a for a in args[:24]], "snapshot_fw.dump")
+        print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
+        raise
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,

@@ -723,3 +723,22 @@ def test_deterministic_backward_debug_mode():
         assert np.array_equal(a[k], b[k]), k                                    # bit-identical from run to run
         scale = np.abs(base[k]).max()
         assert np.abs(a[k] - base[k]).max() <= 2e-5 * scale + 1e-12, k          # and the same gradient as the atomic path
+
+
+def test_debug_flag_dumps_a_snapshot_on_native_errors(tmp_path, monkeypatch):
+    """raster_settings.debug = True: an error inside the native forward leaves `snapshot_fw.dump` with the call's arguments
+    and is re-raised (the public module's behaviour; the reference passes debug=False, gaussian_model_ht.py:821)."""
+    import hip_runner
+    from diff_gaussian_rasterization import GaussianRasterizer
+    monkeypatch.chdir(tmp_path)
+    dev = torch.device("cuda:0")
+    sc = parity.syn.make_scene(64, 64, 48, sh_degree=3, seed=1)
+    kw = parity.scene_kwargs(sc, "sh")
+    rs = hip_runner.settings_from(kw, dev)._replace(debug=True)
+    shs = kw["shs"][:, :4].contiguous().to(dev)          # 4 stored coefficients but sh_degree 3 asks for 16: a native argument error
+    with pytest.raises(RuntimeError, match="gsr_forward"):
+        GaussianRasterizer(rs)(means3D=kw["means3D"].to(dev), means2D=torch.zeros(64, 3, device=dev), shs=shs, colors_precomp=None,
+                               opacities=kw["opacities"].to(dev), scales=kw["scales"].to(dev), rotations=kw["rotations"].to(dev),
+                               cov3D_precomp=None)
+    snap = torch.load(tmp_path / "snapshot_fw.dump")
+    assert torch.equal(snap[0], kw["means3D"]) and snap[14:16] == [48, 64]
