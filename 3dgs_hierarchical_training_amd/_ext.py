@@ -40,7 +40,8 @@ def _register_fakes():
 
     @torch.library.register_fake("gsr::rasterize_forward")
     def _(means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, sh_rest, viewmatrix, projmatrix, campos, bg,
-          points_transform, image_height, image_width, tanfovx, tanfovy, scale_modifier, sh_degree, raw_params, prefiltered, debug):
+          points_transform, image_height, image_width, tanfovx, tanfovy, scale_modifier, sh_degree, raw_params, prefiltered, debug,
+          prepared):
         N, H, W = means3D.shape[0], image_height, image_width
         f = lambda *s: means3D.new_empty(s, dtype=torch.float32)
         b = lambda n: means3D.new_empty((n,), dtype=torch.uint8)
@@ -52,10 +53,13 @@ def _register_fakes():
     @torch.library.register_fake("gsr::rasterize")
     def _(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, sh_rest, viewmatrix, projmatrix, campos,
           bg, points_transform, image_height, image_width, tanfovx, tanfovy, scale_modifier, sh_degree, raw_params, prefiltered, debug,
-          cam_grad, adam_m, adam_v, adam_lr, beta1, beta2, eps, step):
+          cam_grad, adam_m, adam_v, adam_lr, beta1, beta2, eps, step, prepared, next_viewmatrix, next_projmatrix, next_campos,
+          next_height, next_width, next_tanfovx, next_tanfovy):
         N, H, W = means3D.shape[0], image_height, image_width
         f = lambda *s: means3D.new_empty(s, dtype=torch.float32)
-        return f(3, H, W), means3D.new_empty((N,), dtype=torch.int32), f(1, H, W), f(1, H, W)
+        nprep = lib.gsr_prepared_bytes(int(N)) if next_viewmatrix.numel() else 0
+        return (f(3, H, W), means3D.new_empty((N,), dtype=torch.int32), f(1, H, W), f(1, H, W),
+                means3D.new_empty((nprep,), dtype=torch.uint8))
 
     @torch.library.register_fake("gsr::rasterize_backward")
     def _(means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, sh_rest, viewmatrix, projmatrix, campos, bg,

@@ -24,7 +24,7 @@ class GsrForwardArgs(C.Structure):
         ("geom", C.c_void_p), ("image", C.c_void_p),
         ("alloc", ALLOC_FN), ("alloc_user", C.c_void_p),
         ("shs_rest", C.c_void_p), ("raw_params", C.c_int32),
-        ("points_transform", C.c_void_p),
+        ("points_transform", C.c_void_p), ("prepared", C.c_void_p),
     ]
 
 
@@ -50,6 +50,7 @@ class GsrBackwardArgs(C.Structure):
         ("fused_adam", C.c_void_p),
         ("points_transform", C.c_void_p), ("d_points_transform", C.c_void_p),
         ("binning_capacity", C.c_int64), ("forward_flags", C.c_int64),
+        ("next_view", C.c_void_p), ("prepared_out", C.c_void_p),
     ]
 
 
@@ -69,7 +70,8 @@ EXPORTS = [
     "gsr_mark_visible", "gsr_last_error", "gsr_version", "gsr_set_option", "gsr_sort_pairs_u32",
     "gsr_sort_pairs_u16", "gsr_sort_scratch_bytes", "gsr_image_staged_offset", "gsr_profile_read",
     "gsr_loss_workspace_bytes", "gsr_loss_forward", "gsr_loss_backward", "gsr_adam_step",
-    "gsr_knn_scratch_bytes", "gsr_knn_mean_dist2", "gsr_get_counter", "gsr_debug_read_binning",
+    "gsr_knn_scratch_bytes", "gsr_knn_mean_dist2", "gsr_get_counter", "gsr_debug_read_binning", "gsr_prepared_bytes",
+    "gsr_prepare_supported",
 ]
 
 _lib = None
@@ -85,7 +87,9 @@ def load():
             f"{LIB_PATH} not found: the HIP extension is not built (run `python __graft_entry__.py` or "
             "`python 3dgs_hierarchical_training_amd/build.py`).  There is no CPU fallback.")
     lib = C.CDLL(LIB_PATH)
-    for fn in ["gsr_geom_bytes", "gsr_forward_scratch_bytes", "gsr_backward_scratch_bytes"]:
+    lib.gsr_prepare_supported.restype = C.c_int
+    lib.gsr_prepare_supported.argtypes = [C.c_int32, C.c_int32, C.c_int32]
+    for fn in ["gsr_geom_bytes", "gsr_forward_scratch_bytes", "gsr_backward_scratch_bytes", "gsr_prepared_bytes"]:
         getattr(lib, fn).restype = C.c_size_t
         getattr(lib, fn).argtypes = [C.c_int32]
     lib.gsr_image_bytes.restype = C.c_size_t

@@ -293,6 +293,35 @@ __device__ __forceinline__ void stage_store_lin(const float4 (&r)[KN], float* ti
 
 // q = normalize(_rotation), opacity = sigmoid(_opacity), SH = cat(_features_dc, _features_rest) -- so the
 // torch exp / sigmoid / normalize / cat kernels (and their backward) disappear from the train step.
+// Large rects (more than 32 candidate tiles) are counted by the whole wave, 64 candidate tiles per step, so one
+// screen-filling splat costs its wave rect/64 steps instead of rect steps of a single lane.  Every lane of the wave must
+// call this (it ballots and shuffles).  Shared by k_preprocess and the next-view tail of k_preprocess_bwd.
+__device__ __forceinline__ void count_large_rects(bool act, Splat& s, TileRec& rec, int W, int H, int tiles_x, int tiles_y, int tid)
+{
+    const int lane = tid & 63;
+    for (unsigned long long pm = __ballot(act && s.tiles == kTilesPending); pm != 0ull; pm &= pm - 1ull) {
+        const int src = (int)__builtin_ctzll(pm);
+        const float bpx = __shfl(s.px, src, 64), bpy = __shfl(s.py, src, 64), bca = __shfl(s.ca, src, 64);
+        const float bcb = __shfl(s.cb, src, 64), bcc = __shfl(s.cc, src, 64), bop = __shfl(s.op, src, 64);
+        const int brad = __shfl(s.radius, src, 64);
+        int x0, y0, x1, y1;
+        tile_rect_tight(bpx, bpy, brad, bca, bcb, bcc, bop, W, H, tiles_x, tiles_y, x0, y0, x1, y1);
+        const int ww = x1 - x0, full = ww * (y1 - y0);
+        const TileTest tt = make_tile_test(bpx, bpy, bca, bcb, bcc, bop);
+        uint32_t cnt = 0;
+        for (int c0 = 0; c0 < full; c0 += 64) {
+            const int c = c0 + lane;
+            bool ok = false;
+            if (c < full) {
+                const int ty = c / ww, tx = c - ty * ww;
+                ok = tile_accept(tt, x0 + tx, y0 + ty, W, H);
+            }
+            cnt += (uint32_t)__popcll(__ballot(ok));
+        }
+        if (lane == src) { s.tiles = cnt; rec.mask = cnt; }
+    }
+}
+
 template <int DEG, bool RAW>
 __global__ __launch_bounds__(kPreThreads) void k_preprocess(CamParams cp, int N, const float* __restrict__ means,
                                                             const float* __restrict__ scales, const float* __restrict__ rots,
@@ -302,12 +331,12 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess(CamParams cp, int N,
                                                             Splat* __restrict__ splat, int32_t* __restrict__ radii,
                                                             uint32_t* __restrict__ dkey, uint32_t* __restrict__ gid,
                                                             TileRec* __restrict__ tilerec, uint32_t* __restrict__ zero_words,
-                                                            int zero_count)
+                                                            int zero_count, int block0)
 {
     constexpr int NC3 = 3 * (DEG + 1) * (DEG + 1);
     __shared__ float s_sh[kPreThreads * kShStride];
     const int tid = threadIdx.x;
-    const int base = blockIdx.x * kPreThreads;
+    const int base = ((int)blockIdx.x + block0) * kPreThreads;   // block0: first block of a partial launch (0 = the whole cloud)
     const int i = base + tid;
     if (blockIdx.x == 0)   // rides along: clear the head of the depth sort's scratch (saves a fill launch)
         for (int q = tid; q < zero_count; q += kPreThreads) zero_words[q] = 0u;
@@ -381,32 +410,7 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess(CamParams cp, int N,
         }
         preprocess_one(cam, mean, sc, rq, cov_pre ? cv : nullptr, op, nullptr, 3, 1, colors ? colp : nullptr, s, &rec, true);
     }
-    // large rects (more than 32 candidate tiles): counted by the whole wave, 64 candidate tiles per step, so one
-    // screen-filling splat costs its wave rect/64 steps instead of rect steps of a single lane
-    {
-        const int lane = tid & 63;
-        for (unsigned long long pm = __ballot(act && s.tiles == kTilesPending); pm != 0ull; pm &= pm - 1ull) {
-            const int src = (int)__builtin_ctzll(pm);
-            const float bpx = __shfl(s.px, src, 64), bpy = __shfl(s.py, src, 64), bca = __shfl(s.ca, src, 64);
-            const float bcb = __shfl(s.cb, src, 64), bcc = __shfl(s.cc, src, 64), bop = __shfl(s.op, src, 64);
-            const int brad = __shfl(s.radius, src, 64);
-            int x0, y0, x1, y1;
-            tile_rect_tight(bpx, bpy, brad, bca, bcb, bcc, bop, cp.W, cp.H, cam.tiles_x, cam.tiles_y, x0, y0, x1, y1);
-            const int ww = x1 - x0, full = ww * (y1 - y0);
-            const TileTest tt = make_tile_test(bpx, bpy, bca, bcb, bcc, bop);
-            uint32_t cnt = 0;
-            for (int c0 = 0; c0 < full; c0 += 64) {
-                const int c = c0 + lane;
-                bool ok = false;
-                if (c < full) {
-                    const int ty = c / ww, tx = c - ty * ww;
-                    ok = tile_accept(tt, x0 + tx, y0 + ty, cp.W, cp.H);
-                }
-                cnt += (uint32_t)__popcll(__ballot(ok));
-            }
-            if (lane == src) { s.tiles = cnt; rec.mask = cnt; }
-        }
-    }
+    count_large_rects(act, s, rec, cp.W, cp.H, cam.tiles_x, cam.tiles_y, tid);
     // ---- phase 2: rows into the LDS tile, then the colour of the Gaussians that survived the culls
     if (shs) {
         constexpr bool kLinOk = NC3 > 3 && (NR & 1);
@@ -435,6 +439,16 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess(CamParams cp, int N,
     radii[i] = s.radius;
     dkey[i] = s.tiles > 0 ? __float_as_uint(s.depth) : 0xffffffffu;
     gid[i] = (uint32_t)i;
+}
+
+// first kernel of a forward that received a prepared buffer: radii to the caller's tensor + the clears k_preprocess's block 0 does
+__global__ __launch_bounds__(256) void k_prepared_begin(int N, const int32_t* __restrict__ radii_in, int32_t* __restrict__ radii_out,
+                                                        uint32_t* __restrict__ zero_words, int zero_count)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < N) radii_out[i] = radii_in[i];
+    if (blockIdx.x == 0)
+        for (int q = threadIdx.x; q < zero_count; q += 256) zero_words[q] = 0u;
 }
 
 __global__ void k_mark_visible(int N, const float* __restrict__ means, const float* __restrict__ vm, uint8_t* __restrict__ present)
@@ -1503,6 +1517,16 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(int W, int H, int tiles_x, i
 // gathered from LDS.  `row` floats are stored per Gaussian, of which the first `nact` have a gradient in the tile
 // (the rest -- SH bands above the active degree -- see g = 0 but still decay their moments, as dense Adam does).
 // ------------------------------------------------------------------------------------------------
+// where the next-view tail of k_preprocess_bwd<..., PREP> puts what k_preprocess would have produced for the next forward
+struct PrepOut {
+    CamParams cp;
+    Splat* splat;
+    int32_t* radii;
+    uint32_t* dkey;
+    uint32_t* gid;
+    TileRec* rec;
+};
+
 struct AdamDev {
     float* m[6];
     float* v[6];
@@ -1546,13 +1570,15 @@ __device__ __forceinline__ void adam_rows(const float* s_g, int stride, int col0
 }
 
 // the same update when the gradient tile is a linear copy of the rows (stage_in_lin): one 16-byte LDS read per 16-byte stream element
-__device__ __forceinline__ void adam_rows_lin(const float* s_g, int total, float* __restrict__ p, float* __restrict__ m,
+// KEEP: the updated parameters also replace the gradients in the tile (the next-view tail reads its Gaussian's new row there)
+template <bool KEEP>
+__device__ __forceinline__ void adam_rows_lin(float* s_g, int total, float* __restrict__ p, float* __restrict__ m,
                                               float* __restrict__ v, int tid, float step_size, const AdamDev& ad)
 {
     float4* p4 = reinterpret_cast<float4*>(p);
     float4* m4 = reinterpret_cast<float4*>(m);
     float4* v4 = reinterpret_cast<float4*>(v);
-    const float4* g4 = reinterpret_cast<const float4*>(s_g);
+    float4* g4 = reinterpret_cast<float4*>(s_g);
     if ((((uintptr_t)m | (uintptr_t)v) & 15) == 0) {
 #pragma unroll 2
         for (int q = tid; q < total / 4; q += kPreThreads) {
@@ -1563,12 +1589,14 @@ __device__ __forceinline__ void adam_rows_lin(const float* s_g, int total, float
             adam_one(pp.z, g.z, mm.z, vv.z, ad.b1, ad.b2, ad.eps, step_size, ad.inv_bc2s);
             adam_one(pp.w, g.w, mm.w, vv.w, ad.b1, ad.b2, ad.eps, step_size, ad.inv_bc2s);
             nt_store4(p4 + q, pp); nt_store4(m4 + q, mm); nt_store4(v4 + q, vv);
+            if (KEEP) g4[q] = pp;
         }
     } else {
         for (int f = tid; f < total; f += kPreThreads) {
             float pp = p[f], mm = m[f], vv = v[f];
             adam_one(pp, s_g[f], mm, vv, ad.b1, ad.b2, ad.eps, step_size, ad.inv_bc2s);
             p[f] = pp; m[f] = mm; v[f] = vv;
+            if (KEEP) s_g[f] = pp;
         }
     }
 }
@@ -1577,7 +1605,8 @@ __device__ __forceinline__ void adam_rows_lin(const float* s_g, int total, float
 // straight from its registers: neighbouring lanes touch neighbouring rows, so every fetched line is fully used, and the
 // block keeps no LDS copy of these gradients (25 instead of 30.7 kB per block: one more block per CU).
 template <int K>
-__device__ __forceinline__ void adam_own(float* p, float* m, float* v, const float* g, float step_size, const AdamDev& ad)
+__device__ __forceinline__ void adam_own(float* p, float* m, float* v, const float* g, float step_size, const AdamDev& ad,
+                                         float* updated = nullptr)
 {
     if (K == 4 && ((((uintptr_t)p | (uintptr_t)m | (uintptr_t)v) & 15) == 0)) {
         float4 pp = *reinterpret_cast<const float4*>(p);
@@ -1589,6 +1618,7 @@ __device__ __forceinline__ void adam_own(float* p, float* m, float* v, const flo
         nt_store4(reinterpret_cast<float4*>(p), pp);
         nt_store4(reinterpret_cast<float4*>(m), mm);
         nt_store4(reinterpret_cast<float4*>(v), vv);
+        if (updated) { updated[0] = pp.x; updated[1] = pp.y; updated[2] = pp.z; updated[3] = pp.w; }
         return;
     }
     float pp[K], mm[K], vv[K];
@@ -1596,6 +1626,10 @@ __device__ __forceinline__ void adam_own(float* p, float* m, float* v, const flo
     for (int c = 0; c < K; c++) { pp[c] = p[c]; mm[c] = __builtin_nontemporal_load(m + c); vv[c] = __builtin_nontemporal_load(v + c); }
 #pragma unroll
     for (int c = 0; c < K; c++) adam_one(pp[c], g[c], mm[c], vv[c], ad.b1, ad.b2, ad.eps, step_size, ad.inv_bc2s);
+    if (updated) {
+#pragma unroll
+        for (int c = 0; c < K; c++) updated[c] = pp[c];
+    }
 #pragma unroll
     for (int c = 0; c < K; c++) {
         __builtin_nontemporal_store(pp[c], p + c);
@@ -1615,7 +1649,7 @@ constexpr int kCamVals = 47;   // viewmatrix 16 + projmatrix 16 + campos 3 + poi
 // ADAM = true (needs RAW, shs + shs_rest, no cov_pre): optimizer-in-backward, see GsrFusedAdam in include/gsr.h.  The
 // parameter pointers are then read AND written by the block that owns the rows (no __restrict__ promises on them).
 
-template <int DEG, bool RAW, bool CAM, bool ADAM>
+template <int DEG, bool RAW, bool CAM, bool ADAM, bool PREP>
 __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, int N, const float* means,
                                                                 const float* scales, const float* rots,
                                                                 const float* __restrict__ cov_pre, const float* shs,
@@ -1626,11 +1660,13 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, in
                                                                 float* __restrict__ d_shs, float* __restrict__ d_shs_rest,
                                                                 float* __restrict__ d_scales,
                                                                 float* __restrict__ d_rots, float* __restrict__ d_cov,
-                                                                float* __restrict__ cam_partial)
+                                                                float* __restrict__ cam_partial, PrepOut po)
 {
     constexpr int NC3 = 3 * (DEG + 1) * (DEG + 1);
     __shared__ float s_sh[kPreThreads * kShStride];
     __shared__ float s_cam[CAM ? (kPreThreads / 64) * kCamVals : 1];
+    // PREP (with ADAM): the updated raw parameters of this thread's Gaussian, kept for the next-view tail
+    float nmean[3] = {0.f, 0.f, 0.f}, nsc[3] = {0.f, 0.f, 0.f}, nrq[4] = {1.f, 0.f, 0.f, 0.f}, nop = 0.f;
     const int tid = threadIdx.x;
     const int base = blockIdx.x * kPreThreads;
     const int i = base + tid;
@@ -1766,10 +1802,10 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, in
         d_means2d[3 * (size_t)i] = m2d[0]; d_means2d[3 * (size_t)i + 1] = m2d[1]; d_means2d[3 * (size_t)i + 2] = 0.f;
         if (ADAM) {   // this thread is the only reader of its Gaussian's small rows, and it has read them
             const size_t gi = (size_t)i;
-            adam_own<3>(const_cast<float*>(means) + 3 * gi, ad.m[0] + 3 * gi, ad.v[0] + 3 * gi, dmean, ad.step_size[0], ad);
-            adam_own<1>(const_cast<float*>(opac_raw) + gi, ad.m[3] + gi, ad.v[3] + gi, &dop, ad.step_size[3], ad);
-            adam_own<3>(const_cast<float*>(scales) + 3 * gi, ad.m[4] + 3 * gi, ad.v[4] + 3 * gi, dsc, ad.step_size[4], ad);
-            adam_own<4>(const_cast<float*>(rots) + 4 * gi, ad.m[5] + 4 * gi, ad.v[5] + 4 * gi, drq, ad.step_size[5], ad);
+            adam_own<3>(const_cast<float*>(means) + 3 * gi, ad.m[0] + 3 * gi, ad.v[0] + 3 * gi, dmean, ad.step_size[0], ad, PREP ? nmean : nullptr);
+            adam_own<1>(const_cast<float*>(opac_raw) + gi, ad.m[3] + gi, ad.v[3] + gi, &dop, ad.step_size[3], ad, PREP ? &nop : nullptr);
+            adam_own<3>(const_cast<float*>(scales) + 3 * gi, ad.m[4] + 3 * gi, ad.v[4] + 3 * gi, dsc, ad.step_size[4], ad, PREP ? nsc : nullptr);
+            adam_own<4>(const_cast<float*>(rots) + 4 * gi, ad.m[5] + 4 * gi, ad.v[5] + 4 * gi, drq, ad.step_size[5], ad, PREP ? nrq : nullptr);
         } else {
 #pragma unroll
         for (int k = 0; k < 3; k++) d_means[3 * (size_t)i + k] = dmean[k];
@@ -1817,8 +1853,44 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, in
         const size_t b = (size_t)base;
         const int rrow = cp.M * 3 - 3;
         if (lin) {
-            adam_rows_lin(s_dc, nG * 3, const_cast<float*>(shs) + b * 3, ad.m[1] + b * 3, ad.v[1] + b * 3, tid, ad.step_size[1], ad);
-            adam_rows_lin(s_rest, nG * NRL, const_cast<float*>(shs_rest) + b * NRL, ad.m[2] + b * NRL, ad.v[2] + b * NRL, tid, ad.step_size[2], ad);
+            adam_rows_lin<PREP>(s_dc, nG * 3, const_cast<float*>(shs) + b * 3, ad.m[1] + b * 3, ad.v[1] + b * 3, tid, ad.step_size[1], ad);
+            adam_rows_lin<PREP>(s_rest, nG * NRL, const_cast<float*>(shs_rest) + b * NRL, ad.m[2] + b * NRL, ad.v[2] + b * NRL, tid, ad.step_size[2], ad);
+            if (!PREP) return;
+            // ---- next-view tail ("prepare in backward", GsrNextView): this block holds the UPDATED parameters of its 128
+            // Gaussians -- the small groups in the owners' registers, the SH rows in the LDS tile -- so it runs the forward
+            // preprocess of the NEXT render on them right here: the next gsr_forward skips k_preprocess (no second read of the
+            // 236 bytes per Gaussian, and ~2 400 VALU instructions per wave that hide under this kernel's HBM time).
+            // Same functions, same order of operations as k_preprocess<DEG, true>: the records are bit-identical.
+            __syncthreads();
+            const bool act = i < N;
+            Camera cam2 = load_camera(po.cp);
+            cam2.D = DEG;
+            Splat s2;
+            TileRec rec2;
+            float mean2[3] = {nmean[0], nmean[1], nmean[2]};
+            if (act) {
+                apply_points_transform(po.cp.xf, mean2);
+                float sc2[3], rq2[4] = {nrq[0], nrq[1], nrq[2], nrq[3]};
+#pragma unroll
+                for (int k = 0; k < 3; k++) sc2[k] = expf(nsc[k]);
+                const float inv = 1.0f / fmaxf(sqrtf(rq2[0] * rq2[0] + rq2[1] * rq2[1] + rq2[2] * rq2[2] + rq2[3] * rq2[3]), 1e-12f);
+#pragma unroll
+                for (int k = 0; k < 4; k++) rq2[k] *= inv;
+                const float op2 = 1.0f / (1.0f + expf(-nop));
+                preprocess_one(cam2, mean2, sc2, rq2, nullptr, op2, nullptr, 3, 1, nullptr, s2, &rec2, true);
+            }
+            count_large_rects(act, s2, rec2, po.cp.W, po.cp.H, cam2.tiles_x, cam2.tiles_y, tid);
+            if (act && s2.radius > 0) {
+                float col[3];
+                splat_sh_color(cam2, mean2, s_rest + tid * NRL - 3, 3, 1, col, s_dc + tid * 3);
+                s2.r = col[0]; s2.g = col[1]; s2.b = col[2];
+            }
+            if (!act) return;
+            po.splat[i] = s2;
+            po.rec[i] = rec2;
+            po.radii[i] = s2.radius;
+            po.dkey[i] = s2.tiles > 0 ? __float_as_uint(s2.depth) : 0xffffffffu;
+            po.gid[i] = (uint32_t)i;
             return;
         }
         adam_rows(s_sh, kShStride, 0, 3, 3, const_cast<float*>(shs) + b * 3, ad.m[1] + b * 3, ad.v[1] + b * 3, nG, tid, ad.step_size[1], ad);
@@ -1928,6 +2000,23 @@ static GeomLayout geom_layout(int32_t N)
     g.splat = 0;
     g.total = align256((size_t)(N > 0 ? N : 1) * sizeof(Splat));
     return g;
+}
+
+struct PrepLayout {   // "prepare in backward": what k_preprocess would have produced, handed from gsr_backward to the next gsr_forward
+    size_t splat, radii, dkey, gid, rec, bytes;
+};
+static PrepLayout prep_layout(int32_t N)
+{
+    const size_t n = (size_t)(N > 0 ? N : 1);
+    PrepLayout p;
+    size_t o = 0;
+    p.splat = o; o += align256(n * sizeof(Splat));   // == geom_layout(N): the buffer doubles as the forward's `geom`
+    p.radii = o; o += align256(n * 4);
+    p.dkey = o; o += align256(n * 4);
+    p.gid = o; o += align256(n * 4);
+    p.rec = o; o += align256(n * sizeof(TileRec));
+    p.bytes = o;
+    return p;
 }
 
 struct FwdScratch {   // N-sized scratch of the forward
@@ -2101,6 +2190,8 @@ size_t gsr_backward_scratch_bytes(int32_t N)
     return align256(n * kGG * 4) + align256(((n + kPreThreads - 1) / kPreThreads) * kCamVals * 4);
 }
 size_t gsr_sort_scratch_bytes(uint32_t n) { return radix_scratch_bytes(n); }
+size_t gsr_prepared_bytes(int32_t N) { return prep_layout(N).bytes; }
+int gsr_prepare_supported(int32_t M, int32_t D, int32_t raw_params) { return (raw_params && M == 16 && D == 3) ? 1 : 0; }
 const char* gsr_last_error(void) { return g_err; }
 int gsr_version(void) { return 100; }
 
@@ -2299,10 +2390,23 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
     // block 0 of k_preprocess clears the head (digit histograms + tickets) of the depth sort's scratch
     uint32_t* zero_words = depth_onesweep ? reinterpret_cast<uint32_t*>(fs + L.sort) : nullptr;
     const int zero_count = depth_onesweep ? (int)kOnesweepHeadWords : 0;
+    if (a->prepared) {
+        // "prepare in backward": the preceding gsr_backward already ran the preprocess of this render on the updated
+        // parameters (k_preprocess_bwd<..., PREP>); its records, sort keys and tile records are taken from the hand-over buffer
+        if (a->prepared != a->geom) return fail(GSR_ERR_ARG, "prepared: geom must be the prepared buffer itself%s");
+        const PrepLayout PL = prep_layout(N);
+        uint8_t* pb = static_cast<uint8_t*>(a->prepared);
+        dkey = reinterpret_cast<uint32_t*>(pb + PL.dkey);
+        gid = reinterpret_cast<uint32_t*>(pb + PL.gid);
+        ntiles = reinterpret_cast<TileRec*>(pb + PL.rec);
+        ProfScope ps(P_PRE_FWD, st);
+        hipLaunchKernelGGL(k_prepared_begin, dim3((N + 255) / 256), dim3(256), 0, st, N, reinterpret_cast<const int32_t*>(pb + PL.radii),
+                           a->radii, zero_words, zero_count);
+    } else {
 #define GSR_PRE_(DEG, RAW)                                                                                                          \
     hipLaunchKernelGGL((k_preprocess<DEG, RAW>), dim3(grid), dim3(kPreThreads), 0, st, cp, N, a->means3D, a->scales, a->rotations, \
                        a->cov3D_precomp, a->opacities, a->shs, a->shs_rest, a->colors_precomp, splat, a->radii, dkey, gid, ntiles,  \
-                       zero_words, zero_count)
+                       zero_words, zero_count, 0)
 #define GSR_PRE(DEG) do { if (a->raw_params) GSR_PRE_(DEG, true); else GSR_PRE_(DEG, false); } while (0)
     {
         ProfScope ps(P_PRE_FWD, st);
@@ -2315,6 +2419,7 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
     }
 #undef GSR_PRE
 #undef GSR_PRE_
+    }
     int in_alt = 0;
     {
         ProfScope ps(P_SORT_DEPTH, st);
@@ -2482,24 +2587,52 @@ int gsr_backward(const GsrBackwardArgs* a, void* stream_)
         ad.inv_bc2s = 1.f / (float)sqrt(1.0 - pow((double)fa->beta2, (double)fa->step));
     } else if (!a->d_means3D || !a->d_opacities)
         return fail(GSR_ERR_ARG, "missing workspace / gradient pointer%s");
-#define GSR_PREB_(DEG, RAW, CAM, ADAM)                                                                                                      \
-    hipLaunchKernelGGL((k_preprocess_bwd<DEG, RAW, CAM, ADAM>), dim3(grid), dim3(kPreThreads), 0, st, cp, N, a->means3D, a->scales,        \
+    // "prepare in backward": the next render's preprocess rides in the per-Gaussian kernel (see GsrNextView)
+    PrepOut po = {};
+    const GsrNextView* nv = a->next_view;
+    if (nv) {
+        if (!fa || !gsr_prepare_supported(a->M, a->D, a->raw_params) || nv->D != 3 || !a->prepared_out || !nv->viewmatrix || !nv->projmatrix ||
+            !nv->campos || nv->W <= 0 || nv->H <= 0 || ((((uintptr_t)a->shs | (uintptr_t)a->shs_rest) & 15) != 0))
+            return fail(GSR_ERR_ARG, "next_view needs fused_adam, raw_params, M = 16, D = 3, 16-byte aligned SH tensors and a prepared_out buffer%s");
+        const PrepLayout PL = prep_layout(N);
+        uint8_t* pb = static_cast<uint8_t*>(a->prepared_out);
+        po.cp = {nv->viewmatrix, nv->projmatrix, nv->campos, nv->tanfovx, nv->tanfovy, nv->scale_modifier, nv->W, nv->H, nv->D, a->M, nv->points_transform};
+        po.splat = reinterpret_cast<Splat*>(pb + PL.splat);
+        po.radii = reinterpret_cast<int32_t*>(pb + PL.radii);
+        po.dkey = reinterpret_cast<uint32_t*>(pb + PL.dkey);
+        po.gid = reinterpret_cast<uint32_t*>(pb + PL.gid);
+        po.rec = reinterpret_cast<TileRec*>(pb + PL.rec);
+    }
+#define GSR_PREB_(DEG, RAW, CAM, ADAM, PREP)                                                                                                \
+    hipLaunchKernelGGL((k_preprocess_bwd<DEG, RAW, CAM, ADAM, PREP>), dim3(grid), dim3(kPreThreads), 0, st, cp, N, a->means3D, a->scales,  \
                        a->rotations, a->cov3D_precomp, a->shs, a->shs_rest, a->opacities, ad, splat, gg, a->d_means3D, a->d_means2D,        \
                        a->d_opacities, a->d_colors_precomp, a->d_shs, a->d_shs_rest, a->d_scales, a->d_rotations, a->d_cov3D_precomp,      \
-                       cam_partial)
+                       cam_partial, po)
 #define GSR_PREB(DEG)                                                     \
     do {                                                                  \
-        if (fa) { if (want_cam) GSR_PREB_(DEG, true, true, true); else GSR_PREB_(DEG, true, false, true); }                 \
-        else if (a->raw_params) { if (want_cam) GSR_PREB_(DEG, true, true, false); else GSR_PREB_(DEG, true, false, false); }   \
-        else { if (want_cam) GSR_PREB_(DEG, false, true, false); else GSR_PREB_(DEG, false, false, false); }               \
+        if (fa) { if (want_cam) GSR_PREB_(DEG, true, true, true, false); else GSR_PREB_(DEG, true, false, true, false); }                 \
+        else if (a->raw_params) { if (want_cam) GSR_PREB_(DEG, true, true, false, false); else GSR_PREB_(DEG, true, false, false, false); }   \
+        else { if (want_cam) GSR_PREB_(DEG, false, true, false, false); else GSR_PREB_(DEG, false, false, false, false); }               \
     } while (0)
     {
         ProfScope ps(P_PRE_BWD, st);
+        if (nv) {   // D = 3 (checked above)
+            if (want_cam) GSR_PREB_(3, true, true, true, true); else GSR_PREB_(3, true, false, true, true);
+            // a ragged last block whose rows do not form whole 16-byte vectors takes the kernel's general (non-linear) tile
+            // path, which has no next-view tail: the ordinary preprocess runs on that one block, on the updated parameters
+            const int nlast = N - (grid - 1) * kPreThreads;
+            const bool last_lin = (nlast % 4) == 0;   // (the tensors' 16-byte alignment was checked above)
+            if (!last_lin)
+                hipLaunchKernelGGL((k_preprocess<3, true>), dim3(1), dim3(kPreThreads), 0, st, po.cp, N, a->means3D, a->scales, a->rotations,
+                                   (const float*)nullptr, a->opacities, a->shs, a->shs_rest, (const float*)nullptr, po.splat, po.radii, po.dkey,
+                                   po.gid, po.rec, (uint32_t*)nullptr, 0, grid - 1);
+        } else {
         switch (a->shs ? a->D : 0) {
             case 0: GSR_PREB(0); break;
             case 1: GSR_PREB(1); break;
             case 2: GSR_PREB(2); break;
             default: GSR_PREB(3); break;
+        }
         }
     }
 #undef GSR_PREB

@@ -83,7 +83,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> raste
     const Tensor& means3D_, const Tensor& sh_, const Tensor& colors_, const Tensor& opacities_, const Tensor& scales_,
     const Tensor& rotations_, const Tensor& cov3D_, const Tensor& sh_rest_, const Tensor& viewmatrix_, const Tensor& projmatrix_,
     const Tensor& campos_, const Tensor& bg_, const Tensor& xf_, int64_t H, int64_t W, double tanfovx, double tanfovy,
-    double scale_modifier, int64_t sh_degree, bool raw_params, bool prefiltered, bool debug)
+    double scale_modifier, int64_t sh_degree, bool raw_params, bool prefiltered, bool debug, const Tensor& prepared)
 {
     TORCH_CHECK(means3D_.is_cuda(), "GaussianRasterizer: tensors must be on a ROCm/HIP device (no CPU fallback)");
     const c10::hip::HIPGuardMasqueradingAsCUDA guard(means3D_.device());
@@ -96,7 +96,12 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> raste
     const auto bo = means3D.options().dtype(at::kByte);
     Tensor color = at::empty({3, H, W}, fo), depth = at::empty({1, H, W}, fo), alpha = at::empty({1, H, W}, fo);
     Tensor radii = at::empty({N}, means3D.options().dtype(at::kInt));
-    Tensor geom = at::empty({(int64_t)gsr_geom_bytes((int32_t)N)}, bo);
+    // "prepare in backward": the preceding backward already produced this render's splat records (+ keys, tile records) in
+    // `prepared`; that buffer then IS the geometry workspace and the preprocess kernel is skipped
+    if (has(prepared))
+        TORCH_CHECK(prepared.is_contiguous() && prepared.scalar_type() == at::kByte &&
+                        prepared.numel() == (int64_t)gsr_prepared_bytes((int32_t)N), "prepared buffer does not belong to this model");
+    Tensor geom = has(prepared) ? prepared : at::empty({(int64_t)gsr_geom_bytes((int32_t)N)}, bo);
     Tensor image = at::empty({(int64_t)gsr_image_bytes((int32_t)W, (int32_t)H)}, bo);
     AllocCtx actx{bo, Tensor(), {}};
 
@@ -113,6 +118,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> raste
     a.alloc = alloc_cb; a.alloc_user = &actx;
     a.shs_rest = fp(rest); a.raw_params = raw_params;
     a.points_transform = fp(xf);
+    a.prepared = has(prepared) ? prepared.data_ptr() : nullptr;
     GsrForwardOut out{};
     check(gsr_forward(&a, &out, c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()), "gsr_forward");
     // (scratch tensors die here: stream-ordered reuse by the caching allocator is safe, same stream)
@@ -194,7 +200,9 @@ std::vector<Tensor> rasterize_backward_fused(
     const Tensor& bg, const Tensor& xf, const Tensor& geom, const Tensor& image, const Tensor& binning, const Tensor& meta,
     const Tensor& grad_color, const Tensor& grad_depth, const Tensor& grad_alpha, int64_t H, int64_t W, double tanfovx, double tanfovy,
     double scale_modifier, int64_t sh_degree, bool need_vm, bool need_pm, bool need_campos, bool need_xf, at::TensorList adam_m,
-    at::TensorList adam_v, at::ArrayRef<double> adam_lr, double beta1, double beta2, double eps, int64_t step)
+    at::TensorList adam_v, at::ArrayRef<double> adam_lr, double beta1, double beta2, double eps, int64_t step, const Tensor& next_vm,
+    const Tensor& next_pm, const Tensor& next_campos, int64_t next_H, int64_t next_W, double next_tanfovx, double next_tanfovy,
+    Tensor prepared_out)
 {
     const c10::hip::HIPGuardMasqueradingAsCUDA guard(means3D.device());
     TORCH_CHECK(adam_m.size() == 6 && adam_v.size() == 6 && adam_lr.size() == 6, "fused_adam: six groups expected");
@@ -221,6 +229,15 @@ std::vector<Tensor> rasterize_backward_fused(
     a.d_viewmatrix = fpm(d_vm); a.d_projmatrix = fpm(d_pm); a.d_campos = fpm(d_cp); a.d_points_transform = fpm(d_xf);
     a.scratch = scratch.data_ptr();
     a.fused_adam = &fa;
+    GsrNextView nv{};
+    const Tensor nvm = f32c(next_vm), npm = f32c(next_pm), ncp = f32c(next_campos);
+    if (has(prepared_out)) {   // "prepare in backward": this kernel also runs the NEXT render's preprocess on the updated parameters
+        nv.W = (int32_t)next_W; nv.H = (int32_t)next_H; nv.D = (int32_t)sh_degree;
+        nv.scale_modifier = (float)scale_modifier; nv.tanfovx = (float)next_tanfovx; nv.tanfovy = (float)next_tanfovy;
+        nv.viewmatrix = fp(nvm); nv.projmatrix = fp(npm); nv.campos = fp(ncp); nv.points_transform = fp(xf);
+        a.next_view = &nv;
+        a.prepared_out = prepared_out.data_ptr();
+    }
     check(gsr_backward(&a, c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()), "gsr_backward");
     return {d_means2D, d_vm, d_pm, d_cp, d_xf};
 }
@@ -235,6 +252,10 @@ struct Cfg {
     bool raw_params, prefiltered, debug, cam_grad;
     std::vector<double> adam_lr;
     std::vector<Tensor> adam_m, adam_v;   // optimizer moments: plain buffers, not autograd inputs
+    Tensor prepared;                      // input: hand-over buffer of the preceding backward (or undefined)
+    Tensor next_vm, next_pm, next_campos; // camera of the NEXT render (or undefined): the backward prepares it
+    int64_t next_H = 0, next_W = 0;
+    double next_tanfovx = 0, next_tanfovy = 0;
 };
 
 class RasterizeFn : public torch::autograd::Function<RasterizeFn> {
@@ -250,8 +271,13 @@ class RasterizeFn : public torch::autograd::Function<RasterizeFn> {
         // float32 + contiguous once, here: the SAME tensors are saved for the backward
         const Tensor m3 = f32c(means3D), s = f32c(sh), c = f32c(colors), o = f32c(opac), sc = f32c(scales), r = f32c(rots), cv = f32c(cov),
                      rs = f32c(rest), v = f32c(vm), p = f32c(pm), cp = f32c(campos), b = f32c(bg), x = f32c(has(xf) ? xf.slice(0, 0, 3) : xf);
+        Tensor none;
         auto out = op.call(m3, s, c, o, sc, r, cv, rs, v, p, cp, b, x, cfg.H, cfg.W, cfg.tanfovx, cfg.tanfovy, cfg.scale_modifier,
-                           cfg.sh_degree, cfg.raw_params, cfg.prefiltered, cfg.debug);
+                           cfg.sh_degree, cfg.raw_params, cfg.prefiltered, cfg.debug, cfg.prepared.defined() ? cfg.prepared : x.new_empty({0}, x.options().dtype(at::kByte)));
+        // hand-over buffer for the NEXT render, filled by this render's backward (stream-ordered): allocated here so that it
+        // can be returned to the caller as an ordinary output
+        Tensor prep_out = has(cfg.next_vm) ? at::empty({(int64_t)gsr_prepared_bytes((int32_t)m3.size(0))}, m3.options().dtype(at::kByte))
+                                           : at::empty({0}, m3.options().dtype(at::kByte));
         // NOTE: depth is deliberately NOT saved -- the caller mutates it in place (ht3dgs_trainer.py:1290-1292)
         std::vector<Tensor> saved = {m3, s, c, o, sc, r, cv, rs, v, p, cp, b, x, std::get<4>(out), std::get<5>(out), std::get<6>(out),
                                      std::get<7>(out)};
@@ -265,9 +291,14 @@ class RasterizeFn : public torch::autograd::Function<RasterizeFn> {
         ctx->saved_data["eps"] = cfg.eps; ctx->saved_data["step"] = cfg.adam_step;
         ctx->saved_data["xf_rows"] = has(xf) ? xf.size(0) : (int64_t)0;
         ctx->saved_data["done"] = false;
-        ctx->mark_non_differentiable({std::get<1>(out)});
+        ctx->saved_data["prep_out"] = prep_out;
+        ctx->saved_data["next_cam"] = std::vector<Tensor>{has(cfg.next_vm) ? f32c(cfg.next_vm) : x, has(cfg.next_vm) ? f32c(cfg.next_pm) : x,
+                                                          has(cfg.next_vm) ? f32c(cfg.next_campos) : x};
+        ctx->saved_data["next_H"] = cfg.next_H; ctx->saved_data["next_W"] = cfg.next_W;
+        ctx->saved_data["next_tfx"] = cfg.next_tanfovx; ctx->saved_data["next_tfy"] = cfg.next_tanfovy;
+        ctx->mark_non_differentiable({std::get<1>(out), prep_out});
         ctx->set_materialize_grads(false);   // unused depth / alpha outputs arrive undefined -> specialised backward
-        return {std::get<0>(out), std::get<1>(out), std::get<2>(out), std::get<3>(out)};
+        return {std::get<0>(out), std::get<1>(out), std::get<2>(out), std::get<3>(out), prep_out};
     }
 
     static torch::autograd::variable_list backward(torch::autograd::AutogradContext* ctx, torch::autograd::variable_list g)
@@ -294,10 +325,13 @@ class RasterizeFn : public torch::autograd::Function<RasterizeFn> {
             static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("gsr::rasterize_backward_fused", "").typed<decltype(rasterize_backward_fused)>();
             std::vector<Tensor> m = ctx->saved_data["adam_m"].toTensorVector(), v = ctx->saved_data["adam_v"].toTensorVector();
             auto lr = ctx->saved_data["lr"].toDoubleVector();
+            auto nc = ctx->saved_data["next_cam"].toTensorVector();
             auto r = op.call(sv[0], sv[1], sv[7], sv[3], sv[4], sv[5], sv[8], sv[9], sv[10], sv[11], sv[12], sv[13], sv[14], sv[15], sv[16],
                              orE(gc), orE(gd), orE(ga), H, W, tfx, tfy, smod, D, need_vm, need_pm, need_cp, need_xf, m, v, lr,
                              ctx->saved_data["b1"].toDouble(), ctx->saved_data["b2"].toDouble(), ctx->saved_data["eps"].toDouble(),
-                             ctx->saved_data["step"].toInt());
+                             ctx->saved_data["step"].toInt(), nc[0], nc[1], nc[2], ctx->saved_data["next_H"].toInt(),
+                             ctx->saved_data["next_W"].toInt(), ctx->saved_data["next_tfx"].toDouble(), ctx->saved_data["next_tfy"].toDouble(),
+                             ctx->saved_data["prep_out"].toTensor());
             out[1] = r[0]; out[9] = r[1]; out[10] = r[2]; out[11] = r[3]; d_xf = r[4];
         } else {
             static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("gsr::rasterize_backward", "").typed<decltype(rasterize_backward)>();
@@ -312,31 +346,40 @@ class RasterizeFn : public torch::autograd::Function<RasterizeFn> {
     }
 };
 
-std::tuple<Tensor, Tensor, Tensor, Tensor> rasterize(
+std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> rasterize(
     const Tensor& means3D, const Tensor& means2D, const Tensor& sh, const Tensor& colors, const Tensor& opac, const Tensor& scales,
     const Tensor& rots, const Tensor& cov, const Tensor& rest, const Tensor& vm, const Tensor& pm, const Tensor& campos, const Tensor& bg,
     const Tensor& xf, int64_t H, int64_t W, double tanfovx, double tanfovy, double scale_modifier, int64_t sh_degree, bool raw_params,
     bool prefiltered, bool debug, bool cam_grad, at::TensorList adam_m, at::TensorList adam_v, at::ArrayRef<double> adam_lr, double beta1,
-    double beta2, double eps, int64_t step)
+    double beta2, double eps, int64_t step, const Tensor& prepared, const Tensor& next_vm, const Tensor& next_pm, const Tensor& next_campos,
+    int64_t next_H, int64_t next_W, double next_tanfovx, double next_tanfovy)
 {
     Cfg cfg{H, W, sh_degree, step, tanfovx, tanfovy, scale_modifier, beta1, beta2, eps, raw_params, prefiltered, debug, cam_grad,
             std::vector<double>(adam_lr.begin(), adam_lr.end()), adam_m.vec(), adam_v.vec()};
+    if (has(prepared)) cfg.prepared = prepared;
+    if (has(next_vm)) {
+        TORCH_CHECK(!adam_m.empty(), "prepare_next needs fused_adam (the backward that applies the update prepares the next render)");
+        cfg.next_vm = next_vm; cfg.next_pm = next_pm; cfg.next_campos = next_campos;
+        cfg.next_H = next_H; cfg.next_W = next_W; cfg.next_tanfovx = next_tanfovx; cfg.next_tanfovy = next_tanfovy;
+    }
     auto r = RasterizeFn::apply(means3D, means2D, sh, colors, opac, scales, rots, cov, rest, vm, pm, campos, bg, xf, cfg);
-    return {r[0], r[1], r[2], r[3]};
+    return {r[0], r[1], r[2], r[3], r[4]};
 }
 
 // tensors without an autograd key (torch.inference_mode): the forward alone
-std::tuple<Tensor, Tensor, Tensor, Tensor> rasterize_forward_only(
+std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> rasterize_forward_only(
     const Tensor& means3D, const Tensor& means2D, const Tensor& sh, const Tensor& colors, const Tensor& opac, const Tensor& scales,
     const Tensor& rots, const Tensor& cov, const Tensor& rest, const Tensor& vm, const Tensor& pm, const Tensor& campos, const Tensor& bg,
     const Tensor& xf, int64_t H, int64_t W, double tanfovx, double tanfovy, double scale_modifier, int64_t sh_degree, bool raw_params,
     bool prefiltered, bool debug, bool cam_grad, at::TensorList adam_m, at::TensorList adam_v, at::ArrayRef<double> adam_lr, double beta1,
-    double beta2, double eps, int64_t step)
+    double beta2, double eps, int64_t step, const Tensor& prepared, const Tensor& next_vm, const Tensor& next_pm, const Tensor& next_campos,
+    int64_t next_H, int64_t next_W, double next_tanfovx, double next_tanfovy)
 {
     (void)means2D; (void)cam_grad; (void)adam_m; (void)adam_v; (void)adam_lr; (void)beta1; (void)beta2; (void)eps; (void)step;
+    (void)next_vm; (void)next_pm; (void)next_campos; (void)next_H; (void)next_W; (void)next_tanfovx; (void)next_tanfovy;
     auto out = rasterize_forward(means3D, sh, colors, opac, scales, rots, cov, rest, vm, pm, campos, bg, has(xf) ? xf.slice(0, 0, 3) : xf, H, W,
-                                 tanfovx, tanfovy, scale_modifier, sh_degree, raw_params, prefiltered, debug);
-    return {std::get<0>(out), std::get<1>(out), std::get<2>(out), std::get<3>(out)};
+                                 tanfovx, tanfovy, scale_modifier, sh_degree, raw_params, prefiltered, debug, prepared);
+    return {std::get<0>(out), std::get<1>(out), std::get<2>(out), std::get<3>(out), at::empty({0}, means3D.options().dtype(at::kByte))};
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -421,7 +464,7 @@ TORCH_LIBRARY(gsr, m)
     m.def("rasterize_forward(Tensor means3D, Tensor sh, Tensor colors_precomp, Tensor opacities, Tensor scales, Tensor rotations, "
           "Tensor cov3D_precomp, Tensor sh_rest, Tensor viewmatrix, Tensor projmatrix, Tensor campos, Tensor bg, Tensor points_transform, "
           "int image_height, int image_width, float tanfovx, float tanfovy, float scale_modifier, int sh_degree, bool raw_params, "
-          "bool prefiltered, bool debug) -> (Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)");
+          "bool prefiltered, bool debug, Tensor prepared) -> (Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)");
     m.def("rasterize_backward(Tensor means3D, Tensor sh, Tensor colors_precomp, Tensor opacities, Tensor scales, Tensor rotations, "
           "Tensor cov3D_precomp, Tensor sh_rest, Tensor viewmatrix, Tensor projmatrix, Tensor campos, Tensor bg, Tensor points_transform, "
           "Tensor geom, Tensor image, Tensor binning, Tensor meta, Tensor grad_color, Tensor grad_depth, Tensor grad_alpha, "
@@ -432,12 +475,14 @@ TORCH_LIBRARY(gsr, m)
           "Tensor image, Tensor binning, Tensor meta, Tensor grad_color, Tensor grad_depth, Tensor grad_alpha, int image_height, "
           "int image_width, float tanfovx, float tanfovy, float scale_modifier, int sh_degree, bool need_viewmatrix, bool need_projmatrix, "
           "bool need_campos, bool need_points_transform, Tensor(g!)[] adam_m, Tensor(h!)[] adam_v, float[] adam_lr, float beta1, "
-          "float beta2, float eps, int step) -> Tensor[]");
+          "float beta2, float eps, int step, Tensor next_viewmatrix, Tensor next_projmatrix, Tensor next_campos, int next_height, "
+          "int next_width, float next_tanfovx, float next_tanfovy, Tensor(i!) prepared_out) -> Tensor[]");
     m.def("rasterize(Tensor means3D, Tensor means2D, Tensor sh, Tensor colors_precomp, Tensor opacities, Tensor scales, Tensor rotations, "
           "Tensor cov3D_precomp, Tensor sh_rest, Tensor viewmatrix, Tensor projmatrix, Tensor campos, Tensor bg, Tensor points_transform, "
           "int image_height, int image_width, float tanfovx, float tanfovy, float scale_modifier, int sh_degree, bool raw_params, "
           "bool prefiltered, bool debug, bool cam_grad, Tensor[] adam_m, Tensor[] adam_v, float[] adam_lr, float beta1, float beta2, "
-          "float eps, int step) -> (Tensor, Tensor, Tensor, Tensor)");
+          "float eps, int step, Tensor prepared, Tensor next_viewmatrix, Tensor next_projmatrix, Tensor next_campos, int next_height, "
+          "int next_width, float next_tanfovx, float next_tanfovy) -> (Tensor, Tensor, Tensor, Tensor, Tensor)");
     m.def("mark_visible(Tensor means3D, Tensor viewmatrix, Tensor projmatrix) -> Tensor");
     m.def("photometric_loss_forward(Tensor render, Tensor target, float lambda_dssim, bool clamp) -> (Tensor, Tensor)");
     m.def("photometric_loss_backward(Tensor render, Tensor target, Tensor workspace, Tensor grad_loss, float lambda_dssim, bool clamp) -> Tensor");

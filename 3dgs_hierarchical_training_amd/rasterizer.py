@@ -293,7 +293,7 @@ def _e(dev):
 
 
 def _rasterize_ext(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, rs, sh_rest, raw_params,
-                   fused_adam, points_transform):
+                   fused_adam, points_transform, prepared=None, prepare_next=None):
     """torch.ops.gsr.rasterize: empty tensors stand for None; the camera tensors of the settings tuple are ordinary inputs
     (their gradients are produced when one of them requires grad)."""
     ops = E.load()
@@ -316,16 +316,31 @@ def _rasterize_ext(means3D, means2D, sh, colors_precomp, opacities, scales, rota
             raise RuntimeError("fused_adam needs the raw-parameter path (rasterize_gaussians_raw)")
         m, v, lr, b1, b2, eps, step = fused_adam.fused_step_plan({"xyz": means3D, "f_dc": sh, "f_rest": sh_rest, "opacity": opacities,
                                                                   "scaling": scales, "rotation": rotations})
+    eb = _EMPTY.get(("u8", dev))
+    if eb is None:
+        eb = _EMPTY[("u8", dev)] = torch.empty(0, dtype=torch.uint8, device=dev)
+    nx = prepare_next
+    if nx is not None:
+        if fused_adam is None:
+            raise RuntimeError("prepare_next needs fused_adam: the backward that applies the update prepares the next render")
+        if int(nx.sh_degree) != int(rs.sh_degree) or float(nx.scale_modifier) != float(rs.scale_modifier) or int(rs.sh_degree) != 3:
+            raise RuntimeError("prepare_next: the next view must use sh_degree 3 and this view's scale_modifier")
+        nvm, npm, ncp = nx.viewmatrix.to(dev), nx.projmatrix.to(dev), nx.campos.to(dev)
     args = (means3D, means2D, pick(sh), pick(colors_precomp), opacities, pick(scales), pick(rotations), pick(cov3Ds_precomp),
             pick(sh_rest), vm, pm, cp, bg, xf, int(rs.image_height), int(rs.image_width), float(rs.tanfovx),
             float(rs.tanfovy), float(rs.scale_modifier), int(rs.sh_degree), bool(raw_params), bool(rs.prefiltered),
-            bool(rs.debug), bool(cam_grad), m, v, lr, b1, b2, eps, step)
+            bool(rs.debug), bool(cam_grad), m, v, lr, b1, b2, eps, step,
+            eb if prepared is None else prepared, e if nx is None else nvm, e if nx is None else npm, e if nx is None else ncp,
+            0 if nx is None else int(nx.image_height), 0 if nx is None else int(nx.image_width),
+            0.0 if nx is None else float(nx.tanfovx), 0.0 if nx is None else float(nx.tanfovy))
     if not rs.debug:
-        return ops.rasterize(*args)
+        out = ops.rasterize(*args)
+        return out if nx is not None else out[:4]
     # raster_settings.debug = True: what the public module does -- on an error in the native forward, dump the arguments to
     # snapshot_fw.dump for offline inspection and re-raise (the reference always passes debug=False, gaussian_model_ht.py:821)
     try:
-        return ops.rasterize(*args)
+        out = ops.rasterize(*args)
+        return out if nx is not None else out[:4]
     except Exception:
         torch.save([a.detach().cpu() if torch.is_tensor(a) else a for a in args[:24]], "snapshot_fw.dump")
         print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
@@ -342,7 +357,7 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
 
 
 def rasterize_gaussians_raw(means3D, means2D, features_dc, features_rest, opacity_logit, log_scales, rotations_raw,
-                            raster_settings, fused_adam=None, points_transform=None):
+                            raster_settings, fused_adam=None, points_transform=None, prepared=None, prepare_next=None):
     """Extension ("next" row f-2): rasterize straight from HTGaussianModel's raw parameters (_xyz, _features_dc,
     _features_rest, _opacity, _scaling, _rotation; /root/reference/scene/gaussian_model_ht.py:74-82) with the
     activations of :49-65,128-133,176-188 fused into the HIP kernels; gradients are w.r.t. the raw tensors.
@@ -354,10 +369,18 @@ def rasterize_gaussians_raw(means3D, means2D, features_dc, features_rest, opacit
 
     points_transform = [3,4] / [4,4] tensor M: every mean is replaced by M[:3,:3] p + M[:3,3] inside the kernels -- the
     fused form of `get_xyz` under pose fitting (`self.P[k].retr().act(xyz)`, gaussian_model_ht.py:135-148); its
-    gradient comes back through autograd (see pose.py for the SE3 parametrisation)."""
+    gradient comes back through autograd (see pose.py for the SE3 parametrisation).
+
+    prepare_next = the raster settings of the NEXT render of these parameters (with fused_adam): backward() then also runs
+    that render's preprocess on the freshly updated parameters (include/gsr.h GsrNextView) and a FIFTH output -- a byte
+    buffer, valid once backward() has run -- is returned; hand it to the next call as `prepared=` together with the same
+    settings and the (in-place updated) parameter tensors, and that forward skips its preprocess kernel with a bit-identical
+    result.  The caller guarantees that nothing else modifies the parameters in between."""
     if not E.use_ctypes():
         return _rasterize_ext(means3D, means2D, features_dc, None, opacity_logit, log_scales, rotations_raw, None, raster_settings,
-                              features_rest, True, fused_adam, points_transform)
+                              features_rest, True, fused_adam, points_transform, prepared, prepare_next)
+    if prepared is not None or prepare_next is not None:
+        raise RuntimeError("prepared / prepare_next are served by the PyTorch extension binding only")
     e = torch.Tensor([])
     return _RasterizeGaussians.apply(means3D, means2D, features_dc, e, opacity_logit, log_scales, rotations_raw, e,
                                      raster_settings, features_rest, True, *_cam_inputs(raster_settings), fused_adam, points_transform)

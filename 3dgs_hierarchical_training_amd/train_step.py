@@ -132,6 +132,7 @@ class GaussianParams:
             self.optimizer.state[new] = st
         group["params"][0] = new
         setattr(self, self._GROUP_ATTR[group["name"]], new)
+        self._prepared = None            # a hand-over buffer of "prepare in backward" describes the old tensors
         return new
 
     def prune_points(self, mask: torch.Tensor):
@@ -197,10 +198,19 @@ class _LazyVisibility(dict):
         raise KeyError(key)
 
 
+def _same_view(a: GaussianRasterizationSettings, b: GaussianRasterizationSettings) -> bool:
+    if a is b:
+        return True
+    return all((x is y) if torch.is_tensor(x) else (x == y) for x, y in zip(a, b))
+
+
 def render(params: GaussianParams, settings: GaussianRasterizationSettings, clamp: bool = True,
-           fused_activations: bool = False, fused_adam=None) -> Dict:
+           fused_activations: bool = False, fused_adam=None, next_settings: GaussianRasterizationSettings = None) -> Dict:
     """CF3DGS_Render.render with compute_cov3D_python = convert_SHs_python = False.
-    fused_activations=True hands the raw parameters to the kernels (exp / sigmoid / normalize / cat in-kernel)."""
+    fused_activations=True hands the raw parameters to the kernels (exp / sigmoid / normalize / cat in-kernel).
+    next_settings (with fused_adam): the camera of the NEXT render of this model -- its preprocess then rides in this render's
+    backward ("prepare in backward", rasterize_gaussians_raw) and the hand-over buffer is kept on `params` until a render with
+    that camera picks it up (single use; any parameter surgery drops it)."""
     xyz = params.get_xyz
     # gaussian_model_ht.py:800-805 builds `zeros_like(xyz, requires_grad=True) + 0` every render only to receive
     # the 2D positional gradient; its VALUES are never read by the rasterizer.  One zero leaf per model does the same
@@ -211,8 +221,18 @@ def render(params: GaussianParams, settings: GaussianRasterizationSettings, clam
         params._screenspace_zero = screenspace_points
     screenspace_points.grad = None
     if fused_activations:
+        prep, use = getattr(params, "_prepared", None), None
+        if prep is not None:
+            params._prepared = None          # single use: the forward sorts the buffer's keys in place
+            if prep["valid"] and prep["n"] == xyz.shape[0] and prep["xyz"] is params._xyz and _same_view(prep["settings"], settings):
+                use = prep["buf"]
+        want_next = next_settings if (fused_adam is not None and next_settings is not None) else None
         out = rasterize_gaussians_raw(xyz, screenspace_points, params._features_dc, params._features_rest, params._opacity,
-                                      params._scaling, params._rotation, settings, fused_adam=fused_adam)
+                                      params._scaling, params._rotation, settings, fused_adam=fused_adam, prepared=use,
+                                      prepare_next=want_next)
+        if want_next is not None:        # filled by this render's backward; train_step marks it valid once that has run
+            params._prepared = {"buf": out[4], "settings": want_next, "n": xyz.shape[0], "xyz": params._xyz, "valid": False}
+            out = out[:4]
     else:
         rasterizer = GaussianRasterizer(raster_settings=settings)
         out = rasterizer(means3D=xyz, means2D=screenspace_points, shs=params.get_features, colors_precomp=None,
@@ -225,17 +245,21 @@ def render(params: GaussianParams, settings: GaussianRasterizationSettings, clam
 
 def train_step(params: GaussianParams, settings: GaussianRasterizationSettings, gt: torch.Tensor,
                lambda_dssim: float = 0.2, fused_loss: bool = True, fused_activations: bool = True,
-               fused_optimizer: bool = True, densifier=None, iteration: int = 0) -> Dict:
+               fused_optimizer: bool = True, densifier=None, iteration: int = 0, next_settings=None) -> Dict:
     """render -> loss -> backward -> Adam step (ht3dgs_trainer.py:102-166 without densification).
     fused_loss=True evaluates clamp + L1 + SSIM in the HIP loss kernels; False uses the torch restatement.
     fused_activations=True runs exp / sigmoid / normalize / cat inside the rasterizer kernels.
     fused_optimizer=True (needs fused_activations and the "hip" optimizer) applies the Adam step inside the
     per-Gaussian backward kernel -- same update, the gradients just never travel through HBM; optimizer.step()
     then finds no .grad and is a no-op.
+    next_settings: the camera the NEXT train_step of this model will use, when the caller knows it (a trainer draws its frame
+    one step ahead): the backward then also runs the next render's preprocess on the updated parameters and the next forward
+    skips that kernel (same result bit for bit; see rasterize_gaussians_raw).
     densifier (densify.Densifier) + iteration: the adaptive density control of ht3dgs_trainer.py:137-155 runs between
     backward() and optimizer.step(), as in the reference (see densify.py for the ordering note of the fused mode)."""
     fused_adam = params.optimizer if (fused_optimizer and fused_activations and isinstance(params.optimizer, FusedAdam)) else None
-    pkg = render(params, settings, clamp=not fused_loss, fused_activations=fused_activations, fused_adam=fused_adam)
+    pkg = render(params, settings, clamp=not fused_loss, fused_activations=fused_activations, fused_adam=fused_adam,
+                 next_settings=next_settings if params.active_sh_degree == 3 and params.max_sh_degree == 3 else None)
     if fused_loss:
         loss = fused_photometric_loss(pkg["raw_image"], gt, lambda_dssim, clamp=True)
     else:
@@ -245,6 +269,9 @@ def train_step(params: GaussianParams, settings: GaussianRasterizationSettings, 
     if one is None or one.device != loss.device:
         one = params._grad_one = torch.ones((), dtype=loss.dtype, device=loss.device)
     loss.backward(gradient=one)
+    prep = getattr(params, "_prepared", None)
+    if prep is not None and not prep["valid"]:
+        prep["valid"] = True             # the backward that fills the hand-over buffer has been enqueued
     if densifier is not None:
         densifier.after_backward(iteration, pkg)
     params.optimizer.step()

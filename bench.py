@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--clustered", action="store_true", help="load-imbalance variant of the scene (synthetic.make_scene)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip dropin / other_workloads / merge / copy ceiling")
+    ap.add_argument("--no-prepare-next", action="store_true", help="do not run the next render's preprocess inside the backward "
+                    "(\"prepare in backward\": the step then launches k_preprocess at the start of every forward)")
     ap.add_argument("--fwd-ppt", type=int, default=0)
     ap.add_argument("--bwd-ppt", type=int, default=0)
     ap.add_argument("--tile-map", type=int, default=-1, help="2 = 2x2 tile blocks interleaved over the XCDs (default), 1 = single tiles "
@@ -224,7 +226,7 @@ def workload_leg(syn, ts, raster, dev, N, W, H, deg, steps, warmup, clustered=Fa
 
     def f(i):
         it[0] += 1
-        ts.train_step(p, st, gt, densifier=den, iteration=it[0])
+        ts.train_step(p, st, gt, densifier=den, iteration=it[0], next_settings=st)
     for i in range(warmup):
         f(i)
     sec = timed_steps(f, steps, dev)
@@ -356,8 +358,10 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
+    # the next step renders the same view: its preprocess rides in this step's backward ("prepare in backward")
+    nxt = None if args.no_prepare_next else settings
     for _ in range(args.warmup):
-        ts.train_step(params, settings, gt)
+        ts.train_step(params, settings, gt, next_settings=nxt)
     # instance statistics from one un-timed forward (they do not change the timed work)
     with torch.no_grad():
         pkg = ts.render(params, settings)
@@ -371,7 +375,7 @@ def main():
     t0 = time.perf_counter()
     stamps = [t0]
     for _ in range(args.steps):
-        ts.train_step(params, settings, gt)
+        ts.train_step(params, settings, gt, next_settings=nxt)
         stamps.append(time.perf_counter())   # host clock only (each step already waits for the forward's instance count)
     sync_all()
     elapsed = time.perf_counter() - t0
@@ -379,7 +383,7 @@ def main():
     prof_blend = read_profile(lib, ["blend_fwd"])["blend_fwd"]
     lib.gsr_set_option(b"profile", 1)
     for _ in range(min(5, args.steps)):
-        ts.train_step(params, settings, gt)
+        ts.train_step(params, settings, gt, next_settings=nxt)
     torch.cuda.synchronize(dev)
     lib.gsr_set_option(b"profile", 0)
     prof = read_profile(lib, STAGES)
@@ -493,8 +497,10 @@ def main():
                    "gaussians": N, "width": W, "height": H, "sh_degree": deg, "visible": n_visible,
                    "num_rendered_R": R, "parallelism": f"{world} independent segment replica(s), no data-path collective",
                    "train_step": "activations + rasterize fwd + 0.8*L1+0.2*(1-SSIM) + backward + Adam(eps=1e-15) on all 59 floats "
-                                 "per Gaussian (update applied inside the per-Gaussian backward kernel); the unmodified "
-                                 "reference trainer reaches the `dropin` path instead"},
+                                 "per Gaussian (update applied inside the per-Gaussian backward kernel" +
+                                 ("" if args.no_prepare_next else ", which also runs the NEXT step's preprocess on the updated parameters: "
+                                  "one preprocess per step either way, k_preprocess is just not a separate launch") +
+                                 "); the unmodified reference trainer reaches the `dropin` path instead"},
         "fwd_bwd_ms": fwd_ms + bwd_ms, "rasterizer_fwd_ms": fwd_ms, "rasterizer_bwd_ms": bwd_ms,
         "stage_ms": stage_ms, "step_host_ms": step_host, "roofline": roofline, "roofline_other_kernels": others,
     }

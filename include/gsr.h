@@ -79,6 +79,11 @@ typedef struct GsrForwardArgs {
      * `xyz = self.P[k].retr().act(self._xyz.clone())` (gaussian_model_ht.py:135-148): positions move, the Gaussians'
      * own rotations / scales / SH do not, exactly as the reference's get_xyz has it. */
     const float* points_transform;
+    /* ---- "prepare in backward" (see GsrNextView): the buffer a preceding gsr_backward filled through
+     * GsrBackwardArgs::prepared_out for THIS camera and THESE parameter values.  Then `geom` must be the same pointer (the
+     * splat records are its first gsr_geom_bytes(N) bytes), k_preprocess is skipped, and the result is bit-identical to a
+     * forward without it.  NULL = ordinary forward.  The buffer is consumed (its sort keys are sorted in place). */
+    void* prepared;
 } GsrForwardArgs;
 
 typedef struct GsrForwardOut {
@@ -109,6 +114,21 @@ typedef struct GsrFusedAdam {
     float* exp_avg[6];
     float* exp_avg_sq[6];
 } GsrFusedAdam;
+
+/* "Prepare in backward" (extension f-2, with fused_adam only).  Training renders the same parameters again right after
+ * their update; when the caller knows the NEXT camera at backward time, the per-Gaussian backward kernel -- which holds
+ * each Gaussian's freshly updated parameters in registers / LDS -- also runs the forward preprocess of that next render
+ * (projection, tile test, SH colour, sort keys) and leaves the result in `prepared_out`; the next gsr_forward takes it
+ * through GsrForwardArgs::prepared and skips its preprocess kernel: no second read of the 236 bytes per Gaussian, and
+ * the ~2 400 VALU instructions per wave of the preprocess hide under the HBM time of the backward kernel.
+ * Needs raw_params, shs + shs_rest with M = 16, D = 3 (gsr_prepare_supported); the caller guarantees that the parameters
+ * are not modified between this backward and that forward. */
+typedef struct GsrNextView {
+    int32_t W, H, D;
+    float scale_modifier, tanfovx, tanfovy;
+    const float *viewmatrix, *projmatrix, *campos; /* device, as in GsrForwardArgs */
+    const float* points_transform;                  /* device, 12 floats, or NULL */
+} GsrNextView;
 
 typedef struct GsrBackwardArgs {
     int32_t N, M, D, W, H;
@@ -148,6 +168,8 @@ typedef struct GsrBackwardArgs {
     float* d_points_transform;
     int64_t binning_capacity; /* GsrForwardOut::binning_capacity of the forward (0 = num_rendered) */
     int64_t forward_flags;    /* GsrForwardOut::forward_flags of the forward (0 = round-1 caller: process-wide options) */
+    const struct GsrNextView* next_view; /* NULL = none; otherwise prepared_out must point at gsr_prepared_bytes(N) bytes */
+    void* prepared_out;
 } GsrBackwardArgs;
 
 size_t gsr_geom_bytes(int32_t N);
@@ -161,6 +183,8 @@ size_t gsr_binning_bytes(int64_t R, int32_t W, int32_t H);
  * above 65 536 tiles use; smaller images carry 16-bit keys and ask for 4 R bytes less */
 size_t gsr_binning_scratch_bytes(int64_t R);
 size_t gsr_backward_scratch_bytes(int32_t N);
+size_t gsr_prepared_bytes(int32_t N);                       /* "prepare in backward": size of the hand-over buffer */
+int gsr_prepare_supported(int32_t M, int32_t D, int32_t raw_params); /* 1 when gsr_backward can prepare the next view */
 
 int gsr_forward(const GsrForwardArgs* args, GsrForwardOut* out, void* stream);
 int gsr_backward(const GsrBackwardArgs* args, void* stream);

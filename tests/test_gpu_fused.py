@@ -324,3 +324,56 @@ def test_extension_ops_run_under_torch_compile():
     assert abs(float(l0.detach()) - float(l1.detach())) < 1e-6
     for a, b in zip(g0, [a.grad for a in args]):
         assert (a - b).abs().max().item() <= 2e-5 * a.abs().max().item() + 1e-12
+
+
+@pytest.mark.parametrize("N", [12800, 10007, 4098], ids=["whole-blocks", "ragged-odd", "ragged-mod4"])
+def test_prepare_in_backward_is_bit_identical(N):
+    """"Prepare in backward" (GsrNextView): with `next_settings` the backward that applies the Adam step also runs the NEXT
+    render's preprocess on the updated parameters, and that render skips k_preprocess.  Two copies of one model trained on
+    two alternating cameras, one with and one without the hand-over, must stay EQUAL: images, radii, parameters, moments --
+    bit for bit, on whole blocks and on ragged last blocks (N not a multiple of 128 / of 4).  (The blend backward runs in its
+    deterministic debug mode here: with float atomics two runs of the SAME path already differ in the last bits.)"""
+    L = importlib.import_module("3dgs_hierarchical_training_amd._lib")
+    lib = L.load()
+    assert lib.gsr_set_option(b"deterministic_backward", 1) == 0
+    try:
+        _prepare_in_backward_case(N)
+    finally:
+        lib.gsr_set_option(b"deterministic_backward", 0)
+
+
+def _prepare_in_backward_case(N):
+    dev = torch.device("cuda:0")
+    W, H = 320, 240
+    sc = parity.syn.make_scene(N, W, H, sh_degree=3, seed=17)
+    cam2 = parity.syn.make_scene(8, W, H, sh_degree=3, seed=5, posed=True)
+    sc2 = dict(sc)
+    for k in ("viewmatrix", "projmatrix", "campos"):
+        sc2[k] = cam2[k]
+    views = [ts.make_settings(sc, dev, 3), ts.make_settings(sc2, dev, 3)]
+    gts = [parity.syn.target_image(W, H, seed=1).to(dev), parity.syn.target_image(W, H, seed=2).to(dev)]
+    pa, pb = ts.GaussianParams(sc, dev), ts.GaussianParams(sc, dev)
+    names = ["_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation"]
+    used = 0
+    for it in range(6):
+        v = it % 2
+        had = getattr(pa, "_prepared", None) is not None
+        ka = ts.train_step(pa, views[v], gts[v], next_settings=views[(it + 1) % 2])
+        kb = ts.train_step(pb, views[v], gts[v])
+        used += int(had)
+        assert torch.equal(ka["raw_image"], kb["raw_image"]) and torch.equal(ka["radii"], kb["radii"]), it
+        assert torch.equal(ka["depth"], kb["depth"]) and torch.equal(ka["alpha"], kb["alpha"]), it
+        assert torch.equal(ka["viewspace_points"].grad, kb["viewspace_points"].grad), it
+        for k in names:
+            assert torch.equal(getattr(pa, k), getattr(pb, k)), (it, k)
+    assert used == 5                      # every step after the first rendered from a hand-over buffer
+    # a render with a DIFFERENT camera does not pick the buffer up, and surgery drops it
+    ts.train_step(pa, views[0], gts[0], next_settings=views[0])
+    assert pa._prepared is not None
+    with torch.no_grad():
+        ts.render(pa, views[1], fused_activations=True)
+    assert pa._prepared is None
+    ts.train_step(pa, views[0], gts[0], next_settings=views[0])
+    pa.prune_points(torch.zeros(pa.num_points, dtype=torch.bool, device=dev))
+    assert pa._prepared is None
+    ts.train_step(pa, views[0], gts[0])
