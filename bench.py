@@ -474,7 +474,9 @@ def main():
                        "unit": "GB/s", "frac": ab / (blend_bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": ab,
                        "avg_launch_ms": blend_bwd_ms, "note": "VALU-bound (packed f32 math + cross-lane reduction), see DESIGN.md"})
     if preb_ms:
-        ab = 1476.0 * N   # params 236 + ggrad 48 + moments 472 in; params + moments 708 + means2D grad 12 out
+        # params 236 + ggrad 48 + moments 472 in; params + moments 708 + means2D grad 12 out; + 68 out for the next render's
+        # splat / radii / key / id / tile records when that render's preprocess rides along ("prepare in backward")
+        ab = (1476.0 + (0.0 if args.no_prepare_next else 68.0)) * N
         others.append({"kernel": "k_preprocess_bwd (per-Gaussian backward + in-kernel Adam)", "bound": "hbm",
                        "achieved": ab / (preb_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": ab / (preb_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": ab,
