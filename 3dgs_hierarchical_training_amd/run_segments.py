@@ -126,12 +126,20 @@ class RankRunner:
             fr = fr[::max(1, len(fr) // k)][:k]
         return [self._settings(seg, f) for f in fr]
 
-    def _step(self, seg: Segment, settings, target):
+    def _step(self, seg: Segment, settings, target, next_settings=None):
+        """next_settings: the camera of the NEXT step when it is already drawn -- its preprocess then rides in this step's
+        backward (train_step / "prepare in backward")."""
         seg.global_iteration += 1
         if self.step_fn is not None:
             return self.step_fn(seg, settings, target)
         ts.train_step(seg.params, settings, target, fused_optimizer=self.cfg.fused, densifier=seg.densifier,
-                      iteration=seg.global_iteration)
+                      iteration=seg.global_iteration, next_settings=next_settings)
+
+    def _steps_over(self, seg: Segment, frames_drawn):
+        """Train on a pre-drawn list of frames (the frame of step k + 1 is known at step k)."""
+        st = [self._settings(seg, v) for v in frames_drawn]
+        for k, v in enumerate(frames_drawn):
+            self._step(seg, st[k], self.seq.target(v), st[k + 1] if k + 1 < len(st) else None)
 
     def _new_densifier(self, seg: Segment):
         if self.cfg.densify:
@@ -153,10 +161,9 @@ class RankRunner:
         for f in frames[1:]:
             seg.poses[f] = self.seq.rel_pose(f - 1, f) @ seg.poses[f - 1]          # :739-741
             visited.append(f)
-            for _ in range(cfg.leaf_iters_per_frame):
-                v = self.rng.choice(visited)                                         # sample_a_training_frame, :482-505
-                self._step(seg, self._settings(seg, v), self.seq.target(v))
-                steps += 1
+            drawn = [self.rng.choice(visited) for _ in range(cfg.leaf_iters_per_frame)]   # sample_a_training_frame, :482-505
+            self._steps_over(seg, drawn)
+            steps += len(drawn)
         if self.dev.type == "cuda":
             torch.cuda.synchronize(self.dev)
         self.seg = seg
@@ -225,9 +232,7 @@ class RankRunner:
         lvl = self.level - 1 - k
         per = cfg.phase2_iters_per_frame[min(lvl, len(cfg.phase2_iters_per_frame) - 1)]
         n2 = per * len(frames)
-        for _ in range(n2):
-            f = self.rng.choice(frames)
-            self._step(seg, self._settings(seg, f), self.seq.target(f))
+        self._steps_over(seg, [self.rng.choice(frames) for _ in range(n2)])
         if self.dev.type == "cuda":
             torch.cuda.synchronize(self.dev)
         self._emit({"phase": "nonleaf", "level": k, "phase1_steps": n1, "virtual_views": virtual, "phase2_steps": n2,

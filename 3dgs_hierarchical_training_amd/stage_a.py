@@ -91,7 +91,7 @@ def fit_pair(seq, p: int, device, n_points: int = 100_000, single_image_iters: i
     ident = seq.settings_for_pose(torch.eye(4))
     tgt0, tgt1 = seq.target(p), seq.target(p + 1)
     for it in range(1, single_image_iters + 1):
-        pkg = ts.train_step(params, ident, tgt0)
+        pkg = ts.train_step(params, ident, tgt0, next_settings=ident)      # same view every step: its preprocess rides in the backward
         if it > 500 and it % 50 == 0:
             with torch.no_grad():
                 mse = ((pkg["raw_image"].clamp(0, 1) - tgt0) ** 2).mean()
