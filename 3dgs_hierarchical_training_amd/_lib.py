@@ -71,7 +71,7 @@ EXPORTS = [
     "gsr_sort_pairs_u16", "gsr_sort_scratch_bytes", "gsr_image_staged_offset", "gsr_profile_read",
     "gsr_loss_workspace_bytes", "gsr_loss_forward", "gsr_loss_backward", "gsr_adam_step",
     "gsr_knn_scratch_bytes", "gsr_knn_mean_dist2", "gsr_get_counter", "gsr_debug_read_binning", "gsr_prepared_bytes",
-    "gsr_prepare_supported",
+    "gsr_prepare_supported", "gsr_prepared_radii_offset",
 ]
 
 _lib = None
@@ -89,7 +89,7 @@ def load():
     lib = C.CDLL(LIB_PATH)
     lib.gsr_prepare_supported.restype = C.c_int
     lib.gsr_prepare_supported.argtypes = [C.c_int32, C.c_int32, C.c_int32]
-    for fn in ["gsr_geom_bytes", "gsr_forward_scratch_bytes", "gsr_backward_scratch_bytes", "gsr_prepared_bytes"]:
+    for fn in ["gsr_geom_bytes", "gsr_forward_scratch_bytes", "gsr_backward_scratch_bytes", "gsr_prepared_bytes", "gsr_prepared_radii_offset"]:
         getattr(lib, fn).restype = C.c_size_t
         getattr(lib, fn).argtypes = [C.c_int32]
     lib.gsr_image_bytes.restype = C.c_size_t

@@ -95,7 +95,9 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> raste
     const auto fo = means3D.options().dtype(at::kFloat);
     const auto bo = means3D.options().dtype(at::kByte);
     Tensor color = at::empty({3, H, W}, fo), depth = at::empty({1, H, W}, fo), alpha = at::empty({1, H, W}, fo);
-    Tensor radii = at::empty({N}, means3D.options().dtype(at::kInt));
+    // (prepared: the radii already sit in the hand-over buffer -- an int32 view of it, no copy)
+    Tensor radii = has(prepared) ? prepared.slice(0, (int64_t)gsr_prepared_radii_offset((int32_t)N), (int64_t)gsr_prepared_radii_offset((int32_t)N) + 4 * N).view(at::kInt)
+                                 : at::empty({N}, means3D.options().dtype(at::kInt));
     // "prepare in backward": the preceding backward already produced this render's splat records (+ keys, tile records) in
     // `prepared`; that buffer then IS the geometry workspace and the preprocess kernel is skipped
     if (has(prepared))

@@ -184,6 +184,8 @@ size_t gsr_binning_bytes(int64_t R, int32_t W, int32_t H);
 size_t gsr_binning_scratch_bytes(int64_t R);
 size_t gsr_backward_scratch_bytes(int32_t N);
 size_t gsr_prepared_bytes(int32_t N);                       /* "prepare in backward": size of the hand-over buffer */
+size_t gsr_prepared_radii_offset(int32_t N);                /* where its int32 radii[N] start: a forward given `radii` = that
+                                                               address uses them in place instead of copying them out */
 int gsr_prepare_supported(int32_t M, int32_t D, int32_t raw_params); /* 1 when gsr_backward can prepare the next view */
 
 int gsr_forward(const GsrForwardArgs* args, GsrForwardOut* out, void* stream);
