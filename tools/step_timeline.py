@@ -1,7 +1,8 @@
 import sqlite3, sys
 cur=sqlite3.connect(sys.argv[1]).cursor()
 rows=cur.execute("select name,start,end from kernels order by start").fetchall()
-idx=[i for i,r in enumerate(rows) if 'k_preprocess<3, true>' in r[0]]
+# a step ends with the per-Gaussian backward (+ Adam + next preprocess); the next one starts right behind it
+idx=[i+1 for i,r in enumerate(rows) if 'k_preprocess_bwd' in r[0] and i+1 < len(rows)]
 k=int(sys.argv[2]) if len(sys.argv)>2 else -4
 a,b=idx[k],idx[k+1]
 t0=rows[a][1]
