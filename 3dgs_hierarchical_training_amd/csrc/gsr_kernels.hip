@@ -38,6 +38,13 @@ static int g_blend_ppt = 0;   // 0 = default
 static int g_bwd_ppt = 0;
 // 1 (default) = onesweep (decoupled look-back) for the depth sort over N, histogram+scan+scatter for the tile
 // sort over R (measured: 115 vs 140 us and 164 vs 157 us); 0 = three-kernel passes everywhere; 2 = onesweep everywhere
+// prepare in backward: up to this many Gaussians the per-Gaussian backward kernel also counts the digits of the next depth sort
+// (saves that sort's histogram launch: ~7 us + a launch gap on small models); above, its ~2 global adds per key cost more inside
+// the HBM-bound kernel than the histogram kernel does on its own (1 M: +20 us against -8 us).  Both sides of the hand-over
+// evaluate the same predicate on N.
+static int g_prep_hist_max_n = 262144;
+static inline bool prep_counts_digits(int N) { return N <= g_prep_hist_max_n; }
+static int g_emit_hist = 1;   // 1: k_emit counts the tile sort's digits (no histogram launch); 0: k_radix_ghist
 static int g_sort_algo = 2;   // 2: onesweep for both sorts; 1: onesweep depth sort + hist/scan/scatter tile sort; 0: hist/scan/scatter
 
 static int fail(int code, const char* fmt, const char* detail = "")
@@ -322,6 +329,15 @@ __device__ __forceinline__ void count_large_rects(bool act, Splat& s, TileRec& r
     }
 }
 
+// The producer of the depth keys can count the depth sort's digits (4 x 8 bits, per run: radix_sort.h onesweep_run_len) and
+// clear that sort's status words, so the sort needs no histogram launch (onesweep_sort_pairs hist_done).  ghist == nullptr: off.
+// The counters must be zero before the kernel starts.
+struct DepthHist {
+    uint32_t* ghist;
+    uint32_t* status;
+    uint32_t status_words;
+};
+
 template <int DEG, bool RAW>
 __global__ __launch_bounds__(kPreThreads) void k_preprocess(CamParams cp, int N, const float* __restrict__ means,
                                                             const float* __restrict__ scales, const float* __restrict__ rots,
@@ -331,7 +347,7 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess(CamParams cp, int N,
                                                             Splat* __restrict__ splat, int32_t* __restrict__ radii,
                                                             uint32_t* __restrict__ dkey, uint32_t* __restrict__ gid,
                                                             TileRec* __restrict__ tilerec, uint32_t* __restrict__ zero_words,
-                                                            int zero_count, int block0)
+                                                            int zero_count, int block0, DepthHist dh)
 {
     constexpr int NC3 = 3 * (DEG + 1) * (DEG + 1);
     __shared__ float s_sh[kPreThreads * kShStride];
@@ -437,8 +453,14 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess(CamParams cp, int N,
     splat[i] = s;
     tilerec[i] = rec;   // compact emission record: k_tile_counts / k_emit never touch the 48 B splats
     radii[i] = s.radius;
-    dkey[i] = s.tiles > 0 ? __float_as_uint(s.depth) : 0xffffffffu;
+    const uint32_t key = s.tiles > 0 ? __float_as_uint(s.depth) : 0xffffffffu;
+    dkey[i] = key;
     gid[i] = (uint32_t)i;
+    if (dh.ghist) {   // (only the single ragged block behind k_preprocess_bwd's next-view tail comes here: plain global adds)
+        const uint32_t x = (uint32_t)i / onesweep_run_len<uint32_t>((uint32_t)N);
+#pragma unroll
+        for (int p = 0; p < 4; p++) atomicAdd(&dh.ghist[((size_t)p * kOsRanges + x) * 256 + ((key >> (8 * p)) & 255u)], 1u);
+    }
 }
 
 // first kernel of a forward that received a prepared buffer: radii to the caller's tensor + the clears k_preprocess's block 0 does
@@ -573,13 +595,26 @@ __device__ __forceinline__ int select_kth_bit(uint32_t m, uint32_t k)   // posit
 }
 
 // KeyT = uint16_t up to 65536 tiles (the tile sort then moves 6-byte records), uint32_t above
+// EmitHist: the emission also counts the digits of the tile keys it writes, per run of the tile sort, and clears that sort's
+// status words -- what k_radix_ghist would do in a launch of its own right behind it (radix_sort.h, onesweep_run_len).  A
+// workgroup's outputs are consecutive, so they fall into at most two runs unless the frame is tiny: two LDS tables, direct
+// global adds beyond.  ghist == nullptr: off.
+struct EmitHist {
+    uint32_t* ghist;
+    uint32_t* status;
+    uint32_t status_words;
+    int bits;
+    const unsigned long long* n_dev;
+};
+
 template <typename KeyT>
 __global__ __launch_bounds__(kEmitThreads) void k_emit(int N, int W, int H, int tiles_x, int tiles_y,
                                                        const uint32_t* __restrict__ sorted_gid, const Splat* __restrict__ splat,
                                                        const TileRec* __restrict__ tilerec,
                                                        const uint32_t* __restrict__ block_offsets, KeyT* __restrict__ out_tile,
-                                                       uint32_t* __restrict__ out_gid, uint32_t cap)
+                                                       uint32_t* __restrict__ out_gid, uint32_t cap, EmitHist hz)
 {
+    __shared__ uint32_t s_hist[2][4][256];
     __shared__ uint32_t s_wave[4];
     __shared__ uint32_t s_incl[kEmitThreads];
     __shared__ uint32_t s_gid[kEmitThreads];
@@ -589,6 +624,13 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit(int N, int W, int H, int 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = blockIdx.x * kEmitThreads + tid;
     if (tid == 0) s_nbig = 0u;
+    const bool hist = hz.ghist != nullptr;
+    if (hist) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) (&s_hist[0][0][0])[q * kEmitThreads + tid] = 0u;
+        for (uint32_t q = blockIdx.x * kEmitThreads + tid; q < hz.status_words / 4; q += gridDim.x * kEmitThreads)
+            reinterpret_cast<uint4*>(hz.status)[q] = make_uint4(0u, 0u, 0u, 0u);
+    }
     uint32_t g = 0;
     TileRec r;
     r.mask = 0u; r.rect = 1u << 24;
@@ -603,6 +645,26 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit(int N, int W, int H, int 
     if ((r.rect & kTileRecBig) && cnt) s_big[atomicAdd(&s_nbig, 1u)] = (uint32_t)tid;   // order irrelevant: positions are absolute
     __syncthreads();
     const uint32_t base = block_offsets[blockIdx.x];
+    // digit counting (hist): run geometry of the sort over n = min(cap, R) keys
+    const int h_passes = onesweep_passes(hz.bits), h_dbits = onesweep_dbits(hz.bits);
+    uint32_t run_len = 0, x0 = 0;
+    unsigned long long b1 = ~0ull, b2 = ~0ull;
+    if (hist) {
+        const unsigned long long n_keys = hz.n_dev ? min((unsigned long long)cap, *hz.n_dev) : (unsigned long long)cap;
+        run_len = onesweep_run_len<KeyT>((uint32_t)n_keys);
+        if (run_len) { x0 = base / run_len; b1 = (unsigned long long)(x0 + 1) * run_len; b2 = b1 + run_len; }
+    }
+    auto count_key = [&](uint32_t key, uint32_t o) {
+        const int t = o >= b1 ? (o >= b2 ? 2 : 1) : 0;
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            if (p >= h_passes) break;
+            const int wbits = min(h_dbits, hz.bits - h_dbits * p);
+            const uint32_t d = (key >> (h_dbits * p)) & ((1u << wbits) - 1u);
+            if (t < 2) atomicAdd(&s_hist[t][p][d], 1u);
+            else atomicAdd(&hz.ghist[((size_t)p * kOsRanges + o / run_len) * 256 + d], 1u);
+        }
+    };
     for (uint32_t q = tid; q < total; q += kEmitThreads) {
         int lo = 0, hi = kEmitThreads - 1;   // first index with s_incl > q
         while (lo < hi) {
@@ -617,8 +679,10 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit(int N, int W, int H, int 
         const int ty = pos / ww, tx = pos - ty * ww;
         const uint32_t o = base + q;
         if (o < cap) {   // cap = R, or the speculative capacity of gsr_forward (then an overflow is re-run)
-            out_tile[o] = (KeyT)((ry0 + ty) * tiles_x + rx0 + tx);
+            const uint32_t key = (uint32_t)((ry0 + ty) * tiles_x + rx0 + tx);
+            out_tile[o] = (KeyT)key;
             out_gid[o] = s_gid[lo];
+            if (hist) count_key(key, o);
         }
     }
     // large rects: one wave per Gaussian, the exact test on 64 candidate tiles at a time, survivors compacted in order
@@ -646,11 +710,22 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit(int N, int W, int H, int 
             if (ok) {
                 const uint32_t o = run + (uint32_t)__popcll(m & lt);
                 if (o < cap) {
-                    out_tile[o] = (KeyT)(gy * tiles_x + gx);
+                    const uint32_t key = (uint32_t)(gy * tiles_x + gx);
+                    out_tile[o] = (KeyT)key;
                     out_gid[o] = gg;
+                    if (hist) count_key(key, o);
                 }
             }
             run += (uint32_t)__popcll(m);
+        }
+    }
+    if (hist) {
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int e = q * kEmitThreads + tid, t = e >> 10, p = (e >> 8) & 3, d = e & 255;
+            const uint32_t c = s_hist[t][p][d];
+            if (c && x0 + (uint32_t)t < (uint32_t)kOsRanges) atomicAdd(&hz.ghist[((size_t)p * kOsRanges + x0 + t) * 256 + d], c);
         }
     }
 }
@@ -1294,9 +1369,13 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(int W, int H, int tiles_x, i
                                                     const float* __restrict__ g_color, const float* __restrict__ g_depth,
                                                     const float* __restrict__ g_alpha, float* __restrict__ ggrad, int interleave,
                                                     const float* __restrict__ ckpt, int split, int kCkptFirst,
-                                                    const uint32_t* __restrict__ staged4, int tpad, float* __restrict__ det_part)
+                                                    const uint32_t* __restrict__ staged4, int tpad, float* __restrict__ det_part,
+                                                    uint32_t* __restrict__ zero_words, int zero_count)
 {
     constexpr int NT = 128, NW = 2, NV = HAS_DA ? 10 : 9;
+    // (prepare in backward: workgroup 0 clears the digit counters that the per-Gaussian kernel behind this one adds into)
+    if (zero_words && blockIdx.x == 0)
+        for (int q = threadIdx.x; q < zero_count; q += NT) zero_words[q] = 0u;
     // single staging buffer: a batch is ~10^4 cycles of compute, so the second barrier per batch is free, and the
     // smaller LDS footprint lets more tiles share a CU (latency hiding: waves were 33% in s_waitcnt / barriers)
     __shared__ float4 s_a[1][NT], s_b[1][NT], s_c[1][NT];
@@ -1525,6 +1604,7 @@ struct PrepOut {
     uint32_t* dkey;
     uint32_t* gid;
     TileRec* rec;
+    DepthHist dh;
 };
 
 struct AdamDev {
@@ -1885,12 +1965,38 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, in
                 splat_sh_color(cam2, mean2, s_rest + tid * NRL - 3, 3, 1, col, s_dc + tid * 3);
                 s2.r = col[0]; s2.g = col[1]; s2.b = col[2];
             }
-            if (!act) return;
-            po.splat[i] = s2;
-            po.rec[i] = rec2;
-            po.radii[i] = s2.radius;
-            po.dkey[i] = s2.tiles > 0 ? __float_as_uint(s2.depth) : 0xffffffffu;
-            po.gid[i] = (uint32_t)i;
+            uint32_t key2 = 0xffffffffu;
+            if (act) {
+                po.splat[i] = s2;
+                po.rec[i] = rec2;
+                po.radii[i] = s2.radius;
+                key2 = s2.tiles > 0 ? __float_as_uint(s2.depth) : 0xffffffffu;
+                po.dkey[i] = key2;
+                po.gid[i] = (uint32_t)i;
+            }
+            if (po.dh.ghist) {
+                // the depth sort's digit counts of this block's 128 keys (all in one run: 128 divides the sort's tile): four
+                // 256-entry tables in the SH tile, which nobody reads any more; then one global add per non-empty bin
+                __syncthreads();
+                uint32_t* h = reinterpret_cast<uint32_t*>(s_sh);
+#pragma unroll
+                for (int q = 0; q < 1024 / kPreThreads; q++) h[q * kPreThreads + tid] = 0u;
+                __syncthreads();
+                if (act) {
+#pragma unroll
+                    for (int p = 0; p < 4; p++) atomicAdd(&h[p * 256 + ((key2 >> (8 * p)) & 255u)], 1u);
+                }
+                __syncthreads();
+                const uint32_t x = (uint32_t)base / onesweep_run_len<uint32_t>((uint32_t)N);
+#pragma unroll
+                for (int q = 0; q < 1024 / kPreThreads; q++) {
+                    const int e = q * kPreThreads + tid;
+                    const uint32_t c = h[e];
+                    if (c) atomicAdd(&po.dh.ghist[((size_t)(e >> 8) * kOsRanges + x) * 256 + (e & 255)], c);
+                }
+                for (uint32_t q = blockIdx.x * kPreThreads + tid; q < po.dh.status_words / 4; q += gridDim.x * kPreThreads)
+                    reinterpret_cast<uint4*>(po.dh.status)[q] = make_uint4(0u, 0u, 0u, 0u);
+            }
             return;
         }
         adam_rows(s_sh, kShStride, 0, 3, 3, const_cast<float*>(shs) + b * 3, ad.m[1] + b * 3, ad.v[1] + b * 3, nG, tid, ad.step_size[1], ad);
@@ -2003,7 +2109,7 @@ static GeomLayout geom_layout(int32_t N)
 }
 
 struct PrepLayout {   // "prepare in backward": what k_preprocess would have produced, handed from gsr_backward to the next gsr_forward
-    size_t splat, radii, dkey, gid, rec, bytes;
+    size_t splat, radii, dkey, gid, rec, sort, bytes;
 };
 static PrepLayout prep_layout(int32_t N)
 {
@@ -2015,6 +2121,7 @@ static PrepLayout prep_layout(int32_t N)
     p.dkey = o; o += align256(n * 4);
     p.gid = o; o += align256(n * 4);
     p.rec = o; o += align256(n * sizeof(TileRec));
+    p.sort = o; o += align256(onesweep_scratch_bytes((uint32_t)n));   // the depth sort's scratch: digit counts filled in by the backward
     p.bytes = o;
     return p;
 }
@@ -2218,6 +2325,8 @@ int gsr_set_option(const char* name, int value)
         return GSR_OK;
     }
     if (!strcmp(name, "profile")) { g_profile = (value == 2) ? 2 : (value ? 1 : 0); return GSR_OK; }
+    if (!strcmp(name, "prep_hist_max_n")) { g_prep_hist_max_n = value; return GSR_OK; }
+    if (!strcmp(name, "emit_hist")) { g_emit_hist = value ? 1 : 0; return GSR_OK; }
     if (!strcmp(name, "sort_algo")) { if (value < 0 || value > 2) return GSR_ERR_ARG; g_sort_algo = value; return GSR_OK; }
     // 2 = packed-math kernel (default), 3 = scalar 2-pixel kernel (kept for A/B), 1 / 4 = scalar 1 / 4 pixels
     if (!strcmp(name, "blend_bwd_ppt")) { if (value < 0 || value > 4) return GSR_ERR_ARG; g_bwd_ppt = value; return GSR_OK; }
@@ -2283,17 +2392,27 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
         // arrange the ping-pong so that the sorted gids land directly in `list`
         uint32_t* v0 = (tile_passes & 1) ? gid_alt2 : list;
         uint32_t* v1 = (tile_passes & 1) ? list : gid_alt2;
+        // the emission counts the tile sort's digits itself when that sort's head is known to be zero (cleared by k_block_scan)
+        const bool emit_hist = g_sort_algo == 2 && prezeroed && g_emit_hist;
+        EmitHist eh = {};
+        if (emit_hist) {
+            eh.ghist = reinterpret_cast<uint32_t*>(bs + S.sort);
+            eh.status = onesweep_status(bs + S.sort);
+            eh.status_words = onesweep_status_words<KeyT>((uint32_t)capacity, bits);
+            eh.bits = bits;
+            eh.n_dev = n_dev;
+        }
         {
             ProfScope ps(P_EMIT, st);
             hipLaunchKernelGGL(k_emit<KeyT>, dim3(nb), dim3(kEmitThreads), 0, st, N, W, H, tiles_x, tiles_y, sorted_gid, splat,
                                reinterpret_cast<const TileRec*>(fs + L.srec), block_sums, tkey, v0,
-                               (uint32_t)capacity);
+                               (uint32_t)capacity, eh);
         }
         int in_alt = 0;
         {
             ProfScope ps(P_SORT_TILE, st);
             GSR_HIP(g_sort_algo == 2 ? onesweep_sort_pairs<KeyT>(tkey, v0, tkey_alt, v1, (uint32_t)capacity, 0, bits, bs + S.sort,
-                                                                 &in_alt, st, n_dev, prezeroed)
+                                                                 &in_alt, st, n_dev, prezeroed, emit_hist)
                                      : radix_sort_pairs<KeyT>(tkey, v0, tkey_alt, v1, (uint32_t)capacity, 0, tile_passes * 8, bs + S.sort,
                                                               &in_alt, st));
         }
@@ -2391,6 +2510,8 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
     // block 0 of k_preprocess clears the head (digit histograms + tickets) of the depth sort's scratch
     uint32_t* zero_words = depth_onesweep ? reinterpret_cast<uint32_t*>(fs + L.sort) : nullptr;
     const int zero_count = depth_onesweep ? (int)kOnesweepHeadWords : 0;
+    uint8_t* depth_scratch = fs + L.sort;
+    bool depth_hist_done = false;
     if (a->prepared) {
         // "prepare in backward": the preceding gsr_backward already ran the preprocess of this render on the updated
         // parameters (k_preprocess_bwd<..., PREP>); its records, sort keys and tile records are taken from the hand-over buffer
@@ -2401,18 +2522,20 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
         gid = reinterpret_cast<uint32_t*>(pb + PL.gid);
         ntiles = reinterpret_cast<TileRec*>(pb + PL.rec);
         ProfScope ps(P_PRE_FWD, st);
+        // the depth sort's scratch is the buffer's too: its head was cleared in the backward (no memset here), and for small
+        // models the backward also counted the digits and cleared the status words, so the sort starts with its first pass
+        // (onesweep_sort_pairs hist_done)
+        if (depth_onesweep) { depth_scratch = pb + PL.sort; depth_hist_done = prep_counts_digits(N); }
         // radii: a caller that takes them straight from the buffer (gsr_prepared_radii_offset) passes its own pointer into it
-        // and only the clears of k_preprocess's block 0 remain -- a 33 kB memset instead of a 4 N-byte copy kernel
-        if (a->radii == reinterpret_cast<const int32_t*>(pb + PL.radii)) {
-            if (zero_count) GSR_HIP(hipMemsetAsync(zero_words, 0, (size_t)zero_count * 4, st));
-        } else
+        // and nothing at all runs in front of the sort; otherwise a 4 N-byte copy kernel
+        if (a->radii != reinterpret_cast<const int32_t*>(pb + PL.radii))
             hipLaunchKernelGGL(k_prepared_begin, dim3((N + 255) / 256), dim3(256), 0, st, N, reinterpret_cast<const int32_t*>(pb + PL.radii),
-                               a->radii, zero_words, zero_count);
+                               a->radii, (uint32_t*)nullptr, 0);
     } else {
 #define GSR_PRE_(DEG, RAW)                                                                                                          \
     hipLaunchKernelGGL((k_preprocess<DEG, RAW>), dim3(grid), dim3(kPreThreads), 0, st, cp, N, a->means3D, a->scales, a->rotations, \
                        a->cov3D_precomp, a->opacities, a->shs, a->shs_rest, a->colors_precomp, splat, a->radii, dkey, gid, ntiles,  \
-                       zero_words, zero_count, 0)
+                       zero_words, zero_count, 0, DepthHist{})
 #define GSR_PRE(DEG) do { if (a->raw_params) GSR_PRE_(DEG, true); else GSR_PRE_(DEG, false); } while (0)
     {
         ProfScope ps(P_PRE_FWD, st);
@@ -2429,7 +2552,8 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
     int in_alt = 0;
     {
         ProfScope ps(P_SORT_DEPTH, st);
-        GSR_HIP(depth_onesweep ? onesweep_sort_pairs<uint32_t>(dkey, gid, dkey_alt, gid_alt, (uint32_t)N, 0, 32, fs + L.sort, &in_alt, st, nullptr, true)
+        GSR_HIP(depth_onesweep ? onesweep_sort_pairs<uint32_t>(dkey, gid, dkey_alt, gid_alt, (uint32_t)N, 0, 32, depth_scratch, &in_alt, st, nullptr, true,
+                                                               depth_hist_done)
                                : radix_sort_pairs<uint32_t>(dkey, gid, dkey_alt, gid_alt, (uint32_t)N, 0, 32, fs + L.sort, &in_alt, st));
     }
     sorted_gid = in_alt ? gid_alt : gid;
@@ -2522,6 +2646,10 @@ int gsr_backward(const GsrBackwardArgs* a, void* stream_)
     const uint32_t* list = reinterpret_cast<const uint32_t*>(bin + B.list);
     float* gg = static_cast<float*>(a->scratch);
     GSR_HIP(hipMemsetAsync(gg, 0, (size_t)N * kGG * 4, st));
+    // prepare in backward: the digit counters of the next forward's depth sort live in the hand-over buffer; they are cleared by
+    // the blend kernel's workgroup 0 (no launch of their own) and filled by the per-Gaussian kernel behind it
+    uint32_t* prep_head = (a->next_view && a->prepared_out) ? reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(a->prepared_out) + prep_layout(N).sort) : nullptr;
+    bool prep_head_cleared = false;
     if (a->num_rendered > 0) {
         const int ppt = g_bwd_ppt ? g_bwd_ppt : 2;
         const float* img = static_cast<const float*>(a->image);
@@ -2555,10 +2683,13 @@ int gsr_backward(const GsrBackwardArgs* a, void* stream_)
             }
             if (a->grad_depth || a->grad_alpha)
                 hipLaunchKernelGGL(k_blend_bwd2<true>, dim3(grid), dim3(128), 0, st, W, H, tiles_x, T, ranges, list, splat, a->bg, img,
-                                   a->grad_color, a->grad_depth, a->grad_alpha, gg, f_map, ckpt, split, f_ckpt, staged4, tpad, det_part);
+                                   a->grad_color, a->grad_depth, a->grad_alpha, gg, f_map, ckpt, split, f_ckpt, staged4, tpad, det_part,
+                                   prep_head, (int)kOnesweepHeadWords);
             else
                 hipLaunchKernelGGL(k_blend_bwd2<false>, dim3(grid), dim3(128), 0, st, W, H, tiles_x, T, ranges, list, splat, a->bg, img,
-                                   a->grad_color, a->grad_depth, a->grad_alpha, gg, f_map, ckpt, split, f_ckpt, staged4, tpad, det_part);
+                                   a->grad_color, a->grad_depth, a->grad_alpha, gg, f_map, ckpt, split, f_ckpt, staged4, tpad, det_part,
+                                   prep_head, (int)kOnesweepHeadWords);
+            prep_head_cleared = prep_head != nullptr;
             if (g_deterministic) {
                 uint32_t* k0 = reinterpret_cast<uint32_t*>(det_mem + o_k0); uint32_t* k1 = reinterpret_cast<uint32_t*>(det_mem + o_k1);
                 uint32_t* v0 = reinterpret_cast<uint32_t*>(det_mem + o_v0); uint32_t* v1 = reinterpret_cast<uint32_t*>(det_mem + o_v1);
@@ -2608,6 +2739,12 @@ int gsr_backward(const GsrBackwardArgs* a, void* stream_)
         po.dkey = reinterpret_cast<uint32_t*>(pb + PL.dkey);
         po.gid = reinterpret_cast<uint32_t*>(pb + PL.gid);
         po.rec = reinterpret_cast<TileRec*>(pb + PL.rec);
+        if (!prep_head_cleared) GSR_HIP(hipMemsetAsync(prep_head, 0, kOnesweepHeadWords * sizeof(uint32_t), st));   // (no blend launch: empty frame / other variant)
+        if (prep_counts_digits(N)) {
+            po.dh.ghist = prep_head;
+            po.dh.status = onesweep_status(pb + PL.sort);
+            po.dh.status_words = onesweep_status_words<uint32_t>((uint32_t)N, 32);
+        }
     }
 #define GSR_PREB_(DEG, RAW, CAM, ADAM, PREP)                                                                                                \
     hipLaunchKernelGGL((k_preprocess_bwd<DEG, RAW, CAM, ADAM, PREP>), dim3(grid), dim3(kPreThreads), 0, st, cp, N, a->means3D, a->scales,  \
@@ -2631,7 +2768,7 @@ int gsr_backward(const GsrBackwardArgs* a, void* stream_)
             if (!last_lin)
                 hipLaunchKernelGGL((k_preprocess<3, true>), dim3(1), dim3(kPreThreads), 0, st, po.cp, N, a->means3D, a->scales, a->rotations,
                                    (const float*)nullptr, a->opacities, a->shs, a->shs_rest, (const float*)nullptr, po.splat, po.radii, po.dkey,
-                                   po.gid, po.rec, (uint32_t*)nullptr, 0, grid - 1);
+                                   po.gid, po.rec, (uint32_t*)nullptr, 0, grid - 1, po.dh);
         } else {
         switch (a->shs ? a->D : 0) {
             case 0: GSR_PREB(0); break;

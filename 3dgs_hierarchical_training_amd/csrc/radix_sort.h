@@ -267,6 +267,29 @@ constexpr uint32_t kOsLocal = 1u << 30, kOsIncl = 2u << 30, kOsMask = (1u << 30)
 constexpr uint32_t kOsTicketWords = (4 * kOsRanges + 63) / 64 * 64;   // tickets[pass][run], padded
 constexpr uint32_t kOnesweepHeadWords = 4 * kOsRanges * 256 + kOsTicketWords;   // scratch head: ghist[4][256] + tickets (padded); status follows
 
+// Geometry of the per-run digit counts (what k_radix_ghist produces), for kernels that already hold the keys in registers
+// and count the digits themselves -- the producer of the keys then replaces the histogram launch (hist_done below):
+//   run of key position o  = o / onesweep_run_len<KeyT>(n)          (n = number of keys, as the sort will see it)
+//   digit p of key k       = ((k >> begin_bit) >> (dbits p)) & ((1 << min(dbits, bits - dbits p)) - 1), dbits = onesweep_dbits(bits)
+//   counter                = ghist[(p * kOsRanges + run) * 256 + digit]    (ghist = head of the scratch, zero before the first add)
+// and it clears the status words behind the head: onesweep_status_words<KeyT>(capacity, bits) 32-bit words at onesweep_status(scratch).
+template <typename KeyT>
+__host__ __device__ inline uint32_t onesweep_run_len(uint32_t n)
+{
+    constexpr uint64_t kT = (uint64_t)OsCfg<KeyT>::kTile;
+    const uint64_t ntiles = ((uint64_t)n + kT - 1) / kT, per = (ntiles + kOsRanges - 1) / kOsRanges;
+    return (uint32_t)(per * kT);   // (<= n / 32 + 2 kT: no overflow)
+}
+__host__ __device__ inline int onesweep_passes(int bits) { return (bits + 7) / 8; }
+__host__ __device__ inline int onesweep_dbits(int bits) { const int p = onesweep_passes(bits); return (bits + p - 1) / p; }
+template <typename KeyT>
+__host__ __device__ inline uint32_t onesweep_status_words(uint32_t capacity, int bits)
+{
+    const uint32_t nblocks = (capacity + OsCfg<KeyT>::kTile - 1) / OsCfg<KeyT>::kTile;
+    return (uint32_t)((size_t)onesweep_passes(bits) * nblocks * 256);
+}
+__host__ __device__ inline uint32_t* onesweep_status(void* scratch) { return static_cast<uint32_t*>(scratch) + kOnesweepHeadWords; }
+
 template <typename KeyT, int PASSES>
 __global__ __launch_bounds__(256) void k_radix_ghist(const KeyT* __restrict__ keys, uint32_t n, int begin_bit,
                                                      uint32_t* __restrict__ ghist /*[PASSES][8][256]*/,
@@ -470,7 +493,7 @@ inline size_t onesweep_scratch_bytes(uint32_t n)
 template <typename KeyT>
 inline hipError_t onesweep_sort_pairs(KeyT* keys, uint32_t* vals, KeyT* keys_alt, uint32_t* vals_alt, uint32_t n, int begin_bit,
                                       int end_bit, void* scratch, int* in_alt, hipStream_t stream,
-                                      const unsigned long long* n_dev = nullptr, bool head_prezeroed = false)
+                                      const unsigned long long* n_dev = nullptr, bool head_prezeroed = false, bool hist_done = false)
 {
     *in_alt = 0;
     if (n == 0) return hipSuccess;
@@ -479,14 +502,14 @@ inline hipError_t onesweep_sort_pairs(KeyT* keys, uint32_t* vals, KeyT* keys_alt
     if (passes < 1 || passes > 4) return hipErrorInvalidValue;
     // balanced digits: 12 key bits sort as 6 + 6 rather than 8 + 4 (fewer same-digit collisions in the ranking, longer
     // runs per digit in the scatter); the last digit is narrower when the bits do not divide evenly
-    const int dbits = (bits + passes - 1) / passes;   // (12 tile-key bits as 7 + 5 or 8 + 4: +2 / +5 us)
+    const int dbits = (bits + passes - 1) / passes;   // (12 tile-key bits as 7 + 5 or 8 + 4: +2 / +5 us)  == onesweep_dbits(bits)
     const uint32_t nblocks = (n + OsCfg<KeyT>::kTile - 1) / OsCfg<KeyT>::kTile;   // (the scratch is sized for 4096-key tiles: never fewer words)
     uint32_t* ghist = static_cast<uint32_t*>(scratch);
     uint32_t* tickets = ghist + 4 * kOsRanges * 256;   // [pass][run]
     uint32_t* status = tickets + kOsTicketWords;
     // the head (histograms + tickets) must be zero before the histogram kernel; callers that can clear it in a kernel
     // of their own say so.  The status words are cleared by the histogram kernel itself.
-    if (!head_prezeroed) {
+    if (!head_prezeroed && !hist_done) {
         hipError_t e = hipMemsetAsync(scratch, 0, kOnesweepHeadWords * sizeof(uint32_t), stream);
         if (e != hipSuccess) return e;
     }
@@ -494,6 +517,8 @@ inline hipError_t onesweep_sort_pairs(KeyT* keys, uint32_t* vals, KeyT* keys_alt
     // (64 blocks of 1024 threads, to shorten the per-address chains of the closing global atomics: +5 us per sort)
     const uint32_t per_cap = (nblocks + kOsRanges - 1) / kOsRanges;
     const uint32_t hgrid = kOsRanges * (per_cap < 32u ? per_cap : 32u);   // histogram blocks: up to 32 per run
+    // hist_done: the kernel that produced the keys counted the digits and cleared the status words (see onesweep_run_len)
+    if (!hist_done)
     switch (passes) {
         case 1: hipLaunchKernelGGL((k_radix_ghist<KeyT, 1>), dim3(hgrid), dim3(256), 0, stream, keys, n, begin_bit, ghist, n_dev, status, status_words, dbits, bits); break;
         case 2: hipLaunchKernelGGL((k_radix_ghist<KeyT, 2>), dim3(hgrid), dim3(256), 0, stream, keys, n, begin_bit, ghist, n_dev, status, status_words, dbits, bits); break;

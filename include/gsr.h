@@ -82,7 +82,9 @@ typedef struct GsrForwardArgs {
     /* ---- "prepare in backward" (see GsrNextView): the buffer a preceding gsr_backward filled through
      * GsrBackwardArgs::prepared_out for THIS camera and THESE parameter values.  Then `geom` must be the same pointer (the
      * splat records are its first gsr_geom_bytes(N) bytes), k_preprocess is skipped, and the result is bit-identical to a
-     * forward without it.  NULL = ordinary forward.  The buffer is consumed (its sort keys are sorted in place). */
+     * forward without it.  NULL = ordinary forward.  The buffer is consumed: it also holds the depth sort's scratch, pre-cleared
+     * (and for N <= 262 144 with the digit counts already in it) by that backward, and its sort keys are sorted in place --
+     * one forward per hand-over. */
     void* prepared;
 } GsrForwardArgs;
 
