@@ -44,6 +44,7 @@ static int g_bwd_ppt = 0;
 // evaluate the same predicate on N.
 static int g_prep_hist_max_n = 262144;
 static inline bool prep_counts_digits(int N) { return N <= g_prep_hist_max_n; }
+static int g_poll_iters = 20000;   // busy-wait bound of gsr_forward's poll for R (0 = always wait on the event)
 static int g_emit_hist = 1;   // 1: k_emit counts the tile sort's digits (no histogram launch); 0: k_radix_ghist
 static int g_sort_algo = 2;   // 2: onesweep for both sorts; 1: onesweep depth sort + hist/scan/scatter tile sort; 0: hist/scan/scatter
 
@@ -58,6 +59,13 @@ static int fail(int code, const char* fmt, const char* detail = "")
         hipError_t e_ = (expr);                                               \
         if (e_ != hipSuccess) return fail(GSR_ERR_HIP, #expr ": %s", hipGetErrorString(e_)); \
     } while (0)
+
+static inline void cpu_relax()
+{
+#if !defined(__HIP_DEVICE_COMPILE__) && (defined(__x86_64__) || defined(__i386__))
+    __builtin_ia32_pause();
+#endif
+}
 
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -515,7 +523,7 @@ struct ZeroJobs {
 // host_out is given, into pinned host memory (device-visible): the count reaches the host without a copy launch
 template <int NTHR>
 __device__ __forceinline__ void block_scan_body(uint32_t* block_sums, int nb, unsigned long long* total_out, const ZeroJobs& zj,
-                                                unsigned long long* host_out, unsigned long long* s_wsum /*[NTHR/64]*/)
+                                                unsigned long long* host_out, unsigned long long host_seq, unsigned long long* s_wsum /*[NTHR/64]*/)
 {
     constexpr int NWV = NTHR / 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -548,7 +556,12 @@ __device__ __forceinline__ void block_scan_body(uint32_t* block_sums, int nb, un
     }
     if (tid == 0) {
         *total_out = all;
-        if (host_out) { __atomic_store_n(host_out, all, __ATOMIC_RELAXED); __threadfence_system(); }
+        if (host_out) {   // the count, then the call's sequence number: the host polls the second word (gsr_forward)
+            __atomic_store_n(host_out, all, __ATOMIC_RELAXED);
+            __threadfence_system();
+            __atomic_store_n(host_out + 1, host_seq, __ATOMIC_RELAXED);
+            __threadfence_system();
+        }
     }
 }
 
@@ -573,10 +586,10 @@ __global__ __launch_bounds__(kEmitThreads) void k_tile_counts(int N, const uint3
 //  saves the launch but measured 140 us at 1 M Gaussians and +2 us at 50 k: the totals of 3 907 blocks read through
 //  coherent loads by 256 threads are a long latency chain; the single-workgroup launch below stays)
 __global__ __launch_bounds__(1024) void k_block_scan(uint32_t* __restrict__ block_sums, int nb, unsigned long long* __restrict__ total_out,
-                                                     ZeroJobs zj, unsigned long long* __restrict__ host_out)
+                                                     ZeroJobs zj, unsigned long long* __restrict__ host_out, unsigned long long host_seq)
 {
     __shared__ unsigned long long s_wsum[16];
-    block_scan_body<1024>(block_sums, nb, total_out, zj, host_out, s_wsum);
+    block_scan_body<1024>(block_sums, nb, total_out, zj, host_out, host_seq, s_wsum);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2186,7 +2199,8 @@ static BinScratch bin_scratch_layout(int64_t R, int key_bytes = 4)
 // The pinned read-back slot and its event belong to ONE device (an event recorded on another device's stream is an
 // invalid-handle error), and a slot is held by one call at a time: callers on several threads / devices do not serialise
 // on each other while they enqueue or wait.
-struct PinSlot { unsigned long long* host = nullptr; unsigned long long* dev = nullptr; hipEvent_t ev = nullptr; bool busy = false; };
+struct PinSlot { unsigned long long* host = nullptr; unsigned long long* dev = nullptr; hipEvent_t ev = nullptr; bool busy = false;
+                 unsigned long long seq = 0; };   // seq: number of the slot's last use; the scan kernel echoes it behind the count
 static std::mutex g_state_mutex;
 static std::map<int, std::vector<PinSlot*>> g_pin_slots;                     // device -> slots
 static std::map<std::tuple<int, int, int, int>, uint64_t> g_hints;         // (device, W, H, bucket of N) -> capacity
@@ -2210,6 +2224,7 @@ static PinSlot* acquire_pin_slot(int dev)
     if (hipHostMalloc((void**)&s->host, 64, hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer((void**)&s->dev, s->host, 0) != hipSuccess ||
         hipEventCreateWithFlags(&s->ev, hipEventDisableTiming) != hipSuccess) { delete s; return nullptr; }
+    s->host[0] = 0; s->host[1] = 0;
     s->busy = true;
     v.push_back(s);
     return s;
@@ -2326,6 +2341,7 @@ int gsr_set_option(const char* name, int value)
     }
     if (!strcmp(name, "profile")) { g_profile = (value == 2) ? 2 : (value ? 1 : 0); return GSR_OK; }
     if (!strcmp(name, "prep_hist_max_n")) { g_prep_hist_max_n = value; return GSR_OK; }
+    if (!strcmp(name, "poll_iters")) { g_poll_iters = value < 0 ? 0 : value; return GSR_OK; }
     if (!strcmp(name, "emit_hist")) { g_emit_hist = value ? 1 : 0; return GSR_OK; }
     if (!strcmp(name, "sort_algo")) { if (value < 0 || value > 2) return GSR_ERR_ARG; g_sort_algo = value; return GSR_OK; }
     // 2 = packed-math kernel (default), 3 = scalar 2-pixel kernel (kept for A/B), 1 / 4 = scalar 1 / 4 pixels
@@ -2570,7 +2586,7 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
         hipLaunchKernelGGL(k_tile_counts, dim3(nb), dim3(kEmitThreads), 0, st, N, sorted_gid, ntiles, block_sums,
                            reinterpret_cast<TileRec*>(fs + L.srec));
         // the scan writes R straight into the pinned slot (device-visible host memory): no copy launch behind it
-        hipLaunchKernelGGL(k_block_scan, dim3(1), dim3(1024), 0, st, block_sums, nb, total, zj, pin.s->dev);
+        hipLaunchKernelGGL(k_block_scan, dim3(1), dim3(1024), 0, st, block_sums, nb, total, zj, pin.s->dev, ++pin.s->seq);
     }
     GSR_HIP(hipGetLastError());
 
@@ -2580,7 +2596,18 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
         if (rc) return rc;
         rc = launch_blend(true);
         if (rc) return rc;
-        GSR_HIP(hipEventSynchronize(pin.s->ev));   // long past by the time the host gets here
+        // The host needs R: it polls the pinned word the scan kernel writes (seen ~1 us after the store) and only falls back to
+        // the event -- a barrier packet + completion signal behind the kernel, several us later -- when the device is far
+        // behind (the poll is bounded to ~1 ms of busy waiting) or has faulted (the event reports it).
+        {
+            volatile unsigned long long* hp = pin.s->host;
+            const unsigned long long want = pin.s->seq;
+            bool seen = false;
+            if (g_poll_iters > 0)
+                for (int it = 0; it < g_poll_iters && !(seen = (hp[1] == want)); it++) cpu_relax();
+            if (!seen) GSR_HIP(hipEventSynchronize(pin.s->ev));
+            std::atomic_thread_fence(std::memory_order_acquire);
+        }
         g_spec_forwards++;
     } else {
         GSR_HIP(hipStreamSynchronize(st));
