@@ -326,20 +326,26 @@ def test_extension_ops_run_under_torch_compile():
         assert (a - b).abs().max().item() <= 2e-5 * a.abs().max().item() + 1e-12
 
 
+@pytest.mark.parametrize("digits_in_backward", [True, False], ids=["digits-counted-in-backward", "histogram-launch"])
 @pytest.mark.parametrize("N", [12800, 10007, 4098], ids=["whole-blocks", "ragged-odd", "ragged-mod4"])
-def test_prepare_in_backward_is_bit_identical(N):
+def test_prepare_in_backward_is_bit_identical(N, digits_in_backward):
     """"Prepare in backward" (GsrNextView): with `next_settings` the backward that applies the Adam step also runs the NEXT
     render's preprocess on the updated parameters, and that render skips k_preprocess.  Two copies of one model trained on
     two alternating cameras, one with and one without the hand-over, must stay EQUAL: images, radii, parameters, moments --
     bit for bit, on whole blocks and on ragged last blocks (N not a multiple of 128 / of 4).  (The blend backward runs in its
-    deterministic debug mode here: with float atomics two runs of the SAME path already differ in the last bits.)"""
+    deterministic debug mode here: with float atomics two runs of the SAME path already differ in the last bits.)
+    The hand-over buffer also carries the next depth sort's scratch: its counters are cleared by the blend backward, and up
+    to 262 144 Gaussians the per-Gaussian kernel counts the sort's digits too (no histogram launch in the forward); both
+    sides of that threshold are run here ("prep_hist_max_n")."""
     L = importlib.import_module("3dgs_hierarchical_training_amd._lib")
     lib = L.load()
     assert lib.gsr_set_option(b"deterministic_backward", 1) == 0
+    assert lib.gsr_set_option(b"prep_hist_max_n", 262144 if digits_in_backward else 0) == 0
     try:
         _prepare_in_backward_case(N)
     finally:
         lib.gsr_set_option(b"deterministic_backward", 0)
+        lib.gsr_set_option(b"prep_hist_max_n", 262144)
 
 
 def _prepare_in_backward_case(N):

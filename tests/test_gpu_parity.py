@@ -680,6 +680,40 @@ def test_models_of_different_size_alternate_without_overflow_reruns():
     assert lib.gsr_get_counter(b"spec_overflows") == 0
 
 
+@pytest.mark.parametrize("N,W,H,scale", [(20000, 330, 250, 1.0), (300000, 980, 545, 1.0), (3000, 64, 48, 1.0), (3000, 320, 240, 12.0)],
+                         ids=["20k", "300k", "tiny-frame", "large-splats"])
+def test_emit_counts_the_tile_sort_digits(N, W, H, scale):
+    """In the speculative flow k_emit counts the digits of the tile keys it writes (per run of the tile sort) and clears the
+    sort's status words, so no histogram kernel runs in front of the sort's passes (gsr_set_option("emit_hist")).  The per-tile
+    lists -- (ranges, list) through gsr_debug_read_binning -- and the images must be EQUAL to those of the histogram-launch
+    route.  The tiny frame has fewer keys than one run of the sort; with large splats (scale_modifier 12: ~100 tiles per
+    Gaussian, the per-wave emission path) one workgroup's output spans more than two runs, which takes the direct-global-add path."""
+    import importlib
+    import hip_runner
+    L = importlib.import_module("3dgs_hierarchical_training_amd._lib")
+    R_ = importlib.import_module("3dgs_hierarchical_training_amd.rasterizer")
+    lib = L.load()
+    sc = parity.syn.make_scene(N, W, H, sh_degree=3, seed=11, posed=True)
+    sc["scale_modifier"] = scale
+    kw = parity.scene_kwargs(sc, "sh", bg=(0.1, 0.2, 0.3))
+    out = {}
+    try:
+        for mode in (0, 1):
+            assert lib.gsr_set_option(b"emit_hist", mode) == 0
+            lib.gsr_set_option(b"reset_speculation", 1)
+            hip_runner.run_hip(kw)                       # first sight: exact flow, leaves the capacity hint
+            n0 = lib.gsr_get_counter(b"spec_forwards")
+            fwd = hip_runner.run_hip(kw)["fwd"]           # speculative flow
+            assert lib.gsr_get_counter(b"spec_forwards") > n0 and lib.gsr_get_counter(b"spec_overflows") == 0
+            ranges, lst = R_.last_binning()
+            out[mode] = (fwd, ranges.cpu().numpy(), lst.cpu().numpy())
+    finally:
+        lib.gsr_set_option(b"emit_hist", 1)
+    assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+    for a, b in zip(out[0][0], out[1][0]):
+        assert np.array_equal(a, b)
+
+
 def test_sign_encoded_forward_is_bit_identical_with_the_lane_mask_kernel():
     """k_blend_fwd_w6 (default) represents a finished pixel by the sign of its transmittance instead of a lane mask;
     every decision and every accumulation of a live pixel is the same instruction sequence, so the images are EQUAL."""
