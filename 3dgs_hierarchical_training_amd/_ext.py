@@ -41,7 +41,7 @@ def _register_fakes():
     @torch.library.register_fake("gsr::rasterize_forward")
     def _(means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, sh_rest, viewmatrix, projmatrix, campos, bg,
           points_transform, image_height, image_width, tanfovx, tanfovy, scale_modifier, sh_degree, raw_params, prefiltered, debug,
-          prepared, backward_scratch):
+          prepared):
         N, H, W = means3D.shape[0], image_height, image_width
         f = lambda *s: means3D.new_empty(s, dtype=torch.float32)
         b = lambda n: means3D.new_empty((n,), dtype=torch.uint8)
@@ -64,7 +64,7 @@ def _register_fakes():
     @torch.library.register_fake("gsr::rasterize_backward")
     def _(means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, sh_rest, viewmatrix, projmatrix, campos, bg,
           points_transform, geom, image, binning, meta, grad_color, grad_depth, grad_alpha, image_height, image_width, tanfovx, tanfovy,
-          scale_modifier, sh_degree, raw_params, need_viewmatrix, need_projmatrix, need_campos, need_points_transform, scratch):
+          scale_modifier, sh_degree, raw_params, need_viewmatrix, need_projmatrix, need_campos, need_points_transform):
         N = means3D.shape[0]
         f = lambda *s: means3D.new_empty(s, dtype=torch.float32)
         has = lambda t: t.numel() > 0

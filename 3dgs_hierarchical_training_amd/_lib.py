@@ -24,7 +24,7 @@ class GsrForwardArgs(C.Structure):
         ("geom", C.c_void_p), ("image", C.c_void_p),
         ("alloc", ALLOC_FN), ("alloc_user", C.c_void_p),
         ("shs_rest", C.c_void_p), ("raw_params", C.c_int32),
-        ("points_transform", C.c_void_p), ("prepared", C.c_void_p), ("backward_scratch", C.c_void_p),
+        ("points_transform", C.c_void_p), ("prepared", C.c_void_p),
     ]
 
 

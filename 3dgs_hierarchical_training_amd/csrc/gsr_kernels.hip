@@ -1018,19 +1018,16 @@ __global__ __launch_bounds__(64) void k_blend_fwd_w6(int W, int H, int tiles_x, 
                                                      const float* __restrict__ bg, float* __restrict__ out_color,
                                                      float* __restrict__ out_depth, float* __restrict__ out_alpha,
                                                      float* __restrict__ img, uint32_t* __restrict__ staged4, int interleave,
-                                                     float* __restrict__ ckpt, int kCkptFirst, uint4* __restrict__ zero4, uint32_t zero_n4)
+                                                     float* __restrict__ ckpt, int kCkptFirst)
 {
     constexpr int NT = 64;
     __shared__ float4 s_a[2][NT], s_b[2][NT];
     __shared__ float2 s_c[2][NT];
-    const int lane = threadIdx.x;
-    // GsrForwardArgs::backward_scratch: the coming backward's gradient accumulators are cleared here, a few 16-byte stores per
-    // wave of a kernel whose HBM pipe is idle, instead of by a 48 N-byte memset (+ a kernel boundary) in front of the blend backward
-    for (uint32_t q = blockIdx.x * NT + lane; q < zero_n4; q += gridDim.x * NT) zero4[q] = make_uint4(0u, 0u, 0u, 0u);
     const int kslot = blockIdx.x >> 3;
     const int tile = slot_tile(interleave, (int)(blockIdx.x & 7), kslot >> 2, T, tiles_x);
     const int sub = kslot & 3;
     if (tile < 0) return;
+    const int lane = threadIdx.x;
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int px = tx * kTile + (sub & 1) * 8 + (lane & 7);
     const int py = ty * kTile + (sub >> 1) * 8 + (lane >> 3);
@@ -2241,7 +2238,6 @@ struct PinLease {   // releases the slot on every exit path
 // What the forward fixed for its backward (GsrForwardOut::forward_flags): the blend kernel variant, the tile -> XCD map,
 // the first checkpointed batch and whether checkpoints were written at all.  gsr_backward reads them from the flags
 // instead of the process-wide options as they happen to be at backward time.
-constexpr int64_t kFwdFlagScratchCleared = 1ll << 14;   // the forward cleared GsrForwardArgs::backward_scratch
 static inline int64_t pack_fwd_flags(int ppt, int tile_map, int ckpt_first)
 {
     return 1 | ((int64_t)ppt << 1) | ((int64_t)tile_map << 4) | ((int64_t)ckpt_first << 6) | ((int64_t)(ppt >= 5) << 13);
@@ -2447,9 +2443,6 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
     auto launch_binning = [&](uint64_t capacity, const unsigned long long* n_dev, bool prezeroed) -> int {
         return wide_keys ? launch_binning_t(uint32_t{}, capacity, n_dev, prezeroed) : launch_binning_t(uint16_t{}, capacity, n_dev, prezeroed);
     };
-    // GsrForwardArgs::backward_scratch: cleared by the blend kernel (variants 6 / 7), reported in forward_flags bit 14
-    uint4* bwd_zero4 = (a->backward_scratch && opt_ppt >= 6) ? static_cast<uint4*>(a->backward_scratch) : nullptr;
-    const uint32_t bwd_zero_n4 = bwd_zero4 ? (uint32_t)(((size_t)N * kGG * 4 + 15) / 16) : 0u;
     auto launch_blend = [&](bool prezeroed) -> int {
         const int ppt = opt_ppt;   // default 7: one wave per 8x8 sub-tile, sign-encoded done + sub-tile reach bits (6: without the bits, 5: lane mask)
         if (!prezeroed) GSR_HIP(hipMemsetAsync(staged, 0, (size_t)T * 16, st));
@@ -2461,12 +2454,10 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
                                    reinterpret_cast<float*>(bin + B.ckpt), opt_ckpt);
             else if (ppt == 7)
                 hipLaunchKernelGGL(k_blend_fwd_w6<true>, dim3(8 * 4 * slots_per_xcd(opt_map, T, tiles_x)), dim3(64), 0, st, W, H, tiles_x, T, ranges, list, splat, a->bg,
-                                   a->out_color, a->out_depth, a->out_alpha, img, staged, opt_map, reinterpret_cast<float*>(bin + B.ckpt), opt_ckpt,
-                                   bwd_zero4, bwd_zero_n4);
+                                   a->out_color, a->out_depth, a->out_alpha, img, staged, opt_map, reinterpret_cast<float*>(bin + B.ckpt), opt_ckpt);
             else if (ppt == 6)
                 hipLaunchKernelGGL(k_blend_fwd_w6<false>, dim3(8 * 4 * slots_per_xcd(opt_map, T, tiles_x)), dim3(64), 0, st, W, H, tiles_x, T, ranges, list, splat, a->bg,
-                                   a->out_color, a->out_depth, a->out_alpha, img, staged, opt_map, reinterpret_cast<float*>(bin + B.ckpt), opt_ckpt,
-                                   bwd_zero4, bwd_zero_n4);
+                                   a->out_color, a->out_depth, a->out_alpha, img, staged, opt_map, reinterpret_cast<float*>(bin + B.ckpt), opt_ckpt);
             else if (ppt == 1) launch_blend_fwd<1>(W, H, tiles_x, T, ranges, list, splat, a->bg, a->out_color, a->out_depth, a->out_alpha, img, staged, st);
             else if (ppt == 2)
                 hipLaunchKernelGGL(k_blend_fwd2, dim3(8 * ((T + 7) / 8)), dim3(128), 0, st, W, H, tiles_x, T, ranges, list, splat, a->bg,
@@ -2646,7 +2637,7 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
     out->binning = bin;
     out->binning_bytes = B.bytes;
     out->binning_capacity = (int64_t)((speculative && R <= cap) ? cap : R);
-    out->forward_flags = pack_fwd_flags(opt_ppt, opt_map, opt_ckpt) | (bwd_zero4 ? kFwdFlagScratchCleared : 0);
+    out->forward_flags = pack_fwd_flags(opt_ppt, opt_map, opt_ckpt);
     return GSR_OK;
 }
 
@@ -2681,8 +2672,7 @@ int gsr_backward(const GsrBackwardArgs* a, void* stream_)
     const uint2* ranges = reinterpret_cast<const uint2*>(bin + B.ranges);
     const uint32_t* list = reinterpret_cast<const uint32_t*>(bin + B.list);
     float* gg = static_cast<float*>(a->scratch);
-    // (cleared by the forward's blend kernel when it was given this very buffer as backward_scratch)
-    if (!(a->forward_flags & kFwdFlagScratchCleared)) GSR_HIP(hipMemsetAsync(gg, 0, (size_t)N * kGG * 4, st));
+    GSR_HIP(hipMemsetAsync(gg, 0, (size_t)N * kGG * 4, st));
     // prepare in backward: the digit counters of the next forward's depth sort live in the hand-over buffer; they are cleared by
     // the blend kernel's workgroup 0 (no launch of their own) and filled by the per-Gaussian kernel behind it
     uint32_t* prep_head = (a->next_view && a->prepared_out) ? reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(a->prepared_out) + prep_layout(N).sort) : nullptr;

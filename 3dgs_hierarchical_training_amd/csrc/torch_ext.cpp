@@ -83,8 +83,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> raste
     const Tensor& means3D_, const Tensor& sh_, const Tensor& colors_, const Tensor& opacities_, const Tensor& scales_,
     const Tensor& rotations_, const Tensor& cov3D_, const Tensor& sh_rest_, const Tensor& viewmatrix_, const Tensor& projmatrix_,
     const Tensor& campos_, const Tensor& bg_, const Tensor& xf_, int64_t H, int64_t W, double tanfovx, double tanfovy,
-    double scale_modifier, int64_t sh_degree, bool raw_params, bool prefiltered, bool debug, const Tensor& prepared,
-    Tensor backward_scratch)
+    double scale_modifier, int64_t sh_degree, bool raw_params, bool prefiltered, bool debug, const Tensor& prepared)
 {
     TORCH_CHECK(means3D_.is_cuda(), "GaussianRasterizer: tensors must be on a ROCm/HIP device (no CPU fallback)");
     const c10::hip::HIPGuardMasqueradingAsCUDA guard(means3D_.device());
@@ -122,12 +121,6 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> raste
     a.shs_rest = fp(rest); a.raw_params = raw_params;
     a.points_transform = fp(xf);
     a.prepared = has(prepared) ? prepared.data_ptr() : nullptr;
-    // the coming backward's scratch: the blend kernel clears its gradient accumulators on the side (no memset in the backward)
-    if (has(backward_scratch)) {
-        TORCH_CHECK(backward_scratch.is_contiguous() && backward_scratch.scalar_type() == at::kByte &&
-                        backward_scratch.numel() >= (int64_t)gsr_backward_scratch_bytes((int32_t)N), "backward_scratch is too small");
-        a.backward_scratch = backward_scratch.data_ptr();
-    }
     GsrForwardOut out{};
     check(gsr_forward(&a, &out, c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()), "gsr_forward");
     // (scratch tensors die here: stream-ordered reuse by the caching allocator is safe, same stream)
@@ -173,7 +166,7 @@ std::vector<Tensor> rasterize_backward(
     const Tensor& cov, const Tensor& rest, const Tensor& vm, const Tensor& pm, const Tensor& campos, const Tensor& bg, const Tensor& xf,
     const Tensor& geom, const Tensor& image, const Tensor& binning, const Tensor& meta, const Tensor& grad_color, const Tensor& grad_depth,
     const Tensor& grad_alpha, int64_t H, int64_t W, double tanfovx, double tanfovy, double scale_modifier, int64_t sh_degree,
-    bool raw_params, bool need_vm, bool need_pm, bool need_campos, bool need_xf, Tensor scratch_in)
+    bool raw_params, bool need_vm, bool need_pm, bool need_campos, bool need_xf)
 {
     const c10::hip::HIPGuardMasqueradingAsCUDA guard(means3D.device());
     BwdCommon b{means3D, sh, colors, opac, scales, rots, cov, rest, vm, pm, campos, bg, xf, f32c(grad_color), f32c(grad_depth), f32c(grad_alpha)};
@@ -190,11 +183,9 @@ std::vector<Tensor> rasterize_backward(
     Tensor d_vm = need_vm ? at::empty({4, 4}, fo) : none, d_pm = need_pm ? at::empty({4, 4}, fo) : none;
     Tensor d_cp = need_campos ? at::empty({3}, fo) : none;
     Tensor d_xf = (need_xf && has(xf)) ? at::zeros({3, 4}, fo) : none;
-    // (the forward's backward_scratch when there is one: its accumulators were cleared by the blend kernel)
-    Tensor scratch = has(scratch_in) ? scratch_in : at::empty({(int64_t)gsr_backward_scratch_bytes((int32_t)N)}, means3D.options().dtype(at::kByte));
+    Tensor scratch = at::empty({(int64_t)gsr_backward_scratch_bytes((int32_t)N)}, means3D.options().dtype(at::kByte));
     GsrBackwardArgs a{};
     fill_backward_args(a, b, geom, image, binning, meta, H, W, tanfovx, tanfovy, scale_modifier, sh_degree, raw_params);
-    if (!has(scratch_in)) a.forward_flags &= ~(int64_t)(1 << 14);
     a.d_means3D = fpm(d_means3D); a.d_means2D = fpm(d_means2D); a.d_opacities = fpm(d_opac);
     a.d_colors_precomp = fpm(d_col); a.d_shs = fpm(d_sh); a.d_scales = fpm(d_scales); a.d_rotations = fpm(d_rot);
     a.d_cov3D_precomp = fpm(d_cov); a.d_shs_rest = fpm(d_rest);
@@ -213,7 +204,7 @@ std::vector<Tensor> rasterize_backward_fused(
     double scale_modifier, int64_t sh_degree, bool need_vm, bool need_pm, bool need_campos, bool need_xf, at::TensorList adam_m,
     at::TensorList adam_v, at::ArrayRef<double> adam_lr, double beta1, double beta2, double eps, int64_t step, const Tensor& next_vm,
     const Tensor& next_pm, const Tensor& next_campos, int64_t next_H, int64_t next_W, double next_tanfovx, double next_tanfovy,
-    Tensor prepared_out, Tensor scratch_in)
+    Tensor prepared_out)
 {
     const c10::hip::HIPGuardMasqueradingAsCUDA guard(means3D.device());
     TORCH_CHECK(adam_m.size() == 6 && adam_v.size() == 6 && adam_lr.size() == 6, "fused_adam: six groups expected");
@@ -225,7 +216,7 @@ std::vector<Tensor> rasterize_backward_fused(
     Tensor d_vm = need_vm ? at::empty({4, 4}, fo) : none, d_pm = need_pm ? at::empty({4, 4}, fo) : none;
     Tensor d_cp = need_campos ? at::empty({3}, fo) : none;
     Tensor d_xf = (need_xf && has(xf)) ? at::zeros({3, 4}, fo) : none;
-    Tensor scratch = has(scratch_in) ? scratch_in : at::empty({(int64_t)gsr_backward_scratch_bytes((int32_t)N)}, means3D.options().dtype(at::kByte));
+    Tensor scratch = at::empty({(int64_t)gsr_backward_scratch_bytes((int32_t)N)}, means3D.options().dtype(at::kByte));
     GsrFusedAdam fa{};
     fa.beta1 = (float)beta1; fa.beta2 = (float)beta2; fa.eps = (float)eps; fa.step = step;
     for (int q = 0; q < 6; q++) {
@@ -236,7 +227,6 @@ std::vector<Tensor> rasterize_backward_fused(
     }
     GsrBackwardArgs a{};
     fill_backward_args(a, b, geom, image, binning, meta, H, W, tanfovx, tanfovy, scale_modifier, sh_degree, true);
-    if (!has(scratch_in)) a.forward_flags &= ~(int64_t)(1 << 14);
     a.d_means2D = fpm(d_means2D);
     a.d_viewmatrix = fpm(d_vm); a.d_projmatrix = fpm(d_pm); a.d_campos = fpm(d_cp); a.d_points_transform = fpm(d_xf);
     a.scratch = scratch.data_ptr();
@@ -284,19 +274,15 @@ class RasterizeFn : public torch::autograd::Function<RasterizeFn> {
         const Tensor m3 = f32c(means3D), s = f32c(sh), c = f32c(colors), o = f32c(opac), sc = f32c(scales), r = f32c(rots), cv = f32c(cov),
                      rs = f32c(rest), v = f32c(vm), p = f32c(pm), cp = f32c(campos), b = f32c(bg), x = f32c(has(xf) ? xf.slice(0, 0, 3) : xf);
         Tensor none;
-        // this render WILL be differentiated (autograd is recording): its backward's scratch is allocated now, so that the
-        // blend kernel can clear the gradient accumulators in passing
-        Tensor bscratch = at::empty({(int64_t)gsr_backward_scratch_bytes((int32_t)m3.size(0))}, m3.options().dtype(at::kByte));
         auto out = op.call(m3, s, c, o, sc, r, cv, rs, v, p, cp, b, x, cfg.H, cfg.W, cfg.tanfovx, cfg.tanfovy, cfg.scale_modifier,
-                           cfg.sh_degree, cfg.raw_params, cfg.prefiltered, cfg.debug, cfg.prepared.defined() ? cfg.prepared : x.new_empty({0}, x.options().dtype(at::kByte)),
-                           bscratch);
+                           cfg.sh_degree, cfg.raw_params, cfg.prefiltered, cfg.debug, cfg.prepared.defined() ? cfg.prepared : x.new_empty({0}, x.options().dtype(at::kByte)));
         // hand-over buffer for the NEXT render, filled by this render's backward (stream-ordered): allocated here so that it
         // can be returned to the caller as an ordinary output
         Tensor prep_out = has(cfg.next_vm) ? at::empty({(int64_t)gsr_prepared_bytes((int32_t)m3.size(0))}, m3.options().dtype(at::kByte))
                                            : at::empty({0}, m3.options().dtype(at::kByte));
         // NOTE: depth is deliberately NOT saved -- the caller mutates it in place (ht3dgs_trainer.py:1290-1292)
         std::vector<Tensor> saved = {m3, s, c, o, sc, r, cv, rs, v, p, cp, b, x, std::get<4>(out), std::get<5>(out), std::get<6>(out),
-                                     std::get<7>(out), bscratch};
+                                     std::get<7>(out)};
         ctx->save_for_backward(saved);
         ctx->saved_data["adam_m"] = cfg.adam_m; ctx->saved_data["adam_v"] = cfg.adam_v;
         ctx->saved_data["H"] = cfg.H; ctx->saved_data["W"] = cfg.W; ctx->saved_data["D"] = cfg.sh_degree;
@@ -347,15 +333,12 @@ class RasterizeFn : public torch::autograd::Function<RasterizeFn> {
                              ctx->saved_data["b1"].toDouble(), ctx->saved_data["b2"].toDouble(), ctx->saved_data["eps"].toDouble(),
                              ctx->saved_data["step"].toInt(), nc[0], nc[1], nc[2], ctx->saved_data["next_H"].toInt(),
                              ctx->saved_data["next_W"].toInt(), ctx->saved_data["next_tfx"].toDouble(), ctx->saved_data["next_tfy"].toDouble(),
-                             ctx->saved_data["prep_out"].toTensor(), sv[17]);
+                             ctx->saved_data["prep_out"].toTensor());
             out[1] = r[0]; out[9] = r[1]; out[10] = r[2]; out[11] = r[3]; d_xf = r[4];
         } else {
             static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("gsr::rasterize_backward", "").typed<decltype(rasterize_backward)>();
-            const bool first = !ctx->saved_data["done"].toBool();
-            ctx->saved_data["done"] = true;
             auto r = op.call(sv[0], sv[1], sv[2], sv[3], sv[4], sv[5], sv[6], sv[7], sv[8], sv[9], sv[10], sv[11], sv[12], sv[13], sv[14],
-                             sv[15], sv[16], orE(gc), orE(gd), orE(ga), H, W, tfx, tfy, smod, D, raw, need_vm, need_pm, need_cp, need_xf,
-                             first ? sv[17] : e);   // (a second backward over the same render: the pre-cleared scratch is used up)
+                             sv[15], sv[16], orE(gc), orE(gd), orE(ga), H, W, tfx, tfy, smod, D, raw, need_vm, need_pm, need_cp, need_xf);
             out[0] = r[0]; out[1] = r[1]; out[2] = r[2]; out[3] = r[3]; out[4] = r[4]; out[5] = r[5]; out[6] = r[6]; out[7] = r[7]; out[8] = r[8];
             out[9] = r[9]; out[10] = r[10]; out[11] = r[11]; d_xf = r[12];
         }
@@ -397,8 +380,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> rasterize_forward_only(
     (void)means2D; (void)cam_grad; (void)adam_m; (void)adam_v; (void)adam_lr; (void)beta1; (void)beta2; (void)eps; (void)step;
     (void)next_vm; (void)next_pm; (void)next_campos; (void)next_H; (void)next_W; (void)next_tanfovx; (void)next_tanfovy;
     auto out = rasterize_forward(means3D, sh, colors, opac, scales, rots, cov, rest, vm, pm, campos, bg, has(xf) ? xf.slice(0, 0, 3) : xf, H, W,
-                                 tanfovx, tanfovy, scale_modifier, sh_degree, raw_params, prefiltered, debug, prepared,
-                                 at::empty({0}, means3D.options().dtype(at::kByte)));
+                                 tanfovx, tanfovy, scale_modifier, sh_degree, raw_params, prefiltered, debug, prepared);
     return {std::get<0>(out), std::get<1>(out), std::get<2>(out), std::get<3>(out), at::empty({0}, means3D.options().dtype(at::kByte))};
 }
 
@@ -484,19 +466,19 @@ TORCH_LIBRARY(gsr, m)
     m.def("rasterize_forward(Tensor means3D, Tensor sh, Tensor colors_precomp, Tensor opacities, Tensor scales, Tensor rotations, "
           "Tensor cov3D_precomp, Tensor sh_rest, Tensor viewmatrix, Tensor projmatrix, Tensor campos, Tensor bg, Tensor points_transform, "
           "int image_height, int image_width, float tanfovx, float tanfovy, float scale_modifier, int sh_degree, bool raw_params, "
-          "bool prefiltered, bool debug, Tensor prepared, Tensor(a!) backward_scratch) -> (Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)");
+          "bool prefiltered, bool debug, Tensor prepared) -> (Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)");
     m.def("rasterize_backward(Tensor means3D, Tensor sh, Tensor colors_precomp, Tensor opacities, Tensor scales, Tensor rotations, "
           "Tensor cov3D_precomp, Tensor sh_rest, Tensor viewmatrix, Tensor projmatrix, Tensor campos, Tensor bg, Tensor points_transform, "
           "Tensor geom, Tensor image, Tensor binning, Tensor meta, Tensor grad_color, Tensor grad_depth, Tensor grad_alpha, "
           "int image_height, int image_width, float tanfovx, float tanfovy, float scale_modifier, int sh_degree, bool raw_params, "
-          "bool need_viewmatrix, bool need_projmatrix, bool need_campos, bool need_points_transform, Tensor(a!) scratch) -> Tensor[]");
+          "bool need_viewmatrix, bool need_projmatrix, bool need_campos, bool need_points_transform) -> Tensor[]");
     m.def("rasterize_backward_fused(Tensor(a!) means3D, Tensor(b!) sh, Tensor(c!) sh_rest, Tensor(d!) opacities, Tensor(e!) scales, "
           "Tensor(f!) rotations, Tensor viewmatrix, Tensor projmatrix, Tensor campos, Tensor bg, Tensor points_transform, Tensor geom, "
           "Tensor image, Tensor binning, Tensor meta, Tensor grad_color, Tensor grad_depth, Tensor grad_alpha, int image_height, "
           "int image_width, float tanfovx, float tanfovy, float scale_modifier, int sh_degree, bool need_viewmatrix, bool need_projmatrix, "
           "bool need_campos, bool need_points_transform, Tensor(g!)[] adam_m, Tensor(h!)[] adam_v, float[] adam_lr, float beta1, "
           "float beta2, float eps, int step, Tensor next_viewmatrix, Tensor next_projmatrix, Tensor next_campos, int next_height, "
-          "int next_width, float next_tanfovx, float next_tanfovy, Tensor(i!) prepared_out, Tensor(j!) scratch) -> Tensor[]");
+          "int next_width, float next_tanfovx, float next_tanfovy, Tensor(i!) prepared_out) -> Tensor[]");
     m.def("rasterize(Tensor means3D, Tensor means2D, Tensor sh, Tensor colors_precomp, Tensor opacities, Tensor scales, Tensor rotations, "
           "Tensor cov3D_precomp, Tensor sh_rest, Tensor viewmatrix, Tensor projmatrix, Tensor campos, Tensor bg, Tensor points_transform, "
           "int image_height, int image_width, float tanfovx, float tanfovy, float scale_modifier, int sh_degree, bool raw_params, "

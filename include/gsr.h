@@ -86,10 +86,6 @@ typedef struct GsrForwardArgs {
      * (and for N <= 262 144 with the digit counts already in it) by that backward, and its sort keys are sorted in place --
      * one forward per hand-over. */
     void* prepared;
-    /* ---- optional: the gsr_backward_scratch_bytes(N) buffer the coming gsr_backward will be given as `scratch`.  The forward
-     * blend kernel then clears its gradient accumulators on the side (reported in forward_flags), and that backward -- which
-     * must receive the same, untouched buffer -- skips its 48 N-byte memset.  NULL = the backward clears them itself. */
-    void* backward_scratch;
 } GsrForwardArgs;
 
 typedef struct GsrForwardOut {
