@@ -714,6 +714,28 @@ def test_emit_counts_the_tile_sort_digits(N, W, H, scale):
         assert np.array_equal(a, b)
 
 
+def test_backward_twice_over_one_render():
+    """Two backward passes over one render (retain_graph) give the same gradients: nothing the first pass leaves behind in
+    the saved workspaces (gradient accumulators, checkpoints) leaks into the second."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    import hip_runner
+    dev = torch.device("cuda:0")
+    sc = parity.syn.make_scene(20000, 330, 250, sh_degree=3, seed=9, posed=True)
+    kw = parity.scene_kwargs(sc, "sh")
+    t = {k: (None if kw.get(k) is None else kw[k].detach().to(dev).float().requires_grad_(True)) for k in hip_runner.GRAD_KEYS}
+    m2d = torch.zeros(t["means3D"].shape[0], 3, device=dev, requires_grad=True)
+    rast = GaussianRasterizer(hip_runner.settings_from(kw, dev, False, False))
+    color, radii, depth, alpha = rast(means3D=t["means3D"], means2D=m2d, shs=t["shs"], colors_precomp=t["colors_precomp"],
+                                      opacities=t["opacities"], scales=t["scales"], rotations=t["rotations"], cov3D_precomp=t["cov3D_precomp"])
+    w = torch.rand_like(color)
+    loss = (color * w).sum() + 0.3 * depth.sum() + 0.2 * alpha.sum()
+    leaves = [v for v in t.values() if v is not None] + [m2d]
+    g1 = torch.autograd.grad(loss, leaves, retain_graph=True)
+    g2 = torch.autograd.grad(loss, leaves)
+    for a, b in zip(g1, g2):
+        assert (a - b).abs().max().item() <= 2e-5 * a.abs().max().item() + 1e-12
+
+
 def test_sign_encoded_forward_is_bit_identical_with_the_lane_mask_kernel():
     """k_blend_fwd_w6 (default) represents a finished pixel by the sign of its transmittance instead of a lane mask;
     every decision and every accumulation of a live pixel is the same instruction sequence, so the images are EQUAL."""
