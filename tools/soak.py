@@ -1,6 +1,7 @@
 """Stability soak: training steps over six alternating views with densification surgery (clone 3 %, prune ~3 %, opacity reset)
 every 500 / 3000 steps, checking for non-finite parameters.  Needs a GPU:  gpurun -- 'python tools/soak.py [steps] [gaussians]'
-(round 1: 12 000 steps at 300 k in 9 s and 40 000 steps at 1 M -> 2.9 M Gaussians in 73 s, no non-finite value, no hang)."""
+(round 1: 12 000 steps at 300 k in 9 s and 40 000 steps at 1 M -> 2.9 M Gaussians in 73 s, no non-finite value, no hang;
+round 2 runs the loop with the hand-over to the next view, as run_segments.py does)."""
 import sys, time, importlib, torch
 sys.path.insert(0, '.')   # run from the repository root
 syn = importlib.import_module('3dgs_hierarchical_training_amd.synthetic')
@@ -19,7 +20,7 @@ t0 = time.time()
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 6000
 for it in range(steps):
     v = it % 6
-    pkg = ts.train_step(params, views[v], gts[v])
+    pkg = ts.train_step(params, views[v], gts[v], next_settings=views[(it + 1) % 6])   # prepare in backward: the production loop
     if it % 500 == 499:
         n = params._xyz.shape[0]
         # densify: clone 3 % (random), prune 3 % (lowest opacity), like the reference's cadence
