@@ -1505,6 +1505,7 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(int W, int H, int tiles_x, i
     for (int w = 0; w < NW; w++)
 #pragma unroll
         for (int k = 0; k < NV; k++) s_part[w][tid][k] = 0.f;   // the flush below re-zeroes what it consumes
+    const uint32_t part_off = (uint32_t)(wave * NT * NV + lane);
     for (int b = b0; b < b1; b++) {
         const int buf = 0;
         if (b > b0) __syncthreads();   // everyone is done reading the previous batch (and its flush read s_gid)
@@ -1550,7 +1551,10 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(int W, int H, int tiles_x, i
                 if (HAS_DA) gc += gD * zd + gA;
                 S -= gc * w;
                 const f2 om = 1.f - alpha;
-                const f2 inv = {fast_rcp(om.x), fast_rcp(om.y)};
+                // one reciprocal for the two pixels: 1/a = b/(ab), 1/b = a/(ab)  (om >= 0.01: the product cannot underflow; v_rcp_f32
+                // runs at a quarter of the VALU rate, two of them were 8 % of this loop's issue time)
+                const float rab = fast_rcp(om.x * om.y);
+                const f2 inv = f2{om.y, om.x} * rab;
                 const f2 dLda = gc * Tt - S * inv;
                 const f2 dLdpow = G * (op * dLda);
                 // The five geometric gradients are linear in the moments of dLdpow over the pixels:
@@ -1571,8 +1575,15 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(int W, int H, int tiles_x, i
                 // (measured: finishing the reduction with ds_add_f32 from the row leaders is 1.7x SLOWER -- LDS float
                 //  atomics serialise; the transposed DPP reduction below halves the VALU cost instead)
                 const float t = wave_reduce_transposed<NV>(v, lane);
-                if (lane < 8) s_part[wave][j][lane] = t;
-                else if (lane < NV) s_part[wave][j][lane] = t;
+                // lane k < NV holds the total of value k.  The row offset is a SCALAR product (j is wave-uniform); left to itself the
+                // compiler folds it into a v_mad_u64_u32 per visit.
+                uint32_t row;
+#if defined(__HIP_DEVICE_COMPILE__)
+                asm("s_mul_i32 %0, %1, %2" : "=s"(row) : "s"(j), "n"(NV));
+#else
+                row = (uint32_t)j * NV;
+#endif
+                if (lane < NV) (&s_part[0][0][0])[part_off + row] = t;
             }
         }
         __syncthreads();
