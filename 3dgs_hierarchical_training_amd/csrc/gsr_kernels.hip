@@ -344,6 +344,8 @@ struct DepthHist {
     uint32_t* ghist;
     uint32_t* status;
     uint32_t status_words;
+    uint32_t clear_threads;   // threads of k_preprocess_bwd that run its next-view tail (a ragged last block does not): the stride of
+                              // their status clear; 0 = none do, the single-block k_preprocess launch clears instead
 };
 
 template <int DEG, bool RAW>
@@ -457,6 +459,8 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess(CamParams cp, int N,
             s.r = col[0]; s.g = col[1]; s.b = col[2];
         }
     }
+    if (dh.ghist && dh.clear_threads == 0u)   // fewer than 128 Gaussians, ragged: no block of k_preprocess_bwd ran the next-view tail
+        for (uint32_t q = tid; q < dh.status_words / 4; q += kPreThreads) reinterpret_cast<uint4*>(dh.status)[q] = make_uint4(0u, 0u, 0u, 0u);
     if (!act) return;
     splat[i] = s;
     tilerec[i] = rec;   // compact emission record: k_tile_counts / k_emit never touch the 48 B splats
@@ -2020,7 +2024,7 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, in
                     const uint32_t c = h[e];
                     if (c) atomicAdd(&po.dh.ghist[((size_t)(e >> 8) * kOsRanges + x) * 256 + (e & 255)], c);
                 }
-                for (uint32_t q = blockIdx.x * kPreThreads + tid; q < po.dh.status_words / 4; q += gridDim.x * kPreThreads)
+                for (uint32_t q = blockIdx.x * kPreThreads + tid; q < po.dh.status_words / 4; q += po.dh.clear_threads)
                     reinterpret_cast<uint4*>(po.dh.status)[q] = make_uint4(0u, 0u, 0u, 0u);
             }
             return;
@@ -2784,6 +2788,8 @@ int gsr_backward(const GsrBackwardArgs* a, void* stream_)
             po.dh.ghist = prep_head;
             po.dh.status = onesweep_status(pb + PL.sort);
             po.dh.status_words = onesweep_status_words<uint32_t>((uint32_t)N, 32);
+            const int tail_blocks = ((N - (grid - 1) * kPreThreads) % 4 == 0) ? grid : grid - 1;   // (= last_lin below)
+            po.dh.clear_threads = (uint32_t)tail_blocks * kPreThreads;
         }
     }
 #define GSR_PREB_(DEG, RAW, CAM, ADAM, PREP)                                                                                                \

@@ -327,7 +327,7 @@ def test_extension_ops_run_under_torch_compile():
 
 
 @pytest.mark.parametrize("digits_in_backward", [True, False], ids=["digits-counted-in-backward", "histogram-launch"])
-@pytest.mark.parametrize("N", [12800, 10007, 4098], ids=["whole-blocks", "ragged-odd", "ragged-mod4"])
+@pytest.mark.parametrize("N", [12800, 10007, 4098, 101, 130], ids=["whole-blocks", "ragged-odd", "ragged-mod4", "one-ragged-block", "two-blocks-ragged"])
 def test_prepare_in_backward_is_bit_identical(N, digits_in_backward):
     """"Prepare in backward" (GsrNextView): with `next_settings` the backward that applies the Adam step also runs the NEXT
     render's preprocess on the updated parameters, and that render skips k_preprocess.  Two copies of one model trained on
