@@ -40,7 +40,48 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
+def usable_cpus():
+    """Host threads this process can actually keep busy: the visible cores, capped by the container's CPU-time quota
+    (cgroup v2 cpu.max / v1 cfs quota) -- on the GPU boxes 256 cores are visible but the quota is 16 CPUs, and an OpenMP team
+    of 256 under a 16-CPU quota spends its time throttled."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    if quota:
+        n = max(1, min(n, int(quota + 0.999)))
+    return n, quota
+
+
+
+# The host-side thread pools (OpenMP in torch's CPU ops, which build the synthetic scenes) are sized to what the container may
+# use: a team of 256 spinning under a 16-CPU quota exhausts the cgroup's CPU time and the kernel then throttles EVERY thread
+# of the process -- including the one that launches kernels -- for the rest of the 100 ms period (seen as 4-70 ms stalls of
+# single steps).  Respect an explicit OMP_NUM_THREADS of the caller.
+_CPUS, _CPU_QUOTA = usable_cpus()
+os.environ.setdefault("OMP_NUM_THREADS", str(_CPUS))
+os.environ.setdefault("MKL_NUM_THREADS", str(_CPUS))
+
 import torch  # noqa: E402
+
+try:
+    torch.set_num_threads(min(torch.get_num_threads(), _CPUS))
+except Exception:
+    pass
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 STAGES = ["preprocess_fwd", "sort_depth", "scan", "emit", "sort_tile", "ranges", "blend_fwd", "blend_bwd", "preprocess_bwd"]
@@ -87,6 +128,10 @@ def cpu_baseline(scene, threads):
                              image_height=scene["image_height"], image_width=scene["image_width"],
                              tanfovx=scene["tanfovx"], tanfovy=scene["tanfovy"], sh_degree=scene["sh_degree"],
                              shs=scene["shs"], scales=scene["scales"], rotations=scene["rotations"], precision="f32")
+    try:
+        C.CDLL("libgomp.so.1").omp_set_num_threads(threads)
+    except Exception:
+        pass
     t_pre, t_full, reps, R = 0.0, 0.0, 0, 0
     while t_pre + t_full < 10.0 and reps < 64:
         t0 = time.perf_counter()
@@ -549,9 +594,11 @@ def main():
                     extra[name] = {"error": repr(e)}
         res["other_workloads"] = extra
     if world == 1 and not args.no_cpu_baseline:
-        threads = os.cpu_count() or 1
+        threads, quota = _CPUS, _CPU_QUOTA
         try:
             res["cpu_baseline"] = cpu_baseline(scene, threads)
+            res["cpu_baseline"]["host"] = {"visible_cores": os.cpu_count(), "cpu_quota": quota,
+                                           "note": "cores = OpenMP threads used = visible cores capped by the container's CPU-time quota"}
         except Exception as e:  # the checker must never take the bench line down
             res["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": threads, "kind": "port",
                                    "sample": f"failed: {e}"}

@@ -9,6 +9,10 @@ R_ = importlib.import_module("3dgs_hierarchical_training_amd.rasterizer")
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 dev = torch.device("cuda:0")
+import os as _os
+if _os.environ.get("GSR_POLL") is not None:   # A/B of gsr_forward's busy-wait bound
+    L_ = importlib.import_module("3dgs_hierarchical_training_amd._lib")
+    assert L_.load().gsr_set_option(b"poll_iters", int(_os.environ["GSR_POLL"])) == 0
 W, H = 980, 545
 sc = syn.make_scene(N, W, H, sh_degree=3, seed=0)
 params = ts.GaussianParams(sc, dev)
