@@ -52,8 +52,10 @@ if __package__ in (None, ""):      # executed as a script: make the oddly named 
     ts = importlib.import_module("3dgs_hierarchical_training_amd.train_step")
     densify = importlib.import_module("3dgs_hierarchical_training_amd.densify")
     pose_mod = importlib.import_module("3dgs_hierarchical_training_amd.pose")
+    host_mod = importlib.import_module("3dgs_hierarchical_training_amd.host")
 else:
     from . import densify, hierarchy, segments, sequence
+    from . import host as host_mod
     from . import pose as pose_mod
     from . import train_step as ts
 
@@ -304,6 +306,7 @@ def main():
                    importance_views=a.importance_views, densify=a.densify)
     if not torch.cuda.is_available():
         raise SystemExit("run_segments.py needs a ROCm GPU (no CPU fallback in the product path)")
+    host_mod.cap_host_threads()   # the container's CPU quota, not the visible core count (host.py)
     if a.local:
         dev = torch.device("cuda", 0)
         torch.cuda.set_device(dev)
