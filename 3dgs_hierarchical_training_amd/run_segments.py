@@ -300,6 +300,8 @@ def main():
     ap.add_argument("--importance-views", type=int, default=0)
     ap.add_argument("--densify", action="store_true")
     ap.add_argument("--backend", default="nccl")
+    ap.add_argument("--one-device", action="store_true", help="every rank on cuda:0 (with --backend gloo: the multi-process walk on a "
+                                                              "one-GPU box; messages are staged through host memory)")
     a = ap.parse_args()
     cfg = HTConfig(frames=a.frames, width=a.width, height=a.height, gt_gaussians=a.gt_gaussians, leaf_gaussians=a.leaf_gaussians,
                    leaf_iters_per_frame=a.leaf_iters, phase1_iters_per_frame=a.phase1_iters, phase2_iters_per_frame=[a.phase2_iters] * 3,
@@ -318,12 +320,14 @@ def main():
         return
     import torch.distributed as dist
     rank, world, local_rank = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
-    dev = torch.device("cuda", local_rank)
+    if a.one_device and a.backend == "nccl":
+        raise SystemExit("--one-device needs --backend gloo (RCCL refuses two ranks on one device)")
+    dev = torch.device("cuda", 0 if a.one_device else local_rank)
     torch.cuda.set_device(dev)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     dist.init_process_group(a.backend, device_id=dev if a.backend == "nccl" else None)
     seq = sequence.FrameSequence(cfg.frames, cfg.gt_gaussians, cfg.width, cfg.height, dev, seed=cfg.seed)
-    rr = RankRunner(rank, world, segments.DistTransport(), seq, cfg, dev)
+    rr = RankRunner(rank, world, segments.DistTransport(host_staging=(a.backend != "nccl")), seq, cfg, dev)
     t0 = time.perf_counter()
     rr.run(barrier=dist.barrier)
     dist.barrier()

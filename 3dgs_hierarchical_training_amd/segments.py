@@ -52,17 +52,30 @@ def partner(rank: int, level_pairs: List[Tuple[int, int]]) -> Optional[Tuple[str
 
 # ---- transports -------------------------------------------------------------------------------------------------------
 class DistTransport:
-    """torch.distributed point-to-point (RCCL on the GPUs, gloo in the CPU tests)."""
+    """torch.distributed point-to-point (RCCL on the GPUs, gloo in the CPU tests).
 
-    def __init__(self, group=None):
+    host_staging=True moves device tensors through host memory around the send / receive: gloo has no device-side
+    point-to-point, and with it the SAME runner code can be driven by several processes that share ONE GPU
+    (run_segments.py --backend gloo --one-device) -- the way the multi-process walk of the merge tree is exercised on a
+    one-GPU box.  With RCCL the tensors go device to device and this stays off."""
+
+    def __init__(self, group=None, host_staging: bool = False):
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
+        self.host_staging = host_staging
 
     def send(self, t: torch.Tensor, dst: int):
+        if self.host_staging and t.is_cuda:
+            t = t.detach().cpu()
         dist.send(t, dst, group=self.group)
 
     def recv(self, t: torch.Tensor, src: int):
+        if self.host_staging and t.is_cuda:
+            buf = torch.empty(t.shape, dtype=t.dtype, device="cpu")
+            dist.recv(buf, src, group=self.group)
+            t.copy_(buf)
+            return
         dist.recv(t, src, group=self.group)
 
 

@@ -134,3 +134,37 @@ def test_stage_a_pair_fit_recovers_the_relative_pose():
     assert err < 0.35 * err0
     d = sa.run_stage_a(3, lambda p: gt if p == 0 else torch.eye(4), dev, rank=0, world=1)
     assert sorted(d) == ["rel_pose_0_to_1", "rel_pose_1_to_2"] and torch.allclose(d["rel_pose_0_to_1"].cpu(), gt)
+
+
+def test_tree_walked_by_four_processes_sharing_the_gpu():
+    """The one-process-per-rank launcher itself (run_segments.py under torch.distributed.run, RankRunner.run with barriers and the
+    point-to-point exchange at every merge): four processes, all on cuda:0, gloo with the messages staged through host memory --
+    everything but the RCCL transport is what the 8-GPU run executes.  Every level must report its exchange (bytes of the
+    un-pruned child + mask) and the root must end with a model that explains all frames."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "3dgs_hierarchical_training_amd", "run_segments.py"), "--backend", "gloo",
+           "--one-device", "--frames", "20", "--width", "320", "--height", "240", "--gt-gaussians", "60000", "--leaf-gaussians", "30000",
+           "--leaf-iters", "20", "--phase1-iters", "3", "--phase2-iters", "6"]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    recs = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    leaves = [r for r in recs if r.get("phase") == "leaf"]
+    merges = [r for r in recs if r.get("phase") == "merge"]
+    done = [r for r in recs if r.get("phase") == "done"]
+    assert sorted(r["rank"] for r in leaves) == [0, 1, 2, 3]
+    # level 0: (0 <- 1), (2 <- 3); level 1: (0 <- 2): three senders, three receivers, matching byte counts
+    src = sorted((r["level"], r["rank"], r["peer"], r["bytes"]) for r in merges if r["role"] == "src")
+    dst = sorted((r["level"], r["peer"], r["rank"], r["bytes"]) for r in merges if r["role"] == "dst")
+    assert [x[:3] for x in src] == [(0, 1, 0), (0, 3, 2), (1, 2, 0)] and src == dst
+    assert all(b > 30000 * 236 for *_, b in src)               # the UN-pruned child travels (236 B per Gaussian) + mask + poses
+    assert len(done) == 1 and done[0]["world"] == 4 and done[0]["mode"] == "gloo"
+    assert done[0]["psnr"] > 25.0, done[0]
+    print(f"4 processes on one GPU: root PSNR {done[0]['psnr']:.2f} dB, {done[0]['gaussians']} Gaussians, {done[0]['total_s']:.1f} s")
