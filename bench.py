@@ -320,7 +320,7 @@ def merge_leg(dev, dist, world, rank, params, scene, ts, syn, deg):
                     "gaussians_merged": d["n_merged"], "note": "both children's importance run back to back on the one GPU"}
             del d
         return best
-    tr = seg_mod.DistTransport()
+    tr = seg_mod.DistTransport(host_staging=(dist.get_backend() != "nccl"))
     pairs = seg_mod.merge_schedule(world)[0]
     role = seg_mod.partner(rank, pairs)
     for rep in range(2):              # first pass: torch's one-time kernel loads + RCCL's channel set-up; the second is reported
@@ -356,7 +356,7 @@ def merge_leg(dev, dist, world, rank, params, scene, ts, syn, deg):
     dist.all_reduce(v, op=dist.ReduceOp.MAX)
     b = torch.tensor([st["bytes"]], device=dev, dtype=torch.float64)
     dist.all_reduce(b, op=dist.ReduceOp.SUM)
-    return {"merge_ms": float(v[0]), "merge_bytes": float(b[0]), "pairs": len(pairs), "transport": "RCCL send/recv, one xGMI link per pair",
+    return {"merge_ms": float(v[0]), "merge_bytes": float(b[0]), "pairs": len(pairs), "transport": "RCCL send/recv, one xGMI link per pair" if dist.get_backend() == "nccl" else f"{dist.get_backend()} (test transport, host-staged)",
             "importance_views": len(views), "importance_ms_max": float(v[1]), "xfer_ms_max": float(v[2]), "append_ms_max": float(v[3]),
             "gaussians_merged_max": int(v[4]), "link_GBps": (float(b[0]) / len(pairs)) / (float(v[2]) * 1e-3) / 1e9 if float(v[2]) > 0 else None}
 
@@ -368,13 +368,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (no CPU fallback in the product path)")
+    # GSR_BENCH_BACKEND=gloo + GSR_BENCH_ONE_DEVICE=1: every rank on cuda:0, gloo instead of RCCL (point-to-point messages staged
+    # through host memory) -- lets the N > 1 code path of this file run on a one-GPU box (tests/test_gpu_segments.py); the
+    # numbers of such a run mean nothing
+    backend = os.environ.get("GSR_BENCH_BACKEND", "nccl")
+    if os.environ.get("GSR_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1 or os.environ.get("GSR_BENCH_FORCE_DIST") == "1":   # (the env var exercises the RCCL path on one GPU)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        dist.init_process_group(backend, device_id=dev if backend == "nccl" else None)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     syn = importlib.import_module("3dgs_hierarchical_training_amd.synthetic")

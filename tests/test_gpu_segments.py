@@ -168,3 +168,30 @@ def test_tree_walked_by_four_processes_sharing_the_gpu():
     assert len(done) == 1 and done[0]["world"] == 4 and done[0]["mode"] == "gloo"
     assert done[0]["psnr"] > 25.0, done[0]
     print(f"4 processes on one GPU: root PSNR {done[0]['psnr']:.2f} dB, {done[0]['gaussians']} Gaussians, {done[0]['total_s']:.1f} s")
+
+
+def test_bench_line_at_two_ranks_on_one_gpu():
+    """bench.py's N > 1 path (one process per rank under torch.distributed.run, barrier + max-over-ranks timing, one merge level with
+    the point-to-point exchange, rank 0 prints ONE line) run with two processes that share cuda:0 over gloo.  Only the shape of the
+    result is checked -- two processes on one GPU measure nothing."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+           "--gaussians", "200000"]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", GSR_BENCH_BACKEND="gloo", GSR_BENCH_ONE_DEVICE="1")
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines                       # rank 0 alone prints
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["warmup"] == 2 and d["scaling"] == "weak" and d["higher_is_better"] is True
+    assert abs(d["value"] - 2 * 1000.0 / d["ms_per_step"]) < 1e-6 * d["value"]          # whole-job aggregate over both ranks
+    assert "roofline" in d and d["roofline"]["frac"] > 0 and "cpu_baseline" not in d      # cpu_baseline: rank 0 at N = 1 only
+    m = d["merge"]
+    assert m["pairs"] == 1 and m["merge_bytes"] > 200000 * 236 and m["merge_ms"] > 0 and m["gaussians_merged_max"] == 200000
