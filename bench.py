@@ -380,6 +380,9 @@ def main():
     if world > 1 or os.environ.get("GSR_BENCH_FORCE_DIST") == "1":   # (the env var exercises the RCCL path on one GPU)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend, device_id=dev if backend == "nccl" else None)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
