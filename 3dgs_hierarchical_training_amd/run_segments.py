@@ -53,11 +53,20 @@ if __package__ in (None, ""):      # executed as a script: make the oddly named 
     densify = importlib.import_module("3dgs_hierarchical_training_amd.densify")
     pose_mod = importlib.import_module("3dgs_hierarchical_training_amd.pose")
     host_mod = importlib.import_module("3dgs_hierarchical_training_amd.host")
+    stage_a = importlib.import_module("3dgs_hierarchical_training_amd.stage_a")
 else:
     from . import densify, hierarchy, segments, sequence
     from . import host as host_mod
+    from . import stage_a
     from . import pose as pose_mod
     from . import train_step as ts
+
+
+def emit_line(rec):
+    """One report record = one line = ONE write (several ranks share the launcher's stdout: print() issues the text and the
+    newline separately and the lines of two ranks can interleave)."""
+    sys.stdout.write(json.dumps(rec) + "\n")
+    sys.stdout.flush()
 
 
 @dataclass
@@ -109,7 +118,7 @@ class RankRunner:
         self.rng = random.Random(cfg.seed * 1000 + rank)
         self.seg: Optional[Segment] = None
         self.teachers = None
-        self.log = log if log is not None else (lambda rec: print(json.dumps(rec), flush=True))
+        self.log = log if log is not None else emit_line
         self.report = []
 
     def _emit(self, rec):
@@ -285,6 +294,26 @@ def run_local(world: int, seq, cfg: HTConfig, device, log=None):
     return runners[0], [rec for rr in runners for rec in rr.report]
 
 
+def run_stage_a_on(seq, cfg, dev, spec, rank: int, world: int, group=None, log=None, gather_device=None):
+    """Stage A of hierarchical_training (ht3dgs_trainer.py:697-698) on this rank's share of the frame pairs; every rank ends
+    with the full pose table and adopts it.  Returns the report record."""
+    n_points, image_iters, pose_iters = spec
+    t0 = time.perf_counter()
+    table = stage_a.run_stage_a(cfg.frames, lambda p: stage_a.fit_pair(seq, p, dev, n_points=n_points, single_image_iters=image_iters,
+                                                                        pose_iters=pose_iters, seed=cfg.seed),
+                                gather_device or dev, rank=rank, world=world, group=group)
+    if dev.type == "cuda":
+        torch.cuda.synchronize(dev)
+    err = max(float((table[f"rel_pose_{p}_to_{p + 1}"].cpu() - seq.true_rel_pose(p, p + 1)).abs().max()) for p in range(cfg.frames - 1))
+    ident = max(float((torch.eye(4) - seq.true_rel_pose(p, p + 1)).abs().max()) for p in range(cfg.frames - 1))
+    seq.use_pose_table(table)
+    rec = {"rank": rank, "phase": "stage_a", "pairs_total": cfg.frames - 1, "pairs_here": len(stage_a.pairs_of_rank(cfg.frames, rank, world)),
+           "gaussians": n_points, "image_iters": image_iters, "pose_iters": pose_iters, "ms": 1e3 * (time.perf_counter() - t0),
+           "max_abs_pose_error": err, "identity_guess_error": ident}
+    (log or emit_line)(rec)
+    return rec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--local", action="store_true", help="walk the whole tree on one GPU (no process group)")
@@ -300,6 +329,10 @@ def main():
     ap.add_argument("--importance-views", type=int, default=0)
     ap.add_argument("--densify", action="store_true")
     ap.add_argument("--backend", default="nccl")
+    ap.add_argument("--stage-a", type=int, nargs=3, metavar=("GAUSSIANS", "IMAGE_ITERS", "POSE_ITERS"), default=None,
+                    help="run stage A first (relative pose of every consecutive frame pair: single-image 3DGS of frame p, then the "
+                         "SE(3) fit on frame p+1; pairs round-robin over the ranks, one all_gather) and chain ITS poses in stage B "
+                         "instead of the synthetic ground truth.  The reference's counts are 1000 and 300 iterations")
     ap.add_argument("--one-device", action="store_true", help="every rank on cuda:0 (with --backend gloo: the multi-process walk on a "
                                                               "one-GPU box; messages are staged through host memory)")
     a = ap.parse_args()
@@ -314,9 +347,11 @@ def main():
         torch.cuda.set_device(dev)
         seq = sequence.FrameSequence(cfg.frames, cfg.gt_gaussians, cfg.width, cfg.height, dev, seed=cfg.seed)
         t0 = time.perf_counter()
+        if a.stage_a:
+            run_stage_a_on(seq, cfg, dev, a.stage_a, 0, 1)
         root, _ = run_local(a.segments, seq, cfg, dev)
-        print(json.dumps({"phase": "done", "world": a.segments, "mode": "local", "gaussians": root.seg.params.num_points,
-                          "psnr": root.evaluate(), "total_s": time.perf_counter() - t0}), flush=True)
+        emit_line({"phase": "done", "world": a.segments, "mode": "local", "gaussians": root.seg.params.num_points,
+                   "psnr": root.evaluate(), "total_s": time.perf_counter() - t0})
         return
     import torch.distributed as dist
     rank, world, local_rank = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
@@ -329,11 +364,13 @@ def main():
     seq = sequence.FrameSequence(cfg.frames, cfg.gt_gaussians, cfg.width, cfg.height, dev, seed=cfg.seed)
     rr = RankRunner(rank, world, segments.DistTransport(host_staging=(a.backend != "nccl")), seq, cfg, dev)
     t0 = time.perf_counter()
+    if a.stage_a:   # (gloo gathers host tensors; the table is tiny -- 192 bytes per pair)
+        run_stage_a_on(seq, cfg, dev, a.stage_a, rank, world, gather_device=dev if a.backend == "nccl" else torch.device("cpu"))
     rr.run(barrier=dist.barrier)
     dist.barrier()
     if rank == 0:
-        print(json.dumps({"phase": "done", "world": world, "mode": a.backend, "gaussians": rr.seg.params.num_points,
-                          "psnr": rr.evaluate(), "total_s": time.perf_counter() - t0}), flush=True)
+        emit_line({"phase": "done", "world": world, "mode": a.backend, "gaussians": rr.seg.params.num_points,
+                   "psnr": rr.evaluate(), "total_s": time.perf_counter() - t0})
     dist.destroy_process_group()
 
 

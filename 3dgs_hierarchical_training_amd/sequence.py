@@ -54,6 +54,7 @@ class FrameSequence:
         self.w2c = torch.stack(self.w2c)
         self._targets = {}
         self._gt_params = None
+        self.pose_table = None      # stage A's result (`pose_dict`), when it was run: rel_pose() then answers from it
 
     # ---- cameras ---------------------------------------------------------------------------------------------------
     def settings_for_pose(self, pose_w2c: torch.Tensor, bg=None) -> GaussianRasterizationSettings:
@@ -68,9 +69,22 @@ class FrameSequence:
             projmatrix=cam["projmatrix"].to(d), sh_degree=self.sh_degree, campos=cam["campos"].to(d), prefiltered=False,
             debug=False)
 
-    def rel_pose(self, a: int, b: int) -> torch.Tensor:
+    def true_rel_pose(self, a: int, b: int) -> torch.Tensor:
         """Ground-truth `rel_pose_{a}_to_{b}` (camera a coordinates -> camera b coordinates): what stage A estimates."""
         return self.w2c[b] @ torch.linalg.inv(self.w2c[a])
+
+    def use_pose_table(self, pose_dict):
+        """Adopt stage A's `pose_dict` (stage_a.run_stage_a): from here on the segments chain the ESTIMATED relative poses
+        (ht3dgs_trainer.py:739-741, :783-790), as the reference does."""
+        self.pose_table = {k: v.detach().float().cpu() for k, v in pose_dict.items()}
+
+    def rel_pose(self, a: int, b: int) -> torch.Tensor:
+        """`rel_pose_{a}_to_{b}`: stage A's estimate when one was adopted, else the ground truth standing in for it."""
+        if self.pose_table is not None:
+            m = self.pose_table.get(f"rel_pose_{a}_to_{b}")
+            if m is not None:
+                return m.clone()
+        return self.true_rel_pose(a, b)
 
     # ---- targets ---------------------------------------------------------------------------------------------------
     def target(self, f: int) -> torch.Tensor:
@@ -84,6 +98,45 @@ class FrameSequence:
         return self._targets[f]
 
     # ---- leaf initialisation -----------------------------------------------------------------------------------------
+    def depth(self, f: int) -> torch.Tensor:
+        """Expected depth map of frame f, [H, W] (stands in for the monocular depth the reference predicts per frame)."""
+        from . import train_step as ts
+        if self._gt_params is None:
+            self._gt_params = ts.GaussianParams(self.gt_scene, self.device, optimizer="torch")
+        with torch.no_grad():
+            pkg = ts.render(self._gt_params, self.settings_for_pose(self.w2c[f]))
+            return (pkg["depth"][0] / pkg["alpha"][0].clamp_min(1e-3)).clone()
+
+    def pixel_scene(self, f: int, stride: int = 2, seed: int = 0, depth_noise: float = 0.02) -> Dict:
+        """One Gaussian per `stride`-th pixel of frame f, un-projected with the frame's depth into that frame's camera
+        coordinates, coloured with the pixel (SH band 0), sized to its pixel footprint -- the single-image initialisation of
+        stage A (`init_model` from the un-projected monocular depth, ht3dgs_trainer.py:352-363, :172-212).  Such a model
+        explains its image from the first iteration, which is what makes the photometric pose fit on the NEXT frame
+        well-posed (a sparse subset of the scene is not: tools/stage_a_probe.py)."""
+        g = torch.Generator().manual_seed(seed + 7919 * f)
+        img = self.target(f).cpu()                       # [3, H, W]
+        dep = self.depth(f).cpu()
+        cam = syn.make_camera(self.W, self.H)
+        ys, xs = torch.meshgrid(torch.arange(stride // 2, self.H, stride), torch.arange(stride // 2, self.W, stride), indexing="ij")
+        ys, xs = ys.reshape(-1), xs.reshape(-1)
+        z = dep[ys, xs]
+        ok = z > 0.21                                     # in front of the near cut of the rasterizer
+        ys, xs, z = ys[ok], xs[ok], z[ok]
+        z = z * (1.0 + depth_noise * torch.randn(z.shape, generator=g))
+        x = (xs.float() + 0.5 - 0.5 * self.W) / cam["fx"] * z
+        y = (ys.float() + 0.5 - 0.5 * self.H) / cam["fy"] * z
+        n = z.shape[0]
+        sc = dict(self.gt_scene)
+        sc["means3D"] = torch.stack((x, y, z), 1).float().contiguous()
+        sc["scales"] = (0.7 * stride * z / cam["fx"])[:, None].repeat(1, 3).float().contiguous()
+        rot = torch.zeros(n, 4); rot[:, 0] = 1.0
+        sc["rotations"] = rot
+        sc["opacities"] = torch.full((n, 1), 0.7)
+        shs = torch.zeros(n, 16, 3)
+        shs[:, 0] = (img[:, ys, xs].t() - 0.5) / 0.28209479177387814
+        sc["shs"] = shs.contiguous()
+        return sc
+
     def leaf_scene(self, start_fidx: int, n_points: int, seed: int, noise: float = 1.0) -> Dict:
         """A perturbed subset of the ground truth, expressed in the camera frame of `start_fidx` (stands in for
         `init_leaf_3DGS` from monocular depth, :172-212): positions jittered, colours / opacities / scales off."""

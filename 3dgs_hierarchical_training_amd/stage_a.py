@@ -75,18 +75,23 @@ def run_stage_a(n_frames: int, fit_fn: Callable[[int], torch.Tensor], device, ra
 
 
 def fit_pair(seq, p: int, device, n_points: int = 100_000, single_image_iters: int = 1000, pose_iters: int = 300,
-             pose_lr: float = 2e-3, seed: int = 0) -> torch.Tensor:
+             pose_lr: float = 2e-3, seed: int = 0, init: str = "pixels") -> torch.Tensor:
     """compute_relative_pose(p+1, p) on the HIP rasterizer (:336-380): returns rel_pose_{p}_to_{p+1} [4,4] (CPU).
 
-    1. single-image 3DGS of frame p in that frame's own camera coordinates (identity pose), fused train step, no
-       densification (:352-365; early exit on PSNR > 35 after 500 iterations as :300-301);
+    1. single-image 3DGS of frame p in that frame's own camera coordinates (identity pose), initialised from the frame's
+       un-projected depth (sequence.pixel_scene; :352-363), fused train step, no densification (:352-365; early exit on
+       PSNR > 35 after 500 iterations as :300-301);
     2. freeze the Gaussians, fit delta in Exp(delta) (tangent at the identity, `init_RT(None)` :370) on frame p+1 with
        Adam through `points_transform` (pose.py): loss = the same photometric loss."""
     from . import pose as pose_mod
     from . import train_step as ts
     from .loss import fused_photometric_loss
     from .rasterizer import rasterize_gaussians_raw
-    scene = seq.leaf_scene(p, n_points, seed=seed + p)
+    if init == "pixels":     # one Gaussian per strided pixel of frame p, un-projected with its depth (about n_points of them)
+        stride = max(1, int(round((seq.W * seq.H / max(1, n_points)) ** 0.5)))
+        scene = seq.pixel_scene(p, stride=stride, seed=seed)
+    else:                    # a perturbed subset of the ground-truth cloud
+        scene = seq.leaf_scene(p, n_points, seed=seed + p)
     params = ts.GaussianParams(scene, device)
     ident = seq.settings_for_pose(torch.eye(4))
     tgt0, tgt1 = seq.target(p), seq.target(p + 1)

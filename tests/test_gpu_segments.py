@@ -125,8 +125,8 @@ def test_stage_a_pair_fit_recovers_the_relative_pose():
     """compute_relative_pose (:336-380) on the HIP rasterizer for one frame pair: single-image 3DGS, then the SE(3) fit."""
     sa = importlib.import_module("3dgs_hierarchical_training_amd.stage_a")
     dev = torch.device("cuda:0")
-    seq = sequence.FrameSequence(6, 5000, 256, 192, dev, seed=2, step_angle=0.015, step_shift=0.02)
-    rel = sa.fit_pair(seq, 2, dev, n_points=5000, single_image_iters=150, pose_iters=250, pose_lr=1e-3)
+    seq = sequence.FrameSequence(6, 40000, 480, 360, dev, seed=2, step_angle=0.015, step_shift=0.02)
+    rel = sa.fit_pair(seq, 2, dev, n_points=40000, single_image_iters=200, pose_iters=250, pose_lr=1e-3)
     gt = seq.rel_pose(2, 3)
     err0 = (torch.eye(4) - gt)[:3].abs().max().item()
     err = (rel - gt)[:3].abs().max().item()
@@ -137,8 +137,9 @@ def test_stage_a_pair_fit_recovers_the_relative_pose():
 
 
 def test_tree_walked_by_four_processes_sharing_the_gpu():
-    """The one-process-per-rank launcher itself (run_segments.py under torch.distributed.run, RankRunner.run with barriers and the
-    point-to-point exchange at every merge): four processes, all on cuda:0, gloo with the messages staged through host memory --
+    """The one-process-per-rank launcher itself (run_segments.py under torch.distributed.run: stage A sharded over the ranks with its
+    all_gather, then RankRunner.run with barriers and the point-to-point exchange at every merge): four processes, all on cuda:0,
+    gloo with the messages staged through host memory --
     everything but the RCCL transport is what the 8-GPU run executes.  Every level must report its exchange (bytes of the
     un-pruned child + mask) and the root must end with a model that explains all frames."""
     import json
@@ -151,11 +152,18 @@ def test_tree_walked_by_four_processes_sharing_the_gpu():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "3dgs_hierarchical_training_amd", "run_segments.py"), "--backend", "gloo",
            "--one-device", "--frames", "20", "--width", "320", "--height", "240", "--gt-gaussians", "60000", "--leaf-gaussians", "30000",
-           "--leaf-iters", "20", "--phase1-iters", "3", "--phase2-iters", "6"]
+           "--leaf-iters", "20", "--phase1-iters", "3", "--phase2-iters", "6", "--stage-a", "20000", "150", "100"]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     recs = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    # stage A first: 19 frame pairs round-robin over the four ranks (5 + 5 + 5 + 4), one all_gather, every rank holds the table;
+    # stage B then chains the ESTIMATED poses
+    sa = sorted((r["rank"], r["pairs_here"]) for r in recs if r.get("phase") == "stage_a")
+    assert sa == [(0, 5), (1, 5), (2, 5), (3, 4)]
+    for r in recs:
+        if r.get("phase") == "stage_a":
+            assert r["max_abs_pose_error"] < 0.5 * r["identity_guess_error"], r     # (the frames move by ~1 pixel at this size)
     leaves = [r for r in recs if r.get("phase") == "leaf"]
     merges = [r for r in recs if r.get("phase") == "merge"]
     done = [r for r in recs if r.get("phase") == "done"]
@@ -166,7 +174,7 @@ def test_tree_walked_by_four_processes_sharing_the_gpu():
     assert [x[:3] for x in src] == [(0, 1, 0), (0, 3, 2), (1, 2, 0)] and src == dst
     assert all(b > 30000 * 236 for *_, b in src)               # the UN-pruned child travels (236 B per Gaussian) + mask + poses
     assert len(done) == 1 and done[0]["world"] == 4 and done[0]["mode"] == "gloo"
-    assert done[0]["psnr"] > 25.0, done[0]
+    assert done[0]["psnr"] > 20.0, done[0]      # stage B chains stage A's ESTIMATED poses here (46.9 dB with the true ones)
     print(f"4 processes on one GPU: root PSNR {done[0]['psnr']:.2f} dB, {done[0]['gaussians']} Gaussians, {done[0]['total_s']:.1f} s")
 
 
