@@ -85,3 +85,90 @@ extern "C" int gsr_adam_step(const GsrAdamTensor* tensors, int32_t count, float 
     hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(kAdamThreads), 0, (hipStream_t)stream, B);
     return hipGetLastError() == hipSuccess ? GSR_OK : GSR_ERR_HIP;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Pose step of stage A (compute_relative_pose, /root/reference/trainer/ht3dgs_trainer.py:308-333, :367-378): the camera
+// pose is the group element Exp(delta) * B with six tangent numbers delta = (tau, phi) under Adam
+// (`LieGroupParameter.retr()` + torch.optim.Adam in the reference).  One iteration of that loop in torch is ~50 tiny
+// kernels (exponential map, its autograd, the optimizer) -- 1.9 ms of launch latency around a 0.35 ms render at 130 k
+// Gaussians.  Here it is ONE one-thread kernel between two renders: it takes dL/dM (12 floats, from gsr_backward's
+// d_points_transform), chains it to dL/d(delta), applies torch's Adam update to delta and writes the next M = Exp(delta) B
+// where the next render reads its points_transform.  Same statement of the exponential map as pose.py (Rodrigues + left
+// Jacobian, series near 0), evaluated in float64; its Jacobian by central differences in float64 (h = 1e-6: error ~1e-10,
+// far below the float32 gradient it multiplies).  Adam arithmetic in float32, as torch does it for a float32 parameter.
+// ------------------------------------------------------------------------------------------------
+namespace gsr {
+
+__device__ inline void se3_exp_times(const double* d /*6*/, const double* B /*12, row-major 3x4, or nullptr = identity*/, double* M /*12*/)
+{
+    const double tx = d[0], ty = d[1], tz = d[2], px = d[3], py = d[4], pz = d[5];
+    const double th2 = px * px + py * py + pz * pz;
+    double a, b, c;
+    if (th2 < 1e-8) { a = 1.0 - th2 / 6.0; b = 0.5 - th2 / 24.0; c = 1.0 / 6.0 - th2 / 120.0; }
+    else { const double th = sqrt(th2); a = sin(th) / th; b = (1.0 - cos(th)) / th2; c = (th - sin(th)) / (th2 * th); }
+    const double K[9] = {0, -pz, py, pz, 0, -px, -py, px, 0};
+    double K2[9];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) K2[3 * i + j] = K[3 * i] * K[j] + K[3 * i + 1] * K[3 + j] + K[3 * i + 2] * K[6 + j];
+    double R[9], V[9];
+    for (int q = 0; q < 9; q++) { const double e = (q % 4 == 0) ? 1.0 : 0.0; R[q] = e + a * K[q] + b * K2[q]; V[q] = e + b * K[q] + c * K2[q]; }
+    const double t[3] = {V[0] * tx + V[1] * ty + V[2] * tz, V[3] * tx + V[4] * ty + V[5] * tz, V[6] * tx + V[7] * ty + V[8] * tz};
+    for (int i = 0; i < 3; i++) {
+        if (B) {
+            for (int j = 0; j < 4; j++)
+                M[4 * i + j] = R[3 * i] * B[j] + R[3 * i + 1] * B[4 + j] + R[3 * i + 2] * B[8 + j] + (j == 3 ? t[i] : 0.0);
+        } else {
+            M[4 * i] = R[3 * i]; M[4 * i + 1] = R[3 * i + 1]; M[4 * i + 2] = R[3 * i + 2]; M[4 * i + 3] = t[i];
+        }
+    }
+}
+
+__global__ void k_pose_adam(float* __restrict__ delta, float* __restrict__ m, float* __restrict__ v, const float* __restrict__ d_xf,
+                            const float* __restrict__ base, float* __restrict__ xf_out, float lr, float b1, float b2, float eps,
+                            float bc1, float bc2_sqrt, int do_step)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double d[6], B[12], M[12];
+    for (int k = 0; k < 6; k++) d[k] = (double)delta[k];
+    if (base) for (int q = 0; q < 12; q++) B[q] = (double)base[q];
+    const double* Bp = base ? B : nullptr;
+    if (do_step) {
+        float g[6];
+        const double h = 1e-6;
+        for (int k = 0; k < 6; k++) {
+            double Mp[12], Mm[12];
+            const double keep = d[k];
+            d[k] = keep + h; se3_exp_times(d, Bp, Mp);
+            d[k] = keep - h; se3_exp_times(d, Bp, Mm);
+            d[k] = keep;
+            double acc = 0.0;
+            for (int q = 0; q < 12; q++) acc += (double)d_xf[q] * (Mp[q] - Mm[q]) / (2.0 * h);
+            g[k] = (float)acc;
+        }
+        for (int k = 0; k < 6; k++) {   // torch.optim.Adam, single tensor, float32
+            const float mk = b1 * m[k] + (1.f - b1) * g[k];
+            const float vk = b2 * v[k] + (1.f - b2) * g[k] * g[k];
+            m[k] = mk; v[k] = vk;
+            const float denom = sqrtf(vk) / bc2_sqrt + eps;
+            const float p = delta[k] - (lr / bc1) * (mk / denom);
+            delta[k] = p;
+            d[k] = (double)p;
+        }
+    }
+    se3_exp_times(d, Bp, M);
+    for (int q = 0; q < 12; q++) xf_out[q] = (float)M[q];
+}
+
+}  // namespace gsr
+
+extern "C" int gsr_pose_step(float* delta6, float* exp_avg6, float* exp_avg_sq6, const float* d_points_transform12, const float* base12,
+                             float* points_transform_out12, float lr, float beta1, float beta2, float eps, int64_t step, void* stream)
+{
+    if (!delta6 || !points_transform_out12 || step < 0) return GSR_ERR_ARG;
+    if (step > 0 && (!exp_avg6 || !exp_avg_sq6 || !d_points_transform12)) return GSR_ERR_ARG;
+    const float bc1 = step > 0 ? (float)(1.0 - pow((double)beta1, (double)step)) : 1.f;
+    const float bc2s = step > 0 ? (float)sqrt(1.0 - pow((double)beta2, (double)step)) : 1.f;
+    hipLaunchKernelGGL(gsr::k_pose_adam, dim3(1), dim3(64), 0, (hipStream_t)stream, delta6, exp_avg6, exp_avg_sq6, d_points_transform12, base12,
+                       points_transform_out12, lr, beta1, beta2, eps, bc1, bc2s, step > 0 ? 1 : 0);
+    return hipGetLastError() == hipSuccess ? GSR_OK : GSR_ERR_HIP;
+}

@@ -13,6 +13,7 @@
 //   gsr::mark_visible         -> gsr_mark_visible
 //   gsr::photometric_loss_forward / _backward -> gsr_loss_forward / gsr_loss_backward
 //   gsr::adam_step            -> gsr_adam_step
+//   gsr::pose_step            -> gsr_pose_step (stage A: tangent-space Adam + exponential map between two renders)
 //   gsr::knn_mean_dist2       -> gsr_knn_mean_dist2
 //
 // Registered with TORCH_LIBRARY so the ops are visible to the dispatcher (torch.ops.gsr.*, fake kernels in _ext.py for
@@ -445,6 +446,24 @@ void adam_step(at::TensorList params, at::TensorList grads, at::TensorList exp_a
     }
 }
 
+// Pose step of stage A: delta / exp_avg / exp_avg_sq ([6] float32) updated in place from dL/dM, the new M = Exp(delta) * base written
+// into `xf` ([3,4] or [4,4] float32, rows 0..2) -- the tensor the next render reads as points_transform.  step = 0: only evaluates M.
+void pose_step(Tensor delta, Tensor exp_avg, Tensor exp_avg_sq, const Tensor& d_xf, const Tensor& base, Tensor xf, double lr,
+               double beta1, double beta2, double eps, int64_t step)
+{
+    TORCH_CHECK(delta.is_cuda(), "pose_step: tensors must be on a ROCm/HIP device (no CPU fallback)");
+    const c10::hip::HIPGuardMasqueradingAsCUDA guard(delta.device());
+    auto ok6 = [](const Tensor& t) { return t.is_contiguous() && t.scalar_type() == at::kFloat && t.numel() == 6; };
+    TORCH_CHECK(ok6(delta) && (step == 0 || (ok6(exp_avg) && ok6(exp_avg_sq))), "pose_step: delta / moments must be contiguous float32 [6]");
+    TORCH_CHECK(xf.is_contiguous() && xf.scalar_type() == at::kFloat && xf.numel() >= 12, "pose_step: xf must be contiguous float32 [3,4] or [4,4]");
+    Tensor g = has(d_xf) ? f32c(d_xf) : d_xf, b = has(base) ? f32c(base) : base;
+    TORCH_CHECK(step == 0 || (has(g) && g.numel() >= 12), "pose_step: d_xf must hold dL/dM (12 floats)");
+    TORCH_CHECK(!has(b) || b.numel() >= 12, "pose_step: base must hold a 3x4 (or 4x4) matrix");
+    check(gsr_pose_step(delta.data_ptr<float>(), step ? exp_avg.data_ptr<float>() : nullptr, step ? exp_avg_sq.data_ptr<float>() : nullptr,
+                        fp(g), fp(b), xf.data_ptr<float>(), (float)lr, (float)beta1, (float)beta2, (float)eps, step,
+                        c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()), "gsr_pose_step");
+}
+
 Tensor knn_mean_dist2(const Tensor& points_)
 {
     TORCH_CHECK(points_.is_cuda(), "distCUDA2: points must be on a ROCm/HIP device (no CPU fallback)");
@@ -490,6 +509,8 @@ TORCH_LIBRARY(gsr, m)
     m.def("photometric_loss_backward(Tensor render, Tensor target, Tensor workspace, Tensor grad_loss, float lambda_dssim, bool clamp) -> Tensor");
     m.def("adam_step(Tensor(a!)[] params, Tensor[] grads, Tensor(b!)[] exp_avg, Tensor(c!)[] exp_avg_sq, float[] lr, float beta1, "
           "float beta2, float eps, int step) -> ()");
+    m.def("pose_step(Tensor(a!) delta, Tensor(b!) exp_avg, Tensor(c!) exp_avg_sq, Tensor d_xf, Tensor base, Tensor(d!) xf, float lr, "
+          "float beta1, float beta2, float eps, int step) -> ()");
     m.def("knn_mean_dist2(Tensor points) -> Tensor");
     m.def("debug_last() -> Tensor[]", &debug_last);
 }
@@ -503,6 +524,7 @@ TORCH_LIBRARY_IMPL(gsr, CUDA, m)   // the dispatch key of HIP tensors on a ROCm 
     m.impl("photometric_loss_forward", &photometric_loss_forward);
     m.impl("photometric_loss_backward", &photometric_loss_backward);
     m.impl("adam_step", &adam_step);
+    m.impl("pose_step", &pose_step);
     m.impl("knn_mean_dist2", &knn_mean_dist2);
     m.impl("rasterize", &rasterize_forward_only);
 }

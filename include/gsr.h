@@ -269,6 +269,15 @@ typedef struct GsrAdamTensor {
 int gsr_adam_step(const GsrAdamTensor* tensors, int32_t count, float beta1, float beta2, float eps, int64_t step,
                   void* stream);
 
+/* Pose step of stage A (extension f-4; compute_relative_pose, trainer/ht3dgs_trainer.py:308-333): the pose being fitted is
+ * M = Exp(delta) * base with six tangent numbers delta = (tau[3], phi[3]) under Adam -- `LieGroupParameter.retr()` +
+ * torch.optim.Adam in the reference.  step >= 1: chains d_points_transform12 (dL/dM, as written by gsr_backward) to dL/d(delta),
+ * applies torch's Adam update (lr, beta1, beta2, eps; bias correction for `step`) to delta6 / exp_avg6 / exp_avg_sq6 in place
+ * and writes the new M (3x4 row-major) to points_transform_out12 -- where the next gsr_forward reads its points_transform.
+ * step = 0: only evaluates M for the current delta.  base12 = NULL: identity.  All pointers device; one one-thread kernel. */
+int gsr_pose_step(float* delta6, float* exp_avg6, float* exp_avg_sq6, const float* d_points_transform12, const float* base12,
+                  float* points_transform_out12, float lr, float beta1, float beta2, float eps, int64_t step, void* stream);
+
 /* ---- "next" row f-1: simple_knn._C.distCUDA2 ----------------------------------------------------------------
  * out[i] = mean of the squared distances from points[i] to its 3 nearest other points (exact), the semantics of the
  * reference's SciPy twin /root/reference/scene/gaussian_model_ht.py:31-36; called at :211-216. */

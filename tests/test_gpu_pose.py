@@ -158,3 +158,40 @@ def test_camera_optimisation_through_viewmatrix_gradients():
     err = float((t.detach() - true_t).norm() / true_t.norm())
     print(f"loss {l0:.5f} -> {l1:.5f}, relative translation error {err:.3f}")
     assert l1 < 0.1 * l0 and err < 0.1, (l0, l1, err)
+
+
+@pytest.mark.parametrize("with_base", [False, True], ids=["identity-base", "posed-base"])
+def test_pose_step_kernel_equals_torch_exp_map_autograd_and_adam(with_base):
+    """gsr_pose_step (stage A's pose iteration in one kernel): dL/dM -> dL/d(delta) through the exponential map, torch's Adam on
+    the six tangent numbers, next M = Exp(delta) * base -- against pose.retr_matrix under autograd + torch.optim.Adam (what the
+    reference's LieGroupParameter.retr() + Adam loop evaluates), over several steps, including the series branch at delta = 0."""
+    import importlib
+    _ext = importlib.import_module("3dgs_hierarchical_training_amd._ext")
+    pose = importlib.import_module("3dgs_hierarchical_training_amd.pose")
+    ops = _ext.load()
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    Wt = torch.randn(3, 4, generator=g).to(dev)                     # L(M) = sum(Wt * M[:3]) + 0.5 * |M[:3]|^2: dL/dM depends on M
+    pose7 = torch.tensor([0.3, -0.2, 0.5, 0.1, -0.2, 0.3, 0.9]) if with_base else torch.tensor([0, 0, 0, 0, 0, 0, 1.0])
+    pose7 = pose7.to(dev)
+    base = pose.pose7_to_matrix(pose7)[:3].contiguous() if with_base else torch.empty(0, device=dev)
+    lr = 2e-3
+    # torch route
+    d_ref = torch.zeros(6, device=dev, requires_grad=True)
+    opt = torch.optim.Adam([d_ref], lr=lr)
+    # kernel route
+    d_k, m_k, v_k = torch.zeros(6, device=dev), torch.zeros(6, device=dev), torch.zeros(6, device=dev)
+    M_k = torch.zeros(3, 4, device=dev)
+    none = torch.empty(0, device=dev)
+    ops.pose_step(d_k, m_k, v_k, none, base, M_k, lr, 0.9, 0.999, 1e-8, 0)
+    for it in range(1, 41):
+        opt.zero_grad()
+        M_ref = pose.retr_matrix(d_ref, pose7)[:3]
+        assert torch.allclose(M_k, M_ref.detach(), atol=2e-6), (it, (M_k - M_ref).abs().max().item())
+        loss = (Wt * M_ref).sum() + 0.5 * (M_ref ** 2).sum()
+        loss.backward()
+        opt.step()
+        dM = Wt + M_k                                               # the same dL/dM, evaluated at the kernel's own M
+        ops.pose_step(d_k, m_k, v_k, dM, base, M_k, lr, 0.9, 0.999, 1e-8, it)
+        assert torch.allclose(d_k, d_ref.detach(), atol=5e-6, rtol=1e-4), (it, d_k, d_ref)
+    assert d_ref.detach().abs().max().item() > 0.05                # the trajectory actually moved (40 steps of lr 2e-3)
