@@ -256,6 +256,37 @@ def dropin_leg(ts, scene, settings, gt, dev, steps, warmup):
                     "no fused extension entry point is used"}
 
 
+def stage_a_leg(dev, W=980, H=545):
+    """One frame pair of stage A (compute_relative_pose, ht3dgs_trainer.py:336-380) on synthetic frames: the single-image model of
+    ~130 k pixel-Gaussians trained on frame p, then the SE(3) pose fit on frame p + 1 -- ms per iteration of each phase, the pose
+    iteration both as the one-kernel update (gsr_pose_step) and as the torch statement of the reference's loop (exponential map +
+    autograd + torch.optim.Adam on six numbers)."""
+    sequence = importlib.import_module("3dgs_hierarchical_training_amd.sequence")
+    stage_a = importlib.import_module("3dgs_hierarchical_training_amd.stage_a")
+    ts = importlib.import_module("3dgs_hierarchical_training_amd.train_step")
+    seq = sequence.FrameSequence(3, 400_000, W, H, dev, seed=0)
+    seq.target(0); seq.target(1)
+
+    def timed(**kw):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        M = stage_a.fit_pair(seq, 0, dev, n_points=130_000, seed=0, **kw)
+        torch.cuda.synchronize(dev)
+        return time.perf_counter() - t0, M
+    timed(single_image_iters=20, pose_iters=20)                                  # warm-up (kernel loads, allocator)
+    timed(single_image_iters=5, pose_iters=30, fused_pose_step=False)           # ... and of torch's small kernels for the loop statement
+    t_img, _ = timed(single_image_iters=300, pose_iters=0)
+    t_both, M = timed(single_image_iters=300, pose_iters=200)
+    t_torch, _ = timed(single_image_iters=300, pose_iters=100, fused_pose_step=False)
+    T = seq.true_rel_pose(0, 1)
+    return {"gaussians": 130_000, "width": W, "height": H,
+            "image_iteration_ms": 1e3 * t_img / 300, "pose_iteration_ms": 1e3 * (t_both - t_img) / 200,
+            "pose_iteration_ms_torch_loop": 1e3 * (t_torch - t_img) / 100,
+            "pose_error_after_300_plus_200": float((M - T).abs().max()), "identity_guess_error": float((torch.eye(4) - T).abs().max()),
+            "note": "per pair the reference runs up to 1000 image iterations and 300 pose iterations (ht3dgs_trainer.py:274-333); "
+                    "stage A is ~70 % of a scene's render calls"}
+
+
 def workload_leg(syn, ts, raster, dev, N, W, H, deg, steps, warmup, clustered=False, densify_every=0, seed=0):
     dm = importlib.import_module("3dgs_hierarchical_training_amd.densify")
     scene = syn.make_scene(N, W, H, sh_degree=deg, seed=seed, clustered=clustered)
@@ -601,6 +632,10 @@ def main():
                     extra[name] = workload_leg(syn, ts, raster, dev, deg=deg, warmup=3, **kw)
                 except Exception as e:
                     extra[name] = {"error": repr(e)}
+            try:
+                extra["stage-A frame pair @980x545 (single-image model + pose fit)"] = stage_a_leg(dev)
+            except Exception as e:
+                extra["stage-A frame pair @980x545 (single-image model + pose fit)"] = {"error": repr(e)}
         res["other_workloads"] = extra
     if world == 1 and not args.no_cpu_baseline:
         threads, quota = _CPUS, _CPU_QUOTA
