@@ -34,7 +34,9 @@ for it in range(steps):
             params.reset_opacity()
         l = float(pkg["loss"])
         bad = any(not torch.isfinite(g["params"][0]).all() for g in params.optimizer.param_groups)
-        print(it + 1, "N", params._xyz.shape[0], "loss %.5f" % l, "nonfinite", bad, "%.1f s" % (time.time() - t0), flush=True)
+        import resource
+        print(it + 1, "N", params._xyz.shape[0], "loss %.5f" % l, "nonfinite", bad, "%.1f s" % (time.time() - t0),
+              "device reserved %d MiB, host RSS max %d MiB" % (torch.cuda.memory_reserved(dev) >> 20, resource.getrusage(resource.RUSAGE_SELF).ru_maxrss >> 10), flush=True)
         assert not bad and l == l
 torch.cuda.synchronize()
 print("done", steps, "steps in %.1f s" % (time.time() - t0))
