@@ -69,7 +69,7 @@ EXPORTS = [
     "gsr_binning_scratch_bytes", "gsr_backward_scratch_bytes", "gsr_forward", "gsr_backward",
     "gsr_mark_visible", "gsr_last_error", "gsr_version", "gsr_set_option", "gsr_sort_pairs_u32",
     "gsr_sort_pairs_u16", "gsr_sort_scratch_bytes", "gsr_image_staged_offset", "gsr_profile_read",
-    "gsr_loss_workspace_bytes", "gsr_loss_forward", "gsr_loss_backward", "gsr_adam_step", "gsr_pose_step",
+    "gsr_loss_workspace_bytes", "gsr_loss_forward", "gsr_loss_backward", "gsr_adam_step", "gsr_pose_step", "gsr_pose_step_camera",
     "gsr_knn_scratch_bytes", "gsr_knn_mean_dist2", "gsr_get_counter", "gsr_debug_read_binning", "gsr_prepared_bytes",
     "gsr_prepare_supported", "gsr_prepared_radii_offset",
 ]
@@ -114,6 +114,8 @@ def load():
     lib.gsr_adam_step.argtypes = [C.POINTER(GsrAdamTensor), C.c_int32, C.c_float, C.c_float, C.c_float, C.c_int64, C.c_void_p]
     lib.gsr_pose_step.restype = C.c_int
     lib.gsr_pose_step.argtypes = [C.c_void_p] * 6 + [C.c_float] * 4 + [C.c_int64, C.c_void_p]
+    lib.gsr_pose_step_camera.restype = C.c_int
+    lib.gsr_pose_step_camera.argtypes = [C.c_void_p] * 11 + [C.c_float] * 4 + [C.c_int64, C.c_void_p]
     lib.gsr_binning_bytes.restype = C.c_size_t
     lib.gsr_binning_bytes.argtypes = [C.c_int64, C.c_int32, C.c_int32]
     lib.gsr_binning_scratch_bytes.restype = C.c_size_t

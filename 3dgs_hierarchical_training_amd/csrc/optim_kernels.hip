@@ -172,3 +172,94 @@ extern "C" int gsr_pose_step(float* delta6, float* exp_avg6, float* exp_avg_sq6,
                        points_transform_out12, lr, beta1, beta2, eps, bc1, bc2s, step > 0 ? 1 : 0);
     return hipGetLastError() == hipSuccess ? GSR_OK : GSR_ERR_HIP;
 }
+
+// ------------------------------------------------------------------------------------------------
+// The same pose step when the pose lives in the CAMERA of the render instead of a transform of the means: the render's
+// three camera tensors are functions of the world-to-camera matrix M = Exp(delta) * base,
+//   viewmatrix V = M^T,  projmatrix F = V * Pt (Pt = transposed projection, fixed intrinsics),  campos c = -R^T t,
+// and gsr_backward returns dL/dV, dL/dF, dL/dc (d_viewmatrix / d_projmatrix / d_campos).  This kernel folds the three into
+// dL/dM (rows 0..2), chains to dL/d(delta), applies Adam and rewrites V, F and c IN PLACE for the next render of the frame.
+// View-dependent colour keeps its world-frame directions this way (with a transform of the means they would be taken in
+// each camera's own frame).
+// ------------------------------------------------------------------------------------------------
+namespace gsr {
+
+__global__ void k_pose_adam_camera(float* __restrict__ delta, float* __restrict__ m, float* __restrict__ v, const float* __restrict__ d_vm,
+                                   const float* __restrict__ d_pm, const float* __restrict__ d_cp, const float* __restrict__ projT,
+                                   const float* __restrict__ base, float* __restrict__ vm, float* __restrict__ pm, float* __restrict__ cp,
+                                   float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt, int do_step)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double d[6], B[12], M[12], Pt[16];
+    for (int k = 0; k < 6; k++) d[k] = (double)delta[k];
+    if (base) for (int q = 0; q < 12; q++) B[q] = (double)base[q];
+    for (int q = 0; q < 16; q++) Pt[q] = (double)projT[q];
+    const double* Bp = base ? B : nullptr;
+    if (do_step) {
+        se3_exp_times(d, Bp, M);
+        // dL/dV_total = dV + dF Pt^T ;  dL/dM[i][j] = dL/dV_total[j][i]  (V = M^T)
+        double G[12];
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 4; j++) {
+                double a = d_vm ? (double)d_vm[4 * j + i] : 0.0;
+                if (d_pm) for (int k = 0; k < 4; k++) a += (double)d_pm[4 * j + k] * Pt[4 * i + k];
+                G[4 * i + j] = a;
+            }
+        if (d_cp) {   // c_j = -sum_i R_ij t_i
+            for (int i = 0; i < 3; i++) {
+                double gt = 0.0;
+                for (int j = 0; j < 3; j++) { G[4 * i + j] += -M[4 * i + 3] * (double)d_cp[j]; gt += -M[4 * i + j] * (double)d_cp[j]; }
+                G[4 * i + 3] += gt;
+            }
+        }
+        float g[6];
+        const double h = 1e-6;
+        for (int k = 0; k < 6; k++) {
+            double Mp[12], Mm[12];
+            const double keep = d[k];
+            d[k] = keep + h; se3_exp_times(d, Bp, Mp);
+            d[k] = keep - h; se3_exp_times(d, Bp, Mm);
+            d[k] = keep;
+            double acc = 0.0;
+            for (int q = 0; q < 12; q++) acc += G[q] * (Mp[q] - Mm[q]) / (2.0 * h);
+            g[k] = (float)acc;
+        }
+        for (int k = 0; k < 6; k++) {
+            const float mk = b1 * m[k] + (1.f - b1) * g[k];
+            const float vk = b2 * v[k] + (1.f - b2) * g[k] * g[k];
+            m[k] = mk; v[k] = vk;
+            const float denom = sqrtf(vk) / bc2_sqrt + eps;
+            const float p = delta[k] - (lr / bc1) * (mk / denom);
+            delta[k] = p;
+            d[k] = (double)p;
+        }
+    }
+    se3_exp_times(d, Bp, M);
+    double V[16];
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) V[4 * i + j] = j < 3 ? M[4 * j + i] : (i == 3 ? 1.0 : 0.0);   // V = [M; 0 0 0 1]^T
+    for (int q = 0; q < 16; q++) vm[q] = (float)V[q];
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) {
+            double a = 0.0;
+            for (int k = 0; k < 4; k++) a += V[4 * i + k] * Pt[4 * k + j];
+            pm[4 * i + j] = (float)a;
+        }
+    for (int j = 0; j < 3; j++) cp[j] = (float)(-(M[j] * M[3] + M[4 + j] * M[7] + M[8 + j] * M[11]));
+}
+
+}  // namespace gsr
+
+extern "C" int gsr_pose_step_camera(float* delta6, float* exp_avg6, float* exp_avg_sq6, const float* d_viewmatrix16, const float* d_projmatrix16,
+                                    const float* d_campos3, const float* projection_T16, const float* base12, float* viewmatrix16,
+                                    float* projmatrix16, float* campos3, float lr, float beta1, float beta2, float eps, int64_t step, void* stream)
+{
+    if (!delta6 || !projection_T16 || !viewmatrix16 || !projmatrix16 || !campos3 || step < 0) return GSR_ERR_ARG;
+    if (step > 0 && (!exp_avg6 || !exp_avg_sq6 || (!d_viewmatrix16 && !d_projmatrix16 && !d_campos3))) return GSR_ERR_ARG;
+    const float bc1 = step > 0 ? (float)(1.0 - pow((double)beta1, (double)step)) : 1.f;
+    const float bc2s = step > 0 ? (float)sqrt(1.0 - pow((double)beta2, (double)step)) : 1.f;
+    hipLaunchKernelGGL(gsr::k_pose_adam_camera, dim3(1), dim3(64), 0, (hipStream_t)stream, delta6, exp_avg6, exp_avg_sq6, d_viewmatrix16,
+                       d_projmatrix16, d_campos3, projection_T16, base12, viewmatrix16, projmatrix16, campos3, lr, beta1, beta2, eps, bc1, bc2s,
+                       step > 0 ? 1 : 0);
+    return hipGetLastError() == hipSuccess ? GSR_OK : GSR_ERR_HIP;
+}

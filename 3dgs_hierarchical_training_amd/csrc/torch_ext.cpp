@@ -205,7 +205,7 @@ std::vector<Tensor> rasterize_backward_fused(
     double scale_modifier, int64_t sh_degree, bool need_vm, bool need_pm, bool need_campos, bool need_xf, at::TensorList adam_m,
     at::TensorList adam_v, at::ArrayRef<double> adam_lr, double beta1, double beta2, double eps, int64_t step, const Tensor& next_vm,
     const Tensor& next_pm, const Tensor& next_campos, int64_t next_H, int64_t next_W, double next_tanfovx, double next_tanfovy,
-    Tensor prepared_out)
+    Tensor prepared_out, const Tensor& next_xf)
 {
     const c10::hip::HIPGuardMasqueradingAsCUDA guard(means3D.device());
     TORCH_CHECK(adam_m.size() == 6 && adam_v.size() == 6 && adam_lr.size() == 6, "fused_adam: six groups expected");
@@ -233,11 +233,12 @@ std::vector<Tensor> rasterize_backward_fused(
     a.scratch = scratch.data_ptr();
     a.fused_adam = &fa;
     GsrNextView nv{};
-    const Tensor nvm = f32c(next_vm), npm = f32c(next_pm), ncp = f32c(next_campos);
+    // (the next render's own pose transform when its frame has one; otherwise it shares this render's)
+    const Tensor nvm = f32c(next_vm), npm = f32c(next_pm), ncp = f32c(next_campos), nxf = has(next_xf) ? f32c(next_xf.slice(0, 0, 3)) : xf;
     if (has(prepared_out)) {   // "prepare in backward": this kernel also runs the NEXT render's preprocess on the updated parameters
         nv.W = (int32_t)next_W; nv.H = (int32_t)next_H; nv.D = (int32_t)sh_degree;
         nv.scale_modifier = (float)scale_modifier; nv.tanfovx = (float)next_tanfovx; nv.tanfovy = (float)next_tanfovy;
-        nv.viewmatrix = fp(nvm); nv.projmatrix = fp(npm); nv.campos = fp(ncp); nv.points_transform = fp(xf);
+        nv.viewmatrix = fp(nvm); nv.projmatrix = fp(npm); nv.campos = fp(ncp); nv.points_transform = fp(nxf);
         a.next_view = &nv;
         a.prepared_out = prepared_out.data_ptr();
     }
@@ -257,6 +258,7 @@ struct Cfg {
     std::vector<Tensor> adam_m, adam_v;   // optimizer moments: plain buffers, not autograd inputs
     Tensor prepared;                      // input: hand-over buffer of the preceding backward (or undefined)
     Tensor next_vm, next_pm, next_campos; // camera of the NEXT render (or undefined): the backward prepares it
+    Tensor next_xf;                       // ... and its points_transform, when it differs from this render's (per-frame poses)
     int64_t next_H = 0, next_W = 0;
     double next_tanfovx = 0, next_tanfovy = 0;
 };
@@ -296,7 +298,8 @@ class RasterizeFn : public torch::autograd::Function<RasterizeFn> {
         ctx->saved_data["done"] = false;
         ctx->saved_data["prep_out"] = prep_out;
         ctx->saved_data["next_cam"] = std::vector<Tensor>{has(cfg.next_vm) ? f32c(cfg.next_vm) : x, has(cfg.next_vm) ? f32c(cfg.next_pm) : x,
-                                                          has(cfg.next_vm) ? f32c(cfg.next_campos) : x};
+                                                          has(cfg.next_vm) ? f32c(cfg.next_campos) : x,
+                                                          has(cfg.next_xf) ? f32c(cfg.next_xf) : x.new_empty({0})};
         ctx->saved_data["next_H"] = cfg.next_H; ctx->saved_data["next_W"] = cfg.next_W;
         ctx->saved_data["next_tfx"] = cfg.next_tanfovx; ctx->saved_data["next_tfy"] = cfg.next_tanfovy;
         ctx->mark_non_differentiable({std::get<1>(out), prep_out});
@@ -334,7 +337,7 @@ class RasterizeFn : public torch::autograd::Function<RasterizeFn> {
                              ctx->saved_data["b1"].toDouble(), ctx->saved_data["b2"].toDouble(), ctx->saved_data["eps"].toDouble(),
                              ctx->saved_data["step"].toInt(), nc[0], nc[1], nc[2], ctx->saved_data["next_H"].toInt(),
                              ctx->saved_data["next_W"].toInt(), ctx->saved_data["next_tfx"].toDouble(), ctx->saved_data["next_tfy"].toDouble(),
-                             ctx->saved_data["prep_out"].toTensor());
+                             ctx->saved_data["prep_out"].toTensor(), nc[3]);
             out[1] = r[0]; out[9] = r[1]; out[10] = r[2]; out[11] = r[3]; d_xf = r[4];
         } else {
             static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("gsr::rasterize_backward", "").typed<decltype(rasterize_backward)>();
@@ -355,7 +358,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> rasterize(
     const Tensor& xf, int64_t H, int64_t W, double tanfovx, double tanfovy, double scale_modifier, int64_t sh_degree, bool raw_params,
     bool prefiltered, bool debug, bool cam_grad, at::TensorList adam_m, at::TensorList adam_v, at::ArrayRef<double> adam_lr, double beta1,
     double beta2, double eps, int64_t step, const Tensor& prepared, const Tensor& next_vm, const Tensor& next_pm, const Tensor& next_campos,
-    int64_t next_H, int64_t next_W, double next_tanfovx, double next_tanfovy)
+    int64_t next_H, int64_t next_W, double next_tanfovx, double next_tanfovy, const Tensor& next_xf)
 {
     Cfg cfg{H, W, sh_degree, step, tanfovx, tanfovy, scale_modifier, beta1, beta2, eps, raw_params, prefiltered, debug, cam_grad,
             std::vector<double>(adam_lr.begin(), adam_lr.end()), adam_m.vec(), adam_v.vec()};
@@ -364,6 +367,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> rasterize(
         TORCH_CHECK(!adam_m.empty(), "prepare_next needs fused_adam (the backward that applies the update prepares the next render)");
         cfg.next_vm = next_vm; cfg.next_pm = next_pm; cfg.next_campos = next_campos;
         cfg.next_H = next_H; cfg.next_W = next_W; cfg.next_tanfovx = next_tanfovx; cfg.next_tanfovy = next_tanfovy;
+        if (has(next_xf)) cfg.next_xf = next_xf;
     }
     auto r = RasterizeFn::apply(means3D, means2D, sh, colors, opac, scales, rots, cov, rest, vm, pm, campos, bg, xf, cfg);
     return {r[0], r[1], r[2], r[3], r[4]};
@@ -376,9 +380,9 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> rasterize_forward_only(
     const Tensor& xf, int64_t H, int64_t W, double tanfovx, double tanfovy, double scale_modifier, int64_t sh_degree, bool raw_params,
     bool prefiltered, bool debug, bool cam_grad, at::TensorList adam_m, at::TensorList adam_v, at::ArrayRef<double> adam_lr, double beta1,
     double beta2, double eps, int64_t step, const Tensor& prepared, const Tensor& next_vm, const Tensor& next_pm, const Tensor& next_campos,
-    int64_t next_H, int64_t next_W, double next_tanfovx, double next_tanfovy)
+    int64_t next_H, int64_t next_W, double next_tanfovx, double next_tanfovy, const Tensor& next_xf)
 {
-    (void)means2D; (void)cam_grad; (void)adam_m; (void)adam_v; (void)adam_lr; (void)beta1; (void)beta2; (void)eps; (void)step;
+    (void)means2D; (void)next_xf; (void)cam_grad; (void)adam_m; (void)adam_v; (void)adam_lr; (void)beta1; (void)beta2; (void)eps; (void)step;
     (void)next_vm; (void)next_pm; (void)next_campos; (void)next_H; (void)next_W; (void)next_tanfovx; (void)next_tanfovy;
     auto out = rasterize_forward(means3D, sh, colors, opac, scales, rots, cov, rest, vm, pm, campos, bg, has(xf) ? xf.slice(0, 0, 3) : xf, H, W,
                                  tanfovx, tanfovy, scale_modifier, sh_degree, raw_params, prefiltered, debug, prepared);
@@ -464,6 +468,25 @@ void pose_step(Tensor delta, Tensor exp_avg, Tensor exp_avg_sq, const Tensor& d_
                         c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()), "gsr_pose_step");
 }
 
+// Camera-route pose step: the frame's viewmatrix / projmatrix / campos tensors are rewritten in place from their own gradients.
+void pose_step_camera(Tensor delta, Tensor exp_avg, Tensor exp_avg_sq, const Tensor& d_vm, const Tensor& d_pm, const Tensor& d_cp,
+                      const Tensor& projT, const Tensor& base, Tensor vm, Tensor pm, Tensor cp, double lr, double beta1, double beta2,
+                      double eps, int64_t step)
+{
+    TORCH_CHECK(delta.is_cuda(), "pose_step_camera: tensors must be on a ROCm/HIP device (no CPU fallback)");
+    const c10::hip::HIPGuardMasqueradingAsCUDA guard(delta.device());
+    auto okn = [](const Tensor& t, int64_t n) { return t.is_contiguous() && t.scalar_type() == at::kFloat && t.numel() == n; };
+    TORCH_CHECK(okn(delta, 6) && (step == 0 || (okn(exp_avg, 6) && okn(exp_avg_sq, 6))), "pose_step_camera: delta / moments must be contiguous float32 [6]");
+    TORCH_CHECK(okn(vm, 16) && okn(pm, 16) && okn(cp, 3), "pose_step_camera: viewmatrix / projmatrix [4,4] and campos [3] must be contiguous float32");
+    const Tensor gv = has(d_vm) ? f32c(d_vm) : d_vm, gp = has(d_pm) ? f32c(d_pm) : d_pm, gc = has(d_cp) ? f32c(d_cp) : d_cp;
+    const Tensor pt = f32c(projT), b = has(base) ? f32c(base) : base;
+    TORCH_CHECK(pt.numel() == 16 && (!has(b) || b.numel() >= 12), "pose_step_camera: projection_T must be [4,4], base [3,4] or [4,4]");
+    check(gsr_pose_step_camera(delta.data_ptr<float>(), step ? exp_avg.data_ptr<float>() : nullptr, step ? exp_avg_sq.data_ptr<float>() : nullptr,
+                               fp(gv), fp(gp), fp(gc), fp(pt), fp(b), vm.data_ptr<float>(), pm.data_ptr<float>(), cp.data_ptr<float>(),
+                               (float)lr, (float)beta1, (float)beta2, (float)eps, step,
+                               c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()), "gsr_pose_step_camera");
+}
+
 Tensor knn_mean_dist2(const Tensor& points_)
 {
     TORCH_CHECK(points_.is_cuda(), "distCUDA2: points must be on a ROCm/HIP device (no CPU fallback)");
@@ -497,19 +520,22 @@ TORCH_LIBRARY(gsr, m)
           "int image_width, float tanfovx, float tanfovy, float scale_modifier, int sh_degree, bool need_viewmatrix, bool need_projmatrix, "
           "bool need_campos, bool need_points_transform, Tensor(g!)[] adam_m, Tensor(h!)[] adam_v, float[] adam_lr, float beta1, "
           "float beta2, float eps, int step, Tensor next_viewmatrix, Tensor next_projmatrix, Tensor next_campos, int next_height, "
-          "int next_width, float next_tanfovx, float next_tanfovy, Tensor(i!) prepared_out) -> Tensor[]");
+          "int next_width, float next_tanfovx, float next_tanfovy, Tensor(i!) prepared_out, Tensor next_points_transform) -> Tensor[]");
     m.def("rasterize(Tensor means3D, Tensor means2D, Tensor sh, Tensor colors_precomp, Tensor opacities, Tensor scales, Tensor rotations, "
           "Tensor cov3D_precomp, Tensor sh_rest, Tensor viewmatrix, Tensor projmatrix, Tensor campos, Tensor bg, Tensor points_transform, "
           "int image_height, int image_width, float tanfovx, float tanfovy, float scale_modifier, int sh_degree, bool raw_params, "
           "bool prefiltered, bool debug, bool cam_grad, Tensor[] adam_m, Tensor[] adam_v, float[] adam_lr, float beta1, float beta2, "
           "float eps, int step, Tensor prepared, Tensor next_viewmatrix, Tensor next_projmatrix, Tensor next_campos, int next_height, "
-          "int next_width, float next_tanfovx, float next_tanfovy) -> (Tensor, Tensor, Tensor, Tensor, Tensor)");
+          "int next_width, float next_tanfovx, float next_tanfovy, Tensor next_points_transform) -> (Tensor, Tensor, Tensor, Tensor, Tensor)");
     m.def("mark_visible(Tensor means3D, Tensor viewmatrix, Tensor projmatrix) -> Tensor");
     m.def("photometric_loss_forward(Tensor render, Tensor target, float lambda_dssim, bool clamp) -> (Tensor, Tensor)");
     m.def("photometric_loss_backward(Tensor render, Tensor target, Tensor workspace, Tensor grad_loss, float lambda_dssim, bool clamp) -> Tensor");
     m.def("adam_step(Tensor(a!)[] params, Tensor[] grads, Tensor(b!)[] exp_avg, Tensor(c!)[] exp_avg_sq, float[] lr, float beta1, "
           "float beta2, float eps, int step) -> ()");
     m.def("pose_step(Tensor(a!) delta, Tensor(b!) exp_avg, Tensor(c!) exp_avg_sq, Tensor d_xf, Tensor base, Tensor(d!) xf, float lr, "
+          "float beta1, float beta2, float eps, int step) -> ()");
+    m.def("pose_step_camera(Tensor(a!) delta, Tensor(b!) exp_avg, Tensor(c!) exp_avg_sq, Tensor d_viewmatrix, Tensor d_projmatrix, "
+          "Tensor d_campos, Tensor projection_T, Tensor base, Tensor(d!) viewmatrix, Tensor(e!) projmatrix, Tensor(f!) campos, float lr, "
           "float beta1, float beta2, float eps, int step) -> ()");
     m.def("knn_mean_dist2(Tensor points) -> Tensor");
     m.def("debug_last() -> Tensor[]", &debug_last);
@@ -525,6 +551,7 @@ TORCH_LIBRARY_IMPL(gsr, CUDA, m)   // the dispatch key of HIP tensors on a ROCm 
     m.impl("photometric_loss_backward", &photometric_loss_backward);
     m.impl("adam_step", &adam_step);
     m.impl("pose_step", &pose_step);
+    m.impl("pose_step_camera", &pose_step_camera);
     m.impl("knn_mean_dist2", &knn_mean_dist2);
     m.impl("rasterize", &rasterize_forward_only);
 }

@@ -293,7 +293,7 @@ def _e(dev):
 
 
 def _rasterize_ext(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, rs, sh_rest, raw_params,
-                   fused_adam, points_transform, prepared=None, prepare_next=None):
+                   fused_adam, points_transform, prepared=None, prepare_next=None, next_points_transform=None):
     """torch.ops.gsr.rasterize: empty tensors stand for None; the camera tensors of the settings tuple are ordinary inputs
     (their gradients are produced when one of them requires grad)."""
     ops = E.load()
@@ -332,7 +332,8 @@ def _rasterize_ext(means3D, means2D, sh, colors_precomp, opacities, scales, rota
             bool(rs.debug), bool(cam_grad), m, v, lr, b1, b2, eps, step,
             eb if prepared is None else prepared, e if nx is None else nvm, e if nx is None else npm, e if nx is None else ncp,
             0 if nx is None else int(nx.image_height), 0 if nx is None else int(nx.image_width),
-            0.0 if nx is None else float(nx.tanfovx), 0.0 if nx is None else float(nx.tanfovy))
+            0.0 if nx is None else float(nx.tanfovx), 0.0 if nx is None else float(nx.tanfovy),
+            e if (nx is None or next_points_transform is None) else next_points_transform.to(dev))
     if not rs.debug:
         out = ops.rasterize(*args)
         return out if nx is not None else out[:4]
@@ -357,7 +358,8 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
 
 
 def rasterize_gaussians_raw(means3D, means2D, features_dc, features_rest, opacity_logit, log_scales, rotations_raw,
-                            raster_settings, fused_adam=None, points_transform=None, prepared=None, prepare_next=None):
+                            raster_settings, fused_adam=None, points_transform=None, prepared=None, prepare_next=None,
+                            next_points_transform=None):
     """Extension ("next" row f-2): rasterize straight from HTGaussianModel's raw parameters (_xyz, _features_dc,
     _features_rest, _opacity, _scaling, _rotation; /root/reference/scene/gaussian_model_ht.py:74-82) with the
     activations of :49-65,128-133,176-188 fused into the HIP kernels; gradients are w.r.t. the raw tensors.
@@ -375,10 +377,11 @@ def rasterize_gaussians_raw(means3D, means2D, features_dc, features_rest, opacit
     that render's preprocess on the freshly updated parameters (include/gsr.h GsrNextView) and a FIFTH output -- a byte
     buffer, valid once backward() has run -- is returned; hand it to the next call as `prepared=` together with the same
     settings and the (in-place updated) parameter tensors, and that forward skips its preprocess kernel with a bit-identical
-    result.  The caller guarantees that nothing else modifies the parameters in between."""
+    result.  The caller guarantees that nothing else modifies the parameters in between.  next_points_transform = the pose
+    transform of that next render when it is not this render's (per-frame poses under refinement)."""
     if not E.use_ctypes():
         return _rasterize_ext(means3D, means2D, features_dc, None, opacity_logit, log_scales, rotations_raw, None, raster_settings,
-                              features_rest, True, fused_adam, points_transform, prepared, prepare_next)
+                              features_rest, True, fused_adam, points_transform, prepared, prepare_next, next_points_transform)
     if prepared is not None or prepare_next is not None:
         raise RuntimeError("prepared / prepare_next are served by the PyTorch extension binding only")
     e = torch.Tensor([])

@@ -89,6 +89,10 @@ class HTConfig:
     seed: int = 0
     optimizer: str = "hip"
     fused: bool = True
+    fit_pose: bool = False                      # refine each frame's pose while training on it (training_setup(fit_pose=True), :733)
+    pose_lr: float = 1e-5                       # Adam with eps 1e-15 moves a pose by ~lr per step whatever the gradient: on these
+                                                # frames (1-2 px of motion per frame) 5e-6..2e-5 gains 0.4-0.6 dB over fixed stage-A
+                                                # poses, 1e-4 loses 0.5 dB (tools/pose_lr_sweep.sh); the reference's rotation_lr is 1e-3
 
 
 class Segment:
@@ -98,6 +102,22 @@ class Segment:
     def __init__(self, params, frames: List[int], start_fidx: int, poses: Dict[int, torch.Tensor], global_iteration: int = 0):
         self.params, self.frames, self.start_fidx, self.poses, self.global_iteration = params, list(frames), start_fidx, dict(poses), global_iteration
         self.densifier = None
+        self.pose_states = {}        # frame -> train_step.PoseState, while its pose is being refined (cfg.fit_pose)
+
+    def pose_state(self, f: int, template, device, lr: float):
+        ps = self.pose_states.get(f)
+        if ps is None:
+            ps = self.pose_states[f] = ts.CameraPoseState(template, self.poses[f], device, lr=lr)
+            if f == self.start_fidx:
+                ps.freeze()          # the segment's start frame fixes the gauge
+        return ps
+
+    def sync_poses(self):
+        """Refined transforms back into the pose table (what merges, importance views and evaluation read); the optimizer
+        state of the poses ends with the training phase."""
+        for f, ps in self.pose_states.items():
+            self.poses[f] = ps.matrix()
+        self.pose_states = {}
 
     def pose_tensor(self) -> torch.Tensor:
         return torch.stack([self.poses[f] for f in self.frames])
@@ -148,6 +168,17 @@ class RankRunner:
 
     def _steps_over(self, seg: Segment, frames_drawn):
         """Train on a pre-drawn list of frames (the frame of step k + 1 is known at step k)."""
+        if self.cfg.fit_pose and self.step_fn is None:
+            # pose refinement: frame f's camera tensors are functions of Exp(delta_f) * pose_f; after each render of frame f its six
+            # tangent numbers take one Adam step and the camera is rewritten in place (one kernel, train_step.CameraPoseState).
+            # The segment's start frame fixes the gauge and is not refined.
+            states = [seg.pose_state(v, self._settings(seg, v), self.dev, self.cfg.pose_lr) for v in frames_drawn]
+            for k, v in enumerate(frames_drawn):
+                seg.global_iteration += 1
+                ts.train_step(seg.params, states[k].settings, self.seq.target(v), fused_optimizer=self.cfg.fused, densifier=seg.densifier,
+                              iteration=seg.global_iteration, pose=states[k], next_pose=states[k + 1] if k + 1 < len(states) else None)
+            seg.sync_poses()
+            return
         st = [self._settings(seg, v) for v in frames_drawn]
         for k, v in enumerate(frames_drawn):
             self._step(seg, st[k], self.seq.target(v), st[k + 1] if k + 1 < len(st) else None)
@@ -328,6 +359,9 @@ def main():
     ap.add_argument("--phase2-iters", type=int, default=10)
     ap.add_argument("--importance-views", type=int, default=0)
     ap.add_argument("--densify", action="store_true")
+    ap.add_argument("--pose-lr", type=float, default=None)
+    ap.add_argument("--fit-pose", action="store_true", help="refine every frame's pose while training on it (the reference's "
+                                                            "camera_optimizer): one pose-step kernel per train step")
     ap.add_argument("--backend", default="nccl")
     ap.add_argument("--stage-a", type=int, nargs=3, metavar=("GAUSSIANS", "IMAGE_ITERS", "POSE_ITERS"), default=None,
                     help="run stage A first (relative pose of every consecutive frame pair: single-image 3DGS of frame p, then the "
@@ -338,7 +372,9 @@ def main():
     a = ap.parse_args()
     cfg = HTConfig(frames=a.frames, width=a.width, height=a.height, gt_gaussians=a.gt_gaussians, leaf_gaussians=a.leaf_gaussians,
                    leaf_iters_per_frame=a.leaf_iters, phase1_iters_per_frame=a.phase1_iters, phase2_iters_per_frame=[a.phase2_iters] * 3,
-                   importance_views=a.importance_views, densify=a.densify)
+                   importance_views=a.importance_views, densify=a.densify, fit_pose=a.fit_pose)
+    if a.pose_lr is not None:
+        cfg.pose_lr = a.pose_lr
     if not torch.cuda.is_available():
         raise SystemExit("run_segments.py needs a ROCm GPU (no CPU fallback in the product path)")
     host_mod.cap_host_threads()   # the container's CPU quota, not the visible core count (host.py)

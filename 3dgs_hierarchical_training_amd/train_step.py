@@ -204,8 +204,100 @@ def _same_view(a: GaussianRasterizationSettings, b: GaussianRasterizationSetting
     return all((x is y) if torch.is_tensor(x) else (x == y) for x, y in zip(a, b))
 
 
+class PoseState:
+    """One camera pose under refinement, the way the reference keeps it (`self.P[k]`, a lietorch SE3 parameter with its own Adam,
+    gaussian_model_ht.py:296-311, stepped after every render of its frame, ht3dgs_trainer.py:162-166): the pose is the transform
+    M = Exp(delta) * base applied to the Gaussians' means in-kernel (`points_transform`), delta = six tangent numbers.  `step()`
+    is ONE kernel (gsr_pose_step): dL/dM -> dL/d(delta), Adam on delta, next M written in place."""
+
+    def __init__(self, base_w2c: torch.Tensor, device, lr: float = 1e-3, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-15):
+        from . import _ext
+        self._ops = _ext.load()
+        self.base = base_w2c.detach().float()[:3].contiguous().to(device)
+        self.delta = torch.zeros(6, device=device)
+        self.m, self.v = torch.zeros(6, device=device), torch.zeros(6, device=device)
+        self.M = torch.zeros(3, 4, device=device)
+        self.lr, self.b1, self.b2, self.eps, self.steps = lr, beta1, beta2, eps, 0
+        self._none = torch.empty(0, device=device)
+        self._ops.pose_step(self.delta, self.m, self.v, self._none, self.base, self.M, lr, beta1, beta2, eps, 0)
+        self._leaf = None
+        self.frozen = False          # True: rendered through its transform like the others, never stepped (the gauge frame)
+
+    def leaf(self) -> torch.Tensor:
+        """The [3,4] transform as a fresh autograd leaf for one render (its .grad is what `step` consumes)."""
+        self._leaf = self.M.detach().requires_grad_(not self.frozen)
+        return self._leaf
+
+    def step(self):
+        if self.frozen or self._leaf is None or self._leaf.grad is None:
+            self._leaf = None
+            return
+        self.steps += 1
+        self._ops.pose_step(self.delta, self.m, self.v, self._leaf.grad, self.base, self.M, self.lr, self.b1, self.b2, self.eps, self.steps)
+        self._leaf = None
+
+    def matrix(self) -> torch.Tensor:
+        """Current world-to-camera [4,4] on the host."""
+        out = torch.eye(4)
+        out[:3] = self.M.detach().cpu()
+        return out
+
+
+class CameraPoseState:
+    """A frame's pose under refinement, kept in the CAMERA of its renders: `settings` is the frame's raster-settings tuple whose
+    viewmatrix / projmatrix / campos are this object's own device tensors (leaves that receive d_viewmatrix / d_projmatrix /
+    d_campos from the backward), functions of M = Exp(delta) * base (world-to-camera).  `step()` -- ONE kernel,
+    gsr_pose_step_camera -- folds the three gradients into dL/dM, chains to the six tangent numbers, applies Adam and rewrites
+    the three tensors in place: the reference's `camera_optimizer[fidx].step()` after a render of frame fidx
+    (ht3dgs_trainer.py:162-166; Adam eps 1e-15, gaussian_model_ht.py:296-311).  View-dependent colour keeps world-frame
+    directions (PoseState, the transform-of-the-means route, evaluates it in each camera's own frame, as the reference's
+    get_xyz route does)."""
+
+    def __init__(self, template: GaussianRasterizationSettings, base_w2c: torch.Tensor, device, lr: float = 1e-3, beta1: float = 0.9,
+                 beta2: float = 0.999, eps: float = 1e-15):
+        from . import _ext
+        self._ops = _ext.load()
+        vm0, pm0 = template.viewmatrix.detach().double().cpu(), template.projmatrix.detach().double().cpu()
+        self.projT = (torch.linalg.inv(vm0) @ pm0).float().contiguous().to(device)      # projmatrix = viewmatrix @ projection_T
+        self.base = base_w2c.detach().float()[:3].contiguous().to(device)
+        self.delta = torch.zeros(6, device=device)
+        self.m, self.v = torch.zeros(6, device=device), torch.zeros(6, device=device)
+        self.vm = torch.zeros(4, 4, device=device, requires_grad=True)
+        self.pm = torch.zeros(4, 4, device=device, requires_grad=True)
+        self.cp = torch.zeros(3, device=device, requires_grad=True)
+        self.lr, self.b1, self.b2, self.eps, self.steps = lr, beta1, beta2, eps, 0
+        self.frozen = False
+        self._none = torch.empty(0, device=device)
+        with torch.no_grad():
+            self._ops.pose_step_camera(self.delta, self.m, self.v, self._none, self._none, self._none, self.projT, self.base,
+                                       self.vm, self.pm, self.cp, lr, beta1, beta2, eps, 0)
+        self.settings = template._replace(viewmatrix=self.vm, projmatrix=self.pm, campos=self.cp)
+
+    def freeze(self):
+        """The gauge frame: rendered like the others, never stepped, no camera gradients asked for."""
+        self.frozen = True
+        for t in (self.vm, self.pm, self.cp):
+            t.requires_grad_(False)
+
+    def step(self):
+        g = (self.vm.grad, self.pm.grad, self.cp.grad)
+        if self.frozen or all(x is None for x in g):
+            self.vm.grad = self.pm.grad = self.cp.grad = None
+            return
+        self.steps += 1
+        with torch.no_grad():
+            self._ops.pose_step_camera(self.delta, self.m, self.v, *(self._none if x is None else x for x in g), self.projT, self.base,
+                                       self.vm, self.pm, self.cp, self.lr, self.b1, self.b2, self.eps, self.steps)
+        self.vm.grad = self.pm.grad = self.cp.grad = None
+
+    def matrix(self) -> torch.Tensor:
+        """Current world-to-camera [4,4] on the host."""
+        return self.vm.detach().t().contiguous().cpu()
+
+
 def render(params: GaussianParams, settings: GaussianRasterizationSettings, clamp: bool = True,
-           fused_activations: bool = False, fused_adam=None, next_settings: GaussianRasterizationSettings = None) -> Dict:
+           fused_activations: bool = False, fused_adam=None, next_settings: GaussianRasterizationSettings = None,
+           points_transform: torch.Tensor = None, next_points_transform: torch.Tensor = None) -> Dict:
     """CF3DGS_Render.render with compute_cov3D_python = convert_SHs_python = False.
     fused_activations=True hands the raw parameters to the kernels (exp / sigmoid / normalize / cat in-kernel).
     next_settings (with fused_adam): the camera of the NEXT render of this model -- its preprocess then rides in this render's
@@ -224,14 +316,18 @@ def render(params: GaussianParams, settings: GaussianRasterizationSettings, clam
         prep, use = getattr(params, "_prepared", None), None
         if prep is not None:
             params._prepared = None          # single use: the forward sorts the buffer's keys in place
-            if prep["valid"] and prep["n"] == xyz.shape[0] and prep["xyz"] is params._xyz and _same_view(prep["settings"], settings):
+            if prep["valid"] and prep["n"] == xyz.shape[0] and prep["xyz"] is params._xyz and _same_view(prep["settings"], settings) \
+                    and prep.get("cam") == _camera_versions(settings) and _same_transform(prep.get("xf"), points_transform):
                 use = prep["buf"]
         want_next = next_settings if (fused_adam is not None and next_settings is not None) else None
         out = rasterize_gaussians_raw(xyz, screenspace_points, params._features_dc, params._features_rest, params._opacity,
                                       params._scaling, params._rotation, settings, fused_adam=fused_adam, prepared=use,
-                                      prepare_next=want_next)
+                                      prepare_next=want_next, points_transform=points_transform,
+                                      next_points_transform=next_points_transform if want_next is not None else None)
         if want_next is not None:        # filled by this render's backward; train_step marks it valid once that has run
-            params._prepared = {"buf": out[4], "settings": want_next, "n": xyz.shape[0], "xyz": params._xyz, "valid": False}
+            nxf = next_points_transform if next_points_transform is not None else points_transform
+            params._prepared = {"buf": out[4], "settings": want_next, "n": xyz.shape[0], "xyz": params._xyz, "valid": False,
+                                "xf": None if nxf is None else (nxf.data_ptr(), nxf._version), "cam": _camera_versions(want_next)}
             out = out[:4]
     else:
         rasterizer = GaussianRasterizer(raster_settings=settings)
@@ -243,9 +339,24 @@ def render(params: GaussianParams, settings: GaussianRasterizationSettings, clam
                             "depth": rendered_depth, "alpha": rendered_alpha, "viewspace_points": screenspace_points, "radii": radii})
 
 
+def _camera_versions(rs) -> tuple:
+    """Version counters of a settings tuple's camera tensors: a pose step that rewrites them in place (CameraPoseState.step) makes
+    a hand-over buffer prepared for the old values stale."""
+    return (rs.viewmatrix._version, rs.projmatrix._version, rs.campos._version)
+
+
+def _same_transform(tag, xf) -> bool:
+    """The hand-over buffer was prepared with this very pose transform: same storage, not written since (a PoseState.step() of
+    that frame in between bumps the version)."""
+    if tag is None or xf is None:
+        return tag is None and xf is None
+    return tag == (xf.data_ptr(), xf._version)
+
+
 def train_step(params: GaussianParams, settings: GaussianRasterizationSettings, gt: torch.Tensor,
                lambda_dssim: float = 0.2, fused_loss: bool = True, fused_activations: bool = True,
-               fused_optimizer: bool = True, densifier=None, iteration: int = 0, next_settings=None) -> Dict:
+               fused_optimizer: bool = True, densifier=None, iteration: int = 0, next_settings=None,
+               pose: "PoseState" = None, next_pose: "PoseState" = None) -> Dict:
     """render -> loss -> backward -> Adam step (ht3dgs_trainer.py:102-166 without densification).
     fused_loss=True evaluates clamp + L1 + SSIM in the HIP loss kernels; False uses the torch restatement.
     fused_activations=True runs exp / sigmoid / normalize / cat inside the rasterizer kernels.
@@ -258,8 +369,20 @@ def train_step(params: GaussianParams, settings: GaussianRasterizationSettings, 
     densifier (densify.Densifier) + iteration: the adaptive density control of ht3dgs_trainer.py:137-155 runs between
     backward() and optimizer.step(), as in the reference (see densify.py for the ordering note of the fused mode)."""
     fused_adam = params.optimizer if (fused_optimizer and fused_activations and isinstance(params.optimizer, FusedAdam)) else None
+    # pose refinement (the reference's camera_optimizer, ht3dgs_trainer.py:162-166): this frame's transform is an autograd leaf of
+    # the render; the hand-over to the next render is skipped when that render is of THIS frame (its transform changes in between)
+    cam_pose = isinstance(pose, CameraPoseState)
+    if cam_pose:             # the pose is this frame's camera: its settings are the render's settings
+        settings = pose.settings
+        if next_pose is not None:
+            next_settings = next_pose.settings
+    xf = pose.leaf() if (pose is not None and not cam_pose) else None
+    nxt = next_settings if params.active_sh_degree == 3 and params.max_sh_degree == 3 else None
+    if pose is not None and nxt is not None and (next_pose is None or (next_pose is pose and not pose.frozen)):
+        nxt = None               # the next render is of THIS frame, whose pose moves in between: no hand-over
     pkg = render(params, settings, clamp=not fused_loss, fused_activations=fused_activations, fused_adam=fused_adam,
-                 next_settings=next_settings if params.active_sh_degree == 3 and params.max_sh_degree == 3 else None)
+                 next_settings=nxt, points_transform=xf,
+                 next_points_transform=next_pose.M if (xf is not None and next_pose is not None and nxt is not None) else None)
     if fused_loss:
         loss = fused_photometric_loss(pkg["raw_image"], gt, lambda_dssim, clamp=True)
     else:
@@ -272,6 +395,8 @@ def train_step(params: GaussianParams, settings: GaussianRasterizationSettings, 
     prep = getattr(params, "_prepared", None)
     if prep is not None and not prep["valid"]:
         prep["valid"] = True             # the backward that fills the hand-over buffer has been enqueued
+    if pose is not None:
+        pose.step()
     if densifier is not None:
         densifier.after_backward(iteration, pkg)
     params.optimizer.step()

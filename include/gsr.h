@@ -278,6 +278,16 @@ int gsr_adam_step(const GsrAdamTensor* tensors, int32_t count, float beta1, floa
 int gsr_pose_step(float* delta6, float* exp_avg6, float* exp_avg_sq6, const float* d_points_transform12, const float* base12,
                   float* points_transform_out12, float lr, float beta1, float beta2, float eps, int64_t step, void* stream);
 
+/* The same step when the pose lives in the render's CAMERA (the reference's camera_optimizer stepping a frame's pose after each
+ * render of it, trainer/ht3dgs_trainer.py:162-166): viewmatrix = M^T, projmatrix = viewmatrix * projection_T, campos = -R^T t for
+ * the world-to-camera M = Exp(delta) * base.  Takes gsr_backward's d_viewmatrix / d_projmatrix / d_campos (any may be NULL),
+ * folds them into dL/dM, chains to dL/d(delta), applies Adam and rewrites the three camera tensors IN PLACE for the next render
+ * of the frame.  projection_T16 = the transposed projection of the camera's intrinsics (projmatrix = viewmatrix * projection_T).
+ * step = 0: only evaluates the camera tensors for the current delta. */
+int gsr_pose_step_camera(float* delta6, float* exp_avg6, float* exp_avg_sq6, const float* d_viewmatrix16, const float* d_projmatrix16,
+                         const float* d_campos3, const float* projection_T16, const float* base12, float* viewmatrix16,
+                         float* projmatrix16, float* campos3, float lr, float beta1, float beta2, float eps, int64_t step, void* stream);
+
 /* ---- "next" row f-1: simple_knn._C.distCUDA2 ----------------------------------------------------------------
  * out[i] = mean of the squared distances from points[i] to its 3 nearest other points (exact), the semantics of the
  * reference's SciPy twin /root/reference/scene/gaussian_model_ht.py:31-36; called at :211-216. */

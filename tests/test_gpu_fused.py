@@ -383,3 +383,58 @@ def _prepare_in_backward_case(N):
     pa.prune_points(torch.zeros(pa.num_points, dtype=torch.bool, device=dev))
     assert pa._prepared is None
     ts.train_step(pa, views[0], gts[0])
+
+
+def test_pose_refinement_in_the_train_step_keeps_the_hand_over_exact():
+    """The reference steps the current frame's pose after every render (camera_optimizer, ht3dgs_trainer.py:162-166).  Here the
+    pose is the in-kernel transform Exp(delta) * base (train_step.PoseState) and its update is one kernel (gsr_pose_step).  With
+    per-frame transforms the "prepare in backward" hand-over must use the NEXT frame's transform (GsrNextView.points_transform) and
+    must be dropped when the next render is of the SAME frame (its transform changes in between): two copies of a model trained
+    on three alternating frames, one with and one without the hand-over, stay EQUAL -- images, parameters, pose tangents -- and
+    the poses, started off their true values, move towards them."""
+    L = importlib.import_module("3dgs_hierarchical_training_amd._lib")
+    pose_mod = importlib.import_module("3dgs_hierarchical_training_amd.pose")
+    lib = L.load()
+    dev = torch.device("cuda:0")
+    W, H, N = 320, 240, 12800
+    sc = parity.syn.make_scene(N, W, H, sh_degree=3, seed=21)
+    ident = ts.make_settings(sc, dev, 3)
+    true = [pose_mod.se3_exp(torch.tensor(v)) for v in ([0.0] * 6, [0.03, -0.01, 0.02, 0.004, -0.006, 0.003], [-0.02, 0.02, 0.01, -0.005, 0.002, 0.004])]
+    off = [pose_mod.se3_exp(torch.tensor(v)) for v in ([0.0] * 6, [0.006, 0.004, -0.005, 0.002, 0.001, -0.002], [-0.005, 0.006, 0.004, -0.001, -0.002, 0.002])]
+    gtp = ts.GaussianParams(sc, dev, optimizer="torch")
+    with torch.no_grad():
+        gts = [ts.render(gtp, ident, fused_activations=True, points_transform=t[:3].to(dev))["image"].clone() for t in true]
+    order = [0, 1, 2, 2, 1, 0, 1, 1, 2, 0, 2, 1]          # includes the same frame twice in a row
+    assert lib.gsr_set_option(b"deterministic_backward", 1) == 0
+    try:
+        runs = []
+        for hand_over in (True, False):
+            p = ts.GaussianParams(sc, dev)
+            for g in p.optimizer.param_groups:            # the model is the truth: keep it (almost) still, only the poses move
+                g["lr"] = g["lr"] * 1e-3
+            ps = [ts.PoseState(off[k] @ true[k], dev, lr=5e-4) for k in range(3)]
+            ps[0].frozen = True
+            imgs, used = [], 0
+            for i, f in enumerate(order):
+                nf = order[i + 1] if i + 1 < len(order) else None
+                had = getattr(p, "_prepared", None) is not None
+                pkg = ts.train_step(p, ident, gts[f], pose=ps[f], next_settings=ident if (hand_over and nf is not None) else None,
+                                    next_pose=ps[nf] if (hand_over and nf is not None) else None)
+                used += int(had)
+                imgs.append(pkg["raw_image"].detach().clone())
+            runs.append((p, ps, imgs, used))
+        (pa, psa, ia, used_a), (pb, psb, ib, used_b) = runs
+        assert used_b == 0 and used_a == sum(1 for i in range(len(order) - 1) if order[i] != order[i + 1])
+        for x, y in zip(ia, ib):
+            assert torch.equal(x, y)
+        for k in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation"):
+            assert torch.equal(getattr(pa, k), getattr(pb, k)), k
+        for a, b in zip(psa, psb):
+            assert torch.equal(a.delta, b.delta) and torch.equal(a.M, b.M)
+        assert float(psa[0].delta.abs().max()) == 0.0                       # the gauge frame never moves
+        for k in (1, 2):
+            e0 = (off[k] @ true[k] - true[k])[:3].abs().max().item()
+            e1 = (psa[k].matrix() - true[k])[:3].abs().max().item()
+            assert e1 < e0, (k, e0, e1)
+    finally:
+        lib.gsr_set_option(b"deterministic_backward", 0)

@@ -195,3 +195,41 @@ def test_pose_step_kernel_equals_torch_exp_map_autograd_and_adam(with_base):
         ops.pose_step(d_k, m_k, v_k, dM, base, M_k, lr, 0.9, 0.999, 1e-8, it)
         assert torch.allclose(d_k, d_ref.detach(), atol=5e-6, rtol=1e-4), (it, d_k, d_ref)
     assert d_ref.detach().abs().max().item() > 0.05                # the trajectory actually moved (40 steps of lr 2e-3)
+
+
+def test_camera_pose_step_kernel_equals_torch_camera_chain_and_adam():
+    """gsr_pose_step_camera: dL/d(viewmatrix, projmatrix, campos) -> dL/dM -> dL/d(delta) -> Adam -> camera tensors rewritten in
+    place, against the torch statement (camera tensors built from pose.retr_matrix under autograd, torch.optim.Adam)."""
+    import importlib
+    _ext = importlib.import_module("3dgs_hierarchical_training_amd._ext")
+    pose = importlib.import_module("3dgs_hierarchical_training_amd.pose")
+    ops = _ext.load()
+    dev = torch.device("cuda:0")
+    cam = parity.syn.make_camera(320, 240)
+    projT = (torch.linalg.inv(cam["viewmatrix"].double()) @ cam["projmatrix"].double()).float().to(dev)
+    g = torch.Generator().manual_seed(5)
+    Wv, Wp, Wc = torch.randn(4, 4, generator=g).to(dev), torch.randn(4, 4, generator=g).to(dev), torch.randn(3, generator=g).to(dev)
+    pose7 = torch.tensor([0.3, -0.2, 0.5, 0.1, -0.2, 0.3, 0.9]).to(dev)
+    base = pose.pose7_to_matrix(pose7)[:3].contiguous()
+    lr = 1e-3
+
+    def cams(delta):
+        M = pose.retr_matrix(delta, pose7)
+        V = M.t()
+        return V, V @ projT, -(M[:3, :3].t() @ M[:3, 3])
+    d_ref = torch.zeros(6, device=dev, requires_grad=True)
+    opt = torch.optim.Adam([d_ref], lr=lr, eps=1e-15)
+    d_k, m_k, v_k = torch.zeros(6, device=dev), torch.zeros(6, device=dev), torch.zeros(6, device=dev)
+    vm, pm, cp = torch.zeros(4, 4, device=dev), torch.zeros(4, 4, device=dev), torch.zeros(3, device=dev)
+    none = torch.empty(0, device=dev)
+    ops.pose_step_camera(d_k, m_k, v_k, none, none, none, projT, base, vm, pm, cp, lr, 0.9, 0.999, 1e-15, 0)
+    for it in range(1, 31):
+        opt.zero_grad()
+        V, F, c = cams(d_ref)
+        assert torch.allclose(vm, V.detach(), atol=2e-6) and torch.allclose(pm, F.detach(), atol=2e-5) and torch.allclose(cp, c.detach(), atol=2e-6), it
+        loss = (Wv * V).sum() + (Wp * F).sum() * 0.1 + (Wc * c).sum() + 0.5 * (c ** 2).sum()
+        loss.backward()
+        opt.step()
+        ops.pose_step_camera(d_k, m_k, v_k, Wv, 0.1 * Wp, Wc + cp, projT, base, vm, pm, cp, lr, 0.9, 0.999, 1e-15, it)
+        assert torch.allclose(d_k, d_ref.detach(), atol=1e-5, rtol=2e-4), (it, d_k, d_ref)
+    assert d_ref.detach().abs().max().item() > 0.01

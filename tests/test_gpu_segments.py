@@ -203,3 +203,27 @@ def test_bench_line_at_two_ranks_on_one_gpu():
     assert "roofline" in d and d["roofline"]["frac"] > 0 and "cpu_baseline" not in d      # cpu_baseline: rank 0 at N = 1 only
     m = d["merge"]
     assert m["pairs"] == 1 and m["merge_bytes"] > 200000 * 236 and m["merge_ms"] > 0 and m["gaussians_merged_max"] == 200000
+
+
+def test_pose_refinement_in_stage_b_improves_on_noisy_relative_poses():
+    """--fit-pose: every frame's pose is refined while its segment trains on it (the reference's camera_optimizer, one
+    gsr_pose_step_camera kernel per train step).  With a relative-pose table that is off (what an imperfect stage A leaves), the
+    refined run explains the frames better than the run that keeps the table fixed, and its poses end closer to the truth."""
+    dev = torch.device("cuda:0")
+    pose_mod = importlib.import_module("3dgs_hierarchical_training_amd.pose")
+    res = {}
+    for fit in (False, True):
+        cfg = rs.HTConfig(frames=12, width=480, height=360, gt_gaussians=60000, leaf_gaussians=60000, leaf_iters_per_frame=60,
+                          phase1_iters_per_frame=2, phase2_iters_per_frame=[20, 20, 20], fit_pose=fit, pose_lr=2e-5)
+        seq = sequence.FrameSequence(cfg.frames, cfg.gt_gaussians, cfg.width, cfg.height, dev, seed=cfg.seed)
+        g = torch.Generator().manual_seed(11)
+        table = {}
+        for p in range(cfg.frames - 1):
+            noise = pose_mod.se3_exp(torch.cat((0.003 * torch.randn(3, generator=g), 0.0008 * torch.randn(3, generator=g))))
+            table[f"rel_pose_{p}_to_{p + 1}"] = noise @ seq.true_rel_pose(p, p + 1)
+        seq.use_pose_table(table)
+        root, _ = rs.run_local(2, seq, cfg, dev, log=lambda r: None)
+        err = max(float((root.seg.poses[f] - seq.w2c[f] @ torch.linalg.inv(seq.w2c[0]))[:3].abs().max()) for f in root.seg.frames)
+        res[fit] = (root.evaluate(), err)
+    print(f"fixed noisy poses: PSNR {res[False][0]:.2f} dB, worst pose entry off by {res[False][1]:.4f}; refined: {res[True][0]:.2f} dB, {res[True][1]:.4f}")
+    assert res[True][0] > res[False][0] + 0.3 and res[True][1] < res[False][1]
