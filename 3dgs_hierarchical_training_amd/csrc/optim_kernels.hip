@@ -123,40 +123,57 @@ __device__ inline void se3_exp_times(const double* d /*6*/, const double* B /*12
     }
 }
 
-__global__ void k_pose_adam(float* __restrict__ delta, float* __restrict__ m, float* __restrict__ v, const float* __restrict__ d_xf,
-                            const float* __restrict__ base, float* __restrict__ xf_out, float lr, float b1, float b2, float eps,
-                            float bc1, float bc2_sqrt, int do_step)
+// One 64-lane wave; lanes 0..11 evaluate the twelve perturbed exponential maps of the central differences side by side (a
+// float64 sin / cos pair is a few hundred instructions: 13 maps in ONE lane took 33 us, the dependent chain of every step)
+__device__ inline void pose_grad_and_adam(double* d /*6, lane-uniform copy*/, const double* Bp, const double* G /*12*/, float* __restrict__ delta,
+                                          float* __restrict__ m, float* __restrict__ v, float lr, float b1, float b2, float eps, float bc1,
+                                          float bc2_sqrt, double (*s_M)[12], float* s_g)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    double d[6], B[12], M[12];
+    const int lane = threadIdx.x;
+    const double h = 1e-6;
+    if (lane < 12) {
+        double dd[6];
+        for (int k = 0; k < 6; k++) dd[k] = d[k];
+        dd[lane >> 1] += (lane & 1) ? -h : h;
+        se3_exp_times(dd, Bp, s_M[lane]);
+    }
+    __syncthreads();
+    if (lane < 6) {
+        double acc = 0.0;
+        for (int q = 0; q < 12; q++) acc += G[q] * (s_M[2 * lane][q] - s_M[2 * lane + 1][q]) / (2.0 * h);
+        const float g = (float)acc;
+        const float mk = b1 * m[lane] + (1.f - b1) * g;          // torch.optim.Adam, single tensor, float32
+        const float vk = b2 * v[lane] + (1.f - b2) * g * g;
+        m[lane] = mk; v[lane] = vk;
+        const float denom = sqrtf(vk) / bc2_sqrt + eps;
+        const float p = delta[lane] - (lr / bc1) * (mk / denom);
+        delta[lane] = p;
+        s_g[lane] = p;
+    }
+    __syncthreads();
+    for (int k = 0; k < 6; k++) d[k] = (double)s_g[k];
+}
+
+__global__ __launch_bounds__(64) void k_pose_adam(float* __restrict__ delta, float* __restrict__ m, float* __restrict__ v,
+                                                   const float* __restrict__ d_xf, const float* __restrict__ base, float* __restrict__ xf_out,
+                                                   float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt, int do_step)
+{
+    __shared__ double s_M[12][12];
+    __shared__ float s_g[6];
+    double d[6], B[12], G[12];
     for (int k = 0; k < 6; k++) d[k] = (double)delta[k];
     if (base) for (int q = 0; q < 12; q++) B[q] = (double)base[q];
     const double* Bp = base ? B : nullptr;
+    __syncthreads();      // every lane has read delta before lanes 0..5 overwrite it
     if (do_step) {
-        float g[6];
-        const double h = 1e-6;
-        for (int k = 0; k < 6; k++) {
-            double Mp[12], Mm[12];
-            const double keep = d[k];
-            d[k] = keep + h; se3_exp_times(d, Bp, Mp);
-            d[k] = keep - h; se3_exp_times(d, Bp, Mm);
-            d[k] = keep;
-            double acc = 0.0;
-            for (int q = 0; q < 12; q++) acc += (double)d_xf[q] * (Mp[q] - Mm[q]) / (2.0 * h);
-            g[k] = (float)acc;
-        }
-        for (int k = 0; k < 6; k++) {   // torch.optim.Adam, single tensor, float32
-            const float mk = b1 * m[k] + (1.f - b1) * g[k];
-            const float vk = b2 * v[k] + (1.f - b2) * g[k] * g[k];
-            m[k] = mk; v[k] = vk;
-            const float denom = sqrtf(vk) / bc2_sqrt + eps;
-            const float p = delta[k] - (lr / bc1) * (mk / denom);
-            delta[k] = p;
-            d[k] = (double)p;
-        }
+        for (int q = 0; q < 12; q++) G[q] = (double)d_xf[q];
+        pose_grad_and_adam(d, Bp, G, delta, m, v, lr, b1, b2, eps, bc1, bc2_sqrt, s_M, s_g);
     }
-    se3_exp_times(d, Bp, M);
-    for (int q = 0; q < 12; q++) xf_out[q] = (float)M[q];
+    if (threadIdx.x == 0) {
+        double M[12];
+        se3_exp_times(d, Bp, M);
+        for (int q = 0; q < 12; q++) xf_out[q] = (float)M[q];
+    }
 }
 
 }  // namespace gsr
@@ -184,17 +201,21 @@ extern "C" int gsr_pose_step(float* delta6, float* exp_avg6, float* exp_avg_sq6,
 // ------------------------------------------------------------------------------------------------
 namespace gsr {
 
-__global__ void k_pose_adam_camera(float* __restrict__ delta, float* __restrict__ m, float* __restrict__ v, const float* __restrict__ d_vm,
-                                   const float* __restrict__ d_pm, const float* __restrict__ d_cp, const float* __restrict__ projT,
-                                   const float* __restrict__ base, float* __restrict__ vm, float* __restrict__ pm, float* __restrict__ cp,
-                                   float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt, int do_step)
+__global__ __launch_bounds__(64) void k_pose_adam_camera(float* __restrict__ delta, float* __restrict__ m, float* __restrict__ v,
+                                                          const float* __restrict__ d_vm, const float* __restrict__ d_pm,
+                                                          const float* __restrict__ d_cp, const float* __restrict__ projT,
+                                                          const float* __restrict__ base, float* __restrict__ vm, float* __restrict__ pm,
+                                                          float* __restrict__ cp, float lr, float b1, float b2, float eps, float bc1,
+                                                          float bc2_sqrt, int do_step)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    __shared__ double s_M[12][12];
+    __shared__ float s_g[6];
     double d[6], B[12], M[12], Pt[16];
     for (int k = 0; k < 6; k++) d[k] = (double)delta[k];
     if (base) for (int q = 0; q < 12; q++) B[q] = (double)base[q];
     for (int q = 0; q < 16; q++) Pt[q] = (double)projT[q];
     const double* Bp = base ? B : nullptr;
+    __syncthreads();
     if (do_step) {
         se3_exp_times(d, Bp, M);
         // dL/dV_total = dV + dF Pt^T ;  dL/dM[i][j] = dL/dV_total[j][i]  (V = M^T)
@@ -212,28 +233,9 @@ __global__ void k_pose_adam_camera(float* __restrict__ delta, float* __restrict_
                 G[4 * i + 3] += gt;
             }
         }
-        float g[6];
-        const double h = 1e-6;
-        for (int k = 0; k < 6; k++) {
-            double Mp[12], Mm[12];
-            const double keep = d[k];
-            d[k] = keep + h; se3_exp_times(d, Bp, Mp);
-            d[k] = keep - h; se3_exp_times(d, Bp, Mm);
-            d[k] = keep;
-            double acc = 0.0;
-            for (int q = 0; q < 12; q++) acc += G[q] * (Mp[q] - Mm[q]) / (2.0 * h);
-            g[k] = (float)acc;
-        }
-        for (int k = 0; k < 6; k++) {
-            const float mk = b1 * m[k] + (1.f - b1) * g[k];
-            const float vk = b2 * v[k] + (1.f - b2) * g[k] * g[k];
-            m[k] = mk; v[k] = vk;
-            const float denom = sqrtf(vk) / bc2_sqrt + eps;
-            const float p = delta[k] - (lr / bc1) * (mk / denom);
-            delta[k] = p;
-            d[k] = (double)p;
-        }
+        pose_grad_and_adam(d, Bp, G, delta, m, v, lr, b1, b2, eps, bc1, bc2_sqrt, s_M, s_g);
     }
+    if (threadIdx.x != 0) return;
     se3_exp_times(d, Bp, M);
     double V[16];
     for (int i = 0; i < 4; i++)
