@@ -148,7 +148,17 @@ class RankRunner:
 
     # ---- helpers ---------------------------------------------------------------------------------------------------
     def _settings(self, seg: Segment, f: int):
-        return self.seq.settings_for_pose(seg.poses[f])
+        """Raster settings of frame f under the segment's current pose of it -- built once per (frame, pose): a draw of a frame
+        that was drawn before reuses the device tensors (building them is CPU matrix work + four host-to-device copies, a
+        quarter of a leaf's wall time when done per draw)."""
+        cache = seg.__dict__.setdefault("_settings_cache", {})
+        pose = seg.poses[f]
+        hit = cache.get(f)
+        if hit is not None and hit[0] is pose:
+            return hit[1]
+        st = self.seq.settings_for_pose(pose)
+        cache[f] = (pose, st)
+        return st
 
     def _importance_views(self, seg: Segment):
         fr = seg.frames
