@@ -89,6 +89,7 @@ class HTConfig:
     seed: int = 0
     optimizer: str = "hip"
     fused: bool = True
+    stage_a_concurrency: int = 2                # frame pairs fitted at the same time per GPU (streams + host threads), stage_a.run_stage_a
     fit_pose: bool = False                      # refine each frame's pose while training on it (training_setup(fit_pose=True), :733)
     pose_lr: float = 1e-5                       # Adam with eps 1e-15 moves a pose by ~lr per step whatever the gradient: on these
                                                 # frames (1-2 px of motion per frame) 5e-6..2e-5 gains 0.4-0.6 dB over fixed stage-A
@@ -340,9 +341,15 @@ def run_stage_a_on(seq, cfg, dev, spec, rank: int, world: int, group=None, log=N
     with the full pose table and adopts it.  Returns the report record."""
     n_points, image_iters, pose_iters = spec
     t0 = time.perf_counter()
+    mine = stage_a.pairs_of_rank(cfg.frames, rank, world)
+    for f in sorted({q for p in mine for q in (p, p + 1)}):      # targets / depths rendered once, on the main stream, before the workers start
+        seq.target(f)
+    for p in mine:
+        seq.depth(p)
     table = stage_a.run_stage_a(cfg.frames, lambda p: stage_a.fit_pair(seq, p, dev, n_points=n_points, single_image_iters=image_iters,
                                                                         pose_iters=pose_iters, seed=cfg.seed),
-                                gather_device or dev, rank=rank, world=world, group=group)
+                                gather_device or dev, rank=rank, world=world, group=group, concurrency=cfg.stage_a_concurrency,
+                                fit_device=dev)
     if dev.type == "cuda":
         torch.cuda.synchronize(dev)
     err = max(float((table[f"rel_pose_{p}_to_{p + 1}"].cpu() - seq.true_rel_pose(p, p + 1)).abs().max()) for p in range(cfg.frames - 1))

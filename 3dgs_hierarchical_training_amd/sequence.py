@@ -101,11 +101,15 @@ class FrameSequence:
     def depth(self, f: int) -> torch.Tensor:
         """Expected depth map of frame f, [H, W] (stands in for the monocular depth the reference predicts per frame)."""
         from . import train_step as ts
+        cache = self.__dict__.setdefault("_depths", {})
+        if f in cache:
+            return cache[f]
         if self._gt_params is None:
             self._gt_params = ts.GaussianParams(self.gt_scene, self.device, optimizer="torch")
         with torch.no_grad():
             pkg = ts.render(self._gt_params, self.settings_for_pose(self.w2c[f]))
-            return (pkg["depth"][0] / pkg["alpha"][0].clamp_min(1e-3)).clone()
+            cache[f] = (pkg["depth"][0] / pkg["alpha"][0].clamp_min(1e-3)).clone()
+        return cache[f]
 
     def pixel_scene(self, f: int, stride: int = 2, seed: int = 0, depth_noise: float = 0.02) -> Dict:
         """One Gaussian per `stride`-th pixel of frame f, un-projected with the frame's depth into that frame's camera

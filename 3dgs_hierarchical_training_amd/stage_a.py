@@ -60,14 +60,41 @@ def pose_dict_from_table(table: torch.Tensor, vfi: bool = False) -> Dict[str, to
 
 
 def run_stage_a(n_frames: int, fit_fn: Callable[[int], torch.Tensor], device, rank: Optional[int] = None,
-                world: Optional[int] = None, group=None, vfi: bool = False) -> Dict[str, torch.Tensor]:
-    """fit_fn(p) -> [4,4] (or [3,4,4]) relative pose(s) of pair p.  Every rank returns the complete pose_dict."""
+                world: Optional[int] = None, group=None, vfi: bool = False, concurrency: int = 1,
+                fit_device=None) -> Dict[str, torch.Tensor]:
+    """fit_fn(p) -> [4,4] (or [3,4,4]) relative pose(s) of pair p.  Every rank returns the complete pose_dict.
+
+    concurrency > 1 (with fit_device = the GPU the fits run on): that many of this rank's pairs are fitted at the same time, each on
+    a HIP stream and a host thread of its own.  A single-image model of ~130 k Gaussians does not fill an MI355X -- its sorts are
+    latency chains of a few dozen workgroups, its blends run 17 waves per CU -- and two independent fits interleave on the device:
+    0.338 -> 0.262 ms per iteration and pair (tools/two_streams_probe.py; three or four gain nothing more, the Python of the
+    loops then takes turns on the interpreter lock)."""
     if world is None:
         world = dist.get_world_size(group) if dist.is_initialized() else 1
         rank = dist.get_rank(group) if dist.is_initialized() else 0
+    mine = pairs_of_rank(n_frames, rank, world)
+    if concurrency > 1 and fit_device is not None and torch.device(fit_device).type == "cuda" and len(mine) > 1:
+        import threading
+        from concurrent.futures import ThreadPoolExecutor
+        fdev = torch.device(fit_device)
+        main = torch.cuda.current_stream(fdev)
+        tls = threading.local()
+
+        def work(p):
+            if not hasattr(tls, "stream"):
+                tls.stream = torch.cuda.Stream(fdev)
+                tls.stream.wait_stream(main)          # what the main stream produced so far (targets, ...) is visible
+            with torch.cuda.stream(tls.stream):
+                r = fit_fn(p)
+                tls.stream.synchronize()
+            return p, r
+        with ThreadPoolExecutor(max_workers=concurrency) as ex:
+            results = dict(ex.map(work, mine))
+    else:
+        results = {p: fit_fn(p) for p in mine}
     local = {}
-    for p in pairs_of_rank(n_frames, rank, world):
-        r = fit_fn(p)
+    for p in mine:
+        r = results[p]
         if r.dim() == 2:
             eye = torch.eye(4, dtype=r.dtype, device=r.device)
             r = torch.stack((r, eye, eye))
