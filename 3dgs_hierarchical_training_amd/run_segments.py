@@ -346,17 +346,21 @@ def run_stage_a_on(seq, cfg, dev, spec, rank: int, world: int, group=None, log=N
         seq.target(f)
     for p in mine:
         seq.depth(p)
+    # concurrent fits per GPU, as far as the host allows: every fitting thread keeps about one CPU busy (launching, polling for the
+    # instance count), and the ranks of a node share the container's CPU quota
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", "1" if world == 1 else str(world)))
+    conc = max(1, min(cfg.stage_a_concurrency, host_mod.usable_cpus()[0] // (2 * max(1, local_world))))
     table = stage_a.run_stage_a(cfg.frames, lambda p: stage_a.fit_pair(seq, p, dev, n_points=n_points, single_image_iters=image_iters,
                                                                         pose_iters=pose_iters, seed=cfg.seed),
-                                gather_device or dev, rank=rank, world=world, group=group, concurrency=cfg.stage_a_concurrency,
-                                fit_device=dev)
+                                gather_device or dev, rank=rank, world=world, group=group, concurrency=conc, fit_device=dev)
     if dev.type == "cuda":
         torch.cuda.synchronize(dev)
     err = max(float((table[f"rel_pose_{p}_to_{p + 1}"].cpu() - seq.true_rel_pose(p, p + 1)).abs().max()) for p in range(cfg.frames - 1))
     ident = max(float((torch.eye(4) - seq.true_rel_pose(p, p + 1)).abs().max()) for p in range(cfg.frames - 1))
     seq.use_pose_table(table)
     rec = {"rank": rank, "phase": "stage_a", "pairs_total": cfg.frames - 1, "pairs_here": len(stage_a.pairs_of_rank(cfg.frames, rank, world)),
-           "gaussians": n_points, "image_iters": image_iters, "pose_iters": pose_iters, "ms": 1e3 * (time.perf_counter() - t0),
+           "gaussians": n_points, "image_iters": image_iters, "pose_iters": pose_iters, "pairs_at_a_time": conc,
+           "ms": 1e3 * (time.perf_counter() - t0),
            "max_abs_pose_error": err, "identity_guess_error": ident}
     (log or emit_line)(rec)
     return rec
