@@ -17,6 +17,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <map>
 #include <mutex>
@@ -2228,6 +2229,15 @@ static int g_bwd_split = 16; // workgroups a long tile's backward is split over 
 static int g_ckpt_first = 1;  // 128-instance batches of a tile before the forward starts leaving checkpoints
 static int g_tile_map = 2;   // tile -> XCD map: 2 = 2x2 tile blocks interleaved (default), 1 = tiles interleaved, 0 = banded
 static std::atomic<long long> g_spec_overflows{0}, g_spec_forwards{0}, g_exact_forwards{0};
+// host-side time accounting of the two entry points (gsr_get_counter): wall time inside the call, and the part of the forward
+// spent waiting for the instance count -- their difference is what the launching thread really works per call
+static std::atomic<long long> g_fwd_calls{0}, g_fwd_ns{0}, g_fwd_wait_ns{0}, g_bwd_calls{0}, g_bwd_ns{0};
+struct CallTimer {
+    std::atomic<long long>&calls, &ns;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    CallTimer(std::atomic<long long>& c, std::atomic<long long>& n) : calls(c), ns(n) {}
+    ~CallTimer() { calls++; ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); }
+};
 
 static int n_bucket(int N) { return N > 0 ? (int)std::floor(2.0 * std::log2((double)N)) : 0; }
 
@@ -2368,6 +2378,7 @@ int gsr_set_option(const char* name, int value)
 
 int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
 {
+    CallTimer call_timer(g_fwd_calls, g_fwd_ns);
     hipStream_t st = (hipStream_t)stream_;
     if (!a || !out) return fail(GSR_ERR_ARG, "null args%s");
     int rc = check_common(a->N, a->M, a->D, a->W, a->H);
@@ -2617,6 +2628,7 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
         // the event -- a barrier packet + completion signal behind the kernel, several us later -- when the device is far
         // behind (the poll is bounded to ~1 ms of busy waiting) or has faulted (the event reports it).
         {
+            const auto w0 = std::chrono::steady_clock::now();
             volatile unsigned long long* hp = pin.s->host;
             const unsigned long long want = pin.s->seq;
             bool seen = false;
@@ -2624,10 +2636,13 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
                 for (int it = 0; it < g_poll_iters && !(seen = (hp[1] == want)); it++) cpu_relax();
             if (!seen) GSR_HIP(hipEventSynchronize(pin.s->ev));
             std::atomic_thread_fence(std::memory_order_acquire);
+            g_fwd_wait_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - w0).count();
         }
         g_spec_forwards++;
     } else {
+        const auto w0 = std::chrono::steady_clock::now();
         GSR_HIP(hipStreamSynchronize(st));
+        g_fwd_wait_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - w0).count();
         g_exact_forwards++;
     }
     R = *static_cast<volatile unsigned long long*>(pin.s->host);
@@ -2660,6 +2675,7 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
 
 int gsr_backward(const GsrBackwardArgs* a, void* stream_)
 {
+    CallTimer call_timer(g_bwd_calls, g_bwd_ns);
     hipStream_t st = (hipStream_t)stream_;
     if (!a) return fail(GSR_ERR_ARG, "null args%s");
     int rc = check_common(a->N, a->M, a->D, a->W, a->H);
@@ -2853,6 +2869,11 @@ int64_t gsr_get_counter(const char* name)
     if (!strcmp(name, "spec_overflows")) return g_spec_overflows.load();
     if (!strcmp(name, "spec_forwards")) return g_spec_forwards.load();
     if (!strcmp(name, "exact_forwards")) return g_exact_forwards.load();
+    if (!strcmp(name, "forward_calls")) return g_fwd_calls.load();
+    if (!strcmp(name, "forward_ns")) return g_fwd_ns.load();
+    if (!strcmp(name, "forward_wait_ns")) return g_fwd_wait_ns.load();
+    if (!strcmp(name, "backward_calls")) return g_bwd_calls.load();
+    if (!strcmp(name, "backward_ns")) return g_bwd_ns.load();
     if (!strcmp(name, "spec_callers")) { std::lock_guard<std::mutex> lk(g_state_mutex); return (int64_t)g_hints.size(); }
     return -1;
 }

@@ -457,6 +457,7 @@ def main():
     lib.gsr_set_option(b"profile", 2)
     read_profile(lib, STAGES)  # drop anything recorded so far
     sync_all()
+    c0 = {k: lib.gsr_get_counter(k.encode()) for k in ("forward_calls", "forward_ns", "forward_wait_ns", "backward_calls", "backward_ns")}
     t0 = time.perf_counter()
     stamps = [t0]
     for _ in range(args.steps):
@@ -464,6 +465,7 @@ def main():
         stamps.append(time.perf_counter())   # host clock only (each step already waits for the forward's instance count)
     sync_all()
     elapsed = time.perf_counter() - t0
+    c1 = {k: lib.gsr_get_counter(k.encode()) for k in c0}
     lib.gsr_set_option(b"profile", 0)
     prof_blend = read_profile(lib, ["blend_fwd"])["blend_fwd"]
     lib.gsr_set_option(b"profile", 1)
@@ -477,6 +479,14 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # host-side work of the library per forward + backward in the timed steps (counters of gsr_get_counter, read after them)
+    lib_host = None
+    if c1["forward_calls"] > c0["forward_calls"]:
+        nf, nbk = c1["forward_calls"] - c0["forward_calls"], max(1, c1["backward_calls"] - c0["backward_calls"])
+        lib_host = {"gsr_forward_us": 1e-3 * ((c1["forward_ns"] - c0["forward_ns"]) - (c1["forward_wait_ns"] - c0["forward_wait_ns"])) / nf,
+                    "gsr_forward_wait_us": 1e-3 * (c1["forward_wait_ns"] - c0["forward_wait_ns"]) / nf,
+                    "gsr_backward_us": 1e-3 * (c1["backward_ns"] - c0["backward_ns"]) / nbk}
 
     # R and R_eff of the final state (one extra forward outside the timed region)
     with torch.no_grad():
@@ -613,6 +623,10 @@ def main():
             res["host_us"] = host_leg(syn, ts, dev)
         except Exception as e:
             res["host_us"] = {"fwd_bwd_call_us": None, "error": repr(e)}
+        if lib_host is not None:      # the library's own accounting over the timed steps of the headline workload
+            res["host_us"]["timed_steps"] = dict(lib_host, note="wall time inside gsr_forward (minus its wait for the instance count) and "
+                                                 "gsr_backward per call in the timed steps: allocator callbacks + kernel launches; the "
+                                                 "PyTorch dispatcher / autograd / loss ops around them are not in it")
         try:
             res["dropin"] = dropin_leg(ts, scene, settings, gt, dev, steps=min(args.steps, 10), warmup=2)
         except Exception as e:

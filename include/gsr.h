@@ -231,7 +231,10 @@ int gsr_version(void);
 int gsr_set_option(const char* name, int value);
 /* Monotonic counters: "spec_forwards" (forwards launched against a capacity), "spec_overflows" (of those, how many had to
  * re-run the binning because R exceeded the capacity), "exact_forwards" (read-then-launch forwards), "spec_callers"
- * (distinct (device, size, N bucket) entries).  -1 for an unknown name. */
+ * (distinct (device, size, N bucket) entries); host-side time accounting: "forward_calls" / "forward_ns" (wall time inside
+ * gsr_forward) / "forward_wait_ns" (the part of it spent waiting for the instance count) and "backward_calls" / "backward_ns" --
+ * (forward_ns - forward_wait_ns + backward_ns) / calls is what the launching thread works per forward + backward.  -1 for an
+ * unknown name. */
 int64_t gsr_get_counter(const char* name);
 /* Debug / test hook: copy the per-tile ranges (T x {begin, end} uint32) and the (tile, depth, id)-ordered Gaussian-id list
  * (num_rendered uint32) out of a forward's binning buffer into device buffers of the caller (either may be NULL). */
