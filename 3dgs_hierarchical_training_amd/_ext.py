@@ -85,6 +85,10 @@ def _register_fakes():
         C, H, W = render.shape
         return render.new_empty((3,), dtype=torch.float32), render.new_empty((lib.gsr_loss_workspace_bytes(int(C), int(H), int(W)),), dtype=torch.uint8)
 
+    @torch.library.register_fake("gsr::photometric_loss")
+    def _(render, target, lambda_dssim, clamp):
+        return render.new_empty((), dtype=torch.float32)
+
     @torch.library.register_fake("gsr::photometric_loss_backward")
     def _(render, target, workspace, grad_loss, lambda_dssim, clamp):
         return torch.empty_like(render, dtype=torch.float32)

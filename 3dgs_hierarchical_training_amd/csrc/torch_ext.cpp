@@ -450,6 +450,35 @@ void adam_step(at::TensorList params, at::TensorList grads, at::TensorList exp_a
     }
 }
 
+// The loss with its autograd node in C++ (one dispatcher call in the forward, no Python frame in the backward)
+class PhotometricLossFn : public torch::autograd::Function<PhotometricLossFn> {
+   public:
+    static Tensor forward(torch::autograd::AutogradContext* ctx, const Tensor& render, const Tensor& target, double lambda_dssim, bool clamp)
+    {
+        static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("gsr::photometric_loss_forward", "").typed<decltype(photometric_loss_forward)>();
+        const Tensor r = f32c(render), t = f32c(target.device() == render.device() ? target : target.to(render.device()));
+        auto out = op.call(r, t, lambda_dssim, clamp);
+        ctx->save_for_backward({r, t, std::get<1>(out)});
+        ctx->saved_data["lam"] = lambda_dssim; ctx->saved_data["clamp"] = clamp;
+        return std::get<0>(out).select(0, 0);
+    }
+    static torch::autograd::variable_list backward(torch::autograd::AutogradContext* ctx, torch::autograd::variable_list g)
+    {
+        static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("gsr::photometric_loss_backward", "").typed<decltype(photometric_loss_backward)>();
+        auto sv = ctx->get_saved_variables();
+        Tensor d = op.call(sv[0], sv[1], sv[2], g[0], ctx->saved_data["lam"].toDouble(), ctx->saved_data["clamp"].toBool());
+        return {d, Tensor(), Tensor(), Tensor()};
+    }
+};
+Tensor photometric_loss(const Tensor& render, const Tensor& target, double lambda_dssim, bool clamp)
+{
+    return PhotometricLossFn::apply(render, target, lambda_dssim, clamp);
+}
+Tensor photometric_loss_no_grad(const Tensor& render, const Tensor& target, double lambda_dssim, bool clamp)
+{
+    return std::get<0>(photometric_loss_forward(render, target.device() == render.device() ? target : target.to(render.device()), lambda_dssim, clamp)).select(0, 0);
+}
+
 // Pose step of stage A: delta / exp_avg / exp_avg_sq ([6] float32) updated in place from dL/dM, the new M = Exp(delta) * base written
 // into `xf` ([3,4] or [4,4] float32, rows 0..2) -- the tensor the next render reads as points_transform.  step = 0: only evaluates M.
 void pose_step(Tensor delta, Tensor exp_avg, Tensor exp_avg_sq, const Tensor& d_xf, const Tensor& base, Tensor xf, double lr,
@@ -530,6 +559,7 @@ TORCH_LIBRARY(gsr, m)
     m.def("mark_visible(Tensor means3D, Tensor viewmatrix, Tensor projmatrix) -> Tensor");
     m.def("photometric_loss_forward(Tensor render, Tensor target, float lambda_dssim, bool clamp) -> (Tensor, Tensor)");
     m.def("photometric_loss_backward(Tensor render, Tensor target, Tensor workspace, Tensor grad_loss, float lambda_dssim, bool clamp) -> Tensor");
+    m.def("photometric_loss(Tensor render, Tensor target, float lambda_dssim, bool clamp) -> Tensor");
     m.def("adam_step(Tensor(a!)[] params, Tensor[] grads, Tensor(b!)[] exp_avg, Tensor(c!)[] exp_avg_sq, float[] lr, float beta1, "
           "float beta2, float eps, int step) -> ()");
     m.def("pose_step(Tensor(a!) delta, Tensor(b!) exp_avg, Tensor(c!) exp_avg_sq, Tensor d_xf, Tensor base, Tensor(d!) xf, float lr, "
@@ -554,6 +584,11 @@ TORCH_LIBRARY_IMPL(gsr, CUDA, m)   // the dispatch key of HIP tensors on a ROCm 
     m.impl("pose_step_camera", &pose_step_camera);
     m.impl("knn_mean_dist2", &knn_mean_dist2);
     m.impl("rasterize", &rasterize_forward_only);
+    m.impl("photometric_loss", &photometric_loss_no_grad);
 }
 
-TORCH_LIBRARY_IMPL(gsr, Autograd, m) { m.impl("rasterize", &rasterize); }
+TORCH_LIBRARY_IMPL(gsr, Autograd, m)
+{
+    m.impl("rasterize", &rasterize);
+    m.impl("photometric_loss", &photometric_loss);
+}

@@ -32,5 +32,11 @@ class _FusedPhotometricLoss(torch.autograd.Function):
 
 def fused_photometric_loss(render: torch.Tensor, target: torch.Tensor, lambda_dssim: float = 0.2,
                            clamp: bool = True) -> torch.Tensor:
-    """render: raw rasterizer colour [3,H,W] (clamped to [0,1] inside when clamp=True); target [3,H,W]."""
-    return _FusedPhotometricLoss.apply(render, target, lambda_dssim, clamp)
+    """render: raw rasterizer colour [3,H,W] (clamped to [0,1] inside when clamp=True); target [3,H,W].
+    One dispatcher call; the autograd node lives in the extension (csrc/torch_ext.cpp PhotometricLossFn) -- the Python
+    autograd.Function above states the same thing and serves the plain-FFI binding route."""
+    if render.device.type != "cuda":
+        raise RuntimeError("fused_photometric_loss: tensors must be on a ROCm/HIP device (no CPU fallback)")
+    if E.use_ctypes():
+        return _FusedPhotometricLoss.apply(render, target, lambda_dssim, clamp)
+    return E.load().photometric_loss(render, target, float(lambda_dssim), bool(clamp))

@@ -25,6 +25,10 @@ from . import _ext as E
 from . import _lib as L
 
 
+def c_len(opt) -> int:
+    return getattr(opt, "_plan_groups", -1)
+
+
 def _step_int(v) -> int:
     return int(v.item()) if torch.is_tensor(v) else int(v)
 
@@ -121,6 +125,25 @@ class FusedAdam:
         """(exp_avg[6], exp_avg_sq[6], lr[6], beta1, beta2, eps, step) for the optimizer-in-backward mode of gsr_backward:
         counts as this optimizer's next step.  `tensors` are the parameter tensors being rasterized, by group name; they
         must be the optimizer's own."""
+        # fast path: nothing was rebuilt since the previous step (same group dicts, parameter / moment tensors, state entries):
+        # the checks below were all made then -- only the step count and the learning rates are taken anew
+        c = getattr(self, "_plan_cache", None)
+        if c is not None:
+            groups, ps, ts_, sts, ms, vs, idx = c
+            ok = len(self.param_groups) == c_len(self)
+            for k in range(6 if ok else 0):
+                g, st = groups[k], sts[k]
+                if self.param_groups[idx[k]] is not g or g["params"][0] is not ps[k] or tensors[self.FUSED_ORDER[k]] is not ts_[k] or self.state.get(ps[k]) is not st \
+                        or st.get("exp_avg") is not ms[k] or st.get("exp_avg_sq") is not vs[k] or st.get("step") != sts[0].get("step"):
+                    ok = False
+                    break
+            if ok:
+                step = _step_int(sts[0]["step"]) + 1
+                for st in sts:
+                    st["step"] = step
+                self._stepped_in_backward = True
+                return (ms, vs, [float(g["lr"]) for g in groups], float(self.betas[0]), float(self.betas[1]), float(self.eps), step)
+            self._plan_cache = None
         by_name = {g.get("name"): g for g in self.param_groups}
         if set(by_name) != set(self.FUSED_ORDER):
             raise RuntimeError(f"fused_adam: optimizer groups must be named {self.FUSED_ORDER}, got {tuple(by_name)}")
@@ -141,8 +164,12 @@ class FusedAdam:
         for st in states:
             st["step"] = int(step)
         self._stepped_in_backward = True
-        return ([st["exp_avg"] for st in states], [st["exp_avg_sq"] for st in states], lrs, float(self.betas[0]),
-                float(self.betas[1]), float(self.eps), int(step))
+        ms, vs = [st["exp_avg"] for st in states], [st["exp_avg_sq"] for st in states]
+        groups = [by_name[name] for name in self.FUSED_ORDER]
+        self._plan_cache = (groups, [g["params"][0] for g in groups], [tensors[name] for name in self.FUSED_ORDER], states, ms, vs,
+                            [next(i for i, x in enumerate(self.param_groups) if x is g) for g in groups])
+        self._plan_groups = len(self.param_groups)
+        return (ms, vs, lrs, float(self.betas[0]), float(self.betas[1]), float(self.eps), int(step))
 
     def fused_backward_args(self, tensors: Dict[str, torch.Tensor]) -> "L.GsrFusedAdam":
         """The same plan as a GsrFusedAdam struct (ctypes binding)."""
