@@ -54,7 +54,7 @@ def _register_fakes():
     def _(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, sh_rest, viewmatrix, projmatrix, campos,
           bg, points_transform, image_height, image_width, tanfovx, tanfovy, scale_modifier, sh_degree, raw_params, prefiltered, debug,
           cam_grad, adam_m, adam_v, adam_lr, beta1, beta2, eps, step, prepared, next_viewmatrix, next_projmatrix, next_campos,
-          next_height, next_width, next_tanfovx, next_tanfovy, next_points_transform):
+          next_height, next_width, next_tanfovx, next_tanfovy, next_points_transform, next_sh_degree, adam_commit):
         N, H, W = means3D.shape[0], image_height, image_width
         f = lambda *s: means3D.new_empty(s, dtype=torch.float32)
         nprep = lib.gsr_prepared_bytes(int(N)) if next_viewmatrix.numel() else 0
@@ -75,6 +75,31 @@ def _register_fakes():
                 f(N, M - 1, 3) if (has(sh) and has(sh_rest)) else none, f(4, 4) if need_viewmatrix else none,
                 f(4, 4) if need_projmatrix else none, f(3) if need_campos else none,
                 f(3, 4) if (need_points_transform and has(points_transform)) else none]
+
+    @torch.library.register_fake("gsr::rasterize_backward_fused")
+    def _(means3D, sh, sh_rest, opacities, scales, rotations, viewmatrix, projmatrix, campos, bg, points_transform, geom, image, binning,
+          meta, grad_color, grad_depth, grad_alpha, image_height, image_width, tanfovx, tanfovy, scale_modifier, sh_degree,
+          need_viewmatrix, need_projmatrix, need_campos, need_points_transform, adam_m, adam_v, adam_lr, beta1, beta2, eps, step,
+          next_viewmatrix, next_projmatrix, next_campos, next_height, next_width, next_tanfovx, next_tanfovy, prepared_out,
+          next_points_transform, next_sh_degree):
+        f = lambda *s: means3D.new_empty(s, dtype=torch.float32)
+        none = f(0)
+        return [f(means3D.shape[0], 3), f(4, 4) if need_viewmatrix else none, f(4, 4) if need_projmatrix else none,
+                f(3) if need_campos else none, f(3, 4) if (need_points_transform and points_transform.numel() > 0) else none]
+
+    # in-place ops without a return value: nothing to describe beyond the schema's (a!) annotations
+    @torch.library.register_fake("gsr::adam_step")
+    def _(params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step):
+        return None
+
+    @torch.library.register_fake("gsr::pose_step")
+    def _(delta, exp_avg, exp_avg_sq, d_xf, base, xf, lr, beta1, beta2, eps, step):
+        return None
+
+    @torch.library.register_fake("gsr::pose_step_camera")
+    def _(delta, exp_avg, exp_avg_sq, d_viewmatrix, d_projmatrix, d_campos, projection_T, base, viewmatrix, projmatrix, campos, lr,
+          beta1, beta2, eps, step):
+        return None
 
     @torch.library.register_fake("gsr::mark_visible")
     def _(means3D, viewmatrix, projmatrix):

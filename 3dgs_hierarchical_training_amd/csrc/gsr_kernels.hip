@@ -1760,7 +1760,10 @@ constexpr int kCamVals = 47;   // viewmatrix 16 + projmatrix 16 + campos 3 + poi
 // ADAM = true (needs RAW, shs + shs_rest, no cov_pre): optimizer-in-backward, see GsrFusedAdam in include/gsr.h.  The
 // parameter pointers are then read AND written by the block that owns the rows (no __restrict__ promises on them).
 
-template <int DEG, bool RAW, bool CAM, bool ADAM, bool PREP>
+// PREP >= 0 (with ADAM): "prepare in backward" -- the block also runs the NEXT render's preprocess, at SH degree PREP (the degree
+// this render used, or one above it: `oneupSHdegree` between two steps, /root/reference/scene/gaussian_model_ht.py:193-195), on the
+// parameters it has just updated.  -1 = off.
+template <int DEG, bool RAW, bool CAM, bool ADAM, int PREP>
 __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, int N, const float* means,
                                                                 const float* scales, const float* rots,
                                                                 const float* __restrict__ cov_pre, const float* shs,
@@ -1791,16 +1794,20 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, in
 #pragma unroll
         for (int q = 0; q < 12; q++) xg[q] = 0.f;
     }
-    // linear tiles (see stage_in_lin): split storage, every stored coefficient active, aligned full rows
-    constexpr int NRL = NC3 > 3 ? NC3 - 3 : 1;
-    constexpr bool kLinOk = NC3 > 3 && (NRL & 1);
+    // linear tiles (see stage_in_lin): split storage of a 16-coefficient model (max_sh_degree 3, what the reference trains),
+    // aligned rows.  The tile holds the FULL stored rows (3 + 45 floats per Gaussian) at every active degree: the reference
+    // starts every model at active_sh_degree 0 with all 16 coefficients stored and steps the degree up once per 1 000 iterations
+    // (/root/reference/scene/gaussian_model_ht.py:68,193-195; its stage-A models never leave degree 0), so bands above the active
+    // degree get a zero gradient in the tile and stream through the same Adam update as the active ones (dense Adam: their
+    // moments still decay).  Degree 0 reads none of the rest rows here -- the optimizer stream is their only reader.
+    constexpr int NRL = 45;
     float* s_dc = s_sh;
     float* s_rest = s_sh + kPreThreads * 3;
-    const bool lin = kLinOk && shs && shs_rest && (cp.M - 1) * 3 == NRL && vec_ok(shs + (size_t)base * 3, nG * 3) &&
+    const bool lin = shs && shs_rest && cp.M == 16 && vec_ok(shs + (size_t)base * 3, nG * 3) &&
                      vec_ok(shs_rest + (size_t)base * NRL, nG * NRL);   // block-uniform
     if (lin) {
         stage_in_lin<3>(s_dc, shs + (size_t)base * 3, nG, tid);
-        stage_in_lin<NRL>(s_rest, shs_rest + (size_t)base * NRL, nG, tid);
+        if (DEG > 0) stage_in_lin<NRL>(s_rest, shs_rest + (size_t)base * NRL, nG, tid);
         __syncthreads();
     } else if (shs) {
         if (shs_rest) {
@@ -1913,10 +1920,10 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, in
         d_means2d[3 * (size_t)i] = m2d[0]; d_means2d[3 * (size_t)i + 1] = m2d[1]; d_means2d[3 * (size_t)i + 2] = 0.f;
         if (ADAM) {   // this thread is the only reader of its Gaussian's small rows, and it has read them
             const size_t gi = (size_t)i;
-            adam_own<3>(const_cast<float*>(means) + 3 * gi, ad.m[0] + 3 * gi, ad.v[0] + 3 * gi, dmean, ad.step_size[0], ad, PREP ? nmean : nullptr);
-            adam_own<1>(const_cast<float*>(opac_raw) + gi, ad.m[3] + gi, ad.v[3] + gi, &dop, ad.step_size[3], ad, PREP ? &nop : nullptr);
-            adam_own<3>(const_cast<float*>(scales) + 3 * gi, ad.m[4] + 3 * gi, ad.v[4] + 3 * gi, dsc, ad.step_size[4], ad, PREP ? nsc : nullptr);
-            adam_own<4>(const_cast<float*>(rots) + 4 * gi, ad.m[5] + 4 * gi, ad.v[5] + 4 * gi, drq, ad.step_size[5], ad, PREP ? nrq : nullptr);
+            adam_own<3>(const_cast<float*>(means) + 3 * gi, ad.m[0] + 3 * gi, ad.v[0] + 3 * gi, dmean, ad.step_size[0], ad, PREP >= 0 ? nmean : nullptr);
+            adam_own<1>(const_cast<float*>(opac_raw) + gi, ad.m[3] + gi, ad.v[3] + gi, &dop, ad.step_size[3], ad, PREP >= 0 ? &nop : nullptr);
+            adam_own<3>(const_cast<float*>(scales) + 3 * gi, ad.m[4] + 3 * gi, ad.v[4] + 3 * gi, dsc, ad.step_size[4], ad, PREP >= 0 ? nsc : nullptr);
+            adam_own<4>(const_cast<float*>(rots) + 4 * gi, ad.m[5] + 4 * gi, ad.v[5] + 4 * gi, drq, ad.step_size[5], ad, PREP >= 0 ? nrq : nullptr);
         } else {
 #pragma unroll
         for (int k = 0; k < 3; k++) d_means[3 * (size_t)i + k] = dmean[k];
@@ -1964,18 +1971,18 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, in
         const size_t b = (size_t)base;
         const int rrow = cp.M * 3 - 3;
         if (lin) {
-            adam_rows_lin<PREP>(s_dc, nG * 3, const_cast<float*>(shs) + b * 3, ad.m[1] + b * 3, ad.v[1] + b * 3, tid, ad.step_size[1], ad);
-            adam_rows_lin<PREP>(s_rest, nG * NRL, const_cast<float*>(shs_rest) + b * NRL, ad.m[2] + b * NRL, ad.v[2] + b * NRL, tid, ad.step_size[2], ad);
-            if (!PREP) return;
+            adam_rows_lin<(PREP >= 0)>(s_dc, nG * 3, const_cast<float*>(shs) + b * 3, ad.m[1] + b * 3, ad.v[1] + b * 3, tid, ad.step_size[1], ad);
+            adam_rows_lin<(PREP >= 0)>(s_rest, nG * NRL, const_cast<float*>(shs_rest) + b * NRL, ad.m[2] + b * NRL, ad.v[2] + b * NRL, tid, ad.step_size[2], ad);
+            if (PREP < 0) return;
             // ---- next-view tail ("prepare in backward", GsrNextView): this block holds the UPDATED parameters of its 128
             // Gaussians -- the small groups in the owners' registers, the SH rows in the LDS tile -- so it runs the forward
             // preprocess of the NEXT render on them right here: the next gsr_forward skips k_preprocess (no second read of the
             // 236 bytes per Gaussian, and ~2 400 VALU instructions per wave that hide under this kernel's HBM time).
-            // Same functions, same order of operations as k_preprocess<DEG, true>: the records are bit-identical.
+            // Same functions, same order of operations as k_preprocess<PREP, true>: the records are bit-identical.
             __syncthreads();
             const bool act = i < N;
             Camera cam2 = load_camera(po.cp);
-            cam2.D = DEG;
+            cam2.D = PREP < 0 ? 0 : PREP;
             Splat s2;
             TileRec rec2;
             float mean2[3] = {nmean[0], nmean[1], nmean[2]};
@@ -2341,7 +2348,7 @@ size_t gsr_backward_scratch_bytes(int32_t N)
 size_t gsr_sort_scratch_bytes(uint32_t n) { return radix_scratch_bytes(n); }
 size_t gsr_prepared_bytes(int32_t N) { return prep_layout(N).bytes; }
 size_t gsr_prepared_radii_offset(int32_t N) { return prep_layout(N).radii; }
-int gsr_prepare_supported(int32_t M, int32_t D, int32_t raw_params) { return (raw_params && M == 16 && D == 3) ? 1 : 0; }
+int gsr_prepare_supported(int32_t M, int32_t D, int32_t raw_params) { return (raw_params && M == 16 && D >= 0 && D <= 3) ? 1 : 0; }
 const char* gsr_last_error(void) { return g_err; }
 int gsr_version(void) { return 100; }
 
@@ -2788,9 +2795,11 @@ int gsr_backward(const GsrBackwardArgs* a, void* stream_)
     PrepOut po = {};
     const GsrNextView* nv = a->next_view;
     if (nv) {
-        if (!fa || !gsr_prepare_supported(a->M, a->D, a->raw_params) || nv->D != 3 || !a->prepared_out || !nv->viewmatrix || !nv->projmatrix ||
-            !nv->campos || nv->W <= 0 || nv->H <= 0 || ((((uintptr_t)a->shs | (uintptr_t)a->shs_rest) & 15) != 0))
-            return fail(GSR_ERR_ARG, "next_view needs fused_adam, raw_params, M = 16, D = 3, 16-byte aligned SH tensors and a prepared_out buffer%s");
+        if (!fa || !gsr_prepare_supported(a->M, a->D, a->raw_params) || nv->D < a->D || nv->D > a->D + 1 || nv->D > 3 || !a->prepared_out ||
+            !nv->viewmatrix || !nv->projmatrix || !nv->campos || nv->W <= 0 || nv->H <= 0 ||
+            ((((uintptr_t)a->shs | (uintptr_t)a->shs_rest) & 15) != 0))
+            return fail(GSR_ERR_ARG, "next_view needs fused_adam, raw_params, M = 16, a next degree equal to this render's or one above, "
+                                     "16-byte aligned SH tensors and a prepared_out buffer%s");
         const PrepLayout PL = prep_layout(N);
         uint8_t* pb = static_cast<uint8_t*>(a->prepared_out);
         po.cp = {nv->viewmatrix, nv->projmatrix, nv->campos, nv->tanfovx, nv->tanfovy, nv->scale_modifier, nv->W, nv->H, nv->D, a->M, nv->points_transform};
@@ -2815,22 +2824,39 @@ int gsr_backward(const GsrBackwardArgs* a, void* stream_)
                        cam_partial, po)
 #define GSR_PREB(DEG)                                                     \
     do {                                                                  \
-        if (fa) { if (want_cam) GSR_PREB_(DEG, true, true, true, false); else GSR_PREB_(DEG, true, false, true, false); }                 \
-        else if (a->raw_params) { if (want_cam) GSR_PREB_(DEG, true, true, false, false); else GSR_PREB_(DEG, true, false, false, false); }   \
-        else { if (want_cam) GSR_PREB_(DEG, false, true, false, false); else GSR_PREB_(DEG, false, false, false, false); }               \
+        if (fa) { if (want_cam) GSR_PREB_(DEG, true, true, true, -1); else GSR_PREB_(DEG, true, false, true, -1); }                 \
+        else if (a->raw_params) { if (want_cam) GSR_PREB_(DEG, true, true, false, -1); else GSR_PREB_(DEG, true, false, false, -1); }   \
+        else { if (want_cam) GSR_PREB_(DEG, false, true, false, -1); else GSR_PREB_(DEG, false, false, false, -1); }               \
     } while (0)
+#define GSR_PREB_NEXT(DEG, NDEG) do { if (want_cam) GSR_PREB_(DEG, true, true, true, NDEG); else GSR_PREB_(DEG, true, false, true, NDEG); } while (0)
+#define GSR_PRE_TAIL(NDEG)                                                                                                               \
+    hipLaunchKernelGGL((k_preprocess<NDEG, true>), dim3(1), dim3(kPreThreads), 0, st, po.cp, N, a->means3D, a->scales, a->rotations,       \
+                       (const float*)nullptr, a->opacities, a->shs, a->shs_rest, (const float*)nullptr, po.splat, po.radii, po.dkey,     \
+                       po.gid, po.rec, (uint32_t*)nullptr, 0, grid - 1, po.dh)
     {
         ProfScope ps(P_PRE_BWD, st);
-        if (nv) {   // D = 3 (checked above)
-            if (want_cam) GSR_PREB_(3, true, true, true, true); else GSR_PREB_(3, true, false, true, true);
+        if (nv) {   // (this render's degree, the next render's): equal, or one step up (checked above)
+            switch (a->D * 4 + nv->D) {
+                case 0: GSR_PREB_NEXT(0, 0); break;
+                case 1: GSR_PREB_NEXT(0, 1); break;
+                case 5: GSR_PREB_NEXT(1, 1); break;
+                case 6: GSR_PREB_NEXT(1, 2); break;
+                case 10: GSR_PREB_NEXT(2, 2); break;
+                case 11: GSR_PREB_NEXT(2, 3); break;
+                default: GSR_PREB_NEXT(3, 3); break;
+            }
             // a ragged last block whose rows do not form whole 16-byte vectors takes the kernel's general (non-linear) tile
             // path, which has no next-view tail: the ordinary preprocess runs on that one block, on the updated parameters
             const int nlast = N - (grid - 1) * kPreThreads;
             const bool last_lin = (nlast % 4) == 0;   // (the tensors' 16-byte alignment was checked above)
-            if (!last_lin)
-                hipLaunchKernelGGL((k_preprocess<3, true>), dim3(1), dim3(kPreThreads), 0, st, po.cp, N, a->means3D, a->scales, a->rotations,
-                                   (const float*)nullptr, a->opacities, a->shs, a->shs_rest, (const float*)nullptr, po.splat, po.radii, po.dkey,
-                                   po.gid, po.rec, (uint32_t*)nullptr, 0, grid - 1, po.dh);
+            if (!last_lin) {
+                switch (nv->D) {
+                    case 0: GSR_PRE_TAIL(0); break;
+                    case 1: GSR_PRE_TAIL(1); break;
+                    case 2: GSR_PRE_TAIL(2); break;
+                    default: GSR_PRE_TAIL(3); break;
+                }
+            }
         } else {
         switch (a->shs ? a->D : 0) {
             case 0: GSR_PREB(0); break;
@@ -2840,6 +2866,8 @@ int gsr_backward(const GsrBackwardArgs* a, void* stream_)
         }
         }
     }
+#undef GSR_PRE_TAIL
+#undef GSR_PREB_NEXT
 #undef GSR_PREB
 #undef GSR_PREB_
     if (want_cam)

@@ -205,7 +205,7 @@ std::vector<Tensor> rasterize_backward_fused(
     double scale_modifier, int64_t sh_degree, bool need_vm, bool need_pm, bool need_campos, bool need_xf, at::TensorList adam_m,
     at::TensorList adam_v, at::ArrayRef<double> adam_lr, double beta1, double beta2, double eps, int64_t step, const Tensor& next_vm,
     const Tensor& next_pm, const Tensor& next_campos, int64_t next_H, int64_t next_W, double next_tanfovx, double next_tanfovy,
-    Tensor prepared_out, const Tensor& next_xf)
+    Tensor prepared_out, const Tensor& next_xf, int64_t next_sh_degree)
 {
     const c10::hip::HIPGuardMasqueradingAsCUDA guard(means3D.device());
     TORCH_CHECK(adam_m.size() == 6 && adam_v.size() == 6 && adam_lr.size() == 6, "fused_adam: six groups expected");
@@ -236,7 +236,7 @@ std::vector<Tensor> rasterize_backward_fused(
     // (the next render's own pose transform when its frame has one; otherwise it shares this render's)
     const Tensor nvm = f32c(next_vm), npm = f32c(next_pm), ncp = f32c(next_campos), nxf = has(next_xf) ? f32c(next_xf.slice(0, 0, 3)) : xf;
     if (has(prepared_out)) {   // "prepare in backward": this kernel also runs the NEXT render's preprocess on the updated parameters
-        nv.W = (int32_t)next_W; nv.H = (int32_t)next_H; nv.D = (int32_t)sh_degree;
+        nv.W = (int32_t)next_W; nv.H = (int32_t)next_H; nv.D = (int32_t)(next_sh_degree >= 0 ? next_sh_degree : sh_degree);
         nv.scale_modifier = (float)scale_modifier; nv.tanfovx = (float)next_tanfovx; nv.tanfovy = (float)next_tanfovy;
         nv.viewmatrix = fp(nvm); nv.projmatrix = fp(npm); nv.campos = fp(ncp); nv.points_transform = fp(nxf);
         a.next_view = &nv;
@@ -256,10 +256,13 @@ struct Cfg {
     bool raw_params, prefiltered, debug, cam_grad;
     std::vector<double> adam_lr;
     std::vector<Tensor> adam_m, adam_v;   // optimizer moments: plain buffers, not autograd inputs
+    Tensor adam_commit;                   // CPU int64 [1]: number of in-kernel Adam steps this optimizer's backwards have applied.  The
+                                          // step count advances when a backward RUNS (a forward whose graph is dropped leaves no trace);
+                                          // adam_step is the optimizer's step count at forward time, with adam_commit[0] as it was then
     Tensor prepared;                      // input: hand-over buffer of the preceding backward (or undefined)
     Tensor next_vm, next_pm, next_campos; // camera of the NEXT render (or undefined): the backward prepares it
     Tensor next_xf;                       // ... and its points_transform, when it differs from this render's (per-frame poses)
-    int64_t next_H = 0, next_W = 0;
+    int64_t next_H = 0, next_W = 0, next_D = -1;   // next_D: SH degree of the next render (-1 = this render's)
     double next_tanfovx = 0, next_tanfovy = 0;
 };
 
@@ -294,6 +297,8 @@ class RasterizeFn : public torch::autograd::Function<RasterizeFn> {
         ctx->saved_data["n_adam"] = (int64_t)cfg.adam_m.size();
         ctx->saved_data["lr"] = cfg.adam_lr; ctx->saved_data["b1"] = cfg.beta1; ctx->saved_data["b2"] = cfg.beta2;
         ctx->saved_data["eps"] = cfg.eps; ctx->saved_data["step"] = cfg.adam_step;
+        ctx->saved_data["commit"] = cfg.adam_commit.defined() ? cfg.adam_commit : at::zeros({1}, at::TensorOptions().dtype(at::kLong));
+        ctx->saved_data["commit_seen"] = cfg.adam_commit.defined() ? cfg.adam_commit.data_ptr<int64_t>()[0] : (int64_t)0;
         ctx->saved_data["xf_rows"] = has(xf) ? xf.size(0) : (int64_t)0;
         ctx->saved_data["done"] = false;
         ctx->saved_data["prep_out"] = prep_out;
@@ -302,6 +307,7 @@ class RasterizeFn : public torch::autograd::Function<RasterizeFn> {
                                                           has(cfg.next_xf) ? f32c(cfg.next_xf) : x.new_empty({0})};
         ctx->saved_data["next_H"] = cfg.next_H; ctx->saved_data["next_W"] = cfg.next_W;
         ctx->saved_data["next_tfx"] = cfg.next_tanfovx; ctx->saved_data["next_tfy"] = cfg.next_tanfovy;
+        ctx->saved_data["next_D"] = cfg.next_D;
         ctx->mark_non_differentiable({std::get<1>(out), prep_out});
         ctx->set_materialize_grads(false);   // unused depth / alpha outputs arrive undefined -> specialised backward
         return {std::get<0>(out), std::get<1>(out), std::get<2>(out), std::get<3>(out), prep_out};
@@ -332,12 +338,17 @@ class RasterizeFn : public torch::autograd::Function<RasterizeFn> {
             std::vector<Tensor> m = ctx->saved_data["adam_m"].toTensorVector(), v = ctx->saved_data["adam_v"].toTensorVector();
             auto lr = ctx->saved_data["lr"].toDoubleVector();
             auto nc = ctx->saved_data["next_cam"].toTensorVector();
+            // the 1-based step of THIS update: the optimizer's count at forward time + the in-kernel steps applied since + 1
+            Tensor commit = ctx->saved_data["commit"].toTensor();
+            int64_t* commit_p = commit.data_ptr<int64_t>();
+            const int64_t step_now = ctx->saved_data["step"].toInt() + (commit_p[0] - ctx->saved_data["commit_seen"].toInt()) + 1;
             auto r = op.call(sv[0], sv[1], sv[7], sv[3], sv[4], sv[5], sv[8], sv[9], sv[10], sv[11], sv[12], sv[13], sv[14], sv[15], sv[16],
                              orE(gc), orE(gd), orE(ga), H, W, tfx, tfy, smod, D, need_vm, need_pm, need_cp, need_xf, m, v, lr,
                              ctx->saved_data["b1"].toDouble(), ctx->saved_data["b2"].toDouble(), ctx->saved_data["eps"].toDouble(),
-                             ctx->saved_data["step"].toInt(), nc[0], nc[1], nc[2], ctx->saved_data["next_H"].toInt(),
+                             step_now, nc[0], nc[1], nc[2], ctx->saved_data["next_H"].toInt(),
                              ctx->saved_data["next_W"].toInt(), ctx->saved_data["next_tfx"].toDouble(), ctx->saved_data["next_tfy"].toDouble(),
-                             ctx->saved_data["prep_out"].toTensor(), nc[3]);
+                             ctx->saved_data["prep_out"].toTensor(), nc[3], ctx->saved_data["next_D"].toInt());
+            commit_p[0] += 1;   // the update has been enqueued: the optimizer's step count advances (FusedAdam reconciles from this)
             out[1] = r[0]; out[9] = r[1]; out[10] = r[2]; out[11] = r[3]; d_xf = r[4];
         } else {
             static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("gsr::rasterize_backward", "").typed<decltype(rasterize_backward)>();
@@ -358,15 +369,21 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> rasterize(
     const Tensor& xf, int64_t H, int64_t W, double tanfovx, double tanfovy, double scale_modifier, int64_t sh_degree, bool raw_params,
     bool prefiltered, bool debug, bool cam_grad, at::TensorList adam_m, at::TensorList adam_v, at::ArrayRef<double> adam_lr, double beta1,
     double beta2, double eps, int64_t step, const Tensor& prepared, const Tensor& next_vm, const Tensor& next_pm, const Tensor& next_campos,
-    int64_t next_H, int64_t next_W, double next_tanfovx, double next_tanfovy, const Tensor& next_xf)
+    int64_t next_H, int64_t next_W, double next_tanfovx, double next_tanfovy, const Tensor& next_xf, int64_t next_sh_degree,
+    const Tensor& adam_commit)
 {
     Cfg cfg{H, W, sh_degree, step, tanfovx, tanfovy, scale_modifier, beta1, beta2, eps, raw_params, prefiltered, debug, cam_grad,
             std::vector<double>(adam_lr.begin(), adam_lr.end()), adam_m.vec(), adam_v.vec()};
     if (has(prepared)) cfg.prepared = prepared;
+    if (!adam_m.empty()) {
+        TORCH_CHECK(has(adam_commit) && adam_commit.is_cpu() && adam_commit.scalar_type() == at::kLong, "fused_adam: adam_commit must be a CPU int64 tensor");
+        cfg.adam_commit = adam_commit;
+    }
     if (has(next_vm)) {
         TORCH_CHECK(!adam_m.empty(), "prepare_next needs fused_adam (the backward that applies the update prepares the next render)");
         cfg.next_vm = next_vm; cfg.next_pm = next_pm; cfg.next_campos = next_campos;
         cfg.next_H = next_H; cfg.next_W = next_W; cfg.next_tanfovx = next_tanfovx; cfg.next_tanfovy = next_tanfovy;
+        cfg.next_D = next_sh_degree;
         if (has(next_xf)) cfg.next_xf = next_xf;
     }
     auto r = RasterizeFn::apply(means3D, means2D, sh, colors, opac, scales, rots, cov, rest, vm, pm, campos, bg, xf, cfg);
@@ -380,9 +397,10 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> rasterize_forward_only(
     const Tensor& xf, int64_t H, int64_t W, double tanfovx, double tanfovy, double scale_modifier, int64_t sh_degree, bool raw_params,
     bool prefiltered, bool debug, bool cam_grad, at::TensorList adam_m, at::TensorList adam_v, at::ArrayRef<double> adam_lr, double beta1,
     double beta2, double eps, int64_t step, const Tensor& prepared, const Tensor& next_vm, const Tensor& next_pm, const Tensor& next_campos,
-    int64_t next_H, int64_t next_W, double next_tanfovx, double next_tanfovy, const Tensor& next_xf)
+    int64_t next_H, int64_t next_W, double next_tanfovx, double next_tanfovy, const Tensor& next_xf, int64_t next_sh_degree,
+    const Tensor& adam_commit)
 {
-    (void)means2D; (void)next_xf; (void)cam_grad; (void)adam_m; (void)adam_v; (void)adam_lr; (void)beta1; (void)beta2; (void)eps; (void)step;
+    (void)means2D; (void)next_xf; (void)next_sh_degree; (void)adam_commit; (void)cam_grad; (void)adam_m; (void)adam_v; (void)adam_lr; (void)beta1; (void)beta2; (void)eps; (void)step;
     (void)next_vm; (void)next_pm; (void)next_campos; (void)next_H; (void)next_W; (void)next_tanfovx; (void)next_tanfovy;
     auto out = rasterize_forward(means3D, sh, colors, opac, scales, rots, cov, rest, vm, pm, campos, bg, has(xf) ? xf.slice(0, 0, 3) : xf, H, W,
                                  tanfovx, tanfovy, scale_modifier, sh_degree, raw_params, prefiltered, debug, prepared);
@@ -495,6 +513,10 @@ void pose_step(Tensor delta, Tensor exp_avg, Tensor exp_avg_sq, const Tensor& d_
     check(gsr_pose_step(delta.data_ptr<float>(), step ? exp_avg.data_ptr<float>() : nullptr, step ? exp_avg_sq.data_ptr<float>() : nullptr,
                         fp(g), fp(b), xf.data_ptr<float>(), (float)lr, (float)beta1, (float)beta2, (float)eps, step,
                         c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()), "gsr_pose_step");
+    // written through raw pointers: tell autograd's version counters (a hand-over buffer prepared for the old transform is then
+    // recognised as stale, train_step._same_transform; a plain TORCH_LIBRARY op with a (a!) schema does not bump them itself)
+    torch::autograd::impl::bump_version(xf);
+    torch::autograd::impl::bump_version(delta);
 }
 
 // Camera-route pose step: the frame's viewmatrix / projmatrix / campos tensors are rewritten in place from their own gradients.
@@ -514,6 +536,11 @@ void pose_step_camera(Tensor delta, Tensor exp_avg, Tensor exp_avg_sq, const Ten
                                fp(gv), fp(gp), fp(gc), fp(pt), fp(b), vm.data_ptr<float>(), pm.data_ptr<float>(), cp.data_ptr<float>(),
                                (float)lr, (float)beta1, (float)beta2, (float)eps, step,
                                c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()), "gsr_pose_step_camera");
+    // (see pose_step: train_step._camera_versions compares these counters)
+    torch::autograd::impl::bump_version(vm);
+    torch::autograd::impl::bump_version(pm);
+    torch::autograd::impl::bump_version(cp);
+    torch::autograd::impl::bump_version(delta);
 }
 
 Tensor knn_mean_dist2(const Tensor& points_)
@@ -549,13 +576,14 @@ TORCH_LIBRARY(gsr, m)
           "int image_width, float tanfovx, float tanfovy, float scale_modifier, int sh_degree, bool need_viewmatrix, bool need_projmatrix, "
           "bool need_campos, bool need_points_transform, Tensor(g!)[] adam_m, Tensor(h!)[] adam_v, float[] adam_lr, float beta1, "
           "float beta2, float eps, int step, Tensor next_viewmatrix, Tensor next_projmatrix, Tensor next_campos, int next_height, "
-          "int next_width, float next_tanfovx, float next_tanfovy, Tensor(i!) prepared_out, Tensor next_points_transform) -> Tensor[]");
+          "int next_width, float next_tanfovx, float next_tanfovy, Tensor(i!) prepared_out, Tensor next_points_transform, int next_sh_degree) -> Tensor[]");
     m.def("rasterize(Tensor means3D, Tensor means2D, Tensor sh, Tensor colors_precomp, Tensor opacities, Tensor scales, Tensor rotations, "
           "Tensor cov3D_precomp, Tensor sh_rest, Tensor viewmatrix, Tensor projmatrix, Tensor campos, Tensor bg, Tensor points_transform, "
           "int image_height, int image_width, float tanfovx, float tanfovy, float scale_modifier, int sh_degree, bool raw_params, "
           "bool prefiltered, bool debug, bool cam_grad, Tensor[] adam_m, Tensor[] adam_v, float[] adam_lr, float beta1, float beta2, "
           "float eps, int step, Tensor prepared, Tensor next_viewmatrix, Tensor next_projmatrix, Tensor next_campos, int next_height, "
-          "int next_width, float next_tanfovx, float next_tanfovy, Tensor next_points_transform) -> (Tensor, Tensor, Tensor, Tensor, Tensor)");
+          "int next_width, float next_tanfovx, float next_tanfovy, Tensor next_points_transform, int next_sh_degree, Tensor adam_commit) -> "
+          "(Tensor, Tensor, Tensor, Tensor, Tensor)");
     m.def("mark_visible(Tensor means3D, Tensor viewmatrix, Tensor projmatrix) -> Tensor");
     m.def("photometric_loss_forward(Tensor render, Tensor target, float lambda_dssim, bool clamp) -> (Tensor, Tensor)");
     m.def("photometric_loss_backward(Tensor render, Tensor target, Tensor workspace, Tensor grad_loss, float lambda_dssim, bool clamp) -> Tensor");

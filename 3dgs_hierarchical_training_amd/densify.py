@@ -102,6 +102,8 @@ class Densifier:
             sel = torch.zeros_like(sel)
         if bool(sel.any()):
             self._append({name: getattr(p, attr).detach()[sel] for name, attr in p._GROUP_ATTR.items()})
+        else:
+            self.reset_stats()      # the reference's densification_postfix runs (and zeroes the statistics) even with nothing selected
 
         # split: over-reconstructed, large (gradients of the Gaussians that were just appended count as zero)
         n = p.num_points
@@ -123,6 +125,8 @@ class Densifier:
                    "opacity": p._opacity.detach()[sel].repeat(2, 1)}
             self._append(new)
             self._prune(torch.cat((sel, torch.zeros(2 * k, dtype=torch.bool, device=sel.device))))
+        else:
+            self.reset_stats()      # (gaussian_model_ht.py:621-629 via :676: unconditional, so max_radii2D is always zero at the prune below)
 
         mask = (p.get_opacity.detach() < min_opacity).squeeze(1)
         if max_screen_size:

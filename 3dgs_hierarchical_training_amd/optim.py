@@ -47,7 +47,14 @@ class FusedAdam:
             self.param_groups.append(g)
         self.betas, self.eps = tuple(betas), eps
         self.state = {}
-        self._stepped_in_backward = False     # set when a backward applied this optimizer's step in-kernel
+        # Optimizer-in-backward bookkeeping.  A render only PLANS the step (fused_step_plan mutates nothing); the backward that
+        # applies it -- the C++ autograd node, or the ctypes route -- increments `_commit`, and the step counts of the six groups
+        # catch up from it the next time anybody looks (`_reconcile`: plan, step(), state_dict(), step_count).  A forward that
+        # never reaches its backward (no_grad render, an exception in the loss, a dropped graph) therefore leaves no trace.
+        self._commit = torch.zeros(1, dtype=torch.int64)      # CPU; shared with csrc/torch_ext.cpp by reference
+        self._commit_np = self._commit.numpy()
+        self._commit_seen = 0                                  # commits already folded into state[...]["step"]
+        self._commit_at_step = 0                               # value of the counter at the last step() call
 
     # ---- torch.optim protocol ------------------------------------------------------------------------------
     def zero_grad(self, set_to_none: bool = True):
@@ -77,12 +84,31 @@ class FusedAdam:
                 st[k] = m.contiguous()
         return st
 
+    def _reconcile(self):
+        """Fold the in-kernel steps applied since the last look into the six groups' step counts."""
+        n = int(self._commit_np[0]) - self._commit_seen
+        if n <= 0:
+            return
+        self._commit_seen += n
+        for g in self.param_groups:
+            if g.get("name") in self.FUSED_ORDER:
+                st = self.state.get(g["params"][0])
+                if st is not None:
+                    st["step"] = _step_int(st.get("step", 0)) + n
+
+    @property
+    def _stepped_in_backward(self) -> bool:
+        """True when a backward applied this optimizer's step in-kernel since the last step() call."""
+        return int(self._commit_np[0]) > self._commit_at_step
+
     @property
     def step_count(self) -> int:
         """Largest per-tensor step count (all groups advance together in the reference's loop)."""
+        self._reconcile()
         return max([_step_int(st.get("step", 0)) for st in self.state.values()], default=0)
 
     def state_dict(self) -> Dict:
+        self._reconcile()
         index, packed = {}, []
         for g in self.param_groups:
             ids = []
@@ -111,6 +137,7 @@ class FusedAdam:
                 if k not in ("params", "betas", "eps"):
                     g[k] = v
             params += list(zip(saved["params"], g["params"]))
+        self._reconcile()
         self.state = {}
         for idx, p in params:
             s = sd["state"].get(idx)
@@ -122,10 +149,13 @@ class FusedAdam:
 
     # ---- the two ways a step is taken ----------------------------------------------------------------------
     def fused_step_plan(self, tensors: Dict[str, torch.Tensor]):
-        """(exp_avg[6], exp_avg_sq[6], lr[6], beta1, beta2, eps, step) for the optimizer-in-backward mode of gsr_backward:
-        counts as this optimizer's next step.  `tensors` are the parameter tensors being rasterized, by group name; they
-        must be the optimizer's own."""
-        # fast path: nothing was rebuilt since the previous step (same group dicts, parameter / moment tensors, state entries):
+        """(exp_avg[6], exp_avg_sq[6], lr[6], beta1, beta2, eps, step_base, commit) for the optimizer-in-backward mode of
+        gsr_backward.  Mutates nothing: `step_base` is the six groups' current step count and `commit` the CPU counter that the
+        backward increments when it has applied the update; the 1-based step of that update is step_base + (commits since this
+        plan) + 1.  `tensors` are the parameter tensors being rasterized, by group name; they must be the optimizer's own.
+        The learning rates are read here, at render time (the reference sets them before the render, ht3dgs_trainer.py:98)."""
+        self._reconcile()
+        # fast path: nothing was rebuilt since the previous plan (same group dicts, parameter / moment tensors, state entries):
         # the checks below were all made then -- only the step count and the learning rates are taken anew
         c = getattr(self, "_plan_cache", None)
         if c is not None:
@@ -138,11 +168,8 @@ class FusedAdam:
                     ok = False
                     break
             if ok:
-                step = _step_int(sts[0]["step"]) + 1
-                for st in sts:
-                    st["step"] = step
-                self._stepped_in_backward = True
-                return (ms, vs, [float(g["lr"]) for g in groups], float(self.betas[0]), float(self.betas[1]), float(self.eps), step)
+                return (ms, vs, [float(g["lr"]) for g in groups], float(self.betas[0]), float(self.betas[1]), float(self.eps),
+                        _step_int(sts[0]["step"]), self._commit)
             self._plan_cache = None
         by_name = {g.get("name"): g for g in self.param_groups}
         if set(by_name) != set(self.FUSED_ORDER):
@@ -160,31 +187,36 @@ class FusedAdam:
             lrs.append(float(g["lr"]))
         if len(steps) != 1:
             raise RuntimeError(f"fused_adam: the six groups are at different step counts {sorted(steps)}; use step()")
-        step = steps.pop() + 1
+        step = steps.pop()
         for st in states:
             st["step"] = int(step)
-        self._stepped_in_backward = True
         ms, vs = [st["exp_avg"] for st in states], [st["exp_avg_sq"] for st in states]
         groups = [by_name[name] for name in self.FUSED_ORDER]
         self._plan_cache = (groups, [g["params"][0] for g in groups], [tensors[name] for name in self.FUSED_ORDER], states, ms, vs,
                             [next(i for i, x in enumerate(self.param_groups) if x is g) for g in groups])
         self._plan_groups = len(self.param_groups)
-        return (ms, vs, lrs, float(self.betas[0]), float(self.betas[1]), float(self.eps), int(step))
+        return (ms, vs, lrs, float(self.betas[0]), float(self.betas[1]), float(self.eps), int(step), self._commit)
 
     def fused_backward_args(self, tensors: Dict[str, torch.Tensor]) -> "L.GsrFusedAdam":
-        """The same plan as a GsrFusedAdam struct (ctypes binding)."""
-        m, v, lrs, b1, b2, eps, step = self.fused_step_plan(tensors)
+        """The plan as a GsrFusedAdam struct for the update that is applied NOW (ctypes binding: called from its backward, which
+        calls `fused_backward_applied()` once gsr_backward has returned)."""
+        m, v, lrs, b1, b2, eps, step, _ = self.fused_step_plan(tensors)
         fa = L.GsrFusedAdam()
-        fa.beta1, fa.beta2, fa.eps, fa.step = b1, b2, eps, step
+        fa.beta1, fa.beta2, fa.eps, fa.step = b1, b2, eps, step + 1
         for k in range(6):
             fa.lr[k] = lrs[k]
             fa.exp_avg[k], fa.exp_avg_sq[k] = m[k].data_ptr(), v[k].data_ptr()
         return fa
 
+    def fused_backward_applied(self):
+        self._commit_np[0] += 1
+
     @torch.no_grad()
     def step(self):
+        self._reconcile()
         live = [g for g in self.param_groups if g["params"][0].grad is not None]
-        stepped, self._stepped_in_backward = self._stepped_in_backward, False
+        stepped = self._stepped_in_backward
+        self._commit_at_step = int(self._commit_np[0])
         if not live:
             return
         if stepped and any(g.get("name") in self.FUSED_ORDER for g in live):

@@ -272,6 +272,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
             L.check(lib.gsr_backward(C.byref(a), C.c_void_p(stream)), "gsr_backward")
+        if fused is not None:
+            fused.fused_backward_applied()      # the update is enqueued: the optimizer's step count advances now, not at render time
         return (d_means3D, d_means2D, d_sh, d_col, d_opac, d_scales, d_rot, d_cov, None, d_sh_rest, None, d_vm, d_pm, d_cp, None, d_xf)
 
 
@@ -289,6 +291,13 @@ def _e(dev):
     t = _EMPTY.get(dev)
     if t is None:
         t = _EMPTY[dev] = torch.empty(0, dtype=torch.float32, device=dev)
+    return t
+
+
+def _ecpu():
+    t = _EMPTY.get("cpu_i64")
+    if t is None:
+        t = _EMPTY["cpu_i64"] = torch.empty(0, dtype=torch.int64)
     return t
 
 
@@ -310,21 +319,29 @@ def _rasterize_ext(means3D, means2D, sh, colors_precomp, opacities, scales, rota
     if points_transform is not None and tuple(points_transform.shape) not in ((3, 4), (4, 4)):
         raise RuntimeError("points_transform must be a [3,4] or [4,4] tensor")
     xf = e if points_transform is None else points_transform.to(dev)
-    m, v, lr, b1, b2, eps, step = [], [], [], 0.0, 0.0, 0.0, 0
+    m, v, lr, b1, b2, eps, step, commit = [], [], [], 0.0, 0.0, 0.0, 0, None
+    if fused_adam is not None and not (torch.is_grad_enabled() and (means3D.requires_grad or opacities.requires_grad)):
+        fused_adam = None       # a render that cannot reach a backward (torch.no_grad(), detached parameters): nothing to plan
     if fused_adam is not None:
         if not (raw_params and sh_rest is not None and sh is not None and scales is not None):
             raise RuntimeError("fused_adam needs the raw-parameter path (rasterize_gaussians_raw)")
-        m, v, lr, b1, b2, eps, step = fused_adam.fused_step_plan({"xyz": means3D, "f_dc": sh, "f_rest": sh_rest, "opacity": opacities,
-                                                                  "scaling": scales, "rotation": rotations})
+        # a PLAN only: the step count advances when the backward that applies the update runs (csrc/torch_ext.cpp increments
+        # `commit`), so a forward whose graph is dropped leaves the optimizer untouched
+        m, v, lr, b1, b2, eps, step, commit = fused_adam.fused_step_plan({"xyz": means3D, "f_dc": sh, "f_rest": sh_rest, "opacity": opacities,
+                                                                          "scaling": scales, "rotation": rotations})
     eb = _EMPTY.get(("u8", dev))
     if eb is None:
         eb = _EMPTY[("u8", dev)] = torch.empty(0, dtype=torch.uint8, device=dev)
     nx = prepare_next
+    if nx is not None and fused_adam is None and not torch.is_grad_enabled():
+        nx = None               # (a no_grad render has no backward that could prepare anything)
     if nx is not None:
         if fused_adam is None:
             raise RuntimeError("prepare_next needs fused_adam: the backward that applies the update prepares the next render")
-        if int(nx.sh_degree) != int(rs.sh_degree) or float(nx.scale_modifier) != float(rs.scale_modifier) or int(rs.sh_degree) != 3:
-            raise RuntimeError("prepare_next: the next view must use sh_degree 3 and this view's scale_modifier")
+        if int(nx.sh_degree) not in (int(rs.sh_degree), int(rs.sh_degree) + 1) or int(nx.sh_degree) > 3 or \
+                float(nx.scale_modifier) != float(rs.scale_modifier):
+            raise RuntimeError("prepare_next: the next view must use this view's sh_degree or the one above it (oneupSHdegree) and this "
+                               "view's scale_modifier")
         nvm, npm, ncp = nx.viewmatrix.to(dev), nx.projmatrix.to(dev), nx.campos.to(dev)
     args = (means3D, means2D, pick(sh), pick(colors_precomp), opacities, pick(scales), pick(rotations), pick(cov3Ds_precomp),
             pick(sh_rest), vm, pm, cp, bg, xf, int(rs.image_height), int(rs.image_width), float(rs.tanfovx),
@@ -333,15 +350,16 @@ def _rasterize_ext(means3D, means2D, sh, colors_precomp, opacities, scales, rota
             eb if prepared is None else prepared, e if nx is None else nvm, e if nx is None else npm, e if nx is None else ncp,
             0 if nx is None else int(nx.image_height), 0 if nx is None else int(nx.image_width),
             0.0 if nx is None else float(nx.tanfovx), 0.0 if nx is None else float(nx.tanfovy),
-            e if (nx is None or next_points_transform is None) else next_points_transform.to(dev))
+            e if (nx is None or next_points_transform is None) else next_points_transform.to(dev),
+            -1 if nx is None else int(nx.sh_degree), _ecpu() if commit is None else commit)
     if not rs.debug:
         out = ops.rasterize(*args)
-        return out if nx is not None else out[:4]
+        return out if prepare_next is not None else out[:4]
     # raster_settings.debug = True: what the public module does -- on an error in the native forward, dump the arguments to
     # snapshot_fw.dump for offline inspection and re-raise (the reference always passes debug=False, gaussian_model_ht.py:821)
     try:
         out = ops.rasterize(*args)
-        return out if nx is not None else out[:4]
+        return out if prepare_next is not None else out[:4]
     except Exception:
         torch.save([a.detach().cpu() if torch.is_tensor(a) else a for a in args[:24]], "snapshot_fw.dump")
         print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")

@@ -76,7 +76,9 @@ class HTConfig:
     frames: int = 40
     width: int = 980
     height: int = 545
-    sh_degree: int = 3
+    sh_degree: int = 3                          # max_sh_degree: 16 stored coefficients
+    start_sh_degree: int = 0                    # active degree of a new leaf (gaussian_model_ht.py:68) ...
+    sh_up_every: int = 1000                     # ... raised after every this many global iterations (ht3dgs_trainer.py:580-581)
     gt_gaussians: int = 400_000
     leaf_gaussians: int = 200_000
     leaf_iters_per_frame: int = 30              # single_step
@@ -114,11 +116,13 @@ class Segment:
         return ps
 
     def sync_poses(self):
-        """Refined transforms back into the pose table (what merges, importance views and evaluation read); the optimizer
-        state of the poses ends with the training phase."""
+        """Refined transforms back into the pose table (what merges, importance views and evaluation read).  The pose states --
+        tangent numbers, Adam moments, step counts -- live as long as the segment does, as the reference's per-frame
+        `camera_optimizer[fidx]` lives from one `training_setup` to the next (gaussian_model_ht.py:296-311); a merge builds a new
+        Segment and with it fresh states."""
         for f, ps in self.pose_states.items():
-            self.poses[f] = ps.matrix()
-        self.pose_states = {}
+            if ps.steps or f not in self.poses:
+                self.poses[f] = ps.matrix()
 
     def pose_tensor(self) -> torch.Tensor:
         return torch.stack([self.poses[f] for f in self.frames])
@@ -166,7 +170,8 @@ class RankRunner:
         k = self.cfg.importance_views
         if k and len(fr) > k:
             fr = fr[::max(1, len(fr) // k)][:k]
-        return [self._settings(seg, f) for f in fr]
+        return [ts.with_sh_degree(self._settings(seg, f), seg.params.active_sh_degree) if self.step_fn is None else self._settings(seg, f)
+                for f in fr]
 
     def _step(self, seg: Segment, settings, target, next_settings=None):
         """next_settings: the camera of the NEXT step when it is already drawn -- its preprocess then rides in this step's
@@ -174,8 +179,16 @@ class RankRunner:
         seg.global_iteration += 1
         if self.step_fn is not None:
             return self.step_fn(seg, settings, target)
+        up = self._sh_up(seg)
         ts.train_step(seg.params, settings, target, fused_optimizer=self.cfg.fused, densifier=seg.densifier,
-                      iteration=seg.global_iteration, next_settings=next_settings)
+                      iteration=seg.global_iteration, next_settings=next_settings,
+                      next_sh_degree=min(seg.params.active_sh_degree + 1, seg.params.max_sh_degree) if up else None)
+        if up:
+            seg.params.oneup_sh_degree()
+
+    def _sh_up(self, seg: Segment) -> bool:
+        """`if self.global_iteration % 1000 == 0: oneupSHdegree()` after the step (ht3dgs_trainer.py:580-581, :636-637, :909-910)."""
+        return self.cfg.sh_up_every > 0 and seg.global_iteration % self.cfg.sh_up_every == 0
 
     def _steps_over(self, seg: Segment, frames_drawn):
         """Train on a pre-drawn list of frames (the frame of step k + 1 is known at step k)."""
@@ -186,8 +199,12 @@ class RankRunner:
             states = [seg.pose_state(v, self._settings(seg, v), self.dev, self.cfg.pose_lr) for v in frames_drawn]
             for k, v in enumerate(frames_drawn):
                 seg.global_iteration += 1
+                up = self._sh_up(seg)
                 ts.train_step(seg.params, states[k].settings, self.seq.target(v), fused_optimizer=self.cfg.fused, densifier=seg.densifier,
-                              iteration=seg.global_iteration, pose=states[k], next_pose=states[k + 1] if k + 1 < len(states) else None)
+                              iteration=seg.global_iteration, pose=states[k], next_pose=states[k + 1] if k + 1 < len(states) else None,
+                              next_sh_degree=min(seg.params.active_sh_degree + 1, seg.params.max_sh_degree) if up else None)
+                if up:
+                    seg.params.oneup_sh_degree()
             seg.sync_poses()
             return
         st = [self._settings(seg, v) for v in frames_drawn]
@@ -207,6 +224,7 @@ class RankRunner:
         start = frames[0]
         scene = self.seq.leaf_scene(start, cfg.leaf_gaussians, seed=cfg.seed + 17 * self.rank)
         params = ts.GaussianParams(scene, self.dev, optimizer=cfg.optimizer)
+        params.active_sh_degree = min(cfg.start_sh_degree, params.max_sh_degree)      # a new model starts at degree 0 (gaussian_model_ht.py:68)
         seg = Segment(params, frames, start, {start: torch.eye(4)})
         self._new_densifier(seg)
         t0 = time.perf_counter()
@@ -243,15 +261,19 @@ class RankRunner:
         out = hierarchy.merge_recv(self.tr, self.role(k)[1], seg.params.raw(), self._importance_views(seg),
                                    self.cfg.prune_ratio, src_to_dst, importance_fn=self.importance_fn)
         child = out["child"]
+        # (teachers render at the active degree their model was trained at; the leaves of a level advance in lockstep -- same
+        #  iteration counts -- so the child's degree is the destination's)
+        tdeg = seg.params.active_sh_degree
         own_teacher = {"seg": {kk: v.clone() for kk, v in out["teachers"][0].items()}, "start_fidx": seg.start_fidx,
-                       "frames": list(seg.frames)}
-        child_teacher = {"seg": out["teachers"][1], "start_fidx": child["start_fidx"], "frames": list(child["frames"])}
+                       "frames": list(seg.frames), "sh_degree": tdeg}
+        child_teacher = {"seg": out["teachers"][1], "start_fidx": child["start_fidx"], "frames": list(child["frames"]), "sh_degree": tdeg}
         self.teachers = [own_teacher, child_teacher]
         for f in child["frames"]:                                                    # :783-790
             if f not in seg.poses:
                 seg.poses[f] = self.seq.rel_pose(f - 1, f) @ seg.poses[f - 1]
         frames = sorted(set(seg.frames + child["frames"]))                           # :796
-        params = ts.GaussianParams.from_raw(out["merged"], self.dev, sh_degree=self.cfg.sh_degree, optimizer=self.cfg.optimizer)
+        # (the merged model keeps the destination's active degree: `restore` carries it, gaussian_model_ht.py:107-124)
+        params = ts.GaussianParams.from_raw(out["merged"], self.dev, sh_degree=seg.params.active_sh_degree, optimizer=self.cfg.optimizer)
         self.seg = Segment(params, frames, seg.start_fidx, seg.poses, global_iteration=0)   # :792-793
         self._new_densifier(self.seg)
         self._emit({"phase": "merge", "level": k, **{kk: v for kk, v in out.items() if kk not in ("merged", "teachers", "child")}})
@@ -276,7 +298,8 @@ class RankRunner:
                 if teacher is None:
                     raise ValueError(f"frame {f} belongs to no child")
                 p_wrt_teacher = p @ torch.linalg.inv(seg.poses[teacher["start_fidx"]])    # :874
-                pseudo = self.teacher_render_fn(teacher["seg"], self.seq.settings_for_pose(p_wrt_teacher))
+                pseudo = self.teacher_render_fn(teacher["seg"], ts.with_sh_degree(self.seq.settings_for_pose(p_wrt_teacher), teacher["sh_degree"])
+                                                if self.step_fn is None else self.seq.settings_for_pose(p_wrt_teacher))
                 self._step(seg, self.seq.settings_for_pose(p), pseudo)
                 virtual += 1
             else:

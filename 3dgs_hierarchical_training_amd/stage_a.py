@@ -121,7 +121,10 @@ def fit_pair(seq, p: int, device, n_points: int = 100_000, single_image_iters: i
     else:                    # a perturbed subset of the ground-truth cloud
         scene = seq.leaf_scene(p, n_points, seed=seed + p)
     params = ts.GaussianParams(scene, device)
-    ident = seq.settings_for_pose(torch.eye(4))
+    # a stage-A model is a fresh HTGaussianModel: active SH degree 0 with 16 coefficients stored, and its <= 1 000 + 300 iterations
+    # never reach an `oneupSHdegree` (gaussian_model_ht.py:68; train_single_image_3DGS / train_relative_pose have none)
+    params.active_sh_degree = 0
+    ident = ts.with_sh_degree(seq.settings_for_pose(torch.eye(4)), 0)
     tgt0, tgt1 = seq.target(p), seq.target(p + 1)
     for it in range(1, single_image_iters + 1):
         pkg = ts.train_step(params, ident, tgt0, next_settings=ident)      # same view every step: its preprocess rides in the backward

@@ -115,6 +115,14 @@ class GaussianParams:
     def num_points(self):
         return self._xyz.shape[0]
 
+    def oneup_sh_degree(self) -> int:
+        """`oneupSHdegree` (/root/reference/scene/gaussian_model_ht.py:193-195): the reference starts every model at active degree 0
+        (:68) with all (max_sh_degree + 1)^2 coefficients stored and calls this once per 1 000 global iterations
+        (/root/reference/trainer/ht3dgs_trainer.py:580-581); renders use the ACTIVE degree (:818)."""
+        if self.active_sh_degree < self.max_sh_degree:
+            self.active_sh_degree += 1
+        return self.active_sh_degree
+
     # ---- optimizer-state surgery of densification / pruning / opacity reset -----------------------------------------
     # Same protocol as HTGaussianModel (/root/reference/scene/gaussian_model_ht.py:532-629): the parameter tensor of a
     # group is replaced by a new leaf and its Adam moments are sliced / zero-extended / zeroed with it.  Works on
@@ -196,6 +204,40 @@ class _LazyVisibility(dict):
             v = self["visibility_filter"] = self["radii"] > 0
             return v
         raise KeyError(key)
+
+    # the other ways a dict is read see the key as well (a drop-in consumer may use any of them)
+    def get(self, key, default=None):
+        if key == "visibility_filter":
+            return self[key]
+        return super().get(key, default)
+
+    def __contains__(self, key):
+        return key == "visibility_filter" or super().__contains__(key)
+
+    def _materialise(self):
+        self["visibility_filter"]
+        return self
+
+    def keys(self):
+        return dict.keys(self._materialise())
+
+    def items(self):
+        return dict.items(self._materialise())
+
+    def values(self):
+        return dict.values(self._materialise())
+
+    def __iter__(self):
+        return dict.__iter__(self._materialise())
+
+    def __len__(self):
+        return dict.__len__(self._materialise())
+
+
+def with_sh_degree(settings: GaussianRasterizationSettings, degree: int) -> GaussianRasterizationSettings:
+    """The same view at another active SH degree (CF3DGS_Render.render builds its settings from `active_sh_degree` every call,
+    gaussian_model_ht.py:818); the tensors are shared, so `_same_view` recognises the result as the same camera."""
+    return settings if int(settings.sh_degree) == int(degree) else settings._replace(sh_degree=int(degree))
 
 
 def _same_view(a: GaussianRasterizationSettings, b: GaussianRasterizationSettings) -> bool:
@@ -303,6 +345,7 @@ def render(params: GaussianParams, settings: GaussianRasterizationSettings, clam
     next_settings (with fused_adam): the camera of the NEXT render of this model -- its preprocess then rides in this render's
     backward ("prepare in backward", rasterize_gaussians_raw) and the hand-over buffer is kept on `params` until a render with
     that camera picks it up (single use; any parameter surgery drops it)."""
+    settings = with_sh_degree(settings, params.active_sh_degree)     # gaussian_model_ht.py:818: sh_degree = the model's ACTIVE degree
     xyz = params.get_xyz
     # gaussian_model_ht.py:800-805 builds `zeros_like(xyz, requires_grad=True) + 0` every render only to receive
     # the 2D positional gradient; its VALUES are never read by the rasterizer.  One zero leaf per model does the same
@@ -356,7 +399,7 @@ def _same_transform(tag, xf) -> bool:
 def train_step(params: GaussianParams, settings: GaussianRasterizationSettings, gt: torch.Tensor,
                lambda_dssim: float = 0.2, fused_loss: bool = True, fused_activations: bool = True,
                fused_optimizer: bool = True, densifier=None, iteration: int = 0, next_settings=None,
-               pose: "PoseState" = None, next_pose: "PoseState" = None) -> Dict:
+               pose: "PoseState" = None, next_pose: "PoseState" = None, next_sh_degree: int = None) -> Dict:
     """render -> loss -> backward -> Adam step (ht3dgs_trainer.py:102-166 without densification).
     fused_loss=True evaluates clamp + L1 + SSIM in the HIP loss kernels; False uses the torch restatement.
     fused_activations=True runs exp / sigmoid / normalize / cat inside the rasterizer kernels.
@@ -366,6 +409,9 @@ def train_step(params: GaussianParams, settings: GaussianRasterizationSettings, 
     next_settings: the camera the NEXT train_step of this model will use, when the caller knows it (a trainer draws its frame
     one step ahead): the backward then also runs the next render's preprocess on the updated parameters and the next forward
     skips that kernel (same result bit for bit; see rasterize_gaussians_raw).
+    The render uses the model's ACTIVE SH degree (`params.active_sh_degree`, as CF3DGS_Render.render does); next_sh_degree = the
+    degree of the next step when the caller is about to raise it (`oneup_sh_degree()` right after this step: the reference does so
+    when global_iteration % 1000 == 0) -- the hand-over then already carries the colours of the higher degree.
     densifier (densify.Densifier) + iteration: the adaptive density control of ht3dgs_trainer.py:137-155 runs between
     backward() and optimizer.step(), as in the reference (see densify.py for the ordering note of the fused mode)."""
     fused_adam = params.optimizer if (fused_optimizer and fused_activations and isinstance(params.optimizer, FusedAdam)) else None
@@ -377,7 +423,14 @@ def train_step(params: GaussianParams, settings: GaussianRasterizationSettings, 
         if next_pose is not None:
             next_settings = next_pose.settings
     xf = pose.leaf() if (pose is not None and not cam_pose) else None
-    nxt = next_settings if params.active_sh_degree == 3 and params.max_sh_degree == 3 else None
+    deg = int(params.active_sh_degree)
+    settings = with_sh_degree(settings, deg)
+    # the hand-over needs the 16-coefficient layout (max_sh_degree 3, the reference's); any active degree, and the next render may
+    # be one degree up
+    nxt = next_settings if params.max_sh_degree == 3 else None
+    if nxt is not None:
+        ndeg = deg if next_sh_degree is None else int(next_sh_degree)
+        nxt = with_sh_degree(nxt, ndeg) if ndeg in (deg, deg + 1) and ndeg <= 3 else None
     if pose is not None and nxt is not None and (next_pose is None or (next_pose is pose and not pose.frozen)):
         nxt = None               # the next render is of THIS frame, whose pose moves in between: no hand-over
     pkg = render(params, settings, clamp=not fused_loss, fused_activations=fused_activations, fused_adam=fused_adam,

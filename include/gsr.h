@@ -123,8 +123,11 @@ typedef struct GsrFusedAdam {
  * (projection, tile test, SH colour, sort keys) and leaves the result in `prepared_out`; the next gsr_forward takes it
  * through GsrForwardArgs::prepared and skips its preprocess kernel: no second read of the 236 bytes per Gaussian, and
  * the ~2 400 VALU instructions per wave of the preprocess hide under the HBM time of the backward kernel.
- * Needs raw_params, shs + shs_rest with M = 16, D = 3 (gsr_prepare_supported); the caller guarantees that the parameters
- * are not modified between this backward and that forward. */
+ * Needs raw_params, shs + shs_rest with M = 16 stored coefficients at any active degree D = 0..3 (gsr_prepare_supported) --
+ * the reference's models store 16 coefficients from the start and raise the active degree once per 1 000 iterations
+ * (/root/reference/scene/gaussian_model_ht.py:68,193-195); GsrNextView::D is this render's degree or one above it (an
+ * `oneupSHdegree` between the two steps keeps the hand-over).  The caller guarantees that the parameters are not modified
+ * between this backward and that forward. */
 typedef struct GsrNextView {
     int32_t W, H, D;
     float scale_modifier, tanfovx, tanfovy;

@@ -327,8 +327,11 @@ def test_extension_ops_run_under_torch_compile():
 
 
 @pytest.mark.parametrize("digits_in_backward", [True, False], ids=["digits-counted-in-backward", "histogram-launch"])
-@pytest.mark.parametrize("N", [12800, 10007, 4098, 101, 130], ids=["whole-blocks", "ragged-odd", "ragged-mod4", "one-ragged-block", "two-blocks-ragged"])
-def test_prepare_in_backward_is_bit_identical(N, digits_in_backward):
+@pytest.mark.parametrize("N,deg", [(12800, 3), (10007, 3), (4098, 3), (101, 3), (130, 3), (12800, 0), (10007, 0), (4098, 1), (12800, 2), (130, 0),
+                                   (12800, "up"), (10007, "up")],
+                         ids=["whole-blocks", "ragged-odd", "ragged-mod4", "one-ragged-block", "two-blocks-ragged", "deg0-whole", "deg0-ragged-odd",
+                              "deg1-ragged-mod4", "deg2-whole", "deg0-two-blocks-ragged", "degree-steps-up-whole", "degree-steps-up-ragged"])
+def test_prepare_in_backward_is_bit_identical(N, deg, digits_in_backward):
     """"Prepare in backward" (GsrNextView): with `next_settings` the backward that applies the Adam step also runs the NEXT
     render's preprocess on the updated parameters, and that render skips k_preprocess.  Two copies of one model trained on
     two alternating cameras, one with and one without the hand-over, must stay EQUAL: images, radii, parameters, moments --
@@ -336,43 +339,79 @@ def test_prepare_in_backward_is_bit_identical(N, digits_in_backward):
     deterministic debug mode here: with float atomics two runs of the SAME path already differ in the last bits.)
     The hand-over buffer also carries the next depth sort's scratch: its counters are cleared by the blend backward, and up
     to 262 144 Gaussians the per-Gaussian kernel counts the sort's digits too (no histogram launch in the forward); both
-    sides of that threshold are run here ("prep_hist_max_n")."""
+    sides of that threshold are run here ("prep_hist_max_n").
+    deg: the model's ACTIVE SH degree with 16 coefficients stored (gsr_prepare_supported(16, D, 1) for D = 0..3) -- the
+    reference's models start at degree 0 and step up once per 1 000 iterations (gaussian_model_ht.py:68,193-195); "up" walks
+    0 -> 1 -> 2 -> 3 with an `oneup_sh_degree()` after every second step, announced through `next_sh_degree` so that the
+    hand-over survives the change."""
     L = importlib.import_module("3dgs_hierarchical_training_amd._lib")
     lib = L.load()
     assert lib.gsr_set_option(b"deterministic_backward", 1) == 0
     assert lib.gsr_set_option(b"prep_hist_max_n", 262144 if digits_in_backward else 0) == 0
+    for D in range(4):
+        assert lib.gsr_prepare_supported(16, D, 1) == 1
+    assert lib.gsr_prepare_supported(9, 2, 1) == 0 and lib.gsr_prepare_supported(16, 3, 0) == 0
     try:
-        _prepare_in_backward_case(N)
+        _prepare_in_backward_case(N, deg)
     finally:
         lib.gsr_set_option(b"deterministic_backward", 0)
         lib.gsr_set_option(b"prep_hist_max_n", 262144)
 
 
-def _prepare_in_backward_case(N):
+def _prepare_in_backward_case(N, deg=3):
     dev = torch.device("cuda:0")
     W, H = 320, 240
-    sc = parity.syn.make_scene(N, W, H, sh_degree=3, seed=17)
-    cam2 = parity.syn.make_scene(8, W, H, sh_degree=3, seed=5, posed=True)
+    up = deg == "up"
+    d0 = 0 if up else deg
+    sc = parity.syn.make_scene(N, W, H, sh_degree=d0, seed=17)
+    cam2 = parity.syn.make_scene(8, W, H, sh_degree=d0, seed=5, posed=True)
     sc2 = dict(sc)
     for k in ("viewmatrix", "projmatrix", "campos"):
         sc2[k] = cam2[k]
-    views = [ts.make_settings(sc, dev, 3), ts.make_settings(sc2, dev, 3)]
+    views = [ts.make_settings(sc, dev, d0), ts.make_settings(sc2, dev, d0)]
     gts = [parity.syn.target_image(W, H, seed=1).to(dev), parity.syn.target_image(W, H, seed=2).to(dev)]
     pa, pb = ts.GaussianParams(sc, dev), ts.GaussianParams(sc, dev)
+    assert pa.active_sh_degree == d0 and pa.max_sh_degree == 3
     names = ["_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation"]
     used = 0
-    for it in range(6):
+    steps = 8 if up else 6
+    for it in range(steps):
         v = it % 2
         had = getattr(pa, "_prepared", None) is not None
-        ka = ts.train_step(pa, views[v], gts[v], next_settings=views[(it + 1) % 2])
+        raise_after = up and it % 2 == 1 and pa.active_sh_degree < 3          # `oneupSHdegree` after this step
+        ka = ts.train_step(pa, views[v], gts[v], next_settings=views[(it + 1) % 2],
+                           next_sh_degree=pa.active_sh_degree + 1 if raise_after else None)
         kb = ts.train_step(pb, views[v], gts[v])
+        if raise_after:
+            pa.oneup_sh_degree(); pb.oneup_sh_degree()
         used += int(had)
         assert torch.equal(ka["raw_image"], kb["raw_image"]) and torch.equal(ka["radii"], kb["radii"]), it
         assert torch.equal(ka["depth"], kb["depth"]) and torch.equal(ka["alpha"], kb["alpha"]), it
         assert torch.equal(ka["viewspace_points"].grad, kb["viewspace_points"].grad), it
         for k in names:
             assert torch.equal(getattr(pa, k), getattr(pb, k)), (it, k)
-    assert used == 5                      # every step after the first rendered from a hand-over buffer
+        # the moments too (bands above the active degree decay with a zero gradient, as dense Adam has it)
+        for ga, gb in zip(pa.optimizer.param_groups, pb.optimizer.param_groups):
+            sa, sb = pa.optimizer.state[ga["params"][0]], pb.optimizer.state[gb["params"][0]]
+            assert torch.equal(sa["exp_avg"], sb["exp_avg"]) and torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"]), (it, ga["name"])
+    assert used == steps - 1              # every step after the first rendered from a hand-over buffer -- across the degree changes too
+    if up:
+        assert pa.active_sh_degree == 3
+    else:
+        # bands above the active degree received no gradient: untouched parameters, zero moments
+        nact = (d0 + 1) ** 2 - 1
+        assert torch.equal(pa._features_rest[:, nact:], sc["shs"][:, 1 + nact:].to(dev))
+        st = pa.optimizer.state[pa._features_rest]
+        assert float(st["exp_avg"][:, nact:].abs().sum()) == 0.0
+    # an un-announced degree change drops the buffer instead of rendering stale colours
+    if not up and d0 < 3:
+        ts.train_step(pa, views[0], gts[0], next_settings=views[0])
+        ts.train_step(pb, views[0], gts[0])
+        assert pa._prepared is not None
+        pa.oneup_sh_degree(); pb.oneup_sh_degree()
+        ka = ts.train_step(pa, views[0], gts[0], next_settings=views[0])
+        kb = ts.train_step(pb, views[0], gts[0])
+        assert torch.equal(ka["raw_image"], kb["raw_image"])
     # a render with a DIFFERENT camera does not pick the buffer up, and surgery drops it
     ts.train_step(pa, views[0], gts[0], next_settings=views[0])
     assert pa._prepared is not None
@@ -383,6 +422,74 @@ def _prepare_in_backward_case(N):
     pa.prune_points(torch.zeros(pa.num_points, dtype=torch.bool, device=dev))
     assert pa._prepared is None
     ts.train_step(pa, views[0], gts[0])
+
+
+def test_a_render_that_never_reaches_backward_leaves_the_optimizer_untouched():
+    """the in-kernel Adam step is PLANNED at render time and COUNTED when its backward runs.  A fused render under
+    torch.no_grad(), a render whose loss is discarded, and an exception between forward and backward must not advance the bias-
+    correction step; afterwards the fused step and a plain backward + step() on a twin model still agree."""
+    dev = torch.device("cuda:0")
+    W, H, N = 256, 192, 6000
+    sc = parity.syn.make_scene(N, W, H, sh_degree=3, seed=3)
+    st = ts.make_settings(sc, dev, 3)
+    gt = parity.syn.target_image(W, H, seed=1).to(dev)
+    pa, pb = ts.GaussianParams(sc, dev), ts.GaussianParams(sc, dev)
+    ts.train_step(pa, st, gt); ts.train_step(pb, st, gt, fused_optimizer=False)
+    assert pa.optimizer.step_count == 1 and pb.optimizer.step_count == 1
+    with torch.no_grad():                                        # a render that cannot have a backward
+        ts.render(pa, st, fused_activations=True, fused_adam=pa.optimizer)
+    pkg = ts.render(pa, st, fused_activations=True, fused_adam=pa.optimizer)     # a graph that is dropped
+    del pkg
+    assert pa.optimizer.step_count == 1 and not pa.optimizer._stepped_in_backward
+    pa.optimizer.step()                                          # nothing pending: a no-op, no complaint
+    for _ in range(2):
+        ts.train_step(pa, st, gt); ts.train_step(pb, st, gt, fused_optimizer=False)
+    assert pa.optimizer.step_count == 3 and pb.optimizer.step_count == 3
+    # (tolerance as in test_optimizer_in_backward_equals_backward_then_step: float atomics + eps 1e-15 turn the rounding noise of a
+    #  nearly cancelled gradient into a fraction of an lr step on a few elements; a step count off by one -- a wrong bias correction
+    #  1 / (1 - 0.9^t) at t = 2 instead of 3 -- would move EVERY element by 30 % of a step)
+    lrs = {g["name"]: g["lr"] for g in pa.optimizer.param_groups}
+    for name, k in ts.GaussianParams._GROUP_ATTR.items():
+        a, b = getattr(pa, k).detach(), getattr(pb, k).detach()
+        bad = ((a - b).abs() > 0.05 * lrs[name] + 5e-7 * b.abs()).float().mean().item()
+        assert bad < 1e-3, (k, bad)
+    # state_dict reports the reconciled count in torch's layout
+    sd = pa.optimizer.state_dict()
+    assert all(int(v["step"]) == 3 for v in sd["state"].values())
+
+
+def test_pose_step_between_prepare_and_consume_invalidates_the_hand_over():
+    """ADVICE r2: gsr::pose_step / pose_step_camera write the transform / camera tensors through raw pointers; they now bump the
+    tensors' version counters, so the staleness guards of train_step.render (`_same_transform`, `_camera_versions`) fire when a pose
+    moves between the backward that prepared a buffer and the forward that would consume it."""
+    dev = torch.device("cuda:0")
+    W, H, N = 256, 192, 5000
+    sc = parity.syn.make_scene(N, W, H, sh_degree=3, seed=9)
+    ident = ts.make_settings(sc, dev, 3)
+    gt = parity.syn.target_image(W, H, seed=1).to(dev)
+    # camera route
+    cps = ts.CameraPoseState(ident, torch.eye(4), dev, lr=1e-3)
+    v0 = ts._camera_versions(cps.settings)
+    pa = ts.GaussianParams(sc, dev)
+    ts.train_step(pa, cps.settings, gt, next_settings=cps.settings)          # prepares for the SAME camera tensors (no `pose=`: not stepped here)
+    assert pa._prepared is not None and pa._prepared["valid"]
+    pkg = ts.render(ts.GaussianParams(sc, dev, optimizer="torch"), cps.settings, fused_activations=True)
+    pkg["raw_image"].sum().backward()
+    cps.step()                                                               # the pose moves: versions change
+    assert ts._camera_versions(cps.settings) != v0
+    pb = ts.GaussianParams.from_raw(pa.raw(), dev)
+    ka = ts.render(pa, cps.settings, fused_activations=True)                 # must NOT use the stale buffer
+    kb = ts.render(pb, cps.settings, fused_activations=True)
+    assert pa._prepared is None
+    assert torch.equal(ka["raw_image"], kb["raw_image"])
+    # transform-of-the-means route
+    ps = ts.PoseState(torch.eye(4), dev, lr=1e-3)
+    tag = (ps.M.data_ptr(), ps.M._version)
+    leaf = ps.leaf()
+    pkg = ts.render(ts.GaussianParams(sc, dev, optimizer="torch"), ident, fused_activations=True, points_transform=leaf)
+    pkg["raw_image"].sum().backward()
+    ps.step()
+    assert not ts._same_transform(tag, ps.M)
 
 
 def test_pose_refinement_in_the_train_step_keeps_the_hand_over_exact():

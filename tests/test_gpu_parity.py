@@ -76,6 +76,14 @@ def test_parity_full_size(case):
     _run_case(*case[:7], color_only=True, ambig_max_frac=case[7])
 
 
+def test_parity_full_size_depth_alpha_gradients():
+    """The metric's workload (1 M @980x545) with upstream gradients on ALL three outputs: the HAS_DA backward blend and the
+    fork's depth / alpha terms against the oracle at full size (the other
+    full-size cases are colour-only, as the reference's loss is)."""
+    c = FULL[1]
+    _run_case(*c[:7], color_only=False, ambig_max_frac=c[7])
+
+
 def test_full_size_properties():
     """Size-independent properties at the metric's size (1M, 980x545):
     (1) alpha + final transmittance = 1: colour(bg=1) - colour(bg=0) == 1 - alpha per pixel;
@@ -154,7 +162,8 @@ def test_speculative_binning(hint):
         lib.gsr_set_option(b"binning_capacity_hint", 0)
 
 
-@pytest.mark.parametrize("case", [CASES[1], CASES[2], CASES[3], (300000, 980, 545, 3, True, "sh", (0.0, 0.0, 0.0))],
+@pytest.mark.parametrize("case", [CASES[1], CASES[2], CASES[3], (300000, 980, 545, 3, True, "sh", (0.0, 0.0, 0.0)),
+                                  (4000000, 980, 545, 3, True, "sh", (0.0, 0.0, 0.0))],     # BASELINE configs[4] as stated: 4 M, pose gradient on
                          ids=lambda c: f"{c[0]}-{c[1]}x{c[2]}-d{c[3]}-{c[5]}")
 def test_camera_gradients(case):
     """dL/d(viewmatrix, projmatrix, campos) (north_star's dL/dviewmatrix; BASELINE config 5: pose gradients)."""
@@ -164,7 +173,8 @@ def test_camera_gradients(case):
     kw = parity.scene_kwargs(sc, mode, bg=bg)
     o = binding.OracleRender(**kw)
     gc, gd, ga = parity.upstream_grads(H, W, seed=4)
-    rep, out, ref = parity.oracle_case(o, lambda g: hip_runner.run_hip(kw, g, cam_grad=True), (gc, gd, ga), "camera grads")
+    rep, out, ref = parity.oracle_case(o, lambda g: hip_runner.run_hip(kw, g, cam_grad=True), (gc, gd, ga), "camera grads",
+                                       ambig_max_frac=0.035 if N >= 4000000 else None)
     keys = ["viewmatrix", "projmatrix"] + (["campos"] if mode == "sh" else [])
     rep = parity.check_grads({k: out["grads"][k] for k in keys}, ref, "camera grads")
     # the ordinary gradients are unchanged by routing the camera through autograd
