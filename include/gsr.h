@@ -203,10 +203,11 @@ int gsr_version(void);
 
 /* Process-wide knobs (value 0 = default unless stated):
  *   "blend_fwd_ppt"        forward blend kernel: 7 = one wave per 8x8 sub-tile, finished pixels encoded in the sign of T,
- *                          instances the sub-tile cannot see skipped by reach bits (default); 6 = without the reach bits;
- *                          5 = the same decomposition with a lane mask; 1, 3, 4 = 256 / 128 / 64-thread tile kernels
- *                          (1, 2, 4 pixels per thread); 2 = packed two-pixel kernel
- *   "blend_bwd_ppt"        backward blend kernel: 2 = packed two-pixel kernel (default); 1, 3, 4 = scalar variants
+ *                          instances the sub-tile cannot see skipped by reach bits (default); 6 = without the reach bits.
+ *                          1-5 = the A/B kernels of csrc/variants.hip (tile-per-workgroup kernels, the packed two-pixel kernel,
+ *                          the lane-mask predecessor of the default): accepted only by a library built with -DGSR_AB_VARIANTS
+ *   "blend_bwd_ppt"        backward blend kernel: 2 = packed two-pixel kernel (default); 1, 3, 4 = scalar A/B kernels (variants.hip)
+ *   "ab_variants"          query: returns 1 when the library carries the A/B kernels, 0 otherwise (the value is ignored)
  *   "sort_algo"            2 = onesweep for both sorts (default); 1 = onesweep depth sort only; 0 = hist + scan + scatter
  *   "bwd_split"            workgroups the backward of one tile is split over (default 16; 1 = off): each part replays a
  *                          run of 128-instance batches, resuming from the per-pixel checkpoints the forward leaves at

@@ -120,14 +120,22 @@ def test_parity_color_loss_only(case):
     _run_case(*case, color_only=True)
 
 
+def _needs_ab_variants(lib, ppt):
+    """The non-default blend kernels (forward 1-5, backward 1 / 3 / 4) live in csrc/variants.hip, compiled into the library only with
+    -DGSR_AB_VARIANTS (GSR_AB_VARIANTS=1 python 3dgs_hierarchical_training_amd/build.py); the default build carries 6 and 7."""
+    if ppt in (1, 2, 3, 4, 5) and lib.gsr_set_option(b"ab_variants", 0) != 1:
+        pytest.skip("library built without -DGSR_AB_VARIANTS: the A/B blend kernels are not in it")
+
+
 @pytest.mark.parametrize("ppt", [1, 2, 3, 4, 5, 6, 7])
 def test_blend_variants_agree(ppt):
     import importlib
     L = importlib.import_module("3dgs_hierarchical_training_amd._lib")
     lib = L.load()
+    _needs_ab_variants(lib, ppt)
     try:
         assert lib.gsr_set_option(b"blend_fwd_ppt", ppt) == 0
-        assert lib.gsr_set_option(b"blend_bwd_ppt", min(ppt, 4)) == 0
+        assert lib.gsr_set_option(b"blend_bwd_ppt", min(ppt, 4) if ppt <= 5 else 2) == 0
         _run_case(20000, 330, 250, 3, True, "sh", (0.2, 0.3, 0.1))
     finally:
         lib.gsr_set_option(b"blend_fwd_ppt", 0)
@@ -753,6 +761,7 @@ def test_sign_encoded_forward_is_bit_identical_with_the_lane_mask_kernel():
     import hip_runner
     L = importlib.import_module("3dgs_hierarchical_training_amd._lib")
     lib = L.load()
+    _needs_ab_variants(lib, 5)
     sc = parity.syn.make_scene(300000, 980, 545, sh_degree=3, seed=5, posed=True)
     kw = parity.scene_kwargs(sc, "sh", bg=(0.3, 0.2, 0.1))
     outs = {}
