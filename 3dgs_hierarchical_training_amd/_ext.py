@@ -54,7 +54,7 @@ def _register_fakes():
     def _(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, sh_rest, viewmatrix, projmatrix, campos,
           bg, points_transform, image_height, image_width, tanfovx, tanfovy, scale_modifier, sh_degree, raw_params, prefiltered, debug,
           cam_grad, adam_m, adam_v, adam_lr, beta1, beta2, eps, step, prepared, next_viewmatrix, next_projmatrix, next_campos,
-          next_height, next_width, next_tanfovx, next_tanfovy, next_points_transform, next_sh_degree, adam_commit):
+          next_height, next_width, next_tanfovx, next_tanfovy, next_points_transform, next_sh_degree, adam_commit, densify_stats):
         N, H, W = means3D.shape[0], image_height, image_width
         f = lambda *s: means3D.new_empty(s, dtype=torch.float32)
         nprep = lib.gsr_prepared_bytes(int(N)) if next_viewmatrix.numel() else 0
@@ -64,7 +64,7 @@ def _register_fakes():
     @torch.library.register_fake("gsr::rasterize_backward")
     def _(means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, sh_rest, viewmatrix, projmatrix, campos, bg,
           points_transform, geom, image, binning, meta, grad_color, grad_depth, grad_alpha, image_height, image_width, tanfovx, tanfovy,
-          scale_modifier, sh_degree, raw_params, need_viewmatrix, need_projmatrix, need_campos, need_points_transform):
+          scale_modifier, sh_degree, raw_params, need_viewmatrix, need_projmatrix, need_campos, need_points_transform, densify_stats, radii):
         N = means3D.shape[0]
         f = lambda *s: means3D.new_empty(s, dtype=torch.float32)
         has = lambda t: t.numel() > 0
@@ -81,7 +81,7 @@ def _register_fakes():
           meta, grad_color, grad_depth, grad_alpha, image_height, image_width, tanfovx, tanfovy, scale_modifier, sh_degree,
           need_viewmatrix, need_projmatrix, need_campos, need_points_transform, adam_m, adam_v, adam_lr, beta1, beta2, eps, step,
           next_viewmatrix, next_projmatrix, next_campos, next_height, next_width, next_tanfovx, next_tanfovy, prepared_out,
-          next_points_transform, next_sh_degree):
+          next_points_transform, next_sh_degree, densify_stats, radii):
         f = lambda *s: means3D.new_empty(s, dtype=torch.float32)
         none = f(0)
         return [f(means3D.shape[0], 3), f(4, 4) if need_viewmatrix else none, f(4, 4) if need_projmatrix else none,

@@ -50,7 +50,7 @@ class GsrBackwardArgs(C.Structure):
         ("fused_adam", C.c_void_p),
         ("points_transform", C.c_void_p), ("d_points_transform", C.c_void_p),
         ("binning_capacity", C.c_int64), ("forward_flags", C.c_int64),
-        ("next_view", C.c_void_p), ("prepared_out", C.c_void_p),
+        ("next_view", C.c_void_p), ("prepared_out", C.c_void_p), ("densify_stats", C.c_void_p),
     ]
 
 

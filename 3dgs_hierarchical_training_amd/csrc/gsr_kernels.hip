@@ -1167,6 +1167,12 @@ struct PrepOut {
     DepthHist dh;
 };
 
+// Per-iteration densification statistics, accumulated by the per-Gaussian backward kernel (GsrDensifyStats, include/gsr.h)
+struct DensDev {
+    const int32_t* radii;
+    float *grad_accum, *denom, *max_radii;
+};
+
 struct AdamDev {
     float* m[6];
     float* v[6];
@@ -1303,7 +1309,7 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, in
                                                                 float* __restrict__ d_shs, float* __restrict__ d_shs_rest,
                                                                 float* __restrict__ d_scales,
                                                                 float* __restrict__ d_rots, float* __restrict__ d_cov,
-                                                                float* __restrict__ cam_partial, PrepOut po)
+                                                                float* __restrict__ cam_partial, PrepOut po, DensDev ds)
 {
     constexpr int NC3 = 3 * (DEG + 1) * (DEG + 1);
     __shared__ float s_sh[kPreThreads * kShStride];
@@ -1447,6 +1453,14 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, in
             for (int e = 0; e < NC3; e++) s_sh[tid * kShStride + e] = 0.f;
         }
         d_means2d[3 * (size_t)i] = m2d[0]; d_means2d[3 * (size_t)i + 1] = m2d[1]; d_means2d[3 * (size_t)i + 2] = 0.f;
+        if (ds.radii) {   // what the reference's train_step does with radii and means2D.grad after every backward
+            const int r = ds.radii[i];   // (ht3dgs_trainer.py:141-147, gaussian_model_ht.py:718-721): visible = radii > 0
+            if (r > 0) {
+                ds.max_radii[i] = fmaxf(ds.max_radii[i], (float)r);
+                ds.grad_accum[i] += sqrtf(m2d[0] * m2d[0] + m2d[1] * m2d[1]);
+                ds.denom[i] += 1.f;
+            }
+        }
         if (ADAM) {   // this thread is the only reader of its Gaussian's small rows, and it has read them
             const size_t gi = (size_t)i;
             adam_own<3>(const_cast<float*>(means) + 3 * gi, ad.m[0] + 3 * gi, ad.v[0] + 3 * gi, dmean, ad.step_size[0], ad, PREP >= 0 ? nmean : nullptr);
@@ -2325,6 +2339,12 @@ int gsr_backward(const GsrBackwardArgs* a, void* stream_)
         ad.inv_bc2s = 1.f / (float)sqrt(1.0 - pow((double)fa->beta2, (double)fa->step));
     } else if (!a->d_means3D || !a->d_opacities)
         return fail(GSR_ERR_ARG, "missing workspace / gradient pointer%s");
+    DensDev ds = {};
+    if (a->densify_stats) {
+        const GsrDensifyStats* q = a->densify_stats;
+        if (!q->radii || !q->xyz_gradient_accum || !q->denom || !q->max_radii2D) return fail(GSR_ERR_ARG, "densify_stats: four pointers expected%s");
+        ds.radii = q->radii; ds.grad_accum = q->xyz_gradient_accum; ds.denom = q->denom; ds.max_radii = q->max_radii2D;
+    }
     // "prepare in backward": the next render's preprocess rides in the per-Gaussian kernel (see GsrNextView)
     PrepOut po = {};
     const GsrNextView* nv = a->next_view;
@@ -2355,7 +2375,7 @@ int gsr_backward(const GsrBackwardArgs* a, void* stream_)
     hipLaunchKernelGGL((k_preprocess_bwd<DEG, RAW, CAM, ADAM, PREP>), dim3(grid), dim3(kPreThreads), 0, st, cp, N, a->means3D, a->scales,  \
                        a->rotations, a->cov3D_precomp, a->shs, a->shs_rest, a->opacities, ad, splat, gg, a->d_means3D, a->d_means2D,        \
                        a->d_opacities, a->d_colors_precomp, a->d_shs, a->d_shs_rest, a->d_scales, a->d_rotations, a->d_cov3D_precomp,      \
-                       cam_partial, po)
+                       cam_partial, po, ds)
 #define GSR_PREB(DEG)                                                     \
     do {                                                                  \
         if (fa) { if (want_cam) GSR_PREB_(DEG, true, true, true, -1); else GSR_PREB_(DEG, true, false, true, -1); }                 \

@@ -161,13 +161,27 @@ void fill_backward_args(GsrBackwardArgs& a, const BwdCommon& b, const Tensor& ge
     a.points_transform = fp(b.xf);
 }
 
+// densification statistics accumulated by the backward kernel (GsrDensifyStats): stats = {xyz_gradient_accum, denom, max_radii2D}
+// (N float32 elements each, updated in place), radii = the forward's int32 output.  Empty list = none.
+bool fill_densify(GsrDensifyStats& ds, at::TensorList stats, const Tensor& radii, int64_t N)
+{
+    if (stats.empty()) return false;
+    TORCH_CHECK(stats.size() == 3 && has(radii) && radii.scalar_type() == at::kInt && radii.numel() == N && radii.is_contiguous(),
+                "densify_stats: three statistics tensors and the forward's radii expected");
+    for (const Tensor& t : stats)
+        TORCH_CHECK(t.is_cuda() && t.scalar_type() == at::kFloat && t.is_contiguous() && t.numel() == N, "densify_stats: contiguous float32 tensors of N elements");
+    ds.radii = radii.data_ptr<int32_t>();
+    ds.xyz_gradient_accum = stats[0].data_ptr<float>(); ds.denom = stats[1].data_ptr<float>(); ds.max_radii2D = stats[2].data_ptr<float>();
+    return true;
+}
+
 // returns {d_means3D, d_means2D, d_sh, d_colors, d_opac, d_scales, d_rot, d_cov, d_sh_rest, d_vm, d_pm, d_campos, d_xf}
 std::vector<Tensor> rasterize_backward(
     const Tensor& means3D, const Tensor& sh, const Tensor& colors, const Tensor& opac, const Tensor& scales, const Tensor& rots,
     const Tensor& cov, const Tensor& rest, const Tensor& vm, const Tensor& pm, const Tensor& campos, const Tensor& bg, const Tensor& xf,
     const Tensor& geom, const Tensor& image, const Tensor& binning, const Tensor& meta, const Tensor& grad_color, const Tensor& grad_depth,
     const Tensor& grad_alpha, int64_t H, int64_t W, double tanfovx, double tanfovy, double scale_modifier, int64_t sh_degree,
-    bool raw_params, bool need_vm, bool need_pm, bool need_campos, bool need_xf)
+    bool raw_params, bool need_vm, bool need_pm, bool need_campos, bool need_xf, at::TensorList densify_stats, const Tensor& radii)
 {
     const c10::hip::HIPGuardMasqueradingAsCUDA guard(means3D.device());
     BwdCommon b{means3D, sh, colors, opac, scales, rots, cov, rest, vm, pm, campos, bg, xf, f32c(grad_color), f32c(grad_depth), f32c(grad_alpha)};
@@ -192,6 +206,8 @@ std::vector<Tensor> rasterize_backward(
     a.d_cov3D_precomp = fpm(d_cov); a.d_shs_rest = fpm(d_rest);
     a.d_viewmatrix = fpm(d_vm); a.d_projmatrix = fpm(d_pm); a.d_campos = fpm(d_cp); a.d_points_transform = fpm(d_xf);
     a.scratch = scratch.data_ptr();
+    GsrDensifyStats dstat{};
+    if (fill_densify(dstat, densify_stats, radii, N)) a.densify_stats = &dstat;
     check(gsr_backward(&a, c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()), "gsr_backward");
     return {d_means3D, d_means2D, d_sh, d_col, d_opac, d_scales, d_rot, d_cov, d_rest, d_vm, d_pm, d_cp, d_xf};
 }
@@ -205,7 +221,7 @@ std::vector<Tensor> rasterize_backward_fused(
     double scale_modifier, int64_t sh_degree, bool need_vm, bool need_pm, bool need_campos, bool need_xf, at::TensorList adam_m,
     at::TensorList adam_v, at::ArrayRef<double> adam_lr, double beta1, double beta2, double eps, int64_t step, const Tensor& next_vm,
     const Tensor& next_pm, const Tensor& next_campos, int64_t next_H, int64_t next_W, double next_tanfovx, double next_tanfovy,
-    Tensor prepared_out, const Tensor& next_xf, int64_t next_sh_degree)
+    Tensor prepared_out, const Tensor& next_xf, int64_t next_sh_degree, at::TensorList densify_stats, const Tensor& radii)
 {
     const c10::hip::HIPGuardMasqueradingAsCUDA guard(means3D.device());
     TORCH_CHECK(adam_m.size() == 6 && adam_v.size() == 6 && adam_lr.size() == 6, "fused_adam: six groups expected");
@@ -242,6 +258,8 @@ std::vector<Tensor> rasterize_backward_fused(
         a.next_view = &nv;
         a.prepared_out = prepared_out.data_ptr();
     }
+    GsrDensifyStats dstat{};
+    if (fill_densify(dstat, densify_stats, radii, N)) a.densify_stats = &dstat;
     check(gsr_backward(&a, c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()), "gsr_backward");
     return {d_means2D, d_vm, d_pm, d_cp, d_xf};
 }
@@ -256,6 +274,7 @@ struct Cfg {
     bool raw_params, prefiltered, debug, cam_grad;
     std::vector<double> adam_lr;
     std::vector<Tensor> adam_m, adam_v;   // optimizer moments: plain buffers, not autograd inputs
+    std::vector<Tensor> densify_stats;    // {xyz_gradient_accum, denom, max_radii2D} or empty: accumulated by the backward kernel
     Tensor adam_commit;                   // CPU int64 [1]: number of in-kernel Adam steps this optimizer's backwards have applied.  The
                                           // step count advances when a backward RUNS (a forward whose graph is dropped leaves no trace);
                                           // adam_step is the optimizer's step count at forward time, with adam_commit[0] as it was then
@@ -291,6 +310,8 @@ class RasterizeFn : public torch::autograd::Function<RasterizeFn> {
                                      std::get<7>(out)};
         ctx->save_for_backward(saved);
         ctx->saved_data["adam_m"] = cfg.adam_m; ctx->saved_data["adam_v"] = cfg.adam_v;
+        ctx->saved_data["dens"] = cfg.densify_stats;
+        ctx->saved_data["radii"] = cfg.densify_stats.empty() ? Tensor(at::empty({0}, m3.options().dtype(at::kInt))) : std::get<1>(out);
         ctx->saved_data["H"] = cfg.H; ctx->saved_data["W"] = cfg.W; ctx->saved_data["D"] = cfg.sh_degree;
         ctx->saved_data["tfx"] = cfg.tanfovx; ctx->saved_data["tfy"] = cfg.tanfovy; ctx->saved_data["smod"] = cfg.scale_modifier;
         ctx->saved_data["raw"] = cfg.raw_params; ctx->saved_data["cam_grad"] = cfg.cam_grad;
@@ -329,6 +350,8 @@ class RasterizeFn : public torch::autograd::Function<RasterizeFn> {
         Tensor e;
         auto orE = [&](const Tensor& t) { return t.defined() ? t : e; };
         Tensor d_xf;
+        std::vector<Tensor> dens = ctx->saved_data["dens"].toTensorVector();
+        const Tensor radii = ctx->saved_data["radii"].toTensor();
         if (n_adam) {
             // a second backward through the same forward would apply the optimizer step twice
             TORCH_CHECK(!ctx->saved_data["done"].toBool(), "fused_adam: backward() ran twice on the same render (retain_graph); the in-kernel "
@@ -347,13 +370,13 @@ class RasterizeFn : public torch::autograd::Function<RasterizeFn> {
                              ctx->saved_data["b1"].toDouble(), ctx->saved_data["b2"].toDouble(), ctx->saved_data["eps"].toDouble(),
                              step_now, nc[0], nc[1], nc[2], ctx->saved_data["next_H"].toInt(),
                              ctx->saved_data["next_W"].toInt(), ctx->saved_data["next_tfx"].toDouble(), ctx->saved_data["next_tfy"].toDouble(),
-                             ctx->saved_data["prep_out"].toTensor(), nc[3], ctx->saved_data["next_D"].toInt());
+                             ctx->saved_data["prep_out"].toTensor(), nc[3], ctx->saved_data["next_D"].toInt(), dens, radii);
             commit_p[0] += 1;   // the update has been enqueued: the optimizer's step count advances (FusedAdam reconciles from this)
             out[1] = r[0]; out[9] = r[1]; out[10] = r[2]; out[11] = r[3]; d_xf = r[4];
         } else {
             static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("gsr::rasterize_backward", "").typed<decltype(rasterize_backward)>();
             auto r = op.call(sv[0], sv[1], sv[2], sv[3], sv[4], sv[5], sv[6], sv[7], sv[8], sv[9], sv[10], sv[11], sv[12], sv[13], sv[14],
-                             sv[15], sv[16], orE(gc), orE(gd), orE(ga), H, W, tfx, tfy, smod, D, raw, need_vm, need_pm, need_cp, need_xf);
+                             sv[15], sv[16], orE(gc), orE(gd), orE(ga), H, W, tfx, tfy, smod, D, raw, need_vm, need_pm, need_cp, need_xf, dens, radii);
             out[0] = r[0]; out[1] = r[1]; out[2] = r[2]; out[3] = r[3]; out[4] = r[4]; out[5] = r[5]; out[6] = r[6]; out[7] = r[7]; out[8] = r[8];
             out[9] = r[9]; out[10] = r[10]; out[11] = r[11]; d_xf = r[12];
         }
@@ -370,11 +393,12 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> rasterize(
     bool prefiltered, bool debug, bool cam_grad, at::TensorList adam_m, at::TensorList adam_v, at::ArrayRef<double> adam_lr, double beta1,
     double beta2, double eps, int64_t step, const Tensor& prepared, const Tensor& next_vm, const Tensor& next_pm, const Tensor& next_campos,
     int64_t next_H, int64_t next_W, double next_tanfovx, double next_tanfovy, const Tensor& next_xf, int64_t next_sh_degree,
-    const Tensor& adam_commit)
+    const Tensor& adam_commit, at::TensorList densify_stats)
 {
     Cfg cfg{H, W, sh_degree, step, tanfovx, tanfovy, scale_modifier, beta1, beta2, eps, raw_params, prefiltered, debug, cam_grad,
             std::vector<double>(adam_lr.begin(), adam_lr.end()), adam_m.vec(), adam_v.vec()};
     if (has(prepared)) cfg.prepared = prepared;
+    cfg.densify_stats = densify_stats.vec();
     if (!adam_m.empty()) {
         TORCH_CHECK(has(adam_commit) && adam_commit.is_cpu() && adam_commit.scalar_type() == at::kLong, "fused_adam: adam_commit must be a CPU int64 tensor");
         cfg.adam_commit = adam_commit;
@@ -398,9 +422,9 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> rasterize_forward_only(
     bool prefiltered, bool debug, bool cam_grad, at::TensorList adam_m, at::TensorList adam_v, at::ArrayRef<double> adam_lr, double beta1,
     double beta2, double eps, int64_t step, const Tensor& prepared, const Tensor& next_vm, const Tensor& next_pm, const Tensor& next_campos,
     int64_t next_H, int64_t next_W, double next_tanfovx, double next_tanfovy, const Tensor& next_xf, int64_t next_sh_degree,
-    const Tensor& adam_commit)
+    const Tensor& adam_commit, at::TensorList densify_stats)
 {
-    (void)means2D; (void)next_xf; (void)next_sh_degree; (void)adam_commit; (void)cam_grad; (void)adam_m; (void)adam_v; (void)adam_lr; (void)beta1; (void)beta2; (void)eps; (void)step;
+    (void)means2D; (void)next_xf; (void)next_sh_degree; (void)adam_commit; (void)densify_stats; (void)cam_grad; (void)adam_m; (void)adam_v; (void)adam_lr; (void)beta1; (void)beta2; (void)eps; (void)step;
     (void)next_vm; (void)next_pm; (void)next_campos; (void)next_H; (void)next_W; (void)next_tanfovx; (void)next_tanfovy;
     auto out = rasterize_forward(means3D, sh, colors, opac, scales, rots, cov, rest, vm, pm, campos, bg, has(xf) ? xf.slice(0, 0, 3) : xf, H, W,
                                  tanfovx, tanfovy, scale_modifier, sh_degree, raw_params, prefiltered, debug, prepared);
@@ -569,20 +593,20 @@ TORCH_LIBRARY(gsr, m)
           "Tensor cov3D_precomp, Tensor sh_rest, Tensor viewmatrix, Tensor projmatrix, Tensor campos, Tensor bg, Tensor points_transform, "
           "Tensor geom, Tensor image, Tensor binning, Tensor meta, Tensor grad_color, Tensor grad_depth, Tensor grad_alpha, "
           "int image_height, int image_width, float tanfovx, float tanfovy, float scale_modifier, int sh_degree, bool raw_params, "
-          "bool need_viewmatrix, bool need_projmatrix, bool need_campos, bool need_points_transform) -> Tensor[]");
+          "bool need_viewmatrix, bool need_projmatrix, bool need_campos, bool need_points_transform, Tensor(a!)[] densify_stats, Tensor radii) -> Tensor[]");
     m.def("rasterize_backward_fused(Tensor(a!) means3D, Tensor(b!) sh, Tensor(c!) sh_rest, Tensor(d!) opacities, Tensor(e!) scales, "
           "Tensor(f!) rotations, Tensor viewmatrix, Tensor projmatrix, Tensor campos, Tensor bg, Tensor points_transform, Tensor geom, "
           "Tensor image, Tensor binning, Tensor meta, Tensor grad_color, Tensor grad_depth, Tensor grad_alpha, int image_height, "
           "int image_width, float tanfovx, float tanfovy, float scale_modifier, int sh_degree, bool need_viewmatrix, bool need_projmatrix, "
           "bool need_campos, bool need_points_transform, Tensor(g!)[] adam_m, Tensor(h!)[] adam_v, float[] adam_lr, float beta1, "
           "float beta2, float eps, int step, Tensor next_viewmatrix, Tensor next_projmatrix, Tensor next_campos, int next_height, "
-          "int next_width, float next_tanfovx, float next_tanfovy, Tensor(i!) prepared_out, Tensor next_points_transform, int next_sh_degree) -> Tensor[]");
+          "int next_width, float next_tanfovx, float next_tanfovy, Tensor(i!) prepared_out, Tensor next_points_transform, int next_sh_degree, Tensor(j!)[] densify_stats, Tensor radii) -> Tensor[]");
     m.def("rasterize(Tensor means3D, Tensor means2D, Tensor sh, Tensor colors_precomp, Tensor opacities, Tensor scales, Tensor rotations, "
           "Tensor cov3D_precomp, Tensor sh_rest, Tensor viewmatrix, Tensor projmatrix, Tensor campos, Tensor bg, Tensor points_transform, "
           "int image_height, int image_width, float tanfovx, float tanfovy, float scale_modifier, int sh_degree, bool raw_params, "
           "bool prefiltered, bool debug, bool cam_grad, Tensor[] adam_m, Tensor[] adam_v, float[] adam_lr, float beta1, float beta2, "
           "float eps, int step, Tensor prepared, Tensor next_viewmatrix, Tensor next_projmatrix, Tensor next_campos, int next_height, "
-          "int next_width, float next_tanfovx, float next_tanfovy, Tensor next_points_transform, int next_sh_degree, Tensor adam_commit) -> "
+          "int next_width, float next_tanfovx, float next_tanfovy, Tensor next_points_transform, int next_sh_degree, Tensor adam_commit, Tensor[] densify_stats) -> "
           "(Tensor, Tensor, Tensor, Tensor, Tensor)");
     m.def("mark_visible(Tensor means3D, Tensor viewmatrix, Tensor projmatrix) -> Tensor");
     m.def("photometric_loss_forward(Tensor render, Tensor target, float lambda_dssim, bool clamp) -> (Tensor, Tensor)");

@@ -75,6 +75,13 @@ class Densifier:
         self.xyz_gradient_accum += (g[:, :2].norm(dim=-1, keepdim=True)) * vis.unsqueeze(1)
         self.denom += vis.unsqueeze(1).to(self.denom.dtype)
 
+    def fused_stats(self, iteration: int):
+        """The three statistics tensors for the backward kernel to accumulate into (rasterize_gaussians_raw densify_stats), or
+        None when this iteration collects none (iteration >= densify_until_iter, ht3dgs_trainer.py:137)."""
+        if iteration >= self.cfg.densify_until_iter:
+            return None
+        return (self.xyz_gradient_accum, self.denom, self.max_radii2D)
+
     def _keep_stats(self, keep: torch.Tensor):
         self.xyz_gradient_accum = self.xyz_gradient_accum[keep]
         self.denom = self.denom[keep]
@@ -136,12 +143,14 @@ class Densifier:
 
     # ---- ht3dgs_trainer.py:137-155 -------------------------------------------------------------------------------------
     @torch.no_grad()
-    def after_backward(self, iteration: int, pkg) -> bool:
-        """Call between backward() and optimizer.step() (drop-in order).  Returns True when the model was resized."""
+    def after_backward(self, iteration: int, pkg, stats_done: bool = False) -> bool:
+        """Call between backward() and optimizer.step() (drop-in order).  Returns True when the model was resized.
+        stats_done: the backward kernel already accumulated this iteration's statistics (`fused_stats`)."""
         c = self.cfg
         if iteration >= c.densify_until_iter:
             return False
-        self.add_stats(pkg["viewspace_points"], pkg["visibility_filter"], pkg["radii"])
+        if not stats_done:
+            self.add_stats(pkg["viewspace_points"], pkg["visibility_filter"], pkg["radii"])
         resized = False
         if iteration > c.densify_from_iter and iteration % c.densification_interval == 0:
             size_threshold = 20 if iteration > c.opacity_reset_interval else None

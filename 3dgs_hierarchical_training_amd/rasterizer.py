@@ -302,7 +302,7 @@ def _ecpu():
 
 
 def _rasterize_ext(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, rs, sh_rest, raw_params,
-                   fused_adam, points_transform, prepared=None, prepare_next=None, next_points_transform=None):
+                   fused_adam, points_transform, prepared=None, prepare_next=None, next_points_transform=None, densify_stats=None):
     """torch.ops.gsr.rasterize: empty tensors stand for None; the camera tensors of the settings tuple are ordinary inputs
     (their gradients are produced when one of them requires grad)."""
     ops = E.load()
@@ -351,7 +351,8 @@ def _rasterize_ext(means3D, means2D, sh, colors_precomp, opacities, scales, rota
             0 if nx is None else int(nx.image_height), 0 if nx is None else int(nx.image_width),
             0.0 if nx is None else float(nx.tanfovx), 0.0 if nx is None else float(nx.tanfovy),
             e if (nx is None or next_points_transform is None) else next_points_transform.to(dev),
-            -1 if nx is None else int(nx.sh_degree), _ecpu() if commit is None else commit)
+            -1 if nx is None else int(nx.sh_degree), _ecpu() if commit is None else commit,
+            [] if densify_stats is None else list(densify_stats))
     if not rs.debug:
         out = ops.rasterize(*args)
         return out if prepare_next is not None else out[:4]
@@ -377,7 +378,7 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
 
 def rasterize_gaussians_raw(means3D, means2D, features_dc, features_rest, opacity_logit, log_scales, rotations_raw,
                             raster_settings, fused_adam=None, points_transform=None, prepared=None, prepare_next=None,
-                            next_points_transform=None):
+                            next_points_transform=None, densify_stats=None):
     """Extension ("next" row f-2): rasterize straight from HTGaussianModel's raw parameters (_xyz, _features_dc,
     _features_rest, _opacity, _scaling, _rotation; /root/reference/scene/gaussian_model_ht.py:74-82) with the
     activations of :49-65,128-133,176-188 fused into the HIP kernels; gradients are w.r.t. the raw tensors.
@@ -396,12 +397,18 @@ def rasterize_gaussians_raw(means3D, means2D, features_dc, features_rest, opacit
     buffer, valid once backward() has run -- is returned; hand it to the next call as `prepared=` together with the same
     settings and the (in-place updated) parameter tensors, and that forward skips its preprocess kernel with a bit-identical
     result.  The caller guarantees that nothing else modifies the parameters in between.  next_points_transform = the pose
-    transform of that next render when it is not this render's (per-frame poses under refinement)."""
+    transform of that next render when it is not this render's (per-frame poses under refinement).
+
+    densify_stats = (xyz_gradient_accum, denom, max_radii2D), float32 tensors of N elements: backward() then also accumulates
+    the per-iteration densification statistics of /root/reference/trainer/ht3dgs_trainer.py:141-147 and
+    /root/reference/scene/gaussian_model_ht.py:718-721 into them, inside the per-Gaussian backward kernel (include/gsr.h
+    GsrDensifyStats) -- no torch ops on N-sized tensors per step."""
     if not E.use_ctypes():
         return _rasterize_ext(means3D, means2D, features_dc, None, opacity_logit, log_scales, rotations_raw, None, raster_settings,
-                              features_rest, True, fused_adam, points_transform, prepared, prepare_next, next_points_transform)
-    if prepared is not None or prepare_next is not None:
-        raise RuntimeError("prepared / prepare_next are served by the PyTorch extension binding only")
+                              features_rest, True, fused_adam, points_transform, prepared, prepare_next, next_points_transform,
+                              densify_stats)
+    if prepared is not None or prepare_next is not None or densify_stats is not None:
+        raise RuntimeError("prepared / prepare_next / densify_stats are served by the PyTorch extension binding only")
     e = torch.Tensor([])
     return _RasterizeGaussians.apply(means3D, means2D, features_dc, e, opacity_logit, log_scales, rotations_raw, e,
                                      raster_settings, features_rest, True, *_cam_inputs(raster_settings), fused_adam, points_transform)

@@ -15,6 +15,7 @@ from typing import Dict
 import torch
 import torch.nn.functional as F
 
+from ._ext import use_ctypes as E_use_ctypes
 from .loss import fused_photometric_loss
 from .optim import FusedAdam
 from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer, rasterize_gaussians_raw
@@ -339,7 +340,7 @@ class CameraPoseState:
 
 def render(params: GaussianParams, settings: GaussianRasterizationSettings, clamp: bool = True,
            fused_activations: bool = False, fused_adam=None, next_settings: GaussianRasterizationSettings = None,
-           points_transform: torch.Tensor = None, next_points_transform: torch.Tensor = None) -> Dict:
+           points_transform: torch.Tensor = None, next_points_transform: torch.Tensor = None, densify_stats=None) -> Dict:
     """CF3DGS_Render.render with compute_cov3D_python = convert_SHs_python = False.
     fused_activations=True hands the raw parameters to the kernels (exp / sigmoid / normalize / cat in-kernel).
     next_settings (with fused_adam): the camera of the NEXT render of this model -- its preprocess then rides in this render's
@@ -366,7 +367,8 @@ def render(params: GaussianParams, settings: GaussianRasterizationSettings, clam
         out = rasterize_gaussians_raw(xyz, screenspace_points, params._features_dc, params._features_rest, params._opacity,
                                       params._scaling, params._rotation, settings, fused_adam=fused_adam, prepared=use,
                                       prepare_next=want_next, points_transform=points_transform,
-                                      next_points_transform=next_points_transform if want_next is not None else None)
+                                      next_points_transform=next_points_transform if want_next is not None else None,
+                                      densify_stats=densify_stats)
         if want_next is not None:        # filled by this render's backward; train_step marks it valid once that has run
             nxf = next_points_transform if next_points_transform is not None else points_transform
             params._prepared = {"buf": out[4], "settings": want_next, "n": xyz.shape[0], "xyz": params._xyz, "valid": False,
@@ -433,8 +435,11 @@ def train_step(params: GaussianParams, settings: GaussianRasterizationSettings, 
         nxt = with_sh_degree(nxt, ndeg) if ndeg in (deg, deg + 1) and ndeg <= 3 else None
     if pose is not None and nxt is not None and (next_pose is None or (next_pose is pose and not pose.frozen)):
         nxt = None               # the next render is of THIS frame, whose pose moves in between: no hand-over
+    # per-iteration densification statistics (max_radii2D, xyz_gradient_accum, denom: ht3dgs_trainer.py:141-147) accumulate inside
+    # the per-Gaussian backward kernel when the densifier offers its tensors (raw-parameter path through the extension)
+    dstats = densifier.fused_stats(iteration) if (densifier is not None and fused_activations and not E_use_ctypes()) else None
     pkg = render(params, settings, clamp=not fused_loss, fused_activations=fused_activations, fused_adam=fused_adam,
-                 next_settings=nxt, points_transform=xf,
+                 next_settings=nxt, points_transform=xf, densify_stats=dstats,
                  next_points_transform=next_pose.M if (xf is not None and next_pose is not None and nxt is not None) else None)
     if fused_loss:
         loss = fused_photometric_loss(pkg["raw_image"], gt, lambda_dssim, clamp=True)
@@ -451,7 +456,7 @@ def train_step(params: GaussianParams, settings: GaussianRasterizationSettings, 
     if pose is not None:
         pose.step()
     if densifier is not None:
-        densifier.after_backward(iteration, pkg)
+        densifier.after_backward(iteration, pkg, stats_done=dstats is not None)
     params.optimizer.step()
     params.optimizer.zero_grad(set_to_none=True)
     pkg["loss"] = loss.detach()

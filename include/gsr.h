@@ -135,6 +135,18 @@ typedef struct GsrNextView {
     const float* points_transform;                  /* device, 12 floats, or NULL */
 } GsrNextView;
 
+/* Per-iteration densification statistics, folded into the per-Gaussian backward kernel (it holds the screen-space gradient in
+ * registers).  What the reference's train_step does after every backward while iteration < densify_until_iter
+ * (/root/reference/trainer/ht3dgs_trainer.py:137-147, /root/reference/scene/gaussian_model_ht.py:718-721), for the visible
+ * Gaussians (radii > 0):  max_radii2D = max(max_radii2D, radii);  xyz_gradient_accum += |d_means2D[:, :2]|;  denom += 1.
+ * radii = the forward's int32 output; the three float arrays hold N elements each and are updated in place. */
+typedef struct GsrDensifyStats {
+    const int32_t* radii;
+    float* xyz_gradient_accum;
+    float* denom;
+    float* max_radii2D;
+} GsrDensifyStats;
+
 typedef struct GsrBackwardArgs {
     int32_t N, M, D, W, H;
     float scale_modifier, tanfovx, tanfovy;
@@ -175,6 +187,7 @@ typedef struct GsrBackwardArgs {
     int64_t forward_flags;    /* GsrForwardOut::forward_flags of the forward (0 = round-1 caller: process-wide options) */
     const struct GsrNextView* next_view; /* NULL = none; otherwise prepared_out must point at gsr_prepared_bytes(N) bytes */
     void* prepared_out;
+    const struct GsrDensifyStats* densify_stats; /* NULL = none */
 } GsrBackwardArgs;
 
 size_t gsr_geom_bytes(int32_t N);

@@ -173,6 +173,50 @@ def test_fused_adam_through_densification_matches_torch_adam(fused_optimizer):
     assert pa.optimizer.step_count == 8
 
 
+@pytest.mark.parametrize("fused_optimizer", [True, False], ids=["in-backward", "step"])
+def test_densification_statistics_from_the_backward_kernel(fused_optimizer):
+    """The per-iteration statistics of the reference's train_step (max_radii2D, xyz_gradient_accum, denom over the visible
+    Gaussians: ht3dgs_trainer.py:141-147, gaussian_model_ht.py:718-721) are accumulated by the per-Gaussian backward kernel
+    (GsrDensifyStats) and must equal what `Densifier.add_stats` -- the torch statement of the same lines -- makes of the same
+    step's radii and means2D.grad; `add_stats` itself no longer runs in the train step."""
+    dm = importlib.import_module("3dgs_hierarchical_training_amd.densify")
+    dev = torch.device("cuda:0")
+    W, H, N = 320, 240, 20011
+    sc = parity.syn.make_scene(N, W, H, sh_degree=3, seed=31, posed=True)
+    cam2 = parity.syn.make_scene(8, W, H, sh_degree=3, seed=6, posed=True)
+    sc2 = dict(sc)
+    for k in ("viewmatrix", "projmatrix", "campos"):
+        sc2[k] = cam2[k]
+    views = [ts.make_settings(sc, dev, 3), ts.make_settings(sc2, dev, 3)]
+    gt = parity.syn.target_image(W, H, seed=1).to(dev)
+    p = ts.GaussianParams(sc, dev)
+    cfg = dm.DensifyConfig(densify_from_iter=10 ** 9, opacity_reset_interval=10 ** 9)
+    den, ref = dm.Densifier(p, 5.0, cfg), dm.Densifier(p, 5.0, cfg)
+    calls = [0]
+    orig = dm.Densifier.add_stats
+
+    def counted(self, *a):
+        calls[0] += self is den
+        return orig(self, *a)
+    dm.Densifier.add_stats = counted
+    try:
+        for it in range(1, 7):
+            pkg = ts.train_step(p, views[it % 2], gt, densifier=den, iteration=it, fused_optimizer=fused_optimizer,
+                                next_settings=views[(it + 1) % 2])
+            ref.add_stats(pkg["viewspace_points"], pkg["visibility_filter"], pkg["radii"])
+    finally:
+        dm.Densifier.add_stats = orig
+    assert calls[0] == 0                                   # the train step launched no statistics ops of its own
+    assert int((ref.denom > 0).sum()) > N // 3
+    assert torch.equal(den.denom, ref.denom) and torch.equal(den.max_radii2D, ref.max_radii2D)
+    err = (den.xyz_gradient_accum - ref.xyz_gradient_accum).abs().max().item()
+    assert err <= 1e-6 * ref.xyz_gradient_accum.abs().max().item(), err
+    # past densify_until_iter nothing accumulates (ht3dgs_trainer.py:137)
+    den2 = dm.Densifier(p, 5.0, dm.DensifyConfig(densify_until_iter=3, densify_from_iter=10 ** 9, opacity_reset_interval=10 ** 9))
+    ts.train_step(p, views[0], gt, densifier=den2, iteration=5)
+    assert float(den2.denom.sum()) == 0.0
+
+
 def test_optimizer_in_backward_refuses_foreign_tensors():
     dev = torch.device("cuda:0")
     sc = parity.syn.make_scene(2000, 128, 96, sh_degree=3, seed=2)
