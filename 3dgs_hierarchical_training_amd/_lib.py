@@ -71,7 +71,7 @@ EXPORTS = [
     "gsr_sort_pairs_u16", "gsr_sort_scratch_bytes", "gsr_image_staged_offset", "gsr_profile_read",
     "gsr_loss_workspace_bytes", "gsr_loss_forward", "gsr_loss_backward", "gsr_adam_step", "gsr_pose_step", "gsr_pose_step_camera",
     "gsr_knn_scratch_bytes", "gsr_knn_mean_dist2", "gsr_get_counter", "gsr_debug_read_binning", "gsr_prepared_bytes",
-    "gsr_prepare_supported", "gsr_prepared_radii_offset",
+    "gsr_prepare_supported", "gsr_prepared_radii_offset", "gsr_stream_copy",
 ]
 
 _lib = None
@@ -132,6 +132,8 @@ def load():
     lib.gsr_version.restype = C.c_int
     lib.gsr_set_option.restype = C.c_int
     lib.gsr_set_option.argtypes = [C.c_char_p, C.c_int]
+    lib.gsr_stream_copy.restype = C.c_int
+    lib.gsr_stream_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
     lib.gsr_get_counter.restype = C.c_int64
     lib.gsr_get_counter.argtypes = [C.c_char_p]
     lib.gsr_debug_read_binning.restype = C.c_int

@@ -265,3 +265,41 @@ extern "C" int gsr_pose_step_camera(float* delta6, float* exp_avg6, float* exp_a
                        step > 0 ? 1 : 0);
     return hipGetLastError() == hipSuccess ? GSR_OK : GSR_ERR_HIP;
 }
+
+
+// ---- measurement hook: the practical HBM ceiling of the box -------------------------------------------------------------------
+// A float4 streaming copy (read + write), what bench.py reports as roofline.peak_measured next to the 8 TB/s vendor peak.
+// variant 0: plain 16-byte loads / stores, grid-stride; 1: the same with the nt bit; 2: four independent 16-byte loads in flight
+// per lane before the first store (nt): the form the per-Gaussian backward's moment streams use.
+namespace gsr {
+template <int VARIANT>
+__global__ __launch_bounds__(256) void k_stream_copy(const float4* __restrict__ src, float4* __restrict__ dst, size_t n4)
+{
+    const size_t stride = (size_t)gridDim.x * 256u;
+    size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (VARIANT == 2) {
+        for (; i + 3 * stride < n4; i += 4 * stride) {
+            const float4 a = nt_load4(src + i), b = nt_load4(src + i + stride), c = nt_load4(src + i + 2 * stride), d = nt_load4(src + i + 3 * stride);
+            nt_store4(dst + i, a); nt_store4(dst + i + stride, b); nt_store4(dst + i + 2 * stride, c); nt_store4(dst + i + 3 * stride, d);
+        }
+    }
+    for (; i < n4; i += stride) {
+        if (VARIANT == 0) dst[i] = src[i];
+        else nt_store4(dst + i, nt_load4(src + i));
+    }
+}
+}  // namespace gsr
+
+extern "C" int gsr_stream_copy(const void* src, void* dst, size_t bytes, int variant, int blocks, void* stream)
+{
+    if (!src || !dst || (bytes & 15) || (((uintptr_t)src | (uintptr_t)dst) & 15) || blocks <= 0) return GSR_ERR_ARG;
+    const size_t n4 = bytes / 16;
+    const float4* s = static_cast<const float4*>(src);
+    float4* d = static_cast<float4*>(dst);
+    hipStream_t st = (hipStream_t)stream;
+    if (variant == 0) hipLaunchKernelGGL(gsr::k_stream_copy<0>, dim3(blocks), dim3(256), 0, st, s, d, n4);
+    else if (variant == 1) hipLaunchKernelGGL(gsr::k_stream_copy<1>, dim3(blocks), dim3(256), 0, st, s, d, n4);
+    else if (variant == 2) hipLaunchKernelGGL(gsr::k_stream_copy<2>, dim3(blocks), dim3(256), 0, st, s, d, n4);
+    else return GSR_ERR_ARG;
+    return hipGetLastError() == hipSuccess ? GSR_OK : GSR_ERR_HIP;
+}

@@ -40,3 +40,33 @@ def fused_photometric_loss(render: torch.Tensor, target: torch.Tensor, lambda_ds
     if E.use_ctypes():
         return _FusedPhotometricLoss.apply(render, target, lambda_dssim, clamp)
     return E.load().photometric_loss(render, target, float(lambda_dssim), bool(clamp))
+
+
+class _FusedPhotometricTerms(torch.autograd.Function):
+    """The same op with its three results exposed: (loss, mean SSIM, mean L1).  Only `loss` carries a gradient."""
+
+    @staticmethod
+    def forward(ctx, render, target, lambda_dssim, clamp):
+        ops = E.load()
+        render = render.float().contiguous()
+        target = target.to(render.device).float().contiguous()
+        out, ws = ops.photometric_loss_forward(render, target, float(lambda_dssim), bool(clamp))
+        ctx.save_for_backward(render, target, ws)
+        ctx.cfg = (float(lambda_dssim), bool(clamp))
+        loss, ssim_v, l1_v = out[0], out[1], out[2]
+        ctx.mark_non_differentiable(ssim_v, l1_v)
+        return loss, ssim_v, l1_v
+
+    @staticmethod
+    def backward(ctx, grad_loss, _g_ssim, _g_l1):
+        render, target, ws = ctx.saved_tensors
+        lam, clamp = ctx.cfg
+        return E.load().photometric_loss_backward(render, target, ws, grad_loss.contiguous(), lam, clamp), None, None, None
+
+
+def fused_photometric_loss_terms(render: torch.Tensor, target: torch.Tensor, lambda_dssim: float = 0.2, clamp: bool = True):
+    """(loss, mean SSIM, mean L1): what `Loss.forward` of /root/reference/trainer/losses.py:98-136 reports as `loss`,
+    `1 - loss_dssim` and `loss_rgb / (1 - lambda)` -- one fused forward, one fused backward (gsr_autopatch.loss_forward)."""
+    if render.device.type != "cuda":
+        raise RuntimeError("fused_photometric_loss: tensors must be on a ROCm/HIP device (no CPU fallback)")
+    return _FusedPhotometricTerms.apply(render, target, lambda_dssim, clamp)

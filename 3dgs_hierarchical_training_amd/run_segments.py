@@ -325,7 +325,20 @@ class RankRunner:
         return tot / len(seg.frames)
 
     # ---- one rank's whole run (distributed) ----------------------------------------------------------------------------
-    def run(self, barrier=None):
+    def link_selftest(self, all_ok=None) -> bool:
+        """1 MB along every edge of the merge tree this rank takes part in, before any training (segments.link_selftest).
+        all_ok: callable(bool) -> bool that combines the ranks' verdicts (an all-reduce); every rank then leaves together."""
+        self.tr.rank = self.rank
+        st = segments.link_selftest(self.tr, self.schedule, self.dev)
+        good = st["ok"] if all_ok is None else all_ok(st["ok"])
+        self._emit({"phase": "link_selftest", **st, "all_ranks_ok": good})
+        if not good:
+            self._emit({"phase": "error", "error": "merge-tree link self-test failed", "pairs": [p for p in st["pairs"] if not p["ok"]]})
+        return good
+
+    def run(self, barrier=None, all_ok=None):
+        if not self.link_selftest(all_ok):
+            raise SystemExit(3)
         self.train_leaf()
         for k in range(len(self.schedule)):
             if barrier is not None:
@@ -446,7 +459,11 @@ def main():
     t0 = time.perf_counter()
     if a.stage_a:   # (gloo gathers host tensors; the table is tiny -- 192 bytes per pair)
         run_stage_a_on(seq, cfg, dev, a.stage_a, rank, world, gather_device=dev if a.backend == "nccl" else torch.device("cpu"))
-    rr.run(barrier=dist.barrier)
+    def all_ok(mine: bool) -> bool:
+        flag = torch.tensor([1.0 if mine else 0.0], device=dev if a.backend == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(flag.item() >= 1.0)
+    rr.run(barrier=dist.barrier, all_ok=all_ok)
     dist.barrier()
     if rank == 0:
         emit_line({"phase": "done", "world": world, "mode": a.backend, "gaussians": rr.seg.params.num_points,

@@ -107,6 +107,39 @@ def _sync(t: torch.Tensor):
         torch.cuda.synchronize(t.device)
 
 
+def link_selftest(tr, schedule: List[List[Tuple[int, int]]], device, nbytes: int = 1 << 20) -> Dict:
+    """Before the tree is walked: every merge pair of every level exchanges `nbytes` of a rank-dependent pattern in the direction
+    the merge will use (src -> dst) and echoes it back; both ends check what arrived.  Returns {'ok', 'pairs': [...], 'ms'} for
+    this rank; a mismatch names the pair (run_segments aborts with a JSON error line instead of training for minutes towards a
+    broken exchange).  Levels run one after the other, the pairs of a level concurrently -- the order of the merges themselves."""
+    import time
+    t0 = time.perf_counter()
+    n = nbytes // 4
+    idx = torch.arange(n, dtype=torch.int32, device=device)
+    pairs, ok = [], True
+    for lv, level in enumerate(schedule):
+        role = partner(tr.rank, level)
+        if role is None:
+            continue
+        kind, peer = role
+        src, dst = (tr.rank, peer) if kind == "send" else (peer, tr.rank)
+        want = idx * 31 + 7 * src + lv                  # what travels src -> dst
+        echo = want ^ 0x5a5a5a5a                          # and back
+        buf = torch.empty_like(idx)
+        if kind == "send":
+            tr.send(want, peer)
+            tr.recv(buf, peer)
+            good = bool(torch.equal(buf, echo))
+        else:
+            tr.recv(buf, peer)
+            good = bool(torch.equal(buf, want))
+            tr.send(buf ^ 0x5a5a5a5a, peer)
+        ok = ok and good
+        pairs.append({"level": lv, "src": src, "dst": dst, "ok": good})
+    _sync(idx)
+    return {"ok": ok, "pairs": pairs, "bytes": n * 4, "ms": 1e3 * (time.perf_counter() - t0)}
+
+
 # ---- the child message -----------------------------------------------------------------------------------------------
 def pack_segment(seg: Dict[str, torch.Tensor]) -> torch.Tensor:
     n = seg["_xyz"].shape[0]

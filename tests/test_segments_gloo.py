@@ -181,7 +181,13 @@ def _check_tree(world):
     assert rank0[1][1] == list(range(24)) and rank0[1][2] == 0 and rank0[1][3] == list(range(24))   # all frames, all poses chained
     for rank, final, log, steps, renders in res[1:]:
         assert final is None                           # every other rank handed its model up the tree
+    levels = world.bit_length() - 1
     for rank, final, log, steps, renders in res:
+        # before any training every rank tested each edge of the merge tree it takes part in (1 MB there and back)
+        st = [r for r in log if r["phase"] == "link_selftest"]
+        assert len(st) == 1 and st[0]["ok"] and log[0]["phase"] == "link_selftest"
+        n_edges = levels if rank == 0 else (rank & -rank).bit_length()      # rank r merges at levels 0 .. trailing-zeros(r)
+        assert len(st[0]["pairs"]) == n_edges and all(p["ok"] for p in st[0]["pairs"])
         merges = [r for r in log if r["phase"] == "merge"]
         for m in merges:
             if m["role"] == "src":                     # the child travels UN-pruned: 59 floats per Gaussian + 1 mask byte

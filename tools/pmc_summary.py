@@ -14,6 +14,14 @@ import os
 import sys
 
 
+def calib():
+    f = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", "r03_valu_calib.json")
+    try:
+        return json.load(open(f))["classes"]
+    except Exception:
+        return {"plain": 2.366, "double_pass": 4.296, "trans": 8.152}
+
+
 def main(d, out, note=""):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in sorted(glob.glob(os.path.join(d, "pass*", "*counter_collection.csv"))):
@@ -29,8 +37,19 @@ def main(d, out, note=""):
             m["hbm_write_bytes"] = m["WRITE_SIZE"] * 1024
             m["hbm_traffic_bytes"] = m["hbm_read_bytes_corrected"] + m["hbm_write_bytes"]
         if "SQ_INSTS_VALU" in m and "GRBM_GUI_ACTIVE" in m:
-            # 1024 SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs; a wave64 VALU op occupies its SIMD ~4 cycles
-            m["valu_issue_frac_est"] = (m["SQ_INSTS_VALU"] / 1024.0 * 4.0) / (m["GRBM_GUI_ACTIVE"] / 8.0)
+            # 1024 SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs.  Cost of a wave64 VALU instruction in SIMD cycles: CALIBRATED on
+            # this chip (tools/microbench/valu_calib.hip -> profiles/r03_valu_calib.json): ~2.3 for a full-rate op, ~8.2 for a
+            # transcendental (SQ_INSTS_VALU_TRANS).  Packed / DPP / f64 ops (~4.3) are not separable in the counters, so this is a
+            # LOWER bound of the vector pipe's busy fraction.  (Rounds 1-2 multiplied by an uncalibrated 4.0.)
+            cal = calib()
+            trans = m.get("SQ_INSTS_VALU_TRANS_F32", m.get("SQ_INSTS_VALU_TRANS", 0.0))
+            f64 = sum(m.get(c, 0.0) for c in ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_ADD_F64"))
+            cyc = (m["SQ_INSTS_VALU"] - trans - f64) * cal["plain"] + trans * cal["trans"] + f64 * cal["double_pass"]
+            m["valu_trans_instructions"], m["valu_f64_instructions"] = trans, f64
+            m["simd_cycles_available"] = m["GRBM_GUI_ACTIVE"] / 8.0
+            m["valu_pipe_cycles_per_simd_lower_bound"] = cyc / 1024.0
+            m["valu_issue_frac_est"] = (cyc / 1024.0) / (m["GRBM_GUI_ACTIVE"] / 8.0)
+            m["valu_cycles_per_instr_used"] = {"plain": cal["plain"], "trans": cal["trans"], "f64": cal["double_pass"]}
         res["kernels"][k] = m
     json.dump(res, open(out, "w"), indent=1, sort_keys=True)
     for k, m in res["kernels"].items():
