@@ -41,30 +41,35 @@ def _register_fakes():
     @torch.library.register_fake("gsr::rasterize_forward")
     def _(means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, sh_rest, viewmatrix, projmatrix, campos, bg,
           points_transform, image_height, image_width, tanfovx, tanfovy, scale_modifier, sh_degree, raw_params, prefiltered, debug,
-          prepared):
+          prepared, batch_first_block):
         N, H, W = means3D.shape[0], image_height, image_width
         f = lambda *s: means3D.new_empty(s, dtype=torch.float32)
         b = lambda n: means3D.new_empty((n,), dtype=torch.uint8)
         ctx = torch.library.get_ctx()
         nbin = ctx.new_dynamic_size()          # the binning buffer is R-sized: data dependent
-        return (f(3, H, W), means3D.new_empty((N,), dtype=torch.int32), f(1, H, W), f(1, H, W), b(lib.gsr_geom_bytes(int(N))),
-                b(lib.gsr_image_bytes(int(W), int(H))), b(nbin), torch.empty((3,), dtype=torch.int64))
+        B = len(batch_first_block) - 1 if len(batch_first_block) >= 3 else 1
+        lead = (B,) if B > 1 else ()
+        return (f(*lead, 3, H, W), means3D.new_empty((N,), dtype=torch.int32), f(*lead, 1, H, W), f(*lead, 1, H, W), b(lib.gsr_geom_bytes(int(N))),
+                b(lib.gsr_image_bytes_batched(int(W), int(H), B)), b(nbin), torch.empty((3,), dtype=torch.int64))
 
     @torch.library.register_fake("gsr::rasterize")
     def _(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, sh_rest, viewmatrix, projmatrix, campos,
           bg, points_transform, image_height, image_width, tanfovx, tanfovy, scale_modifier, sh_degree, raw_params, prefiltered, debug,
           cam_grad, adam_m, adam_v, adam_lr, beta1, beta2, eps, step, prepared, next_viewmatrix, next_projmatrix, next_campos,
-          next_height, next_width, next_tanfovx, next_tanfovy, next_points_transform, next_sh_degree, adam_commit, densify_stats):
+          next_height, next_width, next_tanfovx, next_tanfovy, next_points_transform, next_sh_degree, adam_commit, densify_stats, batch_first_block):
         N, H, W = means3D.shape[0], image_height, image_width
         f = lambda *s: means3D.new_empty(s, dtype=torch.float32)
         nprep = lib.gsr_prepared_bytes(int(N)) if next_viewmatrix.numel() else 0
-        return (f(3, H, W), means3D.new_empty((N,), dtype=torch.int32), f(1, H, W), f(1, H, W),
+        B = len(batch_first_block) - 1 if len(batch_first_block) >= 3 else 1
+        lead = (B,) if B > 1 else ()
+        return (f(*lead, 3, H, W), means3D.new_empty((N,), dtype=torch.int32), f(*lead, 1, H, W), f(*lead, 1, H, W),
                 means3D.new_empty((nprep,), dtype=torch.uint8))
 
     @torch.library.register_fake("gsr::rasterize_backward")
     def _(means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, sh_rest, viewmatrix, projmatrix, campos, bg,
           points_transform, geom, image, binning, meta, grad_color, grad_depth, grad_alpha, image_height, image_width, tanfovx, tanfovy,
-          scale_modifier, sh_degree, raw_params, need_viewmatrix, need_projmatrix, need_campos, need_points_transform, densify_stats, radii):
+          scale_modifier, sh_degree, raw_params, need_viewmatrix, need_projmatrix, need_campos, need_points_transform, densify_stats, radii,
+          batch_first_block):
         N = means3D.shape[0]
         f = lambda *s: means3D.new_empty(s, dtype=torch.float32)
         has = lambda t: t.numel() > 0
@@ -81,7 +86,7 @@ def _register_fakes():
           meta, grad_color, grad_depth, grad_alpha, image_height, image_width, tanfovx, tanfovy, scale_modifier, sh_degree,
           need_viewmatrix, need_projmatrix, need_campos, need_points_transform, adam_m, adam_v, adam_lr, beta1, beta2, eps, step,
           next_viewmatrix, next_projmatrix, next_campos, next_height, next_width, next_tanfovx, next_tanfovy, prepared_out,
-          next_points_transform, next_sh_degree, densify_stats, radii):
+          next_points_transform, next_sh_degree, densify_stats, radii, batch_first_block):
         f = lambda *s: means3D.new_empty(s, dtype=torch.float32)
         none = f(0)
         return [f(means3D.shape[0], 3), f(4, 4) if need_viewmatrix else none, f(4, 4) if need_projmatrix else none,
@@ -107,8 +112,9 @@ def _register_fakes():
 
     @torch.library.register_fake("gsr::photometric_loss_forward")
     def _(render, target, lambda_dssim, clamp):
-        C, H, W = render.shape
-        return render.new_empty((3,), dtype=torch.float32), render.new_empty((lib.gsr_loss_workspace_bytes(int(C), int(H), int(W)),), dtype=torch.uint8)
+        C, H, W = render.shape[-3:]
+        B = render.shape[0] if render.dim() == 4 else 1
+        return render.new_empty((3,), dtype=torch.float32), render.new_empty((lib.gsr_loss_workspace_bytes(int(B * C), int(H), int(W)),), dtype=torch.uint8)
 
     @torch.library.register_fake("gsr::photometric_loss")
     def _(render, target, lambda_dssim, clamp):

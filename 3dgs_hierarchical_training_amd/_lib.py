@@ -24,7 +24,7 @@ class GsrForwardArgs(C.Structure):
         ("geom", C.c_void_p), ("image", C.c_void_p),
         ("alloc", ALLOC_FN), ("alloc_user", C.c_void_p),
         ("shs_rest", C.c_void_p), ("raw_params", C.c_int32),
-        ("points_transform", C.c_void_p), ("prepared", C.c_void_p),
+        ("points_transform", C.c_void_p), ("prepared", C.c_void_p), ("batch", C.c_void_p),
     ]
 
 
@@ -50,7 +50,7 @@ class GsrBackwardArgs(C.Structure):
         ("fused_adam", C.c_void_p),
         ("points_transform", C.c_void_p), ("d_points_transform", C.c_void_p),
         ("binning_capacity", C.c_int64), ("forward_flags", C.c_int64),
-        ("next_view", C.c_void_p), ("prepared_out", C.c_void_p), ("densify_stats", C.c_void_p),
+        ("next_view", C.c_void_p), ("prepared_out", C.c_void_p), ("densify_stats", C.c_void_p), ("batch", C.c_void_p),
     ]
 
 
@@ -71,7 +71,8 @@ EXPORTS = [
     "gsr_sort_pairs_u16", "gsr_sort_scratch_bytes", "gsr_image_staged_offset", "gsr_profile_read",
     "gsr_loss_workspace_bytes", "gsr_loss_forward", "gsr_loss_backward", "gsr_adam_step", "gsr_pose_step", "gsr_pose_step_camera",
     "gsr_knn_scratch_bytes", "gsr_knn_mean_dist2", "gsr_get_counter", "gsr_debug_read_binning", "gsr_prepared_bytes",
-    "gsr_prepare_supported", "gsr_prepared_radii_offset", "gsr_stream_copy",
+    "gsr_prepare_supported", "gsr_prepared_radii_offset", "gsr_stream_copy", "gsr_image_bytes_batched",
+    "gsr_loss_workspace_bytes_batched", "gsr_loss_forward_batched", "gsr_loss_backward_batched",
 ]
 
 _lib = None
@@ -94,6 +95,8 @@ def load():
         getattr(lib, fn).argtypes = [C.c_int32]
     lib.gsr_image_bytes.restype = C.c_size_t
     lib.gsr_image_bytes.argtypes = [C.c_int32, C.c_int32]
+    lib.gsr_image_bytes_batched.restype = C.c_size_t
+    lib.gsr_image_bytes_batched.argtypes = [C.c_int32, C.c_int32, C.c_int32]
     lib.gsr_image_staged_offset.restype = C.c_size_t
     lib.gsr_image_staged_offset.argtypes = [C.c_int32, C.c_int32]
     lib.gsr_profile_read.restype = C.c_int

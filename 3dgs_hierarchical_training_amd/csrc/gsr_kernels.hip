@@ -99,12 +99,38 @@ struct ProfScope {
     }
 };
 
+// Batched rendering of independent models (GsrBatch, include/gsr.h): B models live in ONE parameter store, model b owning the
+// 128-Gaussian blocks [first_block[b], first_block[b + 1]), each with its own camera (viewmatrix / projmatrix / campos /
+// points_transform are arrays of B entries) and its own W x H image.  The B images are handled as one "tall" image of
+// B * tiles_y tile rows: tile id = b * T + local tile, so a tile's list only ever holds Gaussians of its own model and ONE
+// global depth sort orders every model's lists at once.  B <= 1 = the ordinary single-model render.
+constexpr int kMaxBatch = 16;
+struct BatchDev {
+    int B;
+    int first_block[kMaxBatch + 1];
+};
+
 struct CamParams {
     const float *vm, *pm, *campos;
     float tanfovx, tanfovy, scale_mod;
     int W, H, D, M;
     const float* xf;   // optional rigid / affine transform of the means (3x4 row-major), see GsrForwardArgs::points_transform
+    BatchDev bt;
 };
+
+// Which model a 128-Gaussian block belongs to; moves the camera pointers of `p` (a kernel's own copy) to that model's entries.
+// Block-uniform: scalar compares against kernel arguments.
+__device__ __forceinline__ int select_view(CamParams& p, int block)
+{
+    if (p.bt.B <= 1) return 0;
+    int b = 0;
+#pragma unroll
+    for (int q = 1; q < kMaxBatch; q++) b += (q < p.bt.B && block >= p.bt.first_block[q]) ? 1 : 0;
+    p.vm += 16 * b; p.pm += 16 * b;
+    if (p.campos) p.campos += 3 * b;
+    if (p.xf) p.xf += 12 * b;
+    return b;
+}
 
 // p' = M [p; 1]: the in-kernel form of `P.retr().act(xyz)` (/root/reference/scene/gaussian_model_ht.py:135-148)
 __device__ __forceinline__ void apply_points_transform(const float* __restrict__ xf, float m[3])
@@ -351,6 +377,7 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess(CamParams cp, int N,
     const int tid = threadIdx.x;
     const int base = ((int)blockIdx.x + block0) * kPreThreads;   // block0: first block of a partial launch (0 = the whole cloud)
     const int i = base + tid;
+    const int model = select_view(cp, (int)blockIdx.x + block0);   // batched render: this block's model and its camera
     if (blockIdx.x == 0)   // rides along: clear the head of the depth sort's scratch (saves a fill launch)
         for (int q = tid; q < zero_count; q += kPreThreads) zero_words[q] = 0u;
     // ---- phase 0: SH rows.  Dense, aligned rows (the normal case) are only LOADED here -- into registers; the geometry
@@ -424,6 +451,7 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess(CamParams cp, int N,
         preprocess_one(cam, mean, sc, rq, cov_pre ? cv : nullptr, op, nullptr, 3, 1, colors ? colp : nullptr, s, &rec, true);
     }
     count_large_rects(act, s, rec, cp.W, cp.H, cam.tiles_x, cam.tiles_y, tid);
+    rec.rect += (uint32_t)(model * cam.tiles_y) << 12;   // tile rows of model b start at b * tiles_y in the batch's tall tile grid
     // ---- phase 2: rows into the LDS tile, then the colour of the Gaussians that survived the culls
     if (shs) {
         constexpr bool kLinOk = NC3 > 3 && (NR & 1);
@@ -698,6 +726,7 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit(int N, int W, int H, int 
         const Splat s = splat[gg];
         int x0, y0, x1, y1;
         tile_rect_tight(s.px, s.py, s.radius, s.ca, s.cb, s.cc, s.op, W, H, tiles_x, tiles_y, x0, y0, x1, y1);   // as k_preprocess
+        const int vrow0 = (int)((s_rec[idx].rect >> 12) & 0xfffu) - y0;   // batched render: first tile row of this Gaussian's model (0 otherwise)
         const int ww = x1 - x0, full = ww * (y1 - y0);
         const TileTest tt = make_tile_test(s.px, s.py, s.ca, s.cb, s.cc, s.op);
         uint32_t run = base + (idx ? s_incl[idx - 1] : 0u);
@@ -714,7 +743,7 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit(int N, int W, int H, int 
             if (ok) {
                 const uint32_t o = run + (uint32_t)__popcll(m & lt);
                 if (o < cap) {
-                    const uint32_t key = (uint32_t)(gy * tiles_x + gx);
+                    const uint32_t key = (uint32_t)((gy + vrow0) * tiles_x + gx);
                     out_tile[o] = (KeyT)key;
                     out_gid[o] = gg;
                     if (hist) count_key(key, o);
@@ -789,7 +818,7 @@ __global__ __launch_bounds__(64) void k_blend_fwd_w6(int W, int H, int tiles_x, 
                                                      const float* __restrict__ bg, float* __restrict__ out_color,
                                                      float* __restrict__ out_depth, float* __restrict__ out_alpha,
                                                      float* __restrict__ img, uint32_t* __restrict__ staged4, int interleave,
-                                                     float* __restrict__ ckpt, int kCkptFirst)
+                                                     float* __restrict__ ckpt, int kCkptFirst, int tiles_y)
 {
     constexpr int NT = 64;
     __shared__ float4 s_a[2][NT], s_b[2][NT];
@@ -799,7 +828,9 @@ __global__ __launch_bounds__(64) void k_blend_fwd_w6(int W, int H, int tiles_x, 
     const int sub = kslot & 3;
     if (tile < 0) return;
     const int lane = threadIdx.x;
-    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    // batched render: T = B tiles_x tiles_y tiles of a tall grid, image `bimg` owns the tile rows [bimg tiles_y, (bimg + 1) tiles_y)
+    const int Tl = tiles_x * tiles_y, bimg = tile / Tl, tl = tile - bimg * Tl;
+    const int tx = tl % tiles_x, ty = tl / tiles_x;
     const int px = tx * kTile + (sub & 1) * 8 + (lane & 7);
     const int py = ty * kTile + (sub >> 1) * 8 + (lane >> 3);
     const float pxf = (float)px - 0.5f * (float)W, pyf = (float)py - 0.5f * (float)H;
@@ -886,15 +917,16 @@ __global__ __launch_bounds__(64) void k_blend_fwd_w6(int W, int H, int tiles_x, 
     }
     if (lane == 0) staged4[tile * 4 + sub] = (uint32_t)min(n, batches * NT);
     if (inside) {
-        const size_t P = (size_t)W * H, pid = (size_t)py * W + px;
+        const size_t Pl = (size_t)W * H, P = Pl * (size_t)(T / Tl), pl = (size_t)py * W + px, pid = (size_t)bimg * Pl + pl;
         const float Tf = fabsf(Tr);
         img[pid] = Tf;
         reinterpret_cast<uint32_t*>(img)[P + pid] = last;
         img[2 * P + pid] = C0; img[3 * P + pid] = C1; img[4 * P + pid] = C2;
         img[5 * P + pid] = Dd; img[6 * P + pid] = Aa;
-        out_color[pid] = C0 + Tf * bg[0];
-        out_color[P + pid] = C1 + Tf * bg[1];
-        out_color[2 * P + pid] = C2 + Tf * bg[2];
+        float* oc = out_color + (size_t)bimg * 3 * Pl + pl;   // outputs: [B, 3, H, W], [B, 1, H, W]
+        oc[0] = C0 + Tf * bg[0];
+        oc[Pl] = C1 + Tf * bg[1];
+        oc[2 * Pl] = C2 + Tf * bg[2];
         out_depth[pid] = Dd;
         out_alpha[pid] = Aa;
     }
@@ -919,7 +951,7 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(int W, int H, int tiles_x, i
                                                     const float* __restrict__ g_alpha, float* __restrict__ ggrad, int interleave,
                                                     const float* __restrict__ ckpt, int split, int kCkptFirst,
                                                     const uint32_t* __restrict__ staged4, int tpad, float* __restrict__ det_part,
-                                                    uint32_t* __restrict__ zero_words, int zero_count)
+                                                    uint32_t* __restrict__ zero_words, int zero_count, int tiles_y)
 {
     constexpr int NT = 128, NW = 2, NV = HAS_DA ? 10 : 9;
     // (prepare in backward: workgroup 0 clears the digit counters that the per-Gaussian kernel behind this one adds into)
@@ -936,14 +968,19 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(int W, int H, int tiles_x, i
     const int tile = slot_tile(interleave, tb & 7, tb >> 3, T, tiles_x);   // see k_blend_fwd_w
     if (tile < 0) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const int Tl = tiles_x * tiles_y, bimg = tile / Tl, tl = tile - bimg * Tl;   // batched render: see k_blend_fwd_w6
+    const int tx = tl % tiles_x, ty = tl / tiles_x;
     const int px = tx * kTile + (tid & 15);
     const int py0 = ty * kTile + (tid >> 4) * 2;
     const float pxf = (float)px - 0.5f * (float)W;   // centred pixel coordinates (see Splat)
     const float cyf = 0.5f * (float)H;
     const f2 pyf = {(float)py0 - cyf, (float)(py0 + 1) - cyf};
     const uint2 rg = ranges[tile];
-    const size_t P = (size_t)W * H;
+    const size_t Pl = (size_t)W * H, P = Pl * (size_t)(T / Tl);
+    img += (size_t)bimg * Pl;                       // this image's slice of every state plane (planes are P apart)
+    if (g_color) g_color += (size_t)bimg * 3 * Pl;  // upstream gradients: [B, 3, H, W], [B, 1, H, W]
+    if (g_depth) g_depth += (size_t)bimg * Pl;
+    if (g_alpha) g_alpha += (size_t)bimg * Pl;
     // this workgroup's share of the tile's 128-instance batches, decided from the forward's per-sub-tile staged depths
     // (an upper bound of every pixel's last contributor that all parts of the tile see alike) before anything else is
     // loaded: part 0 takes the first kCkptFirst batches, the rest is divided evenly over parts 1..split-1, each of
@@ -975,7 +1012,7 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(int W, int H, int tiles_x, i
         if (px < W && py < H) {
             const size_t pid = (size_t)py * W + px;
             ncon[p] = reinterpret_cast<const uint32_t*>(img)[P + pid];
-            if (g_color) { gC0[p] = g_color[pid]; gC1[p] = g_color[P + pid]; gC2[p] = g_color[2 * P + pid]; }
+            if (g_color) { gC0[p] = g_color[pid]; gC1[p] = g_color[Pl + pid]; gC2[p] = g_color[2 * Pl + pid]; }
             float s = gC0[p] * img[2 * P + pid] + gC1[p] * img[3 * P + pid] + gC2[p] * img[4 * P + pid];
             if (HAS_DA) {
                 if (g_depth) gD[p] = g_depth[pid];
@@ -1320,6 +1357,7 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, in
     const int base = blockIdx.x * kPreThreads;
     const int i = base + tid;
     const int nG = min(kPreThreads, N - base);
+    select_view(cp, (int)blockIdx.x);   // batched render: this block's model and its camera
     CamGrads cg;
     float xg[12];   // dL/d(points_transform) share of this thread
     if (CAM) {
@@ -1524,6 +1562,7 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, in
             // Same functions, same order of operations as k_preprocess<PREP, true>: the records are bit-identical.
             __syncthreads();
             const bool act = i < N;
+            const int model2 = select_view(po.cp, (int)blockIdx.x);
             Camera cam2 = load_camera(po.cp);
             cam2.D = PREP < 0 ? 0 : PREP;
             Splat s2;
@@ -1541,6 +1580,7 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, in
                 preprocess_one(cam2, mean2, sc2, rq2, nullptr, op2, nullptr, 3, 1, nullptr, s2, &rec2, true);
             }
             count_large_rects(act, s2, rec2, po.cp.W, po.cp.H, cam2.tiles_x, cam2.tiles_y, tid);
+            rec2.rect += (uint32_t)(model2 * cam2.tiles_y) << 12;   // (as k_preprocess)
             if (act && s2.radius > 0) {
                 float col[3];
                 splat_sh_color(cam2, mean2, s_rest + tid * NRL - 3, 3, 1, col, s_dc + tid * 3);
@@ -1651,14 +1691,25 @@ __global__ __launch_bounds__(256) void k_det_reduce(uint32_t R, const uint32_t* 
     for (int r = 0; r < kDetStride; r++) ggrad[(size_t)g * kGG + r] = acc[r];
 }
 
-// one block per camera entry: deterministic sum of the per-block partials
+// one block per camera entry (and, batched, per model: blockIdx.y, over that model's blocks): deterministic sum of the partials
 __global__ __launch_bounds__(256) void k_cam_reduce(const float* __restrict__ partial, int nblocks, float* __restrict__ d_vm,
-                                                    float* __restrict__ d_pm, float* __restrict__ d_campos, float* __restrict__ d_xf)
+                                                    float* __restrict__ d_pm, float* __restrict__ d_campos, float* __restrict__ d_xf,
+                                                    BatchDev bt)
 {
     __shared__ double s[256];
-    const int q = blockIdx.x;
+    const int q = blockIdx.x, m = blockIdx.y;
+    int lo = 0, hi = nblocks;
+    if (bt.B > 1) {
+#pragma unroll
+        for (int k = 0; k < kMaxBatch; k++)
+            if (k == m) { lo = bt.first_block[k]; hi = min(nblocks, bt.first_block[k + 1]); }
+        if (d_vm) d_vm += 16 * m;
+        if (d_pm) d_pm += 16 * m;
+        if (d_campos) d_campos += 3 * m;
+        if (d_xf) d_xf += 12 * m;
+    }
     double a = 0;
-    for (int b = threadIdx.x; b < nblocks; b += 256) a += partial[(size_t)b * kCamVals + q];
+    for (int b = lo + threadIdx.x; b < hi; b += 256) a += partial[(size_t)b * kCamVals + q];
     s[threadIdx.x] = a;
     __syncthreads();
     for (int off = 128; off > 0; off >>= 1) {
@@ -1732,9 +1783,9 @@ static FwdScratch fwd_scratch_layout(int32_t N)
 struct BinLayout {   // persistent: list + ranges + checkpoints of long lists
     size_t list, ranges, ckpt, bytes;
 };
-static BinLayout bin_layout(int64_t R, int32_t W, int32_t H)
+static BinLayout bin_layout(int64_t R, int32_t W, int32_t H, int32_t B = 1)
 {
-    const size_t T = (size_t)((W + kTile - 1) / kTile) * ((H + kTile - 1) / kTile);
+    const size_t T = (size_t)((W + kTile - 1) / kTile) * ((H + kTile - 1) / kTile) * (size_t)(B > 1 ? B : 1);
     BinLayout b;
     b.ranges = 0;
     b.list = align256((T ? T : 1) * sizeof(uint2));
@@ -1820,6 +1871,25 @@ static inline int64_t pack_fwd_flags(int ppt, int tile_map, int ckpt_first)
     return 1 | ((int64_t)ppt << 1) | ((int64_t)tile_map << 4) | ((int64_t)ckpt_first << 6) | ((int64_t)(ppt >= 5) << 13);
 }
 
+// GsrBatch -> the kernels' BatchDev; validates the block table against N.  nullptr / B <= 1: single model.
+static int batch_dev(const GsrBatch* bt, int32_t N, int32_t H, BatchDev& out)
+{
+    out = BatchDev{};
+    out.B = 1;
+    if (!bt || bt->B <= 1) return GSR_OK;
+    if (bt->B > kMaxBatch || !bt->first_block) return fail(GSR_ERR_ARG, "batch: 2..16 models and a first_block table expected%s");
+    const int nblocks = (N + kPreThreads - 1) / kPreThreads;
+    if (bt->first_block[0] != 0 || bt->first_block[bt->B] != nblocks || (N % kPreThreads) != 0)
+        return fail(GSR_ERR_ARG, "batch: first_block must run from 0 to N / 128 and N must be a multiple of 128 (pad every model)%s");
+    for (int q = 0; q < bt->B; q++)
+        if (bt->first_block[q + 1] < bt->first_block[q]) return fail(GSR_ERR_ARG, "batch: first_block must be non-decreasing%s");
+    if ((long long)bt->B * ((H + kTile - 1) / kTile) > 4095) return fail(GSR_ERR_RANGE, "batch: more than 4095 tile rows in total%s");
+    out.B = bt->B;
+    for (int q = 0; q <= bt->B; q++) out.first_block[q] = bt->first_block[q];
+    for (int q = bt->B + 1; q <= kMaxBatch; q++) out.first_block[q] = nblocks;
+    return GSR_OK;
+}
+
 static int check_common(int32_t N, int32_t M, int32_t D, int32_t W, int32_t H)
 {
     if (N < 0 || W <= 0 || H <= 0) return fail(GSR_ERR_ARG, "bad sizes%s");
@@ -1836,15 +1906,15 @@ using namespace gsr;
 
 extern "C" {
 
-size_t gsr_image_staged_offset(int32_t W, int32_t H);
-
 size_t gsr_geom_bytes(int32_t N) { return geom_layout(N).total; }
-size_t gsr_image_staged_offset(int32_t W, int32_t H) { return align256((size_t)W * H * kImgPlanes * 4); }
-size_t gsr_image_bytes(int32_t W, int32_t H)
+static size_t image_staged_offset(int32_t W, int32_t H, int32_t B) { return align256((size_t)W * H * (size_t)(B > 1 ? B : 1) * kImgPlanes * 4); }
+size_t gsr_image_staged_offset(int32_t W, int32_t H) { return image_staged_offset(W, H, 1); }
+size_t gsr_image_bytes_batched(int32_t W, int32_t H, int32_t B)
 {
-    const size_t T = (size_t)((W + kTile - 1) / kTile) * ((H + kTile - 1) / kTile);
-    return gsr_image_staged_offset(W, H) + align256(T * 4 * 4);   // four per-sub-tile counters per tile
+    const size_t T = (size_t)((W + kTile - 1) / kTile) * ((H + kTile - 1) / kTile) * (size_t)(B > 1 ? B : 1);
+    return image_staged_offset(W, H, B) + align256(T * 4 * 4);   // four per-sub-tile counters per tile
 }
+size_t gsr_image_bytes(int32_t W, int32_t H) { return gsr_image_bytes_batched(W, H, 1); }
 
 int gsr_profile_read(const char* name, double* total_ms, int64_t* count)
 {
@@ -1939,15 +2009,20 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
     if (!a->out_color || !a->out_depth || !a->out_alpha || !a->image || !a->bg || !a->alloc)
         return fail(GSR_ERR_ARG, "missing output / workspace pointer%s");
     const int N = a->N, W = a->W, H = a->H;
+    BatchDev bt;
+    rc = batch_dev(a->batch, N, H, bt);
+    if (rc) return rc;
+    const int NB = bt.B;   // images rendered by this call (batched render: a tall grid of NB * tiles_y tile rows)
     // the process-wide options as they are NOW: one forward uses one consistent set and hands it to its backward
     const int opt_ppt = g_blend_ppt ? g_blend_ppt : 7, opt_map = g_tile_map, opt_ckpt = g_ckpt_first;
-    const int tiles_x = (W + kTile - 1) / kTile, tiles_y = (H + kTile - 1) / kTile, T = tiles_x * tiles_y;
+    const int tiles_x = (W + kTile - 1) / kTile, tiles_y = (H + kTile - 1) / kTile, T = tiles_x * tiles_y * NB;
+    if (NB > 1 && opt_ppt < 6) return fail(GSR_ERR_ARG, "batch: served by the default forward blend kernel only%s");
     out->num_rendered = 0; out->binning = nullptr; out->binning_bytes = 0; out->binning_capacity = 0;
     out->forward_flags = pack_fwd_flags(opt_ppt, opt_map, opt_ckpt);
     uint64_t R = 0;
     Splat* splat = static_cast<Splat*>(a->geom);
     float* img = static_cast<float*>(a->image);
-    uint32_t* staged = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(a->image) + gsr_image_staged_offset(W, H));
+    uint32_t* staged = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(a->image) + image_staged_offset(W, H, NB));
     const FwdScratch L = fwd_scratch_layout(N);
     uint8_t* fs = nullptr;
     uint32_t* sorted_gid = nullptr;
@@ -1958,13 +2033,13 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
     const int nb = (N + kEmitThreads - 1) / kEmitThreads;
 
     // ---- R-sized state (binning result + tile-sort scratch) and the stages that need it --------------------------
-    BinLayout B = bin_layout(0, W, H);
+    BinLayout B = bin_layout(0, W, H, NB);
     BinScratch S = bin_scratch_layout(0);
     uint8_t *bin = nullptr, *bs = nullptr;
     uint2* ranges = nullptr;
     uint32_t* list = nullptr;
     auto alloc_binning = [&](uint64_t capacity) -> int {
-        B = bin_layout((int64_t)capacity, W, H);
+        B = bin_layout((int64_t)capacity, W, H, NB);
         bin = static_cast<uint8_t*>(a->alloc(B.bytes, GSR_ALLOC_BINNING, a->alloc_user));
         if (!bin) return fail(GSR_ERR_ALLOC, "binning allocation failed%s");
         ranges = reinterpret_cast<uint2*>(bin + B.ranges);
@@ -2032,10 +2107,10 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
             float* ckpt = reinterpret_cast<float*>(bin + B.ckpt);
             if (ppt == 7)
                 hipLaunchKernelGGL(k_blend_fwd_w6<true>, dim3(8 * 4 * slots_per_xcd(opt_map, T, tiles_x)), dim3(64), 0, st, W, H, tiles_x, T, ranges, list, splat, a->bg,
-                                   a->out_color, a->out_depth, a->out_alpha, img, staged, opt_map, ckpt, opt_ckpt);
+                                   a->out_color, a->out_depth, a->out_alpha, img, staged, opt_map, ckpt, opt_ckpt, tiles_y);
             else if (ppt == 6)
                 hipLaunchKernelGGL(k_blend_fwd_w6<false>, dim3(8 * 4 * slots_per_xcd(opt_map, T, tiles_x)), dim3(64), 0, st, W, H, tiles_x, T, ranges, list, splat, a->bg,
-                                   a->out_color, a->out_depth, a->out_alpha, img, staged, opt_map, ckpt, opt_ckpt);
+                                   a->out_color, a->out_depth, a->out_alpha, img, staged, opt_map, ckpt, opt_ckpt, tiles_y);
 #ifdef GSR_AB_VARIANTS
             else if (!launch_blend_fwd_variant(ppt, W, H, tiles_x, T, ranges, list, splat, a->bg, a->out_color, a->out_depth, a->out_alpha, img, staged,
                                                opt_map, ckpt, opt_ckpt, st))
@@ -2076,7 +2151,7 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
     // kernels that run anyway instead of five separate fill launches. ----
     int dev_id = 0;
     GSR_HIP(hipGetDevice(&dev_id));
-    const auto hint_key = std::make_tuple(dev_id, W, H, n_bucket(N));
+    const auto hint_key = std::make_tuple(dev_id, W, H * NB, n_bucket(N));
     uint64_t hint = 0;
     {
         std::lock_guard<std::mutex> lk(g_state_mutex);
@@ -2100,7 +2175,7 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
     uint32_t* block_sums = reinterpret_cast<uint32_t*>(fs + L.block_sums);
     unsigned long long* total = reinterpret_cast<unsigned long long*>(fs + L.total);
     const bool depth_onesweep = g_sort_algo != 0;
-    CamParams cp = {a->viewmatrix, a->projmatrix, a->campos, a->tanfovx, a->tanfovy, a->scale_modifier, W, H, a->D, a->M, a->points_transform};
+    CamParams cp = {a->viewmatrix, a->projmatrix, a->campos, a->tanfovx, a->tanfovy, a->scale_modifier, W, H, a->D, a->M, a->points_transform, bt};
     const int grid = (N + kPreThreads - 1) / kPreThreads;
     // block 0 of k_preprocess clears the head (digit histograms + tickets) of the depth sort's scratch
     uint32_t* zero_words = depth_onesweep ? reinterpret_cast<uint32_t*>(fs + L.sort) : nullptr;
@@ -2232,6 +2307,10 @@ int gsr_backward(const GsrBackwardArgs* a, void* stream_)
     int rc = check_common(a->N, a->M, a->D, a->W, a->H);
     if (rc) return rc;
     const int N = a->N, W = a->W, H = a->H;
+    BatchDev bt;
+    rc = batch_dev(a->batch, N, H, bt);
+    if (rc) return rc;
+    const int NB = bt.B;
     // the forward's kernel variant / tile map / checkpoint layout travel with its output (forward_flags); a caller of the
     // round-1 ABI (flags 0) gets the process-wide options as before
     int f_ppt = g_blend_ppt ? g_blend_ppt : 7, f_map = g_tile_map, f_ckpt = g_ckpt_first;
@@ -2241,17 +2320,17 @@ int gsr_backward(const GsrBackwardArgs* a, void* stream_)
     }
     (void)f_ppt;
     if (N == 0) {
-        if (a->d_viewmatrix) GSR_HIP(hipMemsetAsync(a->d_viewmatrix, 0, 64, st));
-        if (a->d_projmatrix) GSR_HIP(hipMemsetAsync(a->d_projmatrix, 0, 64, st));
-        if (a->d_campos) GSR_HIP(hipMemsetAsync(a->d_campos, 0, 12, st));
-        if (a->d_points_transform) GSR_HIP(hipMemsetAsync(a->d_points_transform, 0, 48, st));
+        if (a->d_viewmatrix) GSR_HIP(hipMemsetAsync(a->d_viewmatrix, 0, 64 * NB, st));
+        if (a->d_projmatrix) GSR_HIP(hipMemsetAsync(a->d_projmatrix, 0, 64 * NB, st));
+        if (a->d_campos) GSR_HIP(hipMemsetAsync(a->d_campos, 0, 12 * NB, st));
+        if (a->d_points_transform) GSR_HIP(hipMemsetAsync(a->d_points_transform, 0, 48 * NB, st));
         return GSR_OK;
     }
     if (!a->geom || !a->image || !a->binning || !a->scratch || !a->d_means2D)
         return fail(GSR_ERR_ARG, "missing workspace / gradient pointer%s");
-    const int tiles_x = (W + kTile - 1) / kTile, tiles_y = (H + kTile - 1) / kTile, T = tiles_x * tiles_y;
+    const int tiles_x = (W + kTile - 1) / kTile, tiles_y = (H + kTile - 1) / kTile, T = tiles_x * tiles_y * NB;
     const Splat* splat = static_cast<const Splat*>(a->geom);
-    BinLayout B = bin_layout(a->binning_capacity > 0 ? a->binning_capacity : a->num_rendered, W, H);
+    BinLayout B = bin_layout(a->binning_capacity > 0 ? a->binning_capacity : a->num_rendered, W, H, NB);
     const uint8_t* bin = static_cast<const uint8_t*>(a->binning);
     const uint2* ranges = reinterpret_cast<const uint2*>(bin + B.ranges);
     const uint32_t* list = reinterpret_cast<const uint32_t*>(bin + B.list);
@@ -2263,6 +2342,7 @@ int gsr_backward(const GsrBackwardArgs* a, void* stream_)
     bool prep_head_cleared = false;
     if (a->num_rendered > 0) {
         const int ppt = g_bwd_ppt ? g_bwd_ppt : 2;
+        if (NB > 1 && ppt != 2) return fail(GSR_ERR_ARG, "batch: served by the default backward blend kernel only%s");
         const float* img = static_cast<const float*>(a->image);
         ProfScope ps(P_BLEND_BWD, st);
         if (ppt == 2) {
@@ -2273,7 +2353,7 @@ int gsr_backward(const GsrBackwardArgs* a, void* stream_)
             const int tpad = 8 * slots_per_xcd(f_map, T, tiles_x);
             const int grid = split * tpad;
             const float* ckpt = reinterpret_cast<const float*>(bin + B.ckpt);
-            const uint32_t* staged4 = reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(a->image) + gsr_image_staged_offset(W, H));
+            const uint32_t* staged4 = reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(a->image) + image_staged_offset(W, H, NB));
             // deterministic debug mode: R-sized slots + a sort of the instance positions by Gaussian id (stream-ordered
             // allocations of the library's own: gsr_backward has no allocator callback and this is not a hot path)
             float* det_part = nullptr;
@@ -2294,11 +2374,11 @@ int gsr_backward(const GsrBackwardArgs* a, void* stream_)
             if (a->grad_depth || a->grad_alpha)
                 hipLaunchKernelGGL(k_blend_bwd2<true>, dim3(grid), dim3(128), 0, st, W, H, tiles_x, T, ranges, list, splat, a->bg, img,
                                    a->grad_color, a->grad_depth, a->grad_alpha, gg, f_map, ckpt, split, f_ckpt, staged4, tpad, det_part,
-                                   prep_head, (int)kOnesweepHeadWords);
+                                   prep_head, (int)kOnesweepHeadWords, tiles_y);
             else
                 hipLaunchKernelGGL(k_blend_bwd2<false>, dim3(grid), dim3(128), 0, st, W, H, tiles_x, T, ranges, list, splat, a->bg, img,
                                    a->grad_color, a->grad_depth, a->grad_alpha, gg, f_map, ckpt, split, f_ckpt, staged4, tpad, det_part,
-                                   prep_head, (int)kOnesweepHeadWords);
+                                   prep_head, (int)kOnesweepHeadWords, tiles_y);
             prep_head_cleared = prep_head != nullptr;
             if (g_deterministic) {
                 uint32_t* k0 = reinterpret_cast<uint32_t*>(det_mem + o_k0); uint32_t* k1 = reinterpret_cast<uint32_t*>(det_mem + o_k1);
@@ -2320,7 +2400,7 @@ int gsr_backward(const GsrBackwardArgs* a, void* stream_)
         else return fail(GSR_ERR_ARG, "backward blend variants 1, 3, 4 need a library built with -DGSR_AB_VARIANTS%s");
 #endif
     }
-    CamParams cp = {a->viewmatrix, a->projmatrix, a->campos, a->tanfovx, a->tanfovy, a->scale_modifier, W, H, a->D, a->M, a->points_transform};
+    CamParams cp = {a->viewmatrix, a->projmatrix, a->campos, a->tanfovx, a->tanfovy, a->scale_modifier, W, H, a->D, a->M, a->points_transform, bt};
     const int grid = (N + kPreThreads - 1) / kPreThreads;
     const bool want_cam = a->d_viewmatrix || a->d_projmatrix || a->d_campos || a->d_points_transform;
     float* cam_partial = reinterpret_cast<float*>(static_cast<uint8_t*>(a->scratch) + align256((size_t)N * kGG * 4));
@@ -2356,7 +2436,9 @@ int gsr_backward(const GsrBackwardArgs* a, void* stream_)
                                      "16-byte aligned SH tensors and a prepared_out buffer%s");
         const PrepLayout PL = prep_layout(N);
         uint8_t* pb = static_cast<uint8_t*>(a->prepared_out);
-        po.cp = {nv->viewmatrix, nv->projmatrix, nv->campos, nv->tanfovx, nv->tanfovy, nv->scale_modifier, nv->W, nv->H, nv->D, a->M, nv->points_transform};
+        BatchDev nbt = bt;   // the next render is of the same batch (its cameras are arrays of NB entries as well)
+        if (NB > 1 && (long long)NB * ((nv->H + kTile - 1) / kTile) > 4095) return fail(GSR_ERR_RANGE, "batch: more than 4095 tile rows in the next view%s");
+        po.cp = {nv->viewmatrix, nv->projmatrix, nv->campos, nv->tanfovx, nv->tanfovy, nv->scale_modifier, nv->W, nv->H, nv->D, a->M, nv->points_transform, nbt};
         po.splat = reinterpret_cast<Splat*>(pb + PL.splat);
         po.radii = reinterpret_cast<int32_t*>(pb + PL.radii);
         po.dkey = reinterpret_cast<uint32_t*>(pb + PL.dkey);
@@ -2425,8 +2507,8 @@ int gsr_backward(const GsrBackwardArgs* a, void* stream_)
 #undef GSR_PREB
 #undef GSR_PREB_
     if (want_cam)
-        hipLaunchKernelGGL(k_cam_reduce, dim3(kCamVals), dim3(256), 0, st, cam_partial, grid, a->d_viewmatrix, a->d_projmatrix, a->d_campos,
-                           a->d_points_transform);
+        hipLaunchKernelGGL(k_cam_reduce, dim3(kCamVals, NB), dim3(256), 0, st, cam_partial, grid, a->d_viewmatrix, a->d_projmatrix, a->d_campos,
+                           a->d_points_transform, bt);
     GSR_HIP(hipGetLastError());
     return GSR_OK;
 }

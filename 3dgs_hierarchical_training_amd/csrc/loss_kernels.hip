@@ -177,8 +177,10 @@ __global__ __launch_bounds__(256) void k_loss_fwd(const float* __restrict__ raw,
 }
 
 // single block: deterministic reduction of the per-block partials -> out[0] = loss, out[1] = mean ssim, out[2] = mean l1
+// images > 1 (a stack of independent images, gsr_loss_forward_batched): inv_count is ONE image's 1 / (C H W), so the two sums are
+// sums of per-image means; out[0] = the SUM of the images' losses, out[1] / out[2] their mean SSIM / mean L1
 __global__ __launch_bounds__(1024) void k_loss_finish(const float* __restrict__ partial, int nblocks, float inv_count, float lambda,
-                                                      float* __restrict__ out)
+                                                      float* __restrict__ out, int images)
 {
     __shared__ double s0[1024], s1[1024];
     double a = 0, b = 0;
@@ -191,8 +193,8 @@ __global__ __launch_bounds__(1024) void k_loss_finish(const float* __restrict__ 
     }
     if (threadIdx.x == 0) {
         const double ms = s0[0] * inv_count, ml = s1[0] * inv_count;
-        out[0] = (float)((1.0 - lambda) * ml + lambda * (1.0 - ms));
-        out[1] = (float)ms; out[2] = (float)ml;
+        out[0] = (float)((1.0 - lambda) * ml + lambda * ((double)images - ms));
+        out[1] = (float)(ms / images); out[2] = (float)(ml / images);
     }
 }
 
@@ -311,29 +313,44 @@ size_t gsr_loss_workspace_bytes(int32_t C, int32_t H, int32_t W)
     const size_t maps = (size_t)3 * C * H * W * sizeof(float);
     return ((maps + 255) & ~(size_t)255) + ((nb * 2 * sizeof(float) + 255) & ~(size_t)255);
 }
+size_t gsr_loss_workspace_bytes_batched(int32_t images, int32_t C, int32_t H, int32_t W) { return gsr_loss_workspace_bytes(images * C, H, W); }
 
-int gsr_loss_forward(const float* render, const float* target, int32_t C, int32_t H, int32_t W, float lambda_dssim,
-                     int32_t clamp01_render, void* workspace, float* out3, void* stream)
+int gsr_loss_forward_batched(const float* render, const float* target, int32_t images, int32_t C, int32_t H, int32_t W, float lambda_dssim,
+                             int32_t clamp01_render, void* workspace, float* out3, void* stream)
 {
-    if (!render || !target || !workspace || !out3 || C <= 0 || H <= 0 || W <= 0) return GSR_ERR_ARG;
-    const dim3 grid((W + kTW - 1) / kTW, (H + kTH - 1) / kTH, C), block(256);
-    const size_t maps_bytes = (((size_t)3 * C * H * W * sizeof(float)) + 255) & ~(size_t)255;
+    if (!render || !target || !workspace || !out3 || images <= 0 || C <= 0 || H <= 0 || W <= 0) return GSR_ERR_ARG;
+    const int CT = images * C;   // channels are independent of one another in both terms: the stack is CT channel planes
+    const dim3 grid((W + kTW - 1) / kTW, (H + kTH - 1) / kTH, CT), block(256);
+    const size_t maps_bytes = (((size_t)3 * CT * H * W * sizeof(float)) + 255) & ~(size_t)255;
     float* maps = static_cast<float*>(workspace);
     float* partial = reinterpret_cast<float*>(static_cast<uint8_t*>(workspace) + maps_bytes);
     const int nb = (int)(grid.x * grid.y * grid.z);
     hipLaunchKernelGGL(k_loss_fwd, grid, block, 0, (hipStream_t)stream, render, target, H, W, clamp01_render, maps, partial);
-    hipLaunchKernelGGL(k_loss_finish, dim3(1), dim3(1024), 0, (hipStream_t)stream, partial, nb, 1.0f / ((float)C * H * W), lambda_dssim, out3);
+    hipLaunchKernelGGL(k_loss_finish, dim3(1), dim3(1024), 0, (hipStream_t)stream, partial, nb, 1.0f / ((float)C * H * W), lambda_dssim, out3, images);
     return hipGetLastError() == hipSuccess ? GSR_OK : GSR_ERR_HIP;
+}
+
+int gsr_loss_backward_batched(const float* render, const float* target, int32_t images, int32_t C, int32_t H, int32_t W, float lambda_dssim,
+                              int32_t clamp01_render, const void* workspace, const float* grad_loss, float* d_render, void* stream)
+{
+    if (!render || !target || !workspace || !d_render || images <= 0 || C <= 0 || H <= 0 || W <= 0) return GSR_ERR_ARG;
+    const dim3 grid((W + kTW - 1) / kTW, (H + kTH - 1) / kTH, images * C), block(256);
+    // every image with ITS OWN normalisation 1 / (C H W): the gradient of the sum of the images' losses
+    hipLaunchKernelGGL(k_loss_bwd, grid, block, 0, (hipStream_t)stream, render, target, H, W, clamp01_render,
+                       static_cast<const float*>(workspace), grad_loss, 1.0f / ((float)C * H * W), lambda_dssim, d_render);
+    return hipGetLastError() == hipSuccess ? GSR_OK : GSR_ERR_HIP;
+}
+
+int gsr_loss_forward(const float* render, const float* target, int32_t C, int32_t H, int32_t W, float lambda_dssim,
+                     int32_t clamp01_render, void* workspace, float* out3, void* stream)
+{
+    return gsr_loss_forward_batched(render, target, 1, C, H, W, lambda_dssim, clamp01_render, workspace, out3, stream);
 }
 
 int gsr_loss_backward(const float* render, const float* target, int32_t C, int32_t H, int32_t W, float lambda_dssim,
                       int32_t clamp01_render, const void* workspace, const float* grad_loss, float* d_render, void* stream)
 {
-    if (!render || !target || !workspace || !d_render || C <= 0 || H <= 0 || W <= 0) return GSR_ERR_ARG;
-    const dim3 grid((W + kTW - 1) / kTW, (H + kTH - 1) / kTH, C), block(256);
-    hipLaunchKernelGGL(k_loss_bwd, grid, block, 0, (hipStream_t)stream, render, target, H, W, clamp01_render,
-                       static_cast<const float*>(workspace), grad_loss, 1.0f / ((float)C * H * W), lambda_dssim, d_render);
-    return hipGetLastError() == hipSuccess ? GSR_OK : GSR_ERR_HIP;
+    return gsr_loss_backward_batched(render, target, 1, C, H, W, lambda_dssim, clamp01_render, workspace, grad_loss, d_render, stream);
 }
 
 }  // extern "C"

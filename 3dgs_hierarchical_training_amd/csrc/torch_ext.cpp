@@ -50,6 +50,22 @@ void check(int rc, const char* what)
     TORCH_CHECK(rc == 0, what, " failed (code ", rc, "): ", gsr_last_error());
 }
 
+// GsrBatch from an op's `int[] batch_first_block` (B + 1 block offsets; fewer than three entries = a single model)
+struct BatchArg {
+    std::vector<int32_t> fb;
+    GsrBatch b{};
+    explicit BatchArg(at::IntArrayRef first_block)
+    {
+        if (first_block.size() >= 3) {
+            fb.assign(first_block.begin(), first_block.end());
+            b.B = (int32_t)fb.size() - 1;
+            b.first_block = fb.data();
+        }
+    }
+    const GsrBatch* ptr() const { return b.B > 1 ? &b : nullptr; }
+    int64_t B() const { return b.B > 1 ? b.B : 1; }
+};
+
 struct AllocCtx {
     at::TensorOptions opts;
     Tensor binning;
@@ -84,9 +100,12 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> raste
     const Tensor& means3D_, const Tensor& sh_, const Tensor& colors_, const Tensor& opacities_, const Tensor& scales_,
     const Tensor& rotations_, const Tensor& cov3D_, const Tensor& sh_rest_, const Tensor& viewmatrix_, const Tensor& projmatrix_,
     const Tensor& campos_, const Tensor& bg_, const Tensor& xf_, int64_t H, int64_t W, double tanfovx, double tanfovy,
-    double scale_modifier, int64_t sh_degree, bool raw_params, bool prefiltered, bool debug, const Tensor& prepared)
+    double scale_modifier, int64_t sh_degree, bool raw_params, bool prefiltered, bool debug, const Tensor& prepared,
+    at::IntArrayRef batch_first_block)
 {
     TORCH_CHECK(means3D_.is_cuda(), "GaussianRasterizer: tensors must be on a ROCm/HIP device (no CPU fallback)");
+    const BatchArg batch(batch_first_block);
+    const int64_t NB = batch.B();
     const c10::hip::HIPGuardMasqueradingAsCUDA guard(means3D_.device());
     const Tensor means3D = f32c(means3D_), sh = f32c(sh_), colors = f32c(colors_), opac = f32c(opacities_), scales = f32c(scales_),
                  rots = f32c(rotations_), cov = f32c(cov3D_), rest = f32c(sh_rest_), vm = f32c(viewmatrix_), pm = f32c(projmatrix_),
@@ -95,7 +114,13 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> raste
     const int64_t M = has(sh) ? sh.size(1) + (has(rest) ? rest.size(1) : 0) : 0;
     const auto fo = means3D.options().dtype(at::kFloat);
     const auto bo = means3D.options().dtype(at::kByte);
-    Tensor color = at::empty({3, H, W}, fo), depth = at::empty({1, H, W}, fo), alpha = at::empty({1, H, W}, fo);
+    // batched render (GsrBatch): one image per model -- [B,3,H,W] / [B,1,H,W]; cameras are [B,4,4] / [B,3] / [B,3,4]
+    if (NB > 1)
+        TORCH_CHECK(vm.numel() == 16 * NB && pm.numel() == 16 * NB && (!has(campos) || campos.numel() == 3 * NB) && (!has(xf) || xf.numel() == 12 * NB),
+                    "batch: viewmatrix / projmatrix must be [B,4,4], campos [B,3], points_transform [B,3,4]");
+    Tensor color = NB > 1 ? at::empty({NB, 3, H, W}, fo) : at::empty({3, H, W}, fo);
+    Tensor depth = NB > 1 ? at::empty({NB, 1, H, W}, fo) : at::empty({1, H, W}, fo);
+    Tensor alpha = NB > 1 ? at::empty({NB, 1, H, W}, fo) : at::empty({1, H, W}, fo);
     // (prepared: the radii already sit in the hand-over buffer -- an int32 view of it, no copy)
     Tensor radii = has(prepared) ? prepared.slice(0, (int64_t)gsr_prepared_radii_offset((int32_t)N), (int64_t)gsr_prepared_radii_offset((int32_t)N) + 4 * N).view(at::kInt)
                                  : at::empty({N}, means3D.options().dtype(at::kInt));
@@ -105,7 +130,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> raste
         TORCH_CHECK(prepared.is_contiguous() && prepared.scalar_type() == at::kByte &&
                         prepared.numel() == (int64_t)gsr_prepared_bytes((int32_t)N), "prepared buffer does not belong to this model");
     Tensor geom = has(prepared) ? prepared : at::empty({(int64_t)gsr_geom_bytes((int32_t)N)}, bo);
-    Tensor image = at::empty({(int64_t)gsr_image_bytes((int32_t)W, (int32_t)H)}, bo);
+    Tensor image = at::empty({(int64_t)gsr_image_bytes_batched((int32_t)W, (int32_t)H, (int32_t)NB)}, bo);
     AllocCtx actx{bo, Tensor(), {}};
 
     GsrForwardArgs a{};
@@ -122,6 +147,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> raste
     a.shs_rest = fp(rest); a.raw_params = raw_params;
     a.points_transform = fp(xf);
     a.prepared = has(prepared) ? prepared.data_ptr() : nullptr;
+    a.batch = batch.ptr();
     GsrForwardOut out{};
     check(gsr_forward(&a, &out, c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()), "gsr_forward");
     // (scratch tensors die here: stream-ordered reuse by the caching allocator is safe, same stream)
@@ -131,7 +157,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> raste
     Tensor binning = actx.binning.defined() ? actx.binning : at::empty({0}, bo);
     {
         Tensor dims = at::empty({2}, at::TensorOptions().dtype(at::kLong));
-        dims.data_ptr<int64_t>()[0] = W; dims.data_ptr<int64_t>()[1] = H;
+        dims.data_ptr<int64_t>()[0] = W; dims.data_ptr<int64_t>()[1] = H * NB;   // (the staged counters of a batch: one tall image)
         std::lock_guard<std::mutex> lk(g_last_mutex);
         g_last = {image, binning, meta, dims};
     }
@@ -181,9 +207,12 @@ std::vector<Tensor> rasterize_backward(
     const Tensor& cov, const Tensor& rest, const Tensor& vm, const Tensor& pm, const Tensor& campos, const Tensor& bg, const Tensor& xf,
     const Tensor& geom, const Tensor& image, const Tensor& binning, const Tensor& meta, const Tensor& grad_color, const Tensor& grad_depth,
     const Tensor& grad_alpha, int64_t H, int64_t W, double tanfovx, double tanfovy, double scale_modifier, int64_t sh_degree,
-    bool raw_params, bool need_vm, bool need_pm, bool need_campos, bool need_xf, at::TensorList densify_stats, const Tensor& radii)
+    bool raw_params, bool need_vm, bool need_pm, bool need_campos, bool need_xf, at::TensorList densify_stats, const Tensor& radii,
+    at::IntArrayRef batch_first_block)
 {
     const c10::hip::HIPGuardMasqueradingAsCUDA guard(means3D.device());
+    const BatchArg batch(batch_first_block);
+    const int64_t NB = batch.B();
     BwdCommon b{means3D, sh, colors, opac, scales, rots, cov, rest, vm, pm, campos, bg, xf, f32c(grad_color), f32c(grad_depth), f32c(grad_alpha)};
     const int64_t N = means3D.size(0);
     const int64_t M = has(sh) ? sh.size(1) + (has(rest) ? rest.size(1) : 0) : 0;
@@ -195,12 +224,14 @@ std::vector<Tensor> rasterize_backward(
     Tensor d_col = has(colors) ? at::empty({N, 3}, fo) : none;
     Tensor d_scales = has(scales) ? at::empty({N, 3}, fo) : none, d_rot = has(scales) ? at::empty({N, 4}, fo) : none;
     Tensor d_cov = has(cov) ? at::empty({N, 6}, fo) : none;
-    Tensor d_vm = need_vm ? at::empty({4, 4}, fo) : none, d_pm = need_pm ? at::empty({4, 4}, fo) : none;
-    Tensor d_cp = need_campos ? at::empty({3}, fo) : none;
-    Tensor d_xf = (need_xf && has(xf)) ? at::zeros({3, 4}, fo) : none;
+    auto cam_shape = [&](std::vector<int64_t> sh) { if (NB > 1) sh.insert(sh.begin(), NB); return sh; };
+    Tensor d_vm = need_vm ? at::empty(cam_shape({4, 4}), fo) : none, d_pm = need_pm ? at::empty(cam_shape({4, 4}), fo) : none;
+    Tensor d_cp = need_campos ? at::empty(cam_shape({3}), fo) : none;
+    Tensor d_xf = (need_xf && has(xf)) ? at::zeros(cam_shape({3, 4}), fo) : none;
     Tensor scratch = at::empty({(int64_t)gsr_backward_scratch_bytes((int32_t)N)}, means3D.options().dtype(at::kByte));
     GsrBackwardArgs a{};
     fill_backward_args(a, b, geom, image, binning, meta, H, W, tanfovx, tanfovy, scale_modifier, sh_degree, raw_params);
+    a.batch = batch.ptr();
     a.d_means3D = fpm(d_means3D); a.d_means2D = fpm(d_means2D); a.d_opacities = fpm(d_opac);
     a.d_colors_precomp = fpm(d_col); a.d_shs = fpm(d_sh); a.d_scales = fpm(d_scales); a.d_rotations = fpm(d_rot);
     a.d_cov3D_precomp = fpm(d_cov); a.d_shs_rest = fpm(d_rest);
@@ -221,18 +252,22 @@ std::vector<Tensor> rasterize_backward_fused(
     double scale_modifier, int64_t sh_degree, bool need_vm, bool need_pm, bool need_campos, bool need_xf, at::TensorList adam_m,
     at::TensorList adam_v, at::ArrayRef<double> adam_lr, double beta1, double beta2, double eps, int64_t step, const Tensor& next_vm,
     const Tensor& next_pm, const Tensor& next_campos, int64_t next_H, int64_t next_W, double next_tanfovx, double next_tanfovy,
-    Tensor prepared_out, const Tensor& next_xf, int64_t next_sh_degree, at::TensorList densify_stats, const Tensor& radii)
+    Tensor prepared_out, const Tensor& next_xf, int64_t next_sh_degree, at::TensorList densify_stats, const Tensor& radii,
+    at::IntArrayRef batch_first_block)
 {
     const c10::hip::HIPGuardMasqueradingAsCUDA guard(means3D.device());
+    const BatchArg batch(batch_first_block);
+    const int64_t NB = batch.B();
     TORCH_CHECK(adam_m.size() == 6 && adam_v.size() == 6 && adam_lr.size() == 6, "fused_adam: six groups expected");
     Tensor none;
     BwdCommon b{means3D, sh, none, opac, scales, rots, none, rest, vm, pm, campos, bg, xf, f32c(grad_color), f32c(grad_depth), f32c(grad_alpha)};
     const int64_t N = means3D.size(0);
     const auto fo = means3D.options().dtype(at::kFloat);
     Tensor d_means2D = at::empty({N, 3}, fo);
-    Tensor d_vm = need_vm ? at::empty({4, 4}, fo) : none, d_pm = need_pm ? at::empty({4, 4}, fo) : none;
-    Tensor d_cp = need_campos ? at::empty({3}, fo) : none;
-    Tensor d_xf = (need_xf && has(xf)) ? at::zeros({3, 4}, fo) : none;
+    auto cam_shape = [&](std::vector<int64_t> sh) { if (NB > 1) sh.insert(sh.begin(), NB); return sh; };
+    Tensor d_vm = need_vm ? at::empty(cam_shape({4, 4}), fo) : none, d_pm = need_pm ? at::empty(cam_shape({4, 4}), fo) : none;
+    Tensor d_cp = need_campos ? at::empty(cam_shape({3}), fo) : none;
+    Tensor d_xf = (need_xf && has(xf)) ? at::zeros(cam_shape({3, 4}), fo) : none;
     Tensor scratch = at::empty({(int64_t)gsr_backward_scratch_bytes((int32_t)N)}, means3D.options().dtype(at::kByte));
     GsrFusedAdam fa{};
     fa.beta1 = (float)beta1; fa.beta2 = (float)beta2; fa.eps = (float)eps; fa.step = step;
@@ -248,9 +283,13 @@ std::vector<Tensor> rasterize_backward_fused(
     a.d_viewmatrix = fpm(d_vm); a.d_projmatrix = fpm(d_pm); a.d_campos = fpm(d_cp); a.d_points_transform = fpm(d_xf);
     a.scratch = scratch.data_ptr();
     a.fused_adam = &fa;
+    a.batch = batch.ptr();
     GsrNextView nv{};
     // (the next render's own pose transform when its frame has one; otherwise it shares this render's)
-    const Tensor nvm = f32c(next_vm), npm = f32c(next_pm), ncp = f32c(next_campos), nxf = has(next_xf) ? f32c(next_xf.slice(0, 0, 3)) : xf;
+    const Tensor nvm = f32c(next_vm), npm = f32c(next_pm), ncp = f32c(next_campos),
+                 nxf = has(next_xf) ? f32c(NB > 1 ? next_xf : next_xf.slice(0, 0, 3)) : xf;
+    if (has(prepared_out) && NB > 1)
+        TORCH_CHECK(nvm.numel() == 16 * NB && npm.numel() == 16 * NB && ncp.numel() == 3 * NB, "batch: the next view's cameras must be [B,4,4] / [B,3]");
     if (has(prepared_out)) {   // "prepare in backward": this kernel also runs the NEXT render's preprocess on the updated parameters
         nv.W = (int32_t)next_W; nv.H = (int32_t)next_H; nv.D = (int32_t)(next_sh_degree >= 0 ? next_sh_degree : sh_degree);
         nv.scale_modifier = (float)scale_modifier; nv.tanfovx = (float)next_tanfovx; nv.tanfovy = (float)next_tanfovy;
@@ -274,6 +313,7 @@ struct Cfg {
     bool raw_params, prefiltered, debug, cam_grad;
     std::vector<double> adam_lr;
     std::vector<Tensor> adam_m, adam_v;   // optimizer moments: plain buffers, not autograd inputs
+    std::vector<int64_t> batch;           // first 128-Gaussian block of each model + the total (B + 1 entries), or empty: GsrBatch
     std::vector<Tensor> densify_stats;    // {xyz_gradient_accum, denom, max_radii2D} or empty: accumulated by the backward kernel
     Tensor adam_commit;                   // CPU int64 [1]: number of in-kernel Adam steps this optimizer's backwards have applied.  The
                                           // step count advances when a backward RUNS (a forward whose graph is dropped leaves no trace);
@@ -297,10 +337,12 @@ class RasterizeFn : public torch::autograd::Function<RasterizeFn> {
         static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("gsr::rasterize_forward", "").typed<decltype(rasterize_forward)>();
         // float32 + contiguous once, here: the SAME tensors are saved for the backward
         const Tensor m3 = f32c(means3D), s = f32c(sh), c = f32c(colors), o = f32c(opac), sc = f32c(scales), r = f32c(rots), cv = f32c(cov),
-                     rs = f32c(rest), v = f32c(vm), p = f32c(pm), cp = f32c(campos), b = f32c(bg), x = f32c(has(xf) ? xf.slice(0, 0, 3) : xf);
+                     rs = f32c(rest), v = f32c(vm), p = f32c(pm), cp = f32c(campos), b = f32c(bg),
+                     x = f32c((has(xf) && xf.dim() == 2) ? xf.slice(0, 0, 3) : xf);   // [4,4] -> rows 0..2; a batch hands [B,3,4]
         Tensor none;
         auto out = op.call(m3, s, c, o, sc, r, cv, rs, v, p, cp, b, x, cfg.H, cfg.W, cfg.tanfovx, cfg.tanfovy, cfg.scale_modifier,
-                           cfg.sh_degree, cfg.raw_params, cfg.prefiltered, cfg.debug, cfg.prepared.defined() ? cfg.prepared : x.new_empty({0}, x.options().dtype(at::kByte)));
+                           cfg.sh_degree, cfg.raw_params, cfg.prefiltered, cfg.debug, cfg.prepared.defined() ? cfg.prepared : x.new_empty({0}, x.options().dtype(at::kByte)),
+                           cfg.batch);
         // hand-over buffer for the NEXT render, filled by this render's backward (stream-ordered): allocated here so that it
         // can be returned to the caller as an ordinary output
         Tensor prep_out = has(cfg.next_vm) ? at::empty({(int64_t)gsr_prepared_bytes((int32_t)m3.size(0))}, m3.options().dtype(at::kByte))
@@ -311,6 +353,7 @@ class RasterizeFn : public torch::autograd::Function<RasterizeFn> {
         ctx->save_for_backward(saved);
         ctx->saved_data["adam_m"] = cfg.adam_m; ctx->saved_data["adam_v"] = cfg.adam_v;
         ctx->saved_data["dens"] = cfg.densify_stats;
+        ctx->saved_data["batch"] = cfg.batch;
         ctx->saved_data["radii"] = cfg.densify_stats.empty() ? Tensor(at::empty({0}, m3.options().dtype(at::kInt))) : std::get<1>(out);
         ctx->saved_data["H"] = cfg.H; ctx->saved_data["W"] = cfg.W; ctx->saved_data["D"] = cfg.sh_degree;
         ctx->saved_data["tfx"] = cfg.tanfovx; ctx->saved_data["tfy"] = cfg.tanfovy; ctx->saved_data["smod"] = cfg.scale_modifier;
@@ -320,7 +363,7 @@ class RasterizeFn : public torch::autograd::Function<RasterizeFn> {
         ctx->saved_data["eps"] = cfg.eps; ctx->saved_data["step"] = cfg.adam_step;
         ctx->saved_data["commit"] = cfg.adam_commit.defined() ? cfg.adam_commit : at::zeros({1}, at::TensorOptions().dtype(at::kLong));
         ctx->saved_data["commit_seen"] = cfg.adam_commit.defined() ? cfg.adam_commit.data_ptr<int64_t>()[0] : (int64_t)0;
-        ctx->saved_data["xf_rows"] = has(xf) ? xf.size(0) : (int64_t)0;
+        ctx->saved_data["xf_rows"] = (has(xf) && xf.dim() == 2) ? xf.size(0) : (int64_t)0;
         ctx->saved_data["done"] = false;
         ctx->saved_data["prep_out"] = prep_out;
         ctx->saved_data["next_cam"] = std::vector<Tensor>{has(cfg.next_vm) ? f32c(cfg.next_vm) : x, has(cfg.next_vm) ? f32c(cfg.next_pm) : x,
@@ -351,6 +394,7 @@ class RasterizeFn : public torch::autograd::Function<RasterizeFn> {
         auto orE = [&](const Tensor& t) { return t.defined() ? t : e; };
         Tensor d_xf;
         std::vector<Tensor> dens = ctx->saved_data["dens"].toTensorVector();
+        const std::vector<int64_t> bfb = ctx->saved_data["batch"].toIntVector();
         const Tensor radii = ctx->saved_data["radii"].toTensor();
         if (n_adam) {
             // a second backward through the same forward would apply the optimizer step twice
@@ -370,13 +414,13 @@ class RasterizeFn : public torch::autograd::Function<RasterizeFn> {
                              ctx->saved_data["b1"].toDouble(), ctx->saved_data["b2"].toDouble(), ctx->saved_data["eps"].toDouble(),
                              step_now, nc[0], nc[1], nc[2], ctx->saved_data["next_H"].toInt(),
                              ctx->saved_data["next_W"].toInt(), ctx->saved_data["next_tfx"].toDouble(), ctx->saved_data["next_tfy"].toDouble(),
-                             ctx->saved_data["prep_out"].toTensor(), nc[3], ctx->saved_data["next_D"].toInt(), dens, radii);
+                             ctx->saved_data["prep_out"].toTensor(), nc[3], ctx->saved_data["next_D"].toInt(), dens, radii, bfb);
             commit_p[0] += 1;   // the update has been enqueued: the optimizer's step count advances (FusedAdam reconciles from this)
             out[1] = r[0]; out[9] = r[1]; out[10] = r[2]; out[11] = r[3]; d_xf = r[4];
         } else {
             static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("gsr::rasterize_backward", "").typed<decltype(rasterize_backward)>();
             auto r = op.call(sv[0], sv[1], sv[2], sv[3], sv[4], sv[5], sv[6], sv[7], sv[8], sv[9], sv[10], sv[11], sv[12], sv[13], sv[14],
-                             sv[15], sv[16], orE(gc), orE(gd), orE(ga), H, W, tfx, tfy, smod, D, raw, need_vm, need_pm, need_cp, need_xf, dens, radii);
+                             sv[15], sv[16], orE(gc), orE(gd), orE(ga), H, W, tfx, tfy, smod, D, raw, need_vm, need_pm, need_cp, need_xf, dens, radii, bfb);
             out[0] = r[0]; out[1] = r[1]; out[2] = r[2]; out[3] = r[3]; out[4] = r[4]; out[5] = r[5]; out[6] = r[6]; out[7] = r[7]; out[8] = r[8];
             out[9] = r[9]; out[10] = r[10]; out[11] = r[11]; d_xf = r[12];
         }
@@ -393,12 +437,13 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> rasterize(
     bool prefiltered, bool debug, bool cam_grad, at::TensorList adam_m, at::TensorList adam_v, at::ArrayRef<double> adam_lr, double beta1,
     double beta2, double eps, int64_t step, const Tensor& prepared, const Tensor& next_vm, const Tensor& next_pm, const Tensor& next_campos,
     int64_t next_H, int64_t next_W, double next_tanfovx, double next_tanfovy, const Tensor& next_xf, int64_t next_sh_degree,
-    const Tensor& adam_commit, at::TensorList densify_stats)
+    const Tensor& adam_commit, at::TensorList densify_stats, at::IntArrayRef batch_first_block)
 {
     Cfg cfg{H, W, sh_degree, step, tanfovx, tanfovy, scale_modifier, beta1, beta2, eps, raw_params, prefiltered, debug, cam_grad,
             std::vector<double>(adam_lr.begin(), adam_lr.end()), adam_m.vec(), adam_v.vec()};
     if (has(prepared)) cfg.prepared = prepared;
     cfg.densify_stats = densify_stats.vec();
+    cfg.batch.assign(batch_first_block.begin(), batch_first_block.end());
     if (!adam_m.empty()) {
         TORCH_CHECK(has(adam_commit) && adam_commit.is_cpu() && adam_commit.scalar_type() == at::kLong, "fused_adam: adam_commit must be a CPU int64 tensor");
         cfg.adam_commit = adam_commit;
@@ -422,12 +467,12 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> rasterize_forward_only(
     bool prefiltered, bool debug, bool cam_grad, at::TensorList adam_m, at::TensorList adam_v, at::ArrayRef<double> adam_lr, double beta1,
     double beta2, double eps, int64_t step, const Tensor& prepared, const Tensor& next_vm, const Tensor& next_pm, const Tensor& next_campos,
     int64_t next_H, int64_t next_W, double next_tanfovx, double next_tanfovy, const Tensor& next_xf, int64_t next_sh_degree,
-    const Tensor& adam_commit, at::TensorList densify_stats)
+    const Tensor& adam_commit, at::TensorList densify_stats, at::IntArrayRef batch_first_block)
 {
     (void)means2D; (void)next_xf; (void)next_sh_degree; (void)adam_commit; (void)densify_stats; (void)cam_grad; (void)adam_m; (void)adam_v; (void)adam_lr; (void)beta1; (void)beta2; (void)eps; (void)step;
     (void)next_vm; (void)next_pm; (void)next_campos; (void)next_H; (void)next_W; (void)next_tanfovx; (void)next_tanfovy;
-    auto out = rasterize_forward(means3D, sh, colors, opac, scales, rots, cov, rest, vm, pm, campos, bg, has(xf) ? xf.slice(0, 0, 3) : xf, H, W,
-                                 tanfovx, tanfovy, scale_modifier, sh_degree, raw_params, prefiltered, debug, prepared);
+    auto out = rasterize_forward(means3D, sh, colors, opac, scales, rots, cov, rest, vm, pm, campos, bg, (has(xf) && xf.dim() == 2) ? xf.slice(0, 0, 3) : xf, H, W,
+                                 tanfovx, tanfovy, scale_modifier, sh_degree, raw_params, prefiltered, debug, prepared, batch_first_block);
     return {std::get<0>(out), std::get<1>(out), std::get<2>(out), std::get<3>(out), at::empty({0}, means3D.options().dtype(at::kByte))};
 }
 
@@ -443,16 +488,20 @@ Tensor mark_visible(const Tensor& means3D_, const Tensor& vm_, const Tensor& pm_
     return present.to(at::kBool);
 }
 
+// render / target: [C,H,W], or a stack [B,C,H,W] of independent images (a batched render): then the loss is the SUM of the images'
+// losses, each normalised by its own C H W, and every image receives the gradient of its own loss
 std::tuple<Tensor, Tensor> photometric_loss_forward(const Tensor& render_, const Tensor& target_, double lambda_dssim, bool clamp)
 {
     TORCH_CHECK(render_.is_cuda(), "fused_photometric_loss: tensors must be on a ROCm/HIP device (no CPU fallback)");
     const c10::hip::HIPGuardMasqueradingAsCUDA guard(render_.device());
     const Tensor render = f32c(render_), target = f32c(target_);
-    const int32_t C = (int32_t)render.size(0), H = (int32_t)render.size(1), W = (int32_t)render.size(2);
-    Tensor ws = at::empty({(int64_t)gsr_loss_workspace_bytes(C, H, W)}, render.options().dtype(at::kByte));
+    TORCH_CHECK((render.dim() == 3 || render.dim() == 4) && render.sizes() == target.sizes(), "fused_photometric_loss: [C,H,W] or [B,C,H,W] render and target of one shape");
+    const int o = render.dim() == 4 ? 1 : 0;
+    const int32_t B = o ? (int32_t)render.size(0) : 1, C = (int32_t)render.size(o), H = (int32_t)render.size(o + 1), W = (int32_t)render.size(o + 2);
+    Tensor ws = at::empty({(int64_t)gsr_loss_workspace_bytes_batched(B, C, H, W)}, render.options().dtype(at::kByte));
     Tensor out = at::empty({3}, render.options());
-    check(gsr_loss_forward(fp(render), fp(target), C, H, W, (float)lambda_dssim, clamp, ws.data_ptr(), out.data_ptr<float>(),
-                           c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()), "gsr_loss_forward");
+    check(gsr_loss_forward_batched(fp(render), fp(target), B, C, H, W, (float)lambda_dssim, clamp, ws.data_ptr(), out.data_ptr<float>(),
+                                   c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()), "gsr_loss_forward");
     return {out, ws};
 }
 
@@ -461,10 +510,11 @@ Tensor photometric_loss_backward(const Tensor& render_, const Tensor& target_, c
 {
     const c10::hip::HIPGuardMasqueradingAsCUDA guard(render_.device());
     const Tensor render = f32c(render_), target = f32c(target_), g = f32c(grad_loss_);
-    const int32_t C = (int32_t)render.size(0), H = (int32_t)render.size(1), W = (int32_t)render.size(2);
+    const int o = render.dim() == 4 ? 1 : 0;
+    const int32_t B = o ? (int32_t)render.size(0) : 1, C = (int32_t)render.size(o), H = (int32_t)render.size(o + 1), W = (int32_t)render.size(o + 2);
     Tensor d = at::empty_like(render);
-    check(gsr_loss_backward(fp(render), fp(target), C, H, W, (float)lambda_dssim, clamp, ws.data_ptr(), fp(g), d.data_ptr<float>(),
-                            c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()), "gsr_loss_backward");
+    check(gsr_loss_backward_batched(fp(render), fp(target), B, C, H, W, (float)lambda_dssim, clamp, ws.data_ptr(), fp(g), d.data_ptr<float>(),
+                                    c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()), "gsr_loss_backward");
     return d;
 }
 
@@ -588,25 +638,25 @@ TORCH_LIBRARY(gsr, m)
     m.def("rasterize_forward(Tensor means3D, Tensor sh, Tensor colors_precomp, Tensor opacities, Tensor scales, Tensor rotations, "
           "Tensor cov3D_precomp, Tensor sh_rest, Tensor viewmatrix, Tensor projmatrix, Tensor campos, Tensor bg, Tensor points_transform, "
           "int image_height, int image_width, float tanfovx, float tanfovy, float scale_modifier, int sh_degree, bool raw_params, "
-          "bool prefiltered, bool debug, Tensor prepared) -> (Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)");
+          "bool prefiltered, bool debug, Tensor prepared, int[] batch_first_block) -> (Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)");
     m.def("rasterize_backward(Tensor means3D, Tensor sh, Tensor colors_precomp, Tensor opacities, Tensor scales, Tensor rotations, "
           "Tensor cov3D_precomp, Tensor sh_rest, Tensor viewmatrix, Tensor projmatrix, Tensor campos, Tensor bg, Tensor points_transform, "
           "Tensor geom, Tensor image, Tensor binning, Tensor meta, Tensor grad_color, Tensor grad_depth, Tensor grad_alpha, "
           "int image_height, int image_width, float tanfovx, float tanfovy, float scale_modifier, int sh_degree, bool raw_params, "
-          "bool need_viewmatrix, bool need_projmatrix, bool need_campos, bool need_points_transform, Tensor(a!)[] densify_stats, Tensor radii) -> Tensor[]");
+          "bool need_viewmatrix, bool need_projmatrix, bool need_campos, bool need_points_transform, Tensor(a!)[] densify_stats, Tensor radii, int[] batch_first_block) -> Tensor[]");
     m.def("rasterize_backward_fused(Tensor(a!) means3D, Tensor(b!) sh, Tensor(c!) sh_rest, Tensor(d!) opacities, Tensor(e!) scales, "
           "Tensor(f!) rotations, Tensor viewmatrix, Tensor projmatrix, Tensor campos, Tensor bg, Tensor points_transform, Tensor geom, "
           "Tensor image, Tensor binning, Tensor meta, Tensor grad_color, Tensor grad_depth, Tensor grad_alpha, int image_height, "
           "int image_width, float tanfovx, float tanfovy, float scale_modifier, int sh_degree, bool need_viewmatrix, bool need_projmatrix, "
           "bool need_campos, bool need_points_transform, Tensor(g!)[] adam_m, Tensor(h!)[] adam_v, float[] adam_lr, float beta1, "
           "float beta2, float eps, int step, Tensor next_viewmatrix, Tensor next_projmatrix, Tensor next_campos, int next_height, "
-          "int next_width, float next_tanfovx, float next_tanfovy, Tensor(i!) prepared_out, Tensor next_points_transform, int next_sh_degree, Tensor(j!)[] densify_stats, Tensor radii) -> Tensor[]");
+          "int next_width, float next_tanfovx, float next_tanfovy, Tensor(i!) prepared_out, Tensor next_points_transform, int next_sh_degree, Tensor(j!)[] densify_stats, Tensor radii, int[] batch_first_block) -> Tensor[]");
     m.def("rasterize(Tensor means3D, Tensor means2D, Tensor sh, Tensor colors_precomp, Tensor opacities, Tensor scales, Tensor rotations, "
           "Tensor cov3D_precomp, Tensor sh_rest, Tensor viewmatrix, Tensor projmatrix, Tensor campos, Tensor bg, Tensor points_transform, "
           "int image_height, int image_width, float tanfovx, float tanfovy, float scale_modifier, int sh_degree, bool raw_params, "
           "bool prefiltered, bool debug, bool cam_grad, Tensor[] adam_m, Tensor[] adam_v, float[] adam_lr, float beta1, float beta2, "
           "float eps, int step, Tensor prepared, Tensor next_viewmatrix, Tensor next_projmatrix, Tensor next_campos, int next_height, "
-          "int next_width, float next_tanfovx, float next_tanfovy, Tensor next_points_transform, int next_sh_degree, Tensor adam_commit, Tensor[] densify_stats) -> "
+          "int next_width, float next_tanfovx, float next_tanfovy, Tensor next_points_transform, int next_sh_degree, Tensor adam_commit, Tensor[] densify_stats, int[] batch_first_block) -> "
           "(Tensor, Tensor, Tensor, Tensor, Tensor)");
     m.def("mark_visible(Tensor means3D, Tensor viewmatrix, Tensor projmatrix) -> Tensor");
     m.def("photometric_loss_forward(Tensor render, Tensor target, float lambda_dssim, bool clamp) -> (Tensor, Tensor)");

@@ -302,7 +302,8 @@ def _ecpu():
 
 
 def _rasterize_ext(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, rs, sh_rest, raw_params,
-                   fused_adam, points_transform, prepared=None, prepare_next=None, next_points_transform=None, densify_stats=None):
+                   fused_adam, points_transform, prepared=None, prepare_next=None, next_points_transform=None, densify_stats=None,
+                   batch_first_block=None):
     """torch.ops.gsr.rasterize: empty tensors stand for None; the camera tensors of the settings tuple are ordinary inputs
     (their gradients are produced when one of them requires grad)."""
     ops = E.load()
@@ -316,8 +317,11 @@ def _rasterize_ext(means3D, means2D, sh, colors_precomp, opacities, scales, rota
     if vm.device != dev:
         vm, pm, cp = vm.to(dev), pm.to(dev), cp.to(dev)
     bg = rs.bg if rs.bg.device == dev else rs.bg.to(dev)
-    if points_transform is not None and tuple(points_transform.shape) not in ((3, 4), (4, 4)):
-        raise RuntimeError("points_transform must be a [3,4] or [4,4] tensor")
+    nb = (len(batch_first_block) - 1) if batch_first_block is not None else 1
+    if points_transform is not None and tuple(points_transform.shape) not in (((3, 4), (4, 4)) if nb <= 1 else ((nb, 3, 4),)):
+        raise RuntimeError("points_transform must be a [3,4] or [4,4] tensor ([B,3,4] for a batch of B models)")
+    if nb > 1 and (tuple(vm.shape) != (nb, 4, 4) or tuple(pm.shape) != (nb, 4, 4) or tuple(cp.shape) != (nb, 3)):
+        raise RuntimeError("batch: raster_settings.viewmatrix / projmatrix must be [B,4,4] and campos [B,3]")
     xf = e if points_transform is None else points_transform.to(dev)
     m, v, lr, b1, b2, eps, step, commit = [], [], [], 0.0, 0.0, 0.0, 0, None
     if fused_adam is not None and not (torch.is_grad_enabled() and (means3D.requires_grad or opacities.requires_grad)):
@@ -352,7 +356,7 @@ def _rasterize_ext(means3D, means2D, sh, colors_precomp, opacities, scales, rota
             0.0 if nx is None else float(nx.tanfovx), 0.0 if nx is None else float(nx.tanfovy),
             e if (nx is None or next_points_transform is None) else next_points_transform.to(dev),
             -1 if nx is None else int(nx.sh_degree), _ecpu() if commit is None else commit,
-            [] if densify_stats is None else list(densify_stats))
+            [] if densify_stats is None else list(densify_stats), [] if nb <= 1 else [int(x) for x in batch_first_block])
     if not rs.debug:
         out = ops.rasterize(*args)
         return out if prepare_next is not None else out[:4]
@@ -378,7 +382,7 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
 
 def rasterize_gaussians_raw(means3D, means2D, features_dc, features_rest, opacity_logit, log_scales, rotations_raw,
                             raster_settings, fused_adam=None, points_transform=None, prepared=None, prepare_next=None,
-                            next_points_transform=None, densify_stats=None):
+                            next_points_transform=None, densify_stats=None, batch_first_block=None):
     """Extension ("next" row f-2): rasterize straight from HTGaussianModel's raw parameters (_xyz, _features_dc,
     _features_rest, _opacity, _scaling, _rotation; /root/reference/scene/gaussian_model_ht.py:74-82) with the
     activations of :49-65,128-133,176-188 fused into the HIP kernels; gradients are w.r.t. the raw tensors.
@@ -402,13 +406,19 @@ def rasterize_gaussians_raw(means3D, means2D, features_dc, features_rest, opacit
     densify_stats = (xyz_gradient_accum, denom, max_radii2D), float32 tensors of N elements: backward() then also accumulates
     the per-iteration densification statistics of /root/reference/trainer/ht3dgs_trainer.py:141-147 and
     /root/reference/scene/gaussian_model_ht.py:718-721 into them, inside the per-Gaussian backward kernel (include/gsr.h
-    GsrDensifyStats) -- no torch ops on N-sized tensors per step."""
+    GsrDensifyStats) -- no torch ops on N-sized tensors per step.
+
+    batch_first_block = [0, b1, ..., N / 128]: the tensors hold B INDEPENDENT models back to back, model k owning the 128-Gaussian
+    blocks [b_k, b_k+1) (pad every model to a multiple of 128 with Gaussians that are culled); raster_settings then carries one
+    camera per model (viewmatrix / projmatrix [B,4,4], campos [B,3]; points_transform [B,3,4]) and the outputs are [B,3,H,W] /
+    [B,1,H,W]: B renders in one launch chain, each bit-identical with rendering its model alone (include/gsr.h GsrBatch; the
+    independent single-image fits of stage A, /root/reference/trainer/ht3dgs_trainer.py:697-698)."""
     if not E.use_ctypes():
         return _rasterize_ext(means3D, means2D, features_dc, None, opacity_logit, log_scales, rotations_raw, None, raster_settings,
                               features_rest, True, fused_adam, points_transform, prepared, prepare_next, next_points_transform,
-                              densify_stats)
-    if prepared is not None or prepare_next is not None or densify_stats is not None:
-        raise RuntimeError("prepared / prepare_next / densify_stats are served by the PyTorch extension binding only")
+                              densify_stats, batch_first_block)
+    if prepared is not None or prepare_next is not None or densify_stats is not None or batch_first_block is not None:
+        raise RuntimeError("prepared / prepare_next / densify_stats / batch_first_block are served by the PyTorch extension binding only")
     e = torch.Tensor([])
     return _RasterizeGaussians.apply(means3D, means2D, features_dc, e, opacity_logit, log_scales, rotations_raw, e,
                                      raster_settings, features_rest, True, *_cam_inputs(raster_settings), fused_adam, points_transform)

@@ -356,6 +356,9 @@ def render(params: GaussianParams, settings: GaussianRasterizationSettings, clam
         screenspace_points = torch.zeros_like(xyz, requires_grad=True)
         params._screenspace_zero = screenspace_points
     screenspace_points.grad = None
+    bfb = getattr(params, "first_block", None)       # batched.BatchedGaussianParams: B models, B cameras, B images
+    if bfb is not None and not fused_activations:
+        raise RuntimeError("a batch of models renders through the raw-parameter path (fused_activations=True)")
     if fused_activations:
         prep, use = getattr(params, "_prepared", None), None
         if prep is not None:
@@ -368,7 +371,7 @@ def render(params: GaussianParams, settings: GaussianRasterizationSettings, clam
                                       params._scaling, params._rotation, settings, fused_adam=fused_adam, prepared=use,
                                       prepare_next=want_next, points_transform=points_transform,
                                       next_points_transform=next_points_transform if want_next is not None else None,
-                                      densify_stats=densify_stats)
+                                      densify_stats=densify_stats, batch_first_block=bfb)
         if want_next is not None:        # filled by this render's backward; train_step marks it valid once that has run
             nxf = next_points_transform if next_points_transform is not None else points_transform
             params._prepared = {"buf": out[4], "settings": want_next, "n": xyz.shape[0], "xyz": params._xyz, "valid": False,
@@ -441,9 +444,9 @@ def train_step(params: GaussianParams, settings: GaussianRasterizationSettings, 
     pkg = render(params, settings, clamp=not fused_loss, fused_activations=fused_activations, fused_adam=fused_adam,
                  next_settings=nxt, points_transform=xf, densify_stats=dstats,
                  next_points_transform=next_pose.M if (xf is not None and next_pose is not None and nxt is not None) else None)
-    if fused_loss:
-        loss = fused_photometric_loss(pkg["raw_image"], gt, lambda_dssim, clamp=True)
-    else:
+    if fused_loss:          # (a batch hands [B,3,H,W] stacks: the fused loss is then the SUM of the models' losses, every image
+        loss = fused_photometric_loss(pkg["raw_image"], gt, lambda_dssim, clamp=True)     # normalised on its own -- each model gets
+    else:                   # exactly its own loss's gradient, bit-identical with training it alone)
         loss = photometric_loss(pkg["image"], gt, lambda_dssim)
     # same as loss.backward(); the upstream "1" is kept on the device instead of being filled by a launch every step
     one = getattr(params, "_grad_one", None)

@@ -42,6 +42,23 @@ extern "C" {
 /* Allocator callback: return a device pointer to `bytes` bytes (>=256-byte aligned) or NULL. */
 typedef void* (*gsr_alloc_fn)(size_t bytes, int tag, void* user);
 
+/* Batched rendering of INDEPENDENT models in one launch chain (stage A of the reference fits F - 1 single-image models that share
+ * nothing, /root/reference/trainer/ht3dgs_trainer.py:697-698, :336-431; each is a chain of ~17 dependent kernels that fill a
+ * fraction of the chip).  B models live in ONE parameter store of N Gaussians; model b owns the 128-Gaussian blocks
+ * [first_block[b], first_block[b + 1]) -- every model is padded to a multiple of 128 Gaussians (padding = Gaussians that are culled,
+ * e.g. opacity logit -30) and N = 128 first_block[B].  With a batch attached:
+ *   viewmatrix / projmatrix / campos / points_transform (and those of GsrNextView) are arrays of B entries (16 / 16 / 3 / 12 floats);
+ *   out_color is [B,3,H,W], out_depth / out_alpha [B,1,H,W], the upstream gradients of gsr_backward likewise;
+ *   d_viewmatrix / d_projmatrix / d_campos / d_points_transform are arrays of B entries;
+ *   `image` holds gsr_image_bytes_batched(W, H, B) bytes;  W, H, tanfov, bg, sh_degree, scale_modifier are shared.
+ * Every model's image, radii and gradients are bit-identical with rendering it alone: the B images form one tall tile grid
+ * (tile id = b T + tile), a tile's list only holds its own model's Gaussians, and one depth sort orders them all.
+ * first_block is a HOST pointer (B + 1 entries).  B <= 16.  NULL / B <= 1 = the ordinary single-model call. */
+typedef struct GsrBatch {
+    int32_t B;
+    const int32_t* first_block;
+} GsrBatch;
+
 typedef struct GsrForwardArgs {
     int32_t N;           /* Gaussians */
     int32_t M;           /* SH coefficients stored per Gaussian (row stride of shs), e.g. 16 */
@@ -86,6 +103,7 @@ typedef struct GsrForwardArgs {
      * (and for N <= 262 144 with the digit counts already in it) by that backward, and its sort keys are sorted in place --
      * one forward per hand-over. */
     void* prepared;
+    const struct GsrBatch* batch; /* NULL = one model (see GsrBatch) */
 } GsrForwardArgs;
 
 typedef struct GsrForwardOut {
@@ -188,10 +206,12 @@ typedef struct GsrBackwardArgs {
     const struct GsrNextView* next_view; /* NULL = none; otherwise prepared_out must point at gsr_prepared_bytes(N) bytes */
     void* prepared_out;
     const struct GsrDensifyStats* densify_stats; /* NULL = none */
+    const struct GsrBatch* batch;                 /* the forward's batch (NULL = one model) */
 } GsrBackwardArgs;
 
 size_t gsr_geom_bytes(int32_t N);
 size_t gsr_image_bytes(int32_t W, int32_t H);
+size_t gsr_image_bytes_batched(int32_t W, int32_t H, int32_t B); /* image workspace of a batched render (GsrBatch) */
 /* byte offset inside the image workspace of the per-tile uint32 "instances actually staged" counters that
  * the forward blend writes (their sum is R_eff of the roofline accounting) */
 size_t gsr_image_staged_offset(int32_t W, int32_t H);
@@ -273,6 +293,15 @@ int gsr_loss_forward(const float* render, const float* target, int32_t C, int32_
 int gsr_loss_backward(const float* render, const float* target, int32_t C, int32_t H, int32_t W, float lambda_dssim,
                       int32_t clamp01_render, const void* workspace, const float* grad_loss, float* d_render,
                       void* stream);
+
+/* The same over a stack of `images` independent images [images, C, H, W] (a batched render, GsrBatch): every image is normalised by
+ * its own C H W.  out3 = {SUM of the images' losses, mean SSIM, mean L1}; the backward returns the gradient of that sum, i.e. each
+ * image receives exactly the gradient of its own loss. */
+size_t gsr_loss_workspace_bytes_batched(int32_t images, int32_t C, int32_t H, int32_t W);
+int gsr_loss_forward_batched(const float* render, const float* target, int32_t images, int32_t C, int32_t H, int32_t W, float lambda_dssim,
+                             int32_t clamp01_render, void* workspace, float* out3, void* stream);
+int gsr_loss_backward_batched(const float* render, const float* target, int32_t images, int32_t C, int32_t H, int32_t W, float lambda_dssim,
+                              int32_t clamp01_render, const void* workspace, const float* grad_loss, float* d_render, void* stream);
 
 /* ---- "next" row f-2: multi-tensor Adam step in one launch ------------------------------------------------
  * Same update rule as torch.optim.Adam(l, lr=0.0, eps=1e-15) of /root/reference/scene/gaussian_model_ht.py:275-289
