@@ -1826,7 +1826,9 @@ static std::map<std::tuple<int, int, int, int>, uint64_t> g_hints;         // (d
 static long long g_hint_override = -1;                                      // tests: capacity of the NEXT forward (one shot)
 static int g_speculate = 1;
 static int g_deterministic = 0;   // 1: the blend backward accumulates per Gaussian in a fixed order (debug; slower)
-static int g_bwd_split = 16; // workgroups a long tile's backward is split over (checkpoints from the forward); 1 = off
+static int g_bwd_split = 0;  // workgroups a long tile's backward is split over (checkpoints from the forward); 1 = off; 0 = auto: 16 on a
+                             // 980x545 frame, fewer the more tiles there are (the parts that find nothing to do still cost a launch slot:
+                             // 16 x 17 408 workgroups for eight batched images spent 170 of 860 us on them) -- about 35 000 workgroups
 static int g_ckpt_first = 1;  // 128-instance batches of a tile before the forward starts leaving checkpoints
 static int g_tile_map = 2;   // tile -> XCD map: 2 = 2x2 tile blocks interleaved (default), 1 = tiles interleaved, 0 = banded
 static std::atomic<long long> g_spec_overflows{0}, g_spec_forwards{0}, g_exact_forwards{0};
@@ -1967,7 +1969,7 @@ int gsr_set_option(const char* name, int value)
         return 0;
 #endif
     }
-    if (!strcmp(name, "bwd_split")) { if (value < 0 || value > 64) return GSR_ERR_ARG; g_bwd_split = value ? value : 16; return GSR_OK; }
+    if (!strcmp(name, "bwd_split")) { if (value < 0 || value > 64) return GSR_ERR_ARG; g_bwd_split = value; return GSR_OK; }
     if (!strcmp(name, "ckpt_first")) { if (value < 1 || value > 64) return GSR_ERR_ARG; g_ckpt_first = value; return GSR_OK; }
     if (!strcmp(name, "tile_map")) { if (value < 0 || value > 2) return GSR_ERR_ARG; g_tile_map = value; return GSR_OK; }
     if (!strcmp(name, "speculative_binning")) { g_speculate = value ? 1 : 0; return GSR_OK; }
@@ -2349,8 +2351,9 @@ int gsr_backward(const GsrBackwardArgs* a, void* stream_)
             // (checkpoints are written by k_blend_fwd_w only)
             // (sizing the split from the average list length R / T -- fewer empty workgroups on small frames -- measured no
             //  difference: 75 us either way at 50 k Gaussians; the parts that have nothing to do leave after one 16-byte load)
-            const int split = (g_bwd_split > 1 && f_ppt >= 5) ? g_bwd_split : 1;
             const int tpad = 8 * slots_per_xcd(f_map, T, tiles_x);
+            const int want_split = g_bwd_split ? g_bwd_split : std::max(1, std::min(16, 34816 / std::max(1, tpad)));
+            const int split = (want_split > 1 && f_ppt >= 5) ? want_split : 1;
             const int grid = split * tpad;
             const float* ckpt = reinterpret_cast<const float*>(bin + B.ckpt);
             const uint32_t* staged4 = reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(a->image) + image_staged_offset(W, H, NB));

@@ -92,6 +92,7 @@ class HTConfig:
     optimizer: str = "hip"
     fused: bool = True
     stage_a_concurrency: int = 2                # frame pairs fitted at the same time per GPU (streams + host threads), stage_a.run_stage_a
+    stage_a_batch: int = 8                      # frame pairs fitted in ONE launch chain per GPU (stage_a.fit_pairs_batched, GsrBatch); 1 = off
     fit_pose: bool = False                      # refine each frame's pose while training on it (training_setup(fit_pose=True), :733)
     pose_lr: float = 1e-5                       # Adam with eps 1e-15 moves a pose by ~lr per step whatever the gradient: on these
                                                 # frames (1-2 px of motion per frame) 5e-6..2e-5 gains 0.4-0.6 dB over fixed stage-A
@@ -388,14 +389,19 @@ def run_stage_a_on(seq, cfg, dev, spec, rank: int, world: int, group=None, log=N
     conc = max(1, min(cfg.stage_a_concurrency, host_mod.usable_cpus()[0] // (2 * max(1, local_world))))
     table = stage_a.run_stage_a(cfg.frames, lambda p: stage_a.fit_pair(seq, p, dev, n_points=n_points, single_image_iters=image_iters,
                                                                         pose_iters=pose_iters, seed=cfg.seed),
-                                gather_device or dev, rank=rank, world=world, group=group, concurrency=conc, fit_device=dev)
+                                gather_device or dev, rank=rank, world=world, group=group, concurrency=conc, fit_device=dev,
+                                batch=cfg.stage_a_batch,
+                                batch_fn=lambda ps: stage_a.fit_pairs_batched(seq, ps, dev, n_points=n_points, single_image_iters=image_iters,
+                                                                              pose_iters=pose_iters, seed=cfg.seed))
     if dev.type == "cuda":
         torch.cuda.synchronize(dev)
     err = max(float((table[f"rel_pose_{p}_to_{p + 1}"].cpu() - seq.true_rel_pose(p, p + 1)).abs().max()) for p in range(cfg.frames - 1))
     ident = max(float((torch.eye(4) - seq.true_rel_pose(p, p + 1)).abs().max()) for p in range(cfg.frames - 1))
     seq.use_pose_table(table)
     rec = {"rank": rank, "phase": "stage_a", "pairs_total": cfg.frames - 1, "pairs_here": len(stage_a.pairs_of_rank(cfg.frames, rank, world)),
-           "gaussians": n_points, "image_iters": image_iters, "pose_iters": pose_iters, "pairs_at_a_time": conc,
+           "gaussians": n_points, "image_iters": image_iters, "pose_iters": pose_iters,
+           "pairs_at_a_time": cfg.stage_a_batch if cfg.stage_a_batch > 1 else conc,
+           "mode": f"batched: {cfg.stage_a_batch} pairs per launch chain" if cfg.stage_a_batch > 1 else f"{conc} stream(s), one pair each",
            "ms": 1e3 * (time.perf_counter() - t0),
            "max_abs_pose_error": err, "identity_guess_error": ident}
     (log or emit_line)(rec)
@@ -424,12 +430,14 @@ def main():
                     help="run stage A first (relative pose of every consecutive frame pair: single-image 3DGS of frame p, then the "
                          "SE(3) fit on frame p+1; pairs round-robin over the ranks, one all_gather) and chain ITS poses in stage B "
                          "instead of the synthetic ground truth.  The reference's counts are 1000 and 300 iterations")
+    ap.add_argument("--stage-a-batch", type=int, default=8, help="frame pairs of stage A fitted in one launch chain (GsrBatch); 1 = one pair "
+                                                                "per chain, two chains at a time on two streams (round 2)")
     ap.add_argument("--one-device", action="store_true", help="every rank on cuda:0 (with --backend gloo: the multi-process walk on a "
                                                               "one-GPU box; messages are staged through host memory)")
     a = ap.parse_args()
     cfg = HTConfig(frames=a.frames, width=a.width, height=a.height, gt_gaussians=a.gt_gaussians, leaf_gaussians=a.leaf_gaussians,
                    leaf_iters_per_frame=a.leaf_iters, phase1_iters_per_frame=a.phase1_iters, phase2_iters_per_frame=[a.phase2_iters] * 3,
-                   importance_views=a.importance_views, densify=a.densify, fit_pose=a.fit_pose)
+                   importance_views=a.importance_views, densify=a.densify, fit_pose=a.fit_pose, stage_a_batch=a.stage_a_batch)
     if a.pose_lr is not None:
         cfg.pose_lr = a.pose_lr
     if not torch.cuda.is_available():

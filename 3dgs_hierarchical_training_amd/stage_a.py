@@ -61,7 +61,7 @@ def pose_dict_from_table(table: torch.Tensor, vfi: bool = False) -> Dict[str, to
 
 def run_stage_a(n_frames: int, fit_fn: Callable[[int], torch.Tensor], device, rank: Optional[int] = None,
                 world: Optional[int] = None, group=None, vfi: bool = False, concurrency: int = 1,
-                fit_device=None) -> Dict[str, torch.Tensor]:
+                fit_device=None, batch_fn: Optional[Callable[[List[int]], Dict[int, torch.Tensor]]] = None, batch: int = 1) -> Dict[str, torch.Tensor]:
     """fit_fn(p) -> [4,4] (or [3,4,4]) relative pose(s) of pair p.  Every rank returns the complete pose_dict.
 
     concurrency > 1 (with fit_device = the GPU the fits run on): that many of this rank's pairs are fitted at the same time, each on
@@ -73,7 +73,12 @@ def run_stage_a(n_frames: int, fit_fn: Callable[[int], torch.Tensor], device, ra
         world = dist.get_world_size(group) if dist.is_initialized() else 1
         rank = dist.get_rank(group) if dist.is_initialized() else 0
     mine = pairs_of_rank(n_frames, rank, world)
-    if concurrency > 1 and fit_device is not None and torch.device(fit_device).type == "cuda" and len(mine) > 1:
+    if batch_fn is not None and batch > 1 and len(mine) > 1:
+        # `batch` of this rank's pairs per launch chain (fit_pairs_batched): the GPU sees one model `batch` times the size
+        results = {}
+        for lo in range(0, len(mine), batch):
+            results.update(batch_fn(mine[lo:lo + batch]))
+    elif concurrency > 1 and fit_device is not None and torch.device(fit_device).type == "cuda" and len(mine) > 1:
         import threading
         from concurrent.futures import ThreadPoolExecutor
         fdev = torch.device(fit_device)
@@ -164,4 +169,62 @@ def fit_pair(seq, p: int, device, n_points: int = 100_000, single_image_iters: i
         ops.pose_step(delta, m, v, Mi.grad, none, M, pose_lr, 0.9, 0.999, 1e-8, it)       # torch.optim.Adam's defaults
     out = torch.eye(4)
     out[:3] = M.detach().cpu()
+    return out
+
+
+def fit_pairs_batched(seq, pairs: List[int], device, n_points: int = 100_000, single_image_iters: int = 1000, pose_iters: int = 300,
+                      pose_lr: float = 2e-3, seed: int = 0) -> Dict[int, torch.Tensor]:
+    """`fit_pair` for several pairs AT ONCE: the B single-image models live in one parameter store and every step of the B fits is
+    ONE launch chain (batched.BatchedGaussianParams / include/gsr.h GsrBatch) -- B renders, B losses, B Adam updates and the B
+    hand-overs to the next step per pass over the kernels, instead of B chains of ~17 kernels that each fill a fraction of the
+    chip.  Per model the arithmetic is what `fit_pair` does (bit-identical renders and updates, tests/test_gpu_batched.py); what
+    differs is the early exit of the image phase: the reference leaves a model's loop when its PSNR passes 35 dB after 500
+    iterations (ht3dgs_trainer.py:300-301), a batch runs until ALL its models have passed (or the iteration cap) -- a model that
+    is already there simply trains a little longer.  Returns {pair -> rel_pose [4,4] (CPU)}."""
+    from . import batched as bt
+    from . import train_step as ts
+    from . import _ext
+    from .loss import fused_photometric_loss
+    from .rasterizer import rasterize_gaussians_raw
+    B = len(pairs)
+    if B == 1:
+        return {pairs[0]: fit_pair(seq, pairs[0], device, n_points, single_image_iters, pose_iters, pose_lr, seed)}
+    stride = max(1, int(round((seq.W * seq.H / max(1, n_points)) ** 0.5)))
+    scenes = [seq.pixel_scene(p, stride=stride, seed=seed) for p in pairs]
+    params = bt.BatchedGaussianParams(scenes, device)
+    params.active_sh_degree = 0          # fresh models: degree 0, 16 coefficients stored (see fit_pair)
+    ident1 = ts.with_sh_degree(seq.settings_for_pose(torch.eye(4)), 0)
+    ident = bt.batch_settings([ident1] * B, device)
+    tgt0 = torch.stack([seq.target(p) for p in pairs])
+    tgt1 = torch.stack([seq.target(p + 1) for p in pairs])
+    for it in range(1, single_image_iters + 1):
+        pkg = ts.train_step(params, ident, tgt0, next_settings=ident)
+        if it > 500 and it % 50 == 0:
+            with torch.no_grad():
+                mse = ((pkg["raw_image"].clamp(0, 1) - tgt0) ** 2).flatten(1).mean(dim=1)
+            if float((-10 * torch.log10(mse.clamp_min(1e-12))).min()) > 35:
+                break
+    raw = params.raw()
+    m2d = torch.zeros_like(raw["_xyz"])
+    ops = _ext.load()
+    delta = torch.zeros(B, 6, device=device)
+    m, v = torch.zeros(B, 6, device=device), torch.zeros(B, 6, device=device)
+    none = torch.empty(0, device=device)
+    M = torch.zeros(B, 3, 4, device=device)
+    for b in range(B):
+        ops.pose_step(delta[b], m[b], v[b], none, none, M[b], pose_lr, 0.9, 0.999, 1e-8, 0)              # M_b = Exp(0) = identity
+    for it in range(1, pose_iters + 1):
+        Mi = M.detach().requires_grad_(True)
+        img = rasterize_gaussians_raw(raw["_xyz"], m2d, raw["_features_dc"], raw["_features_rest"], raw["_opacity"], raw["_scaling"],
+                                      raw["_rotation"], ident, points_transform=Mi, batch_first_block=params.first_block)[0]
+        fused_photometric_loss(img, tgt1, 0.2, clamp=True).backward()          # sum of the B losses: every transform gets its own gradient
+        g = Mi.grad
+        for b in range(B):                                                        # one one-thread kernel per model (gsr_pose_step)
+            ops.pose_step(delta[b], m[b], v[b], g[b], none, M[b], pose_lr, 0.9, 0.999, 1e-8, it)
+    out = {}
+    Mc = M.detach().cpu()
+    for b, p in enumerate(pairs):
+        T = torch.eye(4)
+        T[:3] = Mc[b]
+        out[p] = T
     return out

@@ -387,6 +387,35 @@ def rccl_probe(dist, dev, world, rank, backend):
             "note": "64 MiB send + recv per level-0 merge pair, all pairs concurrently; rate = both directions / wall time of the pair"}
 
 
+def stage_a_batched_leg(dev, W=980, H=545, B=8, iters=150):
+    """Stage A's image iteration with B frame pairs per launch chain (batched.BatchedGaussianParams / GsrBatch) against one pair per
+    chain: ms per pair and iteration, SH degree 0 with 16 coefficients stored, ~130 k pixel-Gaussians per model."""
+    sequence = importlib.import_module("3dgs_hierarchical_training_amd.sequence")
+    ts = importlib.import_module("3dgs_hierarchical_training_amd.train_step")
+    bt = importlib.import_module("3dgs_hierarchical_training_amd.batched")
+    seq = sequence.FrameSequence(B + 1, 400_000, W, H, dev, seed=0)
+    ident1 = ts.with_sh_degree(seq.settings_for_pose(torch.eye(4)), 0)
+    scenes = [seq.pixel_scene(p, stride=2, seed=0) for p in range(B)]
+    out = {"gaussians_per_model": int(scenes[0]["means3D"].shape[0]), "width": W, "height": H, "sh_degree": 0, "models_per_chain": B}
+    for name, nb in (("one_pair_per_chain", 1), ("batched", B)):
+        if nb == 1:
+            p = ts.GaussianParams(scenes[0], dev)
+            st, tgt = ident1, seq.target(0)
+        else:
+            p = bt.BatchedGaussianParams(scenes, dev)
+            st, tgt = bt.batch_settings([ident1] * B, dev), torch.stack([seq.target(k) for k in range(B)])
+        p.active_sh_degree = 0
+        f = lambda i: ts.train_step(p, st, tgt, next_settings=st)
+        for i in range(20):
+            f(i)
+        out[name + "_ms_per_pair_iteration"] = 1e3 * timed_steps(f, iters, dev) / nb
+        del p
+    out["note"] = ("the reference fits the F - 1 frame pairs of stage A one after the other (ht3dgs_trainer.py:697-698), each a chain of ~17 dependent "
+                   "kernels; batched = B models in one parameter store, one chain per step, every model bit-identical with training it alone; "
+                   "39 pairs x (1000 + 300) iterations on one GPU: profiles/r03_stage_a_batched.txt")
+    return out
+
+
 def workload_leg(syn, ts, raster, dev, N, W, H, deg, steps, warmup, clustered=False, densify_every=0, seed=0):
     dm = importlib.import_module("3dgs_hierarchical_training_amd.densify")
     scene = syn.make_scene(N, W, H, sh_degree=deg, seed=seed, clustered=clustered)
@@ -830,6 +859,10 @@ def main():
                 extra["stage-A frame pair @980x545 (single-image model + pose fit)"] = stage_a_leg(dev)
             except Exception as e:
                 extra["stage-A frame pair @980x545 (single-image model + pose fit)"] = {"error": repr(e)}
+            try:
+                extra["stage-A image iteration, 8 pairs per launch chain (GsrBatch)"] = stage_a_batched_leg(dev)
+            except Exception as e:
+                extra["stage-A image iteration, 8 pairs per launch chain (GsrBatch)"] = {"error": repr(e)}
         res["other_workloads"] = extra
     if world == 1 and not args.no_cpu_baseline:
         threads, quota = _CPUS, _CPU_QUOTA

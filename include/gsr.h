@@ -242,7 +242,8 @@ int gsr_version(void);
  *   "blend_bwd_ppt"        backward blend kernel: 2 = packed two-pixel kernel (default); 1, 3, 4 = scalar A/B kernels (variants.hip)
  *   "ab_variants"          query: returns 1 when the library carries the A/B kernels, 0 otherwise (the value is ignored)
  *   "sort_algo"            2 = onesweep for both sorts (default); 1 = onesweep depth sort only; 0 = hist + scan + scatter
- *   "bwd_split"            workgroups the backward of one tile is split over (default 16; 1 = off): each part replays a
+ *   "bwd_split"            workgroups the backward of one tile is split over (1 = off; default 0 = automatic: 16 on a 980x545 frame,
+ *                          fewer for frames / batches with more tiles, about 35 000 workgroups in all): each part replays a
  *                          run of 128-instance batches, resuming from the per-pixel checkpoints the forward leaves at
  *                          every 128-instance boundary from batch "ckpt_first" (default 1) on
  *   "tile_map"             how tiles are dealt to the eight XCDs: 2 (default) = 2x2 blocks of tiles round-robin, 1 = single

@@ -1,0 +1,35 @@
+"""Stage A at the reference's counts (39 pairs x (1000 + 300) iterations, 130 k-Gaussian single-image models @980x545) on one GPU:
+batched launch chains (GsrBatch) against round 2's two-streams mode, plus per-iteration times by batch size."""
+import importlib, json, sys, time, torch
+sys.path.insert(0, '.')
+sequence = importlib.import_module("3dgs_hierarchical_training_amd.sequence")
+stage_a = importlib.import_module("3dgs_hierarchical_training_amd.stage_a")
+rs = importlib.import_module("3dgs_hierarchical_training_amd.run_segments")
+host = importlib.import_module("3dgs_hierarchical_training_amd.host"); host.cap_host_threads()
+dev = torch.device("cuda:0")
+frames = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+img_it, pose_it = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (1000, 300)
+seq = sequence.FrameSequence(frames, 400000, 980, 545, dev, seed=0)
+for f in range(frames):
+    seq.target(f); seq.depth(f)
+out = {}
+# per-iteration cost by batch size (no early exit: fixed 200 + 100 iterations)
+for B in (1, 2, 4, 8):
+    pairs = list(range(B))
+    stage_a.fit_pairs_batched(seq, pairs, dev, n_points=130000, single_image_iters=20, pose_iters=20)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    stage_a.fit_pairs_batched(seq, pairs, dev, n_points=130000, single_image_iters=200, pose_iters=0)
+    torch.cuda.synchronize(); t1 = time.perf_counter()
+    stage_a.fit_pairs_batched(seq, pairs, dev, n_points=130000, single_image_iters=200, pose_iters=100)
+    torch.cuda.synchronize(); t2 = time.perf_counter()
+    out[f"B={B}"] = {"image_iteration_ms_per_pair": 1e3 * (t1 - t0) / 200 / B, "pose_iteration_ms_per_pair": 1e3 * ((t2 - t1) - (t1 - t0)) / 100 / B}
+    print(B, out[f"B={B}"], flush=True)
+for mode, batch in (("batched x8", 8), ("batched x4", 4), ("two streams (round 2)", 1)):
+    cfg = rs.HTConfig(frames=frames, stage_a_batch=batch)
+    seq.pose_table = None
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    rec = rs.run_stage_a_on(seq, cfg, dev, (130000, img_it, pose_it), 0, 1, log=lambda r: None)
+    torch.cuda.synchronize()
+    out[mode] = {"seconds": time.perf_counter() - t0, "pairs": frames - 1, "max_abs_pose_error": rec["max_abs_pose_error"], "identity_guess_error": rec["identity_guess_error"]}
+    print(mode, out[mode], flush=True)
+print("JSON", json.dumps(out))
