@@ -203,6 +203,11 @@ def test_bench_line_at_two_ranks_on_one_gpu():
     assert "roofline" in d and d["roofline"]["frac"] > 0 and "cpu_baseline" not in d      # cpu_baseline: rank 0 at N = 1 only
     m = d["merge"]
     assert m["pairs"] == 1 and m["merge_bytes"] > 200000 * 236 and m["merge_ms"] > 0 and m["gaussians_merged_max"] == 200000
+    # the process group's self-diagnosis: both ranks answered, the 64 MiB exchange of the one level-0 pair came back intact
+    r = d["rccl"]
+    assert r["world"] == 2 and r["ranks_seen"] == [0, 1] and r["all_ranks_present"] and r["backend"] == "gloo" and r["payload_ok"]
+    assert list(r["link_GBps"]) == ["0<->1"] and r["link_GBps"]["0<->1"] > 0
+    assert d["spec_overflows"] >= 0 and d["config"]["views"] == 8
 
 
 def test_pose_refinement_in_stage_b_improves_on_noisy_relative_poses():
