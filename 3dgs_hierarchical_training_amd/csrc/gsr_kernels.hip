@@ -173,21 +173,68 @@ __device__ __forceinline__ float bfly_single(float a)
 {
     return a + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), CTRL, 0xf, 0xf, false));
 }
-// returns t with: lanes (l&15) in 0..7 -> total of v[l&7]; lanes 8..15 -> total of v[8] (NV = 9) or v[8 + (l&1)] (NV = 10)
+// ---- the reduction with the selects folded into DPP write masks (round 3) ---------------------------------------------------------
+// Written with bfly_pair at all four levels (keep = hi ? b : a, send = hi ? a : b: two selects and one DPP add per pair) the tree
+// costs 11 DPP adds + 16 selects, and a select with an SGPR-pair mask is a double-pass instruction on this chip (4.2 SIMD cycles,
+// like a DPP add; calibrated, profiles/r03_valu_calib*): rounds 1-2 ran that form (blend backward 210 us; 203 with this one).  A DPP instruction can disable its WRITE per
+// bank of four lanes, so for the two row_ror levels the pair step needs none:
+//     out = a + ror(a)                    (all lanes)
+//     out = b + ror(b)   bank_mask = hi   (the lanes that keep b overwrite)
+// Those levels therefore take the wide end of the tree -- row_ror:4 first (hi = lane bit 2: banks 1, 3), then row_ror:8 (hi = bit 3:
+// banks 2, 3; it must come second, a rotation by 4 carries into bit 3) -- and the quad_perm levels, whose lanes cannot be masked by
+// bank, the narrow end: 17 DPP adds + 4 selects instead of 11 + 16.  Returns t; lane l < 16 holds the total of value
+// reduce2_slot<NV>(l) (or none: -1).  Inline asm: the masked second write of `out` cannot be expressed through the builtin.
 template <int NV>
-__device__ __forceinline__ float wave_reduce_transposed(const float* v, int lane)
+__device__ __forceinline__ int reduce2_slot(int lane)
 {
-    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
-    const float r01 = bfly_pair<0xB1>(v[0], v[1], b0), r23 = bfly_pair<0xB1>(v[2], v[3], b0);
-    const float r45 = bfly_pair<0xB1>(v[4], v[5], b0), r67 = bfly_pair<0xB1>(v[6], v[7], b0);
-    const float r8 = (NV == 10) ? bfly_pair<0xB1>(v[8], v[NV - 1], b0) : bfly_single<0xB1>(v[8]);
-    const float q03 = bfly_pair<0x4E>(r01, r23, b1), q47 = bfly_pair<0x4E>(r45, r67, b1);
-    const float q8 = bfly_single<0x4E>(r8);
-    const float o07 = bfly_pair<0x124>(q03, q47, b2);
-    const float o8 = bfly_single<0x124>(q8);
-    float t = bfly_pair<0x128>(o07, o8, b3);
-    // cross-row: gfx950 row / half swaps keep the whole reduction in the VALU (ds_bpermute would put two LDS round
-    // trips on the dependency chain of every (wave, Gaussian))
+    if (lane >= 16) return -1;
+    if (!(lane & 1)) return ((lane >> 2) & 1) + 2 * ((lane >> 3) & 1) + 4 * ((lane >> 1) & 1);
+    if (lane == 1) return 8;
+    return (NV == 10 && lane == 5) ? 9 : -1;
+}
+template <int NV>
+__device__ __forceinline__ float wave_reduce_transposed2(const float* v, int lane)
+{
+    float q03, q47, q8;
+#if defined(__HIP_DEVICE_COMPILE__)
+    float r01, r23, r45, r67, r8;
+    const float v9 = NV == 10 ? v[NV - 1] : 0.f;
+    // (s_nop 1 in front: the inputs were just written by VALU instructions and a DPP read of a VGPR needs two wait states; every
+    //  DPP read inside the block is at least four instructions behind the write it depends on; s_nop 1 behind: the builtins below
+    //  read q03 / q47 / q8 through DPP)
+    if (NV == 10)
+        asm volatile("s_nop 1\n"
+                     "v_add_f32_dpp %3, %8, %8 row_ror:4 row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %3, %9, %9 row_ror:4 row_mask:0xf bank_mask:0xa\n"
+                     "v_add_f32_dpp %4, %10, %10 row_ror:4 row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %4, %11, %11 row_ror:4 row_mask:0xf bank_mask:0xa\n"
+                     "v_add_f32_dpp %5, %12, %12 row_ror:4 row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %5, %13, %13 row_ror:4 row_mask:0xf bank_mask:0xa\n"
+                     "v_add_f32_dpp %6, %14, %14 row_ror:4 row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %6, %15, %15 row_ror:4 row_mask:0xf bank_mask:0xa\n"
+                     "v_add_f32_dpp %7, %16, %16 row_ror:4 row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %7, %17, %17 row_ror:4 row_mask:0xf bank_mask:0xa\n"
+                     "v_add_f32_dpp %0, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %0, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xc\n"
+                     "v_add_f32_dpp %1, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %1, %6, %6 row_ror:8 row_mask:0xf bank_mask:0xc\n"
+                     "v_add_f32_dpp %2, %7, %7 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+                     "s_nop 1"
+                     : "=&v"(q03), "=&v"(q47), "=&v"(q8), "=&v"(r01), "=&v"(r23), "=&v"(r45), "=&v"(r67), "=&v"(r8)
+                     : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]), "v"(v9));
+    else
+        asm volatile("s_nop 1\n"
+                     "v_add_f32_dpp %3, %8, %8 row_ror:4 row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %3, %9, %9 row_ror:4 row_mask:0xf bank_mask:0xa\n"
+                     "v_add_f32_dpp %4, %10, %10 row_ror:4 row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %4, %11, %11 row_ror:4 row_mask:0xf bank_mask:0xa\n"
+                     "v_add_f32_dpp %5, %12, %12 row_ror:4 row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %5, %13, %13 row_ror:4 row_mask:0xf bank_mask:0xa\n"
+                     "v_add_f32_dpp %6, %14, %14 row_ror:4 row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %6, %15, %15 row_ror:4 row_mask:0xf bank_mask:0xa\n"
+                     "v_add_f32_dpp %7, %16, %16 row_ror:4 row_mask:0xf bank_mask:0xf\n"
+                     "v_add_f32_dpp %0, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %0, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xc\n"
+                     "v_add_f32_dpp %1, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %1, %6, %6 row_ror:8 row_mask:0xf bank_mask:0xc\n"
+                     "v_add_f32_dpp %2, %7, %7 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+                     "s_nop 1"
+                     : "=&v"(q03), "=&v"(q47), "=&v"(q8), "=&v"(r01), "=&v"(r23), "=&v"(r45), "=&v"(r67), "=&v"(r8)
+                     : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]));
+#else
+    q03 = q47 = q8 = 0.f; (void)v;
+#endif
+    const bool b0 = lane & 1, b1 = lane & 2;
+    const float o07 = bfly_pair<0x4E>(q03, q47, b1);
+    const float o8 = bfly_single<0x4E>(q8);
+    float t = bfly_pair<0xB1>(o07, o8, b0);
     {
         const unsigned u = __float_as_uint(t);
         const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);   // rows (0,1) and (2,3) exchange
@@ -897,6 +944,9 @@ __global__ __launch_bounds__(64) void k_blend_fwd_w6(int W, int H, int tiles_x, 
             Tr = pass ? test_T : -fabsf(Tr);                  // first failure flips the sign: done, |T| kept
             last = pass ? (uint32_t)(b * NT + j + 1) : last;
         };
+        // (round 3: issuing visit k + 1's broadcast reads before visit k's arithmetic -- two register sets, loop unrolled by two, no
+        //  copies -- 117 -> 131 us with all three reads prefetched, 135 us with the pre-test fields only: the LDS round trip is not what a
+        //  wave waits for here, and the unrolled control flow costs scalar issue slots; the plain loop below stays)
         // (evaluating two instances' alpha before either blend -- two v_exp_f32 in flight -- measured the same: 118 us;
         //  one 16-byte-stride array for the three staged planes, so that a visit needs one address register instead of two:
         //  one v_mov less per visit but 6 instead of 5 kB of LDS per wave -- 26 instead of 32 waves per CU -- 109 -> 113 us)
@@ -961,7 +1011,10 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(int W, int H, int tiles_x, i
     // smaller LDS footprint lets more tiles share a CU (latency hiding: waves were 33% in s_waitcnt / barriers)
     __shared__ float4 s_a[1][NT], s_b[1][NT], s_c[1][NT];
     __shared__ uint32_t s_gid[1][NT];
-    __shared__ float s_part[NW][NT][NV];
+    // ONE row of partials per staged instance: the tile's two waves add theirs into it with ds_add_f32 (each touches a record's nine
+    // words once per batch, from nine lanes: conflict-free; 0 + a + b = 0 + b + a, so the arrival order does not matter).  Round 3:
+    // a row per wave (4.6 kB more LDS per workgroup: 10 instead of 14 workgroups per CU) was 219-226 us where this is 210-211
+    __shared__ float s_part[NT][NV];
     __shared__ uint32_t s_max[NW];
     // grid = split x Tpad workgroups: part `spart` of tile `tile` (parts beyond what the tile's depth needs exit)
     const int spart = (int)blockIdx.x / tpad, tb = (int)blockIdx.x - spart * tpad;
@@ -1075,10 +1128,9 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(int W, int H, int tiles_x, i
     };
     if (b0 * NT + tid < n) stage(b0 * NT + tid);
 #pragma unroll
-    for (int w = 0; w < NW; w++)
-#pragma unroll
-        for (int k = 0; k < NV; k++) s_part[w][tid][k] = 0.f;   // the flush below re-zeroes what it consumes
-    const uint32_t part_off = (uint32_t)(wave * NT * NV + lane);
+    for (int k = 0; k < NV; k++) s_part[tid][k] = 0.f;   // the flush below re-zeroes what it consumes
+    const int part_slot = reduce2_slot<NV>(lane);          // which of a visit's NV totals this lane ends up with (-1: none)
+    const uint32_t part_off = (uint32_t)(part_slot < 0 ? 0 : part_slot);
     for (int b = b0; b < b1; b++) {
         const int buf = 0;
         if (b > b0) __syncthreads();   // everyone is done reading the previous batch (and its flush read s_gid)
@@ -1145,18 +1197,18 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(int W, int H, int tiles_x, i
                 v[6] = t_r.x + t_r.y; v[7] = t_g.x + t_g.y; v[8] = t_b.x + t_b.y;
                 if (HAS_DA) { const f2 t_z = w * gD; v[9] = t_z.x + t_z.y; }
                 Tt *= om;
-                // (measured: finishing the reduction with ds_add_f32 from the row leaders is 1.7x SLOWER -- LDS float
-                //  atomics serialise; the transposed DPP reduction below halves the VALU cost instead)
-                const float t = wave_reduce_transposed<NV>(v, lane);
-                // lane k < NV holds the total of value k.  The row offset is a SCALAR product (j is wave-uniform); left to itself the
-                // compiler folds it into a v_mad_u64_u32 per visit.
+                // (measured: finishing the reduction with ds_add_f32 from the row leaders is 1.7x SLOWER -- four lanes on one
+                //  address serialise; the transposed DPP reduction below halves the VALU cost instead)
+                const float t = wave_reduce_transposed2<NV>(v, lane);
+                // nine (ten) lanes of the first row hold one total each (reduce2_slot).  The row offset is a SCALAR product (j is
+                // wave-uniform); left to itself the compiler folds it into a v_mad_u64_u32 per visit.
                 uint32_t row;
 #if defined(__HIP_DEVICE_COMPILE__)
                 asm("s_mul_i32 %0, %1, %2" : "=s"(row) : "s"(j), "n"(NV));
 #else
                 row = (uint32_t)j * NV;
 #endif
-                if (lane < NV) (&s_part[0][0][0])[part_off + row] = t;
+                if (part_slot >= 0) atomicAdd(&(&s_part[0][0])[part_off + row], t);
             }
         }
         __syncthreads();
@@ -1168,15 +1220,15 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(int W, int H, int tiles_x, i
             const int r = tid & 15, q = tid >> 4;   // 8 groups of 16 lanes
             for (int jj = q; jj < cnt; jj += NT / 16) {
                 if (r < NV) {
-                    float v = s_part[0][jj][r] + s_part[1][jj][r];
+                    float v = s_part[jj][r];
                     if (r < 2) {        // moments -> d/d(pixel-space mean): this lane also needs the OTHER first-order moment
-                        const float mo = s_part[0][jj][r ^ 1] + s_part[1][jj][r ^ 1];
+                        const float mo = s_part[jj][r ^ 1];
                         const float cb = s_a[buf][jj].w;                                 // B'
                         const float c2 = 2.f * (r == 0 ? s_a[buf][jj].z : s_b[buf][jj].x);   // 2 A' (gx) or 2 C' (gy)
                         v = fmaf(cb, mo, c2 * v);
                     } else if (r < 5) v *= (r == 3 ? -1.f : -0.5f);                       // second moments -> conic gradients
                     __builtin_amdgcn_wave_barrier();   // every lane of the group has read both first moments before any is cleared
-                    s_part[0][jj][r] = 0.f; s_part[1][jj][r] = 0.f;   // ready for the next batch (its writers sit behind a barrier)
+                    s_part[jj][r] = 0.f;   // ready for the next batch (its writers sit behind a barrier)
                     // deterministic debug mode: the (tile, instance) partial goes to its own slot, k_det_reduce sums a
                     // Gaussian's slots in list order afterwards; default: one coalesced atomic per record row
                     if (det_part) det_part[((size_t)rg.x + (size_t)b * NT + jj) * kDetStride + r] = r < 2 ? v * kLn2 : v;

@@ -559,6 +559,11 @@ def main():
         lib.gsr_set_option(b"sort_algo", args.sort_algo)
     if args.tile_map >= 0:
         lib.gsr_set_option(b"tile_map", args.tile_map)
+    for kv in os.environ.get("GSR_OPTS", "").split(","):      # A/B runs: GSR_OPTS="exp_bwd=1,bwd_split=8"
+        if "=" in kv:
+            k, v = kv.split("=")
+            if lib.gsr_set_option(k.encode(), int(v)) != 0:
+                raise SystemExit(f"gsr_set_option({k}, {v}) refused")
 
     N, W, H, deg = args.gaussians, args.width, args.height, args.sh_degree
     scene = syn.make_scene(N, W, H, sh_degree=deg, seed=rank, clustered=args.clustered)

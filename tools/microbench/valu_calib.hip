@@ -21,11 +21,12 @@
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
-enum Op { OP_FMA, OP_PKFMA, OP_EXP, OP_RCP, OP_MUL, OP_CNDMASK, OP_DPP_ADD, OP_PERMSWAP, OP_FMA64, OP_MIX_BLEND, OP_COUNT };
+enum Op { OP_FMA, OP_PKFMA, OP_EXP, OP_RCP, OP_MUL, OP_CNDMASK, OP_DPP_ADD, OP_PERMSWAP, OP_FMA64, OP_MIX_BLEND, OP_CNDMASK_SGPR, OP_PERM16, OP_COUNT };
 static const char* kOpName[OP_COUNT] = {"v_fma_f32", "v_pk_fma_f32", "v_exp_f32", "v_rcp_f32", "v_mul_f32", "v_cndmask_b32",
-                                        "v_add_f32 dpp", "v_permlane32_swap", "v_fma_f64", "blend-mix (12 valu + 1 exp)"};
+                                        "v_add_f32 dpp", "v_permlane32_swap", "v_fma_f64", "blend-mix (12 valu + 1 exp)",
+                                        "v_cndmask_b32 (sgpr mask)", "v_permlane16_swap"};
 // vector instructions per unrolled body
-static const int kPerBody[OP_COUNT] = {8, 8, 8, 8, 8, 8, 8, 8, 8, 13};
+static const int kPerBody[OP_COUNT] = {8, 8, 8, 8, 8, 8, 8, 8, 8, 13, 8, 8};
 
 constexpr int kUnroll = 4;
 struct Stamp { unsigned long long c0, c1, r0, r1; };
@@ -83,6 +84,14 @@ __global__ void k_calib(int iters, Stamp* __restrict__ stamps, float* __restrict
             asm volatile("v_fma_f64 %0, %0, %8, %9\n v_fma_f64 %1, %1, %8, %9\n v_fma_f64 %2, %2, %8, %9\n v_fma_f64 %3, %3, %8, %9\n"
                          "v_fma_f64 %4, %4, %8, %9\n v_fma_f64 %5, %5, %8, %9\n v_fma_f64 %6, %6, %8, %9\n v_fma_f64 %7, %7, %8, %9"
                          : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7) : "v"(dm), "v"(dc));
+        } else if (OP == OP_CNDMASK_SGPR) {   // the select as the compiler emits it: VOP3 with the lane mask in an SGPR pair
+            asm volatile("v_cndmask_b32_e64 %0, %0, %8, %9\n v_cndmask_b32_e64 %1, %1, %8, %9\n v_cndmask_b32_e64 %2, %2, %8, %9\n v_cndmask_b32_e64 %3, %3, %8, %9\n"
+                         "v_cndmask_b32_e64 %4, %4, %8, %9\n v_cndmask_b32_e64 %5, %5, %8, %9\n v_cndmask_b32_e64 %6, %6, %8, %9\n v_cndmask_b32_e64 %7, %7, %8, %9"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "s"(0x5555555555555555ull));
+        } else if (OP == OP_PERM16) {
+            asm volatile("v_permlane16_swap_b32 %0, %1\n v_permlane16_swap_b32 %2, %3\n v_permlane16_swap_b32 %4, %5\n v_permlane16_swap_b32 %6, %7\n"
+                         "v_permlane16_swap_b32 %1, %2\n v_permlane16_swap_b32 %3, %4\n v_permlane16_swap_b32 %5, %6\n v_permlane16_swap_b32 %7, %0"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
         } else {   // the forward blend's per-visit mix: 2 sub, 3 fma/mul of the quadratic form, exp, mul+min, 2 cmp-ish selects, 5 fma
             asm volatile("v_sub_f32 %0, %8, %0\n v_sub_f32 %1, %9, %1\n v_mul_f32 %2, %0, %8\n v_fma_f32 %2, %1, %9, %2\n v_mul_f32 %3, %1, %1\n"
                          "v_fma_f32 %2, %3, %8, %2\n v_exp_f32 %3, %2\n v_mul_f32 %3, %3, %8\n v_min_f32 %3, %3, %9\n"
@@ -175,7 +184,7 @@ int main(int argc, char** argv)
     if (sweep<OP_FMA>(iters, d_st, d_sink, json) || sweep<OP_MUL>(iters, d_st, d_sink, json) || sweep<OP_PKFMA>(iters, d_st, d_sink, json) ||
         sweep<OP_EXP>(iters, d_st, d_sink, json) || sweep<OP_RCP>(iters, d_st, d_sink, json) || sweep<OP_CNDMASK>(iters, d_st, d_sink, json) ||
         sweep<OP_DPP_ADD>(iters, d_st, d_sink, json) || sweep<OP_PERMSWAP>(iters, d_st, d_sink, json) || sweep<OP_FMA64>(iters, d_st, d_sink, json) ||
-        sweep<OP_MIX_BLEND>(iters, d_st, d_sink, json))
+        sweep<OP_MIX_BLEND>(iters, d_st, d_sink, json) || sweep<OP_CNDMASK_SGPR>(iters, d_st, d_sink, json) || sweep<OP_PERM16>(iters, d_st, d_sink, json))
         return 1;
     // copy ceiling
     const size_t bytes = (size_t)1 << 30;
