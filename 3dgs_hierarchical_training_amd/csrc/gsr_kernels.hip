@@ -1306,6 +1306,10 @@ __device__ __forceinline__ void adam_rows(const float* s_g, int stride, int col0
 
 // the same update when the gradient tile is a linear copy of the rows (stage_in_lin): one 16-byte LDS read per 16-byte stream element
 // KEEP: the updated parameters also replace the gradients in the tile (the next-view tail reads its Gaussian's new row there)
+// (round 3, measured and dropped: keeping the rows a thread loaded for the tile in its registers -- 49 VGPRs -- and updating them
+//  from there, so that the update stream does not fetch the parameter rows a second time: 311-313 us against 300-318 box to box
+//  at 1 M, 305 against 261-289 for eight batched stage-A models -- the second fetch is served by L2 / the 256 MB infinity cache,
+//  the registers cost more than it does)
 template <bool KEEP>
 __device__ __forceinline__ void adam_rows_lin(float* s_g, int total, float* __restrict__ p, float* __restrict__ m,
                                               float* __restrict__ v, int tid, float step_size, const AdamDev& ad)
