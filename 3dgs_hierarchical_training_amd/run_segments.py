@@ -430,6 +430,8 @@ def main():
                     help="run stage A first (relative pose of every consecutive frame pair: single-image 3DGS of frame p, then the "
                          "SE(3) fit on frame p+1; pairs round-robin over the ranks, one all_gather) and chain ITS poses in stage B "
                          "instead of the synthetic ground truth.  The reference's counts are 1000 and 300 iterations")
+    ap.add_argument("--sh-up-every", type=int, default=1000, help="raise the active SH degree after every this many global iterations of a "
+                                                                  "model (the reference: 1000; a new leaf starts at degree 0)")
     ap.add_argument("--stage-a-batch", type=int, default=8, help="frame pairs of stage A fitted in one launch chain (GsrBatch); 1 = one pair "
                                                                 "per chain, two chains at a time on two streams (round 2)")
     ap.add_argument("--one-device", action="store_true", help="every rank on cuda:0 (with --backend gloo: the multi-process walk on a "
@@ -437,7 +439,7 @@ def main():
     a = ap.parse_args()
     cfg = HTConfig(frames=a.frames, width=a.width, height=a.height, gt_gaussians=a.gt_gaussians, leaf_gaussians=a.leaf_gaussians,
                    leaf_iters_per_frame=a.leaf_iters, phase1_iters_per_frame=a.phase1_iters, phase2_iters_per_frame=[a.phase2_iters] * 3,
-                   importance_views=a.importance_views, densify=a.densify, fit_pose=a.fit_pose, stage_a_batch=a.stage_a_batch)
+                   importance_views=a.importance_views, densify=a.densify, fit_pose=a.fit_pose, stage_a_batch=a.stage_a_batch, sh_up_every=a.sh_up_every)
     if a.pose_lr is not None:
         cfg.pose_lr = a.pose_lr
     if not torch.cuda.is_available():

@@ -637,11 +637,7 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    rccl = None
-    try:
-        rccl = rccl_probe(dist, dev, world, rank, backend)
-    except Exception as e:
-        rccl = {"world": world, "error": repr(e)}
+    rccl = None     # filled under the watchdog below, after the throughput result is safe
 
     # host-side work of the library per forward + backward in the timed steps (counters of gsr_get_counter, read after them)
     lib_host = None
@@ -662,15 +658,26 @@ def main():
 
     def bail():
         if rank == 0 and state["res"] is not None and not state["printed"]:
+            if state["res"].get("rccl") is None:
+                state["res"]["rccl"] = {"world": world, "error": "the process-group probe did not complete within 120 s (watchdog)"}
             state["res"]["merge"] = {"merge_ms": None, "error": "merge exchange did not complete within 120 s (watchdog)"}
             print(json.dumps(state["res"]), flush=True)
         os._exit(0)
 
     import threading
     dog = None
-    if world > 1 and not args.no_extras:
+    if world > 1:        # everything behind the timed steps that talks to another rank runs under this watchdog
         dog = threading.Timer(120.0, bail)
         dog.daemon = True
+
+    def run_probe():
+        nonlocal rccl
+        try:
+            rccl = rccl_probe(dist, dev, world, rank, backend)
+        except Exception as e:   # a diagnostic must never take the bench line down
+            rccl = {"world": world, "error": repr(e)}
+        if state["res"] is not None:
+            state["res"]["rccl"] = rccl
 
     def run_merge():
         nonlocal merge
@@ -684,6 +691,7 @@ def main():
     if rank != 0:
         if dog is not None:
             dog.start()
+        run_probe()
         run_merge()
         if dog is not None:
             dog.cancel()
@@ -808,6 +816,7 @@ def main():
     state["res"] = res
     if dog is not None:
         dog.start()
+    run_probe()
     run_merge()
     if dog is not None:
         dog.cancel()
