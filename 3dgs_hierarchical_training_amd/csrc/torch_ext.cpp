@@ -156,8 +156,8 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> raste
     mp[0] = out.num_rendered; mp[1] = out.binning_capacity; mp[2] = out.forward_flags;
     Tensor binning = actx.binning.defined() ? actx.binning : at::empty({0}, bo);
     {
-        Tensor dims = at::empty({2}, at::TensorOptions().dtype(at::kLong));
-        dims.data_ptr<int64_t>()[0] = W; dims.data_ptr<int64_t>()[1] = H * NB;   // (the staged counters of a batch: one tall image)
+        Tensor dims = at::empty({3}, at::TensorOptions().dtype(at::kLong));
+        dims.data_ptr<int64_t>()[0] = W; dims.data_ptr<int64_t>()[1] = H; dims.data_ptr<int64_t>()[2] = NB;
         std::lock_guard<std::mutex> lk(g_last_mutex);
         g_last = {image, binning, meta, dims};
     }

@@ -41,7 +41,7 @@ class GaussianRasterizationSettings(NamedTuple):
 
 
 # diagnostics of the most recent forward (bench.py reads R and the per-tile staged counters from here)
-_LAST = {"num_rendered": 0, "image": None, "W": 0, "H": 0}
+_LAST = {"num_rendered": 0, "image": None, "W": 0, "H": 0, "B": 1}
 
 
 def _sync_last():
@@ -52,18 +52,18 @@ def _sync_last():
     if len(rec) == 4:
         image, binning, meta, dims = rec
         _LAST.update(num_rendered=int(meta[0]), binning_capacity=int(meta[1]), image=image, binning=binning if binning.numel() else None,
-                     W=int(dims[0]), H=int(dims[1]))
+                     W=int(dims[0]), H=int(dims[1]), B=int(dims[2]) if dims.numel() > 2 else 1)
 
 
 def last_call_info():
     """{'num_rendered': R, 'staged': R_eff} of the most recent forward on this process."""
     lib = L.load()
     _sync_last()
-    img, W, H = _LAST["image"], _LAST["W"], _LAST["H"]
+    img, W, H, B = _LAST["image"], _LAST["W"], _LAST["H"], _LAST.get("B", 1)
     staged = 0
     if img is not None:
-        off = lib.gsr_image_staged_offset(W, H)
-        T = ((W + 15) // 16) * ((H + 15) // 16)
+        T = ((W + 15) // 16) * ((H + 15) // 16) * B          # (a batched render: B images, one tall tile grid)
+        off = lib.gsr_image_bytes_batched(W, H, B) - ((T * 16 + 255) // 256) * 256
         # four counters per tile (one per 8x8 sub-tile wave; tile-level kernels use slot 0): the tile's staged depth
         # is the deepest of its waves
         staged = int(img[off:off + 16 * T].view(torch.int32).view(T, 4).max(dim=1).values.sum().item())
@@ -78,6 +78,8 @@ def last_binning():
     b, W, H, R = _LAST.get("binning"), _LAST["W"], _LAST["H"], _LAST["num_rendered"]
     if b is None:
         raise RuntimeError("no forward has run yet")
+    if _LAST.get("B", 1) > 1:
+        raise RuntimeError("last_binning: not available for a batched render")
     T = ((W + 15) // 16) * ((H + 15) // 16)
     ranges = torch.empty((T, 2), dtype=torch.int32, device=b.device)
     lst = torch.empty((max(R, 1),), dtype=torch.int32, device=b.device)
@@ -183,7 +185,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             L.check(lib.gsr_forward(C.byref(a), C.byref(out), C.c_void_p(stream)), "gsr_forward")
         ws.scratch.clear()  # stream-ordered reuse by the caching allocator is safe: same stream
 
-        _LAST.update(num_rendered=int(out.num_rendered), image=image, W=W, H=H, binning=ws.binning,
+        _LAST.update(num_rendered=int(out.num_rendered), image=image, W=W, H=H, B=1, binning=ws.binning,
                      binning_capacity=int(out.binning_capacity))
         ctx.raster_settings = rs
         ctx.num_rendered = int(out.num_rendered)
