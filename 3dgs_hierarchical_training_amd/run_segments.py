@@ -92,7 +92,9 @@ class HTConfig:
     optimizer: str = "hip"
     fused: bool = True
     stage_a_concurrency: int = 2                # frame pairs fitted at the same time per GPU (streams + host threads), stage_a.run_stage_a
-    stage_a_batch: int = 8                      # frame pairs fitted in ONE launch chain per GPU (stage_a.fit_pairs_batched, GsrBatch); 1 = off
+    stage_a_batch: int = 0                      # frame pairs fitted in ONE launch chain per GPU (stage_a.fit_pairs_batched, GsrBatch); 1 = off;
+                                                # 0 = automatic: 4 per chain with two chains at a time when the host has the CPUs for two launching
+                                                # threads (39 pairs: 6.3 s), 8 per chain otherwise (6.9 s); round 2's one pair per chain on two streams: 8.1 s
     fit_pose: bool = False                      # refine each frame's pose while training on it (training_setup(fit_pose=True), :733)
     pose_lr: float = 1e-5                       # Adam with eps 1e-15 moves a pose by ~lr per step whatever the gradient: on these
                                                 # frames (1-2 px of motion per frame) 5e-6..2e-5 gains 0.4-0.6 dB over fixed stage-A
@@ -387,10 +389,11 @@ def run_stage_a_on(seq, cfg, dev, spec, rank: int, world: int, group=None, log=N
     # instance count), and the ranks of a node share the container's CPU quota
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", "1" if world == 1 else str(world)))
     conc = max(1, min(cfg.stage_a_concurrency, host_mod.usable_cpus()[0] // (2 * max(1, local_world))))
+    batch = cfg.stage_a_batch if cfg.stage_a_batch > 0 else (4 if conc > 1 else 8)
     table = stage_a.run_stage_a(cfg.frames, lambda p: stage_a.fit_pair(seq, p, dev, n_points=n_points, single_image_iters=image_iters,
                                                                         pose_iters=pose_iters, seed=cfg.seed),
                                 gather_device or dev, rank=rank, world=world, group=group, concurrency=conc, fit_device=dev,
-                                batch=cfg.stage_a_batch,
+                                batch=batch,
                                 batch_fn=lambda ps: stage_a.fit_pairs_batched(seq, ps, dev, n_points=n_points, single_image_iters=image_iters,
                                                                               pose_iters=pose_iters, seed=cfg.seed))
     if dev.type == "cuda":
@@ -400,8 +403,8 @@ def run_stage_a_on(seq, cfg, dev, spec, rank: int, world: int, group=None, log=N
     seq.use_pose_table(table)
     rec = {"rank": rank, "phase": "stage_a", "pairs_total": cfg.frames - 1, "pairs_here": len(stage_a.pairs_of_rank(cfg.frames, rank, world)),
            "gaussians": n_points, "image_iters": image_iters, "pose_iters": pose_iters,
-           "pairs_at_a_time": cfg.stage_a_batch if cfg.stage_a_batch > 1 else conc,
-           "mode": f"batched: {cfg.stage_a_batch} pairs per launch chain" if cfg.stage_a_batch > 1 else f"{conc} stream(s), one pair each",
+           "pairs_at_a_time": batch * conc if batch > 1 else conc,
+           "mode": f"batched: {batch} pairs per launch chain, {conc} chain(s) at a time" if batch > 1 else f"{conc} stream(s), one pair each",
            "ms": 1e3 * (time.perf_counter() - t0),
            "max_abs_pose_error": err, "identity_guess_error": ident}
     (log or emit_line)(rec)
@@ -432,8 +435,9 @@ def main():
                          "instead of the synthetic ground truth.  The reference's counts are 1000 and 300 iterations")
     ap.add_argument("--sh-up-every", type=int, default=1000, help="raise the active SH degree after every this many global iterations of a "
                                                                   "model (the reference: 1000; a new leaf starts at degree 0)")
-    ap.add_argument("--stage-a-batch", type=int, default=8, help="frame pairs of stage A fitted in one launch chain (GsrBatch); 1 = one pair "
-                                                                "per chain, two chains at a time on two streams (round 2)")
+    ap.add_argument("--stage-a-batch", type=int, default=0, help="frame pairs of stage A fitted in one launch chain (GsrBatch); 0 = automatic "
+                                                                "(4 per chain, two chains at a time; 8 when the host has CPUs for one launching "
+                                                                "thread only), 1 = one pair per chain, two chains at a time (round 2)")
     ap.add_argument("--one-device", action="store_true", help="every rank on cuda:0 (with --backend gloo: the multi-process walk on a "
                                                               "one-GPU box; messages are staged through host memory)")
     a = ap.parse_args()

@@ -74,10 +74,32 @@ def run_stage_a(n_frames: int, fit_fn: Callable[[int], torch.Tensor], device, ra
         rank = dist.get_rank(group) if dist.is_initialized() else 0
     mine = pairs_of_rank(n_frames, rank, world)
     if batch_fn is not None and batch > 1 and len(mine) > 1:
-        # `batch` of this rank's pairs per launch chain (fit_pairs_batched): the GPU sees one model `batch` times the size
+        # `batch` of this rank's pairs per launch chain (fit_pairs_batched): the GPU sees one model `batch` times the size.
+        # With concurrency > 1 two such chains run at a time, each on its own stream and host thread: one chain's sorts and scans
+        # (latency chains, a few dozen workgroups) then overlap the other's blends.
+        groups = [mine[lo:lo + batch] for lo in range(0, len(mine), batch)]
         results = {}
-        for lo in range(0, len(mine), batch):
-            results.update(batch_fn(mine[lo:lo + batch]))
+        if concurrency > 1 and fit_device is not None and torch.device(fit_device).type == "cuda" and len(groups) > 1:
+            import threading
+            from concurrent.futures import ThreadPoolExecutor
+            fdev = torch.device(fit_device)
+            main = torch.cuda.current_stream(fdev)
+            tls = threading.local()
+
+            def work_group(g):
+                if not hasattr(tls, "stream"):
+                    tls.stream = torch.cuda.Stream(fdev)
+                    tls.stream.wait_stream(main)
+                with torch.cuda.stream(tls.stream):
+                    r = batch_fn(g)
+                    tls.stream.synchronize()
+                return r
+            with ThreadPoolExecutor(max_workers=concurrency) as ex:
+                for r in ex.map(work_group, groups):
+                    results.update(r)
+        else:
+            for g in groups:
+                results.update(batch_fn(g))
     elif concurrency > 1 and fit_device is not None and torch.device(fit_device).type == "cuda" and len(mine) > 1:
         import threading
         from concurrent.futures import ThreadPoolExecutor

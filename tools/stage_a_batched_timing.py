@@ -24,8 +24,9 @@ for B in (1, 2, 4, 8):
     torch.cuda.synchronize(); t2 = time.perf_counter()
     out[f"B={B}"] = {"image_iteration_ms_per_pair": 1e3 * (t1 - t0) / 200 / B, "pose_iteration_ms_per_pair": 1e3 * ((t2 - t1) - (t1 - t0)) / 100 / B}
     print(B, out[f"B={B}"], flush=True)
-for mode, batch in (("batched x8", 8), ("batched x4", 4), ("two streams (round 2)", 1)):
-    cfg = rs.HTConfig(frames=frames, stage_a_batch=batch)
+for mode, batch, conc in (("batched x8", 8, 1), ("batched x4, two chains at a time", 4, 2), ("batched x8, two chains at a time", 8, 2),
+                          ("batched x4", 4, 1), ("two streams (round 2)", 1, 2), ("default (auto)", 0, 2)):
+    cfg = rs.HTConfig(frames=frames, stage_a_batch=batch, stage_a_concurrency=conc)
     seq.pose_table = None
     torch.cuda.synchronize(); t0 = time.perf_counter()
     rec = rs.run_stage_a_on(seq, cfg, dev, (130000, img_it, pose_it), 0, 1, log=lambda r: None)
