@@ -868,7 +868,9 @@ __global__ __launch_bounds__(64) void k_blend_fwd_w6(int W, int H, int tiles_x, 
                                                      float* __restrict__ ckpt, int kCkptFirst, int tiles_y)
 {
     constexpr int NT = 64;
-    __shared__ float4 s_a[2][NT], s_b[2][NT];
+    // s_a and s_b in ONE array (planes 0/1 = A rows of the two buffers, 2/3 = B rows): a visit's two reads share one address
+    // register and differ in the immediate offset
+    __shared__ float4 s_ab[4][NT];
     __shared__ float2 s_c[2][NT];
     const int kslot = blockIdx.x >> 3;
     const int tile = slot_tile(interleave, (int)(blockIdx.x & 7), kslot >> 2, T, tiles_x);
@@ -912,7 +914,7 @@ __global__ __launch_bounds__(64) void k_blend_fwd_w6(int W, int H, int tiles_x, 
             float* c = ckpt + ((size_t)(rg.x >> 7) + tile + (b >> 1) - kCkptFirst) * kCkptFloats + sub * 64 + lane;
             c[0] = fabsf(Tr); c[256] = C0; c[512] = C1; c[768] = C2; c[1024] = Dd; c[1280] = Aa;
         }
-        s_a[buf][lane] = ra; s_b[buf][lane] = rb; s_c[buf][lane] = make_float2(rc.x, rc.y);
+        s_ab[buf][lane] = ra; s_ab[2 + buf][lane] = rb; s_c[buf][lane] = make_float2(rc.x, rc.y);
         const int cnt = min(NT, n - b * NT);
         const unsigned long long reach = REACH ? __ballot(reach_nxt && lane < cnt) : 0ull;
         reach_nxt = false;
@@ -921,8 +923,8 @@ __global__ __launch_bounds__(64) void k_blend_fwd_w6(int W, int H, int tiles_x, 
         const int nxt = (b + 1) * NT + lane;
         if (nxt < n) fetch(nxt);
         auto alpha_of = [&](int j, float& p2) {
-            const float4 A = s_a[buf][j];
-            const float2 Bq = *reinterpret_cast<const float2*>(&s_b[buf][j]);   // C', opacity
+            const float4 A = s_ab[buf][j];
+            const float2 Bq = *reinterpret_cast<const float2*>(&s_ab[2 + buf][j]);   // C', opacity
             const float dx = A.x - pxf, dy = A.y - pyf;
             p2 = fmaf(Bq.x * dy, dy, fmaf(A.w, dy, A.z * dx) * dx);   // log2 of the Gaussian weight
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -933,7 +935,7 @@ __global__ __launch_bounds__(64) void k_blend_fwd_w6(int W, int H, int tiles_x, 
         };
         auto blend = [&](int j, float p2, float alpha) {
             if (p2 > 0.f || alpha < kAlphaMin) return;
-            const float4 B = s_b[buf][j];
+            const float4 B = s_ab[2 + buf][j];
             const float2 C = s_c[buf][j];
             const float test_T = Tr * (1.f - alpha);          // negative for a finished pixel: fails the stop test below
             const bool pass = !(test_T < kTStop);
@@ -1009,7 +1011,7 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(int W, int H, int tiles_x, i
         for (int q = threadIdx.x; q < zero_count; q += NT) zero_words[q] = 0u;
     // single staging buffer: a batch is ~10^4 cycles of compute, so the second barrier per batch is free, and the
     // smaller LDS footprint lets more tiles share a CU (latency hiding: waves were 33% in s_waitcnt / barriers)
-    __shared__ float4 s_a[1][NT], s_b[1][NT], s_c[1][NT];
+    __shared__ float4 s_abc[3][NT];   // planes: A rows, B rows, C rows -- ONE array, so a visit's reads share an address register
     __shared__ uint32_t s_gid[1][NT];
     // ONE row of partials per staged instance: the tile's two waves add theirs into it with ds_add_f32 (each touches a record's nine
     // words once per batch, from nine lanes: conflict-free; 0 + a + b = 0 + b + a, so the arrival order does not matter).  Round 3:
@@ -1134,7 +1136,7 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(int W, int H, int tiles_x, i
     for (int b = b0; b < b1; b++) {
         const int buf = 0;
         if (b > b0) __syncthreads();   // everyone is done reading the previous batch (and its flush read s_gid)
-        s_a[buf][tid] = ra; s_b[buf][tid] = rb; s_c[buf][tid] = rc; s_gid[buf][tid] = rg_id;
+        s_abc[0][tid] = ra; s_abc[1][tid] = rb; s_abc[2][tid] = rc; s_gid[buf][tid] = rg_id;
         __syncthreads();
         const int nxt = (b + 1) * NT + tid;
         if (nxt < n && b + 1 < b1) stage(nxt);
@@ -1144,14 +1146,14 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(int W, int H, int tiles_x, i
         // the reach bits of the batch as two wave-uniform 64-bit masks: the loop below visits set bits only, so an
         // instance this half cannot reach costs nothing at all
         const uint32_t wbit = 1u << wave;
-        const bool r0 = lane < cntw && (__float_as_uint(s_c[buf][lane].w) & wbit);
-        const bool r1 = lane + 64 < cntw && (__float_as_uint(s_c[buf][lane + 64].w) & wbit);
+        const bool r0 = lane < cntw && (__float_as_uint(s_abc[2][lane].w) & wbit);
+        const bool r1 = lane + 64 < cntw && (__float_as_uint(s_abc[2][lane + 64].w) & wbit);
         const unsigned long long reach[2] = {__ballot(r0), __ballot(r1)};
 #pragma unroll 1
         for (int half = 0; half < 2; half++)
         for (unsigned long long rm = reach[half]; rm != 0ull; rm &= rm - 1ull) {
             const int j = half * 64 + (int)__builtin_ctzll(rm);
-            const float4 A = s_a[buf][j], B = s_b[buf][j], C = s_c[buf][j];   // (manual LDS prefetch measured slower)
+            const float4 A = s_abc[0][j], B = s_abc[1][j], C = s_abc[2][j];   // (manual LDS prefetch measured slower)
             const uint32_t idx = (uint32_t)(b * NT + j + 1);
             const float ca = A.z, cb = A.w, cc = B.x, op = B.y, zd = B.z, cr = B.w, cg = C.x, cbl = C.y;   // ca/cb/cc: A', B', C'
             const float dx = A.x - pxf;
@@ -1168,7 +1170,12 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(int W, int H, int tiles_x, i
             alpha.x = fminf(kAlphaMax, alpha.x); alpha.y = fminf(kAlphaMax, alpha.y);
             const bool v0 = !(p2.x > 0.f || alpha.x < kAlphaMin) && idx <= ncon[0];
             const bool v1 = !(p2.y > 0.f || alpha.y < kAlphaMin) && idx <= ncon[1];
-            if (__ballot(v0 || v1) != 0ull) {   // wave-uniform (scalar compare; __any materialises a VGPR)
+            // wave-uniform test on the compare masks themselves: a ballot of the combined bool is lowered to v_cndmask + v_cmp
+            // (two vector instructions per visit, taken or not); ballots of the single compares ARE the compares' SGPR results
+            const unsigned long long any01 =
+                (__builtin_amdgcn_ballot_w64(!(p2.x > 0.f)) & __builtin_amdgcn_ballot_w64(!(alpha.x < kAlphaMin)) & __builtin_amdgcn_ballot_w64(idx <= ncon[0])) |
+                (__builtin_amdgcn_ballot_w64(!(p2.y > 0.f)) & __builtin_amdgcn_ballot_w64(!(alpha.y < kAlphaMin)) & __builtin_amdgcn_ballot_w64(idx <= ncon[1]));
+            if (any01 != 0ull) {
                 alpha.x = v0 ? alpha.x : 0.f; alpha.y = v1 ? alpha.y : 0.f;
                 G.x = v0 ? G.x : 0.f; G.y = v1 ? G.y : 0.f;
                 const f2 w = alpha * Tt;
@@ -1228,8 +1235,8 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(int W, int H, int tiles_x, i
                     float v = s_part[jj][r];
                     if (r < 2) {        // moments -> d/d(pixel-space mean): this lane also needs the OTHER first-order moment
                         const float mo = s_part[jj][r ^ 1];
-                        const float cb = s_a[buf][jj].w;                                 // B'
-                        const float c2 = 2.f * (r == 0 ? s_a[buf][jj].z : s_b[buf][jj].x);   // 2 A' (gx) or 2 C' (gy)
+                        const float cb = s_abc[0][jj].w;                                // B'
+                        const float c2 = 2.f * (r == 0 ? s_abc[0][jj].z : s_abc[1][jj].x);   // 2 A' (gx) or 2 C' (gy)
                         v = fmaf(cb, mo, c2 * v);
                     } else if (r < 5) v *= (r == 3 ? -1.f : -0.5f);                       // second moments -> conic gradients
                     __builtin_amdgcn_wave_barrier();   // every lane of the group has read both first moments before any is cleared
