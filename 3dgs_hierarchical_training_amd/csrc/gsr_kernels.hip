@@ -1166,18 +1166,21 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(int W, int H, int tiles_x, i
 #else
             f2 G = {exp2f(p2.x), exp2f(p2.y)};
 #endif
-            f2 alpha = op * G;
-            alpha.x = fminf(kAlphaMax, alpha.x); alpha.y = fminf(kAlphaMax, alpha.y);
-            const bool v0 = !(p2.x > 0.f || alpha.x < kAlphaMin) && idx <= ncon[0];
-            const bool v1 = !(p2.y > 0.f || alpha.y < kAlphaMin) && idx <= ncon[1];
+            f2 alpha = op * G;   // clamped to kAlphaMax only once the visit is taken (the 1/255 test below reads the same either way)
+            const bool c0p = !(p2.x > 0.f), c0a = !(alpha.x < kAlphaMin), c0n = idx <= ncon[0];
+            const bool c1p = !(p2.y > 0.f), c1a = !(alpha.y < kAlphaMin), c1n = idx <= ncon[1];
+            const bool v0 = c0p && c0a && c0n, v1 = c1p && c1a && c1n;
             // wave-uniform test on the compare masks themselves: a ballot of the combined bool is lowered to v_cndmask + v_cmp
             // (two vector instructions per visit, taken or not); ballots of the single compares ARE the compares' SGPR results
             const unsigned long long any01 =
-                (__builtin_amdgcn_ballot_w64(!(p2.x > 0.f)) & __builtin_amdgcn_ballot_w64(!(alpha.x < kAlphaMin)) & __builtin_amdgcn_ballot_w64(idx <= ncon[0])) |
-                (__builtin_amdgcn_ballot_w64(!(p2.y > 0.f)) & __builtin_amdgcn_ballot_w64(!(alpha.y < kAlphaMin)) & __builtin_amdgcn_ballot_w64(idx <= ncon[1]));
+                (__builtin_amdgcn_ballot_w64(c0p) & __builtin_amdgcn_ballot_w64(c0a) & __builtin_amdgcn_ballot_w64(c0n)) |
+                (__builtin_amdgcn_ballot_w64(c1p) & __builtin_amdgcn_ballot_w64(c1a) & __builtin_amdgcn_ballot_w64(c1n));
             if (any01 != 0ull) {
-                alpha.x = v0 ? alpha.x : 0.f; alpha.y = v1 ? alpha.y : 0.f;
+                // mask G, then alpha from the masked G: two selects, a packed multiply and the clamp instead of four selects here
+                // and the clamp on every visit
                 G.x = v0 ? G.x : 0.f; G.y = v1 ? G.y : 0.f;
+                alpha = op * G;
+                alpha.x = fminf(kAlphaMax, alpha.x); alpha.y = fminf(kAlphaMax, alpha.y);
                 const f2 w = alpha * Tt;
                 f2 gc = gC0 * cr + gC1 * cg + gC2 * cbl;          // <gC, colour of this Gaussian> (+ depth / alpha terms)
                 if (HAS_DA) gc += gD * zd + gA;
