@@ -859,24 +859,26 @@ __global__ __launch_bounds__(256) void k_tile_ranges(uint32_t R, const KeyT* __r
 // exists anyway masks it.  One divergent region per iteration remains (lanes whose alpha passes), inside it the stop is
 // a select, not a branch.  Decisions and results are bit-identical with k_blend_fwd_w for every live lane.
 // ------------------------------------------------------------------------------------------------
+#ifdef GSR_K6_TIMING   // experiment build only (tools/k6_wave_timing.py): per-wave start / end / placement of the forward blend
+__device__ unsigned long long g_k6_dbg[4 * 65536];
+#endif
 template <bool REACH>
-__global__ __launch_bounds__(64) void k_blend_fwd_w6(int W, int H, int tiles_x, int T, const uint2* __restrict__ ranges,
-                                                     const uint32_t* __restrict__ list, const Splat* __restrict__ splat,
-                                                     const float* __restrict__ bg, float* __restrict__ out_color,
-                                                     float* __restrict__ out_depth, float* __restrict__ out_alpha,
-                                                     float* __restrict__ img, uint32_t* __restrict__ staged4, int interleave,
-                                                     float* __restrict__ ckpt, int kCkptFirst, int tiles_y)
+__device__ __forceinline__ void blend_fwd_item(const int xcd, const int kslot, float4 (*s_ab)[64], float2 (*s_c)[64],
+                                               int W, int H, int tiles_x, int T, const uint2* __restrict__ ranges,
+                                               const uint32_t* __restrict__ list, const Splat* __restrict__ splat,
+                                               const float* __restrict__ bg, float* __restrict__ out_color,
+                                               float* __restrict__ out_depth, float* __restrict__ out_alpha,
+                                               float* __restrict__ img, uint32_t* __restrict__ staged4, int interleave,
+                                               float* __restrict__ ckpt, int kCkptFirst, int tiles_y)
 {
     constexpr int NT = 64;
-    // s_a and s_b in ONE array (planes 0/1 = A rows of the two buffers, 2/3 = B rows): a visit's two reads share one address
-    // register and differ in the immediate offset
-    __shared__ float4 s_ab[4][NT];
-    __shared__ float2 s_c[2][NT];
-    const int kslot = blockIdx.x >> 3;
-    const int tile = slot_tile(interleave, (int)(blockIdx.x & 7), kslot >> 2, T, tiles_x);
+#ifdef GSR_K6_TIMING
+    const unsigned long long dbg_t0 = wall_clock64();
+#endif
+    const int tile = slot_tile(interleave, xcd, kslot >> 2, T, tiles_x);
     const int sub = kslot & 3;
     if (tile < 0) return;
-    const int lane = threadIdx.x;
+    const int lane = (int)(threadIdx.x & 63u);
     // batched render: T = B tiles_x tiles_y tiles of a tall grid, image `bimg` owns the tile rows [bimg tiles_y, (bimg + 1) tiles_y)
     const int Tl = tiles_x * tiles_y, bimg = tile / Tl, tl = tile - bimg * Tl;
     const int tx = tl % tiles_x, ty = tl / tiles_x;
@@ -918,7 +920,12 @@ __global__ __launch_bounds__(64) void k_blend_fwd_w6(int W, int H, int tiles_x, 
         const int cnt = min(NT, n - b * NT);
         const unsigned long long reach = REACH ? __ballot(reach_nxt && lane < cnt) : 0ull;
         reach_nxt = false;
-        __syncthreads();   // single-wave workgroup: just orders the LDS writes before the broadcast reads
+        // the staging area belongs to this wave alone: LDS instructions of one wave execute in issue order, so the broadcast
+        // reads below see the writes above -- only the compiler must be kept from reordering them (no s_barrier: the queue
+        // kernel runs sixteen independent waves per workgroup)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         batches = b + 1;
         const int nxt = (b + 1) * NT + lane;
         if (nxt < n) fetch(nxt);
@@ -934,17 +941,23 @@ __global__ __launch_bounds__(64) void k_blend_fwd_w6(int W, int H, int tiles_x, 
 #endif
         };
         auto blend = [&](int j, float p2, float alpha) {
-            if (p2 > 0.f || alpha < kAlphaMin) return;
+            // No divergent region: the visit is skipped when NO lane's alpha passes (scalar test on the compare masks); otherwise
+            // every lane runs the blend with alpha = 0 where its own test failed -- a live pixel then passes the stop test with
+            // test_T = T and adds (+-)0 everywhere.  (The exec-masked form cost s_and_saveexec + s_or exec on every visit, taken or
+            // not: this loop is bound by instructions issued per wave, scalar ones included.)
+            const bool hit = !(p2 > 0.f) && !(alpha < kAlphaMin);
+            if ((__builtin_amdgcn_ballot_w64(!(p2 > 0.f)) & __builtin_amdgcn_ballot_w64(!(alpha < kAlphaMin))) == 0ull) return;
             const float4 B = s_ab[2 + buf][j];
             const float2 C = s_c[buf][j];
-            const float test_T = Tr * (1.f - alpha);          // negative for a finished pixel: fails the stop test below
+            const float am = hit ? alpha : 0.f;
+            const float test_T = Tr * (1.f - am);             // negative for a finished pixel: fails the stop test below
             const bool pass = !(test_T < kTStop);
-            const float asel = pass ? alpha : 0.f;            // a lane that does not blend adds (+-)0 to everything below
+            const float asel = pass ? am : 0.f;               // a lane that does not blend adds (+-)0 to everything below
             const float w = asel * Tr;
             C0 = fmaf(B.w, w, C0); C1 = fmaf(C.x, w, C1); C2 = fmaf(C.y, w, C2);
             Dd = fmaf(B.z, w, Dd); Aa = fmaf(Tr, asel, Aa);   // (k_blend_fwd_w's `A += alpha * T` is contracted to this fma)
             Tr = pass ? test_T : -fabsf(Tr);                  // first failure flips the sign: done, |T| kept
-            last = pass ? (uint32_t)(b * NT + j + 1) : last;
+            last = (pass && hit) ? (uint32_t)(b * NT + j + 1) : last;
         };
         // (round 3: issuing visit k + 1's broadcast reads before visit k's arithmetic -- two register sets, loop unrolled by two, no
         //  copies -- 117 -> 131 us with all three reads prefetched, 135 us with the pre-test fields only: the LDS round trip is not what a
@@ -953,8 +966,13 @@ __global__ __launch_bounds__(64) void k_blend_fwd_w6(int W, int H, int tiles_x, 
         //  one 16-byte-stride array for the three staged planes, so that a visit needs one address register instead of two:
         //  one v_mov less per visit but 6 instead of 5 kB of LDS per wave -- 26 instead of 32 waves per CU -- 109 -> 113 us)
         if (REACH) {
-            for (unsigned long long rm = reach; rm != 0ull; rm &= rm - 1ull) {
+            for (unsigned long long rm = reach; rm != 0ull;) {
                 const int j = (int)__builtin_ctzll(rm);
+#if defined(__HIP_DEVICE_COMPILE__)
+                asm("s_bitset0_b64 %0, %1" : "+s"(rm) : "s"(j));   // rm &= rm - 1 is s_add_u32 + s_addc_u32 + s_and_b64
+#else
+                rm &= rm - 1ull;
+#endif
                 float p2;
                 const float a1 = alpha_of(j, p2);
                 blend(j, p2, a1);
@@ -968,6 +986,14 @@ __global__ __launch_bounds__(64) void k_blend_fwd_w6(int W, int H, int tiles_x, 
         }
     }
     if (lane == 0) staged4[tile * 4 + sub] = (uint32_t)min(n, batches * NT);
+#ifdef GSR_K6_TIMING
+    if (lane == 0 && xcd + 8 * kslot < 65536) {
+        unsigned long long* d = g_k6_dbg + 4 * (size_t)(xcd + 8 * kslot);
+        d[0] = dbg_t0; d[1] = wall_clock64();
+        d[2] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+        d[3] = ((unsigned long long)(uint32_t)n << 32) | (uint32_t)(batches * NT);
+    }
+#endif
     if (inside) {
         const size_t Pl = (size_t)W * H, P = Pl * (size_t)(T / Tl), pl = (size_t)py * W + px, pid = (size_t)bimg * Pl + pl;
         const float Tf = fabsf(Tr);
@@ -983,6 +1009,32 @@ __global__ __launch_bounds__(64) void k_blend_fwd_w6(int W, int H, int tiles_x, 
         out_alpha[pid] = Aa;
     }
 }
+
+
+template <bool REACH>
+__global__ __launch_bounds__(64) void k_blend_fwd_w6(int W, int H, int tiles_x, int T, const uint2* __restrict__ ranges,
+                                                     const uint32_t* __restrict__ list, const Splat* __restrict__ splat,
+                                                     const float* __restrict__ bg, float* __restrict__ out_color,
+                                                     float* __restrict__ out_depth, float* __restrict__ out_alpha,
+                                                     float* __restrict__ img, uint32_t* __restrict__ staged4, int interleave,
+                                                     float* __restrict__ ckpt, int kCkptFirst, int tiles_y)
+{
+    // s_a and s_b in ONE array (planes 0/1 = A rows of the two buffers, 2/3 = B rows): a visit's two reads share one address
+    // register and differ in the immediate offset
+    __shared__ float4 s_ab[4][64];
+    __shared__ float2 s_c[2][64];
+    blend_fwd_item<REACH>((int)(blockIdx.x & 7), (int)(blockIdx.x >> 3), s_ab, s_c, W, H, tiles_x, T, ranges, list, splat, bg, out_color, out_depth,
+                          out_alpha, img, staged4, interleave, ckpt, kCkptFirst, tiles_y);
+}
+
+// (round 3, measured with tools/k6_wave_timing.py on the 1 M / 980x545 frame: the 8.6 k waves are all resident at once, eight to
+//  a SIMD; they start within 2 us, last 57 us on average (p90 76, max 104), half are gone after 58 us and the SIMDs finish between
+//  75 and 106 us -- a SIMD is done when the sum of ITS eight random lists is done, and what is left at the end cannot fill the
+//  vector pipe: one wave alone issues an instruction every 5.5 cycles, of any kind, against 2.4 cycles per VALU instruction for a
+//  full SIMD.  Pulling the (tile, sub-tile) items from a queue instead -- one 16-wave workgroup per CU, a counter in LDS, ~33 items
+//  per workgroup, bit-identical image -- evens the waves out but leaves four per SIMD: 132 us (three: 148, two: 190): per-wave
+//  issue, ~55 instructions of all kinds per visit, is what bounds the loop, so residency beats balance.  One counter per XCD in
+//  global memory: 210 us -- agent-scope atomics on one address complete about every 0.2 us.  The queue kernel is not kept.)
 
 // ------------------------------------------------------------------------------------------------
 // K8: backward blend.  Same staging as the forward; front-to-back replay from the stored totals.  The per-(pixel, Gaussian)
@@ -2022,6 +2074,12 @@ int gsr_prepare_supported(int32_t M, int32_t D, int32_t raw_params) { return (ra
 const char* gsr_last_error(void) { return g_err; }
 int gsr_version(void) { return 100; }
 
+#ifdef GSR_K6_TIMING
+int gsr_debug_k6_timing(unsigned long long* host_dst, int blocks)
+{
+    return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_k6_dbg), sizeof(unsigned long long) * 4 * (size_t)blocks);
+}
+#endif
 int gsr_set_option(const char* name, int value)
 {
     if (!name) return GSR_ERR_ARG;
