@@ -1034,7 +1034,9 @@ __global__ __launch_bounds__(64) void k_blend_fwd_w6(int W, int H, int tiles_x, 
 //  full SIMD.  Pulling the (tile, sub-tile) items from a queue instead -- one 16-wave workgroup per CU, a counter in LDS, ~33 items
 //  per workgroup, bit-identical image -- evens the waves out but leaves four per SIMD: 132 us (three: 148, two: 190): per-wave
 //  issue, ~55 instructions of all kinds per visit, is what bounds the loop, so residency beats balance.  One counter per XCD in
-//  global memory: 210 us -- agent-scope atomics on one address complete about every 0.2 us.  The queue kernel is not kept.)
+//  global memory: 210 us -- agent-scope atomics on one address complete about every 0.2 us.  The queue kernel is not kept.
+//  Records kept in registers (lane j = instance j) and broadcast with v_readlane_b32 instead of LDS reads -- no LDS, no waits in
+//  the visit -- 115 -> 173 us: ten v_readlane per taken visit cost far more vector issue than the two address moves they replace.)
 
 // ------------------------------------------------------------------------------------------------
 // K8: backward blend.  Same staging as the forward; front-to-back replay from the stored totals.  The per-(pixel, Gaussian)
