@@ -11,6 +11,7 @@
 //   backward  K8 k_blend_bwd       front-to-back replay, wave64 DPP reductions, one atomic set per (tile, Gaussian)
 //             K9 k_preprocess_bwd  per Gaussian: conic/cov2D/cov3D/projection/SH chain rule
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -861,6 +862,7 @@ __global__ __launch_bounds__(256) void k_tile_ranges(uint32_t R, const KeyT* __r
 // ------------------------------------------------------------------------------------------------
 #ifdef GSR_K6_TIMING   // experiment build only (tools/k6_wave_timing.py): per-wave start / end / placement of the forward blend
 __device__ unsigned long long g_k6_dbg[4 * 65536];
+__device__ unsigned long long g_k8_dbg[4 * 65536];   // the same for the backward blend's workgroups (wave 0)
 #endif
 template <bool REACH>
 __device__ __forceinline__ void blend_fwd_item(const int xcd, const int kslot, float4 (*s_ab)[64], float2 (*s_c)[64],
@@ -1060,18 +1062,28 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(int W, int H, int tiles_x, i
                                                     uint32_t* __restrict__ zero_words, int zero_count, int tiles_y)
 {
     constexpr int NT = 128, NW = 2, NV = HAS_DA ? 10 : 9;
+#ifdef GSR_K6_TIMING
+    if (threadIdx.x == 0 && blockIdx.x < 65536) { g_k8_dbg[4 * (size_t)blockIdx.x] = wall_clock64(); g_k8_dbg[4 * (size_t)blockIdx.x + 1] = 0ull; }
+#endif
     // (prepare in backward: workgroup 0 clears the digit counters that the per-Gaussian kernel behind this one adds into)
     if (zero_words && blockIdx.x == 0)
         for (int q = threadIdx.x; q < zero_count; q += NT) zero_words[q] = 0u;
     // single staging buffer: a batch is ~10^4 cycles of compute, so the second barrier per batch is free, and the
     // smaller LDS footprint lets more tiles share a CU (latency hiding: waves were 33% in s_waitcnt / barriers)
-    __shared__ float4 s_abc[3][NT];   // planes: A rows, B rows, C rows -- ONE array, so a visit's reads share an address register
+    // Staged planes, ONE array for the two float4 planes so that a visit's reads share an address register:
+    //   s_ab[0] = (x, y, A', B'),  s_ab[1] = (C', opacity, r, g),  s_c = (b, reach bits[, depth, -]).
+    // Without the depth / alpha terms the third plane is a float2 and the workgroup's LDS is 10 240 bytes: SIXTEEN workgroups
+    // (32 waves, the hardware's limit) per CU would fit instead of fourteen; s_max lives in s_gid's first two words for the same
+    // reason.  The kernel's 72 VGPRs still hold it to seven waves per SIMD: forced to 64 (amdgpu_waves_per_eu(8, 8): seven spills)
+    // it measured 199 us against 181-190.
+    __shared__ float4 s_ab[2][NT];
+    __shared__ typename std::conditional<HAS_DA, float4, float2>::type s_c[NT];
     __shared__ uint32_t s_gid[1][NT];
     // ONE row of partials per staged instance: the tile's two waves add theirs into it with ds_add_f32 (each touches a record's nine
     // words once per batch, from nine lanes: conflict-free; 0 + a + b = 0 + b + a, so the arrival order does not matter).  Round 3:
     // a row per wave (4.6 kB more LDS per workgroup: 10 instead of 14 workgroups per CU) was 219-226 us where this is 210-211
     __shared__ float s_part[NT][NV];
-    __shared__ uint32_t s_max[NW];
+    uint32_t* const s_max = &s_gid[0][0];   // [NW], only until the staging below (a barrier sits between)
     // grid = split x Tpad workgroups: part `spart` of tile `tile` (parts beyond what the tile's depth needs exit)
     const int spart = (int)blockIdx.x / tpad, tb = (int)blockIdx.x - spart * tpad;
     const int tile = slot_tile(interleave, tb & 7, tb >> 3, T, tiles_x);   // see k_blend_fwd_w
@@ -1138,6 +1150,7 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(int W, int H, int tiles_x, i
     __syncthreads();
     const int n = (int)max(s_max[0], s_max[1]);
     const int nw = (int)s_max[wave];
+    __syncthreads();   // s_max is s_gid: nobody stages before everyone has read it
     const int nb = (n + NT - 1) / NT;
     b1 = min(b1, nb);
     if (b0 >= b1) return;   // (uniform) the staged depth over-estimated the deepest contributor
@@ -1190,7 +1203,8 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(int W, int H, int tiles_x, i
     for (int b = b0; b < b1; b++) {
         const int buf = 0;
         if (b > b0) __syncthreads();   // everyone is done reading the previous batch (and its flush read s_gid)
-        s_abc[0][tid] = ra; s_abc[1][tid] = rb; s_abc[2][tid] = rc; s_gid[buf][tid] = rg_id;
+        s_ab[0][tid] = ra; s_ab[1][tid] = make_float4(rb.x, rb.y, rb.w, rc.x); s_gid[buf][tid] = rg_id;
+        if constexpr (HAS_DA) s_c[tid] = make_float4(rc.y, rc.w, rb.z, 0.f); else s_c[tid] = make_float2(rc.y, rc.w);
         __syncthreads();
         const int nxt = (b + 1) * NT + tid;
         if (nxt < n && b + 1 < b1) stage(nxt);
@@ -1200,16 +1214,19 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(int W, int H, int tiles_x, i
         // the reach bits of the batch as two wave-uniform 64-bit masks: the loop below visits set bits only, so an
         // instance this half cannot reach costs nothing at all
         const uint32_t wbit = 1u << wave;
-        const bool r0 = lane < cntw && (__float_as_uint(s_abc[2][lane].w) & wbit);
-        const bool r1 = lane + 64 < cntw && (__float_as_uint(s_abc[2][lane + 64].w) & wbit);
+        const bool r0 = lane < cntw && (__float_as_uint(s_c[lane].y) & wbit);
+        const bool r1 = lane + 64 < cntw && (__float_as_uint(s_c[lane + 64].y) & wbit);
         const unsigned long long reach[2] = {__ballot(r0), __ballot(r1)};
 #pragma unroll 1
         for (int half = 0; half < 2; half++)
         for (unsigned long long rm = reach[half]; rm != 0ull; rm &= rm - 1ull) {
             const int j = half * 64 + (int)__builtin_ctzll(rm);
-            const float4 A = s_abc[0][j], B = s_abc[1][j], C = s_abc[2][j];   // (manual LDS prefetch measured slower)
+            const float4 A = s_ab[0][j], B = s_ab[1][j];   // (manual LDS prefetch measured slower)
+            const auto C = s_c[j];
             const uint32_t idx = (uint32_t)(b * NT + j + 1);
-            const float ca = A.z, cb = A.w, cc = B.x, op = B.y, zd = B.z, cr = B.w, cg = C.x, cbl = C.y;   // ca/cb/cc: A', B', C'
+            const float ca = A.z, cb = A.w, cc = B.x, op = B.y, cr = B.z, cg = B.w, cbl = C.x;   // ca/cb/cc: A', B', C'
+            float zd = 0.f;
+            if constexpr (HAS_DA) zd = C.z;
             const float dx = A.x - pxf;
             const f2 dy = A.y - pyf;
             const float adx = ca * dx;
@@ -1292,8 +1309,8 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(int W, int H, int tiles_x, i
                     float v = s_part[jj][r];
                     if (r < 2) {        // moments -> d/d(pixel-space mean): this lane also needs the OTHER first-order moment
                         const float mo = s_part[jj][r ^ 1];
-                        const float cb = s_abc[0][jj].w;                                // B'
-                        const float c2 = 2.f * (r == 0 ? s_abc[0][jj].z : s_abc[1][jj].x);   // 2 A' (gx) or 2 C' (gy)
+                        const float cb = s_ab[0][jj].w;                                // B'
+                        const float c2 = 2.f * (r == 0 ? s_ab[0][jj].z : s_ab[1][jj].x);   // 2 A' (gx) or 2 C' (gy)
                         v = fmaf(cb, mo, c2 * v);
                     } else if (r < 5) v *= (r == 3 ? -1.f : -0.5f);                       // second moments -> conic gradients
                     __builtin_amdgcn_wave_barrier();   // every lane of the group has read both first moments before any is cleared
@@ -1306,6 +1323,14 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(int W, int H, int tiles_x, i
             }
         }
     }
+#ifdef GSR_K6_TIMING
+    if (threadIdx.x == 0 && blockIdx.x < 65536) {
+        unsigned long long* d = g_k8_dbg + 4 * (size_t)blockIdx.x;
+        d[1] = wall_clock64();
+        d[2] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+        d[3] = ((unsigned long long)(uint32_t)n << 32) | (uint32_t)((b1 - b0) * NT);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2080,6 +2105,10 @@ int gsr_version(void) { return 100; }
 int gsr_debug_k6_timing(unsigned long long* host_dst, int blocks)
 {
     return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_k6_dbg), sizeof(unsigned long long) * 4 * (size_t)blocks);
+}
+int gsr_debug_k8_timing(unsigned long long* host_dst, int blocks)
+{
+    return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_k8_dbg), sizeof(unsigned long long) * 4 * (size_t)blocks);
 }
 #endif
 int gsr_set_option(const char* name, int value)
