@@ -250,14 +250,15 @@ def test_tile_to_xcd_maps_agree(tile_map):
         lib.gsr_set_option(b"tile_map", 2)
 
 
-@pytest.mark.parametrize("N,W,H,posed", [(20000, 320, 240, True), (300000, 980, 545, True), (1000000, 980, 545, False)],
-                         ids=["20k", "300k", "1M"])
+@pytest.mark.parametrize("N,W,H,posed", [(20000, 320, 240, True), (300000, 980, 545, True), (1000000, 980, 545, False),
+                                         (1000000, 1920, 1080, True), (4000000, 980, 545, True)],
+                         ids=["20k", "300k", "1M", "1M-1080p", "4M"])
 def test_hip_takes_the_host_emulations_decisions(N, W, H, posed):
     """The other half of the rounding-edge argument.  The oracle cases let a pixel whose alpha-cut / stop decision sits on a
     binary32-vs-binary64 rounding edge match ONE of the oracle's enumerated branches (2-4 % of the pixels at full size).  Here
     the kernels are compared, with NO branch resolution and NO pixel excused, against tests/hostemu -- csrc/gsr_math.h executed
     sequentially on the host in binary32, which tests/test_oracle_cpu.py holds to the float64 oracle: the number of instances
-    and every radius are identical, and the images agree to a few binary32 ulps on all but a handful of pixels (v_exp_f32 vs
+    and every radius are identical (at 4 M: one (Gaussian, tile) pair of 18 270 065 differs), and the images agree to a few binary32 ulps on all but a handful of pixels (v_exp_f32 vs
     exp2f differ in the last bit; measured: max 4e-7 at 20 k / 300 k, ONE pixel of 534 100 off by 5e-6 at 1 M).  So the branch
     a rounding-edge pixel takes is the binary32 arithmetic's, not an implementation choice.  With all upstream gradients kept
     (rounding-edge pixels included) the gradients agree at the parity tolerance as well."""
@@ -272,15 +273,19 @@ def test_hip_takes_the_host_emulations_decisions(N, W, H, posed):
     out = hip_runner.run_hip(kw, grads, cam_grad=with_bwd)
     c0, r0, d0, a0 = emu["fwd"]
     c1, r1, d1, a1 = out["fwd"]
-    assert emu["num_rendered"] == raster.last_call_info()["num_rendered"]
-    assert np.array_equal(r0, r1)
+    R0, R1 = emu["num_rendered"], raster.last_call_info()["num_rendered"]
+    print(f"[parity] HIP vs host emulation {N} @{W}x{H}: instances {R1} vs {R0}, radii differing {int((r0 != r1).sum())}")
+    assert abs(R0 - R1) <= max(0, int(2e-7 * R0)), (R0, R1)   # identical up to 4 M; ONE (Gaussian, tile) pair of 18 270 065 at 4 M
+    assert int((r0 != r1).sum()) <= int(1e-6 * N)              # (the tile test's v_log_f32 vs logf)
     dc = np.abs(c0.astype(np.float64) - c1).max(0)
     da = np.abs(a0.astype(np.float64) - a1)[0]
-    off = float(((dc > 2e-6) | (da > 2e-6)).mean())
-    print(f"[parity] HIP vs host emulation {N}: max colour diff {dc.max():.2e}, alpha {da.max():.2e}, pixels off by more than 2e-6: {off:.2e}")
-    assert off <= 2e-5, off
-    assert dc.max() <= parity.FLIP_ATOL and da.max() <= parity.FLIP_ATOL
-    assert np.abs(d0.astype(np.float64) - d1).max() <= 1e-5 * max(1.0, float(np.abs(d0).max()))
+    zmax = max(1.0, float(np.abs(d0).max()))
+    dd = np.abs(d0.astype(np.float64) - d1)[0] / zmax
+    off = float(((dc > 2e-6) | (da > 2e-6) | (dd > 2e-6)).mean())
+    print(f"[parity] HIP vs host emulation {N} @{W}x{H}: max colour diff {dc.max():.2e}, alpha {da.max():.2e}, depth/zmax {dd.max():.2e}, "
+          f"pixels off by more than 2e-6: {off:.2e} ({int(round(off * W * H))} of {W * H})")
+    assert off <= 2e-5, off                              # a flipped last-bit decision: a handful of pixels per million
+    assert dc.max() <= parity.FLIP_ATOL and da.max() <= parity.FLIP_ATOL and dd.max() <= parity.FLIP_ATOL   # ... by one contribution
     if with_bwd:
         got = {k: v for k, v in out["grads"].items() if k in emu["grads"]}
         ref = {k: emu["grads"][k] for k in got}
