@@ -1703,7 +1703,8 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, in
         const int rrow = cp.M * 3 - 3;
         if (lin) {
             adam_rows_lin<(PREP >= 0)>(s_dc, nG * 3, const_cast<float*>(shs) + b * 3, ad.m[1] + b * 3, ad.v[1] + b * 3, tid, ad.step_size[1], ad);
-            adam_rows_lin<(PREP >= 0)>(s_rest, nG * NRL, const_cast<float*>(shs_rest) + b * NRL, ad.m[2] + b * NRL, ad.v[2] + b * NRL, tid, ad.step_size[2], ad);
+            if (DEG > 0 || ad.m[2])   // (degree 0, moments known to be zero: the group's update is the identity -- GsrFusedAdam)
+                adam_rows_lin<(PREP >= 0)>(s_rest, nG * NRL, const_cast<float*>(shs_rest) + b * NRL, ad.m[2] + b * NRL, ad.v[2] + b * NRL, tid, ad.step_size[2], ad);
             if (PREP < 0) return;
             // ---- next-view tail ("prepare in backward", GsrNextView): this block holds the UPDATED parameters of its 128
             // Gaussians -- the small groups in the owners' registers, the SH rows in the LDS tile -- so it runs the forward
@@ -1771,7 +1772,8 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, in
             return;
         }
         adam_rows(s_sh, kShStride, 0, 3, 3, const_cast<float*>(shs) + b * 3, ad.m[1] + b * 3, ad.v[1] + b * 3, nG, tid, ad.step_size[1], ad);
-        if (rrow == 45 && NC3 == 48)
+        if (DEG == 0 && !ad.m[2]) {}   // f_rest skipped: see GsrFusedAdam
+        else if (rrow == 45 && NC3 == 48)
             adam_rows(s_sh, kShStride, 3, 45, 45, const_cast<float*>(shs_rest) + b * 45, ad.m[2] + b * 45, ad.v[2] + b * 45, nG, tid, ad.step_size[2], ad);
         else if (rrow > 0)
             adam_rows(s_sh, kShStride, 3, rrow, NC3 - 3, const_cast<float*>(shs_rest) + b * rrow, ad.m[2] + b * rrow, ad.v[2] + b * rrow, nG, tid,
@@ -2573,7 +2575,12 @@ int gsr_backward(const GsrBackwardArgs* a, void* stream_)
         if (!a->raw_params || !a->shs || !a->shs_rest || a->cov3D_precomp || a->colors_precomp || !a->scales || !a->rotations || !a->opacities ||
             a->M < 1 || fa->step <= 0)
             return fail(GSR_ERR_ARG, "fused_adam needs raw_params with shs (f_dc) + shs_rest, scales, rotations and opacities%s");
+        // f_rest without moment buffers: the group is skipped (GsrFusedAdam) -- only where its gradient is identically zero
+        const bool skip_rest = !fa->exp_avg[2] && !fa->exp_avg_sq[2];
+        if (skip_rest && (a->D != 0 || (a->next_view && a->next_view->D != 0)))
+            return fail(GSR_ERR_ARG, "fused_adam: the f_rest group may be skipped only at sh_degree 0 (this render and the prepared one)%s");
         for (int q = 0; q < 6; q++) {
+            if (q == 2 && skip_rest) { ad.m[q] = nullptr; ad.v[q] = nullptr; ad.step_size[q] = 0.f; continue; }
             if (!fa->exp_avg[q] || !fa->exp_avg_sq[q]) return fail(GSR_ERR_ARG, "fused_adam: missing moment buffer%s");
             ad.m[q] = fa->exp_avg[q]; ad.v[q] = fa->exp_avg_sq[q];
             ad.step_size[q] = fa->lr[q] / (float)(1.0 - pow((double)fa->beta1, (double)fa->step));

@@ -274,8 +274,8 @@ std::vector<Tensor> rasterize_backward_fused(
     for (int q = 0; q < 6; q++) {
         TORCH_CHECK(adam_m[q].is_contiguous() && adam_v[q].is_contiguous() && adam_m[q].scalar_type() == at::kFloat, "fused_adam: moments must be contiguous float32");
         fa.lr[q] = (float)adam_lr[q];
-        fa.exp_avg[q] = adam_m[q].data_ptr<float>();
-        fa.exp_avg_sq[q] = adam_v[q].data_ptr<float>();
+        fa.exp_avg[q] = adam_m[q].numel() ? adam_m[q].data_ptr<float>() : nullptr;     // (empty = the group is skipped: GsrFusedAdam)
+        fa.exp_avg_sq[q] = adam_v[q].numel() ? adam_v[q].data_ptr<float>() : nullptr;
     }
     GsrBackwardArgs a{};
     fill_backward_args(a, b, geom, image, binning, meta, H, W, tanfovx, tanfovy, scale_modifier, sh_degree, true);

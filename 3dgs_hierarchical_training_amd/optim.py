@@ -148,7 +148,38 @@ class FusedAdam:
                              "exp_avg_sq": s["exp_avg_sq"].to(device=p.device, dtype=torch.float32).clone()}
 
     # ---- the two ways a step is taken ----------------------------------------------------------------------
-    def fused_step_plan(self, tensors: Dict[str, torch.Tensor]):
+    # ---- the f_rest group while its moments are zero ---------------------------------------------------------
+    # A model is created at SH degree 0 (gaussian_model_ht.py:68) and stays there for 1 000 iterations (:193-195; all of stage A):
+    # the 45 f_rest floats per Gaussian then receive an identically zero gradient, their moments are zero, and Adam's update of
+    # them is the identity, bit for bit (0 / (0 + eps) = 0) -- yet it is three quarters of the update's traffic.  A plan for a
+    # degree-0 render that prepares no degree-1 view therefore hands the kernel NO moment buffers for that group (GsrFusedAdam:
+    # the group is skipped), provided the moments are known to be zero: checked once per pair of state tensors (one
+    # count_nonzero, a device sync), re-checked when the tensors are replaced (surgery, load_state_dict) or changed in place
+    # through torch (their version counters), and given up for good when a render at degree >= 1 is planned.
+    def _rest_moments_zero(self, m: torch.Tensor, v: torch.Tensor) -> bool:
+        c = getattr(self, "_rest_zero", None)
+        if c is not None and c[0] is m and c[1] is v and c[2] == m._version and c[3] == v._version:
+            return c[4]
+        z = int(torch.count_nonzero(m)) == 0 and int(torch.count_nonzero(v)) == 0
+        self._rest_zero = (m, v, m._version, v._version, z)
+        self._rest_zero_checks = getattr(self, "_rest_zero_checks", 0) + 1
+        return z
+
+    def _rest_touched(self, m: torch.Tensor, v: torch.Tensor):
+        self._rest_zero = (m, v, m._version, v._version, False)
+
+    def _plan_moments(self, ms, vs, sh_degree, next_sh_degree):
+        if sh_degree is None or int(sh_degree) > 0:
+            self._rest_touched(ms[2], vs[2])          # the group's gradient is (or may be) non-zero from here on
+            return ms, vs
+        if next_sh_degree is not None and int(next_sh_degree) > 0:
+            return ms, vs                              # the prepared degree-1 view reads the rows through the update's tile
+        if not self._rest_moments_zero(ms[2], vs[2]):
+            return ms, vs
+        e = torch.empty(0, dtype=torch.float32, device=ms[2].device)
+        return ms[:2] + [e] + ms[3:], vs[:2] + [e] + vs[3:]
+
+    def fused_step_plan(self, tensors: Dict[str, torch.Tensor], sh_degree=None, next_sh_degree=None):
         """(exp_avg[6], exp_avg_sq[6], lr[6], beta1, beta2, eps, step_base, commit) for the optimizer-in-backward mode of
         gsr_backward.  Mutates nothing: `step_base` is the six groups' current step count and `commit` the CPU counter that the
         backward increments when it has applied the update; the 1-based step of that update is step_base + (commits since this
@@ -168,7 +199,8 @@ class FusedAdam:
                     ok = False
                     break
             if ok:
-                return (ms, vs, [float(g["lr"]) for g in groups], float(self.betas[0]), float(self.betas[1]), float(self.eps),
+                pm, pv = self._plan_moments(ms, vs, sh_degree, next_sh_degree)
+                return (pm, pv, [float(g["lr"]) for g in groups], float(self.betas[0]), float(self.betas[1]), float(self.eps),
                         _step_int(sts[0]["step"]), self._commit)
             self._plan_cache = None
         by_name = {g.get("name"): g for g in self.param_groups}
@@ -195,17 +227,19 @@ class FusedAdam:
         self._plan_cache = (groups, [g["params"][0] for g in groups], [tensors[name] for name in self.FUSED_ORDER], states, ms, vs,
                             [next(i for i, x in enumerate(self.param_groups) if x is g) for g in groups])
         self._plan_groups = len(self.param_groups)
-        return (ms, vs, lrs, float(self.betas[0]), float(self.betas[1]), float(self.eps), int(step), self._commit)
+        pm, pv = self._plan_moments(ms, vs, sh_degree, next_sh_degree)
+        return (pm, pv, lrs, float(self.betas[0]), float(self.betas[1]), float(self.eps), int(step), self._commit)
 
-    def fused_backward_args(self, tensors: Dict[str, torch.Tensor]) -> "L.GsrFusedAdam":
+    def fused_backward_args(self, tensors: Dict[str, torch.Tensor], sh_degree=None, next_sh_degree=None) -> "L.GsrFusedAdam":
         """The plan as a GsrFusedAdam struct for the update that is applied NOW (ctypes binding: called from its backward, which
         calls `fused_backward_applied()` once gsr_backward has returned)."""
-        m, v, lrs, b1, b2, eps, step, _ = self.fused_step_plan(tensors)
+        m, v, lrs, b1, b2, eps, step, _ = self.fused_step_plan(tensors, sh_degree, next_sh_degree)
         fa = L.GsrFusedAdam()
         fa.beta1, fa.beta2, fa.eps, fa.step = b1, b2, eps, step + 1
         for k in range(6):
             fa.lr[k] = lrs[k]
-            fa.exp_avg[k], fa.exp_avg_sq[k] = m[k].data_ptr(), v[k].data_ptr()
+            fa.exp_avg[k] = m[k].data_ptr() if m[k].numel() else None       # (no buffers: the group is skipped)
+            fa.exp_avg_sq[k] = v[k].data_ptr() if v[k].numel() else None
         return fa
 
     def fused_backward_applied(self):
@@ -219,6 +253,11 @@ class FusedAdam:
         self._commit_at_step = int(self._commit_np[0])
         if not live:
             return
+        for g in live:
+            if g.get("name") == "f_rest" and g["params"][0] in self.state:
+                st = self.state[g["params"][0]]
+                if "exp_avg" in st and "exp_avg_sq" in st:
+                    self._rest_touched(st["exp_avg"], st["exp_avg_sq"])   # a .grad reached the group: its moments may leave zero
         if stepped and any(g.get("name") in self.FUSED_ORDER for g in live):
             # the in-kernel step of this iteration has already been applied; a .grad on the same parameters (a second loss
             # term, a second backward) would be a second Adam update with a second step count

@@ -236,7 +236,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             if not (raw_params and has_rest and has_sh and has_scale):
                 raise RuntimeError("fused_adam needs the raw-parameter path (rasterize_gaussians_raw)")
             fa = fused.fused_backward_args({"xyz": means3D, "f_dc": sh, "f_rest": sh_rest, "opacity": opacities,
-                                            "scaling": scales, "rotation": rotations})
+                                            "scaling": scales, "rotation": rotations}, int(rs.sh_degree))
         else:
             d_means3D = torch.empty((N, 3), dtype=torch.float32, device=dev)
             d_opac = torch.empty((N, 1), dtype=torch.float32, device=dev)
@@ -334,7 +334,8 @@ def _rasterize_ext(means3D, means2D, sh, colors_precomp, opacities, scales, rota
         # a PLAN only: the step count advances when the backward that applies the update runs (csrc/torch_ext.cpp increments
         # `commit`), so a forward whose graph is dropped leaves the optimizer untouched
         m, v, lr, b1, b2, eps, step, commit = fused_adam.fused_step_plan({"xyz": means3D, "f_dc": sh, "f_rest": sh_rest, "opacity": opacities,
-                                                                          "scaling": scales, "rotation": rotations})
+                                                                          "scaling": scales, "rotation": rotations}, int(rs.sh_degree),
+                                                                         None if prepare_next is None else int(prepare_next.sh_degree))
     eb = _EMPTY.get(("u8", dev))
     if eb is None:
         eb = _EMPTY[("u8", dev)] = torch.empty(0, dtype=torch.uint8, device=dev)

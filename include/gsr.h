@@ -125,7 +125,13 @@ typedef struct GsrForwardOut {
  * GsrBackwardArgs (means3D, shs, shs_rest, opacities, scales, rotations) are then written through; d_means3D,
  * d_opacities, d_shs, d_shs_rest, d_scales, d_rotations are ignored (may be NULL); d_means2D is still produced
  * (densification statistics, gaussian_model_ht.py:718-721).  Group order of lr / exp_avg / exp_avg_sq:
- * 0 xyz, 1 f_dc, 2 f_rest, 3 opacity, 4 scaling, 5 rotation.  `step` is the 1-based step count. */
+ * 0 xyz, 1 f_dc, 2 f_rest, 3 opacity, 4 scaling, 5 rotation.  `step` is the 1-based step count.
+ * exp_avg[2] == exp_avg_sq[2] == NULL: the f_rest group is left alone -- no read or write of its 45 floats of parameters and 90 of
+ * moments per Gaussian, three quarters of the update's traffic.  Accepted only for a render at sh_degree 0 that prepares no view
+ * of a higher degree (the group's gradient is then identically zero), and CORRECT only if the caller knows the group's moments
+ * to be all zero: Adam with g = m = v = 0 leaves parameter and moments unchanged bit for bit (0 / (0 + eps) = 0), so skipping it
+ * is the same update.  That is a model's state from its creation until its first step at degree >= 1 -- all of stage A and the
+ * first 1 000 iterations of every leaf (gaussian_model_ht.py:68, :193-195); optim.FusedAdam tracks it. */
 typedef struct GsrFusedAdam {
     float beta1, beta2, eps;
     int32_t reserved;

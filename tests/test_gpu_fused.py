@@ -589,3 +589,89 @@ def test_pose_refinement_in_the_train_step_keeps_the_hand_over_exact():
             assert e1 < e0, (k, e0, e1)
     finally:
         lib.gsr_set_option(b"deterministic_backward", 0)
+
+
+def test_f_rest_group_is_skipped_while_its_moments_are_zero():
+    """GsrFusedAdam with no moment buffers for f_rest (exp_avg[2] = exp_avg_sq[2] = NULL): at SH degree 0 the group's gradient is
+    identically zero, and while its moments are zero Adam's update of it is the identity -- FusedAdam then plans the step
+    without the group (three quarters of the update's traffic; all of stage A and a leaf's first 1 000 iterations run like
+    that).  Two copies of one model, one planning with the skip and one that never skips, must stay EQUAL bit for bit --
+    images, parameters, moments -- through degree-0 steps with and without the hand-over, through the announced step up to
+    degree 1 (where the skip ends for good), and after an in-place change of the moments through torch (version counter:
+    re-validated, not skipped).  The library refuses the skip at a degree where the gradient is not zero."""
+    L = importlib.import_module("3dgs_hierarchical_training_amd._lib")
+    lib = L.load()
+    dev = torch.device("cuda:0")
+    W, H, N = 320, 240, 12800 + 37
+    assert lib.gsr_set_option(b"deterministic_backward", 1) == 0
+    try:
+        sc = parity.syn.make_scene(N, W, H, sh_degree=0, seed=21)
+        cam2 = parity.syn.make_scene(8, W, H, sh_degree=0, seed=5, posed=True)
+        sc2 = dict(sc)
+        for k in ("viewmatrix", "projmatrix", "campos"):
+            sc2[k] = cam2[k]
+        views = [ts.make_settings(sc, dev, 0), ts.make_settings(sc2, dev, 0)]
+        gts = [parity.syn.target_image(W, H, seed=1).to(dev), parity.syn.target_image(W, H, seed=2).to(dev)]
+        names = ["_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation"]
+
+        def never(opt):
+            opt._rest_moments_zero = lambda m, v: False
+
+        def same(pa, pb, what):
+            for k in names:
+                assert torch.equal(getattr(pa, k), getattr(pb, k)), (what, k)
+            for ga, gb in zip(pa.optimizer.param_groups, pb.optimizer.param_groups):
+                sa, sb = pa.optimizer.state[ga["params"][0]], pb.optimizer.state[gb["params"][0]]
+                assert torch.equal(sa["exp_avg"], sb["exp_avg"]) and torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"]), (what, ga["name"])
+                assert sa["step"] == sb["step"], (what, ga["name"])
+
+        pa, pb = ts.GaussianParams(sc, dev), ts.GaussianParams(sc, dev)
+        never(pb.optimizer)
+        rest0 = pa._features_rest.detach().clone()
+        for it in range(5):
+            v = it % 2
+            nxt = views[(it + 1) % 2] if it != 2 else None           # one step without the hand-over
+            ka = ts.train_step(pa, views[v], gts[v], next_settings=nxt)
+            kb = ts.train_step(pb, views[v], gts[v], next_settings=nxt)
+            assert torch.equal(ka["raw_image"], kb["raw_image"]), it
+            same(pa, pb, it)
+        grp = {"xyz": pa._xyz, "f_dc": pa._features_dc, "f_rest": pa._features_rest, "opacity": pa._opacity, "scaling": pa._scaling,
+               "rotation": pa._rotation}
+        ms, vs = pa.optimizer.fused_step_plan(grp, 0, 0)[:2]
+        assert ms[2].numel() == 0 and vs[2].numel() == 0 and ms[1].numel() > 0       # the plan really leaves the group out ...
+        assert pb.optimizer.fused_step_plan({k: getattr(pb, a) for k, a in zip(grp, names)}, 0, 0)[0][2].numel() > 0
+        assert pa.optimizer.fused_step_plan(grp, 0, 1)[0][2].numel() > 0             # ... but not in front of a degree-1 view
+        assert pa.optimizer._rest_zero_checks == 1                                   # validated once, not every step
+        assert torch.equal(pa._features_rest, rest0)
+        st = pa.optimizer.state[pa._features_rest]
+        assert int(torch.count_nonzero(st["exp_avg"])) == 0 and int(torch.count_nonzero(st["exp_avg_sq"])) == 0
+        # the step up to degree 1, announced: the hand-over needs the rows, the skip is off for that step and for good afterwards
+        ka = ts.train_step(pa, views[1], gts[1], next_settings=views[0], next_sh_degree=1)
+        kb = ts.train_step(pb, views[1], gts[1], next_settings=views[0], next_sh_degree=1)
+        pa.oneup_sh_degree(); pb.oneup_sh_degree()
+        for it in range(3):
+            v = it % 2
+            ka = ts.train_step(pa, views[v], gts[v], next_settings=views[(it + 1) % 2])
+            kb = ts.train_step(pb, views[v], gts[v], next_settings=views[(it + 1) % 2])
+            assert torch.equal(ka["raw_image"], kb["raw_image"]), it
+            same(pa, pb, ("deg1", it))
+        assert int(torch.count_nonzero(pa.optimizer.state[pa._features_rest]["exp_avg"])) > 0
+        assert pa.optimizer._rest_zero[4] is False
+        # moments changed in place through torch while at degree 0: seen (version counter), re-validated, not skipped
+        pc, pd = ts.GaussianParams(sc, dev), ts.GaussianParams(sc, dev)
+        never(pd.optimizer)
+        ts.train_step(pc, views[0], gts[0]); ts.train_step(pd, views[0], gts[0])
+        for p in (pc, pd):
+            p.optimizer.state[p._features_rest]["exp_avg"].add_(0.01)
+        ts.train_step(pc, views[1], gts[1]); ts.train_step(pd, views[1], gts[1])
+        same(pc, pd, "after an in-place change")
+        assert pc.optimizer._rest_zero_checks == 2 and not torch.equal(pc._features_rest, rest0)
+        # the library's own guard: no skipping where the gradient is not zero
+        pe = ts.GaussianParams(sc, dev)
+        pe.oneup_sh_degree()
+        e = torch.empty(0, device=dev)
+        pe.optimizer._plan_moments = lambda ms, vs, d, nd: (ms[:2] + [e] + ms[3:], vs[:2] + [e] + vs[3:])
+        with pytest.raises(RuntimeError, match="sh_degree 0"):
+            ts.train_step(pe, ts.with_sh_degree(views[0], 1), gts[0])
+    finally:
+        lib.gsr_set_option(b"deterministic_backward", 0)
