@@ -134,3 +134,32 @@ def test_gaussian_params_surgery_on_cpu():
         so = p.optimizer.state[p._opacity]
         assert float(so["exp_avg"].abs().max()) == 0.0 and int(so["step"]) == 3
         assert set(id(g["params"][0]) for g in p.optimizer.param_groups) == {id(getattr(p, a)) for a in p._GROUP_ATTR.values()}
+
+
+def test_plan_leaves_f_rest_out_only_while_its_moments_are_known_to_be_zero():
+    """The planning side of GsrFusedAdam's "no moment buffers for f_rest" (host logic only: the kernels are not involved).
+    Degree 0 and no degree-1 view prepared: the plan carries EMPTY tensors for the group, after ONE validation of the moments;
+    surgery that keeps them zero (prune, cat of zeros: the model file's own calls) is re-validated and keeps the skip; an
+    in-place change through torch, a plan at degree >= 1 or an unknown degree end it."""
+    opt = optim.FusedAdam(_groups(40), lr=0.0, eps=1e-15)
+    tensors = lambda: {g["name"]: g["params"][0] for g in opt.param_groups}
+    ms, vs = opt.fused_step_plan(tensors(), 0, 0)[:2]
+    assert ms[2].numel() == 0 and vs[2].numel() == 0 and all(ms[k].numel() > 0 for k in (0, 1, 3, 4, 5))
+    assert opt.fused_step_plan(tensors(), 0, None)[0][2].numel() == 0 and opt._rest_zero_checks == 1
+    assert opt.fused_step_plan(tensors(), 0, 1)[0][2].numel() > 0                 # the degree-1 hand-over reads the rows
+    assert opt.fused_step_plan(tensors(), 0, 0)[0][2].numel() == 0 and opt._rest_zero_checks == 1
+    keep = torch.arange(40) % 3 != 0
+    _prune_like_the_model_does(opt, keep)
+    assert opt.fused_step_plan(tensors(), 0, 0)[0][2].numel() == 0 and opt._rest_zero_checks == 2   # new tensors: validated again
+    _cat_like_the_model_does(opt, {k: torch.randn((5,) + SHAPES[k]) for k in NAMES})
+    assert opt.fused_step_plan(tensors(), 0, 0)[0][2].numel() == 0 and opt._rest_zero_checks == 3
+    rest = next(g["params"][0] for g in opt.param_groups if g["name"] == "f_rest")
+    opt.state[rest]["exp_avg_sq"][3, 2, 1] = 1e-12                                 # in place through torch: version counter
+    assert opt.fused_step_plan(tensors(), 0, 0)[0][2].numel() > 0 and opt._rest_zero_checks == 4
+    opt.state[rest]["exp_avg_sq"].zero_()
+    assert opt.fused_step_plan(tensors(), 0, 0)[0][2].numel() == 0                 # ... and back
+    assert opt.fused_step_plan(tensors(), 1, 1)[0][2].numel() > 0                  # a degree-1 step: gradients will reach the group
+    assert opt.fused_step_plan(tensors(), 0, 0)[0][2].numel() > 0                  # for good (no re-validation: the mark is "touched")
+    opt2 = optim.FusedAdam(_groups(8), lr=0.0, eps=1e-15)
+    t2 = {g["name"]: g["params"][0] for g in opt2.param_groups}
+    assert opt2.fused_step_plan(t2)[0][2].numel() > 0 and opt2.fused_step_plan(t2, 0, 0)[0][2].numel() > 0   # unknown degree = touched
