@@ -176,8 +176,11 @@ class FusedAdam:
             return ms, vs                              # the prepared degree-1 view reads the rows through the update's tile
         if not self._rest_moments_zero(ms[2], vs[2]):
             return ms, vs
-        e = torch.empty(0, dtype=torch.float32, device=ms[2].device)
-        return ms[:2] + [e] + ms[3:], vs[:2] + [e] + vs[3:]
+        c = getattr(self, "_skip_lists", None)       # (the two lists are rebuilt only when the plan's tensors change)
+        if c is None or c[0] is not ms or c[1] is not vs:
+            e = torch.empty(0, dtype=torch.float32, device=ms[2].device)
+            c = self._skip_lists = (ms, vs, ms[:2] + [e] + ms[3:], vs[:2] + [e] + vs[3:])
+        return c[2], c[3]
 
     def fused_step_plan(self, tensors: Dict[str, torch.Tensor], sh_degree=None, next_sh_degree=None):
         """(exp_avg[6], exp_avg_sq[6], lr[6], beta1, beta2, eps, step_base, commit) for the optimizer-in-backward mode of
