@@ -862,7 +862,8 @@ __global__ __launch_bounds__(256) void k_tile_ranges(uint32_t R, const KeyT* __r
 // ------------------------------------------------------------------------------------------------
 #ifdef GSR_K6_TIMING   // experiment build only (tools/k6_wave_timing.py): per-wave start / end / placement of the forward blend
 __device__ unsigned long long g_k6_dbg[4 * 65536];
-__device__ unsigned long long g_k8_dbg[4 * 65536];   // the same for the backward blend's workgroups (wave 0)
+__device__ unsigned long long g_k8_dbg[4 * 65536];
+__device__ uint32_t g_k6_cnt[2 * 65536];   // per forward-blend wave: visits, taken visits   // the same for the backward blend's workgroups (wave 0)
 #endif
 template <bool REACH>
 __device__ __forceinline__ void blend_fwd_item(const int xcd, const int kslot, float4 (*s_ab)[64], float2 (*s_c)[64],
@@ -876,6 +877,7 @@ __device__ __forceinline__ void blend_fwd_item(const int xcd, const int kslot, f
     constexpr int NT = 64;
 #ifdef GSR_K6_TIMING
     const unsigned long long dbg_t0 = wall_clock64();
+    uint32_t dbg_visits = 0u, dbg_taken = 0u;   // (wave, instance) visits / visits in which some pixel took the instance
 #endif
     const int tile = slot_tile(interleave, xcd, kslot >> 2, T, tiles_x);
     const int sub = kslot & 3;
@@ -948,7 +950,13 @@ __device__ __forceinline__ void blend_fwd_item(const int xcd, const int kslot, f
             // test_T = T and adds (+-)0 everywhere.  (The exec-masked form cost s_and_saveexec + s_or exec on every visit, taken or
             // not: this loop is bound by instructions issued per wave, scalar ones included.)
             const bool hit = !(p2 > 0.f) && !(alpha < kAlphaMin);
+#ifdef GSR_K6_TIMING
+            dbg_visits++;
+#endif
             if ((__builtin_amdgcn_ballot_w64(!(p2 > 0.f)) & __builtin_amdgcn_ballot_w64(!(alpha < kAlphaMin))) == 0ull) return;
+#ifdef GSR_K6_TIMING
+            dbg_taken++;
+#endif
             const float4 B = s_ab[2 + buf][j];
             const float2 C = s_c[buf][j];
             const float am = hit ? alpha : 0.f;
@@ -994,6 +1002,7 @@ __device__ __forceinline__ void blend_fwd_item(const int xcd, const int kslot, f
         d[0] = dbg_t0; d[1] = wall_clock64();
         d[2] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);
         d[3] = ((unsigned long long)(uint32_t)n << 32) | (uint32_t)(batches * NT);
+        g_k6_cnt[2 * (size_t)(xcd + 8 * kslot)] = dbg_visits; g_k6_cnt[2 * (size_t)(xcd + 8 * kslot) + 1] = dbg_taken;
     }
 #endif
     if (inside) {
@@ -2107,6 +2116,10 @@ int gsr_version(void) { return 100; }
 int gsr_debug_k6_timing(unsigned long long* host_dst, int blocks)
 {
     return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_k6_dbg), sizeof(unsigned long long) * 4 * (size_t)blocks);
+}
+int gsr_debug_k6_counts(uint32_t* host_dst, int blocks)
+{
+    return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_k6_cnt), sizeof(uint32_t) * 2 * (size_t)blocks);
 }
 int gsr_debug_k8_timing(unsigned long long* host_dst, int blocks)
 {

@@ -84,5 +84,10 @@ def report(name, fn, blocks, waves_per_block):
     print("   resident workgroups at 0, 10, 20, ... us:", occ)
 
 
+nb6 = min(65536, 8 * 4 * ((T + 7) // 8 + 8))
+cnt = np.zeros(2 * nb6, dtype=np.uint32)
+assert raw.gsr_debug_k6_counts(cnt.ctypes.data_as(C.c_void_p), C.c_int(nb6)) == 0
+cnt = cnt.reshape(nb6, 2).astype(np.int64)
+print("K6 visits (reach bit set) %d, of them taken by at least one pixel %d (%.1f %%)" % (cnt[:, 0].sum(), cnt[:, 1].sum(), 100.0 * cnt[:, 1].sum() / max(1, cnt[:, 0].sum())))
 report("K6 forward blend (k_blend_fwd_w6)", raw.gsr_debug_k6_timing, min(65536, 8 * 4 * ((T + 7) // 8 + 8)), 1)
 report("K8 backward blend (k_blend_bwd2)", raw.gsr_debug_k8_timing, 65536, 2)
