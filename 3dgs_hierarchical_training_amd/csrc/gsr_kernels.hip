@@ -863,6 +863,7 @@ __global__ __launch_bounds__(256) void k_tile_ranges(uint32_t R, const KeyT* __r
 #ifdef GSR_K6_TIMING   // experiment build only (tools/k6_wave_timing.py): per-wave start / end / placement of the forward blend
 __device__ unsigned long long g_k6_dbg[4 * 65536];
 __device__ unsigned long long g_k8_dbg[4 * 65536];
+__device__ unsigned long long g_k6_cyc[2 * 65536];   // per forward-blend wave: cycles in staging / in the visit loops
 __device__ uint32_t g_k6_cnt[2 * 65536];   // per forward-blend wave: visits, taken visits   // the same for the backward blend's workgroups (wave 0)
 #endif
 template <bool REACH>
@@ -878,6 +879,7 @@ __device__ __forceinline__ void blend_fwd_item(const int xcd, const int kslot, f
 #ifdef GSR_K6_TIMING
     const unsigned long long dbg_t0 = wall_clock64();
     uint32_t dbg_visits = 0u, dbg_taken = 0u;   // (wave, instance) visits / visits in which some pixel took the instance
+    unsigned long long dbg_stage = 0ull, dbg_loop = 0ull, dbg_mark = 0ull;   // shader-clock cycles: staging (incl. the wait for the gather) / visit loops
 #endif
     const int tile = slot_tile(interleave, xcd, kslot >> 2, T, tiles_x);
     const int sub = kslot & 3;
@@ -904,14 +906,24 @@ __device__ __forceinline__ void blend_fwd_item(const int xcd, const int kslot, f
     // this sub-tile cannot see costs three scalar instructions instead of twelve vector ones.
     const float sbx0 = (float)(tx * kTile + (sub & 1) * 8) - 0.5f * (float)W, sby0 = (float)(ty * kTile + (sub >> 1) * 8) - 0.5f * (float)H;
     const float sbx1 = fminf(sbx0 + 7.f, (float)(W - 1) - 0.5f * (float)W), sby1 = fminf(sby0 + 7.f, (float)(H - 1) - 0.5f * (float)H);
-    bool reach_nxt = false;
-    auto fetch = [&](int i) {
-        const float4* sp = reinterpret_cast<const float4*>(splat + list[rg.x + i]);
+    // Staging is a two-level dependent gather (list -> record).  Both levels run AHEAD of their use: the records of batch b + 1 are
+    // requested right after batch b is staged and are first touched (box test, pre-scaling, LDS write) at the top of the next
+    // iteration, behind this batch's visits; the ids of batch b + 2 are requested at the same time, so the record gather never
+    // waits for its addresses.  (Until the end of round 3 the box test sat inside the fetch, so the "prefetch" was consumed where
+    // it was issued -- s_waitcnt vmcnt(0) in front of every batch's visits: 115 -> 109 us with the use moved; staging is 7 % of a
+    // wave's time afterwards, tools/k6_wave_timing.py.  The same change in the backward blend, whose batches last ~80 us, and its
+    // first batch's records requested in front of the pixel-state loads: no change, 2 more VGPRs -- not kept.)
+    uint32_t id_nn = 0u;                                   // this lane's id in the batch after the one whose records are in flight
+    auto fetch = [&](uint32_t id) {                        // loads only: nothing here may consume them
+        const float4* sp = reinterpret_cast<const float4*>(splat + id);
         ra = sp[0]; rb = sp[1]; rc = sp[2];
-        if (REACH) reach_nxt = box_accept(make_tile_test(ra.x, ra.y, ra.z, ra.w, rb.x, rb.y), sbx0, sby0, sbx1, sby1);
-        ra.z *= -0.5f * kL2E; ra.w *= -kL2E; rb.x *= -0.5f * kL2E;
     };
-    if (lane < n) fetch(lane);
+    // (every lane loads, from a clamped position: a load under a lane condition ends in copies of its result at the join, and
+    //  the copies wait for the load right there)
+    if (n > 0) {
+        fetch(list[rg.x + min(lane, n - 1)]);
+        id_nn = list[rg.x + min(NT + lane, n - 1)];
+    }
     int batches = 0;
     for (int b = 0; b < nb; b++) {
         const int buf = b & 1;
@@ -920,10 +932,15 @@ __device__ __forceinline__ void blend_fwd_item(const int xcd, const int kslot, f
             float* c = ckpt + ((size_t)(rg.x >> 7) + tile + (b >> 1) - kCkptFirst) * kCkptFloats + sub * 64 + lane;
             c[0] = fabsf(Tr); c[256] = C0; c[512] = C1; c[768] = C2; c[1024] = Dd; c[1280] = Aa;
         }
-        s_ab[buf][lane] = ra; s_ab[2 + buf][lane] = rb; s_c[buf][lane] = make_float2(rc.x, rc.y);
+#ifdef GSR_K6_TIMING
+        dbg_mark = __builtin_readcyclecounter();
+#endif
         const int cnt = min(NT, n - b * NT);
-        const unsigned long long reach = REACH ? __ballot(reach_nxt && lane < cnt) : 0ull;
-        reach_nxt = false;
+        // first use of this batch's records (lanes beyond cnt hold stale ones: masked in the ballot, never visited)
+        const bool reach_me = REACH && box_accept(make_tile_test(ra.x, ra.y, ra.z, ra.w, rb.x, rb.y), sbx0, sby0, sbx1, sby1);
+        ra.z *= -0.5f * kL2E; ra.w *= -kL2E; rb.x *= -0.5f * kL2E;
+        s_ab[buf][lane] = ra; s_ab[2 + buf][lane] = rb; s_c[buf][lane] = make_float2(rc.x, rc.y);
+        const unsigned long long reach = REACH ? __ballot(reach_me && lane < cnt) : 0ull;
         // the staging area belongs to this wave alone: LDS instructions of one wave execute in issue order, so the broadcast
         // reads below see the writes above -- only the compiler must be kept from reordering them (no s_barrier: the queue
         // kernel runs sixteen independent waves per workgroup)
@@ -931,8 +948,12 @@ __device__ __forceinline__ void blend_fwd_item(const int xcd, const int kslot, f
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         batches = b + 1;
+#ifdef GSR_K6_TIMING
+        { const unsigned long long t = __builtin_readcyclecounter(); dbg_stage += t - dbg_mark; dbg_mark = t; }
+#endif
         const int nxt = (b + 1) * NT + lane;
-        if (nxt < n) fetch(nxt);
+        fetch(id_nn);
+        id_nn = list[rg.x + min(nxt + NT, n - 1)];
         auto alpha_of = [&](int j, float& p2) {
             const float4 A = s_ab[buf][j];
             const float2 Bq = *reinterpret_cast<const float2*>(&s_ab[2 + buf][j]);   // C', opacity
@@ -994,6 +1015,9 @@ __device__ __forceinline__ void blend_fwd_item(const int xcd, const int kslot, f
                 blend(j, p2, a1);
             }
         }
+#ifdef GSR_K6_TIMING
+        dbg_loop += __builtin_readcyclecounter() - dbg_mark;
+#endif
     }
     if (lane == 0) staged4[tile * 4 + sub] = (uint32_t)min(n, batches * NT);
 #ifdef GSR_K6_TIMING
@@ -1003,6 +1027,7 @@ __device__ __forceinline__ void blend_fwd_item(const int xcd, const int kslot, f
         d[2] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);
         d[3] = ((unsigned long long)(uint32_t)n << 32) | (uint32_t)(batches * NT);
         g_k6_cnt[2 * (size_t)(xcd + 8 * kslot)] = dbg_visits; g_k6_cnt[2 * (size_t)(xcd + 8 * kslot) + 1] = dbg_taken;
+        g_k6_cyc[2 * (size_t)(xcd + 8 * kslot)] = dbg_stage; g_k6_cyc[2 * (size_t)(xcd + 8 * kslot) + 1] = dbg_loop;
     }
 #endif
     if (inside) {
@@ -1045,7 +1070,12 @@ __global__ __launch_bounds__(64) void k_blend_fwd_w6(int W, int H, int tiles_x, 
 //  full SIMD.  Pulling the (tile, sub-tile) items from a queue instead -- one 16-wave workgroup per CU, a counter in LDS, ~33 items
 //  per workgroup, bit-identical image -- evens the waves out but leaves four per SIMD: 132 us (three: 148, two: 190): per-wave
 //  issue, ~55 instructions of all kinds per visit, is what bounds the loop, so residency beats balance.  One counter per XCD in
-//  global memory: 210 us -- agent-scope atomics on one address complete about every 0.2 us.  The queue kernel is not kept.
+//  global memory: 210 us -- agent-scope atomics on one address complete about every 0.2 us.  With the counter picked by the hardware's
+//  XCC_ID and a WORKGROUP-scope atomic (it then executes in that XCD's L2: `global_atomic_add ... sc0`, no sc1) the pulls cost
+//  nothing, single-wave workgroups can be used at any number per SIMD, the image is bit-identical -- and the kernel takes 140 / 131 /
+//  127 us at 4 / 5 / 6 persistent waves per SIMD: padding THIS kernel's LDS down to 27 / 24 / 19 / 16 waves per CU gives 123 / 127 /
+//  131 / 136 us, and tools/k6_lone_wave.py (uniform lists, no imbalance at all) 48 ns per visit and SIMD at four waves against 43 at
+//  eight and 35 in steady state.  Residency beats balance at every point of the curve.  The queue kernel is not kept.
 //  Records kept in registers (lane j = instance j) and broadcast with v_readlane_b32 instead of LDS reads -- no LDS, no waits in
 //  the visit -- 115 -> 173 us: ten v_readlane per taken visit cost far more vector issue than the two address moves they replace.)
 
@@ -2120,6 +2150,10 @@ int gsr_debug_k6_timing(unsigned long long* host_dst, int blocks)
 int gsr_debug_k6_counts(uint32_t* host_dst, int blocks)
 {
     return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_k6_cnt), sizeof(uint32_t) * 2 * (size_t)blocks);
+}
+int gsr_debug_k6_cycles(unsigned long long* host_dst, int blocks)
+{
+    return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_k6_cyc), sizeof(unsigned long long) * 2 * (size_t)blocks);
 }
 int gsr_debug_k8_timing(unsigned long long* host_dst, int blocks)
 {

@@ -13,13 +13,15 @@ syn = importlib.import_module("3dgs_hierarchical_training_amd.synthetic")
 L = importlib.import_module("3dgs_hierarchical_training_amd._lib")
 lib = L.load()
 dev = torch.device("cuda:0")
-W = H = 16
-for n in (512, 1024, 1536):
+import os
+CASES = [(16, 512), (16, 1024), (256, 512), (512, 512), (736, 512), (1024, 512)] if os.environ.get("GSR_UNIFORM") else [(16, 512), (16, 1024), (16, 1536)]
+for W, n in CASES:
+    H = W
     sc = syn.make_scene(n, W, H, sh_degree=0, seed=0)
     cam_fx = 0.5 * W / sc["tanfovx"]
     z = torch.linspace(2.0, 4.0, n)
     sc["means3D"] = torch.stack((torch.zeros(n), torch.zeros(n), z), 1).contiguous()
-    sc["scales"] = (20.0 * z / cam_fx)[:, None].repeat(1, 3).contiguous()          # sigma = 20 px: G >= 0.85 over the whole tile
+    sc["scales"] = (1.25 * W * z / cam_fx)[:, None].repeat(1, 3).contiguous()     # sigma = 1.25 W px: G >= 0.85 over the whole image
     sc["opacities"] = torch.full((n, 1), 0.005)                                    # above 1/255 everywhere, exp(-0.005 n) stays above 1e-4
     p = ts.GaussianParams(sc, dev)
     st = ts.make_settings(sc, dev, 0)
@@ -39,5 +41,6 @@ for n in (512, 1024, 1536):
         lib.gsr_profile_read(name.encode(), C.byref(tot), C.byref(cnt))
         out[name] = 1e3 * tot.value / max(1, cnt.value)
     lib.gsr_set_option(b"profile", 0)
-    print(f"n {n}: forward blend {out['blend_fwd']:.1f} us = {1e3 * out['blend_fwd'] / n:.0f} ns per instance; backward blend {out['blend_bwd']:.1f} us = "
+    waves = 4 * ((W + 15) // 16) ** 2
+    print(f"{W}x{H} ({waves} forward-blend waves = {waves / 1024:.2f} per SIMD), n {n}: forward blend {out['blend_fwd']:.1f} us = {1e3 * out['blend_fwd'] / n:.0f} ns per instance; backward blend {out['blend_bwd']:.1f} us = "
           f"{1e3 * out['blend_bwd'] / n:.0f} ns per instance")

@@ -89,5 +89,11 @@ cnt = np.zeros(2 * nb6, dtype=np.uint32)
 assert raw.gsr_debug_k6_counts(cnt.ctypes.data_as(C.c_void_p), C.c_int(nb6)) == 0
 cnt = cnt.reshape(nb6, 2).astype(np.int64)
 print("K6 visits (reach bit set) %d, of them taken by at least one pixel %d (%.1f %%)" % (cnt[:, 0].sum(), cnt[:, 1].sum(), 100.0 * cnt[:, 1].sum() / max(1, cnt[:, 0].sum())))
+cyc = np.zeros(2 * nb6, dtype=np.uint64)
+assert raw.gsr_debug_k6_cycles(cyc.ctypes.data_as(C.c_void_p), C.c_int(nb6)) == 0
+cyc = cyc.reshape(nb6, 2).astype(np.float64)
+live = cyc.sum(1) > 0
+print("K6 per wave, s_memtime ticks: staging (wait for the gather, box test, LDS writes) mean %.0f, visit loops mean %.0f -> staging share %.1f %%" % (
+    cyc[live, 0].mean(), cyc[live, 1].mean(), 100.0 * cyc[live, 0].sum() / cyc[live].sum()))
 report("K6 forward blend (k_blend_fwd_w6)", raw.gsr_debug_k6_timing, min(65536, 8 * 4 * ((T + 7) // 8 + 8)), 1)
 report("K8 backward blend (k_blend_bwd2)", raw.gsr_debug_k8_timing, 65536, 2)
