@@ -1100,7 +1100,7 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(int W, int H, int tiles_x, i
                                                     const uint32_t* __restrict__ staged4, int tpad, float* __restrict__ det_part,
                                                     uint32_t* __restrict__ zero_words, int zero_count, int tiles_y)
 {
-    constexpr int NT = 128, NW = 2, NV = HAS_DA ? 10 : 9;
+    constexpr int NT = 128, NV = HAS_DA ? 10 : 9;   // (two waves per workgroup)
 #ifdef GSR_K6_TIMING
     if (threadIdx.x == 0 && blockIdx.x < 65536) { g_k8_dbg[4 * (size_t)blockIdx.x] = wall_clock64(); g_k8_dbg[4 * (size_t)blockIdx.x + 1] = 0ull; }
 #endif
@@ -1122,7 +1122,7 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(int W, int H, int tiles_x, i
     // words once per batch, from nine lanes: conflict-free; 0 + a + b = 0 + b + a, so the arrival order does not matter).  Round 3:
     // a row per wave (4.6 kB more LDS per workgroup: 10 instead of 14 workgroups per CU) was 219-226 us where this is 210-211
     __shared__ float s_part[NT][NV];
-    uint32_t* const s_max = &s_gid[0][0];   // [NW], only until the staging below (a barrier sits between)
+    uint32_t* const s_max = &s_gid[0][0];   // [2], only until the staging below (a barrier sits between)
     // grid = split x Tpad workgroups: part `spart` of tile `tile` (parts beyond what the tile's depth needs exit)
     const int spart = (int)blockIdx.x / tpad, tb = (int)blockIdx.x - spart * tpad;
     const int tile = slot_tile(interleave, tb & 7, tb >> 3, T, tiles_x);   // see k_blend_fwd_w
@@ -2088,7 +2088,6 @@ static int check_common(int32_t N, int32_t M, int32_t D, int32_t W, int32_t H)
     if (N < 0 || W <= 0 || H <= 0) return fail(GSR_ERR_ARG, "bad sizes%s");
     if (D < 0 || D > 3) return fail(GSR_ERR_ARG, "sh_degree must be 0..3%s");
     if (M < 0 || M > 16) return fail(GSR_ERR_ARG, "at most 16 SH coefficients per Gaussian%s");
-    const long long T = (long long)((W + kTile - 1) / kTile) * ((H + kTile - 1) / kTile);
     if (W > 4095 * kTile || H > 4095 * kTile) return fail(GSR_ERR_RANGE, "image side longer than 65520 pixels%s");
     return GSR_OK;
 }
