@@ -745,24 +745,22 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit(int N, int W, int H, int 
             else atomicAdd(&hz.ghist[((size_t)p * kOsRanges + o / run_len) * 256 + d], 1u);
         }
     };
-    for (uint32_t q = tid; q < total; q += kEmitThreads) {
-        int lo = 0, hi = kEmitThreads - 1;   // first index with s_incl > q
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (s_incl[mid] > q) hi = mid; else lo = mid + 1;
-        }
-        const TileRec rr = s_rec[lo];
-        if (rr.rect & kTileRecBig) continue;    // emitted below
-        const uint32_t excl = lo ? s_incl[lo - 1] : 0u;
-        const int pos = select_kth_bit(rr.mask, q - excl);
-        const int ww = (int)((rr.rect >> 24) & 63u), rx0 = (int)(rr.rect & 0xfffu), ry0 = (int)((rr.rect >> 12) & 0xfffu);
-        const int ty = pos / ww, tx = pos - ty * ww;
-        const uint32_t o = base + q;
-        if (o < cap) {   // cap = R, or the speculative capacity of gsr_forward (then an overflow is re-run)
-            const uint32_t key = (uint32_t)((ry0 + ty) * tiles_x + rx0 + tx);
-            out_tile[o] = (KeyT)key;
-            out_gid[o] = s_gid[lo];
-            if (hist) count_key(key, o);
+    // Every thread emits ITS Gaussian's tiles, in mask order (row-major over the rect), at base + its exclusive prefix.  (Round 3:
+    // until then the lanes took consecutive OUTPUT slots and found their Gaussian by an eight-step binary search in LDS, the tile
+    // by clearing k bits and a division -- coalesced stores, but ~150 instructions and eight dependent LDS reads per output; here a
+    // lane's outputs are consecutive addresses of its own, neighbours' runs adjoin, and L2 merges the partial lines.)
+    if (!(r.rect & kTileRecBig) && cnt) {
+        const uint32_t ww = (r.rect >> 24) & 63u, rx0 = r.rect & 0xfffu, ry0 = (r.rect >> 12) & 0xfffu;
+        const uint32_t rcp = (65536u + ww - 1u) / ww;   // floor(pos / ww) = pos * rcp >> 16 for pos < 32 <= 65536 / ww
+        uint32_t o = base + incl - cnt;
+        for (uint32_t m = r.mask; m != 0u; m &= m - 1u, o++) {
+            const uint32_t pos = (uint32_t)__builtin_ctz(m), ty = (pos * rcp) >> 16, tx = pos - ty * ww;
+            if (o < cap) {   // cap = R, or the speculative capacity of gsr_forward (then an overflow is re-run)
+                const uint32_t key = (ry0 + ty) * (uint32_t)tiles_x + rx0 + tx;
+                out_tile[o] = (KeyT)key;
+                out_gid[o] = g;
+                if (hist) count_key(key, o);
+            }
         }
     }
     // large rects: one wave per Gaussian, the exact test on 64 candidate tiles at a time, survivors compacted in order
