@@ -2543,6 +2543,9 @@ int gsr_backward(const GsrBackwardArgs* a, void* stream_)
     const uint2* ranges = reinterpret_cast<const uint2*>(bin + B.ranges);
     const uint32_t* list = reinterpret_cast<const uint32_t*>(bin + B.list);
     float* gg = static_cast<float*>(a->scratch);
+    // (round 3, measured and dropped: the extension allocating this scratch in the FORWARD and clearing it on a side stream behind
+    //  an event, so that the 8 us fill runs next to the forward's kernels instead of in front of the backward's -- 0.863-0.873 ms per
+    //  step against 0.847-0.855 with the fill here, same box: the concurrent fill takes more from the sorts than it saves)
     GSR_HIP(hipMemsetAsync(gg, 0, (size_t)N * kGG * 4, st));
     // prepare in backward: the digit counters of the next forward's depth sort live in the hand-over buffer; they are cleared by
     // the blend kernel's workgroup 0 (no launch of their own) and filled by the per-Gaussian kernel behind it
