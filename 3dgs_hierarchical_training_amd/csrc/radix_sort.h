@@ -436,7 +436,7 @@ __global__ __launch_bounds__(OsCfg<KeyT>::kThreads) void k_onesweep(const KeyT* 
     if (is_digit) {
         // decoupled look-back over earlier tiles
         // (windows of 4 independent loads: the walk is a chain of L2 round trips, and the chain is what a block waits on)
-        uint32_t excl = 0;
+        uint32_t excl = 0, polls = 0;
         const int t_lo = (int)run_start;   // the chain ends at the head of the run: what lies in front is in the digit base
         for (int t = (int)tile - 1; t >= t_lo;) {
             constexpr int kWin = 4;   // (8: same speed, 16: +20 % per pass -- the polls compete for the status lines in L2)
@@ -454,7 +454,13 @@ __global__ __launch_bounds__(OsCfg<KeyT>::kThreads) void k_onesweep(const KeyT* 
                 t--;
                 if (f == kOsIncl) { t = t_lo - 1; done = true; }
             }
-            if (t >= t_lo && done) __builtin_amdgcn_s_sleep(1);
+            if (t >= t_lo && done) {
+                __builtin_amdgcn_s_sleep(1);
+                // a predecessor that never publishes (status words overwritten by a caller's bug) must not hang the device: after
+                // ~10^7 polls -- seconds, where a healthy chain takes microseconds -- the walk gives up and the sort's result is
+                // garbage instead
+                if (++polls > (1u << 23)) break;
+            }
         }
         __hip_atomic_store(my_status, kOsIncl | (excl + real), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_start[tid] = lstart;
