@@ -315,15 +315,22 @@ def make_views(syn, ts, scene, dev, deg, n_views, seed=0):
 
 
 def autopatch_leg(ts, scene, settings, gt, dev, steps, warmup):
-    """What the UNMODIFIED reference trainer reaches once `import gsr_autopatch` ran before it: the
-    trainer's own torch activations + cat and `GaussianRasterizer(...)` call, but its `torch.optim.Adam(l, lr=0.0, eps=1e-15)` over
-    the six named groups comes back as FusedAdam (one HIP launch per step()) and its `Loss.forward` runs the fused L1 + SSIM
-    kernels.  No reference file is edited; no fused rasterizer entry point is used."""
+    """What the UNMODIFIED reference trainer reaches once `import gsr_autopatch` ran before it, driven
+    the way `train_step` drives it (ht3dgs_trainer.py:102-166): `gs_render.render(cam)` -- patched: the model's RAW tensors go to
+    the kernels, activations / SH concat in-kernel --, `Loss.forward` -- patched: fused L1 + SSIM --, `loss.backward()`,
+    `optimizer.step()` -- `torch.optim.Adam(l, lr=0.0, eps=1e-15)` came back as FusedAdam: one launch, a REAL separate step --,
+    `zero_grad`.  No reference file is edited and no optimizer-in-backward / hand-over entry point is used.
+    `with_bookkeeping` adds what the trainer runs under no_grad between backward and step on a densifying iteration: psnr,
+    the max_radii2D update (the trainer's own boolean-mask statement) and add_densification_stats (patched: masked adds)."""
     import gsr_autopatch
+    refstub = importlib.import_module("3dgs_hierarchical_training_amd.refstub")
     gsr_autopatch.apply()
     try:
         p = ts.GaussianParams(scene, dev, optimizer="torch")     # builds torch.optim.Adam(groups, lr=0.0, eps=1e-15) -- patched
         opt_cls = type(p.optimizer).__name__
+        r = refstub.StubRender(p, bg=tuple(float(x) for x in settings.bg.cpu()))
+        cam = refstub.StubCamera(settings.image_width, settings.image_height, settings.tanfovx, settings.tanfovy, settings.viewmatrix,
+                                 settings.projmatrix, settings.campos, original_image=gt)
 
         class _Cfg:
             lambda_dssim, lambda_depth = 0.2, 0.0
@@ -332,33 +339,76 @@ def autopatch_leg(ts, scene, settings, gt, dev, steps, warmup):
             cfg = _Cfg()
         loss_obj = _Loss()
 
-        def f(i):
-            pkg = ts.render(p, settings, clamp=True, fused_activations=False)
+        def step(book):
+            pkg = gsr_autopatch.render_fused(r, cam)
             d = gsr_autopatch.loss_forward(loss_obj, pkg["image"], gt)
             d["loss"].backward()
+            with torch.no_grad():
+                if book:
+                    g = r.gaussians
+                    mse = ((pkg["image"] - gt) ** 2).view(3, -1).mean(1, keepdim=True)           # utils/image_utils.py psnr
+                    (20 * torch.log10(1.0 / torch.sqrt(mse))).mean().double()
+                    vis, radii = pkg["visibility_filter"], pkg["radii"]
+                    g.max_radii2D[vis] = torch.max(g.max_radii2D[vis], radii[vis])
+                    gsr_autopatch.add_densification_stats_fused(g, pkg["viewspace_points"], vis)
+                p.optimizer.step()
+                p.optimizer.zero_grad(set_to_none=True)
+        for i in range(warmup):
+            step(False)
+        sec = timed_steps(lambda i: step(False), steps, dev)
+        for i in range(2):
+            step(True)
+        sec_b = timed_steps(lambda i: step(True), steps, dev)
+        # the legacy form of this leg (rounds 2-3): the wrapper's torch activations + cat + GaussianRasterizer, patched loss + optimizer
+        def old(i):
+            pkg = ts.render(p, settings, clamp=True, fused_activations=False)
+            gsr_autopatch.loss_forward(loss_obj, pkg["image"], gt)["loss"].backward()
             p.optimizer.step()
             p.optimizer.zero_grad(set_to_none=True)
-        for i in range(warmup):
-            f(i)
-        sec = timed_steps(f, steps, dev)
+        for i in range(2):
+            old(i)
+        sec_old = timed_steps(old, steps, dev)
     finally:
         gsr_autopatch.remove()
     del p
     return {"value": 1.0 / sec, "unit": "images/s", "ms_per_step": 1e3 * sec, "steps": steps, "optimizer_class": opt_cls,
-            "path": "`import gsr_autopatch` + the unmodified trainer's calls: torch exp / sigmoid / normalize / cat -> GaussianRasterizer -> "
-                    "clamp -> Loss.forward (patched: fused L1 + SSIM kernels) -> backward -> torch.optim.Adam(...).step() (patched: "
-                    "FusedAdam, one launch)"}
+            "with_bookkeeping_ms_per_step": 1e3 * sec_b, "render_unpatched_ms_per_step": 1e3 * sec_old,
+            "path": "`import gsr_autopatch` + the unmodified trainer's calls: CF3DGS_Render.render (patched: raw parameters -> "
+                    "rasterize_gaussians_raw, in-kernel exp / sigmoid / normalize / cat) -> Loss.forward (patched: fused clamp + L1 + SSIM) "
+                    "-> backward -> torch.optim.Adam(...).step() (patched: FusedAdam, one launch, a separate real step); "
+                    "render_unpatched_* = the same with GSR_AUTOPATCH_RENDER=0 (round 3's form of this leg)"}
 
 
 def rccl_probe(dist, dev, world, rank, backend):
     """Self-diagnosis of the process group for the first multi-GPU run: which ranks answered (an all_gather of rank ids), the
     backend, and the point-to-point rate of every level-0 merge pair (2k <-> 2k+1, 64 MiB each way, all pairs at once -- on the
     xGMI mesh every pair has its own link)."""
-    if dist is None or world == 1:
+    if dist is None:
         return {"world": 1, "ranks_seen": [0], "backend": None, "link_GBps": {}, "note": "single process: no process group"}
     ids = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
     dist.all_gather(ids, torch.tensor([rank], dtype=torch.int64, device=dev))
     seen = sorted(int(t.item()) for t in ids)
+    if world == 1:
+        # GSR_BENCH_FORCE_DIST=1 on one GPU: the process group is real (backend nccl = RCCL), so the collectives this code uses
+        # anywhere (all_gather of stage A's pose rows, the MIN all-reduce of the link self-test, barrier, broadcast) execute once on
+        # device tensors; point-to-point needs a second rank and stays unmeasured
+        x = torch.arange(1 << 20, dtype=torch.float32, device=dev)
+        y = x.clone()
+        dist.all_reduce(y, op=dist.ReduceOp.SUM)
+        mn = torch.tensor([7.0], device=dev)
+        dist.all_reduce(mn, op=dist.ReduceOp.MIN)
+        rows = [torch.empty(5, 3, 4, 4, device=dev)]
+        src = torch.randn(5, 3, 4, 4, device=dev)
+        dist.all_gather(rows, src)
+        bc = torch.full((1024,), 3.0, device=dev)
+        dist.broadcast(bc, 0)
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+        ok = bool(torch.equal(x, y)) and float(mn) == 7.0 and bool(torch.equal(rows[0], src)) and float(bc.sum()) == 3072.0
+        return {"world": 1, "ranks_seen": seen, "all_ranks_present": seen == [0], "backend": dist.get_backend(), "collectives_ok": ok,
+                "collectives": ["all_gather", "all_reduce(SUM)", "all_reduce(MIN)", "broadcast", "barrier"], "link_GBps": {},
+                "note": "process group forced at world 1 (GSR_BENCH_FORCE_DIST=1): collectives on device tensors returned; "
+                        "point-to-point and N > 1 unmeasured"}
     host = backend != "nccl"
     peer = rank ^ 1
     n = 64 << 20

@@ -17,12 +17,27 @@ Importing this module BEFORE the trainer swaps both for the HIP kernels of this 
     in the fused loss kernels (gsr_loss_forward / gsr_loss_backward) and returns the same dict (`loss`, `loss_rgb`,
     `loss_dssim`, `loss_depth`); the depth term, when enabled, stays the reference's own code.
 
+  * `scene.gaussian_model_ht.CF3DGS_Render.render` (round 4; patched when that module is imported, now or later) hands the model's
+    RAW parameter tensors (`_xyz, _features_dc, _features_rest, _opacity, _scaling, _rotation`) to `rasterize_gaussians_raw`: the
+    wrapper's torch exp / sigmoid / normalize / cat (and their backward kernels) run inside the preprocess kernels, `get_xyz`'s
+    pose action `P[idx].retr().act(xyz)` becomes the in-kernel `points_transform`, and the gradients arrive on the raw tensors
+    directly, where `optimizer.step()` (FusedAdam: ONE launch) picks them up.  `optimizer.step()` stays a real, separate step:
+    the trainer's order -- densify / prune / opacity reset BEFORE the step, `update_gaussians=False`, the grads dropped when
+    `densify_and_prune` replaces every parameter (ht3dgs_trainer.py:137-160) -- is untouched.  The returned dict is the
+    reference's (`image` clamped, `depth`, `alpha`, `viewspace_points` whose .grad the backward fills, `visibility_filter`,
+    `radii`).  `override_color`, `compute_cov3D_python`, `convert_SHs_python`, CPU tensors or an unexpected parameter layout
+    fall back to the ORIGINAL method.  `GSR_AUTOPATCH_RENDER=0` leaves the method alone; `GSR_AUTOPATCH_POSE=0` keeps pose
+    renders (rotate_xyz / rotate_seq) on the original method.
+  * `HTGaussianModel.add_densification_stats` (same module) accumulates the same two sums without the boolean-mask gathers
+    (each of them a `nonzero` + host synchronisation): masked adds over N.
+
 `apply()` / `remove()` switch the patches on and off (importing the module calls `apply()`); `GSR_AUTOPATCH=0` disables them.
 The rasterizer itself needs no patch: `diff_gaussian_rasterization` IS this library's drop-in package.
 """
 import importlib
 import importlib.abc
 import importlib.machinery
+import math
 import os
 import sys
 
@@ -37,6 +52,10 @@ _ORIG_ADAM = torch.optim.Adam
 _applied = False
 _patched_loss_classes = []          # [(class, original forward)]
 LOSS_MODULES = ("trainer.losses",)
+RENDER_MODULES = ("scene.gaussian_model_ht",)
+_patched_render_classes = []        # [(class, attribute, original function)]
+RAW_NAMES = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation")
+_REQUIRE_CUDA = True                # (tests drive the dispatch logic with CPU stand-ins and a recording rasterizer)
 
 
 def _pkg():
@@ -63,11 +82,28 @@ def _wants_fused(params, kw) -> bool:
     return True
 
 
-class _AdamDispatch(_ORIG_ADAM):
-    """`torch.optim.Adam` while the patch is applied: constructs FusedAdam for the reference's six-group optimizer and the stock
-    Adam for everything else.  (Returning an object that is not an instance of this class from __new__ skips __init__.)"""
+class _AdamMeta(type(_ORIG_ADAM)):
+    """`isinstance(opt, torch.optim.Adam)` keeps answering True for everything the patched name constructs (stock Adam objects and
+    FusedAdam), as it did before the patch."""
 
-    def __new__(cls, params, *args, **kw):
+    def __instancecheck__(cls, inst):
+        if cls is _AdamDispatch:
+            if isinstance(inst, _ORIG_ADAM):
+                return True
+            optim = sys.modules.get("3dgs_hierarchical_training_amd.optim")
+            return optim is not None and isinstance(inst, optim.FusedAdam)
+        return super().__instancecheck__(inst)
+
+
+class _AdamDispatch(_ORIG_ADAM, metaclass=_AdamMeta):
+    """`torch.optim.Adam` while the patch is applied: constructs FusedAdam for the reference's six-group optimizer and the stock
+    Adam for everything else.  (Returning an object that is not an instance of this class from __new__ skips __init__.)
+    A SUBCLASS defined while the patch is applied (`class My(torch.optim.Adam)`) constructs normally: the dispatch only fires for
+    the patched name itself."""
+
+    def __new__(cls, params=None, *args, **kw):
+        if cls is not _AdamDispatch:
+            return super().__new__(cls)
         params = list(params)
         if _wants_fused(params, kw) and not args:
             optim, _ = _pkg()
@@ -88,7 +124,11 @@ def loss_forward(self, rgb_pred, rgb_gt, depth_pred=None, depth_gt=None, rgb_los
         if orig is None:
             raise RuntimeError("gsr_autopatch.loss_forward: needs a [C,H,W] image on the GPU")
         return orig(self, rgb_pred, rgb_gt, depth_pred, depth_gt, rgb_loss_type, **kwargs)
-    loss, ssim_v, l1_v = loss_mod.fused_photometric_loss_terms(rgb_pred, rgb_gt, lambda_dssim, clamp=False)
+    raw = getattr(rgb_pred, "_gsr_raw", None)      # the patched render's un-clamped colour output (render_fused below), valid while
+    if raw is not None and raw[1] == rgb_pred._version and raw[0].shape == rgb_pred.shape:     # nobody wrote into the clamped image
+        loss, ssim_v, l1_v = loss_mod.fused_photometric_loss_terms(raw[0], rgb_gt, lambda_dssim, clamp=True)  # clamp fused: same value
+    else:
+        loss, ssim_v, l1_v = loss_mod.fused_photometric_loss_terms(rgb_pred, rgb_gt, lambda_dssim, clamp=False)
     rgb_full_loss = (1.0 - lambda_dssim) * l1_v
     dssim_loss = 1.0 - ssim_v
     if lambda_depth != 0.0 and depth_pred is not None and depth_gt is not None:
@@ -102,6 +142,104 @@ def loss_forward(self, rgb_pred, rgb_gt, depth_pred=None, depth_gt=None, rgb_los
     return {'loss': loss, 'loss_rgb': rgb_full_loss, 'loss_dssim': dssim_loss, 'loss_depth': depth_loss}
 
 
+# ---- CF3DGS_Render.render on the raw-parameter path ------------------------------------------------------------------------------
+def _pose_matrix(g):
+    """The transform `get_xyz` applies to the means (/root/reference/scene/gaussian_model_ht.py:135-148), as a [4,4] matrix that
+    keeps its autograd link to the pose parameter (lietorch's `matrix()` is `act` on the basis vectors), or None."""
+    if getattr(g, "rotate_xyz", False):
+        T = g.P[0].retr()
+    elif getattr(g, "rotate_xyz_inverse", False):
+        T = g.P[0].retr().inv()
+    elif getattr(g, "rotate_seq", False):
+        T = g.P[g.seq_idx].retr()
+    else:
+        return None
+    return T.matrix().reshape(4, 4)
+
+
+def _raw_tensors(g):
+    """The six raw parameter tensors when they have the layout the fused path takes, else None."""
+    ts = [getattr(g, k, None) for k in RAW_NAMES]
+    if any(not torch.is_tensor(t) for t in ts):
+        return None
+    x = ts[0]
+    if (_REQUIRE_CUDA and not x.is_cuda) or x.dim() != 2 or x.shape[0] == 0:
+        return None
+    N = x.shape[0]
+    if any(t.dtype != torch.float32 or t.device != x.device or not t.is_contiguous() or t.shape[0] != N for t in ts):
+        return None
+    dc, rest, op, sc, rot = ts[1:]
+    if tuple(x.shape) != (N, 3) or tuple(dc.shape) != (N, 1, 3) or rest.dim() != 3 or rest.shape[1] < 1 or rest.shape[2] != 3 or \
+            tuple(op.shape) != (N, 1) or tuple(sc.shape) != (N, 3) or tuple(rot.shape) != (N, 4):
+        return None
+    return ts
+
+
+def render_fused(self, viewpoint_camera, scaling_modifier=1.0, invert_bg_color=False, override_color=None,
+                 compute_cov3D_python=False, convert_SHs_python=False):
+    """Drop-in body of `CF3DGS_Render.render` (/root/reference/scene/gaussian_model_ht.py:775-908): same arguments, same returned
+    dict.  The model's raw tensors go to the kernels as they are (activations of :128-133,176-188 and the SH concat in-kernel,
+    `get_xyz`'s pose action as `points_transform`); every configuration the fused path does not cover runs the original method."""
+    orig = next((f for c, a, f in _patched_render_classes if a == "render" and isinstance(self, c)), None)
+    g = getattr(self, "gaussians", None)
+    ts = None
+    if override_color is None and not compute_cov3D_python and not convert_SHs_python and g is not None:
+        ts = _raw_tensors(g)
+    posed = ts is not None and (getattr(g, "rotate_xyz", False) or getattr(g, "rotate_xyz_inverse", False) or getattr(g, "rotate_seq", False))
+    if posed and os.environ.get("GSR_AUTOPATCH_POSE", "1") == "0":
+        ts = None
+    if ts is None:
+        if orig is None:
+            raise RuntimeError("gsr_autopatch.render_fused: this configuration needs the original CF3DGS_Render.render")
+        return orig(self, viewpoint_camera, scaling_modifier, invert_bg_color, override_color, compute_cov3D_python, convert_SHs_python)
+    R = importlib.import_module("3dgs_hierarchical_training_amd.rasterizer")
+    xyz, f_dc, f_rest, opacity, scaling, rotation = ts
+    dev = xyz.device
+    # the tensor whose .grad receives the 2D positional gradient (:800-808: `zeros_like(get_xyz, requires_grad=True) + 0` with
+    # retain_grad); its values are never read by the rasterizer
+    screenspace_points = torch.zeros((xyz.shape[0], 3), dtype=torch.float32, device=dev, requires_grad=True)
+    bg = self.bg_color if not invert_bg_color else 1 - self.bg_color
+    settings = R.GaussianRasterizationSettings(
+        image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
+        tanfovx=math.tan(viewpoint_camera.FoVx * 0.5), tanfovy=math.tan(viewpoint_camera.FoVy * 0.5), bg=bg,
+        scale_modifier=scaling_modifier, viewmatrix=viewpoint_camera.world_view_transform,
+        projmatrix=viewpoint_camera.full_proj_transform, sh_degree=g.active_sh_degree, campos=viewpoint_camera.camera_center,
+        prefiltered=False, debug=False)
+    M = _pose_matrix(g) if posed else None
+    image_raw, radii, depth, alpha = R.rasterize_gaussians_raw(xyz, screenspace_points, f_dc, f_rest, opacity, scaling, rotation,
+                                                               settings, points_transform=M)
+    image = image_raw.clamp(0, 1)
+    image._gsr_raw = (image_raw, image._version)       # lets the patched Loss.forward fuse this clamp into the loss kernels
+    return {"image": image, "depth": depth, "alpha": alpha, "viewspace_points": screenspace_points,
+            "visibility_filter": radii > 0, "radii": radii}
+
+
+def add_densification_stats_fused(self, viewspace_point_tensor, update_filter):
+    """Drop-in body of `HTGaussianModel.add_densification_stats` (/root/reference/scene/gaussian_model_ht.py:718-721): the same
+    sums as masked adds over N instead of three boolean-mask gathers / scatters (each a `nonzero` and a host synchronisation)."""
+    g = viewspace_point_tensor.grad
+    if g is None or update_filter.dtype != torch.bool or update_filter.dim() != 1 or update_filter.shape[0] != self.denom.shape[0]:
+        orig = next((f for c, a, f in _patched_render_classes if a == "add_densification_stats" and isinstance(self, c)), None)
+        if orig is None:
+            raise RuntimeError("gsr_autopatch.add_densification_stats_fused: needs a [N] boolean filter and a populated .grad")
+        return orig(self, viewspace_point_tensor, update_filter)
+    f = update_filter.unsqueeze(1)
+    self.xyz_gradient_accum += torch.where(f, torch.norm(g[:, :2], dim=-1, keepdim=True), torch.zeros((), device=g.device, dtype=g.dtype))
+    self.denom += f.to(self.denom.dtype)
+
+
+def _patch_render_module(mod):
+    if os.environ.get("GSR_AUTOPATCH_RENDER", "1") == "0":
+        return
+    for cname, attr, fn in (("CF3DGS_Render", "render", render_fused),
+                            ("HTGaussianModel", "add_densification_stats", add_densification_stats_fused)):
+        cls = getattr(mod, cname, None)
+        if cls is None or not hasattr(cls, attr) or any(c is cls and a == attr for c, a, _ in _patched_render_classes):
+            continue
+        _patched_render_classes.append((cls, attr, getattr(cls, attr)))
+        setattr(cls, attr, fn)
+
+
 def _patch_loss_module(mod):
     cls = getattr(mod, "Loss", None)
     if cls is None or any(c is cls for c, _ in _patched_loss_classes):
@@ -111,11 +249,12 @@ def _patch_loss_module(mod):
 
 
 class _PostImportFinder(importlib.abc.MetaPathFinder):
-    """Patches `trainer.losses` right after it has been executed, whenever that import happens."""
+    """Patches `trainer.losses` / `scene.gaussian_model_ht` right after they have been executed, whenever that import happens."""
 
     def find_spec(self, fullname, path, target=None):
-        if fullname not in LOSS_MODULES or not _applied:
+        if (fullname not in LOSS_MODULES and fullname not in RENDER_MODULES) or not _applied:
             return None
+        patch = _patch_loss_module if fullname in LOSS_MODULES else _patch_render_module
         for finder in sys.meta_path:
             if finder is self or not hasattr(finder, "find_spec"):
                 continue
@@ -124,10 +263,10 @@ class _PostImportFinder(importlib.abc.MetaPathFinder):
                 loader = spec.loader
                 orig_exec = loader.exec_module
 
-                def exec_module(module, _orig=orig_exec):
+                def exec_module(module, _orig=orig_exec, _patch=patch):
                     _orig(module)
                     if _applied:
-                        _patch_loss_module(module)
+                        _patch(module)
                 try:
                     loader.exec_module = exec_module
                 except Exception:
@@ -151,6 +290,9 @@ def apply():
     for name in LOSS_MODULES:
         if name in sys.modules:
             _patch_loss_module(sys.modules[name])
+    for name in RENDER_MODULES:
+        if name in sys.modules:
+            _patch_render_module(sys.modules[name])
 
 
 def remove():
@@ -165,6 +307,9 @@ def remove():
     while _patched_loss_classes:
         cls, fwd = _patched_loss_classes.pop()
         cls.forward = fwd
+    while _patched_render_classes:
+        cls, attr, fn = _patched_render_classes.pop()
+        setattr(cls, attr, fn)
 
 
 if os.environ.get("GSR_AUTOPATCH", "1") != "0":

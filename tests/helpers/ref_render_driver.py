@@ -1,0 +1,135 @@
+"""Subprocess body of tests/test_autopatch_render_cpu.py::test_patched_render_on_the_real_reference_classes.
+
+Imports the REAL /root/reference/scene/gaussian_model_ht.py (authoring container only) under the CPU shim of tools/make_golden.py
+(lietorch / plyfile / simple_knn stubbed, device='cuda' rewritten to 'cpu'), with `gsr_autopatch` imported FIRST, and checks what the
+patched `CF3DGS_Render.render` does with live `CF3DGS_Render` / `HTGaussianModel` objects.  Prints one JSON line."""
+import importlib
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tools"))
+import make_golden as mg                                   # noqa: E402
+
+REF = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
+captured = mg.install_shim(REF)
+import gsr_autopatch                                        # noqa: E402  (applies on import; the finder waits for the model module)
+gsr_autopatch._REQUIRE_CUDA = False                         # CPU stand-in tensors take the fused route in this test
+from scene.cameras import Camera                            # noqa: E402
+from scene.gaussian_model_ht import CF3DGS_Render, HTGaussianModel      # noqa: E402
+from utils.graphics_utils import BasicPointCloud, focal2fov             # noqa: E402
+
+out = {"render_patched": CF3DGS_Render.render is gsr_autopatch.render_fused,
+       "stats_patched": HTGaussianModel.add_densification_stats is gsr_autopatch.add_densification_stats_fused}
+R = importlib.import_module("3dgs_hierarchical_training_amd.rasterizer")
+rec = {}
+
+
+def fake_raw(means3D, means2D, f_dc, f_rest, opacity, scaling, rotation, settings, **kw):
+    rec.update(args=(means3D, means2D, f_dc, f_rest, opacity, scaling, rotation), settings=settings, kw=kw)
+    H, W = settings.image_height, settings.image_width
+    z = means3D.sum() * 0 + means2D.sum() * 0
+    if kw.get("points_transform") is not None:
+        z = z + kw["points_transform"].sum() * 0
+    return torch.full((3, H, W), 1.5) + z, torch.ones(means3D.shape[0], dtype=torch.int32), torch.zeros(1, H, W) + z, torch.zeros(1, H, W) + z
+
+
+R.rasterize_gaussians_raw = fake_raw
+g = np.random.default_rng(14)
+N, W, H = 100, 64, 48
+pts = np.stack([g.uniform(-1, 1, N), g.uniform(-1, 1, N), g.uniform(2, 6, N)], 1)
+pcd = BasicPointCloud(points=pts, colors=g.uniform(0, 1, (N, 3)), normals=np.zeros((N, 3)))
+fx = 80.0
+K = np.array([[fx, 0, W / 2], [0, fx, H / 2], [0, 0, 1]], dtype=np.float32)
+with mg._CudaToCpu():
+    cam = Camera(colmap_id=0, R=np.eye(3), T=np.zeros(3), FoVx=focal2fov(fx, W), FoVy=focal2fov(fx, H), image=torch.zeros(3, H, W),
+                 gt_alpha_mask=None, image_name="x", uid=0, intrinsics=K, data_device="cpu", is_co3d=True)
+    r = CF3DGS_Render(sh_degree=3, view_dependent=True)
+    r.init_model(pcd)
+    m = r.gaussians
+    # 1. the fused route: raw tensors by identity, the settings the original builds, the reference's dict
+    pkg = r.render(cam)
+    out["keys"] = sorted(pkg.keys())
+    out["raw_identity"] = all(a is b for a, b in zip(rec["args"][:1] + rec["args"][2:],
+                                                     (m._xyz, m._features_dc, m._features_rest, m._opacity, m._scaling, m._rotation)))
+    st = rec["settings"]
+    out["settings"] = {"H": st.image_height, "W": st.image_width, "deg": st.sh_degree, "mod": st.scale_modifier,
+                       "vm_is_cam": st.viewmatrix is cam.world_view_transform, "pm_is_cam": st.projmatrix is cam.full_proj_transform,
+                       "cp_is_cam": st.campos is cam.camera_center, "bg_is_model": st.bg is r.bg_color,
+                       "tanfovx": st.tanfovx, "tanfovx_ref": float(np.tan(cam.FoVx * 0.5)), "prefiltered": st.prefiltered, "debug": st.debug}
+    out["image_clamped"] = float(pkg["image"].max())
+    out["has_raw_tag"] = hasattr(pkg["image"], "_gsr_raw") and pkg["image"]._gsr_raw[0].max().item() == 1.5
+    out["no_transform"] = rec["kw"].get("points_transform") is None
+    out["vis_dtype"] = str(pkg["visibility_filter"].dtype)
+    pkg["image"].sum().backward()
+    out["viewspace_leaf_grad"] = pkg["viewspace_points"].grad is not None and pkg["viewspace_points"].requires_grad
+    # 2. the configurations it does not cover go to the ORIGINAL method (the shim's recording GaussianRasterizer sees them)
+    captured.clear()
+    r.render(cam, compute_cov3D_python=True, convert_SHs_python=True)
+    out["fallback_python_modes"] = "kwargs" in captured and captured["kwargs"]["cov3D_precomp"] is not None
+    captured.clear()
+    r.render(cam, override_color=torch.zeros(N, 3))
+    out["fallback_override"] = "kwargs" in captured
+    gsr_autopatch._REQUIRE_CUDA = True
+    captured.clear(); rec.clear()
+    r.render(cam)
+    out["fallback_cpu_tensors"] = "kwargs" in captured and not rec
+    gsr_autopatch._REQUIRE_CUDA = False
+
+    # 3. a pose render: get_xyz's action arrives as points_transform = the pose matrix, linked to the pose parameter
+    class _T:
+        def __init__(self, M):
+            self.M = M
+
+        def matrix(self):
+            return self.M[None]
+
+        def inv(self):
+            return _T(torch.linalg.inv(self.M))
+
+        def act(self, x):
+            return x @ self.M[:3, :3].t() + self.M[:3, 3]
+
+    class _P:
+        def __init__(self):
+            self.t = torch.zeros(3, requires_grad=True)
+
+        def retr(self):
+            M = torch.eye(4)
+            M = M + torch.cat([torch.cat([torch.zeros(3, 3), self.t[:, None]], 1), torch.zeros(1, 4)], 0)
+            return _T(M)
+    m.P = [_P(), _P()]
+    m.rotate_seq, m.seq_idx = True, 1
+    rec.clear()
+    pkg = r.render(cam)
+    xf = rec["kw"].get("points_transform")
+    out["pose_transform_shape"] = list(xf.shape) if xf is not None else None
+    out["pose_means_are_raw"] = rec["args"][0] is m._xyz
+    (pkg["image"].sum() + xf.sum()).backward()
+    out["pose_grad_reaches_parameter"] = m.P[1].t.grad is not None and m.P[0].t.grad is None
+    m.rotate_seq = False
+
+    # 4. add_densification_stats: the masked-add form equals the reference's gather form
+    class _Opt:
+        percent_dense, position_lr_init, position_lr_final, position_lr_delay_mult, position_lr_max_steps = 0.01, 1e-4, 1e-6, 0.01, 1000
+        feature_lr, opacity_lr, scaling_lr, rotation_lr = 0.0025, 0.05, 0.005, 0.001
+    m.spatial_lr_scale = 1.0
+    m.training_setup(_Opt())
+    vs = torch.zeros(N, 3, requires_grad=True)
+    vs.grad = torch.randn(N, 3)
+    filt = torch.rand(N) > 0.4
+    orig = next(f for c, a, f in gsr_autopatch._patched_render_classes if a == "add_densification_stats")
+    m.add_densification_stats(vs, filt)
+    m.add_densification_stats(vs, filt)
+    a1, d1 = m.xyz_gradient_accum.clone(), m.denom.clone()
+    m.xyz_gradient_accum.zero_(); m.denom.zero_()
+    orig(m, vs, filt); orig(m, vs, filt)
+    out["stats_equal"] = bool(torch.equal(a1, m.xyz_gradient_accum) and torch.equal(d1, m.denom))
+gsr_autopatch.remove()
+out["restored"] = CF3DGS_Render.render.__qualname__ == "CF3DGS_Render.render" and CF3DGS_Render.render is not gsr_autopatch.render_fused
+print("RESULT " + json.dumps(out))

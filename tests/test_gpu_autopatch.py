@@ -61,3 +61,158 @@ def test_reference_optimizer_construction_returns_fused_adam_and_matches_torch()
     gsr_autopatch.loss_forward(_L(), pkg["image"], gt)["loss"].backward()
     pa.optimizer.step()
     assert pa.optimizer.step_count == 4
+
+
+refstub = importlib.import_module("3dgs_hierarchical_training_amd.refstub")
+RAW = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation")
+
+
+def _rel(a, b):
+    return float((a - b).norm() / b.norm().clamp_min(1e-20))
+
+
+@pytest.mark.parametrize("deg", [0, 3])
+def test_patched_render_equals_the_unpatched_route(deg):
+    """`gsr_autopatch.render_fused` (raw tensors -> in-kernel activations) against the wrapper's own sequence
+    (torch exp / sigmoid / normalize / cat -> GaussianRasterizer -> clamp) on the same model and camera: same dict, same image,
+    radii and visibility, same gradients on the six raw tensors and on `viewspace_points`."""
+    import gsr_autopatch
+    dev = torch.device("cuda:0")
+    W, H, N = 320, 200, 20000
+    sc = parity.syn.make_scene(N, W, H, sh_degree=3, seed=4, posed=True)
+    sc["sh_degree"] = deg
+    pa, pb = ts.GaussianParams(sc, dev, optimizer="torch"), ts.GaussianParams(sc, dev, optimizer="torch")
+    ra, rb = refstub.StubRender(pa, bg=(0.2, 0.1, 0.3)), refstub.StubRender(pb, bg=(0.2, 0.1, 0.3))
+    cam = refstub.StubCamera.from_scene(sc, dev)
+    g = torch.Generator().manual_seed(5)
+    wc, wd, wa = torch.randn(3, H, W, generator=g).to(dev), 0.1 * torch.randn(1, H, W, generator=g).to(dev), 0.1 * torch.randn(1, H, W, generator=g).to(dev)
+    a = gsr_autopatch.render_fused(ra, cam)
+    b = rb.render(cam)
+    assert sorted(a.keys()) == sorted(b.keys())
+    assert torch.equal(a["radii"], b["radii"]) and torch.equal(a["visibility_filter"], b["visibility_filter"])
+    for k in ("image", "depth", "alpha"):
+        assert float((a[k] - b[k]).abs().max()) <= 2e-6, k
+    assert float(a["image"].max()) <= 1.0 and float(a["image"].min()) >= 0.0
+    for pk in (a, b):
+        ((pk["image"] * wc).sum() + (pk["depth"] * wd).sum() + (pk["alpha"] * wa).sum()).backward()
+    assert _rel(a["viewspace_points"].grad, b["viewspace_points"].grad) < 1e-5
+    for k in RAW:
+        ga, gb = getattr(pa, k).grad, getattr(pb, k).grad
+        if k == "_features_rest" and deg == 0:
+            assert float(ga.abs().max()) == 0.0 and float(gb.abs().max()) == 0.0
+            continue
+        assert _rel(ga, gb) < 1e-4, (k, _rel(ga, gb))
+
+
+def test_patched_pose_render_equals_get_xyz_route():
+    """A pose render (`rotate_seq`: get_xyz = P[idx].retr().act(_xyz), gaussian_model_ht.py:135-148): the fused route passes the
+    pose matrix as the in-kernel points_transform; image and the gradients on the pose parameter and on `_xyz` agree with
+    transforming the means in torch."""
+    import gsr_autopatch
+    dev = torch.device("cuda:0")
+    W, H, N = 256, 192, 8000
+    sc = parity.syn.make_scene(N, W, H, sh_degree=3, seed=6, posed=False)
+
+    class _T:
+        def __init__(self, M):
+            self.M = M
+
+        def matrix(self):
+            return self.M[None]
+
+        def act(self, x):
+            return x @ self.M[:3, :3].t() + self.M[:3, 3]
+
+    class _P:
+        def __init__(self):
+            self.w = torch.tensor([0.02, -0.01, 0.015, 0.03, -0.02, 0.01], device=dev, requires_grad=True)
+
+        def retr(self):
+            w = self.w
+            z = torch.zeros((), device=dev)
+            K = torch.stack([torch.stack([z, -w[2], w[1]]), torch.stack([w[2], z, -w[0]]), torch.stack([-w[1], w[0], z])])
+            Rm = torch.linalg.matrix_exp(K)
+            top = torch.cat([Rm, w[3:, None]], 1)
+            return _T(torch.cat([top, torch.tensor([[0.0, 0.0, 0.0, 1.0]], device=dev)], 0))
+    outs = []
+    for patched in (True, False):
+        p = ts.GaussianParams(sc, dev, optimizer="torch")
+        r = refstub.StubRender(p)
+        r.gaussians.P = [_P(), _P()]
+        r.gaussians.rotate_seq, r.gaussians.seq_idx = True, 1
+        cam = refstub.StubCamera.from_scene(sc, dev)
+        pkg = gsr_autopatch.render_fused(r, cam) if patched else r.render(cam)
+        w = torch.randn(3, H, W, generator=torch.Generator().manual_seed(1)).to(dev)
+        (pkg["image"] * w).sum().backward()
+        outs.append((pkg["image"].detach(), r.gaussians.P[1].w.grad.clone(), p._xyz.grad.clone(), r.gaussians.P[0].w.grad))
+    (ia, wa, xa, w0a), (ib, wb, xb, w0b) = outs
+    assert float((ia - ib).abs().max()) <= 5e-6
+    assert w0a is None and w0b is None
+    assert _rel(wa, wb) < 2e-4, _rel(wa, wb)
+    assert _rel(xa, xb) < 1e-4
+
+
+def test_unmodified_trainer_sequence_on_the_patched_render():
+    """The trainer's own iteration (ht3dgs_trainer.py:102-166) on the three patched pieces -- render_fused, Loss.forward,
+    torch.optim.Adam -> FusedAdam -- against the stock pieces: same parameters after three iterations (Adam's first steps move
+    every entry by ~lr whatever the gradient's size, so agreement is measured in units of lr), densification statistics included;
+    then the reference's order on a densify iteration: statistics, surgery, THEN optimizer.step() on parameters whose .grad the
+    surgery dropped (a no-op step, as in the reference)."""
+    import gsr_autopatch
+    dev = torch.device("cuda:0")
+    W, H, N = 256, 192, 8000
+    sc = parity.syn.make_scene(N, W, H, sh_degree=3, seed=2)
+    gt = parity.syn.target_image(W, H, seed=1).to(dev)
+    gsr_autopatch.apply()
+    try:
+        pa = ts.GaussianParams(sc, dev, optimizer="torch")
+    finally:
+        gsr_autopatch.remove()
+    pb = ts.GaussianParams(sc, dev, optimizer="torch")
+    assert isinstance(pa.optimizer, optim.FusedAdam)
+    ra, rb = refstub.StubRender(pa), refstub.StubRender(pb)
+    cam = refstub.StubCamera.from_scene(sc, dev, original_image=gt)
+
+    class _L:
+        class cfg:
+            lambda_dssim, lambda_depth = 0.2, 0.0
+    for it in range(3):
+        pkg = gsr_autopatch.render_fused(ra, cam)
+        d = gsr_autopatch.loss_forward(_L(), pkg["image"], gt)
+        d["loss"].backward()
+        with torch.no_grad():
+            vis, radii = pkg["visibility_filter"], pkg["radii"]
+            ra.gaussians.max_radii2D[vis] = torch.max(ra.gaussians.max_radii2D[vis], radii[vis])
+            gsr_autopatch.add_densification_stats_fused(ra.gaussians, pkg["viewspace_points"], vis)
+            pa.optimizer.step(); pa.optimizer.zero_grad(set_to_none=True)
+        pkg_b = rb.render(cam)
+        loss_b = ts.photometric_loss(pkg_b["image"], gt, 0.2)
+        if it == 0:
+            assert abs(float(d["loss"]) - float(loss_b)) <= 2e-6
+        loss_b.backward()
+        with torch.no_grad():
+            vis, radii = pkg_b["visibility_filter"], pkg_b["radii"]
+            rb.gaussians.max_radii2D[vis] = torch.max(rb.gaussians.max_radii2D[vis], radii[vis])
+            rb.gaussians.add_densification_stats(pkg_b["viewspace_points"], vis)
+            pb.optimizer.step(); pb.optimizer.zero_grad(set_to_none=True)
+    lrs = {g["name"]: g["lr"] for g in pa.optimizer.param_groups}
+    for name, k in ts.GaussianParams._GROUP_ATTR.items():
+        a, b = getattr(pa, k).detach(), getattr(pb, k).detach()
+        bad = ((a - b).abs() > 0.05 * lrs[name] + 5e-7 * b.abs()).float().mean().item()
+        assert bad < 2e-3, (k, bad)
+    assert torch.equal(ra.gaussians.denom, rb.gaussians.denom)
+    assert _rel(ra.gaussians.xyz_gradient_accum, rb.gaussians.xyz_gradient_accum) < 1e-3
+    assert pa.optimizer.step_count == 3
+    # a densify iteration: the surgery replaces every parameter by a fresh leaf (grad None) before the step
+    before = pa._xyz.detach().clone()
+    pkg = gsr_autopatch.render_fused(ra, cam)
+    gsr_autopatch.loss_forward(_L(), pkg["image"], gt)["loss"].backward()
+    mask = torch.zeros(pa.num_points, dtype=torch.bool, device=dev)
+    mask[::4] = True
+    pa.prune_points(mask)
+    pa.optimizer.step(); pa.optimizer.zero_grad(set_to_none=True)
+    assert torch.equal(pa._xyz.detach(), before[~mask]) and pa.optimizer.step_count == 3      # that iteration's update is dropped
+    pkg = gsr_autopatch.render_fused(ra, cam)                                                # ... and training goes on
+    gsr_autopatch.loss_forward(_L(), pkg["image"], gt)["loss"].backward()
+    pa.optimizer.step()
+    assert pa.optimizer.step_count == 4 and not torch.equal(pa._xyz.detach(), before[~mask])

@@ -232,3 +232,57 @@ def test_pose_refinement_in_stage_b_improves_on_noisy_relative_poses():
         res[fit] = (root.evaluate(), err)
     print(f"fixed noisy poses: PSNR {res[False][0]:.2f} dB, worst pose entry off by {res[False][1]:.4f}; refined: {res[True][0]:.2f} dB, {res[True][1]:.4f}")
     assert res[True][0] > res[False][0] + 0.3 and res[True][1] < res[False][1]
+
+
+def _free_port():
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    return port
+
+
+def test_rccl_process_group_at_world_one_through_bench():
+    """the RCCL backend initialised for real (backend "nccl" IS RCCL on ROCm) on the one GPU a box has --
+    `GSR_BENCH_FORCE_DIST=1 python bench.py`: the process group comes up on the device, the collectives this code uses anywhere
+    (all_gather, all_reduce SUM / MIN, broadcast, barrier) run on device tensors and return the right values, the timed region's
+    barriers are RCCL barriers, and the line says so.  Point-to-point needs a second rank: unmeasured."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               HSA_ENABLE_IPC_MODE_LEGACY="0", GSR_BENCH_FORCE_DIST="1")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--gaussians", "100000",
+                          "--no-extras"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    r = d["rccl"]
+    assert r["backend"] == "nccl" and r["world"] == 1 and r["ranks_seen"] == [0] and r["all_ranks_present"], r
+    assert r["collectives_ok"] is True and "all_gather" in r["collectives"] and "barrier" in r["collectives"], r
+    assert d["n_gpus"] == 1 and d["value"] > 0
+
+
+def test_run_segments_at_world_one_over_rccl():
+    """`run_segments.py --backend nccl` as ONE rank: init_process_group("nccl", device_id=...), stage A's all_gather of the pose
+    rows on DEVICE tensors, the link self-test's MIN all-reduce, RankRunner.run's barriers -- every RCCL call of the launcher
+    except the point-to-point exchange (which needs a peer) executes."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(root, "3dgs_hierarchical_training_amd", "run_segments.py"), "--backend", "nccl",
+           "--frames", "6", "--width", "320", "--height", "240", "--gt-gaussians", "40000", "--leaf-gaussians", "20000",
+           "--leaf-iters", "10", "--phase1-iters", "2", "--phase2-iters", "4", "--stage-a", "10000", "60", "40"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    recs = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    sa = [r for r in recs if r.get("phase") == "stage_a"]
+    assert len(sa) == 1 and sa[0]["pairs_here"] == 5 and sa[0]["max_abs_pose_error"] < sa[0]["identity_guess_error"]
+    done = [r for r in recs if r.get("phase") == "done"]
+    assert len(done) == 1 and done[0]["world"] == 1 and done[0]["mode"] == "nccl" and done[0]["psnr"] > 15.0, done
+    assert not [r for r in recs if r.get("phase") == "error"]
