@@ -146,7 +146,10 @@ def test_patched_pose_render_equals_get_xyz_route():
         (pkg["image"] * w).sum().backward()
         outs.append((pkg["image"].detach(), r.gaussians.P[1].w.grad.clone(), p._xyz.grad.clone(), r.gaussians.P[0].w.grad))
     (ia, wa, xa, w0a), (ib, wb, xb, w0b) = outs
-    assert float((ia - ib).abs().max()) <= 5e-6
+    # the means differ in the last bit between the two routes (torch's matmul vs the kernel's fma chain), so a rounding-edge decision
+    # (a tile rect, the 1/255 threshold) may flip on isolated pixels: everything else agrees to a few ulps
+    diff = (ia - ib).abs()
+    assert float(diff.mean()) <= 1e-6 and float((diff > 5e-6).float().mean()) <= 2e-4, (float(diff.mean()), float((diff > 5e-6).float().mean()))
     assert w0a is None and w0b is None
     assert _rel(wa, wb) < 2e-4, _rel(wa, wb)
     assert _rel(xa, xb) < 1e-4
