@@ -1078,6 +1078,82 @@ __global__ __launch_bounds__(64) void k_blend_fwd_w6(int W, int H, int tiles_x, 
 //  the visit -- 115 -> 173 us: ten v_readlane per taken visit cost far more vector issue than the two address moves they replace.)
 
 // ------------------------------------------------------------------------------------------------
+// Backward prologue (round 4): ONE launch in place of the 48 N-byte memset in front of the backward blend.  Workgroup 0 turns the
+// forward's per-sub-tile staged depths into the backward blend's WORK ITEMS -- (tile, [b0, b1) run of 128-instance batches), each
+// resuming from the checkpoint the forward left at b0 -- as eight lists, one per XCD of the forward's tile map (a tile's items go
+// where its records and pixel planes were last touched), each list ordered by batch index: the first batches of the lists, where
+// every pixel is still alive, are the long items and go first.  Every other workgroup zero-fills the per-Gaussian accumulators.
+// Until round 3 the blend launched split x Tpad workgroups (33 600 on the 980x545 frame) of which 6 377 found work.
+// ------------------------------------------------------------------------------------------------
+constexpr size_t kItemHdrBytes = 2048;
+struct BwdItemHdr {
+    uint32_t count[8];      // items of list x
+    uint32_t offset[8];     // first item of list x in the item array
+    uint32_t pad[16];
+    uint32_t head[8][32];   // queue heads, one 128-byte line each: next item index of list x (device-scope fetch-adds)
+};
+static_assert(sizeof(BwdItemHdr) <= kItemHdrBytes, "item header");
+constexpr int kItemBuckets = 32;   // batch indices 0..30 keep their own bucket of a list, deeper ones share the last
+
+__global__ __launch_bounds__(256) void k_bwd_prologue(float4* __restrict__ gg4, size_t n4, const uint32_t* __restrict__ staged4, int T,
+                                                      int tiles_x, int interleave, int tpad, int kCkptFirst, int split_ok,
+                                                      BwdItemHdr* __restrict__ hdr, uint2* __restrict__ items, uint32_t list_cap,
+                                                      uint32_t first_pull, uint32_t* __restrict__ zero_words, int zero_count)
+{
+    const int tid = threadIdx.x;
+    const int builders = hdr ? 8 : 0;
+    if ((int)blockIdx.x >= builders) {
+        const size_t nblk = gridDim.x - builders, blk = blockIdx.x - builders;
+        const float4 z = {0.f, 0.f, 0.f, 0.f};
+        for (size_t i = blk * 256 + tid; i < n4; i += nblk * 256) gg4[i] = z;
+        return;
+    }
+    // workgroups 0..7 (the first to start; they are done before the fill is): workgroup x builds list x, in its own region of
+    // list_cap items (no cross-workgroup offsets to wait for)
+    const int x = (int)blockIdx.x;
+    // (prepare in backward: the digit counters that the per-Gaussian kernel behind the blend adds into)
+    if (zero_words && x == 0)
+        for (int q = tid; q < zero_count; q += 256) zero_words[q] = 0u;
+    __shared__ uint32_t s_cnt[kItemBuckets + 1], s_cur[kItemBuckets];
+    if (tid <= kItemBuckets) s_cnt[tid] = 0u;
+    if (tid < kItemBuckets) s_cur[tid] = 0u;
+    __syncthreads();
+    auto items_of = [&](int tile) -> int {      // the run [0, kCkptFirst) first, then one item per 128-instance batch
+        const uint4 sd = *reinterpret_cast<const uint4*>(staged4 + 4 * tile);
+        const int nbs = ((int)max(max(sd.x, sd.y), max(sd.z, sd.w)) + 127) / 128;
+        if (nbs == 0) return 0;
+        return (!split_ok || nbs <= kCkptFirst) ? 1 : 1 + nbs - kCkptFirst;
+    };
+    const int slots = tpad >> 3;
+    for (int k = tid; k < slots; k += 256) {
+        const int tile = slot_tile(interleave, x, k, T, tiles_x);
+        if (tile < 0) continue;
+        const int ni = items_of(tile);
+        for (int q = 0; q < ni; q++) atomicAdd(&s_cnt[min(q, kItemBuckets - 1)], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {                              // bucket bases; the total in the last entry
+        uint32_t run = 0;
+        for (int q = 0; q < kItemBuckets; q++) { const uint32_t c = s_cnt[q]; s_cnt[q] = run; run += c; }
+        s_cnt[kItemBuckets] = run;
+        hdr->count[x] = min(run, list_cap); hdr->offset[x] = (uint32_t)x * list_cap; hdr->head[x][0] = first_pull;
+    }
+    __syncthreads();
+    uint2* const mine = items + (size_t)x * list_cap;
+    for (int k = tid; k < slots; k += 256) {
+        const int tile = slot_tile(interleave, x, k, T, tiles_x);
+        if (tile < 0) continue;
+        const int ni = items_of(tile);
+        for (int q = 0; q < ni; q++) {
+            const int bk = min(q, kItemBuckets - 1);
+            const uint32_t pos = s_cnt[bk] + atomicAdd(&s_cur[bk], 1u);
+            // y = first batch of the run; it ends at kCkptFirst (b0 = 0) or after one batch -- bit 31: the tile's only item, runs to the end
+            if (pos < list_cap) mine[pos] = make_uint2((uint32_t)tile, (q == 0 ? 0u : (uint32_t)(kCkptFirst + q - 1)) | (ni == 1 ? 0x80000000u : 0u));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // K8: backward blend.  Same staging as the forward; front-to-back replay from the stored totals.  The per-(pixel, Gaussian)
 // contributions are summed over the lane's pixels, reduced across the wave (transposed DPP butterfly), combined across the
 // tile's two waves in LDS and flushed with ONE set of float atomics per (tile, Gaussian) record.
@@ -1088,23 +1164,23 @@ __global__ __launch_bounds__(64) void k_blend_fwd_w6(int W, int H, int tiles_x, 
 // reference never puts loss on them: lambda_depth = 0, /root/reference/arguments/__init__.py:135).  Skip
 // decisions are branch-free per pixel (masked alpha and G); only the whole-wave skip is a branch.
 // ------------------------------------------------------------------------------------------------
+struct BlendBwdArgs {
+    int W, H, tiles_x, tiles_y, T, interleave, kCkptFirst, pad;
+    const uint2* ranges;
+    const uint32_t* list;
+    const Splat* splat;
+    const float *bg, *img, *g_color, *g_depth, *g_alpha;
+    float* ggrad;
+    const float* ckpt;
+    float* det_part;
+    BwdItemHdr* hdr;
+    const uint2* items;
+};
+
 template <bool HAS_DA>
-__global__ __launch_bounds__(128) void k_blend_bwd2(int W, int H, int tiles_x, int T, const uint2* __restrict__ ranges,
-                                                    const uint32_t* __restrict__ list, const Splat* __restrict__ splat,
-                                                    const float* __restrict__ bg, const float* __restrict__ img,
-                                                    const float* __restrict__ g_color, const float* __restrict__ g_depth,
-                                                    const float* __restrict__ g_alpha, float* __restrict__ ggrad, int interleave,
-                                                    const float* __restrict__ ckpt, int split, int kCkptFirst,
-                                                    const uint32_t* __restrict__ staged4, int tpad, float* __restrict__ det_part,
-                                                    uint32_t* __restrict__ zero_words, int zero_count, int tiles_y)
+__global__ __launch_bounds__(128) void k_blend_bwd2(BlendBwdArgs args_)
 {
     constexpr int NT = 128, NV = HAS_DA ? 10 : 9;   // (two waves per workgroup)
-#ifdef GSR_K6_TIMING
-    if (threadIdx.x == 0 && blockIdx.x < 65536) { g_k8_dbg[4 * (size_t)blockIdx.x] = wall_clock64(); g_k8_dbg[4 * (size_t)blockIdx.x + 1] = 0ull; }
-#endif
-    // (prepare in backward: workgroup 0 clears the digit counters that the per-Gaussian kernel behind this one adds into)
-    if (zero_words && blockIdx.x == 0)
-        for (int q = threadIdx.x; q < zero_count; q += NT) zero_words[q] = 0u;
     // single staging buffer: a batch is ~10^4 cycles of compute, so the second barrier per batch is free, and the
     // smaller LDS footprint lets more tiles share a CU (latency hiding: waves were 33% in s_waitcnt / barriers)
     // Staged planes, ONE array for the two float4 planes so that a visit's reads share an address register:
@@ -1121,42 +1197,92 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(int W, int H, int tiles_x, i
     // a row per wave (4.6 kB more LDS per workgroup: 10 instead of 14 workgroups per CU) was 219-226 us where this is 210-211
     __shared__ float s_part[NT][NV];
     uint32_t* const s_max = &s_gid[0][0];   // [2], only until the staging below (a barrier sits between)
-    // grid = split x Tpad workgroups: part `spart` of tile `tile` (parts beyond what the tile's depth needs exit)
-    const int spart = (int)blockIdx.x / tpad, tb = (int)blockIdx.x - spart * tpad;
-    const int tile = slot_tile(interleave, tb & 7, tb >> 3, T, tiles_x);   // see k_blend_fwd_w
-    if (tile < 0) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int Tl = tiles_x * tiles_y, bimg = tile / Tl, tl = tile - bimg * Tl;   // batched render: see k_blend_fwd_w6
+    // PERSISTENT workgroups (round 4): the grid is what the chip holds at once; each workgroup replays work items -- (tile, run of
+    // 128-instance batches), built by k_bwd_prologue -- until the eight lists are empty.  Workgroup w starts with item (w >> 3) of
+    // list (w & 7) (block b runs on XCD b % 8: the list whose tiles that XCD's L2 saw last -- affinity for speed only), then pulls
+    // the next index of that list with a device-scope fetch-add on its head word (sharded per list: a few thousand pulls per launch,
+    // spread over its duration), and when the list is exhausted moves on to the next one: placement-independent, and the tail of
+    // an unlucky list is shared by everyone.  A head word is peeked with a plain device-scope load first, so the ~28 000 looks at
+    // exhausted lists at the end of the launch are loads, not serialised atomics.
+    __shared__ uint32_t s_pull;
+    constexpr float kL2E = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
+#pragma unroll
+    for (int k = 0; k < NV; k++) s_part[threadIdx.x][k] = 0.f;   // every flush re-zeroes what it consumed
+    int qx = (int)(blockIdx.x & 7u), tried = 0;
+    uint32_t qi = blockIdx.x >> 3;
+    for (;;) {
+    // Nothing but (qx, qi, tried) is carried from item to item.  The kernel's arguments are re-read from the kernarg segment per item
+    // (scalar loads through an opaque copy of the segment pointer) and everything derived from them or from the thread index is
+    // formed per item (a few dozen scalar / vector instructions per ~80 us item): kept live across the item loop -- thirteen pointers,
+    // the frame's dimensions, the hoisted lane constants -- the kernel, 69 SGPRs / 72 VGPRs as a one-item-per-workgroup launch, ran
+    // out of scalar registers and took 93 VGPRs (five instead of seven waves per SIMD).
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const __attribute__((address_space(4))) BlendBwdArgs* KArgs;
+    KArgs ka = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka));
+    int tid = (int)threadIdx.x;
+    asm volatile("" : "+v"(tid));
+#else
+    const BlendBwdArgs* ka = &args_;
+    int tid = (int)threadIdx.x;
+#endif
+    const int lane = tid & 63, wave = tid >> 6;
+    const int part_slot = reduce2_slot<NV>(lane);          // which of a visit's NV totals this lane ends up with (-1: none)
+    const uint32_t part_off = (uint32_t)(part_slot < 0 ? 0 : part_slot);
+    const int W = ka->W, H = ka->H, tiles_x = ka->tiles_x, tiles_y = ka->tiles_y, T = ka->T, kCkptFirst = ka->kCkptFirst;
+    BwdItemHdr* const hdr = ka->hdr;
+    const uint2* const __restrict__ ranges = ka->ranges;
+    const uint32_t* const __restrict__ list = ka->list;
+    const Splat* const __restrict__ splat = ka->splat;
+    const float* const __restrict__ bg = ka->bg;
+    const float* const __restrict__ img = ka->img;
+    const float* const __restrict__ g_color = ka->g_color;
+    const float* const __restrict__ g_depth = ka->g_depth;
+    const float* const __restrict__ g_alpha = ka->g_alpha;
+    float* const __restrict__ ggrad = ka->ggrad;
+    const float* const __restrict__ ckpt = ka->ckpt;
+    float* const __restrict__ det_part = ka->det_part;
+    // ---- next item -------------------------------------------------------------------------------------------------------
+    uint32_t qcount = hdr->count[qx];
+    while (qi >= qcount) {           // (workgroup-uniform: qi and qx are)
+        if (++tried == 8) return;
+        qx = (qx + 1) & 7;
+        qcount = hdr->count[qx];
+        qi = 0xffffffffu;
+        if (qcount == 0u) continue;
+        if (tid == 0) {
+            uint32_t v = __hip_atomic_load(&hdr->head[qx][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (v < qcount) v = __hip_atomic_fetch_add(&hdr->head[qx][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_pull = v;
+        }
+        __syncthreads();
+        qi = s_pull;
+        __syncthreads();
+    }
+    const uint2 item = ka->items[hdr->offset[qx] + qi];
+#ifdef GSR_K6_TIMING
+    const uint32_t dbg_slot = hdr->offset[qx] + qi;
+    if (tid == 0 && dbg_slot < 65536) { g_k8_dbg[4 * (size_t)dbg_slot] = wall_clock64(); g_k8_dbg[4 * (size_t)dbg_slot + 1] = 0ull; }
+#endif
+    const int Tl = tiles_x * tiles_y;
+    const size_t Pl = (size_t)W * H, P = Pl * (size_t)(T / Tl);
+    const float cyf = 0.5f * (float)H;
+    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
+    const int tile = (int)item.x;
+    int b0 = (int)(item.y & 0x7fffffffu);
+    int b1 = (item.y & 0x80000000u) ? 0x7fffffff : (b0 == 0 ? kCkptFirst : b0 + 1);
+    const int bimg = tile / Tl, tl = tile - bimg * Tl;   // batched render: see k_blend_fwd_w6
     const int tx = tl % tiles_x, ty = tl / tiles_x;
     const int px = tx * kTile + (tid & 15);
     const int py0 = ty * kTile + (tid >> 4) * 2;
     const float pxf = (float)px - 0.5f * (float)W;   // centred pixel coordinates (see Splat)
-    const float cyf = 0.5f * (float)H;
     const f2 pyf = {(float)py0 - cyf, (float)(py0 + 1) - cyf};
     const uint2 rg = ranges[tile];
-    const size_t Pl = (size_t)W * H, P = Pl * (size_t)(T / Tl);
-    img += (size_t)bimg * Pl;                       // this image's slice of every state plane (planes are P apart)
-    if (g_color) g_color += (size_t)bimg * 3 * Pl;  // upstream gradients: [B, 3, H, W], [B, 1, H, W]
-    if (g_depth) g_depth += (size_t)bimg * Pl;
-    if (g_alpha) g_alpha += (size_t)bimg * Pl;
-    // this workgroup's share of the tile's 128-instance batches, decided from the forward's per-sub-tile staged depths
-    // (an upper bound of every pixel's last contributor that all parts of the tile see alike) before anything else is
-    // loaded: part 0 takes the first kCkptFirst batches, the rest is divided evenly over parts 1..split-1, each of
-    // which resumes from the checkpoint the forward left at its first batch; surplus parts leave at once
-    int b0 = 0, b1 = 0x7fffffff;
-    if (split > 1 && ckpt) {
-        const uint4 sd = *reinterpret_cast<const uint4*>(staged4 + 4 * tile);
-        const int nbs = ((int)max(max(sd.x, sd.y), max(sd.z, sd.w)) + NT - 1) / NT;
-        if (nbs <= kCkptFirst) { if (spart) return; }
-        else if (spart == 0) b1 = kCkptFirst;
-        else {
-            const int q = (nbs - kCkptFirst + split - 2) / (split - 1);
-            b0 = kCkptFirst + (spart - 1) * q;
-            b1 = b0 + q;
-            if (b0 >= nbs) return;
-        }
-    } else if (spart) return;
-    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
+    const float* const imgb = img + (size_t)bimg * Pl;                       // this image's slice of every state plane (planes are P apart)
+    const float* const g_colorb = g_color ? g_color + (size_t)bimg * 3 * Pl : nullptr;  // upstream gradients: [B, 3, H, W], [B, 1, H, W]
+    const float* const g_depthb = g_depth ? g_depth + (size_t)bimg * Pl : nullptr;
+    const float* const g_alphab = g_alpha ? g_alpha + (size_t)bimg * Pl : nullptr;
+    do {
 
     // S = <gC, suffix colour> + gD * suffix depth + gA * suffix alpha + T_final <bg, gC>: the only combination of the
     // suffix sums the gradient needs, so ONE running value per pixel replaces five (and the bg term rides along)
@@ -1169,15 +1295,15 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(int W, int H, int tiles_x, i
         const int py = py0 + p;
         if (px < W && py < H) {
             const size_t pid = (size_t)py * W + px;
-            ncon[p] = reinterpret_cast<const uint32_t*>(img)[P + pid];
-            if (g_color) { gC0[p] = g_color[pid]; gC1[p] = g_color[Pl + pid]; gC2[p] = g_color[2 * Pl + pid]; }
-            float s = gC0[p] * img[2 * P + pid] + gC1[p] * img[3 * P + pid] + gC2[p] * img[4 * P + pid];
+            ncon[p] = reinterpret_cast<const uint32_t*>(imgb)[P + pid];
+            if (g_colorb) { gC0[p] = g_colorb[pid]; gC1[p] = g_colorb[Pl + pid]; gC2[p] = g_colorb[2 * Pl + pid]; }
+            float s = gC0[p] * imgb[2 * P + pid] + gC1[p] * imgb[3 * P + pid] + gC2[p] * imgb[4 * P + pid];
             if (HAS_DA) {
-                if (g_depth) gD[p] = g_depth[pid];
-                if (g_alpha) gA[p] = g_alpha[pid];
-                s += gD[p] * img[5 * P + pid] + gA[p] * img[6 * P + pid];
+                if (g_depthb) gD[p] = g_depthb[pid];
+                if (g_alphab) gA[p] = g_alphab[pid];
+                s += gD[p] * imgb[5 * P + pid] + gA[p] * imgb[6 * P + pid];
             }
-            S[p] = s + img[pid] * (bg0 * gC0[p] + bg1 * gC1[p] + bg2 * gC2[p]);
+            S[p] = s + imgb[pid] * (bg0 * gC0[p] + bg1 * gC1[p] + bg2 * gC2[p]);
         }
     }
     uint32_t nmax = max(ncon[0], ncon[1]);
@@ -1190,7 +1316,7 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(int W, int H, int tiles_x, i
     __syncthreads();   // s_max is s_gid: nobody stages before everyone has read it
     const int nb = (n + NT - 1) / NT;
     b1 = min(b1, nb);
-    if (b0 >= b1) return;   // (uniform) the staged depth over-estimated the deepest contributor
+    if (b0 >= b1) break;    // (uniform) the staged depth over-estimated the deepest contributor
     if (b0 > 0) {   // resume from the forward's checkpoint at batch b0: T there, S = what is still to come
         const float* c = ckpt + ((size_t)(rg.x >> 7) + tile + b0 - kCkptFirst) * kCkptFloats;
 #pragma unroll
@@ -1213,7 +1339,6 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(int W, int H, int tiles_x, i
     // the staged copy carries the conic pre-multiplied for the exponent in base 2, exactly as k_blend_fwd_w stages it
     // (A' = -log2(e)/2 A, B' = -log2(e) B, C' = -log2(e)/2 C), and log2(G) is evaluated with the same fma nesting, so
     // forward and backward agree on every skip decision bit for bit
-    constexpr float kL2E = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
     // Per staged instance the staging thread also decides, once, which of the two waves (16x8 pixel halves of the tile)
     // the Gaussian can reach at all: the exact box test of the tile culling (gsr_math.h box_accept: minimum of the conic
     // form over the half's pixel box against 2 ln(255 o) + slack) on each half.  A wave skips an instance whose bit is
@@ -1233,10 +1358,6 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(int W, int H, int tiles_x, i
         ra.z *= -0.5f * kL2E; ra.w *= -kL2E; rb.x *= -0.5f * kL2E;
     };
     if (b0 * NT + tid < n) stage(b0 * NT + tid);
-#pragma unroll
-    for (int k = 0; k < NV; k++) s_part[tid][k] = 0.f;   // the flush below re-zeroes what it consumes
-    const int part_slot = reduce2_slot<NV>(lane);          // which of a visit's NV totals this lane ends up with (-1: none)
-    const uint32_t part_off = (uint32_t)(part_slot < 0 ? 0 : part_slot);
     for (int b = b0; b < b1; b++) {
         const int buf = 0;
         if (b > b0) __syncthreads();   // everyone is done reading the previous batch (and its flush read s_gid)
@@ -1361,13 +1482,24 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(int W, int H, int tiles_x, i
         }
     }
 #ifdef GSR_K6_TIMING
-    if (threadIdx.x == 0 && blockIdx.x < 65536) {
-        unsigned long long* d = g_k8_dbg + 4 * (size_t)blockIdx.x;
+    if (threadIdx.x == 0 && dbg_slot < 65536) {
+        unsigned long long* d = g_k8_dbg + 4 * (size_t)dbg_slot;
         d[1] = wall_clock64();
         d[2] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);
         d[3] = ((unsigned long long)(uint32_t)n << 32) | (uint32_t)((b1 - b0) * NT);
     }
 #endif
+    } while (0);
+    // ---- pull the next index of this list ----------------------------------------------------------------------------------
+    // (at the END of the item: issued at its top -- to hide the round trip behind the item -- the returning atomic sat at the head
+    //  of the wave's in-order vmcnt queue, and at t = 0 all 3 584 workgroups pull at once, ~450 per head word: the wave of thread 0
+    //  could not consume its own pixel loads until its pull had come back, 220-230 us per launch against 180-190 without)
+    __syncthreads();   // (s_pull: everyone has read the previous value)
+    if (tid == 0) s_pull = __hip_atomic_fetch_add(&hdr->head[qx][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    qi = s_pull;
+    tried = 0;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1969,9 +2101,11 @@ static FwdScratch fwd_scratch_layout(int32_t N)
     return s;
 }
 
-struct BinLayout {   // persistent: list + ranges + checkpoints of long lists
-    size_t list, ranges, ckpt, bytes;
+struct BinLayout {   // persistent: list + ranges + checkpoints of long lists + the backward blend's work items
+    size_t list, ranges, ckpt, items, bytes;
 };
+
+static size_t bwd_list_cap(int64_t R, size_t T) { return ((size_t)(R > 0 ? R : 0) >> 7) + T + 8; }   // sum of ceil(n_t / 128) <= R / 128 + T
 static BinLayout bin_layout(int64_t R, int32_t W, int32_t H, int32_t B = 1)
 {
     const size_t T = (size_t)((W + kTile - 1) / kTile) * ((H + kTile - 1) / kTile) * (size_t)(B > 1 ? B : 1);
@@ -1979,7 +2113,9 @@ static BinLayout bin_layout(int64_t R, int32_t W, int32_t H, int32_t B = 1)
     b.ranges = 0;
     b.list = align256((T ? T : 1) * sizeof(uint2));
     b.ckpt = b.list + align256((size_t)(R > 0 ? R : 1) * 4);
-    b.bytes = b.ckpt + align256((((size_t)(R > 0 ? R : 0) >> 7) + T + 1) * kCkptFloats * sizeof(float));
+    b.items = b.ckpt + align256((((size_t)(R > 0 ? R : 0) >> 7) + T + 1) * kCkptFloats * sizeof(float));
+    // one 8-byte item per (tile, run of 128-instance batches) the backward blend has to replay: at most R / 128 + T of them
+    b.bytes = b.items + kItemHdrBytes + align256(8 * bwd_list_cap(R, T) * sizeof(uint2));   // eight lists, one per XCD of the tile map
     return b;
 }
 
@@ -2507,6 +2643,22 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
     return GSR_OK;
 }
 
+// workgroups of the backward blend the device holds at once (occupancy x compute units), per kernel variant
+static int blend_bwd_resident(int has_da)
+{
+    static int cached[2] = {0, 0};
+    if (cached[has_da]) return cached[has_da];
+    int dev = 0, cus = 256, per_cu = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    hipError_t e = has_da ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_blend_bwd2<true>, 128, 0)
+                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_blend_bwd2<false>, 128, 0);
+    if (e != hipSuccess || per_cu < 1) per_cu = 12;
+    const char* env = getenv("GSR_BWD_WG_PER_CU");   // (experiments)
+    if (env && atoi(env) > 0) per_cu = atoi(env);
+    return cached[has_da] = per_cu * cus;
+}
+
 int gsr_backward(const GsrBackwardArgs* a, void* stream_)
 {
     CallTimer call_timer(g_bwd_calls, g_bwd_ns);
@@ -2546,26 +2698,51 @@ int gsr_backward(const GsrBackwardArgs* a, void* stream_)
     // (round 3, measured and dropped: the extension allocating this scratch in the FORWARD and clearing it on a side stream behind
     //  an event, so that the 8 us fill runs next to the forward's kernels instead of in front of the backward's -- 0.863-0.873 ms per
     //  step against 0.847-0.855 with the fill here, same box: the concurrent fill takes more from the sorts than it saves)
-    GSR_HIP(hipMemsetAsync(gg, 0, (size_t)N * kGG * 4, st));
     // prepare in backward: the digit counters of the next forward's depth sort live in the hand-over buffer; they are cleared by
-    // the blend kernel's workgroup 0 (no launch of their own) and filled by the per-Gaussian kernel behind it
+    // the prologue's workgroup 0 (no launch of their own) and filled by the per-Gaussian kernel behind the blend
     uint32_t* prep_head = (a->next_view && a->prepared_out) ? reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(a->prepared_out) + prep_layout(N).sort) : nullptr;
     bool prep_head_cleared = false;
+    const int bwd_ppt = g_bwd_ppt ? g_bwd_ppt : 2;
+    const bool blend_items = a->num_rendered > 0 && bwd_ppt == 2;
+    // ONE launch clears the per-Gaussian accumulators and (workgroup 0) builds the backward blend's work items from the forward's
+    // staged depths -- where the 48 N-byte memset stood
+    // (round 3, measured and dropped: the extension allocating this scratch in the FORWARD and clearing it on a side stream behind
+    //  an event, so that the 8 us fill runs next to the forward's kernels instead of in front of the backward's -- 0.863-0.873 ms per
+    //  step against 0.847-0.855 with the fill here, same box: the concurrent fill takes more from the sorts than it saves)
+    BwdItemHdr* item_hdr = nullptr;
+    const uint2* items = nullptr;
+    int bwd_grid = 0;
+    {
+        const uint32_t* staged4 = reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(a->image) + image_staged_offset(W, H, NB));
+        const int tpad = 8 * slots_per_xcd(f_map, T, tiles_x);
+        const int want_split = g_bwd_split ? g_bwd_split : 16;
+        const int split_ok = (want_split > 1 && f_ppt >= 5) ? 1 : 0;
+        const size_t n4 = (size_t)N * kGG / 4;
+        int fill_blocks = (int)std::min<size_t>(4096, (n4 + 255) / 256);
+        if (blend_items) {
+            // (the binning buffer is this library's workspace: the item lists live behind the checkpoints, see bin_layout)
+            uint8_t* binw = const_cast<uint8_t*>(bin);
+            item_hdr = reinterpret_cast<BwdItemHdr*>(binw + B.items);
+            items = reinterpret_cast<const uint2*>(binw + B.items + kItemHdrBytes);
+            // persistent grid: what the chip holds at once (never more workgroups than there can be items), a multiple of 8
+            const int64_t bound = (a->num_rendered >> 7) + T;
+            const int resident = blend_bwd_resident((a->grad_depth || a->grad_alpha) ? 1 : 0);
+            bwd_grid = (int)std::max<int64_t>(8, (std::min<int64_t>(resident, bound) + 7) / 8 * 8);
+        }
+        const uint32_t list_cap = (uint32_t)bwd_list_cap(a->binning_capacity > 0 ? a->binning_capacity : a->num_rendered, (size_t)T);
+        hipLaunchKernelGGL(k_bwd_prologue, dim3(fill_blocks + (blend_items ? 8 : 0)), dim3(256), 0, st, reinterpret_cast<float4*>(gg), n4,
+                           staged4, T, tiles_x, f_map, tpad, f_ckpt, split_ok, item_hdr, const_cast<uint2*>(items), list_cap,
+                           (uint32_t)(bwd_grid / 8), blend_items ? prep_head : nullptr, (int)kOnesweepHeadWords);
+        prep_head_cleared = blend_items && prep_head != nullptr;
+    }
     if (a->num_rendered > 0) {
-        const int ppt = g_bwd_ppt ? g_bwd_ppt : 2;
+        const int ppt = bwd_ppt;
         if (NB > 1 && ppt != 2) return fail(GSR_ERR_ARG, "batch: served by the default backward blend kernel only%s");
         const float* img = static_cast<const float*>(a->image);
         ProfScope ps(P_BLEND_BWD, st);
         if (ppt == 2) {
             // (checkpoints are written by k_blend_fwd_w only)
-            // (sizing the split from the average list length R / T -- fewer empty workgroups on small frames -- measured no
-            //  difference: 75 us either way at 50 k Gaussians; the parts that have nothing to do leave after one 16-byte load)
-            const int tpad = 8 * slots_per_xcd(f_map, T, tiles_x);
-            const int want_split = g_bwd_split ? g_bwd_split : std::max(1, std::min(16, 34816 / std::max(1, tpad)));
-            const int split = (want_split > 1 && f_ppt >= 5) ? want_split : 1;
-            const int grid = split * tpad;
             const float* ckpt = reinterpret_cast<const float*>(bin + B.ckpt);
-            const uint32_t* staged4 = reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(a->image) + image_staged_offset(W, H, NB));
             // deterministic debug mode: R-sized slots + a sort of the instance positions by Gaussian id (stream-ordered
             // allocations of the library's own: gsr_backward has no allocator callback and this is not a hot path)
             float* det_part = nullptr;
@@ -2583,15 +2760,10 @@ int gsr_backward(const GsrBackwardArgs* a, void* stream_)
                 det_part = reinterpret_cast<float*>(det_mem + o_part);
                 GSR_HIP(hipMemsetAsync(det_part, 0, (size_t)Rn * kDetStride * 4, st));
             }
-            if (a->grad_depth || a->grad_alpha)
-                hipLaunchKernelGGL(k_blend_bwd2<true>, dim3(grid), dim3(128), 0, st, W, H, tiles_x, T, ranges, list, splat, a->bg, img,
-                                   a->grad_color, a->grad_depth, a->grad_alpha, gg, f_map, ckpt, split, f_ckpt, staged4, tpad, det_part,
-                                   prep_head, (int)kOnesweepHeadWords, tiles_y);
-            else
-                hipLaunchKernelGGL(k_blend_bwd2<false>, dim3(grid), dim3(128), 0, st, W, H, tiles_x, T, ranges, list, splat, a->bg, img,
-                                   a->grad_color, a->grad_depth, a->grad_alpha, gg, f_map, ckpt, split, f_ckpt, staged4, tpad, det_part,
-                                   prep_head, (int)kOnesweepHeadWords, tiles_y);
-            prep_head_cleared = prep_head != nullptr;
+            BlendBwdArgs ba = {W, H, tiles_x, tiles_y, T, f_map, f_ckpt, 0, ranges, list, splat, a->bg, img, a->grad_color, a->grad_depth,
+                               a->grad_alpha, gg, ckpt, det_part, item_hdr, items};
+            if (a->grad_depth || a->grad_alpha) hipLaunchKernelGGL(k_blend_bwd2<true>, dim3(bwd_grid), dim3(128), 0, st, ba);
+            else hipLaunchKernelGGL(k_blend_bwd2<false>, dim3(bwd_grid), dim3(128), 0, st, ba);
             if (g_deterministic) {
                 uint32_t* k0 = reinterpret_cast<uint32_t*>(det_mem + o_k0); uint32_t* k1 = reinterpret_cast<uint32_t*>(det_mem + o_k1);
                 uint32_t* v0 = reinterpret_cast<uint32_t*>(det_mem + o_v0); uint32_t* v1 = reinterpret_cast<uint32_t*>(det_mem + o_v1);
