@@ -632,12 +632,112 @@ __device__ __forceinline__ void block_scan_body(uint32_t* block_sums, int nb, un
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Balanced placement of the forward blend's waves (round 4).  Measured (tools/k7_slot_map.py): within an XCD the dispatcher deals
+// single-wave workgroups to its 128 SIMDs strictly round-robin -- every aligned run of 128 consecutive slots covers each SIMD once,
+// slot k and slot k + 128 share a SIMD (which SIMD that is rotates from launch to launch) -- and a SIMD finishes at
+// 0.0376 us x (the visits of its 8-9 waves) + 20 us.  The kernel therefore lasts as long as its most loaded COLUMN k mod 128.  A
+// wave's visits are predictable: the same view is rendered again a few iterations later (a trainer cycles through its frames) with
+// nearly the same scene (correlation 0.95-0.96 at eight steps' distance; 0.47 with the previous step's OTHER view).  So: the blend
+// records every wave's visits in a small device-side cache keyed by a hash of the view matrix; the next render of that view sorts
+// each XCD's items by that prediction (descending) and deals them to the slots in snake order -- column totals even out, the
+// shortest items are the ones that start late -- in eight extra workgroups of k_tile_counts, off the critical path.  Affinity
+// for speed only: the permutation is a permutation whatever the cache holds (a miss, a race with another stream: identity or a
+// poorer balance, never a different image).
+// ------------------------------------------------------------------------------------------------
+constexpr int kVcEntries = 32;
+struct ViewCostHdr {
+    unsigned long long hash[kVcEntries];
+    uint32_t stamp[kVcEntries];
+    uint32_t clock, pad[31];
+};
+struct BlendBalance {       // kernel-argument bundle; hdr == nullptr: off
+    ViewCostHdr* hdr;
+    uint16_t* cost;         // [kVcEntries][items]: visits of workgroup-item (xcd + 8 kslot) at the last render of that view
+    uint16_t* perm;         // per call: dispatch slot (xcd + 8 k) -> item's kslot
+    uint32_t* cur;          // per call: [0] cache entry this render records into (0xffffffff: none), [1] perm valid
+    const float* vm;        // the view matrix (16 floats) the hash is taken of
+    int items, nslots4, W, H;
+};
+
+__device__ __forceinline__ unsigned long long view_hash(const float* vm, int W, int H)
+{
+    unsigned long long h = 1469598103934665603ull;
+    for (int i = 0; i < 16; i++) { h ^= (unsigned long long)__float_as_uint(vm[i]); h *= 1099511628211ull; }
+    h ^= ((unsigned long long)(uint32_t)W << 32) | (uint32_t)H; h *= 1099511628211ull;
+    return h | 1ull;        // (0 = empty entry)
+}
+
+__device__ void balance_build(const BlendBalance bb, const int x)
+{
+    __shared__ uint32_t s_hist[1024];
+    __shared__ int s_entry;
+    const int tid = threadIdx.x;
+    const unsigned long long h = view_hash(bb.vm, bb.W, bb.H);
+    if (tid == 0) s_entry = -1;
+    for (int q = tid; q < 1024; q += kEmitThreads) s_hist[q] = 0u;
+    __syncthreads();
+    if (tid < kVcEntries && bb.hdr->hash[tid] == h) s_entry = tid;
+    __syncthreads();
+    const int e = s_entry;
+    if (x == 0 && tid == 0) {   // workgroup 0 keeps the cache's books: touch the entry, or take the least recently used one
+        int rec = e;
+        const uint32_t now = bb.hdr->clock + 1u;
+        if (rec < 0) {
+            uint32_t best = 0xffffffffu;
+            for (int i = 0; i < kVcEntries; i++) if (bb.hdr->stamp[i] < best) { best = bb.hdr->stamp[i]; rec = i; }
+            bb.hdr->hash[rec] = h;
+        }
+        bb.hdr->stamp[rec] = now; bb.hdr->clock = now;
+        bb.cur[0] = (uint32_t)rec; bb.cur[1] = e >= 0 ? 1u : 0u;
+    }
+    if (e < 0) return;          // first render of this view: identity placement (the blend ignores perm)
+    const uint16_t* cost = bb.cost + (size_t)e * bb.items;
+    // counting sort of this XCD's items by predicted visits, descending; ties in any order
+    constexpr int kPer = 20;    // items per thread: up to 5 120 per XCD (65 535 workgroups in all)
+    uint32_t c[kPer];
+#pragma unroll
+    for (int q = 0; q < kPer; q++) {
+        const int k = tid + q * kEmitThreads;
+        c[q] = k < bb.nslots4 ? min((uint32_t)cost[x + 8 * k], 1023u) : 0xffffffffu;
+        if (k < bb.nslots4) atomicAdd(&s_hist[1023u - c[q]], 1u);
+    }
+    __syncthreads();
+    // exclusive scan of the 1024 bins (bin 0 = the largest cost): four bins per thread
+    __shared__ uint32_t s_wave[4];
+    uint32_t v4[4], run = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) { v4[q] = s_hist[4 * tid + q]; run += v4[q]; }
+    uint32_t total;
+    uint32_t base = block_inclusive_scan_256(run, s_wave, total) - run;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; q++) { s_hist[4 * tid + q] = base; base += v4[q]; }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < kPer; q++) {
+        const int k = tid + q * kEmitThreads;
+        if (k >= bb.nslots4) continue;
+        const uint32_t r = atomicAdd(&s_hist[1023u - c[q]], 1u);    // rank in descending order
+        const uint32_t round = r >> 7, col = r & 127u;
+        const uint32_t pos = round * 128u + ((round & 1u) ? 127u - col : col);      // snake over the 128 columns
+        // (the last, partial round keeps its positions inside the range: mirror within what is left of it)
+        const uint32_t left = (uint32_t)bb.nslots4 - round * 128u;
+        const uint32_t pos2 = left >= 128u ? pos : round * 128u + ((round & 1u) ? left - 1u - col : col);
+        bb.perm[x + 8 * (int)pos2] = (uint16_t)k;
+    }
+}
+
 __global__ __launch_bounds__(kEmitThreads) void k_tile_counts(int N, const uint32_t* __restrict__ sorted_gid,
                                                               const TileRec* __restrict__ tilerec, uint32_t* __restrict__ block_sums,
-                                                              TileRec* __restrict__ sorted_rec)
+                                                              TileRec* __restrict__ sorted_rec, BlendBalance bb, int nb)
 {
+    // (eight extra workgroups when bb.hdr is set -- the FIRST eight, so that they run beside the counting, not behind it)
+    const int nbuild = bb.hdr ? 8 : 0, blk = (int)blockIdx.x - nbuild;
+    if (blk < 0) { balance_build(bb, (int)blockIdx.x); return; }
+    (void)nb;
     __shared__ uint32_t s_wave[4];
-    const int j = blockIdx.x * kEmitThreads + threadIdx.x;
+    const int j = blk * kEmitThreads + threadIdx.x;
     uint32_t t = 0;
     if (j < N) {   // the one random gather of the records: k_emit reads them back in depth order, coalesced
         const TileRec r = tilerec[sorted_gid[j]];
@@ -646,7 +746,7 @@ __global__ __launch_bounds__(kEmitThreads) void k_tile_counts(int N, const uint3
     }
     uint32_t total;
     block_inclusive_scan_256(t, s_wave, total);
-    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+    if (threadIdx.x == 0) block_sums[blk] = total;
 }
 
 // (letting the LAST workgroup of k_tile_counts do the scan -- a ticket, agent-scope loads of the other blocks' totals --
@@ -871,9 +971,10 @@ __device__ __forceinline__ void blend_fwd_item(const int xcd, const int kslot, f
                                                const float* __restrict__ bg, float* __restrict__ out_color,
                                                float* __restrict__ out_depth, float* __restrict__ out_alpha,
                                                float* __restrict__ img, uint32_t* __restrict__ staged4, int interleave,
-                                               float* __restrict__ ckpt, int kCkptFirst, int tiles_y)
+                                               float* __restrict__ ckpt, int kCkptFirst, int tiles_y, uint16_t* __restrict__ cost_out)
 {
     constexpr int NT = 64;
+    uint32_t visits = 0u;   // (wave, instance) visits of this item: what the balanced placement of the next render of this view predicts with
 #ifdef GSR_K6_TIMING
     const unsigned long long dbg_t0 = wall_clock64();
     uint32_t dbg_visits = 0u, dbg_taken = 0u;   // (wave, instance) visits / visits in which some pixel took the instance
@@ -881,8 +982,8 @@ __device__ __forceinline__ void blend_fwd_item(const int xcd, const int kslot, f
 #endif
     const int tile = slot_tile(interleave, xcd, kslot >> 2, T, tiles_x);
     const int sub = kslot & 3;
-    if (tile < 0) return;
     const int lane = (int)(threadIdx.x & 63u);
+    if (tile < 0) { if (cost_out && lane == 0) cost_out[xcd + 8 * kslot] = 0; return; }
     // batched render: T = B tiles_x tiles_y tiles of a tall grid, image `bimg` owns the tile rows [bimg tiles_y, (bimg + 1) tiles_y)
     const int Tl = tiles_x * tiles_y, bimg = tile / Tl, tl = tile - bimg * Tl;
     const int tx = tl % tiles_x, ty = tl / tiles_x;
@@ -939,6 +1040,7 @@ __device__ __forceinline__ void blend_fwd_item(const int xcd, const int kslot, f
         ra.z *= -0.5f * kL2E; ra.w *= -kL2E; rb.x *= -0.5f * kL2E;
         s_ab[buf][lane] = ra; s_ab[2 + buf][lane] = rb; s_c[buf][lane] = make_float2(rc.x, rc.y);
         const unsigned long long reach = REACH ? __ballot(reach_me && lane < cnt) : 0ull;
+        visits += REACH ? (uint32_t)__popcll(reach) : (uint32_t)cnt;
         // the staging area belongs to this wave alone: LDS instructions of one wave execute in issue order, so the broadcast
         // reads below see the writes above -- only the compiler must be kept from reordering them (no s_barrier: the queue
         // kernel runs sixteen independent waves per workgroup)
@@ -1018,6 +1120,7 @@ __device__ __forceinline__ void blend_fwd_item(const int xcd, const int kslot, f
 #endif
     }
     if (lane == 0) staged4[tile * 4 + sub] = (uint32_t)min(n, batches * NT);
+    if (cost_out && lane == 0) cost_out[xcd + 8 * kslot] = (uint16_t)min(visits, 65535u);
 #ifdef GSR_K6_TIMING
     if (lane == 0 && xcd + 8 * kslot < 65536) {
         unsigned long long* d = g_k6_dbg + 4 * (size_t)(xcd + 8 * kslot);
@@ -1051,14 +1154,24 @@ __global__ __launch_bounds__(64) void k_blend_fwd_w6(int W, int H, int tiles_x, 
                                                      const float* __restrict__ bg, float* __restrict__ out_color,
                                                      float* __restrict__ out_depth, float* __restrict__ out_alpha,
                                                      float* __restrict__ img, uint32_t* __restrict__ staged4, int interleave,
-                                                     float* __restrict__ ckpt, int kCkptFirst, int tiles_y)
+                                                     float* __restrict__ ckpt, int kCkptFirst, int tiles_y, const BlendBalance bb)
 {
     // s_a and s_b in ONE array (planes 0/1 = A rows of the two buffers, 2/3 = B rows): a visit's two reads share one address
     // register and differ in the immediate offset
     __shared__ float4 s_ab[4][64];
     __shared__ float2 s_c[2][64];
-    blend_fwd_item<REACH>((int)(blockIdx.x & 7), (int)(blockIdx.x >> 3), s_ab, s_c, W, H, tiles_x, T, ranges, list, splat, bg, out_color, out_depth,
-                          out_alpha, img, staged4, interleave, ckpt, kCkptFirst, tiles_y);
+    // balanced placement (see balance_build): the slot -> item table of this render, and where this item's visits are recorded
+    int kslot = (int)(blockIdx.x >> 3);
+    uint16_t* cost_out = nullptr;
+    if (bb.hdr) {
+        const uint32_t* __restrict__ cur = bb.cur;
+        const uint16_t* __restrict__ perm = bb.perm;
+        const uint32_t e = cur[0];
+        if (cur[1]) kslot = (int)perm[blockIdx.x];
+        if (e < (uint32_t)kVcEntries) cost_out = bb.cost + (size_t)e * bb.items;
+    }
+    blend_fwd_item<REACH>((int)(blockIdx.x & 7), kslot, s_ab, s_c, W, H, tiles_x, T, ranges, list, splat, bg, out_color, out_depth,
+                          out_alpha, img, staged4, interleave, ckpt, kCkptFirst, tiles_y, cost_out);
 }
 
 // (round 3, measured with tools/k6_wave_timing.py on the 1 M / 980x545 frame: the 8.6 k waves are all resident at once, eight to
@@ -1261,7 +1374,7 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(BlendBwdArgs args_)
     }
     const uint2 item = ka->items[hdr->offset[qx] + qi];
 #ifdef GSR_K6_TIMING
-    const uint32_t dbg_slot = hdr->offset[qx] + qi;
+    const uint32_t dbg_slot = qi < 8192u ? (uint32_t)qx * 8192u + qi : 65536u;   // (probe table: 8 lists x 8 192 items)
     if (tid == 0 && dbg_slot < 65536) { g_k8_dbg[4 * (size_t)dbg_slot] = wall_clock64(); g_k8_dbg[4 * (size_t)dbg_slot + 1] = 0ull; }
 #endif
     const int Tl = tiles_x * tiles_y;
@@ -2143,6 +2256,9 @@ static BinScratch bin_scratch_layout(int64_t R, int key_bytes = 4)
 // The pinned read-back slot and its event belong to ONE device (an event recorded on another device's stream is an
 // invalid-handle error), and a slot is held by one call at a time: callers on several threads / devices do not serialise
 // on each other while they enqueue or wait.
+// the per-view cost cache of the balanced forward blend: one per (device, frame geometry), a handful at most
+struct ViewCostCache { int dev, W, H, map, items; uint8_t* mem; };
+static std::vector<ViewCostCache> g_view_costs;   // guarded by g_state_mutex
 struct PinSlot { unsigned long long* host = nullptr; unsigned long long* dev = nullptr; hipEvent_t ev = nullptr; bool busy = false;
                  unsigned long long seq = 0; };   // seq: number of the slot's last use; the scan kernel echoes it behind the count
 static std::mutex g_state_mutex;
@@ -2155,6 +2271,7 @@ static int g_bwd_split = 0;  // workgroups a long tile's backward is split over 
                              // 980x545 frame, fewer the more tiles there are (the parts that find nothing to do still cost a launch slot:
                              // 16 x 17 408 workgroups for eight batched images spent 170 of 860 us on them) -- about 35 000 workgroups
 static int g_ckpt_first = 1;  // 128-instance batches of a tile before the forward starts leaving checkpoints
+static int g_blend_balance = 1;   // forward blend: place the waves by the visits each took at the previous render of the same view (balance_build)
 static int g_tile_map = 2;   // tile -> XCD map: 2 = 2x2 tile blocks interleaved (default), 1 = tiles interleaved, 0 = banded
 static std::atomic<long long> g_spec_overflows{0}, g_spec_forwards{0}, g_exact_forwards{0};
 // host-side time accounting of the two entry points (gsr_get_counter): wall time inside the call, and the part of the forward
@@ -2233,7 +2350,16 @@ using namespace gsr;
 extern "C" {
 
 size_t gsr_geom_bytes(int32_t N) { return geom_layout(N).total; }
-static size_t image_staged_offset(int32_t W, int32_t H, int32_t B) { return align256((size_t)W * H * (size_t)(B > 1 ? B : 1) * kImgPlanes * 4); }
+// image workspace: state planes | balanced-placement table of the forward blend (slot -> item, uint16 per workgroup, + 256 bytes of
+// per-call words; single renders only) | staged counters
+static size_t image_balance_offset(int32_t W, int32_t H, int32_t B) { return align256((size_t)W * H * (size_t)(B > 1 ? B : 1) * kImgPlanes * 4); }
+static size_t image_balance_bytes(int32_t W, int32_t H, int32_t B)
+{
+    if (B > 1) return 0;
+    const int tiles_x = (W + kTile - 1) / kTile, T = tiles_x * ((H + kTile - 1) / kTile);
+    return 256 + align256((size_t)32 * slots_per_xcd(2, T, tiles_x) * sizeof(uint16_t) + 64);   // (map 2 has the most slots)
+}
+static size_t image_staged_offset(int32_t W, int32_t H, int32_t B) { return image_balance_offset(W, H, B) + image_balance_bytes(W, H, B); }
 size_t gsr_image_staged_offset(int32_t W, int32_t H) { return image_staged_offset(W, H, 1); }
 size_t gsr_image_bytes_batched(int32_t W, int32_t H, int32_t B)
 {
@@ -2314,6 +2440,7 @@ int gsr_set_option(const char* name, int value)
     if (!strcmp(name, "bwd_split")) { if (value < 0 || value > 64) return GSR_ERR_ARG; g_bwd_split = value; return GSR_OK; }
     if (!strcmp(name, "ckpt_first")) { if (value < 1 || value > 64) return GSR_ERR_ARG; g_ckpt_first = value; return GSR_OK; }
     if (!strcmp(name, "tile_map")) { if (value < 0 || value > 2) return GSR_ERR_ARG; g_tile_map = value; return GSR_OK; }
+    if (!strcmp(name, "blend_balance")) { g_blend_balance = value ? 1 : 0; return GSR_OK; }
     if (!strcmp(name, "speculative_binning")) { g_speculate = value ? 1 : 0; return GSR_OK; }
     if (!strcmp(name, "deterministic_backward")) { g_deterministic = value ? 1 : 0; return GSR_OK; }
     if (!strcmp(name, "binning_capacity_hint")) {   // tests: capacity of the next forward (one shot; forces an overflow re-run)
@@ -2364,6 +2491,7 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
     out->num_rendered = 0; out->binning = nullptr; out->binning_bytes = 0; out->binning_capacity = 0;
     out->forward_flags = pack_fwd_flags(opt_ppt, opt_map, opt_ckpt);
     uint64_t R = 0;
+    BlendBalance bb = {};   // filled in front of k_tile_counts (whose extra workgroups build the placement the blend reads)
     Splat* splat = static_cast<Splat*>(a->geom);
     float* img = static_cast<float*>(a->image);
     uint32_t* staged = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(a->image) + image_staged_offset(W, H, NB));
@@ -2451,10 +2579,10 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
             float* ckpt = reinterpret_cast<float*>(bin + B.ckpt);
             if (ppt == 7)
                 hipLaunchKernelGGL(k_blend_fwd_w6<true>, dim3(8 * 4 * slots_per_xcd(opt_map, T, tiles_x)), dim3(64), 0, st, W, H, tiles_x, T, ranges, list, splat, a->bg,
-                                   a->out_color, a->out_depth, a->out_alpha, img, staged, opt_map, ckpt, opt_ckpt, tiles_y);
+                                   a->out_color, a->out_depth, a->out_alpha, img, staged, opt_map, ckpt, opt_ckpt, tiles_y, bb);
             else if (ppt == 6)
                 hipLaunchKernelGGL(k_blend_fwd_w6<false>, dim3(8 * 4 * slots_per_xcd(opt_map, T, tiles_x)), dim3(64), 0, st, W, H, tiles_x, T, ranges, list, splat, a->bg,
-                                   a->out_color, a->out_depth, a->out_alpha, img, staged, opt_map, ckpt, opt_ckpt, tiles_y);
+                                   a->out_color, a->out_depth, a->out_alpha, img, staged, opt_map, ckpt, opt_ckpt, tiles_y, BlendBalance{});
 #ifdef GSR_AB_VARIANTS
             else if (!launch_blend_fwd_variant(ppt, W, H, tiles_x, T, ranges, list, splat, a->bg, a->out_color, a->out_depth, a->out_alpha, img, staged,
                                                opt_map, ckpt, opt_ckpt, st))
@@ -2581,8 +2709,40 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
             zj.p[1] = staged; zj.words[1] = (uint32_t)T * 4u;
             if (bs) { zj.p[2] = bs + S.sort; zj.words[2] = kOnesweepHeadWords; }
         }
-        hipLaunchKernelGGL(k_tile_counts, dim3(nb), dim3(kEmitThreads), 0, st, N, sorted_gid, ntiles, block_sums,
-                           reinterpret_cast<TileRec*>(fs + L.srec));
+        // balanced placement of the forward blend (balance_build): single renders through the default kernel, frames of up to
+        // 65 535 sub-tile waves; the per-view cost cache is a lazily allocated device buffer per (device, frame geometry)
+        {
+            const int nslots4 = 4 * slots_per_xcd(opt_map, T, tiles_x), items = 8 * nslots4;
+            if (g_blend_balance && NB == 1 && opt_ppt == 7 && items <= 65535 && nslots4 <= 20 * kEmitThreads && a->viewmatrix) {
+                const size_t hdr_bytes = align256(sizeof(ViewCostHdr));
+                uint8_t* mem = nullptr;
+                {
+                    std::lock_guard<std::mutex> lk(g_state_mutex);
+                    for (auto& c : g_view_costs)
+                        if (c.dev == dev_id && c.W == W && c.H == H && c.map == opt_map && c.items == items) mem = c.mem;
+                    if (!mem && g_view_costs.size() < 16) {
+                        if (hipMalloc((void**)&mem, hdr_bytes + (size_t)kVcEntries * items * sizeof(uint16_t)) == hipSuccess) {
+                            hipMemsetAsync(mem, 0, hdr_bytes, st);   // (a reader on another stream that beats this clear sees garbage hashes: a miss)
+                            g_view_costs.push_back({dev_id, W, H, opt_map, items, mem});
+                        } else {
+                            (void)hipGetLastError();
+                            mem = nullptr;
+                        }
+                    }
+                }
+                if (mem) {
+                    uint8_t* ib = static_cast<uint8_t*>(a->image) + image_balance_offset(W, H, NB);
+                    bb.hdr = reinterpret_cast<ViewCostHdr*>(mem);
+                    bb.cost = reinterpret_cast<uint16_t*>(mem + hdr_bytes);
+                    bb.cur = reinterpret_cast<uint32_t*>(ib);
+                    bb.perm = reinterpret_cast<uint16_t*>(ib + 256);
+                    bb.vm = a->viewmatrix;
+                    bb.items = items; bb.nslots4 = nslots4; bb.W = W; bb.H = H;
+                }
+            }
+        }
+        hipLaunchKernelGGL(k_tile_counts, dim3(nb + (bb.hdr ? 8 : 0)), dim3(kEmitThreads), 0, st, N, sorted_gid, ntiles, block_sums,
+                           reinterpret_cast<TileRec*>(fs + L.srec), bb, nb);
         // the scan writes R straight into the pinned slot (device-visible host memory): no copy launch behind it
         hipLaunchKernelGGL(k_block_scan, dim3(1), dim3(1024), 0, st, block_sums, nb, total, zj, pin.s->dev, ++pin.s->seq);
     }

@@ -81,3 +81,4 @@ def test_exports_and_sizes():
         assert hasattr(lib, s)
     assert lib.gsr_geom_bytes(1000) >= 48 * 1000
     assert lib.gsr_image_bytes(980, 545) >= 980 * 545 * 28
+

@@ -675,3 +675,52 @@ def test_f_rest_group_is_skipped_while_its_moments_are_zero():
             ts.train_step(pe, ts.with_sh_degree(views[0], 1), gts[0])
     finally:
         lib.gsr_set_option(b"deterministic_backward", 0)
+
+
+def test_balanced_blend_placement_changes_nothing_but_the_order():
+    """Round 4: the forward blend places its sub-tile waves by the visits each took at the previous render of the same view (a
+    device-side cache keyed by a hash of the view matrix, csrc/gsr_kernels.hip balance_build).  Whatever the cache holds the
+    placement is a permutation: first render of a view (miss: identity), second render (hit: snake order by predicted visits),
+    another view in between, the same view after the scene changed -- image, depth, alpha, radii and the gradients of a
+    deterministic backward are bit-identical with the option switched off."""
+    import importlib
+    L = importlib.import_module("3dgs_hierarchical_training_amd._lib")
+    R = importlib.import_module("3dgs_hierarchical_training_amd.rasterizer")
+    ts = importlib.import_module("3dgs_hierarchical_training_amd.train_step")
+    lib = L.load()
+    dev = torch.device("cuda:0")
+    W, H, N = 500, 333, 60000
+    views = []
+    for seed, posed in ((3, False), (4, True)):
+        sc = parity.syn.make_scene(N, W, H, sh_degree=3, seed=3, posed=False)
+        if posed:
+            cam = parity.syn.make_scene(8, W, H, sh_degree=3, seed=seed, posed=True)
+            for k in ("viewmatrix", "projmatrix", "campos"):
+                sc[k] = cam[k]
+        views.append(sc)
+    g = torch.Generator().manual_seed(9)
+    wc = torch.randn(3, H, W, generator=g).to(dev)
+
+    def run(sc, scale):
+        t = {k: sc[k].to(dev).clone().requires_grad_(True) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
+        with torch.no_grad():
+            t["scales"] *= scale
+        st = ts.make_settings(sc, dev, 3)
+        m2d = torch.zeros(N, 3, device=dev, requires_grad=True)
+        out = R.GaussianRasterizer(st)(means3D=t["means3D"], means2D=m2d, shs=t["shs"], colors_precomp=None, opacities=t["opacities"],
+                                       scales=t["scales"], rotations=t["rotations"], cov3D_precomp=None)
+        (out[0] * wc).sum().backward()
+        return [o.detach().clone() for o in out] + [t[k].grad.clone() for k in sorted(t)] + [m2d.grad.clone()]
+    seq = [(0, 1.0), (0, 1.0), (1, 1.0), (0, 1.3), (1, 1.0), (0, 1.3)]     # (view, scene change)
+    assert lib.gsr_set_option(b"deterministic_backward", 1) == 0
+    try:
+        res = {}
+        for bal in (0, 1):
+            assert lib.gsr_set_option(b"blend_balance", bal) == 0
+            res[bal] = [run(views[v], s) for v, s in seq]
+    finally:
+        lib.gsr_set_option(b"deterministic_backward", 0)
+        lib.gsr_set_option(b"blend_balance", 1)
+    for i, (a, b) in enumerate(zip(res[0], res[1])):
+        for j, (x, y) in enumerate(zip(a, b)):
+            assert torch.equal(x, y), (i, j)
