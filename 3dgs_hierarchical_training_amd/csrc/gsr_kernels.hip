@@ -644,6 +644,11 @@ __device__ __forceinline__ void block_scan_body(uint32_t* block_sums, int nb, un
 // shortest items are the ones that start late -- in eight extra workgroups of k_tile_counts, off the critical path.  Affinity
 // for speed only: the permutation is a permutation whatever the cache holds (a miss, a race with another stream: identity or a
 // poorer balance, never a different image).
+// Measured and dropped (round 4): CHAINING the items beyond the 1 024 waves an XCD holds (96 of 1 120 slots on the 980x545 frame, 59 of
+// them empty edge sub-tiles or padding) behind the shortest resident items, so that nothing starts late -- the wave loop needs the
+// kernel arguments re-read per item to stay at 8 waves per SIMD (+4 us on its own), and a chained pair pays a wave's fixed ~19 us
+// start twice IN SERIES on one wave where the dispatcher starts the late item on the first slot that frees anywhere in the XCD:
+// 116 us against 98 (identity order: 111).
 // ------------------------------------------------------------------------------------------------
 constexpr int kVcEntries = 32;
 struct ViewCostHdr {
@@ -3080,6 +3085,7 @@ int64_t gsr_get_counter(const char* name)
 {
     if (!name) return -1;
     if (!strcmp(name, "spec_overflows")) return g_spec_overflows.load();
+    if (!strcmp(name, "blend_bwd_resident")) return blend_bwd_resident(0);
     if (!strcmp(name, "spec_forwards")) return g_spec_forwards.load();
     if (!strcmp(name, "exact_forwards")) return g_exact_forwards.load();
     if (!strcmp(name, "forward_calls")) return g_fwd_calls.load();
