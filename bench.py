@@ -805,6 +805,9 @@ def main():
                 "cycles_per_instruction": {"plain": cal["plain"], "trans": cal["trans"], "double_pass_not_separable": cal["double_pass"],
                                            "one_wave_alone": cal["single_wave"], "source": cal_src},
                 "valu_pipe_cycles_per_simd": cyc, "simd_cycles_available": avail, "frac": (cyc / avail) if avail else None,
+                # the launch's time at calibrated full vector issue (PMC instruction counts of the committed
+                # summary x calibrated cycles / 1024 SIMDs, at 2.4 GHz) over THIS run's measured launch time
+                "valu_roof_ms": cyc / 2.4e6, "frac_of_valu_roof": (cyc / 2.4e6 / launch_ms) if launch_ms else None,
                 # SQ_WAVE_CYCLES counts resident wave time in units of 4 cycles, summed over the chip
                 "avg_waves_per_simd": (kv["SQ_WAVE_CYCLES"] * 4.0 / (1024.0 * avail)) if ("SQ_WAVE_CYCLES" in kv and avail) else None,
                 "counters_from": pmc_src, "counters_launch_ms": (avail / 2.4e6) if avail else None, "this_run_launch_ms": launch_ms}
