@@ -31,6 +31,7 @@ struct EmuCtx {
     std::vector<int64_t> tile_start;
     std::vector<float> finalT, acc;   // acc [P,5]
     std::vector<uint32_t> ncontrib;
+    std::vector<float> abs_xy;        // absolute pixel-space means of the override (hostemu_set_absolute_pixels)
 };
 
 static Camera make_cam(const EmuIn& in)
@@ -48,6 +49,10 @@ static Camera make_cam(const EmuIn& in)
 // experiment hook: when non-null, overrides the projected state with externally computed (e.g. f64-rounded) values
 static const float *g_ov_xy = nullptr, *g_ov_conic = nullptr, *g_ov_rgb = nullptr;
 void hostemu_override_geom(const float* xy, const float* conic, const float* rgb) { g_ov_xy = xy; g_ov_conic = conic; g_ov_rgb = rgb; }
+// experiment hook: with an override in place, blend with ABSOLUTE binary32 pixel coordinates -- the pixel-space
+// mean as given (not re-centred on the image), d = mean - (float)pixel -- which is how the public CUDA module forms its offsets
+static int g_abs_pixels = 0;
+void hostemu_set_absolute_pixels(int on) { g_abs_pixels = on; }
 
 EmuCtx* hostemu_forward(const EmuIn* in, float* out_color, float* out_depth, float* out_alpha, int32_t* radii)
 {
@@ -63,6 +68,7 @@ EmuCtx* hostemu_forward(const EmuIn* in, float* out_color, float* out_depth, flo
                        in->cov3D_precomp ? in->cov3D_precomp + 6 * (size_t)i : nullptr, in->opacities[i],
                        in->shs ? in->shs + (size_t)i * in->M * 3 : nullptr, 3, 1,
                        in->colors_precomp ? in->colors_precomp + 3 * (size_t)i : nullptr, c->splat[i]);
+        if (g_ov_xy && g_abs_pixels) { if (c->abs_xy.empty()) c->abs_xy.assign(2 * (size_t)N, 0.f); c->abs_xy[2 * i] = g_ov_xy[2 * i]; c->abs_xy[2 * i + 1] = g_ov_xy[2 * i + 1]; }
         if (g_ov_xy && c->splat[i].radius > 0) {
             Splat& s = c->splat[i];
             s.px = g_ov_xy[2 * i] - 0.5f * W; s.py = g_ov_xy[2 * i + 1] - 0.5f * H;
@@ -105,7 +111,9 @@ EmuCtx* hostemu_forward(const EmuIn* in, float* out_color, float* out_depth, flo
                 contributor++;
                 const Splat& s = c->splat[c->list[k]];
                 float G, dx, dy;
-                const float alpha = pair_alpha((float)x - 0.5f * W, (float)y - 0.5f * H, s.px, s.py, s.ca, s.cb, s.cc, s.op, G, dx, dy);
+                const float alpha = c->abs_xy.empty()
+                    ? pair_alpha((float)x - 0.5f * W, (float)y - 0.5f * H, s.px, s.py, s.ca, s.cb, s.cc, s.op, G, dx, dy)
+                    : pair_alpha((float)x, (float)y, c->abs_xy[2 * (size_t)c->list[k]], c->abs_xy[2 * (size_t)c->list[k] + 1], s.ca, s.cb, s.cc, s.op, G, dx, dy);
                 if (alpha == 0.f) continue;
                 if (!blend_step_fwd(p, alpha, s.r, s.g, s.b, s.depth)) break;
                 last = contributor;
