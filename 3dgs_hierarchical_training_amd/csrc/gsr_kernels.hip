@@ -1647,11 +1647,12 @@ struct AdamDev {
     float* m[6];
     float* v[6];
     float step_size[6];   // lr / (1 - beta1^t)
-    float b1, b2, eps, inv_bc2s;
+    float b1, b2, eps;
+    float inv_bc2s[6];    // 1 / sqrt(1 - beta2^t), per group (a group may be steps behind the others: GsrFusedAdam::step_lag)
 };
 
 __device__ __forceinline__ void adam_rows(const float* s_g, int stride, int col0, int row, int nact, float* __restrict__ p,
-                                          float* __restrict__ m, float* __restrict__ v, int nG, int tid, float step_size,
+                                          float* __restrict__ m, float* __restrict__ v, int nG, int tid, float step_size, float bc2,
                                           const AdamDev& ad)
 {
     const int total = nG * row;
@@ -1669,17 +1670,17 @@ __device__ __forceinline__ void adam_rows(const float* s_g, int stride, int col0
                 gs[c] = e < nact ? s_g[g * stride + col0 + e] : 0.f;
                 if (++e == row) { e = 0; g++; }
             }
-            adam_one(pp.x, gs[0], mm.x, vv.x, ad.b1, ad.b2, ad.eps, step_size, ad.inv_bc2s);
-            adam_one(pp.y, gs[1], mm.y, vv.y, ad.b1, ad.b2, ad.eps, step_size, ad.inv_bc2s);
-            adam_one(pp.z, gs[2], mm.z, vv.z, ad.b1, ad.b2, ad.eps, step_size, ad.inv_bc2s);
-            adam_one(pp.w, gs[3], mm.w, vv.w, ad.b1, ad.b2, ad.eps, step_size, ad.inv_bc2s);
+            adam_one(pp.x, gs[0], mm.x, vv.x, ad.b1, ad.b2, ad.eps, step_size, bc2);
+            adam_one(pp.y, gs[1], mm.y, vv.y, ad.b1, ad.b2, ad.eps, step_size, bc2);
+            adam_one(pp.z, gs[2], mm.z, vv.z, ad.b1, ad.b2, ad.eps, step_size, bc2);
+            adam_one(pp.w, gs[3], mm.w, vv.w, ad.b1, ad.b2, ad.eps, step_size, bc2);
             nt_store4(p4 + q, pp); nt_store4(m4 + q, mm); nt_store4(v4 + q, vv);
         }
     } else {
         for (int f = tid; f < total; f += kPreThreads) {
             const int g = f / row, e = f - g * row;
             float pp = p[f], mm = m[f], vv = v[f];
-            adam_one(pp, e < nact ? s_g[g * stride + col0 + e] : 0.f, mm, vv, ad.b1, ad.b2, ad.eps, step_size, ad.inv_bc2s);
+            adam_one(pp, e < nact ? s_g[g * stride + col0 + e] : 0.f, mm, vv, ad.b1, ad.b2, ad.eps, step_size, bc2);
             p[f] = pp; m[f] = mm; v[f] = vv;
         }
     }
@@ -1693,7 +1694,7 @@ __device__ __forceinline__ void adam_rows(const float* s_g, int stride, int col0
 //  the registers cost more than it does)
 template <bool KEEP>
 __device__ __forceinline__ void adam_rows_lin(float* s_g, int total, float* __restrict__ p, float* __restrict__ m,
-                                              float* __restrict__ v, int tid, float step_size, const AdamDev& ad)
+                                              float* __restrict__ v, int tid, float step_size, float bc2, const AdamDev& ad)
 {
     float4* p4 = reinterpret_cast<float4*>(p);
     float4* m4 = reinterpret_cast<float4*>(m);
@@ -1704,17 +1705,17 @@ __device__ __forceinline__ void adam_rows_lin(float* s_g, int total, float* __re
         for (int q = tid; q < total / 4; q += kPreThreads) {
             float4 pp = p4[q], mm = nt_load4(m4 + q), vv = nt_load4(v4 + q);
             const float4 g = g4[q];
-            adam_one(pp.x, g.x, mm.x, vv.x, ad.b1, ad.b2, ad.eps, step_size, ad.inv_bc2s);
-            adam_one(pp.y, g.y, mm.y, vv.y, ad.b1, ad.b2, ad.eps, step_size, ad.inv_bc2s);
-            adam_one(pp.z, g.z, mm.z, vv.z, ad.b1, ad.b2, ad.eps, step_size, ad.inv_bc2s);
-            adam_one(pp.w, g.w, mm.w, vv.w, ad.b1, ad.b2, ad.eps, step_size, ad.inv_bc2s);
+            adam_one(pp.x, g.x, mm.x, vv.x, ad.b1, ad.b2, ad.eps, step_size, bc2);
+            adam_one(pp.y, g.y, mm.y, vv.y, ad.b1, ad.b2, ad.eps, step_size, bc2);
+            adam_one(pp.z, g.z, mm.z, vv.z, ad.b1, ad.b2, ad.eps, step_size, bc2);
+            adam_one(pp.w, g.w, mm.w, vv.w, ad.b1, ad.b2, ad.eps, step_size, bc2);
             nt_store4(p4 + q, pp); nt_store4(m4 + q, mm); nt_store4(v4 + q, vv);
             if (KEEP) g4[q] = pp;
         }
     } else {
         for (int f = tid; f < total; f += kPreThreads) {
             float pp = p[f], mm = m[f], vv = v[f];
-            adam_one(pp, s_g[f], mm, vv, ad.b1, ad.b2, ad.eps, step_size, ad.inv_bc2s);
+            adam_one(pp, s_g[f], mm, vv, ad.b1, ad.b2, ad.eps, step_size, bc2);
             p[f] = pp; m[f] = mm; v[f] = vv;
             if (KEEP) s_g[f] = pp;
         }
@@ -1725,16 +1726,16 @@ __device__ __forceinline__ void adam_rows_lin(float* s_g, int total, float* __re
 // straight from its registers: neighbouring lanes touch neighbouring rows, so every fetched line is fully used, and the
 // block keeps no LDS copy of these gradients (25 instead of 30.7 kB per block: one more block per CU).
 template <int K>
-__device__ __forceinline__ void adam_own(float* p, float* m, float* v, const float* g, float step_size, const AdamDev& ad,
+__device__ __forceinline__ void adam_own(float* p, float* m, float* v, const float* g, float step_size, float bc2, const AdamDev& ad,
                                          float* updated = nullptr)
 {
     if (K == 4 && ((((uintptr_t)p | (uintptr_t)m | (uintptr_t)v) & 15) == 0)) {
         float4 pp = *reinterpret_cast<const float4*>(p);
         float4 mm = nt_load4(reinterpret_cast<const float4*>(m)), vv = nt_load4(reinterpret_cast<const float4*>(v));
-        adam_one(pp.x, g[0], mm.x, vv.x, ad.b1, ad.b2, ad.eps, step_size, ad.inv_bc2s);
-        adam_one(pp.y, g[1], mm.y, vv.y, ad.b1, ad.b2, ad.eps, step_size, ad.inv_bc2s);
-        adam_one(pp.z, g[2], mm.z, vv.z, ad.b1, ad.b2, ad.eps, step_size, ad.inv_bc2s);
-        adam_one(pp.w, g[3], mm.w, vv.w, ad.b1, ad.b2, ad.eps, step_size, ad.inv_bc2s);
+        adam_one(pp.x, g[0], mm.x, vv.x, ad.b1, ad.b2, ad.eps, step_size, bc2);
+        adam_one(pp.y, g[1], mm.y, vv.y, ad.b1, ad.b2, ad.eps, step_size, bc2);
+        adam_one(pp.z, g[2], mm.z, vv.z, ad.b1, ad.b2, ad.eps, step_size, bc2);
+        adam_one(pp.w, g[3], mm.w, vv.w, ad.b1, ad.b2, ad.eps, step_size, bc2);
         nt_store4(reinterpret_cast<float4*>(p), pp);
         nt_store4(reinterpret_cast<float4*>(m), mm);
         nt_store4(reinterpret_cast<float4*>(v), vv);
@@ -1745,7 +1746,7 @@ __device__ __forceinline__ void adam_own(float* p, float* m, float* v, const flo
 #pragma unroll
     for (int c = 0; c < K; c++) { pp[c] = p[c]; mm[c] = __builtin_nontemporal_load(m + c); vv[c] = __builtin_nontemporal_load(v + c); }
 #pragma unroll
-    for (int c = 0; c < K; c++) adam_one(pp[c], g[c], mm[c], vv[c], ad.b1, ad.b2, ad.eps, step_size, ad.inv_bc2s);
+    for (int c = 0; c < K; c++) adam_one(pp[c], g[c], mm[c], vv[c], ad.b1, ad.b2, ad.eps, step_size, bc2);
     if (updated) {
 #pragma unroll
         for (int c = 0; c < K; c++) updated[c] = pp[c];
@@ -1938,10 +1939,10 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, in
         }
         if (ADAM) {   // this thread is the only reader of its Gaussian's small rows, and it has read them
             const size_t gi = (size_t)i;
-            adam_own<3>(const_cast<float*>(means) + 3 * gi, ad.m[0] + 3 * gi, ad.v[0] + 3 * gi, dmean, ad.step_size[0], ad, PREP >= 0 ? nmean : nullptr);
-            adam_own<1>(const_cast<float*>(opac_raw) + gi, ad.m[3] + gi, ad.v[3] + gi, &dop, ad.step_size[3], ad, PREP >= 0 ? &nop : nullptr);
-            adam_own<3>(const_cast<float*>(scales) + 3 * gi, ad.m[4] + 3 * gi, ad.v[4] + 3 * gi, dsc, ad.step_size[4], ad, PREP >= 0 ? nsc : nullptr);
-            adam_own<4>(const_cast<float*>(rots) + 4 * gi, ad.m[5] + 4 * gi, ad.v[5] + 4 * gi, drq, ad.step_size[5], ad, PREP >= 0 ? nrq : nullptr);
+            adam_own<3>(const_cast<float*>(means) + 3 * gi, ad.m[0] + 3 * gi, ad.v[0] + 3 * gi, dmean, ad.step_size[0], ad.inv_bc2s[0], ad, PREP >= 0 ? nmean : nullptr);
+            adam_own<1>(const_cast<float*>(opac_raw) + gi, ad.m[3] + gi, ad.v[3] + gi, &dop, ad.step_size[3], ad.inv_bc2s[3], ad, PREP >= 0 ? &nop : nullptr);
+            adam_own<3>(const_cast<float*>(scales) + 3 * gi, ad.m[4] + 3 * gi, ad.v[4] + 3 * gi, dsc, ad.step_size[4], ad.inv_bc2s[4], ad, PREP >= 0 ? nsc : nullptr);
+            adam_own<4>(const_cast<float*>(rots) + 4 * gi, ad.m[5] + 4 * gi, ad.v[5] + 4 * gi, drq, ad.step_size[5], ad.inv_bc2s[5], ad, PREP >= 0 ? nrq : nullptr);
         } else {
 #pragma unroll
         for (int k = 0; k < 3; k++) d_means[3 * (size_t)i + k] = dmean[k];
@@ -1989,9 +1990,9 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, in
         const size_t b = (size_t)base;
         const int rrow = cp.M * 3 - 3;
         if (lin) {
-            adam_rows_lin<(PREP >= 0)>(s_dc, nG * 3, const_cast<float*>(shs) + b * 3, ad.m[1] + b * 3, ad.v[1] + b * 3, tid, ad.step_size[1], ad);
+            adam_rows_lin<(PREP >= 0)>(s_dc, nG * 3, const_cast<float*>(shs) + b * 3, ad.m[1] + b * 3, ad.v[1] + b * 3, tid, ad.step_size[1], ad.inv_bc2s[1], ad);
             if (DEG > 0 || ad.m[2])   // (degree 0, moments known to be zero: the group's update is the identity -- GsrFusedAdam)
-                adam_rows_lin<(PREP >= 0)>(s_rest, nG * NRL, const_cast<float*>(shs_rest) + b * NRL, ad.m[2] + b * NRL, ad.v[2] + b * NRL, tid, ad.step_size[2], ad);
+                adam_rows_lin<(PREP >= 0)>(s_rest, nG * NRL, const_cast<float*>(shs_rest) + b * NRL, ad.m[2] + b * NRL, ad.v[2] + b * NRL, tid, ad.step_size[2], ad.inv_bc2s[2], ad);
             if (PREP < 0) return;
             // ---- next-view tail ("prepare in backward", GsrNextView): this block holds the UPDATED parameters of its 128
             // Gaussians -- the small groups in the owners' registers, the SH rows in the LDS tile -- so it runs the forward
@@ -2058,13 +2059,13 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, in
             }
             return;
         }
-        adam_rows(s_sh, kShStride, 0, 3, 3, const_cast<float*>(shs) + b * 3, ad.m[1] + b * 3, ad.v[1] + b * 3, nG, tid, ad.step_size[1], ad);
+        adam_rows(s_sh, kShStride, 0, 3, 3, const_cast<float*>(shs) + b * 3, ad.m[1] + b * 3, ad.v[1] + b * 3, nG, tid, ad.step_size[1], ad.inv_bc2s[1], ad);
         if (DEG == 0 && !ad.m[2]) {}   // f_rest skipped: see GsrFusedAdam
         else if (rrow == 45 && NC3 == 48)
-            adam_rows(s_sh, kShStride, 3, 45, 45, const_cast<float*>(shs_rest) + b * 45, ad.m[2] + b * 45, ad.v[2] + b * 45, nG, tid, ad.step_size[2], ad);
+            adam_rows(s_sh, kShStride, 3, 45, 45, const_cast<float*>(shs_rest) + b * 45, ad.m[2] + b * 45, ad.v[2] + b * 45, nG, tid, ad.step_size[2], ad.inv_bc2s[2], ad);
         else if (rrow > 0)
             adam_rows(s_sh, kShStride, 3, rrow, NC3 - 3, const_cast<float*>(shs_rest) + b * rrow, ad.m[2] + b * rrow, ad.v[2] + b * rrow, nG, tid,
-                      ad.step_size[2], ad);
+                      ad.step_size[2], ad.inv_bc2s[2], ad);
     } else if (lin && d_shs && d_shs_rest) {
         __syncthreads();
         stage_out_lin<3>(s_dc, d_shs + (size_t)base * 3, nG, tid);
@@ -2964,13 +2965,18 @@ int gsr_backward(const GsrBackwardArgs* a, void* stream_)
         if (skip_rest && (a->D != 0 || (a->next_view && a->next_view->D != 0)))
             return fail(GSR_ERR_ARG, "fused_adam: the f_rest group may be skipped only at sh_degree 0 (this render and the prepared one)%s");
         for (int q = 0; q < 6; q++) {
+            ad.inv_bc2s[q] = 1.f;
             if (q == 2 && skip_rest) { ad.m[q] = nullptr; ad.v[q] = nullptr; ad.step_size[q] = 0.f; continue; }
             if (!fa->exp_avg[q] || !fa->exp_avg_sq[q]) return fail(GSR_ERR_ARG, "fused_adam: missing moment buffer%s");
             ad.m[q] = fa->exp_avg[q]; ad.v[q] = fa->exp_avg_sq[q];
-            ad.step_size[q] = fa->lr[q] / (float)(1.0 - pow((double)fa->beta1, (double)fa->step));
+            // a group may be steps behind the others (the reference drops the opacity group's update on an opacity-reset
+            // iteration): its bias corrections use its own count
+            const int64_t tq = fa->step - (int64_t)fa->step_lag[q];
+            if (fa->step_lag[q] < 0 || tq < 1) return fail(GSR_ERR_ARG, "fused_adam: step_lag out of range%s");
+            ad.step_size[q] = fa->lr[q] / (float)(1.0 - pow((double)fa->beta1, (double)tq));
+            ad.inv_bc2s[q] = 1.f / (float)sqrt(1.0 - pow((double)fa->beta2, (double)tq));
         }
         ad.b1 = fa->beta1; ad.b2 = fa->beta2; ad.eps = fa->eps;
-        ad.inv_bc2s = 1.f / (float)sqrt(1.0 - pow((double)fa->beta2, (double)fa->step));
     } else if (!a->d_means3D || !a->d_opacities)
         return fail(GSR_ERR_ARG, "missing workspace / gradient pointer%s");
     DensDev ds = {};

@@ -258,7 +258,8 @@ std::vector<Tensor> rasterize_backward_fused(
     const c10::hip::HIPGuardMasqueradingAsCUDA guard(means3D.device());
     const BatchArg batch(batch_first_block);
     const int64_t NB = batch.B();
-    TORCH_CHECK(adam_m.size() == 6 && adam_v.size() == 6 && adam_lr.size() == 6, "fused_adam: six groups expected");
+    // adam_lr: six learning rates, optionally followed by six step lags (GsrFusedAdam::step_lag; whole numbers)
+    TORCH_CHECK(adam_m.size() == 6 && adam_v.size() == 6 && (adam_lr.size() == 6 || adam_lr.size() == 12), "fused_adam: six groups expected");
     Tensor none;
     BwdCommon b{means3D, sh, none, opac, scales, rots, none, rest, vm, pm, campos, bg, xf, f32c(grad_color), f32c(grad_depth), f32c(grad_alpha)};
     const int64_t N = means3D.size(0);
@@ -274,6 +275,7 @@ std::vector<Tensor> rasterize_backward_fused(
     for (int q = 0; q < 6; q++) {
         TORCH_CHECK(adam_m[q].is_contiguous() && adam_v[q].is_contiguous() && adam_m[q].scalar_type() == at::kFloat, "fused_adam: moments must be contiguous float32");
         fa.lr[q] = (float)adam_lr[q];
+        fa.step_lag[q] = adam_lr.size() == 12 ? (int32_t)adam_lr[6 + q] : 0;
         fa.exp_avg[q] = adam_m[q].numel() ? adam_m[q].data_ptr<float>() : nullptr;     // (empty = the group is skipped: GsrFusedAdam)
         fa.exp_avg_sq[q] = adam_v[q].numel() ? adam_v[q].data_ptr<float>() : nullptr;
     }

@@ -12,11 +12,15 @@ Mirrors, without importing the reference, what HTGaussianModel does with the ras
 These are a few torch ops on N-sized tensors once per 100 iterations -- not a kernel.  The optimizer-state surgery is
 GaussianParams' (train_step.py), which works on torch.optim.Adam and FusedAdam alike.
 
-Ordering note for the optimizer-in-backward mode: the reference collects the statistics and densifies BETWEEN
-backward() and optimizer.step() (ht3dgs_trainer.py:135-160).  With the Adam step fused into the backward kernel the
-parameters have already moved by that step when `after_backward` runs; the statistics (means2D.grad, radii) are
-unaffected, the clone / split sources are one Adam step younger.  The drop-in path (torch.optim.Adam) keeps the
-reference's order exactly.
+Ordering on the iterations that touch the parameters (round 4).  The reference collects the statistics and
+densifies BETWEEN backward() and optimizer.step() (ht3dgs_trainer.py:135-160), and its surgery replaces parameter tensors by
+fresh `nn.Parameter`s whose .grad is None -- `densify_and_prune` every one of them (`densification_postfix` runs even when nothing
+is selected, gaussian_model_ht.py:584-629), `reset_opacity` the opacity tensor (:468-474) -- so the `optimizer.step()` that
+follows finds nothing to step for them: THAT ITERATION'S ADAM UPDATE IS DROPPED (all six groups on a densification iteration,
+the opacity group on a reset iteration; their step counts do not advance).  An Adam step fused into the backward kernel would
+already have been applied by then.  `touches_parameters_at(iteration)` therefore tells `train_step` -- the schedule is known
+before the render -- to run such an iteration UNFUSED: gradients to .grad, statistics, surgery, then a real `optimizer.step()`
+on whatever still carries a gradient, exactly the reference's sequence.  One iteration in a hundred.
 """
 from dataclasses import dataclass
 from typing import Optional
@@ -81,6 +85,18 @@ class Densifier:
         if iteration >= self.cfg.densify_until_iter:
             return None
         return (self.xyz_gradient_accum, self.denom, self.max_radii2D)
+
+    def touches_parameters_at(self, iteration: int) -> bool:
+        """True when `after_backward(iteration, ...)` will replace parameter tensors (densify / prune, opacity reset): the schedule of
+        ht3dgs_trainer.py:148-155, known before the render.  train_step keeps the optimizer out of the backward on such iterations
+        (module docstring)."""
+        c = self.cfg
+        if iteration >= c.densify_until_iter:
+            return False
+        if iteration > c.densify_from_iter and iteration % c.densification_interval == 0:
+            return True
+        reset_until = c.reset_until_iter if c.reset_until_iter is not None else c.densify_until_iter
+        return iteration % c.opacity_reset_interval == 0 and iteration < reset_until
 
     def _keep_stats(self, keep: torch.Tensor):
         self.xyz_gradient_accum = self.xyz_gradient_accum[keep]
@@ -155,6 +171,9 @@ class Densifier:
         if iteration > c.densify_from_iter and iteration % c.densification_interval == 0:
             size_threshold = 20 if iteration > c.opacity_reset_interval else None
             self.densify_and_prune(c.densify_grad_threshold, c.min_opacity, size_threshold)
+            # the reference's surgery leaves EVERY parameter a fresh nn.Parameter without .grad, selected or not (module docstring):
+            # the optimizer.step() that follows must find nothing to apply
+            self.params.optimizer.zero_grad(set_to_none=True)
             resized = True
         reset_until = c.reset_until_iter if c.reset_until_iter is not None else c.densify_until_iter
         if iteration % c.opacity_reset_interval == 0 and iteration < reset_until:

@@ -182,8 +182,18 @@ class FusedAdam:
             c = self._skip_lists = (ms, vs, ms[:2] + [e] + ms[3:], vs[:2] + [e] + vs[3:])
         return c[2], c[3]
 
+    @staticmethod
+    def _step_lags(steps):
+        """(base, lags): the six groups' step counts as the largest one and how far each group is behind it (GsrFusedAdam::step_lag).
+        The groups leave lockstep the way they do in the reference: an opacity reset replaces the opacity tensor between backward()
+        and optimizer.step(), which then skips it (gaussian_model_ht.py:468-474, ht3dgs_trainer.py:153-160).  The lags ride behind
+        the six learning rates (whole numbers); none when all are zero."""
+        base = max(steps)
+        lags = [float(base - t) for t in steps]
+        return int(base), (lags if any(lags) else [])
+
     def fused_step_plan(self, tensors: Dict[str, torch.Tensor], sh_degree=None, next_sh_degree=None):
-        """(exp_avg[6], exp_avg_sq[6], lr[6], beta1, beta2, eps, step_base, commit) for the optimizer-in-backward mode of
+        """(exp_avg[6], exp_avg_sq[6], lr[6] (+ step lags[6]), beta1, beta2, eps, step_base, commit) for the optimizer-in-backward mode of
         gsr_backward.  Mutates nothing: `step_base` is the six groups' current step count and `commit` the CPU counter that the
         backward increments when it has applied the update; the 1-based step of that update is step_base + (commits since this
         plan) + 1.  `tensors` are the parameter tensors being rasterized, by group name; they must be the optimizer's own.
@@ -198,18 +208,19 @@ class FusedAdam:
             for k in range(6 if ok else 0):
                 g, st = groups[k], sts[k]
                 if self.param_groups[idx[k]] is not g or g["params"][0] is not ps[k] or tensors[self.FUSED_ORDER[k]] is not ts_[k] or self.state.get(ps[k]) is not st \
-                        or st.get("exp_avg") is not ms[k] or st.get("exp_avg_sq") is not vs[k] or st.get("step") != sts[0].get("step"):
+                        or st.get("exp_avg") is not ms[k] or st.get("exp_avg_sq") is not vs[k]:
                     ok = False
                     break
             if ok:
                 pm, pv = self._plan_moments(ms, vs, sh_degree, next_sh_degree)
-                return (pm, pv, [float(g["lr"]) for g in groups], float(self.betas[0]), float(self.betas[1]), float(self.eps),
-                        _step_int(sts[0]["step"]), self._commit)
+                base, lags = self._step_lags([_step_int(st["step"]) for st in sts])
+                return (pm, pv, [float(g["lr"]) for g in groups] + lags, float(self.betas[0]), float(self.betas[1]), float(self.eps),
+                        base, self._commit)
             self._plan_cache = None
         by_name = {g.get("name"): g for g in self.param_groups}
         if set(by_name) != set(self.FUSED_ORDER):
             raise RuntimeError(f"fused_adam: optimizer groups must be named {self.FUSED_ORDER}, got {tuple(by_name)}")
-        states, steps, lrs = [], set(), []
+        states, steps, lrs = [], [], []
         for name in self.FUSED_ORDER:
             g = by_name[name]
             p = g["params"][0]
@@ -218,20 +229,18 @@ class FusedAdam:
                 raise RuntimeError(f"fused_adam: group '{name}' is not the contiguous float32 tensor that was rasterized")
             st = self._state(p)
             states.append(st)
-            steps.add(_step_int(st["step"]))
+            steps.append(_step_int(st["step"]))
             lrs.append(float(g["lr"]))
-        if len(steps) != 1:
-            raise RuntimeError(f"fused_adam: the six groups are at different step counts {sorted(steps)}; use step()")
-        step = steps.pop()
-        for st in states:
-            st["step"] = int(step)
+        for st, t in zip(states, steps):
+            st["step"] = int(t)
+        step, lags = self._step_lags(steps)
         ms, vs = [st["exp_avg"] for st in states], [st["exp_avg_sq"] for st in states]
         groups = [by_name[name] for name in self.FUSED_ORDER]
         self._plan_cache = (groups, [g["params"][0] for g in groups], [tensors[name] for name in self.FUSED_ORDER], states, ms, vs,
                             [next(i for i, x in enumerate(self.param_groups) if x is g) for g in groups])
         self._plan_groups = len(self.param_groups)
         pm, pv = self._plan_moments(ms, vs, sh_degree, next_sh_degree)
-        return (pm, pv, lrs, float(self.betas[0]), float(self.betas[1]), float(self.eps), int(step), self._commit)
+        return (pm, pv, lrs + lags, float(self.betas[0]), float(self.betas[1]), float(self.eps), int(step), self._commit)
 
     def fused_backward_args(self, tensors: Dict[str, torch.Tensor], sh_degree=None, next_sh_degree=None) -> "L.GsrFusedAdam":
         """The plan as a GsrFusedAdam struct for the update that is applied NOW (ctypes binding: called from its backward, which
@@ -241,6 +250,7 @@ class FusedAdam:
         fa.beta1, fa.beta2, fa.eps, fa.step = b1, b2, eps, step + 1
         for k in range(6):
             fa.lr[k] = lrs[k]
+            fa.step_lag[k] = int(lrs[6 + k]) if len(lrs) == 12 else 0
             fa.exp_avg[k] = m[k].data_ptr() if m[k].numel() else None       # (no buffers: the group is skipped)
             fa.exp_avg_sq[k] = v[k].data_ptr() if v[k].numel() else None
         return fa

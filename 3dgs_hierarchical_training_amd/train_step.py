@@ -418,8 +418,14 @@ def train_step(params: GaussianParams, settings: GaussianRasterizationSettings, 
     degree of the next step when the caller is about to raise it (`oneup_sh_degree()` right after this step: the reference does so
     when global_iteration % 1000 == 0) -- the hand-over then already carries the colours of the higher degree.
     densifier (densify.Densifier) + iteration: the adaptive density control of ht3dgs_trainer.py:137-155 runs between
-    backward() and optimizer.step(), as in the reference (see densify.py for the ordering note of the fused mode)."""
+    backward() and optimizer.step(), as in the reference; on the iterations where it replaces parameter tensors the step is not
+    fused into the backward, so that the update the reference drops there is dropped here too (densify.py)."""
     fused_adam = params.optimizer if (fused_optimizer and fused_activations and isinstance(params.optimizer, FusedAdam)) else None
+    # an iteration whose `after_backward` replaces parameter tensors (densify / prune, opacity reset) runs UNFUSED: the reference's
+    # surgery sits between backward() and optimizer.step() and drops that iteration's update of the tensors it replaces
+    # (ht3dgs_trainer.py:137-160; densify.py) -- an update applied inside the backward kernel could not be dropped any more
+    if fused_adam is not None and densifier is not None and densifier.touches_parameters_at(iteration):
+        fused_adam = None
     # pose refinement (the reference's camera_optimizer, ht3dgs_trainer.py:162-166): this frame's transform is an autograd leaf of
     # the render; the hand-over to the next render is skipped when that render is of THIS frame (its transform changes in between)
     cam_pose = isinstance(pose, CameraPoseState)

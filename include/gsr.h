@@ -139,6 +139,10 @@ typedef struct GsrFusedAdam {
     float lr[6];
     float* exp_avg[6];
     float* exp_avg_sq[6];
+    int32_t step_lag[6];    /* round 4: group q is at step `step - step_lag[q]` (its bias corrections use that count); all zero =
+                             * the six groups in lockstep.  The reference drops a group's update when its tensor is replaced
+                             * between backward() and optimizer.step() (opacity reset: gaussian_model_ht.py:468-474,
+                             * ht3dgs_trainer.py:153-160), after which that group's count stays behind the others'. */
 } GsrFusedAdam;
 
 /* "Prepare in backward" (extension f-2, with fused_adam only).  Training renders the same parameters again right after
