@@ -75,11 +75,13 @@ def _register_fakes():
         has = lambda t: t.numel() > 0
         M = (sh.shape[1] + (sh_rest.shape[1] if has(sh_rest) else 0)) if has(sh) else 0
         none = f(0)
+        B = len(batch_first_block) - 1 if len(batch_first_block) >= 3 else 1
+        lead = (B,) if B > 1 else ()           # a batch of B models: one camera gradient per model (as the real op returns them)
         return [f(N, 3), f(N, 3), f(N, 1 if has(sh_rest) else M, 3) if has(sh) else none, f(N, 3) if has(colors_precomp) else none,
                 f(N, 1), f(N, 3) if has(scales) else none, f(N, 4) if has(scales) else none, f(N, 6) if has(cov3D_precomp) else none,
-                f(N, M - 1, 3) if (has(sh) and has(sh_rest)) else none, f(4, 4) if need_viewmatrix else none,
-                f(4, 4) if need_projmatrix else none, f(3) if need_campos else none,
-                f(3, 4) if (need_points_transform and has(points_transform)) else none]
+                f(N, M - 1, 3) if (has(sh) and has(sh_rest)) else none, f(*lead, 4, 4) if need_viewmatrix else none,
+                f(*lead, 4, 4) if need_projmatrix else none, f(*lead, 3) if need_campos else none,
+                f(*lead, 3, 4) if (need_points_transform and has(points_transform)) else none]
 
     @torch.library.register_fake("gsr::rasterize_backward_fused")
     def _(means3D, sh, sh_rest, opacities, scales, rotations, viewmatrix, projmatrix, campos, bg, points_transform, geom, image, binning,
@@ -89,8 +91,10 @@ def _register_fakes():
           next_points_transform, next_sh_degree, densify_stats, radii, batch_first_block):
         f = lambda *s: means3D.new_empty(s, dtype=torch.float32)
         none = f(0)
-        return [f(means3D.shape[0], 3), f(4, 4) if need_viewmatrix else none, f(4, 4) if need_projmatrix else none,
-                f(3) if need_campos else none, f(3, 4) if (need_points_transform and points_transform.numel() > 0) else none]
+        B = len(batch_first_block) - 1 if len(batch_first_block) >= 3 else 1
+        lead = (B,) if B > 1 else ()
+        return [f(means3D.shape[0], 3), f(*lead, 4, 4) if need_viewmatrix else none, f(*lead, 4, 4) if need_projmatrix else none,
+                f(*lead, 3) if need_campos else none, f(*lead, 3, 4) if (need_points_transform and points_transform.numel() > 0) else none]
 
     # in-place ops without a return value: nothing to describe beyond the schema's (a!) annotations
     @torch.library.register_fake("gsr::adam_step")

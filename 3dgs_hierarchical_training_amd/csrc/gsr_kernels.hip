@@ -624,6 +624,7 @@ __device__ __forceinline__ void block_scan_body(uint32_t* block_sums, int nb, un
     if (tid == 0) {
         *total_out = all;
         if (host_out) {   // the count, then the call's sequence number: the host polls the second word (gsr_forward)
+            __atomic_store_n(host_out + 2, (unsigned long long)g_onesweep_giveups, __ATOMIC_RELAXED);   // (sorts that gave up so far: see radix_sort.h)
             __atomic_store_n(host_out, all, __ATOMIC_RELAXED);
             __threadfence_system();
             __atomic_store_n(host_out + 1, host_seq, __ATOMIC_RELAXED);
@@ -2782,6 +2783,19 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
         g_exact_forwards++;
     }
     R = *static_cast<volatile unsigned long long*>(pin.s->host);
+    {   // a look-back of one of the radix sorts gave up (since the last call that looked): whatever was sorted is garbage
+        static std::map<int, unsigned long long> seen_giveups;   // per device; guarded by g_state_mutex
+        const unsigned long long gv = static_cast<volatile unsigned long long*>(pin.s->host)[2];
+        bool fresh;
+        {
+            std::lock_guard<std::mutex> lk(g_state_mutex);
+            unsigned long long& seen = seen_giveups[dev_id];
+            fresh = gv != seen;
+            seen = gv;
+        }
+        if (fresh)
+            return fail(GSR_ERR_HIP, "a radix-sort look-back gave up (status words overwritten?): the binning of this or the previous forward is invalid%s");
+    }
     if (R > 0xfffffff0ull) return fail(GSR_ERR_RANGE, "more than 2^32 instances%s");
     if (!speculative || R > cap) {   // exact flow, or the capacity was too small (the truncated result is overwritten)
         if (speculative) g_spec_overflows++;

@@ -262,6 +262,9 @@ inline uint32_t onesweep_resident_blocks(KernelT kernel, int threads)
     cache[key] = v;
     return v;
 }
+// Look-backs that gave up (a predecessor never published: the status words were overwritten by a caller's bug).  The sort's result is
+// then garbage; the counter lets the host say so: gsr_forward reads it back with the instance count and fails the call.
+__device__ unsigned int g_onesweep_giveups = 0u;
 constexpr int kOsRanges = 32;
 constexpr uint32_t kOsLocal = 1u << 30, kOsIncl = 2u << 30, kOsMask = (1u << 30) - 1u;
 constexpr uint32_t kOsTicketWords = (4 * kOsRanges + 63) / 64 * 64;   // tickets[pass][run], padded
@@ -457,9 +460,9 @@ __global__ __launch_bounds__(OsCfg<KeyT>::kThreads) void k_onesweep(const KeyT* 
             if (t >= t_lo && done) {
                 __builtin_amdgcn_s_sleep(1);
                 // a predecessor that never publishes (status words overwritten by a caller's bug) must not hang the device: after
-                // ~10^7 polls -- seconds, where a healthy chain takes microseconds -- the walk gives up and the sort's result is
-                // garbage instead
-                if (++polls > (1u << 23)) break;
+                // ~10^7 polls -- seconds, where a healthy chain takes microseconds -- the walk gives up, the sort's result is
+                // garbage, and g_onesweep_giveups says so (gsr_forward returns GSR_ERR_HIP)
+                if (++polls > (1u << 23)) { atomicAdd(&g_onesweep_giveups, 1u); break; }
             }
         }
         __hip_atomic_store(my_status, kOsIncl | (excl + real), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

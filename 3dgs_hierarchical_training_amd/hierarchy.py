@@ -65,7 +65,7 @@ def prune_mask(importance: torch.Tensor, prune_ratio: float) -> torch.Tensor:
 
 
 def merge_send(tr, dst: int, seg: Dict[str, torch.Tensor], views, prune_ratio: float, frames=None, poses=None,
-               start_fidx: int = 0, global_iteration: int = 0, importance_fn=calc_importance, drop=None) -> Dict:
+               start_fidx: int = 0, global_iteration: int = 0, importance_fn=calc_importance, drop=None, sh_degree: int = -1) -> Dict:
     """Source side of one pair: own importance -> drop mask; ship the UN-PRUNED child + mask + frames / poses.
     `drop`: a mask computed beforehand (then `views` is not used)."""
     t0 = time.perf_counter()
@@ -73,7 +73,7 @@ def merge_send(tr, dst: int, seg: Dict[str, torch.Tensor], views, prune_ratio: f
         drop = prune_mask(importance_fn(seg, views), prune_ratio)
     imp_ms = _elapsed_ms(t0, seg["_xyz"])
     st = segments.send_child(tr, dst, seg, drop=drop, frames=frames, poses=poses, start_fidx=start_fidx,
-                             global_iteration=global_iteration)
+                             global_iteration=global_iteration, sh_degree=sh_degree)
     return {"role": "src", "peer": dst, "importance_ms": imp_ms, "send_ms": st["ms"], "bytes": st["bytes"],
             "n": int(seg["_xyz"].shape[0]), "n_dropped": int(drop.sum())}
 

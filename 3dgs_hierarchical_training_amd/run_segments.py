@@ -252,7 +252,8 @@ class RankRunner:
         seg, self.tr.rank = self.seg, self.rank
         st = hierarchy.merge_send(self.tr, self.role(k)[1], seg.params.raw(), self._importance_views(seg), self.cfg.prune_ratio,
                                   frames=seg.frames, poses=seg.pose_tensor(), start_fidx=seg.start_fidx,
-                                  global_iteration=seg.global_iteration, importance_fn=self.importance_fn)
+                                  global_iteration=seg.global_iteration, importance_fn=self.importance_fn,
+                                  sh_degree=seg.params.active_sh_degree)
         self.seg = None          # this GPU is free from here on
         self._emit({"phase": "merge", "level": k, **st})
 
@@ -264,12 +265,14 @@ class RankRunner:
         out = hierarchy.merge_recv(self.tr, self.role(k)[1], seg.params.raw(), self._importance_views(seg),
                                    self.cfg.prune_ratio, src_to_dst, importance_fn=self.importance_fn)
         child = out["child"]
-        # (teachers render at the active degree their model was trained at; the leaves of a level advance in lockstep -- same
-        #  iteration counts -- so the child's degree is the destination's)
+        # teachers render at the active degree their model was trained at: the destination's own, and the child's as its message
+        # states it (uneven frame splits or iteration counts can leave the two on different sides of an oneupSHdegree boundary)
         tdeg = seg.params.active_sh_degree
+        cdeg = child.get("sh_degree", -1)
+        cdeg = tdeg if cdeg is None or cdeg < 0 else min(int(cdeg), seg.params.max_sh_degree)
         own_teacher = {"seg": {kk: v.clone() for kk, v in out["teachers"][0].items()}, "start_fidx": seg.start_fidx,
                        "frames": list(seg.frames), "sh_degree": tdeg}
-        child_teacher = {"seg": out["teachers"][1], "start_fidx": child["start_fidx"], "frames": list(child["frames"]), "sh_degree": tdeg}
+        child_teacher = {"seg": out["teachers"][1], "start_fidx": child["start_fidx"], "frames": list(child["frames"]), "sh_degree": cdeg}
         self.teachers = [own_teacher, child_teacher]
         for f in child["frames"]:                                                    # :783-790
             if f not in seg.poses:
@@ -279,7 +282,8 @@ class RankRunner:
         params = ts.GaussianParams.from_raw(out["merged"], self.dev, sh_degree=seg.params.active_sh_degree, optimizer=self.cfg.optimizer)
         self.seg = Segment(params, frames, seg.start_fidx, seg.poses, global_iteration=0)   # :792-793
         self._new_densifier(self.seg)
-        self._emit({"phase": "merge", "level": k, **{kk: v for kk, v in out.items() if kk not in ("merged", "teachers", "child")}})
+        self._emit({"phase": "merge", "level": k, "sh_degree_dst": tdeg, "sh_degree_child": cdeg, "sh_degree_merged": tdeg,
+                    **{kk: v for kk, v in out.items() if kk not in ("merged", "teachers", "child")}})
 
     # ---- non-leaf training (:757-764, :815-900) ------------------------------------------------------------------------
     def train_nonleaf(self, k: int):
@@ -340,6 +344,10 @@ class RankRunner:
         return good
 
     def run(self, barrier=None, all_ok=None):
+        # a rank whose link self-test failed must not leave alone while its peers walk on to a merge that then never completes: with
+        # more than one rank the verdicts have to be combined
+        if all_ok is None and self.world > 1 and not isinstance(self.tr, segments.LocalTransport):
+            raise RuntimeError("RankRunner.run: with world > 1 pass all_ok (a MIN all-reduce of the ranks' link self-test verdicts)")
         if not self.link_selftest(all_ok):
             raise SystemExit(3)
         self.train_leaf()
@@ -390,6 +398,9 @@ def run_stage_a_on(seq, cfg, dev, spec, rank: int, world: int, group=None, log=N
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", "1" if world == 1 else str(world)))
     conc = max(1, min(cfg.stage_a_concurrency, host_mod.usable_cpus()[0] // (2 * max(1, local_world))))
     batch = cfg.stage_a_batch if cfg.stage_a_batch > 0 else (4 if conc > 1 else 8)
+    # the kernels' limits on a batch (include/gsr.h GsrBatch): 16 models per launch chain, B * tile rows <= 4095
+    tiles_y = (cfg.height + 15) // 16
+    batch = max(1, min(batch, 16, 4095 // max(1, tiles_y)))
     table = stage_a.run_stage_a(cfg.frames, lambda p: stage_a.fit_pair(seq, p, dev, n_points=n_points, single_image_iters=image_iters,
                                                                         pose_iters=pose_iters, seed=cfg.seed),
                                 gather_device or dev, rank=rank, world=world, group=group, concurrency=conc, fit_device=dev,

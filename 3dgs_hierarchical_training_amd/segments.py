@@ -160,14 +160,16 @@ def unpack_segment(flat: torch.Tensor) -> Dict[str, torch.Tensor]:
 
 def send_child(tr, dst: int, seg: Dict[str, torch.Tensor], drop: Optional[torch.Tensor] = None,
                frames: Optional[List[int]] = None, poses: Optional[torch.Tensor] = None, start_fidx: int = 0,
-               global_iteration: int = 0) -> Dict:
-    """Header (sizes, variable N), then the un-pruned 59-float rows, then mask / frames / poses.  Returns
-    {'bytes', 'ms'} (ms includes the wait for the receiver)."""
+               global_iteration: int = 0, sh_degree: int = -1) -> Dict:
+    """Header (sizes, variable N, the child's ACTIVE SH degree), then the un-pruned 59-float rows, then mask / frames / poses.
+    Returns {'bytes', 'ms'} (ms includes the wait for the receiver).  sh_degree: the degree the child was trained at -- the receiver
+    renders it as a teacher at THAT degree (uneven frame splits or iteration counts can leave the two sides of a merge on
+    different sides of an `oneupSHdegree` boundary; -1 = not stated)."""
     dev = seg["_xyz"].device
     n = seg["_xyz"].shape[0]
     frames = list(frames or [])
     t0 = time.perf_counter()
-    hdr = torch.tensor([n, len(frames), int(start_fidx), int(global_iteration), 0 if drop is None else 1],
+    hdr = torch.tensor([n, len(frames), int(start_fidx), int(global_iteration), 0 if drop is None else 1, int(sh_degree)],
                        dtype=torch.int64, device=dev)
     tr.send(hdr, dst)
     nbytes = hdr.numel() * 8
@@ -188,12 +190,12 @@ def send_child(tr, dst: int, seg: Dict[str, torch.Tensor], drop: Optional[torch.
 
 
 def recv_child(tr, src: int, device) -> Dict:
-    """Counterpart of send_child: {'seg', 'drop', 'frames', 'poses', 'start_fidx', 'global_iteration', 'bytes', 'ms'}."""
+    """Counterpart of send_child: {'seg', 'drop', 'frames', 'poses', 'start_fidx', 'global_iteration', 'sh_degree', 'bytes', 'ms'}."""
     t0 = time.perf_counter()
-    hdr = torch.zeros(5, dtype=torch.int64, device=device)
+    hdr = torch.zeros(6, dtype=torch.int64, device=device)
     tr.recv(hdr, src)
-    n, nf, start_fidx, giter, has_mask = (int(v) for v in hdr.tolist())
-    nbytes = 40
+    n, nf, start_fidx, giter, has_mask, sh_degree = (int(v) for v in hdr.tolist())
+    nbytes = 48
     flat = torch.empty((n, FLOATS_PER_GAUSSIAN), dtype=torch.float32, device=device)
     tr.recv(flat, src)
     nbytes += flat.numel() * 4
@@ -214,7 +216,7 @@ def recv_child(tr, src: int, device) -> Dict:
         nbytes += nf * (8 + 64)
     _sync(flat)
     return {"seg": unpack_segment(flat), "drop": drop, "frames": frames, "poses": poses, "start_fidx": start_fidx,
-            "global_iteration": giter, "bytes": nbytes, "ms": 1e3 * (time.perf_counter() - t0)}
+            "global_iteration": giter, "sh_degree": sh_degree, "bytes": nbytes, "ms": 1e3 * (time.perf_counter() - t0)}
 
 
 # ---- round-1 names (kept: the world_size-2 exchange test and external callers use them) ---------------------------------

@@ -147,7 +147,11 @@ def _tree_worker(rank, world, port, q):
 
     rr = rs.RankRunner(rank, world, seg_mod.DistTransport(), seq, cfg, torch.device("cpu"), log=log.append,
                        importance_fn=_fake_importance, step_fn=step_fn, teacher_render_fn=teacher_render)
-    final = rr.run(barrier=dist.barrier)
+    def all_ok(mine):                     # the combiner run_segments.py passes: one MIN all-reduce of the ranks' self-test verdicts
+        flag = torch.tensor([1.0 if mine else 0.0])
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(flag.item() >= 1.0)
+    final = rr.run(barrier=dist.barrier, all_ok=all_ok)
     dist.barrier()
     dist.destroy_process_group()
     q.put((rank, None if final is None else (final.params.num_points, final.frames, final.start_fidx, sorted(final.poses)),
