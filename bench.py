@@ -780,7 +780,7 @@ def main():
         pass
     pmc, pmc_src = {}, None
     if (N, W, H, deg, args.clustered) == (1_000_000, 980, 545, 3, False):
-        for name in ("r03_pmc_blend.json", "r02_pmc_blend.json", "r01_pmc_blend.json"):
+        for name in ("r04_pmc_blend.json", "r03_pmc_blend.json", "r02_pmc_blend.json", "r01_pmc_blend.json"):
             pmc_file = os.path.join(REPO, "profiles", name)
             if not os.path.exists(pmc_file):
                 continue
