@@ -57,7 +57,8 @@ class GsrBackwardArgs(C.Structure):
 class GsrFusedAdam(C.Structure):
     _fields_ = [("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("reserved", C.c_int32),
                 ("step", C.c_int64), ("lr", C.c_float * 6), ("exp_avg", C.c_void_p * 6), ("exp_avg_sq", C.c_void_p * 6),
-                ("step_lag", C.c_int32 * 6)]
+                ("step_lag", C.c_int32 * 6), ("param_out", C.c_void_p * 6), ("exp_avg_out", C.c_void_p * 6),
+                ("exp_avg_sq_out", C.c_void_p * 6)]
 
 
 class GsrAdamTensor(C.Structure):

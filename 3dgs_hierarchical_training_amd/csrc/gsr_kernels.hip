@@ -1650,17 +1650,24 @@ struct AdamDev {
     float step_size[6];   // lr / (1 - beta1^t)
     float b1, b2, eps;
     float inv_bc2s[6];    // 1 / sqrt(1 - beta2^t), per group (a group may be steps behind the others: GsrFusedAdam::step_lag)
+    long long dp[6], dm[6], dv[6];   // byte offsets from a group's parameter / moment rows to where the UPDATED rows go (0: in place; GsrFusedAdam::param_out ...)
 };
+template <typename T>
+__device__ __forceinline__ T* adam_out(T* p, long long d) { return reinterpret_cast<T*>(reinterpret_cast<char*>(p) + d); }
 
 __device__ __forceinline__ void adam_rows(const float* s_g, int stride, int col0, int row, int nact, float* __restrict__ p,
                                           float* __restrict__ m, float* __restrict__ v, int nG, int tid, float step_size, float bc2,
-                                          const AdamDev& ad)
+                                          int grp, const AdamDev& ad)
 {
     const int total = nG * row;
-    if (((((uintptr_t)p | (uintptr_t)m | (uintptr_t)v) & 15) == 0) && (total & 3) == 0) {
+    float* const po = adam_out(p, ad.dp[grp]); float* const mo = adam_out(m, ad.dm[grp]); float* const vo = adam_out(v, ad.dv[grp]);
+    if (((((uintptr_t)p | (uintptr_t)m | (uintptr_t)v | (uintptr_t)po | (uintptr_t)mo | (uintptr_t)vo) & 15) == 0) && (total & 3) == 0) {
         float4* p4 = reinterpret_cast<float4*>(p);
         float4* m4 = reinterpret_cast<float4*>(m);
         float4* v4 = reinterpret_cast<float4*>(v);
+        float4* po4 = reinterpret_cast<float4*>(po);
+        float4* mo4 = reinterpret_cast<float4*>(mo);
+        float4* vo4 = reinterpret_cast<float4*>(vo);
         for (int q = tid; q < total / 4; q += kPreThreads) {
             float4 pp = p4[q], mm = nt_load4(m4 + q), vv = nt_load4(v4 + q);   // moments are touched once per step: keep them out of L2
             const int f = 4 * q;
@@ -1675,14 +1682,14 @@ __device__ __forceinline__ void adam_rows(const float* s_g, int stride, int col0
             adam_one(pp.y, gs[1], mm.y, vv.y, ad.b1, ad.b2, ad.eps, step_size, bc2);
             adam_one(pp.z, gs[2], mm.z, vv.z, ad.b1, ad.b2, ad.eps, step_size, bc2);
             adam_one(pp.w, gs[3], mm.w, vv.w, ad.b1, ad.b2, ad.eps, step_size, bc2);
-            nt_store4(p4 + q, pp); nt_store4(m4 + q, mm); nt_store4(v4 + q, vv);
+            nt_store4(po4 + q, pp); nt_store4(mo4 + q, mm); nt_store4(vo4 + q, vv);
         }
     } else {
         for (int f = tid; f < total; f += kPreThreads) {
             const int g = f / row, e = f - g * row;
             float pp = p[f], mm = m[f], vv = v[f];
             adam_one(pp, e < nact ? s_g[g * stride + col0 + e] : 0.f, mm, vv, ad.b1, ad.b2, ad.eps, step_size, bc2);
-            p[f] = pp; m[f] = mm; v[f] = vv;
+            po[f] = pp; mo[f] = mm; vo[f] = vv;
         }
     }
 }
@@ -1695,13 +1702,17 @@ __device__ __forceinline__ void adam_rows(const float* s_g, int stride, int col0
 //  the registers cost more than it does)
 template <bool KEEP>
 __device__ __forceinline__ void adam_rows_lin(float* s_g, int total, float* __restrict__ p, float* __restrict__ m,
-                                              float* __restrict__ v, int tid, float step_size, float bc2, const AdamDev& ad)
+                                              float* __restrict__ v, int tid, float step_size, float bc2, int grp, const AdamDev& ad)
 {
     float4* p4 = reinterpret_cast<float4*>(p);
     float4* m4 = reinterpret_cast<float4*>(m);
     float4* v4 = reinterpret_cast<float4*>(v);
     float4* g4 = reinterpret_cast<float4*>(s_g);
-    if ((((uintptr_t)m | (uintptr_t)v) & 15) == 0) {
+    float* const po = adam_out(p, ad.dp[grp]); float* const mo = adam_out(m, ad.dm[grp]); float* const vo = adam_out(v, ad.dv[grp]);
+    float4* po4 = reinterpret_cast<float4*>(po);
+    float4* mo4 = reinterpret_cast<float4*>(mo);
+    float4* vo4 = reinterpret_cast<float4*>(vo);
+    if ((((uintptr_t)m | (uintptr_t)v | (uintptr_t)po | (uintptr_t)mo | (uintptr_t)vo) & 15) == 0) {
 #pragma unroll 2
         for (int q = tid; q < total / 4; q += kPreThreads) {
             float4 pp = p4[q], mm = nt_load4(m4 + q), vv = nt_load4(v4 + q);
@@ -1710,14 +1721,14 @@ __device__ __forceinline__ void adam_rows_lin(float* s_g, int total, float* __re
             adam_one(pp.y, g.y, mm.y, vv.y, ad.b1, ad.b2, ad.eps, step_size, bc2);
             adam_one(pp.z, g.z, mm.z, vv.z, ad.b1, ad.b2, ad.eps, step_size, bc2);
             adam_one(pp.w, g.w, mm.w, vv.w, ad.b1, ad.b2, ad.eps, step_size, bc2);
-            nt_store4(p4 + q, pp); nt_store4(m4 + q, mm); nt_store4(v4 + q, vv);
+            nt_store4(po4 + q, pp); nt_store4(mo4 + q, mm); nt_store4(vo4 + q, vv);
             if (KEEP) g4[q] = pp;
         }
     } else {
         for (int f = tid; f < total; f += kPreThreads) {
             float pp = p[f], mm = m[f], vv = v[f];
             adam_one(pp, s_g[f], mm, vv, ad.b1, ad.b2, ad.eps, step_size, bc2);
-            p[f] = pp; m[f] = mm; v[f] = vv;
+            po[f] = pp; mo[f] = mm; vo[f] = vv;
             if (KEEP) s_g[f] = pp;
         }
     }
@@ -1727,19 +1738,20 @@ __device__ __forceinline__ void adam_rows_lin(float* s_g, int total, float* __re
 // straight from its registers: neighbouring lanes touch neighbouring rows, so every fetched line is fully used, and the
 // block keeps no LDS copy of these gradients (25 instead of 30.7 kB per block: one more block per CU).
 template <int K>
-__device__ __forceinline__ void adam_own(float* p, float* m, float* v, const float* g, float step_size, float bc2, const AdamDev& ad,
+__device__ __forceinline__ void adam_own(float* p, float* m, float* v, const float* g, float step_size, float bc2, int grp, const AdamDev& ad,
                                          float* updated = nullptr)
 {
-    if (K == 4 && ((((uintptr_t)p | (uintptr_t)m | (uintptr_t)v) & 15) == 0)) {
+    float* const po = adam_out(p, ad.dp[grp]); float* const mo = adam_out(m, ad.dm[grp]); float* const vo = adam_out(v, ad.dv[grp]);
+    if (K == 4 && ((((uintptr_t)p | (uintptr_t)m | (uintptr_t)v | (uintptr_t)po | (uintptr_t)mo | (uintptr_t)vo) & 15) == 0)) {
         float4 pp = *reinterpret_cast<const float4*>(p);
         float4 mm = nt_load4(reinterpret_cast<const float4*>(m)), vv = nt_load4(reinterpret_cast<const float4*>(v));
         adam_one(pp.x, g[0], mm.x, vv.x, ad.b1, ad.b2, ad.eps, step_size, bc2);
         adam_one(pp.y, g[1], mm.y, vv.y, ad.b1, ad.b2, ad.eps, step_size, bc2);
         adam_one(pp.z, g[2], mm.z, vv.z, ad.b1, ad.b2, ad.eps, step_size, bc2);
         adam_one(pp.w, g[3], mm.w, vv.w, ad.b1, ad.b2, ad.eps, step_size, bc2);
-        nt_store4(reinterpret_cast<float4*>(p), pp);
-        nt_store4(reinterpret_cast<float4*>(m), mm);
-        nt_store4(reinterpret_cast<float4*>(v), vv);
+        nt_store4(reinterpret_cast<float4*>(po), pp);
+        nt_store4(reinterpret_cast<float4*>(mo), mm);
+        nt_store4(reinterpret_cast<float4*>(vo), vv);
         if (updated) { updated[0] = pp.x; updated[1] = pp.y; updated[2] = pp.z; updated[3] = pp.w; }
         return;
     }
@@ -1754,9 +1766,9 @@ __device__ __forceinline__ void adam_own(float* p, float* m, float* v, const flo
     }
 #pragma unroll
     for (int c = 0; c < K; c++) {
-        __builtin_nontemporal_store(pp[c], p + c);
-        __builtin_nontemporal_store(mm[c], m + c);
-        __builtin_nontemporal_store(vv[c], v + c);
+        __builtin_nontemporal_store(pp[c], po + c);
+        __builtin_nontemporal_store(mm[c], mo + c);
+        __builtin_nontemporal_store(vv[c], vo + c);
     }
 }
 
@@ -1940,10 +1952,10 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, in
         }
         if (ADAM) {   // this thread is the only reader of its Gaussian's small rows, and it has read them
             const size_t gi = (size_t)i;
-            adam_own<3>(const_cast<float*>(means) + 3 * gi, ad.m[0] + 3 * gi, ad.v[0] + 3 * gi, dmean, ad.step_size[0], ad.inv_bc2s[0], ad, PREP >= 0 ? nmean : nullptr);
-            adam_own<1>(const_cast<float*>(opac_raw) + gi, ad.m[3] + gi, ad.v[3] + gi, &dop, ad.step_size[3], ad.inv_bc2s[3], ad, PREP >= 0 ? &nop : nullptr);
-            adam_own<3>(const_cast<float*>(scales) + 3 * gi, ad.m[4] + 3 * gi, ad.v[4] + 3 * gi, dsc, ad.step_size[4], ad.inv_bc2s[4], ad, PREP >= 0 ? nsc : nullptr);
-            adam_own<4>(const_cast<float*>(rots) + 4 * gi, ad.m[5] + 4 * gi, ad.v[5] + 4 * gi, drq, ad.step_size[5], ad.inv_bc2s[5], ad, PREP >= 0 ? nrq : nullptr);
+            adam_own<3>(const_cast<float*>(means) + 3 * gi, ad.m[0] + 3 * gi, ad.v[0] + 3 * gi, dmean, ad.step_size[0], ad.inv_bc2s[0], 0, ad, PREP >= 0 ? nmean : nullptr);
+            adam_own<1>(const_cast<float*>(opac_raw) + gi, ad.m[3] + gi, ad.v[3] + gi, &dop, ad.step_size[3], ad.inv_bc2s[3], 3, ad, PREP >= 0 ? &nop : nullptr);
+            adam_own<3>(const_cast<float*>(scales) + 3 * gi, ad.m[4] + 3 * gi, ad.v[4] + 3 * gi, dsc, ad.step_size[4], ad.inv_bc2s[4], 4, ad, PREP >= 0 ? nsc : nullptr);
+            adam_own<4>(const_cast<float*>(rots) + 4 * gi, ad.m[5] + 4 * gi, ad.v[5] + 4 * gi, drq, ad.step_size[5], ad.inv_bc2s[5], 5, ad, PREP >= 0 ? nrq : nullptr);
         } else {
 #pragma unroll
         for (int k = 0; k < 3; k++) d_means[3 * (size_t)i + k] = dmean[k];
@@ -1991,9 +2003,9 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, in
         const size_t b = (size_t)base;
         const int rrow = cp.M * 3 - 3;
         if (lin) {
-            adam_rows_lin<(PREP >= 0)>(s_dc, nG * 3, const_cast<float*>(shs) + b * 3, ad.m[1] + b * 3, ad.v[1] + b * 3, tid, ad.step_size[1], ad.inv_bc2s[1], ad);
+            adam_rows_lin<(PREP >= 0)>(s_dc, nG * 3, const_cast<float*>(shs) + b * 3, ad.m[1] + b * 3, ad.v[1] + b * 3, tid, ad.step_size[1], ad.inv_bc2s[1], 1, ad);
             if (DEG > 0 || ad.m[2])   // (degree 0, moments known to be zero: the group's update is the identity -- GsrFusedAdam)
-                adam_rows_lin<(PREP >= 0)>(s_rest, nG * NRL, const_cast<float*>(shs_rest) + b * NRL, ad.m[2] + b * NRL, ad.v[2] + b * NRL, tid, ad.step_size[2], ad.inv_bc2s[2], ad);
+                adam_rows_lin<(PREP >= 0)>(s_rest, nG * NRL, const_cast<float*>(shs_rest) + b * NRL, ad.m[2] + b * NRL, ad.v[2] + b * NRL, tid, ad.step_size[2], ad.inv_bc2s[2], 2, ad);
             if (PREP < 0) return;
             // ---- next-view tail ("prepare in backward", GsrNextView): this block holds the UPDATED parameters of its 128
             // Gaussians -- the small groups in the owners' registers, the SH rows in the LDS tile -- so it runs the forward
@@ -2060,13 +2072,13 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, in
             }
             return;
         }
-        adam_rows(s_sh, kShStride, 0, 3, 3, const_cast<float*>(shs) + b * 3, ad.m[1] + b * 3, ad.v[1] + b * 3, nG, tid, ad.step_size[1], ad.inv_bc2s[1], ad);
+        adam_rows(s_sh, kShStride, 0, 3, 3, const_cast<float*>(shs) + b * 3, ad.m[1] + b * 3, ad.v[1] + b * 3, nG, tid, ad.step_size[1], ad.inv_bc2s[1], 1, ad);
         if (DEG == 0 && !ad.m[2]) {}   // f_rest skipped: see GsrFusedAdam
         else if (rrow == 45 && NC3 == 48)
-            adam_rows(s_sh, kShStride, 3, 45, 45, const_cast<float*>(shs_rest) + b * 45, ad.m[2] + b * 45, ad.v[2] + b * 45, nG, tid, ad.step_size[2], ad.inv_bc2s[2], ad);
+            adam_rows(s_sh, kShStride, 3, 45, 45, const_cast<float*>(shs_rest) + b * 45, ad.m[2] + b * 45, ad.v[2] + b * 45, nG, tid, ad.step_size[2], ad.inv_bc2s[2], 2, ad);
         else if (rrow > 0)
             adam_rows(s_sh, kShStride, 3, rrow, NC3 - 3, const_cast<float*>(shs_rest) + b * rrow, ad.m[2] + b * rrow, ad.v[2] + b * rrow, nG, tid,
-                      ad.step_size[2], ad.inv_bc2s[2], ad);
+                      ad.step_size[2], ad.inv_bc2s[2], 2, ad);
     } else if (lin && d_shs && d_shs_rest) {
         __syncthreads();
         stage_out_lin<3>(s_dc, d_shs + (size_t)base * 3, nG, tid);
@@ -2989,6 +3001,15 @@ int gsr_backward(const GsrBackwardArgs* a, void* stream_)
             if (fa->step_lag[q] < 0 || tq < 1) return fail(GSR_ERR_ARG, "fused_adam: step_lag out of range%s");
             ad.step_size[q] = fa->lr[q] / (float)(1.0 - pow((double)fa->beta1, (double)tq));
             ad.inv_bc2s[q] = 1.f / (float)sqrt(1.0 - pow((double)fa->beta2, (double)tq));
+            // deferred application: the updated rows go to buffers of their own and the caller adopts them (or not) later
+            const float* pin[6] = {a->means3D, a->shs, a->shs_rest, a->opacities, a->scales, a->rotations};
+            if (fa->param_out[q] || fa->exp_avg_out[q] || fa->exp_avg_sq_out[q]) {
+                if (!fa->param_out[q] || !fa->exp_avg_out[q] || !fa->exp_avg_sq_out[q]) return fail(GSR_ERR_ARG, "fused_adam: a group's three output buffers come together%s");
+                if (a->next_view) return fail(GSR_ERR_ARG, "fused_adam: deferred application (param_out) cannot prepare a next view%s");
+                ad.dp[q] = (long long)((const char*)fa->param_out[q] - (const char*)pin[q]);
+                ad.dm[q] = (long long)((const char*)fa->exp_avg_out[q] - (const char*)fa->exp_avg[q]);
+                ad.dv[q] = (long long)((const char*)fa->exp_avg_sq_out[q] - (const char*)fa->exp_avg_sq[q]);
+            }
         }
         ad.b1 = fa->beta1; ad.b2 = fa->beta2; ad.eps = fa->eps;
     } else if (!a->d_means3D || !a->d_opacities)

@@ -259,7 +259,9 @@ std::vector<Tensor> rasterize_backward_fused(
     const BatchArg batch(batch_first_block);
     const int64_t NB = batch.B();
     // adam_lr: six learning rates, optionally followed by six step lags (GsrFusedAdam::step_lag; whole numbers)
-    TORCH_CHECK(adam_m.size() == 6 && adam_v.size() == 6 && (adam_lr.size() == 6 || adam_lr.size() == 12), "fused_adam: six groups expected");
+    // deferred application (GsrFusedAdam::param_out): adam_m = six moments + six moment outputs + six parameter outputs, adam_v = six + six
+    const bool deferred = adam_m.size() == 18 && adam_v.size() == 12;
+    TORCH_CHECK(((adam_m.size() == 6 && adam_v.size() == 6) || deferred) && (adam_lr.size() == 6 || adam_lr.size() == 12), "fused_adam: six groups expected");
     Tensor none;
     BwdCommon b{means3D, sh, none, opac, scales, rots, none, rest, vm, pm, campos, bg, xf, f32c(grad_color), f32c(grad_depth), f32c(grad_alpha)};
     const int64_t N = means3D.size(0);
@@ -278,6 +280,14 @@ std::vector<Tensor> rasterize_backward_fused(
         fa.step_lag[q] = adam_lr.size() == 12 ? (int32_t)adam_lr[6 + q] : 0;
         fa.exp_avg[q] = adam_m[q].numel() ? adam_m[q].data_ptr<float>() : nullptr;     // (empty = the group is skipped: GsrFusedAdam)
         fa.exp_avg_sq[q] = adam_v[q].numel() ? adam_v[q].data_ptr<float>() : nullptr;
+        if (deferred && adam_m[q].numel()) {
+            TORCH_CHECK(adam_m[6 + q].is_contiguous() && adam_v[6 + q].is_contiguous() && adam_m[12 + q].is_contiguous() &&
+                        adam_m[6 + q].numel() == adam_m[q].numel() && adam_v[6 + q].numel() == adam_m[q].numel() && adam_m[12 + q].numel() == adam_m[q].numel(),
+                        "fused_adam (deferred): output buffers must be contiguous and shaped like their group");
+            fa.exp_avg_out[q] = adam_m[6 + q].data_ptr<float>();
+            fa.exp_avg_sq_out[q] = adam_v[6 + q].data_ptr<float>();
+            fa.param_out[q] = adam_m[12 + q].data_ptr<float>();
+        }
     }
     GsrBackwardArgs a{};
     fill_backward_args(a, b, geom, image, binning, meta, H, W, tanfovx, tanfovy, scale_modifier, sh_degree, true);

@@ -55,9 +55,18 @@ class FusedAdam:
         self._commit_np = self._commit.numpy()
         self._commit_seen = 0                                  # commits already folded into state[...]["step"]
         self._commit_at_step = 0                               # value of the counter at the last step() call
+        # Deferred application (round 4; what gsr_autopatch's render uses under the UNMODIFIED trainer): the backward kernel writes
+        # the Adam-updated rows and moments into shadow buffers and `step()` ADOPTS them by swapping storages -- no second pass over
+        # 1.65 kB per Gaussian -- while everything the trainer may do between backward() and step() keeps the reference's meaning:
+        # densify / prune / reset surgery sees the un-updated state and drops the update, a skipped step() leaves the model alone.
+        self._pending = None
+        self._shadow = {}                                      # group name -> [param, exp_avg, exp_avg_sq] shadow tensors
+        self._def_commit = torch.zeros(1, dtype=torch.int64)   # CPU; incremented by the backward that filled the shadows
+        self._def_commit_np = self._def_commit.numpy()
 
     # ---- torch.optim protocol ------------------------------------------------------------------------------
     def zero_grad(self, set_to_none: bool = True):
+        self._pending = None          # a deferred update nobody stepped is dropped with the gradients it stands for
         for g in self.param_groups:
             p = g["params"][0]
             if set_to_none:
@@ -242,6 +251,98 @@ class FusedAdam:
         pm, pv = self._plan_moments(ms, vs, sh_degree, next_sh_degree)
         return (pm, pv, lrs + lags, float(self.betas[0]), float(self.betas[1]), float(self.eps), int(step), self._commit)
 
+    # ---- deferred application ---------------------------------------------------------------------------------------
+    def deferred_ready(self, tensors: Dict[str, torch.Tensor]) -> bool:
+        """May this render's backward fill the shadows?  The six tensors are this optimizer's own contiguous float32 leaves, all
+        want a gradient, and none carries a stale .grad (a trainer that lets gradients accumulate gets torch's accumulation)."""
+        by_name = {g.get("name"): g for g in self.param_groups}
+        if set(by_name) != set(self.FUSED_ORDER) or len(self.param_groups) != 6:
+            return False
+        for name in self.FUSED_ORDER:
+            p, t = by_name[name]["params"][0], tensors.get(name)
+            if t is not p or not p.requires_grad or p.grad is not None or not p.is_contiguous() or p.dtype != torch.float32 or not p.is_cuda:
+                return False
+        return True
+
+    def flush_pending_as_grads(self):
+        """A deferred update that was neither adopted (`step()`) nor dropped (`zero_grad()`) when the next render arrives: the trainer
+        is letting gradients accumulate.  Give it what torch would hold -- the gradient, recovered from the shadow first moment
+        (m' = b1 m + (1 - b1) g) -- and step aside: `deferred_ready` then sees a .grad and the render takes the plain route."""
+        pend, self._pending = self._pending, None
+        if pend is None or int(self._def_commit_np[0]) <= pend["commit_at_plan"]:
+            return
+        b1 = float(self.betas[0])
+        with torch.no_grad():
+            for k, name in enumerate(self.FUSED_ORDER):
+                p = pend["params"][k]
+                if pend["skipped"][k] or self.state.get(p) is None or self.state[p].get("exp_avg") is not pend["m"][k]:
+                    continue
+                g = (pend["mo"][k] - b1 * pend["m"][k]) / (1.0 - b1)
+                p.grad = g if p.grad is None else p.grad + g
+
+    def deferred_step_plan(self, tensors: Dict[str, torch.Tensor], sh_degree=None):
+        """Like fused_step_plan, for a backward that writes the update into shadow buffers: returns
+        (exp_avg[6] + exp_avg_out[6] + param_out[6], exp_avg_sq[6] + exp_avg_sq_out[6], lr (+ lags), b1, b2, eps, step_base, commit)."""
+        pm, pv, lr, b1, b2, eps, step, _ = self.fused_step_plan(tensors, sh_degree, None)
+        by_name = {g.get("name"): g for g in self.param_groups}
+        ps = [by_name[n]["params"][0] for n in self.FUSED_ORDER]
+        po, mo, vo, skipped = [], [], [], []
+        for k, name in enumerate(self.FUSED_ORDER):
+            p = ps[k]
+            sh = self._shadow.get(name)
+            if sh is None or sh[0].shape != p.shape or sh[0].device != p.device:
+                sh = self._shadow[name] = [torch.empty_like(p.detach()), torch.empty_like(p.detach()), torch.empty_like(p.detach())]
+            skip = pm[k].numel() == 0            # (the f_rest group while its moments are zero: left alone, nothing to adopt)
+            skipped.append(skip)
+            po.append(sh[0]); mo.append(sh[1]); vo.append(sh[2])
+        st = [self.state[p] for p in ps]
+        self._pending = {"params": ps, "m": [s_["exp_avg"] for s_ in st], "v": [s_["exp_avg_sq"] for s_ in st], "po": po, "mo": mo, "vo": vo,
+                         "skipped": skipped, "commit_at_plan": int(self._def_commit_np[0]),
+                         "lr": [float(by_name[n]["lr"]) for n in self.FUSED_ORDER]}
+        return (list(pm) + mo + po, list(pv) + vo, lr, b1, b2, eps, step, self._def_commit)
+
+    def _adopt_pending(self) -> bool:
+        """step() of a deferred update: swap the shadows in.  False when there is nothing valid to adopt."""
+        pend, self._pending = self._pending, None
+        if pend is None or int(self._def_commit_np[0]) <= pend["commit_at_plan"]:
+            return False                      # no backward filled the shadows (no_grad render, dropped graph)
+        by_name = {g.get("name"): g for g in self.param_groups}
+        if set(by_name) != set(self.FUSED_ORDER):
+            return False
+        other_grad = any(by_name[n]["params"][0] is pend["params"][k] and by_name[n]["params"][0].grad is not None
+                         for k, n in enumerate(self.FUSED_ORDER))
+        if other_grad or [float(by_name[n]["lr"]) for n in self.FUSED_ORDER] != pend["lr"]:
+            # a learning rate changed between the render and step() (the reference sets them before the render), or another backward
+            # left a .grad on these parameters: the shadows do not hold the step torch would take -- recover the gradients (they
+            # accumulate onto whatever .grad is there) and let the plain step below do it
+            self._pending = pend
+            self.flush_pending_as_grads()
+            return False
+        # per group, as torch steps per parameter: a group whose tensor (or moments) the trainer replaced between backward() and
+        # step() has no gradient in the reference and is not stepped (opacity reset: that one group; densification: all six);
+        # the others adopt their shadows
+        adopted = False
+        with torch.no_grad():
+            for k, name in enumerate(self.FUSED_ORDER):
+                p = by_name[name]["params"][0]
+                st = self.state.get(p)
+                if p is not pend["params"][k] or p.grad is not None or st is None:
+                    continue
+                if pend["skipped"][k]:            # (f_rest while its moments are zero: the update was the identity; count the step)
+                    st["step"] = _step_int(st.get("step", 0)) + 1
+                    continue
+                if st.get("exp_avg") is not pend["m"][k] or st.get("exp_avg_sq") is not pend["v"][k]:
+                    continue
+                old = p.data
+                p.data = pend["po"][k]
+                sh = self._shadow[name]
+                sh[0], sh[1], sh[2] = old, st["exp_avg"], st["exp_avg_sq"]
+                st["exp_avg"], st["exp_avg_sq"] = pend["mo"][k], pend["vo"][k]
+                st["step"] = _step_int(st["step"]) + 1
+                adopted = True
+        self._plan_cache = None
+        return adopted
+
     def fused_backward_args(self, tensors: Dict[str, torch.Tensor], sh_degree=None, next_sh_degree=None) -> "L.GsrFusedAdam":
         """The plan as a GsrFusedAdam struct for the update that is applied NOW (ctypes binding: called from its backward, which
         calls `fused_backward_applied()` once gsr_backward has returned)."""
@@ -261,6 +362,8 @@ class FusedAdam:
     @torch.no_grad()
     def step(self):
         self._reconcile()
+        if self._pending is not None and self._adopt_pending():
+            return
         live = [g for g in self.param_groups if g["params"][0].grad is not None]
         stepped = self._stepped_in_backward
         self._commit_at_step = int(self._commit_np[0])

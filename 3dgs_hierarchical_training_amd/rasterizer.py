@@ -305,7 +305,7 @@ def _ecpu():
 
 def _rasterize_ext(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, rs, sh_rest, raw_params,
                    fused_adam, points_transform, prepared=None, prepare_next=None, next_points_transform=None, densify_stats=None,
-                   batch_first_block=None):
+                   batch_first_block=None, fused_adam_deferred=False):
     """torch.ops.gsr.rasterize: empty tensors stand for None; the camera tensors of the settings tuple are ordinary inputs
     (their gradients are produced when one of them requires grad)."""
     ops = E.load()
@@ -333,9 +333,14 @@ def _rasterize_ext(means3D, means2D, sh, colors_precomp, opacities, scales, rota
             raise RuntimeError("fused_adam needs the raw-parameter path (rasterize_gaussians_raw)")
         # a PLAN only: the step count advances when the backward that applies the update runs (csrc/torch_ext.cpp increments
         # `commit`), so a forward whose graph is dropped leaves the optimizer untouched
-        m, v, lr, b1, b2, eps, step, commit = fused_adam.fused_step_plan({"xyz": means3D, "f_dc": sh, "f_rest": sh_rest, "opacity": opacities,
-                                                                          "scaling": scales, "rotation": rotations}, int(rs.sh_degree),
-                                                                         None if prepare_next is None else int(prepare_next.sh_degree))
+        group_tensors = {"xyz": means3D, "f_dc": sh, "f_rest": sh_rest, "opacity": opacities, "scaling": scales, "rotation": rotations}
+        if fused_adam_deferred:      # the update goes to shadow buffers; optimizer.step() adopts it (optim.FusedAdam, deferred application)
+            if prepare_next is not None:
+                raise RuntimeError("fused_adam_deferred: a deferred update cannot prepare a next view")
+            m, v, lr, b1, b2, eps, step, commit = fused_adam.deferred_step_plan(group_tensors, int(rs.sh_degree))
+        else:
+            m, v, lr, b1, b2, eps, step, commit = fused_adam.fused_step_plan(group_tensors, int(rs.sh_degree),
+                                                                             None if prepare_next is None else int(prepare_next.sh_degree))
     eb = _EMPTY.get(("u8", dev))
     if eb is None:
         eb = _EMPTY[("u8", dev)] = torch.empty(0, dtype=torch.uint8, device=dev)
@@ -385,7 +390,7 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
 
 def rasterize_gaussians_raw(means3D, means2D, features_dc, features_rest, opacity_logit, log_scales, rotations_raw,
                             raster_settings, fused_adam=None, points_transform=None, prepared=None, prepare_next=None,
-                            next_points_transform=None, densify_stats=None, batch_first_block=None):
+                            next_points_transform=None, densify_stats=None, batch_first_block=None, fused_adam_deferred=False):
     """Extension ("next" row f-2): rasterize straight from HTGaussianModel's raw parameters (_xyz, _features_dc,
     _features_rest, _opacity, _scaling, _rotation; /root/reference/scene/gaussian_model_ht.py:74-82) with the
     activations of :49-65,128-133,176-188 fused into the HIP kernels; gradients are w.r.t. the raw tensors.
@@ -411,6 +416,11 @@ def rasterize_gaussians_raw(means3D, means2D, features_dc, features_rest, opacit
     /root/reference/scene/gaussian_model_ht.py:718-721 into them, inside the per-Gaussian backward kernel (include/gsr.h
     GsrDensifyStats) -- no torch ops on N-sized tensors per step.
 
+    fused_adam_deferred = True (with fused_adam): backward() writes the Adam-updated parameters and moments into the optimizer's
+    shadow buffers instead of in place (include/gsr.h GsrFusedAdam::param_out) and `fused_adam.step()` adopts them by swapping
+    storages; until then the model is untouched, so surgery or a skipped step between backward() and step() keep the reference's
+    meaning (what gsr_autopatch.render_fused uses under the unmodified trainer).
+
     batch_first_block = [0, b1, ..., N / 128]: the tensors hold B INDEPENDENT models back to back, model k owning the 128-Gaussian
     blocks [b_k, b_k+1) (pad every model to a multiple of 128 with Gaussians that are culled); raster_settings then carries one
     camera per model (viewmatrix / projmatrix [B,4,4], campos [B,3]; points_transform [B,3,4]) and the outputs are [B,3,H,W] /
@@ -419,9 +429,9 @@ def rasterize_gaussians_raw(means3D, means2D, features_dc, features_rest, opacit
     if not E.use_ctypes():
         return _rasterize_ext(means3D, means2D, features_dc, None, opacity_logit, log_scales, rotations_raw, None, raster_settings,
                               features_rest, True, fused_adam, points_transform, prepared, prepare_next, next_points_transform,
-                              densify_stats, batch_first_block)
-    if prepared is not None or prepare_next is not None or densify_stats is not None or batch_first_block is not None:
-        raise RuntimeError("prepared / prepare_next / densify_stats / batch_first_block are served by the PyTorch extension binding only")
+                              densify_stats, batch_first_block, fused_adam_deferred)
+    if prepared is not None or prepare_next is not None or densify_stats is not None or batch_first_block is not None or fused_adam_deferred:
+        raise RuntimeError("prepared / prepare_next / densify_stats / batch_first_block / fused_adam_deferred are served by the PyTorch extension binding only")
     e = torch.Tensor([])
     return _RasterizeGaussians.apply(means3D, means2D, features_dc, e, opacity_logit, log_scales, rotations_raw, e,
                                      raster_settings, features_rest, True, *_cam_inputs(raster_settings), fused_adam, points_transform)

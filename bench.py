@@ -317,9 +317,12 @@ def make_views(syn, ts, scene, dev, deg, n_views, seed=0):
 def autopatch_leg(ts, scene, settings, gt, dev, steps, warmup):
     """What the UNMODIFIED reference trainer reaches once `import gsr_autopatch` ran before it, driven
     the way `train_step` drives it (ht3dgs_trainer.py:102-166): `gs_render.render(cam)` -- patched: the model's RAW tensors go to
-    the kernels, activations / SH concat in-kernel --, `Loss.forward` -- patched: fused L1 + SSIM --, `loss.backward()`,
-    `optimizer.step()` -- `torch.optim.Adam(l, lr=0.0, eps=1e-15)` came back as FusedAdam: one launch, a REAL separate step --,
-    `zero_grad`.  No reference file is edited and no optimizer-in-backward / hand-over entry point is used.
+    the kernels, activations / SH concat in-kernel --, `Loss.forward` -- patched: fused L1 + SSIM --, `loss.backward()` -- the
+    per-Gaussian backward kernel also computes the Adam update into the optimizer's SHADOW buffers, the model untouched --,
+    `optimizer.step()` -- `torch.optim.Adam(l, lr=0.0, eps=1e-15)` came back as FusedAdam: adopts the shadows by swapping storages;
+    anything the trainer does between backward() and step() keeps the reference's meaning (optim.FusedAdam, deferred application) --,
+    `zero_grad`.  No reference file is edited; the hand-over of the next preprocess is not used (the trainer draws its frames at
+    random).  `separate_step_ms_per_step` = the same with GSR_AUTOPATCH_DEFERRED=0 (gradients to .grad, one-launch FusedAdam.step()).
     `with_bookkeeping` adds what the trainer runs under no_grad between backward and step on a densifying iteration: psnr,
     the max_radii2D update (the trainer's own boolean-mask statement) and add_densification_stats (patched: masked adds)."""
     import gsr_autopatch
@@ -359,6 +362,17 @@ def autopatch_leg(ts, scene, settings, gt, dev, steps, warmup):
         for i in range(2):
             step(True)
         sec_b = timed_steps(lambda i: step(True), steps, dev)
+        prev_def = os.environ.get("GSR_AUTOPATCH_DEFERRED")
+        os.environ["GSR_AUTOPATCH_DEFERRED"] = "0"
+        try:
+            for i in range(2):
+                step(False)
+            sec_sep = timed_steps(lambda i: step(False), steps, dev)
+        finally:
+            if prev_def is None:
+                os.environ.pop("GSR_AUTOPATCH_DEFERRED", None)
+            else:
+                os.environ["GSR_AUTOPATCH_DEFERRED"] = prev_def
         # the legacy form of this leg (rounds 2-3): the wrapper's torch activations + cat + GaussianRasterizer, patched loss + optimizer
         def old(i):
             pkg = ts.render(p, settings, clamp=True, fused_activations=False)
@@ -372,10 +386,12 @@ def autopatch_leg(ts, scene, settings, gt, dev, steps, warmup):
         gsr_autopatch.remove()
     del p
     return {"value": 1.0 / sec, "unit": "images/s", "ms_per_step": 1e3 * sec, "steps": steps, "optimizer_class": opt_cls,
-            "with_bookkeeping_ms_per_step": 1e3 * sec_b, "render_unpatched_ms_per_step": 1e3 * sec_old,
+            "with_bookkeeping_ms_per_step": 1e3 * sec_b, "separate_step_ms_per_step": 1e3 * sec_sep,
+            "render_unpatched_ms_per_step": 1e3 * sec_old,
             "path": "`import gsr_autopatch` + the unmodified trainer's calls: CF3DGS_Render.render (patched: raw parameters -> "
                     "rasterize_gaussians_raw, in-kernel exp / sigmoid / normalize / cat) -> Loss.forward (patched: fused clamp + L1 + SSIM) "
-                    "-> backward -> torch.optim.Adam(...).step() (patched: FusedAdam, one launch, a separate real step); "
+                    "-> backward (the Adam update computed into shadow buffers) -> torch.optim.Adam(...).step() (patched: FusedAdam adopts "
+                    "the shadows by a storage swap); separate_step_* = GSR_AUTOPATCH_DEFERRED=0 (gradients to .grad + one-launch step); "
                     "render_unpatched_* = the same with GSR_AUTOPATCH_RENDER=0 (round 3's form of this leg)"}
 
 

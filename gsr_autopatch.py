@@ -21,9 +21,11 @@ Importing this module BEFORE the trainer swaps both for the HIP kernels of this 
     RAW parameter tensors (`_xyz, _features_dc, _features_rest, _opacity, _scaling, _rotation`) to `rasterize_gaussians_raw`: the
     wrapper's torch exp / sigmoid / normalize / cat (and their backward kernels) run inside the preprocess kernels, `get_xyz`'s
     pose action `P[idx].retr().act(xyz)` becomes the in-kernel `points_transform`, and the gradients arrive on the raw tensors
-    directly, where `optimizer.step()` (FusedAdam: ONE launch) picks them up.  `optimizer.step()` stays a real, separate step:
-    the trainer's order -- densify / prune / opacity reset BEFORE the step, `update_gaussians=False`, the grads dropped when
-    `densify_and_prune` replaces every parameter (ht3dgs_trainer.py:137-160) -- is untouched.  The returned dict is the
+    directly, where `optimizer.step()` picks them up.  With the FusedAdam this module hands out, the backward kernel also computes
+    that step's Adam update into SHADOW buffers (the model untouched) and `optimizer.step()` adopts it by swapping storages: the
+    trainer's order -- densify / prune / opacity reset BEFORE the step, `update_gaussians=False`, the update dropped when
+    `densify_and_prune` replaces every parameter (ht3dgs_trainer.py:137-160) -- is untouched, the separate 1.65 kB-per-Gaussian
+    optimizer pass is gone.  (`GSR_AUTOPATCH_DEFERRED=0`: gradients to .grad and a one-launch FusedAdam.step() instead.)  The returned dict is the
     reference's (`image` clamped, `depth`, `alpha`, `viewspace_points` whose .grad the backward fills, `visibility_filter`,
     `radii`).  `override_color`, `compute_cov3D_python`, `convert_SHs_python`, CPU tensors or an unexpected parameter layout
     fall back to the ORIGINAL method.  `GSR_AUTOPATCH_RENDER=0` leaves the method alone; `GSR_AUTOPATCH_POSE=0` keeps pose
@@ -206,8 +208,17 @@ def render_fused(self, viewpoint_camera, scaling_modifier=1.0, invert_bg_color=F
         projmatrix=viewpoint_camera.full_proj_transform, sh_degree=g.active_sh_degree, campos=viewpoint_camera.camera_center,
         prefiltered=False, debug=False)
     M = _pose_matrix(g) if posed else None
+    # DEFERRED optimizer step: when the model's optimizer is the FusedAdam this module handed out, the backward kernel also computes
+    # the Adam update -- into shadow buffers, the model untouched -- and the trainer's `optimizer.step()` adopts it by swapping
+    # storages.  Everything the trainer may do in between keeps its meaning (surgery sees the un-updated state and drops the
+    # update; a skipped step leaves the model alone; stale .grad = torch's accumulation on the plain route).  GSR_AUTOPATCH_DEFERRED=0: off.
+    opt, deferred = getattr(g, "optimizer", None), False
+    if opt is not None and hasattr(opt, "deferred_ready") and torch.is_grad_enabled() and os.environ.get("GSR_AUTOPATCH_DEFERRED", "1") != "0":
+        opt.flush_pending_as_grads()
+        deferred = opt.deferred_ready({"xyz": xyz, "f_dc": f_dc, "f_rest": f_rest, "opacity": opacity, "scaling": scaling, "rotation": rotation})
     image_raw, radii, depth, alpha = R.rasterize_gaussians_raw(xyz, screenspace_points, f_dc, f_rest, opacity, scaling, rotation,
-                                                               settings, points_transform=M)
+                                                               settings, points_transform=M, fused_adam=opt if deferred else None,
+                                                               fused_adam_deferred=deferred)
     image = image_raw.clamp(0, 1)
     image._gsr_raw = (image_raw, image._version)       # lets the patched Loss.forward fuse this clamp into the loss kernels
     return {"image": image, "depth": depth, "alpha": alpha, "viewspace_points": screenspace_points,

@@ -143,6 +143,13 @@ typedef struct GsrFusedAdam {
                              * the six groups in lockstep.  The reference drops a group's update when its tensor is replaced
                              * between backward() and optimizer.step() (opacity reset: gaussian_model_ht.py:468-474,
                              * ht3dgs_trainer.py:153-160), after which that group's count stays behind the others'. */
+    /* round 4, DEFERRED application: when a group's three pointers are set, its updated parameter rows and moments are written
+     * THERE instead of in place (inputs untouched), and the caller adopts them -- swaps the buffers -- when its `optimizer.step()`
+     * runs, or drops them when the step never comes (the reference's trainer densifies between backward() and step() and then
+     * steps nothing: ht3dgs_trainer.py:137-160).  All NULL = in place.  Not together with next_view. */
+    float* param_out[6];
+    float* exp_avg_out[6];
+    float* exp_avg_sq_out[6];
 } GsrFusedAdam;
 
 /* "Prepare in backward" (extension f-2, with fused_adam only).  Training renders the same parameters again right after
