@@ -1224,7 +1224,7 @@ __global__ __launch_bounds__(256) void k_bwd_prologue(float4* __restrict__ gg4, 
     if ((int)blockIdx.x >= builders) {
         const size_t nblk = gridDim.x - builders, blk = blockIdx.x - builders;
         const float4 z = {0.f, 0.f, 0.f, 0.f};
-        for (size_t i = blk * 256 + tid; i < n4; i += nblk * 256) gg4[i] = z;
+        for (size_t i = blk * 256 + tid; i < n4; i += nblk * 256) nt_store4(gg4 + i, z);   // (the blend's atomics are the next to touch these lines)
         return;
     }
     // workgroups 0..7 (the first to start; they are done before the fill is): workgroup x builds list x, in its own region of
