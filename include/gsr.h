@@ -259,10 +259,13 @@ int gsr_version(void);
  *   "blend_bwd_ppt"        backward blend kernel: 2 = packed two-pixel kernel (default); 1, 3, 4 = scalar A/B kernels (variants.hip)
  *   "ab_variants"          query: returns 1 when the library carries the A/B kernels, 0 otherwise (the value is ignored)
  *   "sort_algo"            2 = onesweep for both sorts (default); 1 = onesweep depth sort only; 0 = hist + scan + scatter
- *   "bwd_split"            workgroups the backward of one tile is split over (1 = off; default 0 = automatic: 16 on a 980x545 frame,
- *                          fewer for frames / batches with more tiles, about 35 000 workgroups in all): each part replays a
- *                          run of 128-instance batches, resuming from the per-pixel checkpoints the forward leaves at
- *                          every 128-instance boundary from batch "ckpt_first" (default 1) on
+ *   "bwd_split"            1 = the backward of a tile is ONE work item (off); anything else (default 0) = one item per 128-instance
+ *                          batch beyond the first "ckpt_first" (default 1) batches, each resuming from the per-pixel checkpoint the
+ *                          forward leaves at every 128-instance boundary.  (Round 4: the items are listed by k_bwd_prologue and
+ *                          replayed by persistent workgroups; up to round 3 the value was the number of workgroups per tile.)
+ *   "blend_balance"        1 (default) = the forward blend places its sub-tile waves by the visits each took at the previous
+ *                          render of the same view (device-side cache keyed by a hash of the view matrix; single renders through
+ *                          the default kernel); 0 = dispatch order = tile order.  Same image either way
  *   "tile_map"             how tiles are dealt to the eight XCDs: 2 (default) = 2x2 blocks of tiles round-robin, 1 = single
  *                          tiles round-robin (tile t on XCD t % 8), 0 = one contiguous band of tiles per XCD
  *   "speculative_binning"  1 (default) = R-dependent stages launched against a capacity, R read back late;
@@ -290,7 +293,7 @@ int gsr_set_option(const char* name, int value);
  * gsr_forward) / "forward_wait_ns" (the part of it spent waiting for the instance count) and "backward_calls" / "backward_ns" --
  * (forward_ns - forward_wait_ns + backward_ns) / calls is what the launching thread works per forward + backward.  -1 for an
  * unknown name. */
-int64_t gsr_get_counter(const char* name);
+int64_t gsr_get_counter(const char* name);   /* + "blend_bwd_resident": workgroups of the backward blend the device holds at once */
 /* Debug / test hook: copy the per-tile ranges (T x {begin, end} uint32) and the (tile, depth, id)-ordered Gaussian-id list
  * (num_rendered uint32) out of a forward's binning buffer into device buffers of the caller (either may be NULL). */
 int gsr_debug_read_binning(const void* binning, int64_t binning_capacity, int64_t num_rendered, int32_t W, int32_t H,
