@@ -590,7 +590,8 @@ struct ZeroJobs {
 // host_out is given, into pinned host memory (device-visible): the count reaches the host without a copy launch
 template <int NTHR>
 __device__ __forceinline__ void block_scan_body(uint32_t* block_sums, int nb, unsigned long long* total_out, const ZeroJobs& zj,
-                                                unsigned long long* host_out, unsigned long long host_seq, unsigned long long* s_wsum /*[NTHR/64]*/)
+                                                unsigned long long* host_out, unsigned long long host_seq, unsigned long long* s_wsum /*[NTHR/64]*/,
+                                                const unsigned int* window_overflow = nullptr)
 {
     constexpr int NWV = NTHR / 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -625,6 +626,7 @@ __device__ __forceinline__ void block_scan_body(uint32_t* block_sums, int nb, un
         *total_out = all;
         if (host_out) {   // the count, then the call's sequence number: the host polls the second word (gsr_forward)
             __atomic_store_n(host_out + 2, (unsigned long long)g_onesweep_giveups, __ATOMIC_RELAXED);   // (sorts that gave up so far: see radix_sort.h)
+            __atomic_store_n(host_out + 3, (unsigned long long)(window_overflow ? *window_overflow : 0u), __ATOMIC_RELAXED);   // (depth keys beyond the 9-bit sort's window)
             __atomic_store_n(host_out, all, __ATOMIC_RELAXED);
             __threadfence_system();
             __atomic_store_n(host_out + 1, host_seq, __ATOMIC_RELAXED);
@@ -759,10 +761,11 @@ __global__ __launch_bounds__(kEmitThreads) void k_tile_counts(int N, const uint3
 //  saves the launch but measured 140 us at 1 M Gaussians and +2 us at 50 k: the totals of 3 907 blocks read through
 //  coherent loads by 256 threads are a long latency chain; the single-workgroup launch below stays)
 __global__ __launch_bounds__(1024) void k_block_scan(uint32_t* __restrict__ block_sums, int nb, unsigned long long* __restrict__ total_out,
-                                                     ZeroJobs zj, unsigned long long* __restrict__ host_out, unsigned long long host_seq)
+                                                     ZeroJobs zj, unsigned long long* __restrict__ host_out, unsigned long long host_seq,
+                                                     const unsigned int* __restrict__ window_overflow)
 {
     __shared__ unsigned long long s_wsum[16];
-    block_scan_body<1024>(block_sums, nb, total_out, zj, host_out, host_seq, s_wsum);
+    block_scan_body<1024>(block_sums, nb, total_out, zj, host_out, host_seq, s_wsum, window_overflow);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2278,6 +2281,8 @@ static BinScratch bin_scratch_layout(int64_t R, int key_bytes = 4)
 // the per-view cost cache of the balanced forward blend: one per (device, frame geometry), a handful at most
 struct ViewCostCache { int dev, W, H, map, items; uint8_t* mem; };
 static std::vector<ViewCostCache> g_view_costs;   // guarded by g_state_mutex
+static std::map<std::tuple<int, int, int, int>, bool> g_full_depth_sort;   // callers whose depths left the 27-bit window once: four 8-bit passes from then on
+
 struct PinSlot { unsigned long long* host = nullptr; unsigned long long* dev = nullptr; hipEvent_t ev = nullptr; bool busy = false;
                  unsigned long long seq = 0; };   // seq: number of the slot's last use; the scan kernel echoes it behind the count
 static std::mutex g_state_mutex;
@@ -2290,9 +2295,11 @@ static int g_bwd_split = 0;  // workgroups a long tile's backward is split over 
                              // 980x545 frame, fewer the more tiles there are (the parts that find nothing to do still cost a launch slot:
                              // 16 x 17 408 workgroups for eight batched images spent 170 of 860 us on them) -- about 35 000 workgroups
 static int g_ckpt_first = 1;  // 128-instance batches of a tile before the forward starts leaving checkpoints
+constexpr uint32_t kDepthKeyBias = 0x3E4CCCCDu;   // bit pattern of the near plane, 0.2f (gsr_math.h kNearZ): no visible Gaussian's depth key lies below it
+static int g_depth_sort9 = 1;     // depth sort of large models in three 9-bit passes over (key - near-plane bits) (radix_sort.h); 0 = four 8-bit passes
 static int g_blend_balance = 1;   // forward blend: place the waves by the visits each took at the previous render of the same view (balance_build)
 static int g_tile_map = 2;   // tile -> XCD map: 2 = 2x2 tile blocks interleaved (default), 1 = tiles interleaved, 0 = banded
-static std::atomic<long long> g_spec_overflows{0}, g_spec_forwards{0}, g_exact_forwards{0};
+static std::atomic<long long> g_spec_overflows{0}, g_spec_forwards{0}, g_exact_forwards{0}, g_depth_window_resorts{0};
 // host-side time accounting of the two entry points (gsr_get_counter): wall time inside the call, and the part of the forward
 // spent waiting for the instance count -- their difference is what the launching thread really works per call
 static std::atomic<long long> g_fwd_calls{0}, g_fwd_ns{0}, g_fwd_wait_ns{0}, g_bwd_calls{0}, g_bwd_ns{0};
@@ -2460,6 +2467,7 @@ int gsr_set_option(const char* name, int value)
     if (!strcmp(name, "ckpt_first")) { if (value < 1 || value > 64) return GSR_ERR_ARG; g_ckpt_first = value; return GSR_OK; }
     if (!strcmp(name, "tile_map")) { if (value < 0 || value > 2) return GSR_ERR_ARG; g_tile_map = value; return GSR_OK; }
     if (!strcmp(name, "blend_balance")) { g_blend_balance = value ? 1 : 0; return GSR_OK; }
+    if (!strcmp(name, "depth_sort9")) { g_depth_sort9 = value ? 1 : 0; return GSR_OK; }
     if (!strcmp(name, "speculative_binning")) { g_speculate = value ? 1 : 0; return GSR_OK; }
     if (!strcmp(name, "deterministic_backward")) { g_deterministic = value ? 1 : 0; return GSR_OK; }
     if (!strcmp(name, "binning_capacity_hint")) {   // tests: capacity of the next forward (one shot; forces an overflow re-run)
@@ -2470,7 +2478,8 @@ int gsr_set_option(const char* name, int value)
     if (!strcmp(name, "reset_speculation")) {       // forget every capacity hint and zero the counters
         std::lock_guard<std::mutex> lk(g_state_mutex);
         g_hints.clear(); g_hint_override = -1;
-        g_spec_overflows = 0; g_spec_forwards = 0; g_exact_forwards = 0;
+        g_spec_overflows = 0; g_spec_forwards = 0; g_exact_forwards = 0; g_depth_window_resorts = 0;
+        g_full_depth_sort.clear();
         return GSR_OK;
     }
     if (!strcmp(name, "profile")) { g_profile = (value == 2) ? 2 : (value ? 1 : 0); return GSR_OK; }
@@ -2670,7 +2679,7 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
     const int grid = (N + kPreThreads - 1) / kPreThreads;
     // block 0 of k_preprocess clears the head (digit histograms + tickets) of the depth sort's scratch
     uint32_t* zero_words = depth_onesweep ? reinterpret_cast<uint32_t*>(fs + L.sort) : nullptr;
-    const int zero_count = depth_onesweep ? (int)kOnesweepHeadWords : 0;
+    const int zero_count = depth_onesweep ? (int)kOnesweepHeadWordsMax : 0;   // (either layout of the depth sort's head)
     uint8_t* depth_scratch = fs + L.sort;
     bool depth_hist_done = false;
     if (a->prepared) {
@@ -2711,10 +2720,20 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
 #undef GSR_PRE_
     }
     int in_alt = 0;
+    // large models: three 9-bit passes over the 27-bit depth window (radix_sort.h); small ones keep the four 8-bit passes whose
+    // digits the producer of the keys has counted (no histogram launch).  A caller whose depths left the window once stays on
+    // the full sort.
+    bool wide_depth = depth_onesweep && g_depth_sort9 && !depth_hist_done && N > g_prep_hist_max_n;
+    if (wide_depth) {
+        std::lock_guard<std::mutex> lk(g_state_mutex);
+        auto it = g_full_depth_sort.find(hint_key);
+        if (it != g_full_depth_sort.end() && it->second) wide_depth = false;
+    }
+    const unsigned int* window_overflow = wide_depth ? onesweep_overflow_word(depth_scratch) : nullptr;   // (in the sort's zeroed scratch head)
     {
         ProfScope ps(P_SORT_DEPTH, st);
-        GSR_HIP(depth_onesweep ? onesweep_sort_pairs<uint32_t>(dkey, gid, dkey_alt, gid_alt, (uint32_t)N, 0, 32, depth_scratch, &in_alt, st, nullptr, true,
-                                                               depth_hist_done)
+        GSR_HIP(depth_onesweep ? onesweep_sort_pairs<uint32_t>(dkey, gid, dkey_alt, gid_alt, (uint32_t)N, 0, wide_depth ? 27 : 32, depth_scratch, &in_alt, st,
+                                                               nullptr, true, depth_hist_done, wide_depth ? 9 : 8, kDepthKeyBias)
                                : radix_sort_pairs<uint32_t>(dkey, gid, dkey_alt, gid_alt, (uint32_t)N, 0, 32, fs + L.sort, &in_alt, st));
     }
     sorted_gid = in_alt ? gid_alt : gid;
@@ -2763,7 +2782,7 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
         hipLaunchKernelGGL(k_tile_counts, dim3(nb + (bb.hdr ? 8 : 0)), dim3(kEmitThreads), 0, st, N, sorted_gid, ntiles, block_sums,
                            reinterpret_cast<TileRec*>(fs + L.srec), bb, nb);
         // the scan writes R straight into the pinned slot (device-visible host memory): no copy launch behind it
-        hipLaunchKernelGGL(k_block_scan, dim3(1), dim3(1024), 0, st, block_sums, nb, total, zj, pin.s->dev, ++pin.s->seq);
+        hipLaunchKernelGGL(k_block_scan, dim3(1), dim3(1024), 0, st, block_sums, nb, total, zj, pin.s->dev, ++pin.s->seq, window_overflow);
     }
     GSR_HIP(hipGetLastError());
 
@@ -2808,9 +2827,30 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
         if (fresh)
             return fail(GSR_ERR_HIP, "a radix-sort look-back gave up (status words overwritten?): the binning of this or the previous forward is invalid%s");
     }
+    bool resorted = false;
+    if (wide_depth && static_cast<volatile unsigned long long*>(pin.s->host)[3] != 0ull) {
+        // a depth key beyond the 27-bit window of the three-pass sort (a visible Gaussian farther than 13 107 units): its clamped digit
+        // ordered it by index among its like.  Sort again on all 32 bits -- from the clamped result, which kept equal keys in index
+        // order, so the stable full sort of it IS the sort -- recount, rescan, and take the exact flow; this caller stays on the
+        // four-pass sort from now on.
+        { std::lock_guard<std::mutex> lk(g_state_mutex); g_full_depth_sort[hint_key] = true; }
+        g_depth_window_resorts++;
+        uint32_t *k0 = in_alt ? dkey_alt : dkey, *v0 = in_alt ? gid_alt : gid, *k1 = in_alt ? dkey : dkey_alt, *v1 = in_alt ? gid : gid_alt;
+        int alt2 = 0;
+        GSR_HIP(onesweep_sort_pairs<uint32_t>(k0, v0, k1, v1, (uint32_t)N, 0, 32, depth_scratch, &alt2, st));
+        sorted_gid = alt2 ? v1 : v0;
+        hipLaunchKernelGGL(k_tile_counts, dim3(nb), dim3(kEmitThreads), 0, st, N, sorted_gid, ntiles, block_sums, reinterpret_cast<TileRec*>(fs + L.srec),
+                           BlendBalance{}, nb);
+        hipLaunchKernelGGL(k_block_scan, dim3(1), dim3(1024), 0, st, block_sums, nb, total, ZeroJobs{}, pin.s->dev, ++pin.s->seq,
+                           (const unsigned int*)nullptr);
+        GSR_HIP(hipStreamSynchronize(st));
+        std::atomic_thread_fence(std::memory_order_acquire);
+        R = *static_cast<volatile unsigned long long*>(pin.s->host);
+        resorted = true;
+    }
     if (R > 0xfffffff0ull) return fail(GSR_ERR_RANGE, "more than 2^32 instances%s");
-    if (!speculative || R > cap) {   // exact flow, or the capacity was too small (the truncated result is overwritten)
-        if (speculative) g_spec_overflows++;
+    if (!speculative || R > cap || resorted) {   // exact flow, or the capacity was too small (the truncated result is overwritten)
+        if (speculative && !resorted) g_spec_overflows++;
         rc = alloc_binning(R);
         if (rc) return rc;
         rc = launch_binning(R, nullptr, false);
@@ -2830,7 +2870,7 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
     out->num_rendered = (int64_t)R;
     out->binning = bin;
     out->binning_bytes = B.bytes;
-    out->binning_capacity = (int64_t)((speculative && R <= cap) ? cap : R);
+    out->binning_capacity = (int64_t)((speculative && R <= cap && !resorted) ? cap : R);
     out->forward_flags = pack_fwd_flags(opt_ppt, opt_map, opt_ckpt);
     return GSR_OK;
 }
@@ -2924,7 +2964,7 @@ int gsr_backward(const GsrBackwardArgs* a, void* stream_)
         const uint32_t list_cap = (uint32_t)bwd_list_cap(a->binning_capacity > 0 ? a->binning_capacity : a->num_rendered, (size_t)T);
         hipLaunchKernelGGL(k_bwd_prologue, dim3(fill_blocks + (blend_items ? 8 : 0)), dim3(256), 0, st, reinterpret_cast<float4*>(gg), n4,
                            staged4, T, tiles_x, f_map, tpad, f_ckpt, split_ok, item_hdr, const_cast<uint2*>(items), list_cap,
-                           (uint32_t)(bwd_grid / 8), blend_items ? prep_head : nullptr, (int)kOnesweepHeadWords);
+                           (uint32_t)(bwd_grid / 8), blend_items ? prep_head : nullptr, (int)kOnesweepHeadWordsMax);
         prep_head_cleared = blend_items && prep_head != nullptr;
     }
     if (a->num_rendered > 0) {
@@ -3039,7 +3079,7 @@ int gsr_backward(const GsrBackwardArgs* a, void* stream_)
         po.dkey = reinterpret_cast<uint32_t*>(pb + PL.dkey);
         po.gid = reinterpret_cast<uint32_t*>(pb + PL.gid);
         po.rec = reinterpret_cast<TileRec*>(pb + PL.rec);
-        if (!prep_head_cleared) GSR_HIP(hipMemsetAsync(prep_head, 0, kOnesweepHeadWords * sizeof(uint32_t), st));   // (no blend launch: empty frame / other variant)
+        if (!prep_head_cleared) GSR_HIP(hipMemsetAsync(prep_head, 0, kOnesweepHeadWordsMax * sizeof(uint32_t), st));   // (no blend launch: empty frame / other variant)
         if (prep_counts_digits(N)) {
             po.dh.ghist = prep_head;
             po.dh.status = onesweep_status(pb + PL.sort);
@@ -3126,6 +3166,7 @@ int64_t gsr_get_counter(const char* name)
 {
     if (!name) return -1;
     if (!strcmp(name, "spec_overflows")) return g_spec_overflows.load();
+    if (!strcmp(name, "depth_window_resorts")) return g_depth_window_resorts.load();
     if (!strcmp(name, "blend_bwd_resident")) return blend_bwd_resident(0);
     if (!strcmp(name, "spec_forwards")) return g_spec_forwards.load();
     if (!strcmp(name, "exact_forwards")) return g_exact_forwards.load();

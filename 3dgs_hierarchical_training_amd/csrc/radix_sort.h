@@ -269,6 +269,17 @@ constexpr int kOsRanges = 32;
 constexpr uint32_t kOsLocal = 1u << 30, kOsIncl = 2u << 30, kOsMask = (1u << 30) - 1u;
 constexpr uint32_t kOsTicketWords = (4 * kOsRanges + 63) / 64 * 64;   // tickets[pass][run], padded
 constexpr uint32_t kOnesweepHeadWords = 4 * kOsRanges * 256 + kOsTicketWords;   // scratch head: ghist[4][256] + tickets (padded); status follows
+// Round 4, the depth sort over more than a few hundred thousand keys: THREE passes of 9-bit digits over the 27 bits of
+// (key - bias) -- positive floats between the near plane (0.2) and 0.2 x 2^16 = 13 107 -- instead of four of 8 over 32 (76 -> 61 us
+// at 1 M keys).  512-entry digit tables: k_onesweep<KeyT, 512> holds 64 + 32 kB of XOR-mask / count tables per 16-wave workgroup,
+// one workgroup per CU (the 245 tiles of 1 M keys are co-resident all the same); table stride in memory 512.  A key beyond the
+// window is clamped (so the passes stay well defined) and COUNTED in a word of the sort's own (zeroed) scratch head
+// (onesweep_overflow_word): the caller then sorts again with the four 8-bit passes -- from the clamped result: a stable sort of
+// the full keys of any permutation that kept equal keys in index order is the sort.
+constexpr uint32_t kOnesweepHeadWords9 = 3 * kOsRanges * 512 + kOsTicketWords;
+constexpr uint32_t kOnesweepHeadWordsMax = kOnesweepHeadWords9 > kOnesweepHeadWords ? kOnesweepHeadWords9 : kOnesweepHeadWords;
+// (the 9-bit layout uses 3 x 32 of its 128 ticket words; word 100 of them counts the keys beyond the window)
+inline unsigned int* onesweep_overflow_word(void* scratch) { return static_cast<unsigned int*>(scratch) + 3 * kOsRanges * 512 + 100; }
 
 // Geometry of the per-run digit counts (what k_radix_ghist produces), for kernels that already hold the keys in registers
 // and count the digits themselves -- the producer of the keys then replaces the histogram launch (hist_done below):
@@ -293,11 +304,14 @@ __host__ __device__ inline uint32_t onesweep_status_words(uint32_t capacity, int
 }
 __host__ __device__ inline uint32_t* onesweep_status(void* scratch) { return static_cast<uint32_t*>(scratch) + kOnesweepHeadWords; }
 
-template <typename KeyT, int PASSES>
+// GS = stride of the digit tables (256; 512 for 9-bit digits).  bias / kclamp: the digit is taken of min(key - bias, kclamp)
+// (0 / all ones: of the key); a key beyond the window that is not the all-ones padding key is counted in *overflow.
+template <typename KeyT, int PASSES, int GS = 256>
 __global__ __launch_bounds__(256) void k_radix_ghist(const KeyT* __restrict__ keys, uint32_t n, int begin_bit,
-                                                     uint32_t* __restrict__ ghist /*[PASSES][8][256]*/,
+                                                     uint32_t* __restrict__ ghist /*[PASSES][runs][GS]*/,
                                                      const unsigned long long* __restrict__ n_dev,
-                                                     uint32_t* __restrict__ status, uint32_t status_words, int dbits, int bits)
+                                                     uint32_t* __restrict__ status, uint32_t status_words, int dbits, int bits, uint32_t bias = 0u,
+                                                     uint32_t kclamp = 0xffffffffu, unsigned int* __restrict__ overflow = nullptr)
 {
     // digit p covers key bits [dbits p, min(dbits (p + 1), bits)) above begin_bit (<= 8 wide: the tables keep 256 entries)
     uint32_t dmask[PASSES];
@@ -307,10 +321,12 @@ __global__ __launch_bounds__(256) void k_radix_ghist(const KeyT* __restrict__ ke
     // clear the look-back status words of all passes (they are first touched by the pass kernels that follow)
     for (uint32_t q = blockIdx.x * 256 + threadIdx.x; q < status_words / 4; q += gridDim.x * 256)
         reinterpret_cast<uint4*>(status)[q] = make_uint4(0u, 0u, 0u, 0u);
-    __shared__ uint32_t h[PASSES][256];
+    __shared__ uint32_t h[PASSES][GS];
     const int tid = threadIdx.x;
+    bool beyond = false;
 #pragma unroll
-    for (int p = 0; p < PASSES; p++) h[p][tid] = 0;
+    for (int p = 0; p < PASSES; p++)
+        for (int d = tid; d < GS; d += 256) h[p][d] = 0;
     __syncthreads();
     constexpr uint64_t kT = (uint64_t)OsCfg<KeyT>::kTile;
     const uint64_t ntiles = ((uint64_t)n + kT - 1) / kT, per = (ntiles + kOsRanges - 1) / kOsRanges;
@@ -328,21 +344,27 @@ __global__ __launch_bounds__(256) void k_radix_ghist(const KeyT* __restrict__ ke
         for (int c = 0; c < 4; c++) {
 #pragma unroll
             for (int e = 0; e < KPV / 4; e++) {
-                const uint32_t k = (sizeof(KeyT) == 4 ? w[c] : ((w[c] >> (16 * e)) & 0xffffu)) >> begin_bit;
+                const uint32_t kraw = (uint32_t)(sizeof(KeyT) == 4 ? w[c] : ((w[c] >> (16 * e)) & 0xffffu));
+                beyond |= (kraw - bias > kclamp) && kraw != (uint32_t)(KeyT)~(KeyT)0;
+                const uint32_t k = min(kraw - bias, kclamp) >> begin_bit;
 #pragma unroll
                 for (int p = 0; p < PASSES; p++) atomicAdd(&h[p][(k >> (dbits * p)) & dmask[p]], 1u);
             }
         }
     }
     for (uint32_t i = nv * KPV + sub * 256 + tid; i < len; i += bpr * 256) {
-        const uint32_t k = (uint32_t)kr[i] >> begin_bit;
+        const uint32_t kraw = (uint32_t)kr[i];
+        beyond |= (kraw - bias > kclamp) && kraw != (uint32_t)(KeyT)~(KeyT)0;
+        const uint32_t k = min(kraw - bias, kclamp) >> begin_bit;
 #pragma unroll
         for (int p = 0; p < PASSES; p++) atomicAdd(&h[p][(k >> (dbits * p)) & dmask[p]], 1u);
     }
+    if (overflow && __any(beyond) && (threadIdx.x & 63) == 0) atomicAdd(overflow, 1u);
     __syncthreads();
 #pragma unroll
     for (int p = 0; p < PASSES; p++)
-        if (h[p][tid]) atomicAdd(&ghist[(p * kOsRanges + x) * 256 + tid], h[p][tid]);
+        for (int d = tid; d < GS; d += 256)
+            if (h[p][d]) atomicAdd(&ghist[(p * kOsRanges + x) * GS + d], h[p][d]);
 }
 
 // 512 threads x 8 keys per tile: the same 4096-key tile as the three-kernel path, but half the ranking rounds per
@@ -363,8 +385,10 @@ __global__ __launch_bounds__(OsCfg<KeyT>::kThreads) void k_onesweep(const KeyT* 
                                                          const uint32_t* __restrict__ ghist /*[256] this pass*/,
                                                          uint32_t* __restrict__ status /*[nblocks][256]*/,
                                                          uint32_t* __restrict__ ticket,
-                                                         const unsigned long long* __restrict__ n_dev, uint32_t dmask, int runs)
+                                                         const unsigned long long* __restrict__ n_dev, uint32_t dmask, int runs,
+                                                         uint32_t bias = 0u, uint32_t kclamp = 0xffffffffu)
 {
+    constexpr int GS = NB > 256 ? NB : 256;   // stride of the digit tables in memory (status words, per-run digit counts)
     constexpr int kOsThreads = OsCfg<KeyT>::kThreads, kOsTile = OsCfg<KeyT>::kTile, kOsIPT = kOsTile / kOsThreads, kOsWaves = kOsThreads / 64;
     if (n_dev) n = (uint32_t)min((unsigned long long)n, *n_dev);   // device-side count: tiles past it exit at once
     __shared__ unsigned long long s_mask[kOsWaves][NB];
@@ -403,7 +427,7 @@ __global__ __launch_bounds__(OsCfg<KeyT>::kThreads) void k_onesweep(const KeyT* 
         if (p < valid) {
             key[r] = kin[base + p];
             val[r] = vin[base + p];
-            dig[r] = ((uint32_t)key[r] >> shift) & dmask;
+            dig[r] = (min((uint32_t)key[r] - bias, kclamp) >> shift) & dmask;
         } else {
             key[r] = (KeyT)~(KeyT)0; val[r] = 0u; dig[r] = (uint32_t)(NB - 1);
         }
@@ -422,7 +446,7 @@ __global__ __launch_bounds__(OsCfg<KeyT>::kThreads) void k_onesweep(const KeyT* 
         }
     }
     const uint32_t real = (tid == NB - 1) ? mine - ((uint32_t)kOsTile - valid) : mine;   // real keys of this digit
-    uint32_t* my_status = status + (size_t)tile * 256 + (tid & (NB - 1));
+    uint32_t* my_status = status + (size_t)tile * GS + (tid & (NB - 1));
     if (is_digit) __hip_atomic_store(my_status, kOsLocal | real, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // local exclusive start of each digit (block scan of `mine`) and digit base (block scan of the global histogram)
     const uint32_t lstart = block_scan_excl<kOsWaves>(mine, s_wsum, tid);
@@ -430,7 +454,7 @@ __global__ __launch_bounds__(OsCfg<KeyT>::kThreads) void k_onesweep(const KeyT* 
     if (is_digit) {
 #pragma unroll
         for (int x = 0; x < kOsRanges; x++) {
-            const uint32_t c = ghist[x * 256 + tid];
+            const uint32_t c = ghist[x * GS + tid];
             gtot += c;
             gpre += (uint32_t)x < run ? c : 0u;
         }
@@ -446,7 +470,7 @@ __global__ __launch_bounds__(OsCfg<KeyT>::kThreads) void k_onesweep(const KeyT* 
             uint32_t v[kWin];
 #pragma unroll
             for (int q = 0; q < kWin; q++)
-                v[q] = (t - q >= t_lo) ? __hip_atomic_load(status + (size_t)(t - q) * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kOsIncl;
+                v[q] = (t - q >= t_lo) ? __hip_atomic_load(status + (size_t)(t - q) * GS + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kOsIncl;
             bool done = false;
 #pragma unroll
             for (int q = 0; q < kWin; q++) {
@@ -482,7 +506,7 @@ __global__ __launch_bounds__(OsCfg<KeyT>::kThreads) void k_onesweep(const KeyT* 
         const uint32_t p = r * kOsThreads + tid;
         if (p < valid) {
             const KeyT k = s_keys[p];
-            const uint32_t d = ((uint32_t)k >> shift) & dmask;
+            const uint32_t d = (min((uint32_t)k - bias, kclamp) >> shift) & dmask;
             const uint32_t g = s_gbase[d] + p;
             kout[g] = k;
             vout[g] = s_vals[p];
@@ -493,8 +517,11 @@ __global__ __launch_bounds__(OsCfg<KeyT>::kThreads) void k_onesweep(const KeyT* 
 inline size_t onesweep_scratch_bytes(uint32_t n)
 {
     const size_t nblocks = ((size_t)n + kOsTile - 1) / kOsTile;
-    // ghist[4][256] + tickets[4] (padded) + status[4 passes][nblocks][256]
-    return ((kOnesweepHeadWords + 4 * (nblocks ? nblocks : 1) * 256) * sizeof(uint32_t) + 255) & ~(size_t)255;
+    // ghist[4][runs][256] + tickets (padded) + status[4 passes][nblocks][256], or the 9-bit layout: ghist[3][runs][512] + tickets +
+    // status[3][nblocks][512]
+    const size_t nb = nblocks ? nblocks : 1;
+    const size_t w8 = kOnesweepHeadWords + 4 * nb * 256, w9 = kOnesweepHeadWords9 + 3 * nb * 512;
+    return ((w8 > w9 ? w8 : w9) * sizeof(uint32_t) + 255) & ~(size_t)255;
 }
 
 // begin_bit..end_bit in 8-bit passes (at most 4).  Same contract as radix_sort_pairs.  n_dev != nullptr: `n` is only a
@@ -502,32 +529,40 @@ inline size_t onesweep_scratch_bytes(uint32_t n)
 template <typename KeyT>
 inline hipError_t onesweep_sort_pairs(KeyT* keys, uint32_t* vals, KeyT* keys_alt, uint32_t* vals_alt, uint32_t n, int begin_bit,
                                       int end_bit, void* scratch, int* in_alt, hipStream_t stream,
-                                      const unsigned long long* n_dev = nullptr, bool head_prezeroed = false, bool hist_done = false)
+                                      const unsigned long long* n_dev = nullptr, bool head_prezeroed = false, bool hist_done = false,
+                                      int max_digit_bits = 8, uint32_t bias = 0u)
 {
     *in_alt = 0;
     if (n == 0) return hipSuccess;
     const int bits = end_bit - begin_bit;
-    const int passes = (bits + 7) / 8;
-    if (passes < 1 || passes > 4) return hipErrorInvalidValue;
+    const bool wide = max_digit_bits == 9;                    // 9-bit digits: 512-entry tables, table stride 512, own head layout
+    const int passes = (bits + (wide ? 9 : 8) - 1) / (wide ? 9 : 8);
+    if (passes < 1 || passes > 4 || (wide && (passes != 3 || sizeof(KeyT) != 4 || hist_done || begin_bit != 0))) return hipErrorInvalidValue;
+    const uint32_t GS = wide ? 512u : 256u;
+    const uint32_t kclamp = (wide && bits < 32) ? ((1u << bits) - 1u) : 0xffffffffu;
+    if (!wide) bias = 0u;
     // balanced digits: 12 key bits sort as 6 + 6 rather than 8 + 4 (fewer same-digit collisions in the ranking, longer
     // runs per digit in the scatter); the last digit is narrower when the bits do not divide evenly
     const int dbits = (bits + passes - 1) / passes;   // (12 tile-key bits as 7 + 5 or 8 + 4: +2 / +5 us)  == onesweep_dbits(bits)
     const uint32_t nblocks = (n + OsCfg<KeyT>::kTile - 1) / OsCfg<KeyT>::kTile;   // (the scratch is sized for 4096-key tiles: never fewer words)
     uint32_t* ghist = static_cast<uint32_t*>(scratch);
-    uint32_t* tickets = ghist + 4 * kOsRanges * 256;   // [pass][run]
+    uint32_t* tickets = ghist + (wide ? 3 * kOsRanges * 512 : 4 * kOsRanges * 256);   // [pass][run]
     uint32_t* status = tickets + kOsTicketWords;
     // the head (histograms + tickets) must be zero before the histogram kernel; callers that can clear it in a kernel
-    // of their own say so.  The status words are cleared by the histogram kernel itself.
+    // of their own say so (kOnesweepHeadWordsMax words cover both layouts).  The status words are cleared by the histogram kernel itself.
     if (!head_prezeroed && !hist_done) {
-        hipError_t e = hipMemsetAsync(scratch, 0, kOnesweepHeadWords * sizeof(uint32_t), stream);
+        hipError_t e = hipMemsetAsync(scratch, 0, (wide ? kOnesweepHeadWords9 : kOnesweepHeadWords) * sizeof(uint32_t), stream);
         if (e != hipSuccess) return e;
     }
-    const uint32_t status_words = (uint32_t)((size_t)passes * nblocks * 256);
+    const uint32_t status_words = (uint32_t)((size_t)passes * nblocks * GS);
     // (64 blocks of 1024 threads, to shorten the per-address chains of the closing global atomics: +5 us per sort)
     const uint32_t per_cap = (nblocks + kOsRanges - 1) / kOsRanges;
     const uint32_t hgrid = kOsRanges * (per_cap < 32u ? per_cap : 32u);   // histogram blocks: up to 32 per run
     // hist_done: the kernel that produced the keys counted the digits and cleared the status words (see onesweep_run_len)
-    if (!hist_done)
+    if (wide)
+        hipLaunchKernelGGL((k_radix_ghist<KeyT, 3, 512>), dim3(hgrid), dim3(256), 0, stream, keys, n, begin_bit, ghist, n_dev, status, status_words, dbits, bits,
+                           bias, kclamp, onesweep_overflow_word(scratch));
+    else if (!hist_done)
     switch (passes) {
         case 1: hipLaunchKernelGGL((k_radix_ghist<KeyT, 1>), dim3(hgrid), dim3(256), 0, stream, keys, n, begin_bit, ghist, n_dev, status, status_words, dbits, bits); break;
         case 2: hipLaunchKernelGGL((k_radix_ghist<KeyT, 2>), dim3(hgrid), dim3(256), 0, stream, keys, n, begin_bit, ghist, n_dev, status, status_words, dbits, bits); break;
@@ -544,7 +579,12 @@ inline hipError_t onesweep_sort_pairs(KeyT* keys, uint32_t* vals, KeyT* keys_alt
         const uint32_t resident = wbits <= 6 ? onesweep_resident_blocks(k_onesweep<KeyT, 64>, OsCfg<KeyT>::kThreads)
                                              : onesweep_resident_blocks(k_onesweep<KeyT, 256>, OsCfg<KeyT>::kThreads);
         uint32_t* tk_p = pgrid <= resident ? (uint32_t*)nullptr : tickets + p * kOsRanges;
-        if (wbits <= 6)
+        if (wide) {
+            const uint32_t res9 = onesweep_resident_blocks(k_onesweep<KeyT, 512>, OsCfg<KeyT>::kThreads);
+            uint32_t* tk9 = pgrid <= res9 ? (uint32_t*)nullptr : tickets + p * kOsRanges;
+            hipLaunchKernelGGL((k_onesweep<KeyT, 512>), dim3(pgrid), dim3(OsCfg<KeyT>::kThreads), 0, stream, kin, vin, kout, vout, n,
+                               begin_bit + dbits * p, ghist + p * kOsRanges * 512, status + (size_t)p * nblocks * 512, tk9, n_dev, pmask, runs, bias, kclamp);
+        } else if (wbits <= 6)
             hipLaunchKernelGGL((k_onesweep<KeyT, 64>), dim3(pgrid), dim3(OsCfg<KeyT>::kThreads), 0, stream, kin, vin, kout, vout, n,
                                begin_bit + dbits * p, ghist + p * kOsRanges * 256, status + (size_t)p * nblocks * 256, tk_p, n_dev, pmask, runs);
         else
@@ -562,7 +602,8 @@ inline size_t radix_scratch_bytes(uint32_t n)
     const size_t nblocks = ((size_t)n + kSortTile - 1) / kSortTile;
     const size_t osblocks = ((size_t)n + kOsTile - 1) / kOsTile;
     const size_t three_kernel = ((256 * (nblocks ? nblocks : 1) + 8 * 256) * sizeof(uint32_t) + 255) & ~(size_t)255;   // hist + totals
-    const size_t onesweep = ((kOnesweepHeadWords + 4 * (osblocks ? osblocks : 1) * 256) * sizeof(uint32_t) + 255) & ~(size_t)255;
+    const size_t onesweep = onesweep_scratch_bytes(n);   // (either digit-table layout)
+    (void)osblocks;
     return three_kernel > onesweep ? three_kernel : onesweep;
 }
 

@@ -263,6 +263,10 @@ int gsr_version(void);
  *                          batch beyond the first "ckpt_first" (default 1) batches, each resuming from the per-pixel checkpoint the
  *                          forward leaves at every 128-instance boundary.  (Round 4: the items are listed by k_bwd_prologue and
  *                          replayed by persistent workgroups; up to round 3 the value was the number of workgroups per tile.)
+ *   "depth_sort9"          1 (default) = depth sort of models above "prep_hist_max_n" Gaussians in THREE 9-bit passes over the 27 bits
+ *                          of (key - bits(0.2f)): depths between the near plane and 13 107 units; a visible Gaussian beyond that
+ *                          makes the forward sort again on all 32 bits (counter "depth_window_resorts") and keeps that caller on
+ *                          the four 8-bit passes; 0 = always four 8-bit passes.  Same order either way
  *   "blend_balance"        1 (default) = the forward blend places its sub-tile waves by the visits each took at the previous
  *                          render of the same view (device-side cache keyed by a hash of the view matrix; single renders through
  *                          the default kernel); 0 = dispatch order = tile order.  Same image either way
@@ -293,7 +297,7 @@ int gsr_set_option(const char* name, int value);
  * gsr_forward) / "forward_wait_ns" (the part of it spent waiting for the instance count) and "backward_calls" / "backward_ns" --
  * (forward_ns - forward_wait_ns + backward_ns) / calls is what the launching thread works per forward + backward.  -1 for an
  * unknown name. */
-int64_t gsr_get_counter(const char* name);   /* + "blend_bwd_resident": workgroups of the backward blend the device holds at once */
+int64_t gsr_get_counter(const char* name);   /* + "blend_bwd_resident": workgroups of the backward blend the device holds at once; "depth_window_resorts" */
 /* Debug / test hook: copy the per-tile ranges (T x {begin, end} uint32) and the (tile, depth, id)-ordered Gaussian-id list
  * (num_rendered uint32) out of a forward's binning buffer into device buffers of the caller (either may be NULL). */
 int gsr_debug_read_binning(const void* binning, int64_t binning_capacity, int64_t num_rendered, int32_t W, int32_t H,

@@ -769,3 +769,59 @@ def test_densify_and_reset_iterations_drop_that_iterations_update_like_the_refer
         assert int(sa.get("step", 0)) == int(sb.get("step", 0)), (k, sa.get("step"), sb.get("step"))
     pa.optimizer._reconcile()
     assert int(pa.optimizer.state[pa._xyz]["step"]) == 5 and int(pa.optimizer.state[pa._opacity]["step"]) in (3, 4)
+
+
+def test_three_pass_depth_sort_and_its_window_overflow():
+    """Round 4: models above 262 144 Gaussians sort their depth keys in three 9-bit passes over the 27 bits of (key - bits(0.2)) --
+    the window [0.2, 13 107) of view depths.  (i) Inside the window the forward is bit-identical with the four 8-bit passes.
+    (ii) A visible Gaussian beyond the window is detected (a counter in the sort's scratch head, read back with the instance
+    count), the forward sorts again on all 32 bits from the clamped result and takes the exact flow: bit-identical again, the
+    counter "depth_window_resorts" says so, and that caller stays on the four-pass sort (no second resort)."""
+    import importlib
+    L = importlib.import_module("3dgs_hierarchical_training_amd._lib")
+    R = importlib.import_module("3dgs_hierarchical_training_amd.rasterizer")
+    lib = L.load()
+    lib.gsr_get_counter.restype = __import__("ctypes").c_int64
+    dev = torch.device("cuda:0")
+    W, H, N = 400, 300, 300000
+    sc = parity.syn.make_scene(N, W, H, sh_degree=1, seed=17, posed=False)
+    st = ts.make_settings(sc, dev, 1)
+
+    def render(means):
+        out = R.GaussianRasterizer(st)(means3D=means, means2D=torch.zeros(N, 3, device=dev), shs=sc["shs"].to(dev), colors_precomp=None,
+                                       opacities=sc["opacities"].to(dev), scales=scales, rotations=sc["rotations"].to(dev), cov3D_precomp=None)
+        return [o.clone() for o in out]
+    scales = sc["scales"].to(dev)
+    near = sc["means3D"].to(dev)
+    # far: the same cloud with a few hundred Gaussians pushed along their viewing rays to depths of 20 000 - 60 000 (still on screen,
+    # scaled up with the distance so that they keep covering pixels)
+    far = near.clone()
+    idx = torch.arange(0, N, 1000, device=dev)
+    f = torch.linspace(4000.0, 9000.0, idx.numel(), device=dev)[:, None]
+    far[idx] = far[idx] * f
+    scales_far = scales.clone()
+    scales_far[idx] = scales_far[idx] * f
+    try:
+        assert lib.gsr_set_option(b"reset_speculation", 1) == 0
+        res = {}
+        for mode in (0, 1):
+            assert lib.gsr_set_option(b"depth_sort9", mode) == 0
+            res[mode, "near"] = render(near)
+            c0 = lib.gsr_get_counter(b"depth_window_resorts")
+            scales = scales_far
+            res[mode, "far"] = render(far)
+            c1 = lib.gsr_get_counter(b"depth_window_resorts")
+            res[mode, "far2"] = render(far)
+            c2 = lib.gsr_get_counter(b"depth_window_resorts")
+            scales = sc["scales"].to(dev)
+            if mode == 1:
+                assert (c1 - c0, c2 - c1) == (1, 0), (c0, c1, c2)
+            else:
+                assert c0 == c1 == c2
+        assert int((res[1, "far"][1][idx] > 0).sum()) > 10          # (far Gaussians are on screen: their keys were sorted, not culled)
+        for key in ("near", "far", "far2"):
+            for a, b in zip(res[0, key], res[1, key]):
+                assert torch.equal(a, b), key
+    finally:
+        lib.gsr_set_option(b"depth_sort9", 1)
+        lib.gsr_set_option(b"reset_speculation", 1)
