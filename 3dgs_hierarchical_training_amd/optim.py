@@ -275,9 +275,10 @@ class FusedAdam:
         with torch.no_grad():
             for k, name in enumerate(self.FUSED_ORDER):
                 p = pend["params"][k]
-                if pend["skipped"][k] or self.state.get(p) is None or self.state[p].get("exp_avg") is not pend["m"][k]:
+                if self.state.get(p) is None or self.state[p].get("exp_avg") is not pend["m"][k]:
                     continue
-                g = (pend["mo"][k] - b1 * pend["m"][k]) / (1.0 - b1)
+                # (a group the kernel skipped -- f_rest at degree 0 with zero moments -- had an identically zero gradient)
+                g = torch.zeros_like(p) if pend["skipped"][k] else (pend["mo"][k] - b1 * pend["m"][k]) / (1.0 - b1)
                 p.grad = g if p.grad is None else p.grad + g
 
     def deferred_step_plan(self, tensors: Dict[str, torch.Tensor], sh_degree=None):
