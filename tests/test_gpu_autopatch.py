@@ -315,3 +315,37 @@ def test_deferred_adam_under_the_unmodified_trainer_equals_the_separate_step(mon
             assert bad < 3e-3, (i, k, bad)
     for k in RAW:      # the dropped step left the model bit for bit alone
         assert torch.equal(sa[1][k], sa[0][k])
+
+
+def test_deferred_adam_at_sh_degree_zero_skips_the_rest_group_like_the_separate_step(monkeypatch):
+    """The reference starts every model at active SH degree 0 (gaussian_model_ht.py:68; all of stage A stays there): f_rest then has
+    an identically zero gradient and, while its moments are zero, the in-kernel update leaves the group out (no shadow to adopt).
+    The deferred route must keep the six step counts and the parameters in line with the separate-step route through the first
+    iterations at degree 0 and across the step up to degree 1."""
+    dev = torch.device("cuda:0")
+    W, H, N = 256, 192, 5000
+    sc = parity.syn.make_scene(N, W, H, sh_degree=3, seed=14)
+    sc["sh_degree"] = 0
+    gt = parity.syn.target_image(W, H, seed=5).to(dev)
+    cam = refstub.StubCamera.from_scene(sc, dev, original_image=gt)
+    out = {}
+    for deferred in (True, False):
+        monkeypatch.setenv("GSR_AUTOPATCH_DEFERRED", "1" if deferred else "0")
+        p, r = _autopatched_model(sc, dev)
+        rest0 = p._features_rest.detach().clone()
+        for _ in range(3):
+            _iteration(r, cam, gt)
+        assert torch.equal(p._features_rest.detach(), rest0)          # degree 0: the bands above it never move
+        p.oneup_sh_degree()
+        for _ in range(2):
+            _iteration(r, cam, gt)
+        assert not torch.equal(p._features_rest.detach(), rest0)
+        o = p.optimizer
+        out[deferred] = ({k: getattr(p, k).detach().clone() for k in RAW},
+                         {g["name"]: int(o.state[g["params"][0]]["step"]) for g in o.param_groups})
+    assert out[True][1] == out[False][1] and set(out[True][1].values()) == {5}, (out[True][1], out[False][1])
+    lrs = {"_xyz": 0.00016, "_features_dc": 0.0025, "_features_rest": 0.0025 / 20.0, "_opacity": 0.05, "_scaling": 0.005, "_rotation": 0.001}
+    for k in RAW:
+        a, b = out[True][0][k], out[False][0][k]
+        bad = ((a - b).abs() > 0.05 * lrs[k] + 5e-7 * b.abs()).float().mean().item()
+        assert bad < 3e-3, (k, bad)

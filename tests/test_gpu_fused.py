@@ -825,3 +825,40 @@ def test_three_pass_depth_sort_and_its_window_overflow():
     finally:
         lib.gsr_set_option(b"depth_sort9", 1)
         lib.gsr_set_option(b"reset_speculation", 1)
+
+
+def test_balanced_blend_placement_survives_more_views_than_the_cache_holds():
+    """The per-view visit cache of the forward blend holds 32 views (least recently used out): a walk over 40 cameras, twice --
+    every second visit a hit on a live entry or a miss on an evicted one -- renders each view bit-identically with the placement
+    switched off."""
+    import importlib
+    L = importlib.import_module("3dgs_hierarchical_training_amd._lib")
+    R = importlib.import_module("3dgs_hierarchical_training_amd.rasterizer")
+    lib = L.load()
+    dev = torch.device("cuda:0")
+    W, H, N = 200, 150, 8000
+    sc = parity.syn.make_scene(N, W, H, sh_degree=1, seed=3, posed=False)
+    t = {k: sc[k].to(dev) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
+    sts = []
+    for v in range(40):
+        cam = parity.syn.make_scene(8, W, H, sh_degree=1, seed=100 + v, posed=True)
+        sts.append(ts.make_settings(dict(sc, viewmatrix=cam["viewmatrix"], projmatrix=cam["projmatrix"], campos=cam["campos"]), dev, 1))
+
+    def walk():
+        outs = []
+        for rep in range(2):
+            for st in sts:
+                o = R.GaussianRasterizer(st)(means3D=t["means3D"], means2D=torch.zeros(N, 3, device=dev), shs=t["shs"], colors_precomp=None,
+                                             opacities=t["opacities"], scales=t["scales"], rotations=t["rotations"], cov3D_precomp=None)
+                outs.append([x.clone() for x in o])
+        return outs
+    try:
+        assert lib.gsr_set_option(b"blend_balance", 0) == 0
+        a = walk()
+        assert lib.gsr_set_option(b"blend_balance", 1) == 0
+        b = walk()
+    finally:
+        lib.gsr_set_option(b"blend_balance", 1)
+    for i, (x, y) in enumerate(zip(a, b)):
+        for u, v in zip(x, y):
+            assert torch.equal(u, v), i
