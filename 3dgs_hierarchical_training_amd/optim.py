@@ -341,7 +341,10 @@ class FusedAdam:
                 st["exp_avg"], st["exp_avg_sq"] = pend["mo"][k], pend["vo"][k]
                 st["step"] = _step_int(st["step"]) + 1
                 adopted = True
-        self._plan_cache = None
+                c = self._plan_cache       # keep the next plan on its fast path: the cached moment lists follow the swap
+                if c is not None and c[3][k] is st:
+                    c[4][k], c[5][k] = st["exp_avg"], st["exp_avg_sq"]
+        self._skip_lists = None            # (built from the moment lists)
         return adopted
 
     def fused_backward_args(self, tensors: Dict[str, torch.Tensor], sh_degree=None, next_sh_degree=None) -> "L.GsrFusedAdam":

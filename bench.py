@@ -921,6 +921,12 @@ def main():
             res["dropin"] = {"value": None, "error": repr(e)}
         try:
             res["dropin_autopatch"] = autopatch_leg(ts, scene, settings, gt, dev, steps=min(args.steps, 10), warmup=2)
+            # ... and at what stage A of the reference runs (~70 % of a scene's render calls): one single-image model of ~130 k
+            # Gaussians, active SH degree 0 with 16 coefficients stored (gaussian_model_ht.py:68), the same camera every iteration
+            sc_a = syn.make_scene(130_000, W, H, sh_degree=0, seed=3)
+            leg_a = autopatch_leg(ts, sc_a, ts.make_settings(sc_a, dev, 0), syn.target_image(W, H, seed=2).to(dev), dev, steps=40, warmup=10)
+            res["dropin_autopatch"]["stage_a_130k_degree0"] = {k: leg_a[k] for k in ("value", "ms_per_step", "separate_step_ms_per_step",
+                                                                                    "render_unpatched_ms_per_step", "steps")}
         except Exception as e:
             res["dropin_autopatch"] = {"value": None, "error": repr(e)}
         del params, den

@@ -1,5 +1,6 @@
 """gsr_autopatch on the GPU: the redirected optimizer and loss give what the stock torch pieces give."""
 import importlib
+import os
 
 import pytest
 import torch
@@ -155,7 +156,7 @@ def test_patched_pose_render_equals_get_xyz_route():
     assert _rel(xa, xb) < 1e-4
 
 
-def test_unmodified_trainer_sequence_on_the_patched_render():
+def test_unmodified_trainer_sequence_on_the_patched_render(monkeypatch):
     """The trainer's own iteration (ht3dgs_trainer.py:102-166) on the three patched pieces -- render_fused, Loss.forward,
     torch.optim.Adam -> FusedAdam -- against the stock pieces: same parameters after three iterations (Adam's first steps move
     every entry by ~lr whatever the gradient's size, so agreement is measured in units of lr), densification statistics included;
@@ -173,6 +174,7 @@ def test_unmodified_trainer_sequence_on_the_patched_render():
         gsr_autopatch.remove()
     pb = ts.GaussianParams(sc, dev, optimizer="torch")
     assert isinstance(pa.optimizer, optim.FusedAdam)
+    monkeypatch.setenv("GSR_AUTOPATCH_DEFERRED_MIN_N", "0")    # (exercise the deferred optimizer step on this small model too)
     ra, rb = refstub.StubRender(pa), refstub.StubRender(pb)
     cam = refstub.StubCamera.from_scene(sc, dev, original_image=gt)
 
@@ -261,6 +263,8 @@ def test_deferred_adam_under_the_unmodified_trainer_equals_the_separate_step(mon
     gt = parity.syn.target_image(W, H, seed=3).to(dev)
     cam = refstub.StubCamera.from_scene(sc, dev, original_image=gt)
 
+    monkeypatch.setenv("GSR_AUTOPATCH_DEFERRED_MIN_N", "0")      # (the route is meant for large models; the scenarios run on a small one)
+
     def scenario(deferred):
         monkeypatch.setenv("GSR_AUTOPATCH_DEFERRED", "1" if deferred else "0")
         p, r = _autopatched_model(sc, dev)
@@ -329,6 +333,7 @@ def test_deferred_adam_at_sh_degree_zero_skips_the_rest_group_like_the_separate_
     gt = parity.syn.target_image(W, H, seed=5).to(dev)
     cam = refstub.StubCamera.from_scene(sc, dev, original_image=gt)
     out = {}
+    monkeypatch.setenv("GSR_AUTOPATCH_DEFERRED_MIN_N", "0")
     for deferred in (True, False):
         monkeypatch.setenv("GSR_AUTOPATCH_DEFERRED", "1" if deferred else "0")
         p, r = _autopatched_model(sc, dev)
