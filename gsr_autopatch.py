@@ -25,8 +25,8 @@ Importing this module BEFORE the trainer swaps both for the HIP kernels of this 
     that step's Adam update into SHADOW buffers (the model untouched) and `optimizer.step()` adopts it by swapping storages: the
     trainer's order -- densify / prune / opacity reset BEFORE the step, `update_gaussians=False`, the update dropped when
     `densify_and_prune` replaces every parameter (ht3dgs_trainer.py:137-160) -- is untouched, the separate 1.65 kB-per-Gaussian
-    optimizer pass is gone.  (`GSR_AUTOPATCH_DEFERRED=0`: gradients to .grad and a one-launch FusedAdam.step() instead -- which is
-    also what models below `GSR_AUTOPATCH_DEFERRED_MIN_N` = 250 000 Gaussians get: they are bound by the host's launch path.)  The returned dict is the
+    optimizer pass is gone.  (`GSR_AUTOPATCH_DEFERRED=0`: gradients to .grad and a one-launch FusedAdam.step() instead;
+    `GSR_AUTOPATCH_DEFERRED_MIN_N`: the same for models below that many Gaussians, default 0.)  The returned dict is the
     reference's (`image` clamped, `depth`, `alpha`, `viewspace_points` whose .grad the backward fills, `visibility_filter`,
     `radii`).  `override_color`, `compute_cov3D_python`, `convert_SHs_python`, CPU tensors or an unexpected parameter layout
     fall back to the ORIGINAL method.  `GSR_AUTOPATCH_RENDER=0` leaves the method alone; `GSR_AUTOPATCH_POSE=0` keeps pose
@@ -216,10 +216,10 @@ def render_fused(self, viewpoint_camera, scaling_modifier=1.0, invert_bg_color=F
     opt, deferred = getattr(g, "optimizer", None), False
     if opt is not None and hasattr(opt, "deferred_ready") and torch.is_grad_enabled() and os.environ.get("GSR_AUTOPATCH_DEFERRED", "1") != "0":
         opt.flush_pending_as_grads()
-        # (small models -- stage A's ~130 k Gaussians -- are bound by the host's launch path, where adopting the shadows costs more
-        #  Python than the separate one-launch step costs device time: measured 0.45 against 0.42 ms per step at 130 k, 0.90 against
-        #  0.99 ms at 1 M)
-        if xyz.shape[0] >= int(os.environ.get("GSR_AUTOPATCH_DEFERRED_MIN_N", "250000")):
+        # (GSR_AUTOPATCH_DEFERRED_MIN_N: models below that many Gaussians keep the separate step; default 0 -- measured with the
+        #  route's own order bias removed, the deferred step is the faster one at stage A's 130 k Gaussians too: 0.375 against
+        #  0.40-0.42 ms per step; 0.90 against 0.98 ms at 1 M)
+        if xyz.shape[0] >= int(os.environ.get("GSR_AUTOPATCH_DEFERRED_MIN_N", "0")):
             deferred = opt.deferred_ready({"xyz": xyz, "f_dc": f_dc, "f_rest": f_rest, "opacity": opacity, "scaling": scaling, "rotation": rotation})
     image_raw, radii, depth, alpha = R.rasterize_gaussians_raw(xyz, screenspace_points, f_dc, f_rest, opacity, scaling, rotation,
                                                                settings, points_transform=M, fused_adam=opt if deferred else None,
