@@ -1241,10 +1241,12 @@ __global__ __launch_bounds__(256) void k_bwd_prologue(float4* __restrict__ gg4, 
     if (tid < kItemBuckets) s_cur[tid] = 0u;
     __syncthreads();
     auto items_of = [&](int tile) -> int {      // the run [0, kCkptFirst) first, then one item per 128-instance batch
+        if (!split_ok) return 1;                // (no checkpoints -- a forward variant that leaves none, or "bwd_split" 1: the whole tile, whatever
+                                                //  the staged counters say: those variants do not all write them)
         const uint4 sd = *reinterpret_cast<const uint4*>(staged4 + 4 * tile);
         const int nbs = ((int)max(max(sd.x, sd.y), max(sd.z, sd.w)) + 127) / 128;
         if (nbs == 0) return 0;
-        return (!split_ok || nbs <= kCkptFirst) ? 1 : 1 + nbs - kCkptFirst;
+        return nbs <= kCkptFirst ? 1 : 1 + nbs - kCkptFirst;
     };
     const int slots = tpad >> 3;
     for (int k = tid; k < slots; k += 256) {
