@@ -110,6 +110,18 @@ def _register_fakes():
           beta1, beta2, eps, step):
         return None
 
+    @torch.library.register_fake("gsr::masked_max_")
+    def _(dst, src, mask):
+        return None
+
+    @torch.library.register_fake("gsr::densify_stats_add_")
+    def _(accum, denom, grad, mask):
+        return None
+
+    @torch.library.register_fake("gsr::psnr")
+    def _(a, b):
+        return a.new_empty((a.shape[0], 1), dtype=torch.float32)
+
     @torch.library.register_fake("gsr::mark_visible")
     def _(means3D, viewmatrix, projmatrix):
         return means3D.new_empty((means3D.shape[0],), dtype=torch.bool)

@@ -8,6 +8,7 @@
 //   m += (g - m)(1 - b1);  v = b2 v + (1 - b2) g^2;  p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <algorithm>
 
 #include "../../include/gsr.h"
 #include "adam_math.h"
@@ -301,5 +302,87 @@ extern "C" int gsr_stream_copy(const void* src, void* dst, size_t bytes, int var
     else if (variant == 1) hipLaunchKernelGGL(gsr::k_stream_copy<1>, dim3(blocks), dim3(256), 0, st, s, d, n4);
     else if (variant == 2) hipLaunchKernelGGL(gsr::k_stream_copy<2>, dim3(blocks), dim3(256), 0, st, s, d, n4);
     else return GSR_ERR_ARG;
+    return hipGetLastError() == hipSuccess ? GSR_OK : GSR_ERR_HIP;
+}
+
+
+// ---- the trainer's per-iteration bookkeeping as three one-launch kernels (round 4; gsr_autopatch) ----------------------------------
+// Between backward() and optimizer.step() the reference's train step (trainer/ht3dgs_trainer.py:137-148) evaluates, under
+// no_grad, the training PSNR (utils/image_utils.py:16-18: ~10 small torch kernels), the running maximum of the visible Gaussians'
+// screen radii (three boolean-mask index operations) and the densification statistics (scene/gaussian_model_ht.py:718-721: three
+// more).  On models of stage A's size the iteration is bound by the host's launch path, so those ~25 launches are a third of it.
+namespace gsr {
+__global__ __launch_bounds__(256) void k_masked_max(float* __restrict__ dst, const int32_t* __restrict__ src, const uint8_t* __restrict__ mask, int n)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n && mask[i]) dst[i] = fmaxf(dst[i], (float)src[i]);
+}
+
+__global__ __launch_bounds__(256) void k_densify_stats_add(float* __restrict__ accum, float* __restrict__ denom, const float* __restrict__ grad3,
+                                                           const uint8_t* __restrict__ mask, int n)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n && mask[i]) {
+        const float gx = grad3[3 * (size_t)i], gy = grad3[3 * (size_t)i + 1];
+        accum[i] += sqrtf(gx * gx + gy * gy);
+        denom[i] += 1.f;
+    }
+}
+
+// per channel: sum of squared differences over P pixels (partials per block), then 20 log10(1 / sqrt(mse)) by one small block
+__global__ __launch_bounds__(256) void k_psnr_partial(const float* __restrict__ a, const float* __restrict__ b, int C, long long P,
+                                                      float* __restrict__ partial /*[blocks][C]*/)
+{
+    __shared__ float s_red[4];
+    const int tid = threadIdx.x;
+    for (int c = 0; c < C; c++) {
+        float acc = 0.f;
+        const float* pa = a + (size_t)c * P;
+        const float* pb = b + (size_t)c * P;
+        for (long long i = (long long)blockIdx.x * 256 + tid; i < P; i += (long long)gridDim.x * 256) { const float d = pa[i] - pb[i]; acc = fmaf(d, d, acc); }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        if ((tid & 63) == 0) s_red[tid >> 6] = acc;
+        __syncthreads();
+        if (tid == 0) partial[(size_t)blockIdx.x * C + c] = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(64) void k_psnr_finish(const float* __restrict__ partial, int blocks, int C, long long P, float* __restrict__ out)
+{
+    for (int c = threadIdx.x; c < C; c += 64) {
+        double sse = 0.0;
+        for (int k = 0; k < blocks; k++) sse += (double)partial[(size_t)k * C + c];
+        const float mse = (float)(sse / (double)P);
+        out[c] = 20.f * log10f(1.0f / sqrtf(mse));
+    }
+}
+}  // namespace gsr
+
+extern "C" int gsr_masked_max(float* dst, const int32_t* src, const uint8_t* mask, int32_t n, void* stream)
+{
+    if (n <= 0) return GSR_OK;
+    if (!dst || !src || !mask) return GSR_ERR_ARG;
+    hipLaunchKernelGGL(gsr::k_masked_max, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, dst, src, mask, n);
+    return hipGetLastError() == hipSuccess ? GSR_OK : GSR_ERR_HIP;
+}
+
+extern "C" int gsr_densify_stats_add(float* xyz_gradient_accum, float* denom, const float* viewspace_grad3, const uint8_t* mask, int32_t n, void* stream)
+{
+    if (n <= 0) return GSR_OK;
+    if (!xyz_gradient_accum || !denom || !viewspace_grad3 || !mask) return GSR_ERR_ARG;
+    hipLaunchKernelGGL(gsr::k_densify_stats_add, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, xyz_gradient_accum, denom, viewspace_grad3, mask, n);
+    return hipGetLastError() == hipSuccess ? GSR_OK : GSR_ERR_HIP;
+}
+
+extern "C" size_t gsr_psnr_scratch_bytes(int32_t C) { return (size_t)256 * (size_t)(C > 0 ? C : 1) * sizeof(float); }
+
+extern "C" int gsr_psnr(const float* a, const float* b, int32_t C, int64_t P, float* out, void* scratch, void* stream)
+{
+    if (!a || !b || !out || !scratch || C <= 0 || P <= 0) return GSR_ERR_ARG;
+    const int blocks = (int)std::min<int64_t>(256, (P + 255) / 256);
+    hipLaunchKernelGGL(gsr::k_psnr_partial, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, b, C, (long long)P, static_cast<float*>(scratch));
+    hipLaunchKernelGGL(gsr::k_psnr_finish, dim3(1), dim3(64), 0, (hipStream_t)stream, static_cast<const float*>(scratch), blocks, C, (long long)P, out);
     return hipGetLastError() == hipSuccess ? GSR_OK : GSR_ERR_HIP;
 }

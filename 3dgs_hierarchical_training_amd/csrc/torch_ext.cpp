@@ -645,6 +645,48 @@ Tensor knn_mean_dist2(const Tensor& points_)
 
 }  // namespace
 
+// ---- the trainer's per-iteration bookkeeping (gsr_masked_max / gsr_densify_stats_add / gsr_psnr; include/gsr.h) ------------------
+void masked_max_(Tensor dst, const Tensor& src, const Tensor& mask)
+{
+    TORCH_CHECK(dst.is_cuda(), "masked_max_: tensors must be on a ROCm/HIP device (no CPU fallback)");
+    const c10::hip::HIPGuardMasqueradingAsCUDA guard(dst.device());
+    TORCH_CHECK(dst.is_contiguous() && dst.scalar_type() == at::kFloat && src.is_contiguous() && src.scalar_type() == at::kInt &&
+                mask.is_contiguous() && mask.scalar_type() == at::kBool && dst.dim() == 1 && src.numel() == dst.numel() && mask.numel() == dst.numel(),
+                "masked_max_: dst float32 [n], src int32 [n], mask bool [n], contiguous");
+    check(gsr_masked_max(dst.data_ptr<float>(), src.data_ptr<int32_t>(), reinterpret_cast<const uint8_t*>(mask.data_ptr<bool>()), (int32_t)dst.numel(),
+                         c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()), "gsr_masked_max");
+    torch::autograd::impl::bump_version(dst);
+}
+
+void densify_stats_add_(Tensor accum, Tensor denom, const Tensor& grad, const Tensor& mask)
+{
+    TORCH_CHECK(accum.is_cuda(), "densify_stats_add_: tensors must be on a ROCm/HIP device (no CPU fallback)");
+    const c10::hip::HIPGuardMasqueradingAsCUDA guard(accum.device());
+    const int64_t n = mask.numel();
+    TORCH_CHECK(accum.is_contiguous() && denom.is_contiguous() && grad.is_contiguous() && mask.is_contiguous() && accum.scalar_type() == at::kFloat &&
+                denom.scalar_type() == at::kFloat && grad.scalar_type() == at::kFloat && mask.scalar_type() == at::kBool && accum.numel() == n &&
+                denom.numel() == n && grad.numel() == 3 * n, "densify_stats_add_: accum / denom float32 [n(,1)], grad float32 [n,3], mask bool [n], contiguous");
+    check(gsr_densify_stats_add(accum.data_ptr<float>(), denom.data_ptr<float>(), grad.data_ptr<float>(),
+                                reinterpret_cast<const uint8_t*>(mask.data_ptr<bool>()), (int32_t)n,
+                                c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()), "gsr_densify_stats_add");
+    torch::autograd::impl::bump_version(accum);
+    torch::autograd::impl::bump_version(denom);
+}
+
+Tensor psnr(const Tensor& a, const Tensor& b)
+{
+    TORCH_CHECK(a.is_cuda(), "psnr: tensors must be on a ROCm/HIP device (no CPU fallback)");
+    const c10::hip::HIPGuardMasqueradingAsCUDA guard(a.device());
+    const Tensor x = f32c(a), y = f32c(b);
+    TORCH_CHECK(x.dim() >= 2 && x.sizes() == y.sizes(), "psnr: two images of the same shape [C, ...]");
+    const int64_t C = x.size(0), P = x.numel() / C;
+    Tensor out = at::empty({C, 1}, x.options());
+    Tensor scratch = at::empty({(int64_t)gsr_psnr_scratch_bytes((int32_t)C)}, x.options().dtype(at::kByte));
+    check(gsr_psnr(x.data_ptr<float>(), y.data_ptr<float>(), (int32_t)C, P, out.data_ptr<float>(), scratch.data_ptr(),
+                   c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()), "gsr_psnr");
+    return out;
+}
+
 TORCH_LIBRARY(gsr, m)
 {
     m.def("rasterize_forward(Tensor means3D, Tensor sh, Tensor colors_precomp, Tensor opacities, Tensor scales, Tensor rotations, "
@@ -682,6 +724,9 @@ TORCH_LIBRARY(gsr, m)
           "Tensor d_campos, Tensor projection_T, Tensor base, Tensor(d!) viewmatrix, Tensor(e!) projmatrix, Tensor(f!) campos, float lr, "
           "float beta1, float beta2, float eps, int step) -> ()");
     m.def("knn_mean_dist2(Tensor points) -> Tensor");
+    m.def("masked_max_(Tensor(a!) dst, Tensor src, Tensor mask) -> ()");
+    m.def("densify_stats_add_(Tensor(a!) accum, Tensor(b!) denom, Tensor grad, Tensor mask) -> ()");
+    m.def("psnr(Tensor a, Tensor b) -> Tensor");
     m.def("debug_last() -> Tensor[]", &debug_last);
 }
 
@@ -697,6 +742,9 @@ TORCH_LIBRARY_IMPL(gsr, CUDA, m)   // the dispatch key of HIP tensors on a ROCm 
     m.impl("pose_step", &pose_step);
     m.impl("pose_step_camera", &pose_step_camera);
     m.impl("knn_mean_dist2", &knn_mean_dist2);
+    m.impl("masked_max_", &masked_max_);
+    m.impl("densify_stats_add_", &densify_stats_add_);
+    m.impl("psnr", &psnr);
     m.impl("rasterize", &rasterize_forward_only);
     m.impl("photometric_loss", &photometric_loss_no_grad);
 }

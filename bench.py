@@ -323,8 +323,10 @@ def autopatch_leg(ts, scene, settings, gt, dev, steps, warmup):
     anything the trainer does between backward() and step() keeps the reference's meaning (optim.FusedAdam, deferred application) --,
     `zero_grad`.  No reference file is edited; the hand-over of the next preprocess is not used (the trainer draws its frames at
     random).  `separate_step_ms_per_step` = the same with GSR_AUTOPATCH_DEFERRED=0 (gradients to .grad, one-launch FusedAdam.step()).
-    `with_bookkeeping` adds what the trainer runs under no_grad between backward and step on a densifying iteration: psnr,
-    the max_radii2D update (the trainer's own boolean-mask statement) and add_densification_stats (patched: masked adds)."""
+    `with_bookkeeping` adds what the trainer runs under no_grad between backward and step on a densifying iteration: psnr
+    (patched: gsr_psnr), the max_radii2D update (the trainer's own boolean-mask statement, on the patched render's LazyMask: one
+    launch) and add_densification_stats (patched: one launch); `with_stock_bookkeeping` = the same three as the reference wrote
+    them (torch psnr, a plain bool mask: three `nonzero` synchronisations each)."""
     import gsr_autopatch
     refstub = importlib.import_module("3dgs_hierarchical_training_amd.refstub")
     gsr_autopatch.apply()
@@ -342,18 +344,26 @@ def autopatch_leg(ts, scene, settings, gt, dev, steps, warmup):
             cfg = _Cfg()
         loss_obj = _Loss()
 
-        def step(book):
+        def stock_psnr(a, b):                                    # utils/image_utils.py:16-18
+            mse = ((a - b) ** 2).view(a.shape[0], -1).mean(1, keepdim=True)
+            return 20 * torch.log10(1.0 / torch.sqrt(mse))
+
+        def step(book, stock=False):
             pkg = gsr_autopatch.render_fused(r, cam)
             d = gsr_autopatch.loss_forward(loss_obj, pkg["image"], gt)
             d["loss"].backward()
             with torch.no_grad():
                 if book:
                     g = r.gaussians
-                    mse = ((pkg["image"] - gt) ** 2).view(3, -1).mean(1, keepdim=True)           # utils/image_utils.py psnr
-                    (20 * torch.log10(1.0 / torch.sqrt(mse))).mean().double()
+                    (stock_psnr if stock else gsr_autopatch.psnr_fused)(pkg["image"], gt).mean().double()
                     vis, radii = pkg["visibility_filter"], pkg["radii"]
-                    g.max_radii2D[vis] = torch.max(g.max_radii2D[vis], radii[vis])
-                    gsr_autopatch.add_densification_stats_fused(g, pkg["viewspace_points"], vis)
+                    if stock:
+                        vis = vis.as_subclass(torch.Tensor)
+                    g.max_radii2D[vis] = torch.max(g.max_radii2D[vis], radii[vis])     # the trainer's own statement
+                    if stock:
+                        refstub.StubGaussians.add_densification_stats(g, pkg["viewspace_points"], vis)
+                    else:
+                        gsr_autopatch.add_densification_stats_fused(g, pkg["viewspace_points"], vis)
                 p.optimizer.step()
                 p.optimizer.zero_grad(set_to_none=True)
         for i in range(warmup):
@@ -362,6 +372,9 @@ def autopatch_leg(ts, scene, settings, gt, dev, steps, warmup):
         for i in range(2):
             step(True)
         sec_b = timed_steps(lambda i: step(True), steps, dev)
+        for i in range(2):
+            step(True, stock=True)
+        sec_bs = timed_steps(lambda i: step(True, stock=True), steps, dev)
         prev_def = os.environ.get("GSR_AUTOPATCH_DEFERRED")
         os.environ["GSR_AUTOPATCH_DEFERRED"] = "0"
         try:
@@ -391,7 +404,8 @@ def autopatch_leg(ts, scene, settings, gt, dev, steps, warmup):
         gsr_autopatch.remove()
     del p
     return {"value": 1.0 / sec, "unit": "images/s", "ms_per_step": 1e3 * sec, "steps": steps, "optimizer_class": opt_cls,
-            "with_bookkeeping_ms_per_step": 1e3 * sec_b, "separate_step_ms_per_step": 1e3 * sec_sep,
+            "with_bookkeeping_ms_per_step": 1e3 * sec_b, "with_stock_bookkeeping_ms_per_step": 1e3 * sec_bs,
+            "separate_step_ms_per_step": 1e3 * sec_sep,
             "render_unpatched_ms_per_step": 1e3 * sec_old,
             "path": "`import gsr_autopatch` + the unmodified trainer's calls: CF3DGS_Render.render (patched: raw parameters -> "
                     "rasterize_gaussians_raw, in-kernel exp / sigmoid / normalize / cat) -> Loss.forward (patched: fused clamp + L1 + SSIM) "
@@ -930,8 +944,8 @@ def main():
             # Gaussians, active SH degree 0 with 16 coefficients stored (gaussian_model_ht.py:68), the same camera every iteration
             sc_a = syn.make_scene(130_000, W, H, sh_degree=0, seed=3)
             leg_a = autopatch_leg(ts, sc_a, ts.make_settings(sc_a, dev, 0), syn.target_image(W, H, seed=2).to(dev), dev, steps=40, warmup=10)
-            res["dropin_autopatch"]["stage_a_130k_degree0"] = {k: leg_a[k] for k in ("value", "ms_per_step", "separate_step_ms_per_step",
-                                                                                    "render_unpatched_ms_per_step", "steps")}
+            res["dropin_autopatch"]["stage_a_130k_degree0"] = {k: leg_a[k] for k in ("value", "ms_per_step", "with_bookkeeping_ms_per_step",
+                                                                                    "with_stock_bookkeeping_ms_per_step", "separate_step_ms_per_step", "render_unpatched_ms_per_step", "steps")}
         except Exception as e:
             res["dropin_autopatch"] = {"value": None, "error": repr(e)}
         del params, den

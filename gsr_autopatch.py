@@ -32,7 +32,11 @@ Importing this module BEFORE the trainer swaps both for the HIP kernels of this 
     fall back to the ORIGINAL method.  `GSR_AUTOPATCH_RENDER=0` leaves the method alone; `GSR_AUTOPATCH_POSE=0` keeps pose
     renders (rotate_xyz / rotate_seq) on the original method.
   * `HTGaussianModel.add_densification_stats` (same module) accumulates the same two sums without the boolean-mask gathers
-    (each of them a `nonzero` + host synchronisation): masked adds over N.
+    (each of them a `nonzero` + host synchronisation): one masked-add launch over N (gsr_densify_stats_add).
+  * the render's `visibility_filter` is a bool-tensor subclass (`LazyMask`) under which the trainer's
+    `max_radii2D[vis] = torch.max(max_radii2D[vis], radii[vis])` is one launch (gsr_masked_max) instead of three `nonzero`s;
+    `utils.image_utils.psnr` (the training PSNR of every iteration) is two launches (gsr_psnr).  `GSR_AUTOPATCH_LAZY_MASK=0` /
+    `GSR_AUTOPATCH_PSNR=0` switch those off.
 
 `apply()` / `remove()` switch the patches on and off (importing the module calls `apply()`); `GSR_AUTOPATCH=0` disables them.
 The rasterizer itself needs no patch: `diff_gaussian_rasterization` IS this library's drop-in package.
@@ -63,6 +67,10 @@ _REQUIRE_CUDA = True                # (tests drive the dispatch logic with CPU s
 
 def _pkg():
     return importlib.import_module("3dgs_hierarchical_training_amd.optim"), importlib.import_module("3dgs_hierarchical_training_amd.loss")
+
+
+def _ops():
+    return importlib.import_module("3dgs_hierarchical_training_amd._ext").load()
 
 
 def _wants_fused(params, kw) -> bool:
@@ -143,6 +151,94 @@ def loss_forward(self, rgb_pred, rgb_gt, depth_pred=None, depth_gt=None, rgb_los
     else:
         depth_loss = torch.zeros((), device=rgb_pred.device)
     return {'loss': loss, 'loss_rgb': rgb_full_loss, 'loss_dssim': dssim_loss, 'loss_depth': depth_loss}
+
+
+# ---- the visibility mask of the patched render: boolean-mask statements without their host synchronisations ------------------------
+# The trainer's per-iteration statistics statement (/root/reference/trainer/ht3dgs_trainer.py:143-144),
+#     gaussians.max_radii2D[visibility_filter] = torch.max(gaussians.max_radii2D[visibility_filter], radii[visibility_filter])
+# is three boolean-mask index operations, each a `nonzero` with a host synchronisation that drains the launch queue -- +0.4 ms per
+# iteration at every model size, in stage A as well (the statistics run on every iteration below `densify_until_iter`).  The mask
+# this module's render returns is a bool tensor SUBCLASS that recognises exactly that pattern through `__torch_function__`:
+# `dense[mask]` becomes a lazy selection (nothing gathered), `torch.max(selection, selection)` the element-wise maximum of the dense
+# tensors, `dense[mask] = selection` one `torch.where` written in place -- the same values, no `nonzero`.  Anything else done with the
+# mask or a selection (arithmetic, .sum(), printing, indexing other shapes ...) falls back to the plain tensors, gathered for real.
+# GSR_AUTOPATCH_LAZY_MASK=0: the render returns a plain bool tensor.
+class _LazySelection:
+    """`dense[mask]` that has not been gathered.  Tensor-like only as far as the statement above needs; everything else
+    materialises."""
+
+    def __init__(self, dense, mask, max_of=None):
+        self._dense, self.mask, self.max_of = dense, mask, max_of      # max_of = (a, b): the element-wise maximum, not yet evaluated
+
+    @property
+    def dense(self):
+        if self._dense is None:
+            self._dense = torch.maximum(*self.max_of)
+        return self._dense
+
+    @property
+    def dense_shape(self):
+        return self.max_of[0].shape if self._dense is None else self._dense.shape
+
+    def materialise(self):
+        return self.dense[self.mask.as_subclass(torch.Tensor)]
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if func is torch.max and len(args) == 2 and not kwargs and isinstance(args[0], _LazySelection) and isinstance(args[1], _LazySelection) \
+                and args[0].mask is args[1].mask and args[0].dense_shape == args[1].dense_shape:
+            return _LazySelection(None, args[0].mask, max_of=(args[0].dense, args[1].dense))
+        unwrap = lambda a: a.materialise() if isinstance(a, _LazySelection) else a
+        return func(*[unwrap(a) for a in args], **{k: unwrap(v) for k, v in kwargs.items()})
+
+    def __getattr__(self, name):          # methods / properties of the gathered tensor (.shape, .sum(), .float(), ...)
+        return getattr(self.materialise(), name)
+
+    def __repr__(self):
+        return repr(self.materialise())
+
+
+def _lazy_dunder(name):
+    def f(self, *a, **k):
+        return getattr(self.materialise(), name)(*a, **k)
+    return f
+
+
+for _n in ("add", "radd", "sub", "rsub", "mul", "rmul", "truediv", "rtruediv", "neg", "abs", "lt", "le", "gt", "ge", "eq", "ne", "len",
+           "getitem", "iter", "float", "int", "bool", "and", "or", "invert", "pow", "matmul"):
+    setattr(_LazySelection, f"__{_n}__", _lazy_dunder(f"__{_n}__"))
+
+
+class LazyMask(torch.Tensor):
+    """The `visibility_filter` of the patched render: a bool tensor that turns `dense[mask]` / `dense[mask] = selection` on a
+    1-D tensor of its own length into their synchronisation-free forms (see above) and is an ordinary bool tensor otherwise."""
+
+    @staticmethod
+    def __new__(cls, mask):
+        return torch.Tensor._make_subclass(cls, mask, False)
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if func is torch.Tensor.__getitem__ and len(args) == 2 and isinstance(args[1], LazyMask) and type(args[0]) is torch.Tensor \
+                and args[0].dim() == 1 and args[0].shape == args[1].shape and not kwargs:
+            return _LazySelection(args[0], args[1])
+        if func is torch.Tensor.__setitem__ and len(args) == 3 and isinstance(args[1], LazyMask) and isinstance(args[2], _LazySelection) \
+                and args[2].mask is args[1] and type(args[0]) is torch.Tensor and args[0].shape == args[1].shape \
+                and args[2].dense_shape == args[0].shape and not kwargs:
+            dst, m, sel = args[0], args[1].as_subclass(torch.Tensor), args[2]
+            with torch._C.DisableTorchFunctionSubclass():
+                pair = getattr(sel, "max_of", None)         # torch.max(dst[mask], radii[mask]): one launch (gsr_masked_max)
+                if pair is not None and pair[0] is dst and dst.is_cuda and dst.dtype == torch.float32 and dst.is_contiguous() \
+                        and pair[1].dtype == torch.int32 and pair[1].is_contiguous() and m.is_contiguous() and not dst.requires_grad:
+                    _ops().masked_max_(dst, pair[1], m)
+                else:
+                    dst.copy_(torch.where(m, sel.dense.to(dst.dtype), dst))
+            return None
+        unwrap = lambda a: a.materialise() if isinstance(a, _LazySelection) else a
+        with torch._C.DisableTorchFunctionSubclass():
+            return func(*[unwrap(a) for a in args], **{k: unwrap(v) for k, v in kwargs.items()})
 
 
 # ---- CF3DGS_Render.render on the raw-parameter path ------------------------------------------------------------------------------
@@ -226,19 +322,29 @@ def render_fused(self, viewpoint_camera, scaling_modifier=1.0, invert_bg_color=F
                                                                fused_adam_deferred=deferred)
     image = image_raw.clamp(0, 1)
     image._gsr_raw = (image_raw, image._version)       # lets the patched Loss.forward fuse this clamp into the loss kernels
+    visible = radii > 0
+    if os.environ.get("GSR_AUTOPATCH_LAZY_MASK", "1") != "0":
+        visible = LazyMask(visible)            # (the trainer's boolean-mask statistics statement without its host synchronisations)
     return {"image": image, "depth": depth, "alpha": alpha, "viewspace_points": screenspace_points,
-            "visibility_filter": radii > 0, "radii": radii}
+            "visibility_filter": visible, "radii": radii}
 
 
 def add_densification_stats_fused(self, viewspace_point_tensor, update_filter):
     """Drop-in body of `HTGaussianModel.add_densification_stats` (/root/reference/scene/gaussian_model_ht.py:718-721): the same
     sums as masked adds over N instead of three boolean-mask gathers / scatters (each a `nonzero` and a host synchronisation)."""
+    if isinstance(update_filter, LazyMask):
+        update_filter = update_filter.as_subclass(torch.Tensor)
     g = viewspace_point_tensor.grad
     if g is None or update_filter.dtype != torch.bool or update_filter.dim() != 1 or update_filter.shape[0] != self.denom.shape[0]:
         orig = next((f for c, a, f in _patched_render_classes if a == "add_densification_stats" and isinstance(self, c)), None)
         if orig is None:
             raise RuntimeError("gsr_autopatch.add_densification_stats_fused: needs a [N] boolean filter and a populated .grad")
         return orig(self, viewspace_point_tensor, update_filter)
+    acc, den = self.xyz_gradient_accum, self.denom
+    if g.is_cuda and all(t.dtype == torch.float32 and t.is_contiguous() and not t.requires_grad for t in (acc, den, g)) and \
+            update_filter.is_contiguous() and acc.numel() == den.numel() == update_filter.shape[0] and tuple(g.shape) == (den.shape[0], 3):
+        _ops().densify_stats_add_(acc, den, g, update_filter)       # one launch (gsr_densify_stats_add)
+        return
     f = update_filter.unsqueeze(1)
     self.xyz_gradient_accum += torch.where(f, torch.norm(g[:, :2], dim=-1, keepdim=True), torch.zeros((), device=g.device, dtype=g.dtype))
     self.denom += f.to(self.denom.dtype)
@@ -256,6 +362,40 @@ def _patch_render_module(mod):
         setattr(cls, attr, fn)
 
 
+# ---- utils.image_utils.psnr: the training PSNR the trainer evaluates on every iteration (ht3dgs_trainer.py:138) ---------------------
+IMAGE_UTILS_MODULES = ("utils.image_utils",)
+_patched_psnr = []                  # [(module, attribute, original function)]
+
+
+def psnr_fused(img1, img2):
+    """Drop-in body of `psnr` (/root/reference/utils/image_utils.py:16-18): per-channel 20 log10(1 / sqrt(mse)), [C, 1], in two
+    launches (gsr_psnr) instead of the statement's nine.  Anything but two same-shaped float32 GPU images runs the original."""
+    if torch.is_tensor(img1) and torch.is_tensor(img2) and img1.is_cuda and img2.is_cuda and img1.dtype == torch.float32 and \
+            img2.dtype == torch.float32 and img1.dim() >= 2 and img1.shape == img2.shape and img1.numel() > 0 and \
+            not (torch.is_grad_enabled() and (img1.requires_grad or img2.requires_grad)):
+        return _ops().psnr(img1, img2)
+    orig = next((f for m, a, f in _patched_psnr if a == "psnr"), None)
+    if orig is None:
+        mse = (((img1 - img2)) ** 2).view(img1.shape[0], -1).mean(1, keepdim=True)
+        return 20 * torch.log10(1.0 / torch.sqrt(mse))
+    return orig(img1, img2)
+
+
+def _patch_image_utils_module(mod):
+    if os.environ.get("GSR_AUTOPATCH_PSNR", "1") == "0":
+        return
+    orig = getattr(mod, "psnr", None)
+    if orig is None or orig is psnr_fused or any(m is mod for m, _, _ in _patched_psnr):
+        return
+    _patched_psnr.append((mod, "psnr", orig))
+    mod.psnr = psnr_fused
+    # modules that did `from utils.image_utils import psnr` before this patch hold the original under their own name
+    for other in list(sys.modules.values()):
+        if other is not None and other is not mod and getattr(other, "__dict__", {}).get("psnr") is orig:
+            _patched_psnr.append((other, "psnr", orig))
+            other.psnr = psnr_fused
+
+
 def _patch_loss_module(mod):
     cls = getattr(mod, "Loss", None)
     if cls is None or any(c is cls for c, _ in _patched_loss_classes):
@@ -268,9 +408,10 @@ class _PostImportFinder(importlib.abc.MetaPathFinder):
     """Patches `trainer.losses` / `scene.gaussian_model_ht` right after they have been executed, whenever that import happens."""
 
     def find_spec(self, fullname, path, target=None):
-        if (fullname not in LOSS_MODULES and fullname not in RENDER_MODULES) or not _applied:
+        if (fullname not in LOSS_MODULES and fullname not in RENDER_MODULES and fullname not in IMAGE_UTILS_MODULES) or not _applied:
             return None
-        patch = _patch_loss_module if fullname in LOSS_MODULES else _patch_render_module
+        patch = _patch_loss_module if fullname in LOSS_MODULES else _patch_render_module if fullname in RENDER_MODULES \
+            else _patch_image_utils_module
         for finder in sys.meta_path:
             if finder is self or not hasattr(finder, "find_spec"):
                 continue
@@ -309,6 +450,9 @@ def apply():
     for name in RENDER_MODULES:
         if name in sys.modules:
             _patch_render_module(sys.modules[name])
+    for name in IMAGE_UTILS_MODULES:
+        if name in sys.modules:
+            _patch_image_utils_module(sys.modules[name])
 
 
 def remove():
@@ -326,6 +470,9 @@ def remove():
     while _patched_render_classes:
         cls, attr, fn = _patched_render_classes.pop()
         setattr(cls, attr, fn)
+    while _patched_psnr:
+        mod, attr, fn = _patched_psnr.pop()
+        setattr(mod, attr, fn)
 
 
 if os.environ.get("GSR_AUTOPATCH", "1") != "0":

@@ -362,6 +362,19 @@ int gsr_pose_step_camera(float* delta6, float* exp_avg6, float* exp_avg_sq6, con
                          const float* d_campos3, const float* projection_T16, const float* base12, float* viewmatrix16,
                          float* projmatrix16, float* campos3, float lr, float beta1, float beta2, float eps, int64_t step, void* stream);
 
+/* The trainer's per-iteration bookkeeping between backward() and optimizer.step() (trainer/ht3dgs_trainer.py:137-148), one launch
+ * each instead of the reference's ~25 small torch kernels (what gsr_autopatch routes the unmodified trainer's statements to):
+ *   gsr_masked_max         dst[i] = max(dst[i], (float)src[i]) where mask[i]: `max_radii2D[vis] = torch.max(max_radii2D[vis], radii[vis])`
+ *   gsr_densify_stats_add  HTGaussianModel.add_densification_stats (scene/gaussian_model_ht.py:718-721): accum[i] += |grad[i, :2]|,
+ *                          denom[i] += 1 where mask[i]; viewspace_grad3 = the [N,3] gradient of the screen-space points
+ *   gsr_psnr               utils/image_utils.py:16-18 `psnr(img1, img2)`: out[c] = 20 log10(1 / sqrt(mean_c (a - b)^2)) for C planes of P
+ *                          pixels each; scratch = gsr_psnr_scratch_bytes(C) bytes (two launches: partial sums, finish)
+ * mask: one byte per element (torch.bool). */
+int gsr_masked_max(float* dst, const int32_t* src, const uint8_t* mask, int32_t n, void* stream);
+int gsr_densify_stats_add(float* xyz_gradient_accum, float* denom, const float* viewspace_grad3, const uint8_t* mask, int32_t n, void* stream);
+size_t gsr_psnr_scratch_bytes(int32_t C);
+int gsr_psnr(const float* a, const float* b, int32_t C, int64_t P, float* out, void* scratch, void* stream);
+
 /* ---- "next" row f-1: simple_knn._C.distCUDA2 ----------------------------------------------------------------
  * out[i] = mean of the squared distances from points[i] to its 3 nearest other points (exact), the semantics of the
  * reference's SciPy twin /root/reference/scene/gaussian_model_ht.py:31-36; called at :211-216. */

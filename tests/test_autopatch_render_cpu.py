@@ -168,3 +168,59 @@ def test_patched_render_on_the_real_reference_classes():
     assert s["vm_is_cam"] and s["pm_is_cam"] and s["cp_is_cam"] and s["bg_is_model"] and s["deg"] == 0 and s["mod"] == 1.0
     assert abs(s["tanfovx"] - s["tanfovx_ref"]) < 1e-12 and s["prefiltered"] is False and s["debug"] is False
     assert r["image_clamped"] == 1.0 and r["pose_transform_shape"] == [4, 4] and r["vis_dtype"] == "torch.bool"
+
+
+def test_lazy_mask_statement_equals_boolean_mask_indexing(autopatch):
+    """The `visibility_filter` the patched render returns (gsr_autopatch.LazyMask): the trainer's statistics statement
+    (ht3dgs_trainer.py:143-144) gives the same result as with a plain bool mask -- float maxima of a float and an int32 tensor
+    included -- and everything else one may do with the mask or a selection behaves like the plain tensors."""
+    g = torch.Generator().manual_seed(7)
+    for n in (1, 5, 1000):
+        plain = torch.rand(n, generator=g) > 0.4
+        m = autopatch.LazyMask(plain.clone())
+        a = torch.rand(n, generator=g) * 30
+        r = torch.randint(0, 40, (n,), generator=g, dtype=torch.int32)
+        b = a.clone()
+        a[m] = torch.max(a[m], r[m])
+        b[plain] = torch.max(b[plain], r[plain])
+        assert torch.equal(a, b) and a.dtype == torch.float32
+        # fall-backs: a selection used any other way is the gathered tensor; the mask is a bool tensor
+        assert torch.equal(a[m] * 2 + 1, b[plain] * 2 + 1) and a[m].shape == b[plain].shape and float(a[m].sum()) == float(b[plain].sum())
+        assert torch.equal(~m, ~plain) and int(m.sum()) == int(plain.sum()) and m.dtype == torch.bool and torch.equal(m & plain, plain)
+        x = torch.arange(2 * n, dtype=torch.float32).reshape(n, 2)
+        assert torch.equal(x[m], x[plain])                         # other shapes: ordinary indexing
+        c = a.clone(); c[m] = 5.0
+        d = b.clone(); d[plain] = 5.0
+        assert torch.equal(c, d)
+        if int(plain.sum()):
+            assert float(torch.max(a[m])) == float(torch.max(b[plain]))
+        m2 = autopatch.LazyMask(plain.clone())
+        e = a.clone(); e[m2] = torch.max(a[m], r[m])                # selections of ANOTHER mask object: the general path
+        assert torch.equal(e, b)
+
+
+def test_psnr_is_patched_in_image_utils_and_in_modules_that_imported_it_before(monkeypatch):
+    """`from utils.image_utils import psnr` binds the function in the trainer module: apply() replaces it in both places, remove()
+    restores both; CPU tensors keep running the original statement."""
+    import sys
+    import types
+    import gsr_autopatch
+    gsr_autopatch.remove()
+    iu, tr = types.ModuleType("utils.image_utils"), types.ModuleType("trainer_like")
+
+    def psnr(img1, img2):
+        mse = (((img1 - img2)) ** 2).view(img1.shape[0], -1).mean(1, keepdim=True)
+        return 20 * torch.log10(1.0 / torch.sqrt(mse))
+    iu.psnr = psnr
+    tr.psnr = psnr
+    monkeypatch.setitem(sys.modules, "utils.image_utils", iu)
+    monkeypatch.setitem(sys.modules, "trainer_like", tr)
+    gsr_autopatch.apply()
+    try:
+        assert iu.psnr is gsr_autopatch.psnr_fused and tr.psnr is gsr_autopatch.psnr_fused
+        a, b = torch.rand(3, 6, 5), torch.rand(3, 6, 5)
+        assert torch.equal(tr.psnr(a, b), psnr(a, b))
+    finally:
+        gsr_autopatch.remove()
+    assert iu.psnr is psnr and tr.psnr is psnr
+    gsr_autopatch.apply()

@@ -206,6 +206,9 @@ def test_unmodified_trainer_sequence_on_the_patched_render(monkeypatch):
         bad = ((a - b).abs() > 0.05 * lrs[name] + 5e-7 * b.abs()).float().mean().item()
         assert bad < 2e-3, (k, bad)
     assert torch.equal(ra.gaussians.denom, rb.gaussians.denom)
+    # the trainer's boolean-mask statement ran on the patched render's LazyMask (no nonzero / host synchronisation): same maxima
+    assert isinstance(pkg["visibility_filter"], gsr_autopatch.LazyMask) and type(pkg_b["visibility_filter"]) is torch.Tensor
+    assert torch.equal(ra.gaussians.max_radii2D, rb.gaussians.max_radii2D) and float(ra.gaussians.max_radii2D.max()) > 0
     assert _rel(ra.gaussians.xyz_gradient_accum, rb.gaussians.xyz_gradient_accum) < 1e-3
     assert pa.optimizer.step_count == 3
     # a densify iteration: the surgery replaces every parameter by a fresh leaf (grad None) before the step
@@ -354,3 +357,50 @@ def test_deferred_adam_at_sh_degree_zero_skips_the_rest_group_like_the_separate_
         a, b = out[True][0][k], out[False][0][k]
         bad = ((a - b).abs() > 0.05 * lrs[k] + 5e-7 * b.abs()).float().mean().item()
         assert bad < 3e-3, (k, bad)
+
+
+def test_bookkeeping_kernels_equal_the_trainers_torch_statements():
+    """gsr_masked_max / gsr_densify_stats_add / gsr_psnr against the statements they replace (ht3dgs_trainer.py:138,143-144,
+    gaussian_model_ht.py:718-721, utils/image_utils.py:16-18), through the patched entry points."""
+    import gsr_autopatch
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(5)
+    for N in (1, 63, 257, 100_003):
+        radii = torch.randint(0, 40, (N,), generator=g, dtype=torch.int32).to(dev)
+        radii[::3] = 0
+        maxr = (torch.rand(N, generator=g) * 30).to(dev)
+        grad = torch.randn(N, 3, generator=g).to(dev)
+        accum, denom = torch.rand(N, 1, generator=g).to(dev), torch.randint(0, 5, (N, 1), generator=g).float().to(dev)
+        vis = radii > 0
+        # the reference's statements on a plain bool mask
+        maxr_ref, accum_ref, denom_ref = maxr.clone(), accum.clone(), denom.clone()
+        maxr_ref[vis] = torch.max(maxr_ref[vis], radii[vis])
+        accum_ref[vis] += torch.norm(grad[vis, :2], dim=-1, keepdim=True)
+        denom_ref[vis] += 1
+        # the same statement on the patched render's mask + the patched method
+        lazy = gsr_autopatch.LazyMask(vis)
+        maxr[lazy] = torch.max(maxr[lazy], radii[lazy])
+        assert torch.equal(maxr, maxr_ref)
+
+        class _G:
+            pass
+        gg = _G()
+        gg.xyz_gradient_accum, gg.denom = accum, denom
+        vp = torch.zeros(N, 3, device=dev, requires_grad=True)
+        vp.grad = grad
+        with torch.no_grad():
+            gsr_autopatch.add_densification_stats_fused(gg, vp, lazy)
+        assert gg.xyz_gradient_accum is accum and torch.equal(denom, denom_ref)
+        assert torch.allclose(accum, accum_ref, rtol=2e-6, atol=1e-7)
+    for shape in ((3, 545, 980), (3, 7, 5), (1, 64, 64), (4, 1, 1)):
+        a, b = torch.rand(shape, generator=g).to(dev), torch.rand(shape, generator=g).to(dev)
+        mse = ((a - b) ** 2).view(a.shape[0], -1).mean(1, keepdim=True)
+        want = 20 * torch.log10(1.0 / torch.sqrt(mse))
+        got = gsr_autopatch.psnr_fused(a, b)
+        assert got.shape == want.shape and torch.allclose(got, want, rtol=0, atol=2e-4), (shape, got, want)
+        a.requires_grad_(True)                                   # outside no_grad with a differentiable input: the original statement
+        assert gsr_autopatch.psnr_fused(a, b).requires_grad
+        with torch.no_grad():
+            assert torch.allclose(gsr_autopatch.psnr_fused(a, b), want, rtol=0, atol=2e-4)
+    same = torch.rand(3, 8, 8, device=dev)
+    assert torch.isinf(gsr_autopatch.psnr_fused(same, same.clone())).all()       # mse 0 -> +inf, like the reference's expression
