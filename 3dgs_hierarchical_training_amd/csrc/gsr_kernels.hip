@@ -952,6 +952,470 @@ __global__ __launch_bounds__(256) void k_tile_ranges(uint32_t R, const KeyT* __r
 }
 
 // ------------------------------------------------------------------------------------------------
+// Direct binning (round 4): the tile lists WITHOUT an instance stream and without a tile sort.
+// The instance list is the stable partition, by tile, of the (Gaussian, tile) pairs taken in depth order.  The sort route writes
+// the pairs out as 6-byte records (k_emit), moves them twice (two 6-bit onesweep passes) and reads the keys once more for the
+// ranges; here every pair is written exactly once, 4 bytes, at its final place:
+//   k_chunk_counts   the depth-ordered Gaussians are cut into NC chunks of S (a multiple of 64), one WAVE per chunk: the gather of the
+//                    tile records into depth order (as k_tile_counts) and the chunk's per-tile histogram, M[chunk][tile] (u16);
+//   k_chunk_scan1/2  exclusive prefix of M down each tile's column (two levels: inside groups of Cg chunks, then over the groups by
+//                    one workgroup, which also forms the tile bases = the ranges, R for the host and the small clears);
+//   k_chunk_scatter  one wave per chunk again, with the chunk's row of start positions as an LDS counter table and a 64-bit lane
+//                    mask per tile: per step of 64 Gaussians every lane ORs its bit into the masks of its tiles, then reads each mask
+//                    back -- position = counter + popcount(mask below my lane) -- and the lowest lane of a mask advances the counter
+//                    and clears the mask.  OR and add commute: the list is the sort's list bit for bit, with no atomics' order in it.
+// LDS per scatter wave: 12 bytes per tile (26 kB at 980x545: six waves per CU, the whole chunk set resident at 1 M Gaussians); frames
+// of more than kDbMaxTiles tiles (and 32-bit tile keys) keep the sort route.  Chunk c of the scatter runs on XCD (c / ceil(NC / 8)):
+// an XCD owns a contiguous eighth of the depth order, so the 4-byte stores it scatters over a tile's segment fill whole lines of
+// ITS L2 before they leave it.
+// ------------------------------------------------------------------------------------------------
+constexpr int kDbMaxTiles = 4096;
+constexpr int kDbCountWaves = 4;      // chunks per workgroup of k_chunk_counts (kEmitThreads / 64: balance_build shares the launch)
+struct DirectBin {
+    int N, T, Tp /* T rounded up to 64 */, S, NC, G, Cg;
+    uint16_t* M;        // [NC][Tp]  per-chunk tile counts -> exclusive prefixes inside the chunk's group
+    uint32_t* GT;       // [G][Tp]   group totals -> absolute start of the group inside the tile's segment
+    uint32_t* tbase;    // [T + 1]   tile bases (saturated at 2^32 - 1)
+};
+
+// all 64 lanes walk the candidate tiles of ONE large rect (more than 32 tiles: no mask in its TileRec), 64 at a time, in the
+// emission's order (row-major over the tight rect, the exact test per tile): f(accepted, tile key) on every lane, every round
+template <typename F>
+__device__ __forceinline__ void big_rect_tiles(const Splat& s, uint32_t rect, int W, int H, int tiles_x, int tiles_y, int lane, F&& f)
+{
+    int x0, y0, x1, y1;
+    tile_rect_tight(s.px, s.py, s.radius, s.ca, s.cb, s.cc, s.op, W, H, tiles_x, tiles_y, x0, y0, x1, y1);   // as k_preprocess
+    const int vrow0 = (int)((rect >> 12) & 0xfffu) - y0;   // batched render: first tile row of this Gaussian's model (0 otherwise)
+    const int ww = x1 - x0, full = ww * (y1 - y0);
+    const TileTest tt = make_tile_test(s.px, s.py, s.ca, s.cb, s.cc, s.op);
+    for (int c0 = 0; c0 < full; c0 += 64) {
+        const int c = c0 + lane;
+        bool ok = false;
+        uint32_t key = 0u;
+        if (c < full) {
+            const int ty = c / ww, tx = c - ty * ww;
+            ok = tile_accept(tt, x0 + tx, y0 + ty, W, H);
+            key = (uint32_t)((y0 + ty + vrow0) * tiles_x + x0 + tx);
+        }
+        f(ok, key);
+    }
+}
+
+// the tiles of a small rect, in mask order: f(tile key).  Two tiles per iteration: the walk of a lone wave is a chain of dependent
+// instructions (lowest bit -> row -> key -> address), two independent chains per trip nearly halve it.
+template <typename F>
+__device__ __forceinline__ void small_rect_tiles(const TileRec& r, int tiles_x, F&& f)
+{
+    const uint32_t ww = (r.rect >> 24) & 63u, rx0 = r.rect & 0xfffu, ry0 = (r.rect >> 12) & 0xfffu;
+    const uint32_t rcp = (65536u + ww - 1u) / (ww ? ww : 1u);   // floor(pos / ww) = pos * rcp >> 16 for pos < 32 <= 65536 / ww
+    const uint32_t base = ry0 * (uint32_t)tiles_x + rx0, skip = (uint32_t)tiles_x - ww;   // key = base + pos + (pos / ww) * (tiles_x - ww)
+    for (uint32_t m = r.mask; m != 0u;) {
+        const uint32_t m1 = m & (m - 1u);
+        const uint32_t p0 = (uint32_t)__builtin_ctz(m);
+        f(base + p0 + ((p0 * rcp) >> 16) * skip);
+        if (m1 != 0u) {
+            const uint32_t p1 = (uint32_t)__builtin_ctz(m1);
+            f(base + p1 + ((p1 * rcp) >> 16) * skip);
+        }
+        m = m1 & (m1 - 1u);
+    }
+}
+
+// inclusive prefix sum over the 64 lanes by DPP row shifts and row broadcasts (no LDS round trips: ~8 instructions)
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    auto dpp = [](uint32_t v, auto ctrl, auto rmask, auto bmask) {
+        return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, decltype(ctrl)::value, decltype(rmask)::value, decltype(bmask)::value, false);
+    };
+    using std::integral_constant;
+    uint32_t r = x;
+    r += dpp(x, integral_constant<int, 0x111>{}, integral_constant<int, 0xf>{}, integral_constant<int, 0xf>{});   // row_shr:1
+    r += dpp(x, integral_constant<int, 0x112>{}, integral_constant<int, 0xf>{}, integral_constant<int, 0xf>{});   // row_shr:2
+    r += dpp(x, integral_constant<int, 0x113>{}, integral_constant<int, 0xf>{}, integral_constant<int, 0xf>{});   // row_shr:3
+    r += dpp(r, integral_constant<int, 0x114>{}, integral_constant<int, 0xf>{}, integral_constant<int, 0xe>{});   // row_shr:4, banks 1-3
+    r += dpp(r, integral_constant<int, 0x118>{}, integral_constant<int, 0xf>{}, integral_constant<int, 0xc>{});   // row_shr:8, banks 2-3
+    r += dpp(r, integral_constant<int, 0x142>{}, integral_constant<int, 0xa>{}, integral_constant<int, 0xf>{});   // row_bcast:15 -> rows 1, 3
+    r += dpp(r, integral_constant<int, 0x143>{}, integral_constant<int, 0xc>{}, integral_constant<int, 0xf>{});   // row_bcast:31 -> rows 2, 3
+    return r;
+#else
+    return x;
+#endif
+}
+
+__global__ __launch_bounds__(kEmitThreads) void k_chunk_counts(DirectBin db, int W, int H, int tiles_x, int tiles_y,
+                                                               const uint32_t* __restrict__ sorted_gid, const TileRec* __restrict__ tilerec,
+                                                               const Splat* __restrict__ splat, TileRec* __restrict__ sorted_rec, BlendBalance bb)
+{
+    const int nbuild = bb.hdr ? 8 : 0, c = (int)blockIdx.x - nbuild;
+    if (c < 0) { balance_build(bb, (int)blockIdx.x); return; }
+    // one workgroup per chunk: its four waves take the chunk's steps of 64 Gaussians in turn and count into ONE table (adds commute)
+    __shared__ uint32_t s_h[kDbMaxTiles / 2];   // two u16 counters per word (a chunk holds fewer than 65 536 Gaussians)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < db.Tp / 2; i += kEmitThreads) s_h[i] = 0u;
+    __syncthreads();
+    const int j0 = c * db.S + wave * 64, j1 = min(db.N, c * db.S + db.S);
+    constexpr int kStride = 64 * kDbCountWaves;
+    // two loads ahead: the index of this wave's step after next and the record of its next step are in flight while a step is counted
+    auto load_gid = [&](int j) -> uint32_t { return j < j1 ? sorted_gid[j] : 0xffffffffu; };
+    auto load_rec = [&](uint32_t g) -> TileRec { TileRec r; r.mask = 0u; r.rect = 1u << 24; if (g != 0xffffffffu) r = tilerec[g]; return r; };
+    uint32_t gA = load_gid(j0 + lane), gB = load_gid(j0 + kStride + lane);
+    TileRec rA = load_rec(gA);
+    for (int j = j0 + lane; j - lane < j1; j += kStride) {
+        const uint32_t g = gA;
+        const TileRec r = rA;
+        gA = gB;
+        rA = load_rec(gA);
+        gB = load_gid(j + 2 * kStride);
+        if (j < j1) sorted_rec[j] = r;
+        const bool big = (r.rect & kTileRecBig) != 0u;
+        if (!big) small_rect_tiles(r, tiles_x, [&](uint32_t t) { atomicAdd(&s_h[t >> 1], 1u << (16u * (t & 1u))); });
+        for (unsigned long long bm = __ballot(big && r.mask != 0u); bm != 0ull; bm &= bm - 1ull) {
+            const int b = (int)__builtin_ctzll(bm);
+            const uint32_t gg = (uint32_t)__builtin_amdgcn_readlane((int)g, b), rect = (uint32_t)__builtin_amdgcn_readlane((int)r.rect, b);
+            const Splat s = splat[gg];
+            big_rect_tiles(s, rect, W, H, tiles_x, tiles_y, lane, [&](bool ok, uint32_t t) { if (ok) atomicAdd(&s_h[t >> 1], 1u << (16u * (t & 1u))); });
+        }
+    }
+    __syncthreads();
+    uint32_t* const row = reinterpret_cast<uint32_t*>(db.M + (size_t)c * db.Tp);
+    for (int i = tid; i < db.Tp / 2; i += kEmitThreads) row[i] = s_h[i];
+}
+
+// level 1: thread (tile, group) turns its group's counts into exclusive prefixes, in place, and writes the group's total
+__global__ __launch_bounds__(256) void k_chunk_scan1(DirectBin db)
+{
+    const int t = (int)(blockIdx.x * 256u + threadIdx.x), grp = (int)blockIdx.y;
+    if (t >= db.Tp) return;
+    const int c0 = grp * db.Cg, c1 = min(db.NC, c0 + db.Cg);
+    uint16_t* p = db.M + (size_t)c0 * db.Tp + t;
+    uint32_t run = 0u;
+    int c = c0;
+    for (; c + 8 <= c1; c += 8, p += 8 * (size_t)db.Tp) {
+        uint32_t v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = p[(size_t)k * db.Tp];
+#pragma unroll
+        for (int k = 0; k < 8; k++) { p[(size_t)k * db.Tp] = (uint16_t)run; run += v[k]; }
+    }
+    for (; c < c1; c++, p += db.Tp) { const uint32_t v = *p; *p = (uint16_t)run; run += v; }
+    db.GT[(size_t)grp * db.Tp + t] = run;
+}
+
+// level 2 (one workgroup): per tile, the group totals -> starts relative to the tile's base (in place) and the tile's total; the
+// tile bases (exclusive scan over the tiles); R to the host; the small clears
+__global__ __launch_bounds__(1024) void k_chunk_scan2(DirectBin db, unsigned long long* __restrict__ total_out, ZeroJobs zj,
+                                                      unsigned long long* __restrict__ host_out, unsigned long long host_seq,
+                                                      const unsigned int* __restrict__ window_overflow)
+{
+    __shared__ unsigned long long s_wsum[16];
+    __shared__ uint32_t s_tot[kDbMaxTiles];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        uint32_t* z = static_cast<uint32_t*>(zj.p[j]);
+        for (uint32_t q = tid; q < zj.words[j]; q += 1024) z[q] = 0u;
+    }
+    constexpr int K = kDbMaxTiles / 1024;
+    // column t = tid + 1024 k: rows are read coalesced, eight groups of every column of this thread in flight at a time (sixteen: 19 us against 14.5)
+    uint32_t run[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) run[k] = 0u;
+    for (int g0 = 0; g0 < db.G; g0 += 8) {
+        uint32_t v[K][8];
+#pragma unroll
+        for (int k = 0; k < K; k++)
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int t = tid + 1024 * k, g = g0 + q;
+                v[k][q] = (t < db.Tp && g < db.G) ? db.GT[(size_t)g * db.Tp + t] : 0u;
+            }
+#pragma unroll
+        for (int k = 0; k < K; k++)
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int t = tid + 1024 * k, g = g0 + q;
+                if (t < db.Tp && g < db.G) db.GT[(size_t)g * db.Tp + t] = run[k];
+                run[k] += v[k][q];
+            }
+    }
+#pragma unroll
+    for (int k = 0; k < K; k++) s_tot[tid + 1024 * k] = (tid + 1024 * k < db.T) ? run[k] : 0u;
+    __syncthreads();
+    // exclusive scan over the tiles: four consecutive tiles per thread
+    uint32_t tot[K];
+    unsigned long long sum = 0ull;
+#pragma unroll
+    for (int k = 0; k < K; k++) { tot[k] = s_tot[tid * K + k]; sum += tot[k]; }
+    unsigned long long inc = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned long long y = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += y;
+    }
+    if (lane == 63) s_wsum[wave] = inc;
+    __syncthreads();
+    unsigned long long add = 0ull, all = 0ull;
+#pragma unroll
+    for (int w = 0; w < 16; w++) { const unsigned long long t = s_wsum[w]; add += (w < wave) ? t : 0ull; all += t; }
+    unsigned long long pre = add + inc - sum;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const int t = tid * K + k;
+        if (t < db.T) db.tbase[t] = (uint32_t)min(pre, 0xffffffffull);   // (beyond 2^32 instances the host fails the call: positions only have to stay in bounds)
+        pre += tot[k];
+    }
+    if (tid == 0) {
+        db.tbase[db.T] = (uint32_t)min(all, 0xffffffffull);
+        *total_out = all;
+        if (host_out) {   // as block_scan_body
+            __atomic_store_n(host_out + 2, (unsigned long long)g_onesweep_giveups, __ATOMIC_RELAXED);
+            __atomic_store_n(host_out + 3, (unsigned long long)(window_overflow ? *window_overflow : 0u), __ATOMIC_RELAXED);
+            __atomic_store_n(host_out, all, __ATOMIC_RELAXED);
+            __threadfence_system();
+            __atomic_store_n(host_out + 1, host_seq, __ATOMIC_RELAXED);
+            __threadfence_system();
+        }
+    }
+}
+
+// (Measured and dropped: both levels in ONE launch, the last block of a slab / of the grid to arrive -- a ticket behind a
+//  __threadfence() -- doing the next level: 47 us against 5.5 + 14.5.  An agent-scope release writes the XCD's whole L2 back, and the
+//  chunk tables the level-1 blocks have just rewritten are 6 MB of dirty lines.)
+// One wave per chunk.  LDS: a 64-bit lane mask and a position counter per tile, and the step's (tile, owner lane) pairs.
+// Per step of 64 depth-consecutive Gaussians:
+//   owners   every lane walks ITS record's tiles: ORs its bit into the tile's mask and appends (tile, lane) to the pair buffer at its
+//            exclusive prefix -- no reads, nothing waits;
+//   place    the pairs are dealt to the lanes 64 at a time (a lane's tile count does not matter any more: a wave of records with
+//            4.5 tiles on average and one of 30 takes five rounds, not thirty): position = counter + popcount(mask below the owner);
+//   advance  every pair adds one to its tile's counter and clears the mask (adds commute; nothing is read).
+// A single wave's LDS operations execute in program order, so the three parts need no barrier between them -- only the compiler
+// has to keep them apart.  Large rects (no mask in the record) are walked by all 64 lanes, one Gaussian at a time, in the same three
+// parts.  The list is the sort route's list bit for bit.
+constexpr int kDbPairs = 1024;        // pair buffer (a step whose small rects hold more is cut into runs of lanes that fit)
+__device__ __forceinline__ void lds_order() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+
+#ifdef GSR_DB_TIMING
+__device__ unsigned long long g_db_dbg[16];   // s_memtime ticks per part, summed over the waves of every launch (tools/db_timing.sh)
+#define DB_T(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); if (lane == 0) dbt[k] += now_ - dbt_last; dbt_last = now_; } while (0)
+#else
+#define DB_T(k) do { } while (0)
+#endif
+__global__ __launch_bounds__(64) void k_chunk_scatter(DirectBin db, int W, int H, int tiles_x, int tiles_y,
+                                                      const uint32_t* __restrict__ sorted_gid, const TileRec* __restrict__ sorted_rec,
+                                                      const Splat* __restrict__ splat, uint32_t* __restrict__ list, uint2* __restrict__ ranges,
+                                                      uint32_t cap)
+{
+    extern __shared__ unsigned long long s_dyn[];
+    unsigned long long* const s_mask = s_dyn;                                  // [Tp]
+    uint32_t* const s_cnt = reinterpret_cast<uint32_t*>(s_dyn + db.Tp);       // [Tp]
+    uint32_t* const s_pair = s_cnt + db.Tp;                                    // [kDbPairs]
+    const int lane = threadIdx.x, b = (int)blockIdx.x;
+    {   // the ranges: tile bases clipped to the list's capacity (an overflowing speculative launch is run again)
+        const int t = b * 64 + lane;
+        if (t < db.T) {
+            const uint32_t lo = min(db.tbase[t], cap), hi = min(db.tbase[t + 1], cap);
+            ranges[t] = hi > lo ? make_uint2(lo, hi) : make_uint2(0u, 0u);   // (an empty tile reads (0, 0), as on the sort route)
+        }
+    }
+    const int per = (db.NC + 7) >> 3, c = (b & 7) * per + (b >> 3);
+    if ((b >> 3) >= per || c >= db.NC) return;
+#ifdef GSR_DB_TIMING
+    unsigned long long dbt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dbt_last = __builtin_readcyclecounter();
+#endif
+    {
+        const uint32_t* gt = db.GT + (size_t)(c / db.Cg) * db.Tp;
+        const uint16_t* mr = db.M + (size_t)c * db.Tp;
+        // (sixteen rows of loads in flight per wait: one at a time this loop was a fifth of the kernel)
+        for (int i0 = 0; i0 < db.Tp; i0 += 1024) {
+            uint32_t a[16], bb2[16], cc2[16];
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const int i = i0 + 64 * q + lane;
+                const bool v = i < db.Tp;
+                a[q] = v && i < db.T ? db.tbase[i] : 0u;
+                bb2[q] = v ? gt[i] : 0u;
+                cc2[q] = v ? (uint32_t)mr[i] : 0u;
+            }
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const int i = i0 + 64 * q + lane;
+                if (i < db.Tp) { s_cnt[i] = a[q] + bb2[q] + cc2[q]; s_mask[i] = 0ull; }
+            }
+        }
+    }
+    lds_order();
+    DB_T(0);
+    const unsigned long long me = 1ull << lane, lt = lanemask_lt();
+    const int j0 = c * db.S, j1 = min(db.N, j0 + db.S);
+    auto load_gid = [&](int j) -> uint32_t { return j < j1 ? sorted_gid[j] : 0u; };
+    auto load_rec = [&](int j) -> TileRec { TileRec r; r.mask = 0u; r.rect = 1u << 24; if (j < j1) r = sorted_rec[j]; return r; };
+    // two steps of loads in flight (a sorted record arrives from HBM after ~1.5 us under this kernel's traffic)
+    uint32_t gA = load_gid(j0 + lane), gB = load_gid(j0 + 64 + lane);
+    TileRec rA = load_rec(j0 + lane), rB = load_rec(j0 + 64 + lane);
+    for (int j = j0 + lane; j - lane < j1; j += 64) {
+        const uint32_t g = gA;
+        const TileRec r = rA;
+        gA = gB; rA = rB;
+        gB = load_gid(j + 128);
+        rB = load_rec(j + 128);
+        // A large rect (no mask in its record) is walked by all 64 lanes, once, and its accepted tiles go into the pair buffer like
+        // everyone's; one of more tiles than the buffer holds ("huge") is walked three times instead, outside the buffer.
+        const bool big = (r.rect & kTileRecBig) != 0u && r.mask != 0u, huge = big && r.mask > (uint32_t)kDbPairs;
+        const unsigned long long bigs = __ballot(big && !huge), huges = __ballot(huge);
+        const uint32_t cnt = huge ? 0u : tilerec_count(r);
+        const uint32_t incl = wave_inclusive_sum(cnt);
+        // runs of lanes whose pairs fit the buffer: ONE run unless the step holds more than kDbPairs pairs
+        auto run_end = [&](int lo, uint32_t before) -> int {
+            const unsigned long long over = __ballot(incl - before > (uint32_t)kDbPairs) & ~((1ull << lo) - 1ull);
+            return over ? (int)__builtin_ctzll(over) : 64;
+        };
+        // the pairs of lanes lo .. hi-1 into the buffer (with_or: and their bits into the masks -- every lane's, whatever its run)
+        auto owners = [&](int lo, int hi, uint32_t before, bool with_or) {
+            const bool mine = lane >= lo && lane < hi;
+            if (!big && (with_or || mine)) {
+                uint32_t* o = s_pair + (incl - cnt - before);
+                small_rect_tiles(r, tiles_x, [&](uint32_t t) {
+                    if (with_or) atomicOr(&s_mask[t], me);
+                    if (mine) *o++ = (t << 6) | (uint32_t)lane;
+                });
+            }
+            for (unsigned long long bm = bigs; bm != 0ull; bm &= bm - 1ull) {
+                const int bl = (int)__builtin_ctzll(bm);
+                const bool in_run = bl >= lo && bl < hi;
+                if (!with_or && !in_run) continue;
+                const uint32_t gg = (uint32_t)__builtin_amdgcn_readlane((int)g, bl), rect = (uint32_t)__builtin_amdgcn_readlane((int)r.rect, bl);
+                uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)(incl - cnt), bl) - before;
+                const Splat s = splat[gg];
+                big_rect_tiles(s, rect, W, H, tiles_x, tiles_y, lane, [&](bool ok, uint32_t t) {
+                    const unsigned long long acc = __ballot(ok);
+                    if (ok) {
+                        if (with_or) atomicOr(&s_mask[t], 1ull << bl);
+                        if (in_run) s_pair[(o + (uint32_t)__popcll(acc & lt)) & (uint32_t)(kDbPairs - 1)] = (t << 6) | (uint32_t)bl;
+                    }
+                    o += (uint32_t)__popcll(acc);
+                });
+            }
+        };
+        int lo = 0, hi = run_end(0, 0u);
+        uint32_t before = 0u;
+        const bool one_run = hi == 64;
+        DB_T(1);
+        owners(0, hi, 0u, true);
+        DB_T(2);
+        for (unsigned long long bm = huges; bm != 0ull; bm &= bm - 1ull) {
+            const int bl = (int)__builtin_ctzll(bm);
+            const uint32_t gg = (uint32_t)__builtin_amdgcn_readlane((int)g, bl), rect = (uint32_t)__builtin_amdgcn_readlane((int)r.rect, bl);
+            const Splat s = splat[gg];
+            big_rect_tiles(s, rect, W, H, tiles_x, tiles_y, lane, [&](bool ok, uint32_t t) { if (ok) atomicOr(&s_mask[t], 1ull << bl); });
+        }
+        // the loads of the step after next have had a step and this owner loop to arrive; taken HERE, in front of this step's
+        // scattered stores (a wait for a load is a wait for every store issued before it: vmcnt counts both)
+        asm volatile("" : "+v"(gA), "+v"(rA.mask), "+v"(rA.rect));   // (the NEXT step's: issued a step ago)
+        lds_order();
+        DB_T(3);
+        // place: the pairs, 64 at a time, four rounds per batch of LDS round trips
+        for (;;) {
+            const uint32_t P = (uint32_t)__builtin_amdgcn_readlane((int)incl, hi - 1) - before;
+            // (straight-line code per batch size: with uniform branches between the rounds the compiler drains the LDS queue at every
+            //  join, and the batch became one round trip per READ -- three thousand cycles per step, a third of the kernel)
+            for (uint32_t p0 = 0u; p0 < P; p0 += 512u) {
+                const uint32_t left = P - p0;
+                auto batch = [&](auto rounds_tag) {
+                    constexpr int RN = decltype(rounds_tag)::value;
+                    uint32_t e[RN], go[RN], base[RN];
+                    unsigned long long mk[RN];
+#pragma unroll
+                    for (int q = 0; q < RN; q++) e[q] = s_pair[(p0 + 64u * q + (uint32_t)lane) & (uint32_t)(kDbPairs - 1)];   // (in bounds whatever P is)
+#pragma unroll
+                    for (int q = 0; q < RN; q++) {
+                        const bool v = 64u * q + (uint32_t)lane < left;
+                        e[q] = v ? e[q] : 0xffffffffu;
+                        const uint32_t t = v ? e[q] >> 6 : 0u;
+                        go[q] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((e[q] & 63u) << 2), (int)g);   // (every lane: an owner's index is fetched from ITS lane)
+                        mk[q] = s_mask[t];
+                        base[q] = s_cnt[t];
+                    }
+#pragma unroll
+                    for (int q = 0; q < RN; q++)
+                        if (e[q] != 0xffffffffu) {
+                            const uint32_t pos = base[q] + (uint32_t)__popcll(mk[q] & ((1ull << (e[q] & 63u)) - 1ull));
+                            if (pos < cap) list[pos] = go[q];   // (plain stores: merged in this XCD's L2; nontemporal ones measured 166 us against 50)
+                        }
+                };
+                if (left <= 128u) batch(std::integral_constant<int, 2>{});
+                else if (left <= 256u) batch(std::integral_constant<int, 4>{});
+                else if (left <= 384u) batch(std::integral_constant<int, 6>{});
+                else batch(std::integral_constant<int, 8>{});
+            }
+            if (hi == 64) break;
+            lds_order();       // (rare) the next run of lanes refills the pair buffer
+            before += P;
+            lo = hi;
+            hi = run_end(lo, before);
+            owners(lo, hi, before, false);
+            lds_order();
+        }
+        for (unsigned long long bm = huges; bm != 0ull; bm &= bm - 1ull) {
+            const int bl = (int)__builtin_ctzll(bm);
+            const uint32_t gg = (uint32_t)__builtin_amdgcn_readlane((int)g, bl), rect = (uint32_t)__builtin_amdgcn_readlane((int)r.rect, bl);
+            const Splat s = splat[gg];
+            big_rect_tiles(s, rect, W, H, tiles_x, tiles_y, lane, [&](bool ok, uint32_t t) {
+                if (ok) {
+                    const uint32_t pos = s_cnt[t] + (uint32_t)__popcll(s_mask[t] & ((1ull << bl) - 1ull));
+                    if (pos < cap) list[pos] = gg;
+                }
+            });
+        }
+        lds_order();
+        DB_T(4);
+        // advance: every (Gaussian, tile) adds one to the tile's counter and clears the mask
+        if (one_run) {   // (the pair buffer still holds the whole step: dealt to the lanes like the placement, nothing read back but the pairs)
+            const uint32_t P = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            for (uint32_t p0 = 0u; p0 < P; p0 += 512u) {
+                const uint32_t left = P - p0;
+                auto batch = [&](auto rounds_tag) {
+                    constexpr int RN = decltype(rounds_tag)::value;
+                    uint32_t e[RN];
+#pragma unroll
+                    for (int q = 0; q < RN; q++) e[q] = s_pair[(p0 + 64u * q + (uint32_t)lane) & (uint32_t)(kDbPairs - 1)];
+#pragma unroll
+                    for (int q = 0; q < RN; q++)
+                        if (64u * q + (uint32_t)lane < left) { atomicAdd(&s_cnt[e[q] >> 6], 1u); s_mask[e[q] >> 6] = 0ull; }
+                };
+                if (left <= 128u) batch(std::integral_constant<int, 2>{});
+                else if (left <= 256u) batch(std::integral_constant<int, 4>{});
+                else if (left <= 384u) batch(std::integral_constant<int, 6>{});
+                else batch(std::integral_constant<int, 8>{});
+            }
+        } else {
+            if (!big) small_rect_tiles(r, tiles_x, [&](uint32_t t) { atomicAdd(&s_cnt[t], 1u); s_mask[t] = 0ull; });
+            for (unsigned long long bm = bigs; bm != 0ull; bm &= bm - 1ull) {
+                const int bl = (int)__builtin_ctzll(bm);
+                const uint32_t gg = (uint32_t)__builtin_amdgcn_readlane((int)g, bl), rect = (uint32_t)__builtin_amdgcn_readlane((int)r.rect, bl);
+                const Splat s = splat[gg];
+                big_rect_tiles(s, rect, W, H, tiles_x, tiles_y, lane, [&](bool ok, uint32_t t) { if (ok) { atomicAdd(&s_cnt[t], 1u); s_mask[t] = 0ull; } });
+            }
+        }
+        for (unsigned long long bm = huges; bm != 0ull; bm &= bm - 1ull) {
+            const int bl = (int)__builtin_ctzll(bm);
+            const uint32_t gg = (uint32_t)__builtin_amdgcn_readlane((int)g, bl), rect = (uint32_t)__builtin_amdgcn_readlane((int)r.rect, bl);
+            const Splat s = splat[gg];
+            big_rect_tiles(s, rect, W, H, tiles_x, tiles_y, lane, [&](bool ok, uint32_t t) { if (ok) { atomicAdd(&s_cnt[t], 1u); s_mask[t] = 0ull; } });
+        }
+        lds_order();
+        DB_T(5);
+    }
+#ifdef GSR_DB_TIMING
+    if (lane == 0) {
+        for (int k = 0; k < 6; k++) atomicAdd(&g_db_dbg[k], dbt[k]);
+        atomicAdd(&g_db_dbg[6], 1ull);
+        atomicAdd(&g_db_dbg[7], (unsigned long long)((j1 - j0 + 63) / 64));
+    }
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
 // K7: forward blend.  One 64-lane wave = one workgroup = one 8x8 pixel block; the four waves of a tile are independent: each
 // stages the tile's list itself in batches of 64 through LDS (the gathers of the other three hit L2), needs no workgroup
 // barrier, and stops as soon as ITS 64 pixels are saturated.  block b: XCD b & 7, slot b >> 3 -> (tile, sub-tile) through
@@ -2299,6 +2763,7 @@ static int g_bwd_split = 0;  // workgroups a long tile's backward is split over 
 static int g_ckpt_first = 1;  // 128-instance batches of a tile before the forward starts leaving checkpoints
 constexpr uint32_t kDepthKeyBias = 0x3E4CCCCDu;   // bit pattern of the near plane, 0.2f (gsr_math.h kNearZ): no visible Gaussian's depth key lies below it
 static int g_depth_sort9 = 1;     // depth sort of large models in three 9-bit passes over (key - near-plane bits) (radix_sort.h); 0 = four 8-bit passes
+static int g_direct_bin = 1;      // tile lists by direct placement (k_chunk_counts / k_chunk_scatter) instead of emit + tile sort + ranges; 0 = the sort route
 static int g_blend_balance = 1;   // forward blend: place the waves by the visits each took at the previous render of the same view (balance_build)
 static int g_tile_map = 2;   // tile -> XCD map: 2 = 2x2 tile blocks interleaved (default), 1 = tiles interleaved, 0 = banded
 static std::atomic<long long> g_spec_overflows{0}, g_spec_forwards{0}, g_exact_forwards{0}, g_depth_window_resorts{0};
@@ -2429,6 +2894,9 @@ int gsr_prepare_supported(int32_t M, int32_t D, int32_t raw_params) { return (ra
 const char* gsr_last_error(void) { return g_err; }
 int gsr_version(void) { return 100; }
 
+#ifdef GSR_DB_TIMING
+int gsr_debug_db_timing(unsigned long long* host_dst) { return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_db_dbg), sizeof(unsigned long long) * 16); }
+#endif
 #ifdef GSR_K6_TIMING
 int gsr_debug_k6_timing(unsigned long long* host_dst, int blocks)
 {
@@ -2470,6 +2938,7 @@ int gsr_set_option(const char* name, int value)
     if (!strcmp(name, "tile_map")) { if (value < 0 || value > 2) return GSR_ERR_ARG; g_tile_map = value; return GSR_OK; }
     if (!strcmp(name, "blend_balance")) { g_blend_balance = value ? 1 : 0; return GSR_OK; }
     if (!strcmp(name, "depth_sort9")) { g_depth_sort9 = value ? 1 : 0; return GSR_OK; }
+    if (!strcmp(name, "direct_binning")) { g_direct_bin = value ? 1 : 0; return GSR_OK; }
     if (!strcmp(name, "speculative_binning")) { g_speculate = value ? 1 : 0; return GSR_OK; }
     if (!strcmp(name, "deterministic_backward")) { g_deterministic = value ? 1 : 0; return GSR_OK; }
     if (!strcmp(name, "binning_capacity_hint")) {   // tests: capacity of the next forward (one shot; forces an overflow re-run)
@@ -2498,6 +2967,42 @@ int gsr_set_option(const char* name, int value)
         g_bwd_ppt = value; return GSR_OK;
     }
     return GSR_ERR_ARG;
+}
+
+// geometry + scratch of the direct binning for N Gaussians on T tiles; false: this frame keeps the sort route
+struct DirectBinScratch { size_t M, GT, tbase, bytes; };
+static bool direct_bin_geometry(int N, int T, DirectBin& db, DirectBinScratch& ds)
+{
+    if (N < 1 || T < 1 || T > kDbMaxTiles) return false;
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    db.N = N; db.T = T; db.Tp = (T + 63) & ~63;
+    const int lds = 12 * db.Tp + 4 * kDbPairs;
+    const char* env = getenv("GSR_DB_WAVES_PER_CU");   // (experiments)
+    int per_cu = std::min(16, (160 * 1024) / lds);
+    if (env && atoi(env) > 0) per_cu = atoi(env);
+    const long long resident = (long long)cus * per_cu;
+    const char* env_s = getenv("GSR_DB_MIN_CHUNK");
+    const int min_s = env_s && atoi(env_s) > 0 ? atoi(env_s) : 256;
+    long long S = ((long long)N + resident - 1) / resident;
+    S = std::max<long long>(min_s, (S + 63) & ~63ll);
+    if (S > 65472) return false;
+    db.S = (int)S;
+    db.NC = (int)(((long long)N + S - 1) / S);
+    int G = 1;
+    while (G * G < db.NC) G++;
+    db.Cg = std::max(1, std::min((db.NC + G - 1) / G, 65535 / db.S));
+    db.G = (db.NC + db.Cg - 1) / db.Cg;
+    size_t o = 0;
+    ds.M = o; o += align256((size_t)db.NC * db.Tp * sizeof(uint16_t));
+    ds.GT = o; o += align256((size_t)db.G * db.Tp * sizeof(uint32_t));
+    ds.tbase = o; o += align256((size_t)(db.Tp + 1) * sizeof(uint32_t));
+    ds.bytes = o;
+    return true;
 }
 
 int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
@@ -2538,6 +3043,10 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
     BinLayout B = bin_layout(0, W, H, NB);
     BinScratch S = bin_scratch_layout(0);
     uint8_t *bin = nullptr, *bs = nullptr;
+    // direct binning (k_chunk_counts ... k_chunk_scatter) where the frame's tile tables fit a wave's LDS; else emit + tile sort
+    DirectBin db = {};
+    DirectBinScratch dbs = {};
+    const bool direct = g_direct_bin && g_sort_algo == 2 && !wide_keys && direct_bin_geometry(N, T, db, dbs);
     uint2* ranges = nullptr;
     uint32_t* list = nullptr;
     auto alloc_binning = [&](uint64_t capacity) -> int {
@@ -2547,7 +3056,7 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
         ranges = reinterpret_cast<uint2*>(bin + B.ranges);
         list = reinterpret_cast<uint32_t*>(bin + B.list);
         bs = nullptr;
-        if (capacity == 0) return GSR_OK;
+        if (capacity == 0 || direct) return GSR_OK;
         S = bin_scratch_layout((int64_t)capacity, wide_keys ? 4 : 2);
         bs = static_cast<uint8_t*>(a->alloc(S.bytes, GSR_ALLOC_SCRATCH, a->alloc_user));
         if (!bs) return fail(GSR_ERR_ALLOC, "binning scratch allocation failed%s");
@@ -2599,6 +3108,14 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
         return GSR_OK;
     };
     auto launch_binning = [&](uint64_t capacity, const unsigned long long* n_dev, bool prezeroed) -> int {
+        if (direct) {
+            if (capacity == 0) { GSR_HIP(hipMemsetAsync(ranges, 0, (size_t)T * sizeof(uint2), st)); return GSR_OK; }
+            ProfScope ps(P_EMIT, st);
+            const int per = (db.NC + 7) / 8, grid = std::max(8 * per, (T + 63) / 64);
+            hipLaunchKernelGGL(k_chunk_scatter, dim3(grid), dim3(64), (size_t)12 * db.Tp + 4 * kDbPairs, st, db, W, H, tiles_x, tiles_y, sorted_gid,
+                               reinterpret_cast<const TileRec*>(fs + L.srec), splat, list, ranges, (uint32_t)std::min<uint64_t>(capacity, 0xffffffffull));
+            return GSR_OK;
+        }
         return wide_keys ? launch_binning_t(uint32_t{}, capacity, n_dev, prezeroed) : launch_binning_t(uint16_t{}, capacity, n_dev, prezeroed);
     };
     auto launch_blend = [&](bool prezeroed) -> int {
@@ -2741,6 +3258,20 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
     sorted_gid = in_alt ? gid_alt : gid;
     PinLease pin(acquire_pin_slot(dev_id));
     if (!pin.s) return fail(GSR_ERR_HIP, "pinned read-back slot allocation failed%s");
+    // tiles-touched in depth order: R to the pinned slot, and what the binning needs (block offsets / the chunk tables)
+    auto launch_counts = [&](const BlendBalance& bal, const ZeroJobs& zjobs, const unsigned int* wo, unsigned long long seq) {
+        TileRec* srec = reinterpret_cast<TileRec*>(fs + L.srec);
+        if (direct) {
+            hipLaunchKernelGGL(k_chunk_counts, dim3(db.NC + (bal.hdr ? 8 : 0)), dim3(kEmitThreads), 0, st, db, W, H,
+                               tiles_x, tiles_y, sorted_gid, ntiles, splat, srec, bal);
+            hipLaunchKernelGGL(k_chunk_scan1, dim3((db.Tp + 255) / 256, db.G), dim3(256), 0, st, db);
+            hipLaunchKernelGGL(k_chunk_scan2, dim3(1), dim3(1024), 0, st, db, total, zjobs, pin.s->dev, seq, wo);
+        } else {
+            hipLaunchKernelGGL(k_tile_counts, dim3(nb + (bal.hdr ? 8 : 0)), dim3(kEmitThreads), 0, st, N, sorted_gid, ntiles, block_sums, srec, bal, nb);
+            // the scan writes R straight into the pinned slot (device-visible host memory): no copy launch behind it
+            hipLaunchKernelGGL(k_block_scan, dim3(1), dim3(1024), 0, st, block_sums, nb, total, zjobs, pin.s->dev, seq, wo);
+        }
+    };
     {
         ProfScope ps(P_SCAN, st);
         ZeroJobs zj = {};
@@ -2781,10 +3312,14 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
                 }
             }
         }
-        hipLaunchKernelGGL(k_tile_counts, dim3(nb + (bb.hdr ? 8 : 0)), dim3(kEmitThreads), 0, st, N, sorted_gid, ntiles, block_sums,
-                           reinterpret_cast<TileRec*>(fs + L.srec), bb, nb);
-        // the scan writes R straight into the pinned slot (device-visible host memory): no copy launch behind it
-        hipLaunchKernelGGL(k_block_scan, dim3(1), dim3(1024), 0, st, block_sums, nb, total, zj, pin.s->dev, ++pin.s->seq, window_overflow);
+        if (direct) {
+            uint8_t* dm = static_cast<uint8_t*>(a->alloc(dbs.bytes, GSR_ALLOC_SCRATCH, a->alloc_user));
+            if (!dm) return fail(GSR_ERR_ALLOC, "direct-binning scratch allocation failed%s");
+            db.M = reinterpret_cast<uint16_t*>(dm + dbs.M); db.GT = reinterpret_cast<uint32_t*>(dm + dbs.GT); db.tbase = reinterpret_cast<uint32_t*>(dm + dbs.tbase);
+            zj.p[0] = nullptr; zj.words[0] = 0u;   // (the scatter writes every tile's range; there is no sort scratch)
+            zj.p[2] = nullptr; zj.words[2] = 0u;
+        }
+        launch_counts(bb, zj, window_overflow, ++pin.s->seq);
     }
     GSR_HIP(hipGetLastError());
 
@@ -2841,10 +3376,7 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
         int alt2 = 0;
         GSR_HIP(onesweep_sort_pairs<uint32_t>(k0, v0, k1, v1, (uint32_t)N, 0, 32, depth_scratch, &alt2, st));
         sorted_gid = alt2 ? v1 : v0;
-        hipLaunchKernelGGL(k_tile_counts, dim3(nb), dim3(kEmitThreads), 0, st, N, sorted_gid, ntiles, block_sums, reinterpret_cast<TileRec*>(fs + L.srec),
-                           BlendBalance{}, nb);
-        hipLaunchKernelGGL(k_block_scan, dim3(1), dim3(1024), 0, st, block_sums, nb, total, ZeroJobs{}, pin.s->dev, ++pin.s->seq,
-                           (const unsigned int*)nullptr);
+        launch_counts(BlendBalance{}, ZeroJobs{}, nullptr, ++pin.s->seq);
         GSR_HIP(hipStreamSynchronize(st));
         std::atomic_thread_fence(std::memory_order_acquire);
         R = *static_cast<volatile unsigned long long*>(pin.s->host);

@@ -626,6 +626,59 @@ def test_binning_is_the_oracle_list_filtered_by_the_exact_tile_test(N, W, H, deg
     o.close()
 
 
+@pytest.mark.parametrize("name", ["syn", "medium-rects", "large-and-huge", "few", "overflow-rerun", "two-streams-of-depth"])
+def test_direct_binning_is_the_sort_routes_list(name):
+    """The tile lists by direct placement (k_chunk_counts / k_chunk_scan / k_chunk_scatter: every (Gaussian, tile) pair written once,
+    at its final place) against emit + stable tile sort + ranges: (ranges, list) and the images bit for bit.  Scenes that reach every
+    branch of the scatter: ordinary records; steps whose 64 records hold more pairs than the pair buffer (rects of ~25 tiles: runs of
+    lanes); large rects (no mask in the record: walked by the wave) and huge ones (more tiles than the buffer: walked outside it);
+    fewer Gaussians than a step; a speculative capacity that overflows (positions beyond it are dropped, the call runs again)."""
+    import importlib
+    import hip_runner
+    R_ = importlib.import_module("3dgs_hierarchical_training_amd.rasterizer")
+    L = importlib.import_module("3dgs_hierarchical_training_amd._lib")
+    lib = L.load()
+    W, H = 980, 545
+    if name == "syn":
+        sc = parity.syn.make_scene(60000, W, H, sh_degree=1, seed=3, posed=True)
+    elif name == "medium-rects":
+        sc = parity.syn.make_scene(9000, W, H, sh_degree=0, seed=5, sigma_px=11.0)
+    elif name == "large-and-huge":
+        sc = parity.syn.make_scene(4000, W, H, sh_degree=0, seed=6, sigma_px=6.0)
+        g = torch.Generator().manual_seed(1)
+        big = torch.randperm(4000, generator=g)[:150]
+        sc["scales"][big[:120]] *= 8.0          # rects of a few hundred tiles
+        sc["scales"][big[120:]] *= 60.0         # the whole frame: more tiles than the pair buffer holds
+    elif name == "few":
+        sc = parity.syn.make_scene(37, W, H, sh_degree=0, seed=7, sigma_px=20.0, frac_behind=0.0)
+    elif name == "two-streams-of-depth":
+        sc = parity.syn.make_scene(130000, W, H, sh_degree=0, seed=8)
+        sc["means3D"][::2] = sc["means3D"][1::2]       # pairs of Gaussians at the same place: equal depth keys, order by index
+    else:
+        sc = parity.syn.make_scene(30000, W, H, sh_degree=0, seed=9)
+    kw = parity.scene_kwargs(sc, "sh", bg=(0.1, 0.2, 0.3))
+    res = {}
+    try:
+        for direct in (0, 1):
+            assert lib.gsr_set_option(b"direct_binning", direct) == 0
+            if name == "overflow-rerun":
+                assert lib.gsr_set_option(b"binning_capacity_hint", 5000) == 0
+            fwd = hip_runner.run_hip(kw)["fwd"]
+            ranges, lst = R_.last_binning()
+            res[direct] = (fwd, ranges.cpu().numpy().copy(), lst.cpu().numpy().copy(), R_._LAST["num_rendered"])
+    finally:
+        lib.gsr_set_option(b"direct_binning", 1)
+        lib.gsr_set_option(b"binning_capacity_hint", 0)
+    (fa, ra, la, na), (fb, rb, lb, nb_) = res[0], res[1]
+    assert na == nb_ and na > 0
+    assert np.array_equal(ra, rb), "tile ranges differ"
+    assert np.array_equal(la[:na], lb[:nb_]), "instance lists differ"
+    for x, y in zip(fa, fb):
+        assert np.array_equal(x, y)
+    counts = np.diff(rb, axis=1)[:, 0]
+    print(f"{name}: R {na}, longest tile list {counts.max()}, tiles in use {(counts > 0).sum()} of {counts.shape[0]}")
+
+
 # ---- the reference-derived fixtures, on the HIP path ---------------------------------------------------------------------
 def _fixture_settings(g, tag, dev, noncontig):
     from diff_gaussian_rasterization import GaussianRasterizationSettings

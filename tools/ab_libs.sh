@@ -10,7 +10,7 @@ for r in $(seq 1 ${2:-2}); do
     timeout 600 python bench.py --steps ${STEPS:-30} --warmup ${WARM:-5} --no-cpu-baseline --no-extras $3 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
-print('$w', round(d['value'], 1), round(d['ms_per_step'], 4), {k: round(v * 1000) for k, v in d.get('stage_ms', {}).items()})"
+print('$w', round(d['value'], 1), round(d['ms_per_step'], 4), {k: (round(v * 1000) if v is not None else None) for k, v in d.get('stage_ms', {}).items()})"
   done
 done
 cp /tmp/cur.so $D/libgsr_hip.so
