@@ -958,8 +958,8 @@ __global__ __launch_bounds__(256) void k_tile_ranges(uint32_t R, const KeyT* __r
 // ranges; here every pair is written exactly once, 4 bytes, at its final place:
 //   k_chunk_counts   the depth-ordered Gaussians are cut into NC chunks of S (a multiple of 64), one WAVE per chunk: the gather of the
 //                    tile records into depth order (as k_tile_counts) and the chunk's per-tile histogram, M[chunk][tile] (u16);
-//   k_chunk_scan1/2  exclusive prefix of M down each tile's column (two levels: inside groups of Cg chunks, then over the groups by
-//                    one workgroup, which also forms the tile bases = the ranges, R for the host and the small clears);
+//   k_chunk_scan1/2  exclusive prefix of M down each tile's column (two levels: inside groups of Cg chunks, then over the groups, a block
+//                    per 256-tile slab, which also forms the tile bases = the ranges; R for the host and the small clears ride along);
 //   k_chunk_scatter  one wave per chunk again, with the chunk's row of start positions as an LDS counter table and a 64-bit lane
 //                    mask per tile: per step of 64 Gaussians every lane ORs its bit into the masks of its tiles, then reads each mask
 //                    back -- position = counter + popcount(mask below my lane) -- and the lowest lane of a mask advances the counter
@@ -976,6 +976,7 @@ struct DirectBin {
     uint16_t* M;        // [NC][Tp]  per-chunk tile counts -> exclusive prefixes inside the chunk's group
     uint32_t* GT;       // [G][Tp]   group totals -> absolute start of the group inside the tile's segment
     uint32_t* tbase;    // [T + 1]   tile bases (saturated at 2^32 - 1)
+    uint32_t* bsum;     // [G][slabs] instances per (group, 256-tile slab)
 };
 
 // all 64 lanes walk the candidate tiles of ONE large rect (more than 32 tiles: no mask in its TileRec), 64 at a time, in the
@@ -1082,90 +1083,84 @@ __global__ __launch_bounds__(kEmitThreads) void k_chunk_counts(DirectBin db, int
     for (int i = tid; i < db.Tp / 2; i += kEmitThreads) row[i] = s_h[i];
 }
 
-// level 1: thread (tile, group) turns its group's counts into exclusive prefixes, in place, and writes the group's total
+// level 1 (grid: 256-tile slabs x groups): thread (tile, group) turns its group's counts into exclusive prefixes, in place, and writes
+// the group's total; the block's sum of those goes to bsum[group][slab]
 __global__ __launch_bounds__(256) void k_chunk_scan1(DirectBin db)
 {
-    const int t = (int)(blockIdx.x * 256u + threadIdx.x), grp = (int)blockIdx.y;
-    if (t >= db.Tp) return;
-    const int c0 = grp * db.Cg, c1 = min(db.NC, c0 + db.Cg);
-    uint16_t* p = db.M + (size_t)c0 * db.Tp + t;
+    __shared__ uint32_t s_w[4];
+    const int tid = threadIdx.x, t = (int)(blockIdx.x * 256u) + tid, grp = (int)blockIdx.y;
     uint32_t run = 0u;
-    int c = c0;
-    for (; c + 8 <= c1; c += 8, p += 8 * (size_t)db.Tp) {
-        uint32_t v[8];
+    if (t < db.Tp) {
+        const int c0 = grp * db.Cg, c1 = min(db.NC, c0 + db.Cg);
+        uint16_t* p = db.M + (size_t)c0 * db.Tp + t;
+        int c = c0;
+        for (; c + 8 <= c1; c += 8, p += 8 * (size_t)db.Tp) {
+            uint32_t v[8];
 #pragma unroll
-        for (int k = 0; k < 8; k++) v[k] = p[(size_t)k * db.Tp];
+            for (int k = 0; k < 8; k++) v[k] = p[(size_t)k * db.Tp];
 #pragma unroll
-        for (int k = 0; k < 8; k++) { p[(size_t)k * db.Tp] = (uint16_t)run; run += v[k]; }
+            for (int k = 0; k < 8; k++) { p[(size_t)k * db.Tp] = (uint16_t)run; run += v[k]; }
+        }
+        for (; c < c1; c++, p += db.Tp) { const uint32_t v = *p; *p = (uint16_t)run; run += v; }
+        db.GT[(size_t)grp * db.Tp + t] = run;
     }
-    for (; c < c1; c++, p += db.Tp) { const uint32_t v = *p; *p = (uint16_t)run; run += v; }
-    db.GT[(size_t)grp * db.Tp + t] = run;
+    const uint32_t inc = wave_inclusive_sum(run);
+    if ((tid & 63) == 63) s_w[tid >> 6] = inc;
+    __syncthreads();
+    if (tid == 0) db.bsum[(size_t)grp * gridDim.x + blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
 }
 
-// level 2 (one workgroup): per tile, the group totals -> starts relative to the tile's base (in place) and the tile's total; the
-// tile bases (exclusive scan over the tiles); R to the host; the small clears
-__global__ __launch_bounds__(1024) void k_chunk_scan2(DirectBin db, unsigned long long* __restrict__ total_out, ZeroJobs zj,
-                                                      unsigned long long* __restrict__ host_out, unsigned long long host_seq,
-                                                      const unsigned int* __restrict__ window_overflow)
+// level 2 (one block per 256-tile slab): per tile, the group totals -> starts relative to the tile's base (in place; every group of
+// a tile in flight at once) and the tile's total; the slab's offset from the block sums of level 1, the tile bases by a block scan.
+// Block 0: R to the host.  The small clears are spread over the grid.
+constexpr int kDbMaxGroups = 64;
+__global__ __launch_bounds__(256) void k_chunk_scan2(DirectBin db, unsigned long long* __restrict__ total_out, ZeroJobs zj,
+                                                     unsigned long long* __restrict__ host_out, unsigned long long host_seq,
+                                                     const unsigned int* __restrict__ window_overflow)
 {
-    __shared__ unsigned long long s_wsum[16];
-    __shared__ uint32_t s_tot[kDbMaxTiles];
+    __shared__ unsigned long long s_lo[4], s_all[4];
+    __shared__ uint32_t s_w[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int slab = (int)blockIdx.x, nslab = (int)gridDim.x, t = slab * 256 + tid;
 #pragma unroll
     for (int j = 0; j < 3; j++) {
         uint32_t* z = static_cast<uint32_t*>(zj.p[j]);
-        for (uint32_t q = tid; q < zj.words[j]; q += 1024) z[q] = 0u;
+        for (uint32_t q = (uint32_t)(slab * 256 + tid); q < zj.words[j]; q += (uint32_t)nslab * 256u) z[q] = 0u;
     }
-    constexpr int K = kDbMaxTiles / 1024;
-    // column t = tid + 1024 k: rows are read coalesced, eight groups of every column of this thread in flight at a time (sixteen: 19 us against 14.5)
-    uint32_t run[K];
-#pragma unroll
-    for (int k = 0; k < K; k++) run[k] = 0u;
-    for (int g0 = 0; g0 < db.G; g0 += 8) {
-        uint32_t v[K][8];
-#pragma unroll
-        for (int k = 0; k < K; k++)
-#pragma unroll
-            for (int q = 0; q < 8; q++) {
-                const int t = tid + 1024 * k, g = g0 + q;
-                v[k][q] = (t < db.Tp && g < db.G) ? db.GT[(size_t)g * db.Tp + t] : 0u;
-            }
-#pragma unroll
-        for (int k = 0; k < K; k++)
-#pragma unroll
-            for (int q = 0; q < 8; q++) {
-                const int t = tid + 1024 * k, g = g0 + q;
-                if (t < db.Tp && g < db.G) db.GT[(size_t)g * db.Tp + t] = run[k];
-                run[k] += v[k][q];
-            }
+    // this slab's offset (the instances of the slabs below it) and R, from the level-1 block sums
+    unsigned long long lo = 0ull, all = 0ull;
+    for (int i = tid; i < db.G * nslab; i += 256) {
+        const uint32_t v = db.bsum[i];
+        all += v;
+        if (i % nslab < slab) lo += v;
     }
 #pragma unroll
-    for (int k = 0; k < K; k++) s_tot[tid + 1024 * k] = (tid + 1024 * k < db.T) ? run[k] : 0u;
+    for (int off = 32; off > 0; off >>= 1) { lo += __shfl_xor(lo, off, 64); all += __shfl_xor(all, off, 64); }
+    if (lane == 0) { s_lo[wave] = lo; s_all[wave] = all; }
+    // the column of every tile of the slab
+    uint32_t tot = 0u;
+    if (t < db.Tp) {
+        uint32_t v[kDbMaxGroups];
+#pragma unroll
+        for (int g = 0; g < kDbMaxGroups; g++) v[g] = g < db.G ? db.GT[(size_t)g * db.Tp + t] : 0u;
+#pragma unroll
+        for (int g = 0; g < kDbMaxGroups; g++) {
+            if (g < db.G) db.GT[(size_t)g * db.Tp + t] = tot;
+            tot += v[g];
+        }
+    }
+    if (t >= db.T) tot = 0u;
+    const uint32_t inc = wave_inclusive_sum(tot);
+    if (lane == 63) s_w[wave] = inc;
     __syncthreads();
-    // exclusive scan over the tiles: four consecutive tiles per thread
-    uint32_t tot[K];
-    unsigned long long sum = 0ull;
+    lo = s_lo[0] + s_lo[1] + s_lo[2] + s_lo[3];
+    all = s_all[0] + s_all[1] + s_all[2] + s_all[3];
+    uint32_t add = 0u;
 #pragma unroll
-    for (int k = 0; k < K; k++) { tot[k] = s_tot[tid * K + k]; sum += tot[k]; }
-    unsigned long long inc = sum;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const unsigned long long y = __shfl_up(inc, off, 64);
-        if (lane >= off) inc += y;
-    }
-    if (lane == 63) s_wsum[wave] = inc;
-    __syncthreads();
-    unsigned long long add = 0ull, all = 0ull;
-#pragma unroll
-    for (int w = 0; w < 16; w++) { const unsigned long long t = s_wsum[w]; add += (w < wave) ? t : 0ull; all += t; }
-    unsigned long long pre = add + inc - sum;
-#pragma unroll
-    for (int k = 0; k < K; k++) {
-        const int t = tid * K + k;
-        if (t < db.T) db.tbase[t] = (uint32_t)min(pre, 0xffffffffull);   // (beyond 2^32 instances the host fails the call: positions only have to stay in bounds)
-        pre += tot[k];
-    }
-    if (tid == 0) {
+    for (int w = 0; w < 4; w++) add += w < wave ? s_w[w] : 0u;
+    // (beyond 2^32 instances the host fails the call: positions only have to stay in bounds)
+    if (t < db.T) db.tbase[t] = (uint32_t)min(lo + add + inc - tot, 0xffffffffull);
+    if (slab == 0 && tid == 0) {
         db.tbase[db.T] = (uint32_t)min(all, 0xffffffffull);
         *total_out = all;
         if (host_out) {   // as block_scan_body
@@ -1180,7 +1175,7 @@ __global__ __launch_bounds__(1024) void k_chunk_scan2(DirectBin db, unsigned lon
 }
 
 // (Measured and dropped: both levels in ONE launch, the last block of a slab / of the grid to arrive -- a ticket behind a
-//  __threadfence() -- doing the next level: 47 us against 5.5 + 14.5.  An agent-scope release writes the XCD's whole L2 back, and the
+//  __threadfence() -- doing the next level: 47 us against 5.5 + 14.5 (level 2 was one workgroup then).  An agent-scope release writes the XCD's whole L2 back, and the
 //  chunk tables the level-1 blocks have just rewritten are 6 MB of dirty lines.)
 // One wave per chunk.  LDS: a 64-bit lane mask and a position counter per tile, and the step's (tile, owner lane) pairs.
 // Per step of 64 depth-consecutive Gaussians:
@@ -1226,11 +1221,13 @@ __global__ __launch_bounds__(64) void k_chunk_scatter(DirectBin db, int W, int H
     {
         const uint32_t* gt = db.GT + (size_t)(c / db.Cg) * db.Tp;
         const uint16_t* mr = db.M + (size_t)c * db.Tp;
-        // (sixteen rows of loads in flight per wait: one at a time this loop was a fifth of the kernel)
-        for (int i0 = 0; i0 < db.Tp; i0 += 1024) {
-            uint32_t a[16], bb2[16], cc2[16];
+        // (every row of a 980x545 frame's tables in flight at once -- the chunk's rows were written by other XCDs and come from memory,
+        //  ~1.7 us a round trip: one row at a time this loop was a fifth of the kernel, sixteen at a time still three round trips)
+        constexpr int kRows = 36;
+        for (int i0 = 0; i0 < db.Tp; i0 += 64 * kRows) {
+            uint32_t a[kRows], bb2[kRows], cc2[kRows];
 #pragma unroll
-            for (int q = 0; q < 16; q++) {
+            for (int q = 0; q < kRows; q++) {
                 const int i = i0 + 64 * q + lane;
                 const bool v = i < db.Tp;
                 a[q] = v && i < db.T ? db.tbase[i] : 0u;
@@ -1238,7 +1235,7 @@ __global__ __launch_bounds__(64) void k_chunk_scatter(DirectBin db, int W, int H
                 cc2[q] = v ? (uint32_t)mr[i] : 0u;
             }
 #pragma unroll
-            for (int q = 0; q < 16; q++) {
+            for (int q = 0; q < kRows; q++) {
                 const int i = i0 + 64 * q + lane;
                 if (i < db.Tp) { s_cnt[i] = a[q] + bb2[q] + cc2[q]; s_mask[i] = 0ull; }
             }
@@ -2970,7 +2967,7 @@ int gsr_set_option(const char* name, int value)
 }
 
 // geometry + scratch of the direct binning for N Gaussians on T tiles; false: this frame keeps the sort route
-struct DirectBinScratch { size_t M, GT, tbase, bytes; };
+struct DirectBinScratch { size_t M, GT, tbase, bsum, bytes; };
 static bool direct_bin_geometry(int N, int T, DirectBin& db, DirectBinScratch& ds)
 {
     if (N < 1 || T < 1 || T > kDbMaxTiles) return false;
@@ -2987,7 +2984,7 @@ static bool direct_bin_geometry(int N, int T, DirectBin& db, DirectBinScratch& d
     if (env && atoi(env) > 0) per_cu = atoi(env);
     const long long resident = (long long)cus * per_cu;
     const char* env_s = getenv("GSR_DB_MIN_CHUNK");
-    const int min_s = env_s && atoi(env_s) > 0 ? atoi(env_s) : 256;
+    const int min_s = env_s && atoi(env_s) > 0 ? atoi(env_s) : 128;   // (measured at 20 k - 130 k Gaussians: 128 beats 64, 256 and 512)
     long long S = ((long long)N + resident - 1) / resident;
     S = std::max<long long>(min_s, (S + 63) & ~63ll);
     if (S > 65472) return false;
@@ -2997,10 +2994,12 @@ static bool direct_bin_geometry(int N, int T, DirectBin& db, DirectBinScratch& d
     while (G * G < db.NC) G++;
     db.Cg = std::max(1, std::min((db.NC + G - 1) / G, 65535 / db.S));
     db.G = (db.NC + db.Cg - 1) / db.Cg;
+    if (db.G > kDbMaxGroups) return false;
     size_t o = 0;
     ds.M = o; o += align256((size_t)db.NC * db.Tp * sizeof(uint16_t));
     ds.GT = o; o += align256((size_t)db.G * db.Tp * sizeof(uint32_t));
     ds.tbase = o; o += align256((size_t)(db.Tp + 1) * sizeof(uint32_t));
+    ds.bsum = o; o += align256((size_t)db.G * ((db.Tp + 255) / 256) * sizeof(uint32_t));
     ds.bytes = o;
     return true;
 }
@@ -3180,7 +3179,7 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
     const bool speculative = g_speculate && g_sort_algo == 2 && hint > 0;
     const uint64_t cap = speculative ? hint : 0;
 
-    fs = static_cast<uint8_t*>(a->alloc(L.bytes, GSR_ALLOC_SCRATCH, a->alloc_user));
+    fs = static_cast<uint8_t*>(a->alloc(align256(L.bytes) + (direct ? dbs.bytes : 0), GSR_ALLOC_SCRATCH, a->alloc_user));   // (+ the chunk tables of the direct binning)
     if (!fs) return fail(GSR_ERR_ALLOC, "scratch allocation failed%s");
     if (speculative) {
         rc = alloc_binning(cap);
@@ -3265,7 +3264,7 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
             hipLaunchKernelGGL(k_chunk_counts, dim3(db.NC + (bal.hdr ? 8 : 0)), dim3(kEmitThreads), 0, st, db, W, H,
                                tiles_x, tiles_y, sorted_gid, ntiles, splat, srec, bal);
             hipLaunchKernelGGL(k_chunk_scan1, dim3((db.Tp + 255) / 256, db.G), dim3(256), 0, st, db);
-            hipLaunchKernelGGL(k_chunk_scan2, dim3(1), dim3(1024), 0, st, db, total, zjobs, pin.s->dev, seq, wo);
+            hipLaunchKernelGGL(k_chunk_scan2, dim3((db.Tp + 255) / 256), dim3(256), 0, st, db, total, zjobs, pin.s->dev, seq, wo);
         } else {
             hipLaunchKernelGGL(k_tile_counts, dim3(nb + (bal.hdr ? 8 : 0)), dim3(kEmitThreads), 0, st, N, sorted_gid, ntiles, block_sums, srec, bal, nb);
             // the scan writes R straight into the pinned slot (device-visible host memory): no copy launch behind it
@@ -3313,9 +3312,9 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
             }
         }
         if (direct) {
-            uint8_t* dm = static_cast<uint8_t*>(a->alloc(dbs.bytes, GSR_ALLOC_SCRATCH, a->alloc_user));
-            if (!dm) return fail(GSR_ERR_ALLOC, "direct-binning scratch allocation failed%s");
+            uint8_t* dm = fs + align256(L.bytes);
             db.M = reinterpret_cast<uint16_t*>(dm + dbs.M); db.GT = reinterpret_cast<uint32_t*>(dm + dbs.GT); db.tbase = reinterpret_cast<uint32_t*>(dm + dbs.tbase);
+            db.bsum = reinterpret_cast<uint32_t*>(dm + dbs.bsum);
             zj.p[0] = nullptr; zj.words[0] = 0u;   // (the scatter writes every tile's range; there is no sort scratch)
             zj.p[2] = nullptr; zj.words[2] = 0u;
         }

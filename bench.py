@@ -501,8 +501,35 @@ def stage_a_batched_leg(dev, W=980, H=545, B=8, iters=150):
     return out
 
 
+_densify_warmed = False
+
+
+def warm_densify(syn, ts, dm, dev):
+    """One untimed clone + split + prune on a throw-away model: the first use of torch's masked-index / randn / bmm kernels loads
+    their code objects and initialises rocBLAS -- 0.2-0.6 s on a box whose page cache is cold, which a 300-step leg would report as
+    +2 ms per step (measured: the three densifications of the C3 leg cost 570 + 14 + 266 ms on a fresh box, 5-15 ms each warm)."""
+    global _densify_warmed
+    if _densify_warmed:
+        return
+    _densify_warmed = True
+    sc = syn.make_scene(20_000, 256, 256, sh_degree=3, seed=11)
+    p = ts.GaussianParams(sc, dev)
+    med = float(p.get_scaling.detach().max(dim=1).values.median())
+    den = dm.Densifier(p, scene_extent=med / 0.01, cfg=dm.DensifyConfig(densify_from_iter=0, densification_interval=1, percent_dense=0.01,
+                                                                         opacity_reset_interval=10 ** 9, max_points=10 ** 6))
+    with torch.no_grad():
+        for rep in range(2):
+            den.xyz_gradient_accum.fill_(1.0)
+            den.denom.fill_(1.0)
+            den.densify_and_prune(1e-6, 0.2, 20.0)      # half of the model is "small" (cloned), half "large" (split); low opacities pruned
+    del p, den
+    torch.cuda.synchronize(dev)
+
+
 def workload_leg(syn, ts, raster, dev, N, W, H, deg, steps, warmup, clustered=False, densify_every=0, seed=0):
     dm = importlib.import_module("3dgs_hierarchical_training_amd.densify")
+    if densify_every:
+        warm_densify(syn, ts, dm, dev)
     scene = syn.make_scene(N, W, H, sh_degree=deg, seed=seed, clustered=clustered)
     gt = syn.target_image(W, H, seed=1).to(dev)
     p = ts.GaussianParams(scene, dev)
