@@ -3681,6 +3681,16 @@ int gsr_backward(const GsrBackwardArgs* a, void* stream_)
     return GSR_OK;
 }
 
+int gsr_debug_direct_binning_geometry(int32_t N, int32_t T, int64_t out[7])
+{
+    if (!out) return GSR_ERR_ARG;
+    DirectBin db = {};
+    DirectBinScratch ds = {};
+    const bool ok = direct_bin_geometry(N, T, db, ds);
+    out[0] = ok ? 1 : 0; out[1] = db.S; out[2] = db.NC; out[3] = db.G; out[4] = db.Cg; out[5] = db.Tp; out[6] = ok ? (int64_t)ds.bytes : 0;
+    return GSR_OK;
+}
+
 int gsr_debug_read_binning(const void* binning, int64_t binning_capacity, int64_t num_rendered, int32_t W, int32_t H,
                             uint32_t* ranges_out, uint32_t* list_out, void* stream_)
 {

@@ -267,6 +267,10 @@ int gsr_version(void);
  *                          of (key - bits(0.2f)): depths between the near plane and 13 107 units; a visible Gaussian beyond that
  *                          makes the forward sort again on all 32 bits (counter "depth_window_resorts") and keeps that caller on
  *                          the four 8-bit passes; 0 = always four 8-bit passes.  Same order either way
+ *   "direct_binning"       1 (default) = the per-tile lists are built by direct placement -- per-chunk tile histograms over the
+ *                          depth-ordered Gaussians, column scans, one wave per chunk that places every (Gaussian, tile) pair at
+ *                          its final position -- on frames of up to 4 096 tiles; 0 = emit + stable tile sort + ranges (what larger
+ *                          frames always take).  Same list, bit for bit
  *   "blend_balance"        1 (default) = the forward blend places its sub-tile waves by the visits each took at the previous
  *                          render of the same view (device-side cache keyed by a hash of the view matrix; single renders through
  *                          the default kernel); 0 = dispatch order = tile order.  Same image either way
@@ -302,8 +306,14 @@ int64_t gsr_get_counter(const char* name);   /* + "blend_bwd_resident": workgrou
  * (num_rendered uint32) out of a forward's binning buffer into device buffers of the caller (either may be NULL). */
 int gsr_debug_read_binning(const void* binning, int64_t binning_capacity, int64_t num_rendered, int32_t W, int32_t H,
                            uint32_t* ranges_out, uint32_t* list_out, void* stream);
+/* Debug / test hook: the geometry the direct binning (option "direct_binning", default on: tile lists by per-chunk tile histograms,
+ * column scans and a one-wave-per-chunk scatter instead of emit + tile sort + ranges) would use for N Gaussians on T tiles:
+ * out[0..6] = { 1 if the direct route serves this frame (0: the sort route -- more than 4 096 tiles, or N out of range),
+ * Gaussians per chunk S (a multiple of 64), chunks NC, groups G, chunks per group Cg, T rounded up to 64, scratch bytes }.  Host only. */
+int gsr_debug_direct_binning_geometry(int32_t N, int32_t T, int64_t out[7]);
 /* Sum of the recorded durations of stage `name` ("preprocess_fwd", "sort_depth", "scan", "emit", "sort_tile",
- * "ranges", "blend_fwd", "blend_bwd", "preprocess_bwd") since the last read; synchronises on the events. */
+ * "ranges", "blend_fwd", "blend_bwd", "preprocess_bwd") since the last read; synchronises on the events.  With the direct binning
+ * "scan" = k_chunk_counts + the two column scans, "emit" = k_chunk_scatter, "sort_tile" / "ranges" record nothing. */
 int gsr_profile_read(const char* name, double* total_ms, int64_t* count);
 
 /* ---- "next" row f-3: fused photometric loss of the train step -----------------------

@@ -80,3 +80,28 @@ def test_product_path_does_not_import_oracle():
                 if fn.endswith((".py", ".hip", ".h")):
                     txt = open(os.path.join(dp, fn)).read()
                     assert "import oracle" not in txt and "from oracle" not in txt and "hostemu" not in txt.replace("tests/hostemu", ""), fn
+
+
+def test_direct_binning_geometry_invariants():
+    """Host logic of the direct binning (csrc/gsr_kernels.hip direct_bin_geometry): chunks of whole 64-Gaussian steps that cover N,
+    u16 counters that cannot overflow (a chunk, and a group of chunks, below 65 536 Gaussians), at most 64 groups, frames above
+    4 096 tiles left to the sort route.  No GPU needed."""
+    L = importlib.import_module("3dgs_hierarchical_training_amd._lib")
+    lib = L.load()
+    out = (C.c_int64 * 7)()
+    for N in (1, 63, 64, 65, 1000, 20_000, 130_000, 1_000_000, 4_000_000, 30_000_000):
+        for T in (1, 64, 256, 2170, 4096):
+            assert lib.gsr_debug_direct_binning_geometry(N, T, out) == 0
+            ok, S, NC, G, Cg, Tp, nbytes = (int(v) for v in out)
+            if not ok:
+                assert N > 4_000_000      # (only a model too large for 16-bit chunk counters is refused at these frame sizes)
+                continue
+            assert S % 64 == 0 and S >= 128 and S <= 65472
+            assert NC * S >= N > (NC - 1) * S
+            assert G * Cg >= NC > (G - 1) * Cg and 1 <= G <= 64
+            assert Cg * S <= 65535
+            assert Tp % 64 == 0 and T <= Tp < T + 64
+            assert nbytes >= NC * Tp * 2 + G * Tp * 4 + (T + 1) * 4
+    for N, T in ((0, 100), (1000, 0), (1000, 4097), (1000, 8160)):
+        assert lib.gsr_debug_direct_binning_geometry(N, T, out) == 0 and out[0] == 0
+
