@@ -872,6 +872,9 @@ def main():
                 "valu_roof_ms": cyc / 2.4e6, "frac_of_valu_roof": (cyc / 2.4e6 / launch_ms) if launch_ms else None,
                 # SQ_WAVE_CYCLES counts resident wave time in units of 4 cycles, summed over the chip
                 "avg_waves_per_simd": (kv["SQ_WAVE_CYCLES"] * 4.0 / (1024.0 * avail)) if ("SQ_WAVE_CYCLES" in kv and avail) else None,
+                # the hardware's own count of the cycles a SIMD's vector pipe was executing (SQ_ACTIVE_INST_VALU, units of 4 cycles,
+                # summed over the 1024 SIMDs) against the launch: what the calibrated estimate above bounds from below
+                "valu_busy_frac_counted": (kv["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * avail)) if ("SQ_ACTIVE_INST_VALU" in kv and avail) else None,
                 "counters_from": pmc_src, "counters_launch_ms": (avail / 2.4e6) if avail else None, "this_run_launch_ms": launch_ms}
 
     kb = next((v for k, v in pmc.items() if "k_blend_fwd" in k), {})
@@ -900,11 +903,13 @@ def main():
                        "avg_launch_ms": preb_ms, "traffic": kv.get("hbm_traffic_bytes"), "note": "durations from the untimed stage-profiling steps"})
     binds = None
     if valu_fwd and valu_fwd.get("frac") is not None:
-        binds = (f"not HBM: the vector pipe is busy >= {valu_fwd['frac']:.2f} of the launch at the calibrated {cal['plain']:.2f} cycles per wave64 "
-                 f"instruction ({cal['trans']:.1f} per transcendental); a wave alone on its SIMD issues one independent instruction per "
-                 f"{cal['single_wave']:.1f} cycles, and the launch averages {valu_fwd['avg_waves_per_simd']:.1f} resident waves per SIMD "
-                 "(one wave per 8x8 sub-tile, all started at once: the kernel ends with its longest lists) -- latency / occupancy-bound "
-                 "between the two roofs (DESIGN.md section 5)") if valu_fwd.get("avg_waves_per_simd") else None
+        counted = valu_fwd.get("valu_busy_frac_counted")
+        binds = (f"not HBM: the vector pipe.  By the hardware's own count (SQ_ACTIVE_INST_VALU) a SIMD's vector pipe is executing "
+                 f"{counted:.2f} of the launch; instruction counts x the calibrated {cal['plain']:.2f} cycles per plain wave64 instruction "
+                 f"({cal['trans']:.1f} per transcendental, {cal['double_pass']:.1f} per packed / DPP instruction, which the counters cannot separate) "
+                 f"bound that from below at {valu_fwd['frac']:.2f}.  The launch averages {valu_fwd['avg_waves_per_simd']:.1f} resident waves per SIMD "
+                 "(one wave per 8x8 sub-tile, all started at once: the kernel ends with its longest lists); fewer instructions per visit is "
+                 "the lever that is left (DESIGN.md sections 4, 8)") if (valu_fwd.get("avg_waves_per_simd") and counted) else None
     roofline = {"kernel": "gsr::k_blend_fwd_w6<true>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                 "traffic_source": f"{pmc_src} (rocprofv3 --pmc, separate passes; a committed summary, not this run)" if traffic else None,
