@@ -1559,6 +1559,9 @@ __device__ __forceinline__ void blend_fwd_item(const int xcd, const int kslot, f
             Dd = fmaf(B.z, w, Dd); Aa = fmaf(Tr, asel, Aa);   // (k_blend_fwd_w's `A += alpha * T` is contracted to this fma)
             Tr = pass ? test_T : -fabsf(Tr);                  // first failure flips the sign: done, |T| kept
             last = (pass && hit) ? (uint32_t)(b * NT + j + 1) : last;
+            // (round 4, measured again at eight waves per SIMD and 0.86 counted vector-pipe activity: the lanes that blend under EXEC
+            //  -- `if (hit) { if (pass) {...} else T = -|T| }`, 26 instead of 31 vector instructions per taken visit, three more
+            //  branches -- 105 us against 99-101)
         };
         // (round 3: issuing visit k + 1's broadcast reads before visit k's arithmetic -- two register sets, loop unrolled by two, no
         //  copies -- 117 -> 131 us with all three reads prefetched, 135 us with the pre-test fields only: the LDS round trip is not what a
