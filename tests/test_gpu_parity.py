@@ -679,6 +679,34 @@ def test_direct_binning_is_the_sort_routes_list(name):
     print(f"{name}: R {na}, longest tile list {counts.max()}, tiles in use {(counts > 0).sum()} of {counts.shape[0]}")
 
 
+@pytest.mark.parametrize("W,H,N", [(16, 16, 500), (17, 33, 900), (640, 480, 20000), (1024, 1024, 50000), (1040, 1024, 20000), (250, 3000, 8000)],
+                         ids=["one-tile", "2x3-tiles", "vga", "4096-tiles", "4160-tiles-sort-route", "tall"])
+def test_direct_binning_frame_sizes(W, H, N):
+    """Direct placement against the sort route over frame geometries: a single tile, ragged edge tiles, exactly the 4 096 tiles the
+    LDS tables hold, one tile row more (both options then take the sort route: the test is the option's no-op there), a tall frame
+    (tile ids in a narrow grid)."""
+    import importlib
+    import hip_runner
+    R_ = importlib.import_module("3dgs_hierarchical_training_amd.rasterizer")
+    L = importlib.import_module("3dgs_hierarchical_training_amd._lib")
+    lib = L.load()
+    sc = parity.syn.make_scene(N, W, H, sh_degree=0, seed=W + H, sigma_px=4.0)
+    kw = parity.scene_kwargs(sc, "sh")
+    res = {}
+    try:
+        for direct in (0, 1):
+            assert lib.gsr_set_option(b"direct_binning", direct) == 0
+            fwd = hip_runner.run_hip(kw)["fwd"]
+            ranges, lst = R_.last_binning()
+            res[direct] = (fwd, ranges.cpu().numpy().copy(), lst.cpu().numpy().copy(), R_._LAST["num_rendered"])
+    finally:
+        lib.gsr_set_option(b"direct_binning", 1)
+    (fa, ra, la, na), (fb, rb, lb, nb_) = res[0], res[1]
+    assert na == nb_ and na > 0 and np.array_equal(ra, rb) and np.array_equal(la[:na], lb[:nb_])
+    for x, y in zip(fa, fb):
+        assert np.array_equal(x, y)
+
+
 # ---- the reference-derived fixtures, on the HIP path ---------------------------------------------------------------------
 def _fixture_settings(g, tag, dev, noncontig):
     from diff_gaussian_rasterization import GaussianRasterizationSettings
