@@ -720,9 +720,10 @@ def main():
         pkg = ts.render(params, settings)
     n_visible = int((pkg["radii"] > 0).sum().item())
     del pkg
-    # timed region: HIP events only around the forward blend kernel (the roofline kernel); an event pair is a ~10 us
-    # stream bubble, so the per-stage breakdown is taken from a few extra UNTIMED steps afterwards
-    lib.gsr_set_option(b"profile", 2)
+    # timed region: only the forward blend kernel (the roofline kernel) is timed, by the start / stop timestamps of its own dispatch, and
+    # only on every third step -- a timed launch idles the queue ~11 us (tools/api_timeline.sh), all of it inside `value`; three is coprime
+    # with the eight rotating views, so every view is sampled.  The per-stage breakdown comes from a few extra UNTIMED steps afterwards
+    lib.gsr_set_option(b"profile", 3)
     read_profile(lib, STAGES)  # drop anything recorded so far
     sync_all()
     counters = ("forward_calls", "forward_ns", "forward_wait_ns", "backward_calls", "backward_ns", "spec_overflows", "spec_forwards", "exact_forwards")

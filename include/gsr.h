@@ -285,15 +285,19 @@ int gsr_version(void);
  *   "deterministic_backward" 1 = debug mode: the blend backward writes every (tile, Gaussian) partial gradient to its own slot and
  *                          a second kernel sums each Gaussian's slots in list order -- no float atomics, bit-identical gradients
  *                          from run to run (the default accumulates with atomics in arrival order); several times slower
- *   "profile"              1 = HIP events around every stage on the caller's stream, 2 = around the forward blend kernel
- *                          only (an event pair costs ~10 us of stream bubble per stage)
+ *   "profile"              1 = HIP events around every stage on the caller's stream (an event pair costs ~10 us of stream
+ *                          bubble per stage), 2 = only the forward blend kernel is timed, through the start / stop timestamps of
+ *                          its own dispatch (hipExtLaunchKernelGGL: still ~11 us of idle queue around the launch), 3 = as 2 on
+ *                          every THIRD forward (bench.py's timed region: all of eight rotating views get sampled)
  *   "emit_hist"            1 (default) = the emission kernel counts the tile sort's digits itself (speculative flow); 0 = a
  *                          histogram kernel in front of the sort's passes.  Same lists either way (A/B and tests)
  *   "prep_hist_max_n"      "prepare in backward": up to this many Gaussians (default 262 144) the per-Gaussian backward kernel
  *                          also counts the next depth sort's digits.  Read by BOTH the backward that fills a hand-over buffer
  *                          and the forward that consumes it: do not change it between the two
- *   "poll_iters"           bound of gsr_forward's busy-wait on the pinned instance-count word before it falls back to the
- *                          event (default 20 000 spins, about a millisecond; 0 = always wait on the event) */
+ *   "poll_iters"           bound of gsr_forward's busy-wait on the pinned instance-count word, in units of ~50 ns (default
+ *                          400 000 = 20 ms; past it the call waits with hipStreamSynchronize, which also reports a faulted
+ *                          device); 0 = no busy waiting: an event is recorded behind the scan kernel and waited on (up to
+ *                          round 3 that event was recorded on every forward: ~6 us of idle queue each) */
 int gsr_set_option(const char* name, int value);
 /* Monotonic counters: "spec_forwards" (forwards launched against a capacity), "spec_overflows" (of those, how many had to
  * re-run the binning because R exceeded the capacity), "exact_forwards" (read-then-launch forwards), "spec_callers"
