@@ -1227,19 +1227,19 @@ __global__ __launch_bounds__(64) void k_chunk_scatter(DirectBin db, int W, int H
         //  ~1.7 us a round trip: one row at a time this loop was a fifth of the kernel, sixteen at a time still three round trips)
         constexpr int kRows = 36;
         for (int i0 = 0; i0 < db.Tp; i0 += 64 * kRows) {
-            uint32_t a[kRows], bb2[kRows], cc2[kRows];
+            uint32_t tb[kRows], gb[kRows], mc[kRows];   // tile base, the group's start in the tile, the chunk's start in the group
 #pragma unroll
             for (int q = 0; q < kRows; q++) {
                 const int i = i0 + 64 * q + lane;
                 const bool v = i < db.Tp;
-                a[q] = v && i < db.T ? db.tbase[i] : 0u;
-                bb2[q] = v ? gt[i] : 0u;
-                cc2[q] = v ? (uint32_t)mr[i] : 0u;
+                tb[q] = v && i < db.T ? db.tbase[i] : 0u;
+                gb[q] = v ? gt[i] : 0u;
+                mc[q] = v ? (uint32_t)mr[i] : 0u;
             }
 #pragma unroll
             for (int q = 0; q < kRows; q++) {
                 const int i = i0 + 64 * q + lane;
-                if (i < db.Tp) { s_cnt[i] = a[q] + bb2[q] + cc2[q]; s_mask[i] = 0ull; }
+                if (i < db.Tp) { s_cnt[i] = tb[q] + gb[q] + mc[q]; s_mask[i] = 0ull; }
             }
         }
     }
@@ -2976,11 +2976,12 @@ struct DirectBinScratch { size_t M, GT, tbase, bsum, bytes; };
 static bool direct_bin_geometry(int N, int T, DirectBin& db, DirectBinScratch& ds)
 {
     if (N < 1 || T < 1 || T > kDbMaxTiles) return false;
-    static int cus = 0;
+    static std::atomic<int> cus_cached{0};   // (compute units of the first device asked about: all devices of a node are alike)
+    int cus = cus_cached.load(std::memory_order_relaxed);
     if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+        int dev = 0, n = 0;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+        cus_cached.store(cus, std::memory_order_relaxed);
     }
     db.N = N; db.T = T; db.Tp = (T + 63) & ~63;
     const int lds = 12 * db.Tp + 4 * kDbPairs;
