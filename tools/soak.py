@@ -3,7 +3,8 @@ every 500 / 3000 steps, checking for non-finite parameters.  Needs a GPU:  gpuru
 (round 1: 12 000 steps at 300 k in 9 s and 40 000 steps at 1 M -> 2.9 M Gaussians in 73 s, no non-finite value, no hang;
 round 2 runs the loop with the hand-over to the next view, as run_segments.py does; round 3: the model starts at SH degree 0 and is
 raised every 1 000 steps with the hand-over kept across the change, and a real `Densifier` collects its statistics inside the backward
-kernel and densifies / prunes every 500 steps on top of the random surgery)."""
+kernel and densifies / prunes every 500 steps on top of the random surgery; round 4, with the direct binning and the persistent backward
+blend: 40 000 steps at 1 M -> 2.95 M Gaussians in 72 s, 12 000 steps at 300 k in 9.0 s, no non-finite value, no hang)."""
 import sys, time, importlib, torch
 sys.path.insert(0, '.')   # run from the repository root
 syn = importlib.import_module('3dgs_hierarchical_training_amd.synthetic')
