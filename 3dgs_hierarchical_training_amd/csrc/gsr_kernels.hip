@@ -3498,9 +3498,6 @@ int gsr_backward(const GsrBackwardArgs* a, void* stream_)
     const bool blend_items = a->num_rendered > 0 && bwd_ppt == 2;
     // ONE launch clears the per-Gaussian accumulators and (workgroup 0) builds the backward blend's work items from the forward's
     // staged depths -- where the 48 N-byte memset stood
-    // (round 3, measured and dropped: the extension allocating this scratch in the FORWARD and clearing it on a side stream behind
-    //  an event, so that the 8 us fill runs next to the forward's kernels instead of in front of the backward's -- 0.863-0.873 ms per
-    //  step against 0.847-0.855 with the fill here, same box: the concurrent fill takes more from the sorts than it saves)
     BwdItemHdr* item_hdr = nullptr;
     const uint2* items = nullptr;
     int bwd_grid = 0;
