@@ -41,7 +41,7 @@ def _register_fakes():
     @torch.library.register_fake("gsr::rasterize_forward")
     def _(means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, sh_rest, viewmatrix, projmatrix, campos, bg,
           points_transform, image_height, image_width, tanfovx, tanfovy, scale_modifier, sh_degree, raw_params, prefiltered, debug,
-          prepared, batch_first_block):
+          prepared, batch_first_block, view_id=0):
         N, H, W = means3D.shape[0], image_height, image_width
         f = lambda *s: means3D.new_empty(s, dtype=torch.float32)
         b = lambda n: means3D.new_empty((n,), dtype=torch.uint8)
@@ -56,7 +56,7 @@ def _register_fakes():
     def _(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, sh_rest, viewmatrix, projmatrix, campos,
           bg, points_transform, image_height, image_width, tanfovx, tanfovy, scale_modifier, sh_degree, raw_params, prefiltered, debug,
           cam_grad, adam_m, adam_v, adam_lr, beta1, beta2, eps, step, prepared, next_viewmatrix, next_projmatrix, next_campos,
-          next_height, next_width, next_tanfovx, next_tanfovy, next_points_transform, next_sh_degree, adam_commit, densify_stats, batch_first_block):
+          next_height, next_width, next_tanfovx, next_tanfovy, next_points_transform, next_sh_degree, adam_commit, densify_stats, batch_first_block, view_id=0):
         N, H, W = means3D.shape[0], image_height, image_width
         f = lambda *s: means3D.new_empty(s, dtype=torch.float32)
         nprep = lib.gsr_prepared_bytes(int(N)) if next_viewmatrix.numel() else 0

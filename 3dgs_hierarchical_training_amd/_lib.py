@@ -25,6 +25,7 @@ class GsrForwardArgs(C.Structure):
         ("alloc", ALLOC_FN), ("alloc_user", C.c_void_p),
         ("shs_rest", C.c_void_p), ("raw_params", C.c_int32),
         ("points_transform", C.c_void_p), ("prepared", C.c_void_p), ("batch", C.c_void_p),
+        ("view_id", C.c_int64),
     ]
 
 
@@ -72,7 +73,7 @@ EXPORTS = [
     "gsr_mark_visible", "gsr_last_error", "gsr_version", "gsr_set_option", "gsr_sort_pairs_u32",
     "gsr_sort_pairs_u16", "gsr_sort_scratch_bytes", "gsr_image_staged_offset", "gsr_profile_read",
     "gsr_loss_workspace_bytes", "gsr_loss_forward", "gsr_loss_backward", "gsr_adam_step", "gsr_pose_step", "gsr_pose_step_camera",
-    "gsr_knn_scratch_bytes", "gsr_knn_mean_dist2", "gsr_get_counter", "gsr_debug_read_binning", "gsr_debug_direct_binning_geometry", "gsr_prepared_bytes",
+    "gsr_knn_scratch_bytes", "gsr_knn_mean_dist2", "gsr_get_counter", "gsr_debug_read_binning", "gsr_debug_direct_binning_geometry", "gsr_debug_view_cache_stats", "gsr_prepared_bytes",
     "gsr_prepare_supported", "gsr_prepared_radii_offset", "gsr_stream_copy", "gsr_image_bytes_batched",
     "gsr_masked_max", "gsr_densify_stats_add", "gsr_psnr_scratch_bytes", "gsr_psnr",
     "gsr_loss_workspace_bytes_batched", "gsr_loss_forward_batched", "gsr_loss_backward_batched",
@@ -144,6 +145,8 @@ def load():
     lib.gsr_get_counter.argtypes = [C.c_char_p]
     lib.gsr_debug_direct_binning_geometry.restype = C.c_int
     lib.gsr_debug_direct_binning_geometry.argtypes = [C.c_int32, C.c_int32, C.POINTER(C.c_int64)]
+    lib.gsr_debug_view_cache_stats.restype = C.c_int
+    lib.gsr_debug_view_cache_stats.argtypes = [C.c_int32, C.c_int32, C.POINTER(C.c_int64)]
     lib.gsr_debug_read_binning.restype = C.c_int
     lib.gsr_debug_read_binning.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     for fn in ["gsr_sort_pairs_u32", "gsr_sort_pairs_u16"]:

@@ -655,52 +655,80 @@ __device__ __forceinline__ void block_scan_body(uint32_t* block_sums, int nb, un
 // start twice IN SERIES on one wave where the dispatcher starts the late item on the first slot that frees anywhere in the XCD:
 // 116 us against 98 (identity order: 111).
 // ------------------------------------------------------------------------------------------------
-constexpr int kVcEntries = 32;
+constexpr int kVcEntries = 128;
+constexpr int kVcPoseFloats = 28;   // view matrix (16) + points_transform (12; identity when the caller passes none)
 struct ViewCostHdr {
-    unsigned long long hash[kVcEntries];
+    unsigned long long key[kVcEntries];     // 0 = empty; 2 = keyed by pose (nearest stored pose within the tolerance); odd = keyed by the caller's view id
     uint32_t stamp[kVcEntries];
     uint32_t clock, pad[31];
+    float pose[kVcEntries][kVcPoseFloats];  // the pose of the entry's last render (both kinds of key)
 };
 struct BlendBalance {       // kernel-argument bundle; hdr == nullptr: off
     ViewCostHdr* hdr;
     uint16_t* cost;         // [kVcEntries][items]: visits of workgroup-item (xcd + 8 kslot) at the last render of that view
     uint16_t* perm;         // per call: dispatch slot (xcd + 8 k) -> item's kslot
-    uint32_t* cur;          // per call: [0] cache entry this render records into (0xffffffff: none), [1] perm valid
-    const float* vm;        // the view matrix (16 floats) the hash is taken of
+    uint32_t* cur;          // per call: [0] cache entry this render records into (0xffffffff: none), [1 + x] XCD x's slice of perm is valid
+    const float* vm;        // what identifies the frame: the view matrix (16 floats) ...
+    const float* pt;        // ... and the points transform (12 floats, or nullptr) -- the reference trains with an identity camera and moves the points
+    long long view_id;      // ... or, when non-zero, the caller's frame id (GsrForwardArgs::view_id): exact match, the pose may drift freely
+    float tol;              // pose match: largest absolute difference of any of the 28 entries
     int items, nslots4, W, H;
 };
 
-__device__ __forceinline__ unsigned long long view_hash(const float* vm, int W, int H)
+// Which cache entry is this render's view?  (round 5: until round 4 the key was a bit-exact hash of the view matrix -- under the
+// reference's calling convention, identity camera + the pose through get_xyz (/root/reference/trainer/trainer.py:993-995,
+// scene/gaussian_model_ht.py:135-148), every frame hashed to ONE entry; and a camera that carries a pose under refinement changes its
+// bits every step (ht3dgs_trainer.py:162-166) and never hit.)  With a view id: the entry of that id.  Without: the entry whose stored
+// pose (view matrix and points transform) is nearest to this render's, if within `tol` in every entry -- a pose under refinement moves
+// by ~1e-4..1e-3 per step and the entry follows it (the stored pose is replaced on every hit); two frames closer than `tol` to each other
+// share an entry, which is harmless: their visit counts are as correlated as one frame's with itself a few steps later.
+// Every builder workgroup decides for itself (they cannot synchronise); the decisions may differ when another stream touches the cache
+// in between -- each XCD's slice of perm carries its own valid flag, so any mix is still a permutation per XCD.
+__device__ __forceinline__ unsigned long long view_id_key(long long id)
 {
-    unsigned long long h = 1469598103934665603ull;
-    for (int i = 0; i < 16; i++) { h ^= (unsigned long long)__float_as_uint(vm[i]); h *= 1099511628211ull; }
-    h ^= ((unsigned long long)(uint32_t)W << 32) | (uint32_t)H; h *= 1099511628211ull;
-    return h | 1ull;        // (0 = empty entry)
+    unsigned long long h = 1469598103934665603ull ^ (unsigned long long)id;
+    h *= 1099511628211ull; h ^= h >> 29; h *= 1099511628211ull;
+    return h | 1ull;
 }
 
 __device__ void balance_build(const BlendBalance bb, const int x)
 {
     __shared__ uint32_t s_hist[1024];
-    __shared__ int s_entry;
+    __shared__ unsigned long long s_best;
+    __shared__ float s_pose[kVcPoseFloats];
     const int tid = threadIdx.x;
-    const unsigned long long h = view_hash(bb.vm, bb.W, bb.H);
-    if (tid == 0) s_entry = -1;
+    if (tid == 0) s_best = ~0ull;
+    if (tid < 16) s_pose[tid] = bb.vm[tid];
+    else if (tid < kVcPoseFloats) s_pose[tid] = bb.pt ? bb.pt[tid - 16] : (((tid - 16) % 5 == 0) ? 1.f : 0.f);   // rows of [I | 0]
     for (int q = tid; q < 1024; q += kEmitThreads) s_hist[q] = 0u;
     __syncthreads();
-    if (tid < kVcEntries && bb.hdr->hash[tid] == h) s_entry = tid;
+    const unsigned long long want = bb.view_id ? view_id_key(bb.view_id) : 2ull;
+    if (tid < kVcEntries && bb.hdr->key[tid] == want) {
+        float d = 0.f;
+        if (!bb.view_id) {
+            const float* p = bb.hdr->pose[tid];
+            bool near = true;        // (fmaxf drops a NaN difference: a NaN pose must match nothing)
+            for (int i = 0; i < kVcPoseFloats; i++) { const float df = fabsf(p[i] - s_pose[i]); near = near && (df <= bb.tol); d = fmaxf(d, df); }
+            if (!near) d = 3.0e38f;
+        }
+        if (d <= bb.tol) atomicMin(&s_best, ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)tid);
+    }
     __syncthreads();
-    const int e = s_entry;
+    const int e = s_best == ~0ull ? -1 : (int)(s_best & 0xffffffffull);
     if (x == 0 && tid == 0) {   // workgroup 0 keeps the cache's books: touch the entry, or take the least recently used one
         int rec = e;
         const uint32_t now = bb.hdr->clock + 1u;
         if (rec < 0) {
             uint32_t best = 0xffffffffu;
             for (int i = 0; i < kVcEntries; i++) if (bb.hdr->stamp[i] < best) { best = bb.hdr->stamp[i]; rec = i; }
-            bb.hdr->hash[rec] = h;
+            bb.hdr->key[rec] = want;
         }
+        for (int i = 0; i < kVcPoseFloats; i++) bb.hdr->pose[rec][i] = s_pose[i];
         bb.hdr->stamp[rec] = now; bb.hdr->clock = now;
-        bb.cur[0] = (uint32_t)rec; bb.cur[1] = e >= 0 ? 1u : 0u;
+        bb.hdr->pad[0] += 1u; bb.hdr->pad[1] += e >= 0 ? 1u : 0u;      // lookups / hits (gsr_debug_view_cache_stats)
+        bb.cur[0] = (uint32_t)rec;
     }
+    if (tid == 0) bb.cur[1 + x] = e >= 0 ? 1u : 0u;
     if (e < 0) return;          // first render of this view: identity placement (the blend ignores perm)
     const uint16_t* cost = bb.cost + (size_t)e * bb.items;
     // counting sort of this XCD's items by predicted visits, descending; ties in any order
@@ -1642,7 +1670,10 @@ __global__ __launch_bounds__(64) void k_blend_fwd_w6(int W, int H, int tiles_x, 
         const uint32_t* __restrict__ cur = bb.cur;
         const uint16_t* __restrict__ perm = bb.perm;
         const uint32_t e = cur[0];
-        if (cur[1]) kslot = (int)perm[blockIdx.x];
+        if (cur[1 + (blockIdx.x & 7u)]) {       // this XCD's slice of the table was built (each builder workgroup says so itself)
+            const int k = (int)perm[blockIdx.x];
+            if (k < bb.nslots4) kslot = k;
+        }
         if (e < (uint32_t)kVcEntries) cost_out = bb.cost + (size_t)e * bb.items;
     }
     blend_fwd_item<REACH>((int)(blockIdx.x & 7), kslot, s_ab, s_c, W, H, tiles_x, T, ranges, list, splat, bg, out_color, out_depth,
@@ -2766,6 +2797,7 @@ static int g_ckpt_first = 1;  // 128-instance batches of a tile before the forwa
 constexpr uint32_t kDepthKeyBias = 0x3E4CCCCDu;   // bit pattern of the near plane, 0.2f (gsr_math.h kNearZ): no visible Gaussian's depth key lies below it
 static int g_depth_sort9 = 1;     // depth sort of large models in three 9-bit passes over (key - near-plane bits) (radix_sort.h); 0 = four 8-bit passes
 static int g_direct_bin = 1;      // tile lists by direct placement (k_chunk_counts / k_chunk_scatter) instead of emit + tile sort + ranges; 0 = the sort route
+static int g_view_pose_tol_e6 = 2000;   // balanced placement without a view id: a render belongs to the cached view whose pose is within this (x 1e-6) in every matrix entry
 static int g_blend_balance = 1;   // forward blend: place the waves by the visits each took at the previous render of the same view (balance_build)
 static int g_tile_map = 2;   // tile -> XCD map: 2 = 2x2 tile blocks interleaved (default), 1 = tiles interleaved, 0 = banded
 static std::atomic<long long> g_spec_overflows{0}, g_spec_forwards{0}, g_exact_forwards{0}, g_depth_window_resorts{0};
@@ -2939,6 +2971,7 @@ int gsr_set_option(const char* name, int value)
     if (!strcmp(name, "ckpt_first")) { if (value < 1 || value > 64) return GSR_ERR_ARG; g_ckpt_first = value; return GSR_OK; }
     if (!strcmp(name, "tile_map")) { if (value < 0 || value > 2) return GSR_ERR_ARG; g_tile_map = value; return GSR_OK; }
     if (!strcmp(name, "blend_balance")) { g_blend_balance = value ? 1 : 0; return GSR_OK; }
+    if (!strcmp(name, "view_pose_tol_e6")) { if (value < 0) return GSR_ERR_ARG; g_view_pose_tol_e6 = value; return GSR_OK; }
     if (!strcmp(name, "depth_sort9")) { g_depth_sort9 = value ? 1 : 0; return GSR_OK; }
     if (!strcmp(name, "direct_binning")) { g_direct_bin = value ? 1 : 0; return GSR_OK; }
     if (!strcmp(name, "speculative_binning")) { g_speculate = value ? 1 : 0; return GSR_OK; }
@@ -3322,7 +3355,8 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
                     bb.cost = reinterpret_cast<uint16_t*>(mem + hdr_bytes);
                     bb.cur = reinterpret_cast<uint32_t*>(ib);
                     bb.perm = reinterpret_cast<uint16_t*>(ib + 256);
-                    bb.vm = a->viewmatrix;
+                    bb.vm = a->viewmatrix; bb.pt = a->points_transform; bb.view_id = (long long)a->view_id;
+                    bb.tol = 1e-6f * (float)g_view_pose_tol_e6;
                     bb.items = items; bb.nslots4 = nslots4; bb.W = W; bb.H = H;
                 }
             }
@@ -3702,6 +3736,27 @@ int gsr_backward(const GsrBackwardArgs* a, void* stream_)
         hipLaunchKernelGGL(k_cam_reduce, dim3(kCamVals, NB), dim3(256), 0, st, cam_partial, grid, a->d_viewmatrix, a->d_projmatrix, a->d_campos,
                            a->d_points_transform, bt);
     GSR_HIP(hipGetLastError());
+    return GSR_OK;
+}
+
+int gsr_debug_view_cache_stats(int32_t W, int32_t H, int64_t out[4])
+{
+    // the balanced placement's per-view cost caches of the CURRENT device for this frame size: lookups, hits, entries in use, caches
+    int dev_id = 0;
+    if (hipGetDevice(&dev_id) != hipSuccess) return fail(GSR_ERR_HIP, "hipGetDevice failed%s");
+    out[0] = out[1] = out[2] = out[3] = 0;
+    std::vector<uint8_t*> mems;
+    {
+        std::lock_guard<std::mutex> lk(g_state_mutex);
+        for (auto& c : g_view_costs) if (c.dev == dev_id && c.W == W && c.H == H) mems.push_back(c.mem);
+    }
+    for (uint8_t* m : mems) {
+        ViewCostHdr h;
+        if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(&h, m, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess)
+            return fail(GSR_ERR_HIP, "view cache read-back failed%s");
+        out[0] += h.pad[0]; out[1] += h.pad[1]; out[3] += 1;
+        for (int i = 0; i < kVcEntries; i++) out[2] += h.key[i] != 0ull;
+    }
     return GSR_OK;
 }
 

@@ -101,7 +101,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> raste
     const Tensor& rotations_, const Tensor& cov3D_, const Tensor& sh_rest_, const Tensor& viewmatrix_, const Tensor& projmatrix_,
     const Tensor& campos_, const Tensor& bg_, const Tensor& xf_, int64_t H, int64_t W, double tanfovx, double tanfovy,
     double scale_modifier, int64_t sh_degree, bool raw_params, bool prefiltered, bool debug, const Tensor& prepared,
-    at::IntArrayRef batch_first_block)
+    at::IntArrayRef batch_first_block, int64_t view_id)
 {
     TORCH_CHECK(means3D_.is_cuda(), "GaussianRasterizer: tensors must be on a ROCm/HIP device (no CPU fallback)");
     const BatchArg batch(batch_first_block);
@@ -148,6 +148,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> raste
     a.points_transform = fp(xf);
     a.prepared = has(prepared) ? prepared.data_ptr() : nullptr;
     a.batch = batch.ptr();
+    a.view_id = view_id;
     GsrForwardOut out{};
     check(gsr_forward(&a, &out, c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()), "gsr_forward");
     // (scratch tensors die here: stream-ordered reuse by the caching allocator is safe, same stream)
@@ -334,6 +335,7 @@ struct Cfg {
     Tensor next_vm, next_pm, next_campos; // camera of the NEXT render (or undefined): the backward prepares it
     Tensor next_xf;                       // ... and its points_transform, when it differs from this render's (per-frame poses)
     int64_t next_H = 0, next_W = 0, next_D = -1;   // next_D: SH degree of the next render (-1 = this render's)
+    int64_t view_id = 0;                           // GsrForwardArgs::view_id
     double next_tanfovx = 0, next_tanfovy = 0;
 };
 
@@ -354,7 +356,7 @@ class RasterizeFn : public torch::autograd::Function<RasterizeFn> {
         Tensor none;
         auto out = op.call(m3, s, c, o, sc, r, cv, rs, v, p, cp, b, x, cfg.H, cfg.W, cfg.tanfovx, cfg.tanfovy, cfg.scale_modifier,
                            cfg.sh_degree, cfg.raw_params, cfg.prefiltered, cfg.debug, cfg.prepared.defined() ? cfg.prepared : x.new_empty({0}, x.options().dtype(at::kByte)),
-                           cfg.batch);
+                           cfg.batch, cfg.view_id);
         // hand-over buffer for the NEXT render, filled by this render's backward (stream-ordered): allocated here so that it
         // can be returned to the caller as an ordinary output
         Tensor prep_out = has(cfg.next_vm) ? at::empty({(int64_t)gsr_prepared_bytes((int32_t)m3.size(0))}, m3.options().dtype(at::kByte))
@@ -449,13 +451,14 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> rasterize(
     bool prefiltered, bool debug, bool cam_grad, at::TensorList adam_m, at::TensorList adam_v, at::ArrayRef<double> adam_lr, double beta1,
     double beta2, double eps, int64_t step, const Tensor& prepared, const Tensor& next_vm, const Tensor& next_pm, const Tensor& next_campos,
     int64_t next_H, int64_t next_W, double next_tanfovx, double next_tanfovy, const Tensor& next_xf, int64_t next_sh_degree,
-    const Tensor& adam_commit, at::TensorList densify_stats, at::IntArrayRef batch_first_block)
+    const Tensor& adam_commit, at::TensorList densify_stats, at::IntArrayRef batch_first_block, int64_t view_id)
 {
     Cfg cfg{H, W, sh_degree, step, tanfovx, tanfovy, scale_modifier, beta1, beta2, eps, raw_params, prefiltered, debug, cam_grad,
             std::vector<double>(adam_lr.begin(), adam_lr.end()), adam_m.vec(), adam_v.vec()};
     if (has(prepared)) cfg.prepared = prepared;
     cfg.densify_stats = densify_stats.vec();
     cfg.batch.assign(batch_first_block.begin(), batch_first_block.end());
+    cfg.view_id = view_id;
     if (!adam_m.empty()) {
         TORCH_CHECK(has(adam_commit) && adam_commit.is_cpu() && adam_commit.scalar_type() == at::kLong, "fused_adam: adam_commit must be a CPU int64 tensor");
         cfg.adam_commit = adam_commit;
@@ -479,12 +482,12 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> rasterize_forward_only(
     bool prefiltered, bool debug, bool cam_grad, at::TensorList adam_m, at::TensorList adam_v, at::ArrayRef<double> adam_lr, double beta1,
     double beta2, double eps, int64_t step, const Tensor& prepared, const Tensor& next_vm, const Tensor& next_pm, const Tensor& next_campos,
     int64_t next_H, int64_t next_W, double next_tanfovx, double next_tanfovy, const Tensor& next_xf, int64_t next_sh_degree,
-    const Tensor& adam_commit, at::TensorList densify_stats, at::IntArrayRef batch_first_block)
+    const Tensor& adam_commit, at::TensorList densify_stats, at::IntArrayRef batch_first_block, int64_t view_id)
 {
     (void)means2D; (void)next_xf; (void)next_sh_degree; (void)adam_commit; (void)densify_stats; (void)cam_grad; (void)adam_m; (void)adam_v; (void)adam_lr; (void)beta1; (void)beta2; (void)eps; (void)step;
     (void)next_vm; (void)next_pm; (void)next_campos; (void)next_H; (void)next_W; (void)next_tanfovx; (void)next_tanfovy;
     auto out = rasterize_forward(means3D, sh, colors, opac, scales, rots, cov, rest, vm, pm, campos, bg, (has(xf) && xf.dim() == 2) ? xf.slice(0, 0, 3) : xf, H, W,
-                                 tanfovx, tanfovy, scale_modifier, sh_degree, raw_params, prefiltered, debug, prepared, batch_first_block);
+                                 tanfovx, tanfovy, scale_modifier, sh_degree, raw_params, prefiltered, debug, prepared, batch_first_block, view_id);
     return {std::get<0>(out), std::get<1>(out), std::get<2>(out), std::get<3>(out), at::empty({0}, means3D.options().dtype(at::kByte))};
 }
 
@@ -692,7 +695,7 @@ TORCH_LIBRARY(gsr, m)
     m.def("rasterize_forward(Tensor means3D, Tensor sh, Tensor colors_precomp, Tensor opacities, Tensor scales, Tensor rotations, "
           "Tensor cov3D_precomp, Tensor sh_rest, Tensor viewmatrix, Tensor projmatrix, Tensor campos, Tensor bg, Tensor points_transform, "
           "int image_height, int image_width, float tanfovx, float tanfovy, float scale_modifier, int sh_degree, bool raw_params, "
-          "bool prefiltered, bool debug, Tensor prepared, int[] batch_first_block) -> (Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)");
+          "bool prefiltered, bool debug, Tensor prepared, int[] batch_first_block, int view_id=0) -> (Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)");
     m.def("rasterize_backward(Tensor means3D, Tensor sh, Tensor colors_precomp, Tensor opacities, Tensor scales, Tensor rotations, "
           "Tensor cov3D_precomp, Tensor sh_rest, Tensor viewmatrix, Tensor projmatrix, Tensor campos, Tensor bg, Tensor points_transform, "
           "Tensor geom, Tensor image, Tensor binning, Tensor meta, Tensor grad_color, Tensor grad_depth, Tensor grad_alpha, "
@@ -710,7 +713,7 @@ TORCH_LIBRARY(gsr, m)
           "int image_height, int image_width, float tanfovx, float tanfovy, float scale_modifier, int sh_degree, bool raw_params, "
           "bool prefiltered, bool debug, bool cam_grad, Tensor[] adam_m, Tensor[] adam_v, float[] adam_lr, float beta1, float beta2, "
           "float eps, int step, Tensor prepared, Tensor next_viewmatrix, Tensor next_projmatrix, Tensor next_campos, int next_height, "
-          "int next_width, float next_tanfovx, float next_tanfovy, Tensor next_points_transform, int next_sh_degree, Tensor adam_commit, Tensor[] densify_stats, int[] batch_first_block) -> "
+          "int next_width, float next_tanfovx, float next_tanfovy, Tensor next_points_transform, int next_sh_degree, Tensor adam_commit, Tensor[] densify_stats, int[] batch_first_block, int view_id=0) -> "
           "(Tensor, Tensor, Tensor, Tensor, Tensor)");
     m.def("mark_visible(Tensor means3D, Tensor viewmatrix, Tensor projmatrix) -> Tensor");
     m.def("photometric_loss_forward(Tensor render, Tensor target, float lambda_dssim, bool clamp) -> (Tensor, Tensor)");

@@ -132,7 +132,7 @@ class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
                 sh_rest=None, raw_params=False, viewmatrix=None, projmatrix=None, campos=None, fused_adam=None,
-                points_transform=None):
+                points_transform=None, view_id=0):
         # viewmatrix / projmatrix / campos are ALSO passed as explicit tensor inputs (same objects as in
         # raster_settings) so that autograd can return their gradients: a NamedTuple cannot carry grads.
         lib = L.load()
@@ -179,6 +179,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         a.alloc, a.alloc_user = ws.cb, None
         a.shs_rest, a.raw_params = _ptr(sh_rest), int(bool(raw_params))
         a.points_transform = _ptr(xf)
+        a.view_id = int(view_id)
         out = L.GsrForwardOut()
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
@@ -218,7 +219,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         dev = means3D.device
         grad_color, grad_depth, grad_alpha = _f32c(grad_color), _f32c(grad_depth), _f32c(grad_alpha)
         if grad_color is None and grad_depth is None and grad_alpha is None:
-            return (None,) * 16
+            return (None,) * 17
         need_vm, need_pm, need_cp = ctx.needs_input_grad[11], ctx.needs_input_grad[12], ctx.needs_input_grad[13]
         d_vm = torch.empty((4, 4), dtype=torch.float32, device=dev) if need_vm else None
         d_pm = torch.empty((4, 4), dtype=torch.float32, device=dev) if need_pm else None
@@ -276,7 +277,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             L.check(lib.gsr_backward(C.byref(a), C.c_void_p(stream)), "gsr_backward")
         if fused is not None:
             fused.fused_backward_applied()      # the update is enqueued: the optimizer's step count advances now, not at render time
-        return (d_means3D, d_means2D, d_sh, d_col, d_opac, d_scales, d_rot, d_cov, None, d_sh_rest, None, d_vm, d_pm, d_cp, None, d_xf)
+        return (d_means3D, d_means2D, d_sh, d_col, d_opac, d_scales, d_rot, d_cov, None, d_sh_rest, None, d_vm, d_pm, d_cp, None, d_xf, None)
 
 
 def _cam_inputs(rs):
@@ -305,7 +306,7 @@ def _ecpu():
 
 def _rasterize_ext(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, rs, sh_rest, raw_params,
                    fused_adam, points_transform, prepared=None, prepare_next=None, next_points_transform=None, densify_stats=None,
-                   batch_first_block=None, fused_adam_deferred=False):
+                   batch_first_block=None, fused_adam_deferred=False, view_id=0):
     """torch.ops.gsr.rasterize: empty tensors stand for None; the camera tensors of the settings tuple are ordinary inputs
     (their gradients are produced when one of them requires grad)."""
     ops = E.load()
@@ -364,7 +365,7 @@ def _rasterize_ext(means3D, means2D, sh, colors_precomp, opacities, scales, rota
             0.0 if nx is None else float(nx.tanfovx), 0.0 if nx is None else float(nx.tanfovy),
             e if (nx is None or next_points_transform is None) else next_points_transform.to(dev),
             -1 if nx is None else int(nx.sh_degree), _ecpu() if commit is None else commit,
-            [] if densify_stats is None else list(densify_stats), [] if nb <= 1 else [int(x) for x in batch_first_block])
+            [] if densify_stats is None else list(densify_stats), [] if nb <= 1 else [int(x) for x in batch_first_block], int(view_id))
     if not rs.debug:
         out = ops.rasterize(*args)
         return out if prepare_next is not None else out[:4]
@@ -380,17 +381,18 @@ def _rasterize_ext(means3D, means2D, sh, colors_precomp, opacities, scales, rota
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
-                        points_transform=None):
+                        points_transform=None, view_id=0):
     if not E.use_ctypes():
         return _rasterize_ext(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
-                              None, False, None, points_transform)
+                              None, False, None, points_transform, view_id=view_id)
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                                     raster_settings, None, False, *_cam_inputs(raster_settings), None, points_transform)
+                                     raster_settings, None, False, *_cam_inputs(raster_settings), None, points_transform, view_id)
 
 
 def rasterize_gaussians_raw(means3D, means2D, features_dc, features_rest, opacity_logit, log_scales, rotations_raw,
                             raster_settings, fused_adam=None, points_transform=None, prepared=None, prepare_next=None,
-                            next_points_transform=None, densify_stats=None, batch_first_block=None, fused_adam_deferred=False):
+                            next_points_transform=None, densify_stats=None, batch_first_block=None, fused_adam_deferred=False,
+                            view_id=0):
     """Extension ("next" row f-2): rasterize straight from HTGaussianModel's raw parameters (_xyz, _features_dc,
     _features_rest, _opacity, _scaling, _rotation; /root/reference/scene/gaussian_model_ht.py:74-82) with the
     activations of :49-65,128-133,176-188 fused into the HIP kernels; gradients are w.r.t. the raw tensors.
@@ -425,16 +427,19 @@ def rasterize_gaussians_raw(means3D, means2D, features_dc, features_rest, opacit
     blocks [b_k, b_k+1) (pad every model to a multiple of 128 with Gaussians that are culled); raster_settings then carries one
     camera per model (viewmatrix / projmatrix [B,4,4], campos [B,3]; points_transform [B,3,4]) and the outputs are [B,3,H,W] /
     [B,1,H,W]: B renders in one launch chain, each bit-identical with rendering its model alone (include/gsr.h GsrBatch; the
-    independent single-image fits of stage A, /root/reference/trainer/ht3dgs_trainer.py:697-698)."""
+    independent single-image fits of stage A, /root/reference/trainer/ht3dgs_trainer.py:697-698).
+
+    view_id = the caller's id of the frame shown (non-zero, the same whenever the same frame is rendered; 0 = none): speed only --
+    the forward blend's balanced placement recognises the frame by it instead of by its pose (include/gsr.h GsrForwardArgs::view_id)."""
     if not E.use_ctypes():
         return _rasterize_ext(means3D, means2D, features_dc, None, opacity_logit, log_scales, rotations_raw, None, raster_settings,
                               features_rest, True, fused_adam, points_transform, prepared, prepare_next, next_points_transform,
-                              densify_stats, batch_first_block, fused_adam_deferred)
+                              densify_stats, batch_first_block, fused_adam_deferred, view_id)
     if prepared is not None or prepare_next is not None or densify_stats is not None or batch_first_block is not None or fused_adam_deferred:
         raise RuntimeError("prepared / prepare_next / densify_stats / batch_first_block / fused_adam_deferred are served by the PyTorch extension binding only")
     e = torch.Tensor([])
     return _RasterizeGaussians.apply(means3D, means2D, features_dc, e, opacity_logit, log_scales, rotations_raw, e,
-                                     raster_settings, features_rest, True, *_cam_inputs(raster_settings), fused_adam, points_transform)
+                                     raster_settings, features_rest, True, *_cam_inputs(raster_settings), fused_adam, points_transform, view_id)
 
 
 class GaussianRasterizer(nn.Module):

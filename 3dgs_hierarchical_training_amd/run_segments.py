@@ -422,6 +422,55 @@ def run_stage_a_on(seq, cfg, dev, spec, rank: int, world: int, group=None, log=N
     return rec
 
 
+def self_launch(a):
+    """`python run_segments.py --ranks N` with no launcher around it: become the launcher (VERDICT r4 item 1 -- a bare command must
+    never turn into a one-rank walk of an N-segment job)."""
+    import socket
+    import subprocess
+    if not a.launch_check and not a.one_device:
+        ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if ndev < a.ranks:
+            emit_line({"phase": "error", "error": f"--ranks {a.ranks} but {ndev} GPU(s) visible to this process: refusing to start"})
+            raise SystemExit(3)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.ranks), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def launch_check(a):
+    """The process group and the merge tree's edges, nothing else: rank ids all_gathered, `segments.link_selftest` along every
+    (dst, src) pair of every level, verdicts combined by the MIN all-reduce the real run uses.  Host tensors under gloo."""
+    import torch.distributed as dist
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if a.ranks and a.ranks != world:
+        if rank == 0:
+            emit_line({"phase": "error", "error": f"--ranks {a.ranks} but WORLD_SIZE={world}"})
+        raise SystemExit(2)
+    on_dev = a.backend == "nccl"
+    dev = torch.device("cuda", 0 if a.one_device else int(os.environ.get("LOCAL_RANK", "0"))) if on_dev else torch.device("cpu")
+    if on_dev:
+        torch.cuda.set_device(dev)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(a.backend, device_id=dev if on_dev else None)
+    ids = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(ids, torch.tensor([rank], dtype=torch.int64, device=dev))
+    tr = segments.DistTransport()
+    st = segments.link_selftest(tr, segments.merge_schedule(world), dev)
+    flag = torch.tensor([1.0 if st["ok"] else 0.0], device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    dist.barrier()
+    if rank == 0:
+        emit_line({"phase": "launch_check", "world": world, "backend": a.backend, "ranks_seen": sorted(int(t.item()) for t in ids),
+                   "selftest_ok": bool(flag.item() >= 1.0), "edges_of_rank0": st["pairs"]})
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--local", action="store_true", help="walk the whole tree on one GPU (no process group)")
@@ -451,7 +500,16 @@ def main():
                                                                 "thread only), 1 = one pair per chain, two chains at a time (round 2)")
     ap.add_argument("--one-device", action="store_true", help="every rank on cuda:0 (with --backend gloo: the multi-process walk on a "
                                                               "one-GPU box; messages are staged through host memory)")
+    ap.add_argument("--ranks", type=int, default=0, help="as a BARE command (WORLD_SIZE unset): start this many ranks of this very script "
+                                                         "under torch.distributed.run (one per GPU, rendezvous on 127.0.0.1) and exit with their code; "
+                                                         "fewer visible devices than ranks: a JSON error line and exit code 3")
+    ap.add_argument("--launch-check", action="store_true", help="launcher plumbing only (needs no GPU with --backend gloo): form the process "
+                                                                "group, run the link self-test along every edge of the merge tree, report, leave")
     a = ap.parse_args()
+    if a.ranks > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(a)
+    if a.launch_check:
+        return launch_check(a)
     cfg = HTConfig(frames=a.frames, width=a.width, height=a.height, gt_gaussians=a.gt_gaussians, leaf_gaussians=a.leaf_gaussians,
                    leaf_iters_per_frame=a.leaf_iters, phase1_iters_per_frame=a.phase1_iters, phase2_iters_per_frame=[a.phase2_iters] * 3,
                    importance_views=a.importance_views, densify=a.densify, fit_pose=a.fit_pose, stage_a_batch=a.stage_a_batch, sh_up_every=a.sh_up_every)
@@ -473,6 +531,13 @@ def main():
         return
     import torch.distributed as dist
     rank, world, local_rank = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+    if a.ranks and a.ranks != world:
+        if rank == 0:
+            emit_line({"phase": "error", "error": f"--ranks {a.ranks} but WORLD_SIZE={world}"})
+        raise SystemExit(2)
+    if not a.one_device and torch.cuda.device_count() <= local_rank:
+        emit_line({"phase": "error", "rank": rank, "error": f"LOCAL_RANK={local_rank} has no device: {torch.cuda.device_count()} GPU(s) visible"})
+        raise SystemExit(3)
     if a.one_device and a.backend == "nccl":
         raise SystemExit("--one-device needs --backend gloo (RCCL refuses two ranks on one device)")
     dev = torch.device("cuda", 0 if a.one_device else local_rank)

@@ -340,8 +340,10 @@ class CameraPoseState:
 
 def render(params: GaussianParams, settings: GaussianRasterizationSettings, clamp: bool = True,
            fused_activations: bool = False, fused_adam=None, next_settings: GaussianRasterizationSettings = None,
-           points_transform: torch.Tensor = None, next_points_transform: torch.Tensor = None, densify_stats=None) -> Dict:
+           points_transform: torch.Tensor = None, next_points_transform: torch.Tensor = None, densify_stats=None,
+           view_id: int = 0) -> Dict:
     """CF3DGS_Render.render with compute_cov3D_python = convert_SHs_python = False.
+    view_id: the frame's id (non-zero; the reference's `viewpoint_camera.uid`) -- speed only (rasterize_gaussians_raw).
     fused_activations=True hands the raw parameters to the kernels (exp / sigmoid / normalize / cat in-kernel).
     next_settings (with fused_adam): the camera of the NEXT render of this model -- its preprocess then rides in this render's
     backward ("prepare in backward", rasterize_gaussians_raw) and the hand-over buffer is kept on `params` until a render with
@@ -371,7 +373,7 @@ def render(params: GaussianParams, settings: GaussianRasterizationSettings, clam
                                       params._scaling, params._rotation, settings, fused_adam=fused_adam, prepared=use,
                                       prepare_next=want_next, points_transform=points_transform,
                                       next_points_transform=next_points_transform if want_next is not None else None,
-                                      densify_stats=densify_stats, batch_first_block=bfb)
+                                      densify_stats=densify_stats, batch_first_block=bfb, view_id=view_id)
         if want_next is not None:        # filled by this render's backward; train_step marks it valid once that has run
             nxf = next_points_transform if next_points_transform is not None else points_transform
             params._prepared = {"buf": out[4], "settings": want_next, "n": xyz.shape[0], "xyz": params._xyz, "valid": False,
@@ -404,7 +406,7 @@ def _same_transform(tag, xf) -> bool:
 def train_step(params: GaussianParams, settings: GaussianRasterizationSettings, gt: torch.Tensor,
                lambda_dssim: float = 0.2, fused_loss: bool = True, fused_activations: bool = True,
                fused_optimizer: bool = True, densifier=None, iteration: int = 0, next_settings=None,
-               pose: "PoseState" = None, next_pose: "PoseState" = None, next_sh_degree: int = None) -> Dict:
+               pose: "PoseState" = None, next_pose: "PoseState" = None, next_sh_degree: int = None, view_id: int = 0) -> Dict:
     """render -> loss -> backward -> Adam step (ht3dgs_trainer.py:102-166 without densification).
     fused_loss=True evaluates clamp + L1 + SSIM in the HIP loss kernels; False uses the torch restatement.
     fused_activations=True runs exp / sigmoid / normalize / cat inside the rasterizer kernels.
@@ -448,7 +450,7 @@ def train_step(params: GaussianParams, settings: GaussianRasterizationSettings, 
     # the per-Gaussian backward kernel when the densifier offers its tensors (raw-parameter path through the extension)
     dstats = densifier.fused_stats(iteration) if (densifier is not None and fused_activations and not E_use_ctypes()) else None
     pkg = render(params, settings, clamp=not fused_loss, fused_activations=fused_activations, fused_adam=fused_adam,
-                 next_settings=nxt, points_transform=xf, densify_stats=dstats,
+                 next_settings=nxt, points_transform=xf, densify_stats=dstats, view_id=view_id,
                  next_points_transform=next_pose.M if (xf is not None and next_pose is not None and nxt is not None) else None)
     if fused_loss:          # (a batch hands [B,3,H,W] stacks: the fused loss is then the SUM of the models' losses, every image
         loss = fused_photometric_loss(pkg["raw_image"], gt, lambda_dssim, clamp=True)     # normalised on its own -- each model gets

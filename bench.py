@@ -414,7 +414,7 @@ def autopatch_leg(ts, scene, settings, gt, dev, steps, warmup):
                     "render_unpatched_* = the same with GSR_AUTOPATCH_RENDER=0 (round 3's form of this leg)"}
 
 
-def rccl_probe(dist, dev, world, rank, backend):
+def rccl_probe(dist, dev, world, rank, backend, payload=64 << 20):
     """Self-diagnosis of the process group for the first multi-GPU run: which ranks answered (an all_gather of rank ids), the
     backend, and the point-to-point rate of every level-0 merge pair (2k <-> 2k+1, 64 MiB each way, all pairs at once -- on the
     xGMI mesh every pair has its own link)."""
@@ -446,7 +446,7 @@ def rccl_probe(dist, dev, world, rank, backend):
                         "point-to-point and N > 1 unmeasured"}
     host = backend != "nccl"
     peer = rank ^ 1
-    n = 64 << 20
+    n = payload
     mine = torch.full((n,), rank & 0xff, dtype=torch.uint8, device="cpu" if host else dev)
     theirs = torch.empty_like(mine)
     rate, ok = 0.0, 1.0
@@ -639,13 +639,78 @@ def merge_leg(dev, dist, world, rank, params, scene, ts, syn, deg):
             "gaussians_merged_max": int(v[4]), "link_GBps": (float(b[0]) / len(pairs)) / (float(v[2]) * 1e-3) / 1e9 if float(v[2]) > 0 else None}
 
 
+METRIC = "train-step images/sec + fwd+bwd ms @1M Gaussians, 980x545; 1/2/4/8 GPU"   # BASELINE.json's metric
+
+
+def error_line(args, world, msg, code):
+    """A run that cannot measure what was asked prints ONE JSON line saying so and exits non-zero: never a number of a smaller job."""
+    print(json.dumps({"metric": METRIC, "value": None, "unit": "images/s", "n_gpus": args.gpus, "world_size_seen": world,
+                      "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "error": msg}), flush=True)
+    raise SystemExit(code)
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` as a BARE command (no torch.distributed.run around it, WORLD_SIZE unset): this process becomes the
+    launcher -- it starts `torch.distributed.run --nnodes=1 --nproc-per-node N` on this very file with the same arguments (one rank per
+    GPU over RCCL, rendezvous on 127.0.0.1 and a free port), passes the ranks' output through (rank 0 prints the one JSON line) and
+    exits with their code.  Fewer than N visible devices: a JSON error line and exit code 3 -- never a silent world-1 run
+    (GSR_BENCH_ONE_DEVICE=1, the one-GPU test plumbing, puts every rank on cuda:0 and lifts that check)."""
+    import socket
+    import subprocess
+    one_dev = os.environ.get("GSR_BENCH_ONE_DEVICE") == "1"
+    if not LAUNCH_CHECK and not one_dev:
+        ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if ndev < args.gpus:
+            error_line(args, 1, f"--gpus {args.gpus} but {ndev} GPU(s) visible to this process: refusing to run a smaller job under that name", 3)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
+    env["GSR_BENCH_SELF_LAUNCHED"] = "1"
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+# GSR_BENCH_LAUNCH_CHECK=1: launcher plumbing only (tests/test_launch_cpu.py, no GPU): the ranks come up, form the process group,
+# run the group's self-diagnosis and rank 0 prints a line with "value": null and "launch_check": true.  Nothing is rendered or timed.
+LAUNCH_CHECK = os.environ.get("GSR_BENCH_LAUNCH_CHECK") == "1"
+
+
+def launch_check(args, world, rank):
+    import torch.distributed as dist
+    backend = os.environ.get("GSR_BENCH_BACKEND", "nccl")
+    if backend == "nccl":
+        error_line(args, world, "GSR_BENCH_LAUNCH_CHECK needs GSR_BENCH_BACKEND=gloo (it runs without a GPU)", 2)
+    dist.init_process_group(backend)
+    r = rccl_probe(dist, torch.device("cpu"), world, rank, backend, payload=1 << 20)
+    if rank == 0:
+        print(json.dumps({"metric": METRIC, "value": None, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "launch_check": True, "self_launched": os.environ.get("GSR_BENCH_SELF_LAUNCHED") == "1", "rccl": r}), flush=True)
+    dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:      # a launcher that started another number of ranks than the line would claim
+        if rank == 0:
+            error_line(args, world, f"--gpus {args.gpus} but WORLD_SIZE={world}", 2)
+        raise SystemExit(2)
+    if LAUNCH_CHECK:
+        return launch_check(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (no CPU fallback in the product path)")
+    if os.environ.get("GSR_BENCH_ONE_DEVICE") != "1" and torch.cuda.device_count() <= local_rank:
+        if rank == 0:
+            error_line(args, world, f"rank with LOCAL_RANK={local_rank} has no device: {torch.cuda.device_count()} GPU(s) visible", 3)
+        raise SystemExit(3)
     # GSR_BENCH_BACKEND=gloo + GSR_BENCH_ONE_DEVICE=1: every rank on cuda:0, gloo instead of RCCL (point-to-point messages staged
     # through host memory) -- lets the N > 1 code path of this file run on a one-GPU box (tests/test_gpu_segments.py); the
     # numbers of such a run mean nothing
@@ -662,7 +727,6 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend, device_id=dev if backend == "nccl" else None)
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     syn = importlib.import_module("3dgs_hierarchical_training_amd.synthetic")
     ts = importlib.import_module("3dgs_hierarchical_training_amd.train_step")
@@ -918,7 +982,7 @@ def main():
                 "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": blend_ms,
                 "launches_timed": prof["blend_fwd"][1], "R": R, "R_eff": R_eff, "R_eff_per_view": r_eff_views, "P": P, "T": T}
     res = {
-        "metric": "train-step images/sec + fwd+bwd ms @1M Gaussians, 980x545; 1/2/4/8 GPU",   # BASELINE.json's metric
+        "metric": METRIC,
         "value": world * args.steps / elapsed, "unit": "images/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",

@@ -256,6 +256,23 @@ def _pose_matrix(g):
     return T.matrix().reshape(4, 4)
 
 
+def _view_id(cam, g) -> int:
+    """A non-zero number that is the same whenever the same FRAME is rendered: the camera's `uid` (the frame index, or index + 0.5
+    for an interpolated frame: /root/reference/trainer/trainer.py:556, :573) together with the pose slot `get_xyz` applies under
+    `rotate_seq` (gaussian_model_ht.py:145-146).  The reference trains with an identity camera and moves the points, and steps the
+    pose after every render, so neither the camera's matrices nor the pose's bits identify the frame; the id does.  Speed only
+    (the forward blend's balanced placement, include/gsr.h GsrForwardArgs::view_id).  0 = unknown (GSR_AUTOPATCH_VIEW_ID=0: off)."""
+    if os.environ.get("GSR_AUTOPATCH_VIEW_ID", "1") == "0":
+        return 0
+    try:
+        vid = 1 + int(round(2.0 * float(getattr(cam, "uid"))))
+        if getattr(g, "rotate_seq", False):
+            vid += 1000003 * (1 + int(g.seq_idx))
+        return vid if vid != 0 else 1
+    except Exception:
+        return 0
+
+
 def _raw_tensors(g):
     """The six raw parameter tensors when they have the layout the fused path takes, else None."""
     ts = [getattr(g, k, None) for k in RAW_NAMES]
@@ -319,7 +336,7 @@ def render_fused(self, viewpoint_camera, scaling_modifier=1.0, invert_bg_color=F
             deferred = opt.deferred_ready({"xyz": xyz, "f_dc": f_dc, "f_rest": f_rest, "opacity": opacity, "scaling": scaling, "rotation": rotation})
     image_raw, radii, depth, alpha = R.rasterize_gaussians_raw(xyz, screenspace_points, f_dc, f_rest, opacity, scaling, rotation,
                                                                settings, points_transform=M, fused_adam=opt if deferred else None,
-                                                               fused_adam_deferred=deferred)
+                                                               fused_adam_deferred=deferred, view_id=_view_id(viewpoint_camera, g))
     image = image_raw.clamp(0, 1)
     image._gsr_raw = (image_raw, image._version)       # lets the patched Loss.forward fuse this clamp into the loss kernels
     visible = radii > 0

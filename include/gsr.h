@@ -104,6 +104,13 @@ typedef struct GsrForwardArgs {
      * one forward per hand-over. */
     void* prepared;
     const struct GsrBatch* batch; /* NULL = one model (see GsrBatch) */
+    /* ---- round 5: the caller's id of the FRAME this render shows (the reference's `viewpoint_camera.uid`, trainer/trainer.py:573;
+     * any non-zero number that is the same whenever the same frame is rendered).  0 = none.  Speed only, never the result: the
+     * forward blend places its waves by the work each did at the previous render of the same frame ("blend_balance"); with an id
+     * that frame is recognised whatever its pose does in between, without one it is recognised by its pose (view matrix AND
+     * points_transform within "view_pose_tol_e6" of the previous render's -- the reference keeps an identity camera and moves the
+     * points, gaussian_model_ht.py:135-148, and steps the pose after every render, ht3dgs_trainer.py:162-166). */
+    int64_t view_id;
 } GsrForwardArgs;
 
 typedef struct GsrForwardOut {
