@@ -29,6 +29,37 @@ class StubCamera:
                    scene["projmatrix"].to(device), scene["campos"].to(device), uid, original_image)
 
 
+class _StubSE3:
+    """What `P[k].retr()` returns, as far as `get_xyz` and gsr_autopatch read it: `.act(points)` and `.matrix()` ([1,4,4])."""
+
+    def __init__(self, M):
+        self.M = M
+
+    def matrix(self):
+        return self.M[None]
+
+    def act(self, x):
+        return x @ self.M[:3, :3].t() + self.M[:3, 3]
+
+
+class StubPose:
+    """One frame's pose parameter the way `HTGaussianModel` keeps it (`self.P[k]`, a lietorch SE3 parameter with an Adam of its own,
+    gaussian_model_ht.py:296-311): six numbers (rotation vector, translation), `retr()` -> the rigid transform with its autograd
+    link.  (lietorch is not in the image; the exponential of the rotation part is torch.linalg.matrix_exp.)"""
+
+    def __init__(self, w0, device, lr: float = 1e-4):
+        self.w = torch.tensor([float(v) for v in w0], device=device, requires_grad=True)
+        self.optimizer = torch.optim.Adam([self.w], lr=lr, eps=1e-15)
+        self._row = torch.tensor([[0.0, 0.0, 0.0, 1.0]], device=device)
+
+    def retr(self):
+        w = self.w
+        z = torch.zeros((), device=w.device)
+        K = torch.stack([torch.stack([z, -w[2], w[1]]), torch.stack([w[2], z, -w[0]]), torch.stack([-w[1], w[0], z])])
+        top = torch.cat([torch.linalg.matrix_exp(K), w[3:, None]], 1)
+        return _StubSE3(torch.cat([top, self._row], 0))
+
+
 class StubGaussians:
     """The attributes of `HTGaussianModel` the render wrapper reads (gaussian_model_ht.py:67-90,128-188), on top of an object that
     holds the six raw tensors and the optimizer (train_step.GaussianParams)."""

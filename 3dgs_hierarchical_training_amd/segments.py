@@ -57,26 +57,49 @@ class DistTransport:
     host_staging=True moves device tensors through host memory around the send / receive: gloo has no device-side
     point-to-point, and with it the SAME runner code can be driven by several processes that share ONE GPU
     (run_segments.py --backend gloo --one-device) -- the way the multi-process walk of the merge tree is exercised on a
-    one-GPU box.  With RCCL the tensors go device to device and this stays off."""
+    one-GPU box.  With RCCL the tensors go device to device and this stays off.
+
+    A message a rank addresses to ITSELF (a rank that holds both children of a merge; the one-GPU test of the RCCL
+    point-to-point path) cannot use the blocking pair -- `send` would wait for a receive that is never posted.  It is held
+    back until the matching `recv`, and both halves then go out as ONE grouped call (`batch_isend_irecv([isend, irecv])`),
+    which RCCL accepts for a self pair (tools/rccl_selfpair.py on MI355X, RCCL 2.26.6: 1 MiB and 64 MiB device tensors,
+    payload intact)."""
 
     def __init__(self, group=None, host_staging: bool = False):
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.host_staging = host_staging
+        self._to_self = deque()
+        self._self_over_wire = dist.get_backend(group) == "nccl"
 
     def send(self, t: torch.Tensor, dst: int):
         if self.host_staging and t.is_cuda:
             t = t.detach().cpu()
+        if dst == self.rank:
+            self._to_self.append(t.detach())
+            return
         dist.send(t, dst, group=self.group)
 
     def recv(self, t: torch.Tensor, src: int):
-        if self.host_staging and t.is_cuda:
-            buf = torch.empty(t.shape, dtype=t.dtype, device="cpu")
+        buf = torch.empty(t.shape, dtype=t.dtype, device="cpu") if (self.host_staging and t.is_cuda) else t
+        if src == self.rank:
+            if not self._to_self:
+                raise RuntimeError(f"DistTransport: rank {self.rank} receives from itself before it sent")
+            m = self._to_self.popleft()
+            if m.shape != buf.shape or m.dtype != buf.dtype:
+                raise RuntimeError(f"DistTransport: self message {tuple(m.shape)} {m.dtype} does not match the receive buffer "
+                                   f"{tuple(buf.shape)} {buf.dtype}")
+            if self._self_over_wire:
+                for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, m, self.rank, group=self.group),
+                                                 dist.P2POp(dist.irecv, buf, self.rank, group=self.group)]):
+                    w.wait()
+            else:           # gloo has no pair from a rank to itself ("Pair is not connected"): the mailbox alone
+                buf.copy_(m)
+        else:
             dist.recv(buf, src, group=self.group)
+        if buf is not t:
             t.copy_(buf)
-            return
-        dist.recv(t, src, group=self.group)
 
 
 class LocalTransport:

@@ -414,6 +414,91 @@ def autopatch_leg(ts, scene, settings, gt, dev, steps, warmup):
                     "render_unpatched_* = the same with GSR_AUTOPATCH_RENDER=0 (round 3's form of this leg)"}
 
 
+def posed_frames_leg(ts, lib, scene, settings, dev, steps, warmup, frames=8):
+    """The reference's calling convention, which the other legs do not have: EVERY frame is rendered through an
+    identity camera, the frame's pose acts on the points (`rotate_seq`: get_xyz = P[seq_idx].retr().act(_xyz), /root/reference/scene/
+    gaussian_model_ht.py:135-148 -- `points_transform` on the patched route) and the frame's pose optimizer steps after every render
+    (/root/reference/trainer/ht3dgs_trainer.py:162-166); the frame is drawn at random every iteration (:497-536).  `import gsr_autopatch`
+    + the trainer's calls, `frames` frames with their own targets, camera uid = frame index.  Reported with the forward blend's balanced
+    placement on and off (same process, same model): ms per step, the blend kernel's own duration (its dispatch's timestamps, every third
+    launch), and the view-cost cache's hit rate -- by the camera's uid (what gsr_autopatch passes) and by pose alone (GSR_AUTOPATCH_VIEW_ID=0)."""
+    import random
+    import gsr_autopatch
+    refstub = importlib.import_module("3dgs_hierarchical_training_amd.refstub")
+    syn = importlib.import_module("3dgs_hierarchical_training_amd.synthetic")
+    W, H = int(settings.image_width), int(settings.image_height)
+    gsr_autopatch.apply()
+    try:
+        p = ts.GaussianParams(scene, dev, optimizer="torch")
+        r = refstub.StubRender(p, bg=tuple(float(x) for x in settings.bg.cpu()))
+        g = r.gaussians
+        gen = torch.Generator().manual_seed(4321)
+        g.P = [refstub.StubPose(torch.cat([0.02 * torch.randn(3, generator=gen), 0.03 * torch.randn(3, generator=gen)]).tolist() if f else [0.0] * 6, dev)
+               for f in range(frames)]
+        g.rotate_seq = True
+        cams = [refstub.StubCamera(W, H, settings.tanfovx, settings.tanfovy, settings.viewmatrix, settings.projmatrix, settings.campos,
+                                   uid=f, original_image=syn.target_image(W, H, seed=40 + f).to(dev)) for f in range(frames)]
+
+        class _Cfg:
+            lambda_dssim, lambda_depth = 0.2, 0.0
+
+        class _Loss:
+            cfg = _Cfg()
+        loss_obj = _Loss()
+        rng = random.Random(7)
+
+        def step(i):
+            f = rng.randrange(frames)
+            g.seq_idx = f
+            pkg = gsr_autopatch.render_fused(r, cams[f])
+            gsr_autopatch.loss_forward(loss_obj, pkg["image"], cams[f].original_image)["loss"].backward()
+            with torch.no_grad():
+                p.optimizer.step()
+                p.optimizer.zero_grad(set_to_none=True)
+                g.P[f].optimizer.step()                      # camera_optimizer[fidx].step(): the pose's bits change after every render
+                g.P[f].optimizer.zero_grad(set_to_none=True)
+
+        def stats():
+            out = (C.c_int64 * 4)()
+            lib.gsr_debug_view_cache_stats(W, H, out)
+            return out[0], out[1]
+
+        def measure(balance, by_uid):
+            lib.gsr_set_option(b"blend_balance", balance)
+            prev = os.environ.get("GSR_AUTOPATCH_VIEW_ID")
+            os.environ["GSR_AUTOPATCH_VIEW_ID"] = "1" if by_uid else "0"
+            try:
+                for i in range(max(warmup, 2 * frames)):
+                    step(i)
+                lib.gsr_set_option(b"profile", 3)
+                read_profile(lib, ["blend_fwd"])
+                s0 = stats()
+                sec = timed_steps(step, steps, dev)
+                s1 = stats()
+                lib.gsr_set_option(b"profile", 0)
+                tot, cnt = read_profile(lib, ["blend_fwd"])["blend_fwd"]
+            finally:
+                lib.gsr_set_option(b"profile", 0)
+                if prev is None:
+                    os.environ.pop("GSR_AUTOPATCH_VIEW_ID", None)
+                else:
+                    os.environ["GSR_AUTOPATCH_VIEW_ID"] = prev
+            look = s1[0] - s0[0]
+            return {"ms_per_step": 1e3 * sec, "blend_fwd_us": (1e3 * tot / cnt) if cnt else None, "blend_launches_timed": cnt,
+                    "view_cache_hit_rate": ((s1[1] - s0[1]) / look) if look else None}
+        out = {"frames": frames, "steps": steps,
+               "balance_off": measure(0, True), "balance_on_by_uid": measure(1, True), "balance_on_by_pose": measure(1, False)}
+        lib.gsr_set_option(b"blend_balance", 1)
+    finally:
+        lib.gsr_set_option(b"blend_balance", 1)
+        gsr_autopatch.remove()
+    del p
+    out["note"] = ("identity camera for every frame, the pose through get_xyz (points_transform), torch.optim.Adam on the frame's six pose numbers "
+                   "after every render, frames drawn at random; the pose's autograd chain (matrix exponential, 4x4 products) is torch's, as the "
+                   "reference's is lietorch's: its host time is in ms_per_step")
+    return out
+
+
 def rccl_probe(dist, dev, world, rank, backend, payload=64 << 20):
     """Self-diagnosis of the process group for the first multi-GPU run: which ranks answered (an all_gather of rank ids), the
     backend, and the point-to-point rate of every level-0 merge pair (2k <-> 2k+1, 64 MiB each way, all pairs at once -- on the
@@ -440,10 +525,28 @@ def rccl_probe(dist, dev, world, rank, backend, payload=64 << 20):
         dist.barrier()
         torch.cuda.synchronize(dev)
         ok = bool(torch.equal(x, y)) and float(mn) == 7.0 and bool(torch.equal(rows[0], src)) and float(bc.sum()) == 3072.0
+        # point-to-point on DEVICE tensors as a self pair: one grouped isend + irecv (what segments.DistTransport issues for a message a
+        # rank addresses to itself) -- the RCCL send / recv kernels execute; the "link" is this GPU's own HBM
+        p2p = {"ok": False}
+        try:
+            a = torch.arange(payload // 4, dtype=torch.float32, device=dev)
+            b = torch.zeros_like(a)
+            for rep in range(3):
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, a, 0), dist.P2POp(dist.irecv, b, 0)]):
+                    w.wait()
+                torch.cuda.synchronize(dev)
+                dt = time.perf_counter() - t0
+            p2p = {"ok": bool(torch.equal(a, b)), "bytes": payload, "ms": 1e3 * dt, "GBps": payload / dt / 1e9}
+        except Exception as e:
+            p2p = {"ok": False, "error": repr(e)[:300]}
         return {"world": 1, "ranks_seen": seen, "all_ranks_present": seen == [0], "backend": dist.get_backend(), "collectives_ok": ok,
                 "collectives": ["all_gather", "all_reduce(SUM)", "all_reduce(MIN)", "broadcast", "barrier"], "link_GBps": {},
-                "note": "process group forced at world 1 (GSR_BENCH_FORCE_DIST=1): collectives on device tensors returned; "
-                        "point-to-point and N > 1 unmeasured"}
+                "p2p_self_pair": p2p,
+                "note": "process group forced at world 1 (GSR_BENCH_FORCE_DIST=1): collectives on device tensors returned, and the "
+                        "point-to-point kernels ran as a self pair (batch_isend_irecv of one isend + one irecv to rank 0); a second "
+                        "GPU and N > 1 stay unmeasured"}
     host = backend != "nccl"
     peer = rank ^ 1
     n = payload
@@ -582,17 +685,23 @@ def merge_leg(dev, dist, world, rank, params, scene, ts, syn, deg):
     hier.calc_importance(raw, views[:1])      # warm the non-fused backward variant
     if world == 1:
         best = None
+        # with a process group at world 1 (GSR_BENCH_FORCE_DIST=1, backend nccl) the child travels through RCCL's point-to-point
+        # kernels as a self pair (segments.DistTransport); without one, through the in-process mailbox (a device copy)
+        over_rccl = dist is not None and dist.get_backend() == "nccl"
         for rep in range(2):          # the first pass pays torch's one-time kernel loads (topk, masked gathers); report the second
-            tr = seg_mod.LocalTransport(2)
+            tr = seg_mod.DistTransport() if over_rccl else seg_mod.LocalTransport(2)
             torch.cuda.synchronize(dev)
             t0 = time.perf_counter()
-            tr.rank = 1
+            if not over_rccl:
+                tr.rank = 1
             s = hier.merge_send(tr, 0, raw, views, 0.5)
-            tr.rank = 0
-            d = hier.merge_recv(tr, 1, raw, views, 0.5, T)
+            if not over_rccl:
+                tr.rank = 0
+            d = hier.merge_recv(tr, 0 if over_rccl else 1, raw, views, 0.5, T)
             torch.cuda.synchronize(dev)
             total = 1e3 * (time.perf_counter() - t0)
-            best = {"merge_ms": total, "merge_bytes": s["bytes"], "pairs": 1, "transport": "in-process device copy (N = 1)",
+            best = {"merge_ms": total, "merge_bytes": s["bytes"], "pairs": 1,
+                    "transport": "RCCL send / recv kernels, self pair on one GPU (N = 1)" if over_rccl else "in-process device copy (N = 1)",
                     "importance_views": len(views), "importance_ms_src": s["importance_ms"], "importance_ms_dst": d["importance_ms"],
                     "send_ms": s["send_ms"], "recv_ms": d["recv_ms"], "append_ms": d["append_ms"], "gaussians_child": s["n"],
                     "gaussians_merged": d["n_merged"], "note": "both children's importance run back to back on the one GPU"}
@@ -864,7 +973,8 @@ def main():
 
     def run_merge():
         nonlocal merge
-        if args.no_extras or os.environ.get("GSR_BENCH_MERGE", "1") == "0":
+        want = os.environ.get("GSR_BENCH_MERGE")        # "1": also with --no-extras; "0": never
+        if want == "0" or (args.no_extras and want != "1"):
             return
         try:
             merge = merge_leg(dev, dist, world, rank, params, scene, ts, syn, deg)
@@ -1045,6 +1155,11 @@ def main():
                                                                                     "with_stock_bookkeeping_ms_per_step", "separate_step_ms_per_step", "render_unpatched_ms_per_step", "steps")}
         except Exception as e:
             res["dropin_autopatch"] = {"value": None, "error": repr(e)}
+        try:
+            if isinstance(res.get("dropin_autopatch"), dict) and res["dropin_autopatch"].get("value"):
+                res["dropin_autopatch"]["posed_frames_identity_camera"] = posed_frames_leg(ts, lib, scene, settings, dev, steps=96, warmup=24)
+        except Exception as e:
+            res["dropin_autopatch"]["posed_frames_identity_camera"] = {"error": repr(e)}
         del params, den
         torch.cuda.empty_cache()
         extra = {}

@@ -279,8 +279,11 @@ int gsr_version(void);
  *                          its final position -- on frames of up to 4 096 tiles; 0 = emit + stable tile sort + ranges (what larger
  *                          frames always take).  Same list, bit for bit
  *   "blend_balance"        1 (default) = the forward blend places its sub-tile waves by the visits each took at the previous
- *                          render of the same view (device-side cache keyed by a hash of the view matrix; single renders through
+ *                          render of the same frame (device-side cache of 128 frames per frame size, least recently used out; a
+ *                          frame is recognised by GsrForwardArgs::view_id or, without one, by its pose; single renders through
  *                          the default kernel); 0 = dispatch order = tile order.  Same image either way
+ *   "view_pose_tol_e6"     (default 2000 = 2e-3) without a view id a render belongs to the cached frame whose view matrix and
+ *                          points_transform are within this, x 1e-6, of its own in every entry (the nearest such frame)
  *   "tile_map"             how tiles are dealt to the eight XCDs: 2 (default) = 2x2 blocks of tiles round-robin, 1 = single
  *                          tiles round-robin (tile t on XCD t % 8), 0 = one contiguous band of tiles per XCD
  *   "speculative_binning"  1 (default) = R-dependent stages launched against a capacity, R read back late;
@@ -322,6 +325,10 @@ int gsr_debug_read_binning(const void* binning, int64_t binning_capacity, int64_
  * out[0..6] = { 1 if the direct route serves this frame (0: the sort route -- more than 4 096 tiles, or N out of range),
  * Gaussians per chunk S (a multiple of 64), chunks NC, groups G, chunks per group Cg, T rounded up to 64, scratch bytes }.  Host only. */
 int gsr_debug_direct_binning_geometry(int32_t N, int32_t T, int64_t out[7]);
+/* The balanced placement's per-view cost caches of the CURRENT device for frames of W x H (synchronises the device):
+ * out = {lookups, hits, entries in use, caches}.  A hit = the render found the entry of its frame (by GsrForwardArgs::view_id,
+ * or by pose within "view_pose_tol_e6") and placed its waves by that frame's previous visit counts. */
+int gsr_debug_view_cache_stats(int32_t W, int32_t H, int64_t out[4]);
 /* Sum of the recorded durations of stage `name` ("preprocess_fwd", "sort_depth", "scan", "emit", "sort_tile",
  * "ranges", "blend_fwd", "blend_bwd", "preprocess_bwd") since the last read; synchronises on the events.  With the direct binning
  * "scan" = k_chunk_counts + the two column scans, "emit" = k_chunk_scatter, "sort_tile" / "ranges" record nothing. */

@@ -828,7 +828,7 @@ def test_three_pass_depth_sort_and_its_window_overflow():
 
 
 def test_balanced_blend_placement_survives_more_views_than_the_cache_holds():
-    """The per-view visit cache of the forward blend holds 32 views (least recently used out): a walk over 40 cameras, twice --
+    """The per-view visit cache of the forward blend holds 128 views (least recently used out): a walk over 140 cameras, twice --
     every second visit a hit on a live entry or a miss on an evicted one -- renders each view bit-identically with the placement
     switched off."""
     import importlib
@@ -840,7 +840,7 @@ def test_balanced_blend_placement_survives_more_views_than_the_cache_holds():
     sc = parity.syn.make_scene(N, W, H, sh_degree=1, seed=3, posed=False)
     t = {k: sc[k].to(dev) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
     sts = []
-    for v in range(40):
+    for v in range(140):
         cam = parity.syn.make_scene(8, W, H, sh_degree=1, seed=100 + v, posed=True)
         sts.append(ts.make_settings(dict(sc, viewmatrix=cam["viewmatrix"], projmatrix=cam["projmatrix"], campos=cam["campos"]), dev, 1))
 
@@ -862,3 +862,91 @@ def test_balanced_blend_placement_survives_more_views_than_the_cache_holds():
     for i, (x, y) in enumerate(zip(a, b)):
         for u, v in zip(x, y):
             assert torch.equal(u, v), i
+
+
+def _view_cache_stats(lib, W, H):
+    import ctypes as C
+    out = (C.c_int64 * 4)()
+    assert lib.gsr_debug_view_cache_stats(W, H, out) == 0
+    return {"lookups": out[0], "hits": out[1], "entries": out[2], "caches": out[3]}
+
+
+@pytest.mark.parametrize("with_id", [False, True])
+def test_balanced_blend_placement_recognises_frames_under_the_reference_calling_convention(with_id):
+    """VERDICT r4 item 2.  The reference renders every frame through an IDENTITY camera and moves the points
+    (/root/reference/trainer/trainer.py:993-995, scene/gaussian_model_ht.py:135-148: `points_transform` here), and steps the frame's
+    pose after every render (ht3dgs_trainer.py:162-166).  Eight frames visited in random order, each pose drifting by ~1e-4 per visit:
+    with the caller's frame id (what gsr_autopatch fills from `viewpoint_camera.uid`) and without one (frames recognised by their
+    pose, view matrix AND points transform, within the tolerance) every visit after a frame's first is a HIT on that frame's own
+    entry -- the round-4 key (a hash of the view-matrix bits alone) put all eight frames into one entry -- and the image / radii are
+    bit-identical with the placement switched off."""
+    import importlib
+    L = importlib.import_module("3dgs_hierarchical_training_amd._lib")
+    R = importlib.import_module("3dgs_hierarchical_training_amd.rasterizer")
+    lib = L.load()
+    dev = torch.device("cuda:0")
+    W, H, N, F = 487 + (1 if with_id else 0), 300, 40000, 8        # (a frame size of its own: a fresh cache, so the counters below are this test's)
+    sc = parity.syn.make_scene(N, W, H, sh_degree=1, seed=3, posed=False)
+    st = ts.make_settings(sc, dev, 1)                  # identity camera for every frame
+    p = ts.GaussianParams(sc, dev, optimizer="torch")
+    gen = torch.Generator().manual_seed(5)
+    base = []
+    for f in range(F):
+        M = torch.eye(4)
+        M[:3, :3] = parity.syn.random_rotation(gen, 0.05)
+        M[:3, 3] = 0.05 * torch.randn(3, generator=gen)
+        base.append(M[:3].contiguous())
+    order = [int(x) for x in torch.randint(0, F, (48,), generator=gen)]
+    drift = [1e-4 * torch.randn(3, 4, generator=gen) for _ in order]
+
+    def walk():
+        poses = [b.clone() for b in base]
+        outs = []
+        with torch.no_grad():
+            for f, d in zip(order, drift):
+                poses[f] = poses[f] + d                               # the pose step after the previous render of this frame
+                o = R.rasterize_gaussians_raw(p._xyz, torch.zeros(N, 3, device=dev), p._features_dc, p._features_rest, p._opacity, p._scaling,
+                                              p._rotation, st, points_transform=poses[f].to(dev), view_id=(f + 1) if with_id else 0)
+                outs.append([x.clone() for x in o[:4]])
+        return outs
+    try:
+        assert lib.gsr_set_option(b"blend_balance", 0) == 0
+        a = walk()
+        assert lib.gsr_set_option(b"blend_balance", 1) == 0
+        s0 = _view_cache_stats(lib, W, H)
+        b = walk()
+        s1 = _view_cache_stats(lib, W, H)
+    finally:
+        lib.gsr_set_option(b"blend_balance", 1)
+    for i, (x, y) in enumerate(zip(a, b)):
+        for u, v in zip(x, y):
+            assert torch.equal(u, v), i
+    lookups, hits = s1["lookups"] - s0["lookups"], s1["hits"] - s0["hits"]
+    assert lookups == len(order) and hits == len(order) - len(set(order)), (s0, s1)      # every frame misses once, then always hits
+    assert s1["entries"] - s0["entries"] == len(set(order)), (s0, s1)                      # ... on an entry of its own
+
+
+def test_view_cache_keeps_frames_apart_that_are_farther_than_the_tolerance():
+    """Without an id two poses share a cache entry only when every matrix entry is within "view_pose_tol_e6" (default 2e-3): a pose
+    2e-2 away is another frame (its own entry), one 5e-4 away is the same frame (a hit, and the entry follows it)."""
+    import importlib
+    L = importlib.import_module("3dgs_hierarchical_training_amd._lib")
+    R = importlib.import_module("3dgs_hierarchical_training_amd.rasterizer")
+    lib = L.load()
+    dev = torch.device("cuda:0")
+    W, H, N = 491, 300, 20000
+    sc = parity.syn.make_scene(N, W, H, sh_degree=1, seed=4, posed=False)
+    st = ts.make_settings(sc, dev, 1)
+    p = ts.GaussianParams(sc, dev, optimizer="torch")
+
+    def render(tx):
+        M = torch.eye(4)[:3].contiguous()
+        M[0, 3] = tx
+        with torch.no_grad():
+            R.rasterize_gaussians_raw(p._xyz, torch.zeros(N, 3, device=dev), p._features_dc, p._features_rest, p._opacity, p._scaling,
+                                      p._rotation, st, points_transform=M.to(dev))
+    s0 = _view_cache_stats(lib, W, H)
+    for tx in (0.0, 5e-4, 1e-3, 1.5e-3, 2e-2, 2.05e-2, 1.9e-3):      # the entry follows its frame: 1.9e-3 is 4e-4 from the last render of frame A
+        render(tx)
+    s1 = _view_cache_stats(lib, W, H)
+    assert s1["lookups"] - s0["lookups"] == 7 and s1["hits"] - s0["hits"] == 5 and s1["entries"] - s0["entries"] == 2, (s0, s1)

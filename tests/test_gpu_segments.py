@@ -189,10 +189,11 @@ def test_bench_line_at_two_ranks_on_one_gpu():
     import sys
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
-           "--gaussians", "200000"]
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", GSR_BENCH_BACKEND="gloo", GSR_BENCH_ONE_DEVICE="1")
+    # round 5: the BARE command -- bench.py starts torch.distributed.run itself when --gpus > 1 and no launcher is around it
+    # (tests/test_launch_cpu.py covers the launcher's refusals; the explicit torch.distributed.run form is what the 4-process walk uses)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--gaussians", "200000"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", GSR_BENCH_BACKEND="gloo", GSR_BENCH_ONE_DEVICE="1")
     out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -261,7 +262,58 @@ def test_rccl_process_group_at_world_one_through_bench():
     r = d["rccl"]
     assert r["backend"] == "nccl" and r["world"] == 1 and r["ranks_seen"] == [0] and r["all_ranks_present"], r
     assert r["collectives_ok"] is True and "all_gather" in r["collectives"] and "barrier" in r["collectives"], r
+    assert r["p2p_self_pair"]["ok"] is True and r["p2p_self_pair"]["bytes"] == 64 << 20, r          # RCCL's send / recv kernels on device tensors
     assert d["n_gpus"] == 1 and d["value"] > 0
+
+
+def test_merge_level_travels_through_rccl_point_to_point_on_one_gpu():
+    """The one merge level of bench.py at world 1 with the process group up: the un-pruned child + mask go through
+    segments.DistTransport as a self pair -- RCCL's point-to-point kernels on device tensors, the path `dist.send / recv` take on a
+    real node, executed for the first time in round 5."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               HSA_ENABLE_IPC_MODE_LEGACY="0", GSR_BENCH_FORCE_DIST="1", GSR_BENCH_MERGE="1")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--gaussians", "100000",
+                          "--no-extras", "--no-cpu-baseline"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    m = d["merge"]
+    assert "RCCL" in m["transport"] and m["merge_bytes"] > 100000 * 236 and m["gaussians_merged"] == 100000 and m["merge_ms"] > 0, m
+
+
+def test_child_message_over_rccl_as_a_self_pair():
+    """segments.send_child / recv_child on DEVICE tensors over backend nccl, one rank addressing itself (tests/helpers/
+    rccl_selfpair_child.py): header, 200 k un-pruned rows (47 MB), mask, frames, poses arrive intact."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "helpers", "rccl_selfpair_child.py")], cwd=root, env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert d["ok"] is True and d["backend"] == "nccl" and d["over_wire"] is True and d["bytes"] == d["recv_bytes"] > 200000 * 237, d
+
+
+def test_bare_bench_command_refuses_more_gpus_than_the_box_has():
+    import json
+    import os
+    import subprocess
+    import sys
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two devices present")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "GSR_BENCH_ONE_DEVICE")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 3 and len(lines) == 1 and lines[0]["value"] is None and lines[0]["n_gpus"] == 2 and "1 GPU(s) visible" in lines[0]["error"]
 
 
 def test_run_segments_at_world_one_over_rccl():
