@@ -262,6 +262,8 @@ __device__ __forceinline__ float row_sum_to_lane15(float v)
 }
 
 constexpr int kPreThreads = 128;
+constexpr uint32_t kDepthKeyBias = 0x3E4CCCCDu;   // bit pattern of the near plane, 0.2f (gsr_math.h kNearZ): no visible Gaussian's depth key lies below it
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x);   // (defined with the direct binning)
 constexpr int kShStride = 49;   // 48 floats + 1 pad: conflict-free column reads
 
 // Coalesced 16-byte streaming of a block's contiguous [nG][ROW] float rows into / out of the padded LDS tile
@@ -420,10 +422,12 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess(CamParams cp, int N,
                                                             Splat* __restrict__ splat, int32_t* __restrict__ radii,
                                                             uint32_t* __restrict__ dkey, uint32_t* __restrict__ gid,
                                                             TileRec* __restrict__ tilerec, uint32_t* __restrict__ zero_words,
-                                                            int zero_count, int block0, DepthHist dh)
+                                                            int zero_count, int block0, DepthHist dh, uint2* __restrict__ early_parts = nullptr,
+                                                            uint32_t window_max = 0xffffffffu)
 {
     constexpr int NC3 = 3 * (DEG + 1) * (DEG + 1);
     __shared__ float s_sh[kPreThreads * kShStride];
+    __shared__ uint32_t s_early[2][kPreThreads / 64];
     const int tid = threadIdx.x;
     const int base = ((int)blockIdx.x + block0) * kPreThreads;   // block0: first block of a partial launch (0 = the whole cloud)
     const int i = base + tid;
@@ -502,6 +506,23 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess(CamParams cp, int N,
     }
     count_large_rects(act, s, rec, cp.W, cp.H, cam.tiles_x, cam.tiles_y, tid);
     rec.rect += (uint32_t)(model * cam.tiles_y) << 12;   // tile rows of model b start at b * tiles_y in the batch's tall tile grid
+    // ---- early R (round 5): the instance count is the sum of the tile counts, whatever order the depth sort puts them in -- this
+    // block's share (and its count of visible depth keys beyond the three-pass sort's window) goes to early_parts[block]; the
+    // depth sort's histogram kernel adds the shares up and hands the total to the host (radix_sort.h OsRider) while the sort,
+    // the tile counts and the scan are still to run
+    if (early_parts) {
+        const uint32_t nt = act ? s.tiles : 0u;
+        const uint32_t far = (nt > 0u && __float_as_uint(s.depth) - kDepthKeyBias > window_max) ? 1u : 0u;
+        const uint32_t st_ = wave_inclusive_sum(nt), sf_ = wave_inclusive_sum(far);
+        if ((tid & 63) == 63) { s_early[0][tid >> 6] = st_; s_early[1][tid >> 6] = sf_; }
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t t0 = 0u, t1 = 0u;
+#pragma unroll
+            for (int w = 0; w < kPreThreads / 64; w++) { t0 += s_early[0][w]; t1 += s_early[1][w]; }
+            early_parts[blockIdx.x + block0] = make_uint2(t0, t1);
+        }
+    }
     // ---- phase 2: rows into the LDS tile, then the colour of the Gaussians that survived the culls
     if (shs) {
         constexpr bool kLinOk = NC3 > 3 && (NR & 1);
@@ -2138,6 +2159,8 @@ struct PrepOut {
     uint32_t* gid;
     TileRec* rec;
     DepthHist dh;
+    uint2* early_parts;      // per block: (tile instances, visible depth keys beyond the three-pass sort's window) -- see k_preprocess
+    uint32_t early_window;
 };
 
 // Per-iteration densification statistics, accumulated by the per-Gaussian backward kernel (GsrDensifyStats, include/gsr.h)
@@ -2535,6 +2558,20 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, in
             }
             count_large_rects(act, s2, rec2, po.cp.W, po.cp.H, cam2.tiles_x, cam2.tiles_y, tid);
             rec2.rect += (uint32_t)(model2 * cam2.tiles_y) << 12;   // (as k_preprocess)
+            if (po.early_parts) {   // this block's share of the NEXT forward's instance count (k_preprocess, "early R")
+                __shared__ uint32_t s_early2[2][kPreThreads / 64];
+                const uint32_t nt = act ? s2.tiles : 0u;
+                const uint32_t far = (nt > 0u && __float_as_uint(s2.depth) - kDepthKeyBias > po.early_window) ? 1u : 0u;
+                const uint32_t st_ = wave_inclusive_sum(nt), sf_ = wave_inclusive_sum(far);
+                if ((tid & 63) == 63) { s_early2[0][tid >> 6] = st_; s_early2[1][tid >> 6] = sf_; }
+                __syncthreads();
+                if (tid == 0) {
+                    uint32_t t0 = 0u, t1 = 0u;
+#pragma unroll
+                    for (int w = 0; w < kPreThreads / 64; w++) { t0 += s_early2[0][w]; t1 += s_early2[1][w]; }
+                    po.early_parts[blockIdx.x] = make_uint2(t0, t1);
+                }
+            }
             if (act && s2.radius > 0) {
                 float col[3];
                 splat_sh_color(cam2, mean2, s_rest + tid * NRL - 3, 3, 1, col, s_dc + tid * 3);
@@ -2696,7 +2733,7 @@ static GeomLayout geom_layout(int32_t N)
 }
 
 struct PrepLayout {   // "prepare in backward": what k_preprocess would have produced, handed from gsr_backward to the next gsr_forward
-    size_t splat, radii, dkey, gid, rec, sort, bytes;
+    size_t splat, radii, dkey, gid, rec, sort, early, bytes;
 };
 static PrepLayout prep_layout(int32_t N)
 {
@@ -2709,12 +2746,13 @@ static PrepLayout prep_layout(int32_t N)
     p.gid = o; o += align256(n * 4);
     p.rec = o; o += align256(n * sizeof(TileRec));
     p.sort = o; o += align256(onesweep_scratch_bytes((uint32_t)n));   // the depth sort's scratch: digit counts filled in by the backward
+    p.early = o; o += align256(((n + kPreThreads - 1) / kPreThreads) * sizeof(uint2));   // per-block shares of the next forward's R
     p.bytes = o;
     return p;
 }
 
 struct FwdScratch {   // N-sized scratch of the forward
-    size_t dkey, gid, dkey_alt, gid_alt, ntiles, srec, block_sums, total, sort;
+    size_t dkey, gid, dkey_alt, gid_alt, ntiles, srec, block_sums, total, early, sort;
     size_t bytes;
 };
 static FwdScratch fwd_scratch_layout(int32_t N)
@@ -2730,6 +2768,7 @@ static FwdScratch fwd_scratch_layout(int32_t N)
     s.srec = o; o += align256(n * sizeof(TileRec));
     s.block_sums = o; o += align256(((n + kEmitThreads - 1) / kEmitThreads) * 4);
     s.total = o; o += 256;
+    s.early = o; o += align256(((n + kPreThreads - 1) / kPreThreads) * sizeof(uint2));   // k_preprocess's per-block shares of R (OsRider)
     s.sort = o; o += radix_scratch_bytes((uint32_t)n);
     s.bytes = o;
     return s;
@@ -2794,10 +2833,10 @@ static int g_bwd_split = 0;  // workgroups a long tile's backward is split over 
                              // 980x545 frame, fewer the more tiles there are (the parts that find nothing to do still cost a launch slot:
                              // 16 x 17 408 workgroups for eight batched images spent 170 of 860 us on them) -- about 35 000 workgroups
 static int g_ckpt_first = 1;  // 128-instance batches of a tile before the forward starts leaving checkpoints
-constexpr uint32_t kDepthKeyBias = 0x3E4CCCCDu;   // bit pattern of the near plane, 0.2f (gsr_math.h kNearZ): no visible Gaussian's depth key lies below it
 static int g_depth_sort9 = 1;     // depth sort of large models in three 9-bit passes over (key - near-plane bits) (radix_sort.h); 0 = four 8-bit passes
 static int g_direct_bin = 1;      // tile lists by direct placement (k_chunk_counts / k_chunk_scatter) instead of emit + tile sort + ranges; 0 = the sort route
 static int g_view_pose_tol_e6 = 2000;   // balanced placement without a view id: a render belongs to the cached view whose pose is within this (x 1e-6) in every matrix entry
+static int g_early_r = 1;         // the host learns R from the preprocess's per-block shares (published by the depth sort's histogram kernel) instead of from the scan
 static int g_blend_balance = 1;   // forward blend: place the waves by the visits each took at the previous render of the same view (balance_build)
 static int g_tile_map = 2;   // tile -> XCD map: 2 = 2x2 tile blocks interleaved (default), 1 = tiles interleaved, 0 = banded
 static std::atomic<long long> g_spec_overflows{0}, g_spec_forwards{0}, g_exact_forwards{0}, g_depth_window_resorts{0};
@@ -2971,6 +3010,7 @@ int gsr_set_option(const char* name, int value)
     if (!strcmp(name, "ckpt_first")) { if (value < 1 || value > 64) return GSR_ERR_ARG; g_ckpt_first = value; return GSR_OK; }
     if (!strcmp(name, "tile_map")) { if (value < 0 || value > 2) return GSR_ERR_ARG; g_tile_map = value; return GSR_OK; }
     if (!strcmp(name, "blend_balance")) { g_blend_balance = value ? 1 : 0; return GSR_OK; }
+    if (!strcmp(name, "early_r")) { g_early_r = value ? 1 : 0; return GSR_OK; }
     if (!strcmp(name, "view_pose_tol_e6")) { if (value < 0) return GSR_ERR_ARG; g_view_pose_tol_e6 = value; return GSR_OK; }
     if (!strcmp(name, "depth_sort9")) { g_depth_sort9 = value ? 1 : 0; return GSR_OK; }
     if (!strcmp(name, "direct_binning")) { g_direct_bin = value ? 1 : 0; return GSR_OK; }
@@ -3249,6 +3289,15 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
     const int zero_count = depth_onesweep ? (int)kOnesweepHeadWordsMax : 0;   // (either layout of the depth sort's head)
     uint8_t* depth_scratch = fs + L.sort;
     bool depth_hist_done = false;
+    // early R (round 5): a speculative forward that runs its own preprocess learns R from k_preprocess's per-block shares, summed and
+    // published by the depth sort's histogram kernel (radix_sort.h OsRider) -- the host's wait for R at the end of this function then
+    // ends ~10 us into the forward instead of behind sort + counts + scan, and the caller can enqueue its loss and its backward while
+    // the forward is still running.  (A forward that takes a prepared buffer finds the shares in it: the backward that ran its
+    // preprocess left them there, k_preprocess_bwd's next-view tail.)
+    const bool early_r = g_early_r && speculative && depth_onesweep;
+    uint2* early_parts = early_r ? reinterpret_cast<uint2*>(a->prepared ? static_cast<uint8_t*>(a->prepared) + prep_layout(N).early : fs + L.early) : nullptr;
+    // visible depth keys beyond the 27-bit window of the three-pass sort are counted whenever this forward MAY sort on it
+    const uint32_t early_window = N > g_prep_hist_max_n ? (1u << 27) - 1u : 0xffffffffu;
     if (a->prepared) {
         // "prepare in backward": the preceding gsr_backward already ran the preprocess of this render on the updated
         // parameters (k_preprocess_bwd<..., PREP>); its records, sort keys and tile records are taken from the hand-over buffer
@@ -3272,7 +3321,7 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
 #define GSR_PRE_(DEG, RAW)                                                                                                          \
     hipLaunchKernelGGL((k_preprocess<DEG, RAW>), dim3(grid), dim3(kPreThreads), 0, st, cp, N, a->means3D, a->scales, a->rotations, \
                        a->cov3D_precomp, a->opacities, a->shs, a->shs_rest, a->colors_precomp, splat, a->radii, dkey, gid, ntiles,  \
-                       zero_words, zero_count, 0, DepthHist{})
+                       zero_words, zero_count, 0, DepthHist{}, early_parts, early_window)
 #define GSR_PRE(DEG) do { if (a->raw_params) GSR_PRE_(DEG, true); else GSR_PRE_(DEG, false); } while (0)
     {
         ProfScope ps(P_PRE_FWD, st);
@@ -3297,27 +3346,30 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
         if (it != g_full_depth_sort.end() && it->second) wide_depth = false;
     }
     const unsigned int* window_overflow = wide_depth ? onesweep_overflow_word(depth_scratch) : nullptr;   // (in the sort's zeroed scratch head)
+    PinLease pin(acquire_pin_slot(dev_id));
+    if (!pin.s) return fail(GSR_ERR_HIP, "pinned read-back slot allocation failed%s");
+    OsRider rider = {};
+    if (early_r) { rider.parts = early_parts; rider.nparts = (uint32_t)grid; rider.host = pin.s->dev; rider.seq = ++pin.s->seq; }
     {
         ProfScope ps(P_SORT_DEPTH, st);
         GSR_HIP(depth_onesweep ? onesweep_sort_pairs<uint32_t>(dkey, gid, dkey_alt, gid_alt, (uint32_t)N, 0, wide_depth ? 27 : 32, depth_scratch, &in_alt, st,
-                                                               nullptr, true, depth_hist_done, wide_depth ? 9 : 8, kDepthKeyBias)
+                                                               nullptr, true, depth_hist_done, wide_depth ? 9 : 8, kDepthKeyBias, early_r ? &rider : nullptr)
                                : radix_sort_pairs<uint32_t>(dkey, gid, dkey_alt, gid_alt, (uint32_t)N, 0, 32, fs + L.sort, &in_alt, st));
     }
     sorted_gid = in_alt ? gid_alt : gid;
-    PinLease pin(acquire_pin_slot(dev_id));
-    if (!pin.s) return fail(GSR_ERR_HIP, "pinned read-back slot allocation failed%s");
     // tiles-touched in depth order: R to the pinned slot, and what the binning needs (block offsets / the chunk tables)
-    auto launch_counts = [&](const BlendBalance& bal, const ZeroJobs& zjobs, const unsigned int* wo, unsigned long long seq) {
+    auto launch_counts = [&](const BlendBalance& bal, const ZeroJobs& zjobs, const unsigned int* wo, unsigned long long seq, bool publish = true) {
         TileRec* srec = reinterpret_cast<TileRec*>(fs + L.srec);
+        unsigned long long* const host_slot = publish ? pin.s->dev : nullptr;   // (early R: the histogram kernel already told the host)
         if (direct) {
             hipLaunchKernelGGL(k_chunk_counts, dim3(db.NC + (bal.hdr ? 8 : 0)), dim3(kEmitThreads), 0, st, db, W, H,
                                tiles_x, tiles_y, sorted_gid, ntiles, splat, srec, bal);
             hipLaunchKernelGGL(k_chunk_scan1, dim3((db.Tp + 255) / 256, db.G), dim3(256), 0, st, db);
-            hipLaunchKernelGGL(k_chunk_scan2, dim3((db.Tp + 255) / 256), dim3(256), 0, st, db, total, zjobs, pin.s->dev, seq, wo);
+            hipLaunchKernelGGL(k_chunk_scan2, dim3((db.Tp + 255) / 256), dim3(256), 0, st, db, total, zjobs, host_slot, seq, wo);
         } else {
             hipLaunchKernelGGL(k_tile_counts, dim3(nb + (bal.hdr ? 8 : 0)), dim3(kEmitThreads), 0, st, N, sorted_gid, ntiles, block_sums, srec, bal, nb);
             // the scan writes R straight into the pinned slot (device-visible host memory): no copy launch behind it
-            hipLaunchKernelGGL(k_block_scan, dim3(1), dim3(1024), 0, st, block_sums, nb, total, zjobs, pin.s->dev, seq, wo);
+            hipLaunchKernelGGL(k_block_scan, dim3(1), dim3(1024), 0, st, block_sums, nb, total, zjobs, host_slot, seq, wo);
         }
     };
     {
@@ -3368,7 +3420,8 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
             zj.p[0] = nullptr; zj.words[0] = 0u;   // (the scatter writes every tile's range; there is no sort scratch)
             zj.p[2] = nullptr; zj.words[2] = 0u;
         }
-        launch_counts(bb, zj, window_overflow, ++pin.s->seq);
+        if (early_r) launch_counts(bb, zj, window_overflow, 0ull, false);
+        else launch_counts(bb, zj, window_overflow, ++pin.s->seq);
     }
     GSR_HIP(hipGetLastError());
 
@@ -3670,6 +3723,8 @@ int gsr_backward(const GsrBackwardArgs* a, void* stream_)
         po.dkey = reinterpret_cast<uint32_t*>(pb + PL.dkey);
         po.gid = reinterpret_cast<uint32_t*>(pb + PL.gid);
         po.rec = reinterpret_cast<TileRec*>(pb + PL.rec);
+        po.early_parts = reinterpret_cast<uint2*>(pb + PL.early);
+        po.early_window = N > g_prep_hist_max_n ? (1u << 27) - 1u : 0xffffffffu;   // (counted whenever the next forward MAY sort on the 27-bit window)
         if (!prep_head_cleared) GSR_HIP(hipMemsetAsync(prep_head, 0, kOnesweepHeadWordsMax * sizeof(uint32_t), st));   // (no blend launch: empty frame / other variant)
         if (prep_counts_digits(N)) {
             po.dh.ghist = prep_head;
@@ -3694,7 +3749,7 @@ int gsr_backward(const GsrBackwardArgs* a, void* stream_)
 #define GSR_PRE_TAIL(NDEG)                                                                                                               \
     hipLaunchKernelGGL((k_preprocess<NDEG, true>), dim3(1), dim3(kPreThreads), 0, st, po.cp, N, a->means3D, a->scales, a->rotations,       \
                        (const float*)nullptr, a->opacities, a->shs, a->shs_rest, (const float*)nullptr, po.splat, po.radii, po.dkey,     \
-                       po.gid, po.rec, (uint32_t*)nullptr, 0, grid - 1, po.dh)
+                       po.gid, po.rec, (uint32_t*)nullptr, 0, grid - 1, po.dh, po.early_parts, po.early_window)
     {
         ProfScope ps(P_PRE_BWD, st);
         if (nv) {   // (this render's degree, the next render's): equal, or one step up (checked above)

@@ -265,6 +265,7 @@ inline uint32_t onesweep_resident_blocks(KernelT kernel, int threads)
 // Look-backs that gave up (a predecessor never published: the status words were overwritten by a caller's bug).  The sort's result is
 // then garbage; the counter lets the host say so: gsr_forward reads it back with the instance count and fails the call.
 __device__ unsigned int g_onesweep_giveups = 0u;
+struct OsRider;
 constexpr int kOsRanges = 32;
 constexpr uint32_t kOsLocal = 1u << 30, kOsIncl = 2u << 30, kOsMask = (1u << 30) - 1u;
 constexpr uint32_t kOsTicketWords = (4 * kOsRanges + 63) / 64 * 64;   // tickets[pass][run], padded
@@ -304,6 +305,19 @@ __host__ __device__ inline uint32_t onesweep_status_words(uint32_t capacity, int
 }
 __host__ __device__ inline uint32_t* onesweep_status(void* scratch) { return static_cast<uint32_t*>(scratch) + kOnesweepHeadWords; }
 
+// A rider on the histogram kernel (round 5): the kernel that PRODUCED the keys left per-block partial sums of something the host is
+// waiting for (gsr_forward: the instance count R = the sum of the Gaussians' tile counts, which does not depend on the order this sort
+// is about to establish); the histogram kernel's last block adds them up and publishes the total to pinned host memory -- a kernel
+// boundary after the producer, no launch of its own, and the host has its number ~10 us into the forward instead of behind the sort,
+// the tile counts and the scan.  host: [0] sum of parts.x, [1] seq (written last), [2] look-backs that gave up so far, [3] sum of parts.y.
+struct OsRider {
+    const uint2* parts;
+    uint32_t nparts;
+    unsigned long long* host;   // nullptr: no rider
+    unsigned long long seq;
+};
+__device__ __forceinline__ void onesweep_rider_publish(const OsRider& rd, unsigned long long (*s_r)[16]);
+
 // GS = stride of the digit tables (256; 512 for 9-bit digits).  bias / kclamp: the digit is taken of min(key - bias, kclamp)
 // (0 / all ones: of the key); a key beyond the window that is not the all-ones padding key is counted in *overflow.
 template <typename KeyT, int PASSES, int GS = 256>
@@ -311,8 +325,12 @@ __global__ __launch_bounds__(256) void k_radix_ghist(const KeyT* __restrict__ ke
                                                      uint32_t* __restrict__ ghist /*[PASSES][runs][GS]*/,
                                                      const unsigned long long* __restrict__ n_dev,
                                                      uint32_t* __restrict__ status, uint32_t status_words, int dbits, int bits, uint32_t bias = 0u,
-                                                     uint32_t kclamp = 0xffffffffu, unsigned int* __restrict__ overflow = nullptr)
+                                                     uint32_t kclamp = 0xffffffffu, unsigned int* __restrict__ overflow = nullptr, OsRider rider = OsRider{})
 {
+    if (rider.host && blockIdx.x == gridDim.x - 1) {   // (block-uniform)
+        __shared__ unsigned long long s_r[2][16];
+        onesweep_rider_publish(rider, s_r);
+    }
     // digit p covers key bits [dbits p, min(dbits (p + 1), bits)) above begin_bit (<= 8 wide: the tables keep 256 entries)
     uint32_t dmask[PASSES];
 #pragma unroll
@@ -367,6 +385,26 @@ __global__ __launch_bounds__(256) void k_radix_ghist(const KeyT* __restrict__ ke
             if (h[p][d]) atomicAdd(&ghist[(p * kOsRanges + x) * GS + d], h[p][d]);
 }
 
+__device__ __forceinline__ void onesweep_rider_publish(const OsRider& rd, unsigned long long (*s_r)[16])
+{
+    unsigned long long a = 0ull, b = 0ull;
+    for (uint32_t q = threadIdx.x; q < rd.nparts; q += blockDim.x) { const uint2 v = rd.parts[q]; a += v.x; b += v.y; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off, 64); b += __shfl_xor(b, off, 64); }
+    if ((threadIdx.x & 63u) == 0u) { s_r[0][threadIdx.x >> 6] = a; s_r[1][threadIdx.x >> 6] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a = b = 0ull;
+        for (uint32_t w = 0; w < blockDim.x / 64u; w++) { a += s_r[0][w]; b += s_r[1][w]; }
+        __atomic_store_n(rd.host + 2, (unsigned long long)g_onesweep_giveups, __ATOMIC_RELAXED);
+        __atomic_store_n(rd.host + 3, b, __ATOMIC_RELAXED);
+        __atomic_store_n(rd.host, a, __ATOMIC_RELAXED);
+        __threadfence_system();
+        __atomic_store_n(rd.host + 1, rd.seq, __ATOMIC_RELAXED);
+        __threadfence_system();
+    }
+}
+
 // 512 threads x 8 keys per tile: the same 4096-key tile as the three-kernel path, but half the ranking rounds per
 // wave and twice the waves to hide the LDS / look-back latency behind (a workgroup's latency chain, not bandwidth,
 // is what a pass costs)
@@ -386,10 +424,14 @@ __global__ __launch_bounds__(OsCfg<KeyT>::kThreads) void k_onesweep(const KeyT* 
                                                          uint32_t* __restrict__ status /*[nblocks][256]*/,
                                                          uint32_t* __restrict__ ticket,
                                                          const unsigned long long* __restrict__ n_dev, uint32_t dmask, int runs,
-                                                         uint32_t bias = 0u, uint32_t kclamp = 0xffffffffu)
+                                                         uint32_t bias = 0u, uint32_t kclamp = 0xffffffffu, OsRider rider = OsRider{})
 {
     constexpr int GS = NB > 256 ? NB : 256;   // stride of the digit tables in memory (status words, per-run digit counts)
     constexpr int kOsThreads = OsCfg<KeyT>::kThreads, kOsTile = OsCfg<KeyT>::kTile, kOsIPT = kOsTile / kOsThreads, kOsWaves = kOsThreads / 64;
+    if (rider.host && blockIdx.x == gridDim.x - 1) {   // (block-uniform; first pass of a sort whose producer counted the digits: no histogram kernel to ride on)
+        __shared__ unsigned long long s_r[2][16];
+        onesweep_rider_publish(rider, s_r);
+    }
     if (n_dev) n = (uint32_t)min((unsigned long long)n, *n_dev);   // device-side count: tiles past it exit at once
     __shared__ unsigned long long s_mask[kOsWaves][NB];
     __shared__ uint32_t s_cnt[kOsWaves][NB];
@@ -530,8 +572,11 @@ template <typename KeyT>
 inline hipError_t onesweep_sort_pairs(KeyT* keys, uint32_t* vals, KeyT* keys_alt, uint32_t* vals_alt, uint32_t n, int begin_bit,
                                       int end_bit, void* scratch, int* in_alt, hipStream_t stream,
                                       const unsigned long long* n_dev = nullptr, bool head_prezeroed = false, bool hist_done = false,
-                                      int max_digit_bits = 8, uint32_t bias = 0u)
+                                      int max_digit_bits = 8, uint32_t bias = 0u, const OsRider* rider = nullptr)
 {
+    const bool wide_ = max_digit_bits == 9;
+    const OsRider rd = (rider && (wide_ || !hist_done)) ? *rider : OsRider{};   // rides on the histogram launch ...
+    const OsRider rd0 = (rider && !wide_ && hist_done) ? *rider : OsRider{};      // ... or, when the producer counted the digits, on the first pass
     *in_alt = 0;
     if (n == 0) return hipSuccess;
     const int bits = end_bit - begin_bit;
@@ -561,13 +606,13 @@ inline hipError_t onesweep_sort_pairs(KeyT* keys, uint32_t* vals, KeyT* keys_alt
     // hist_done: the kernel that produced the keys counted the digits and cleared the status words (see onesweep_run_len)
     if (wide)
         hipLaunchKernelGGL((k_radix_ghist<KeyT, 3, 512>), dim3(hgrid), dim3(256), 0, stream, keys, n, begin_bit, ghist, n_dev, status, status_words, dbits, bits,
-                           bias, kclamp, onesweep_overflow_word(scratch));
+                           bias, kclamp, onesweep_overflow_word(scratch), rd);
     else if (!hist_done)
     switch (passes) {
-        case 1: hipLaunchKernelGGL((k_radix_ghist<KeyT, 1>), dim3(hgrid), dim3(256), 0, stream, keys, n, begin_bit, ghist, n_dev, status, status_words, dbits, bits); break;
-        case 2: hipLaunchKernelGGL((k_radix_ghist<KeyT, 2>), dim3(hgrid), dim3(256), 0, stream, keys, n, begin_bit, ghist, n_dev, status, status_words, dbits, bits); break;
-        case 3: hipLaunchKernelGGL((k_radix_ghist<KeyT, 3>), dim3(hgrid), dim3(256), 0, stream, keys, n, begin_bit, ghist, n_dev, status, status_words, dbits, bits); break;
-        default: hipLaunchKernelGGL((k_radix_ghist<KeyT, 4>), dim3(hgrid), dim3(256), 0, stream, keys, n, begin_bit, ghist, n_dev, status, status_words, dbits, bits); break;
+        case 1: hipLaunchKernelGGL((k_radix_ghist<KeyT, 1>), dim3(hgrid), dim3(256), 0, stream, keys, n, begin_bit, ghist, n_dev, status, status_words, dbits, bits, 0u, 0xffffffffu, (unsigned int*)nullptr, rd); break;
+        case 2: hipLaunchKernelGGL((k_radix_ghist<KeyT, 2>), dim3(hgrid), dim3(256), 0, stream, keys, n, begin_bit, ghist, n_dev, status, status_words, dbits, bits, 0u, 0xffffffffu, (unsigned int*)nullptr, rd); break;
+        case 3: hipLaunchKernelGGL((k_radix_ghist<KeyT, 3>), dim3(hgrid), dim3(256), 0, stream, keys, n, begin_bit, ghist, n_dev, status, status_words, dbits, bits, 0u, 0xffffffffu, (unsigned int*)nullptr, rd); break;
+        default: hipLaunchKernelGGL((k_radix_ghist<KeyT, 4>), dim3(hgrid), dim3(256), 0, stream, keys, n, begin_bit, ghist, n_dev, status, status_words, dbits, bits, 0u, 0xffffffffu, (unsigned int*)nullptr, rd); break;
     }
     KeyT *kin = keys, *kout = keys_alt;
     uint32_t *vin = vals, *vout = vals_alt;
@@ -586,10 +631,12 @@ inline hipError_t onesweep_sort_pairs(KeyT* keys, uint32_t* vals, KeyT* keys_alt
                                begin_bit + dbits * p, ghist + p * kOsRanges * 512, status + (size_t)p * nblocks * 512, tk9, n_dev, pmask, runs, bias, kclamp);
         } else if (wbits <= 6)
             hipLaunchKernelGGL((k_onesweep<KeyT, 64>), dim3(pgrid), dim3(OsCfg<KeyT>::kThreads), 0, stream, kin, vin, kout, vout, n,
-                               begin_bit + dbits * p, ghist + p * kOsRanges * 256, status + (size_t)p * nblocks * 256, tk_p, n_dev, pmask, runs);
+                               begin_bit + dbits * p, ghist + p * kOsRanges * 256, status + (size_t)p * nblocks * 256, tk_p, n_dev, pmask, runs,
+                               0u, 0xffffffffu, p == 0 ? rd0 : OsRider{});
         else
             hipLaunchKernelGGL((k_onesweep<KeyT, 256>), dim3(pgrid), dim3(OsCfg<KeyT>::kThreads), 0, stream, kin, vin, kout, vout, n,
-                               begin_bit + dbits * p, ghist + p * kOsRanges * 256, status + (size_t)p * nblocks * 256, tk_p, n_dev, pmask, runs);
+                               begin_bit + dbits * p, ghist + p * kOsRanges * 256, status + (size_t)p * nblocks * 256, tk_p, n_dev, pmask, runs,
+                               0u, 0xffffffffu, p == 0 ? rd0 : OsRider{});
         KeyT* tk = kin; kin = kout; kout = tk;
         uint32_t* tv = vin; vin = vout; vout = tv;
         *in_alt ^= 1;

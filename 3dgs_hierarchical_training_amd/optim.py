@@ -262,15 +262,26 @@ class FusedAdam:
             p, t = by_name[name]["params"][0], tensors.get(name)
             if t is not p or not p.requires_grad or p.grad is not None or not p.is_contiguous() or p.dtype != torch.float32 or not p.is_cuda:
                 return False
+        # an earlier render of this model still holds a plan whose backward has not run (loss = f(render A) + f(render B)):
+        # that plan stays, THIS render takes the plain gradient route, and step() -- which then finds a .grad beside the committed
+        # shadows -- recovers render A's gradient and adds it (`_adopt_pending`, other_grad).  Torch's sum, not the last node's update.
+        if self._pending is not None:
+            return False
         return True
 
     def flush_pending_as_grads(self):
         """A deferred update that was neither adopted (`step()`) nor dropped (`zero_grad()`) when the next render arrives: the trainer
         is letting gradients accumulate.  Give it what torch would hold -- the gradient, recovered from the shadow first moment
         (m' = b1 m + (1 - b1) g) -- and step aside: `deferred_ready` then sees a .grad and the render takes the plain route."""
-        pend, self._pending = self._pending, None
-        if pend is None or int(self._def_commit_np[0]) <= pend["commit_at_plan"]:
+        pend = self._pending
+        if pend is None:
             return
+        if int(self._def_commit_np[0]) <= pend["commit_at_plan"]:
+            # not committed: its backward has not run -- yet.  It may still (two renders feeding one backward), so the plan is KEPT:
+            # `deferred_ready` sends the arriving render down the plain route; a graph that was simply dropped costs the same one
+            # plain iteration, and step() / zero_grad() clear the plan either way
+            return
+        self._pending = None
         b1 = float(self.betas[0])
         with torch.no_grad():
             for k, name in enumerate(self.FUSED_ORDER):

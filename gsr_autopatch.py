@@ -169,11 +169,23 @@ class _LazySelection:
 
     def __init__(self, dense, mask, max_of=None):
         self._dense, self.mask, self.max_of = dense, mask, max_of      # max_of = (a, b): the element-wise maximum, not yet evaluated
+        # eager `dense[mask]` would have copied the values NOW: remember the version counters of what stands for them and refuse to
+        # be evaluated after an in-place write to any of it -- the trainer's one statement never does that
+        self._versions = [(t, t._version) for t in ((dense,) if dense is not None else tuple(max_of)) + (mask,)]
+
+    def _check(self):
+        for t, v in self._versions:
+            if t._version != v:
+                raise RuntimeError("gsr_autopatch: a tensor indexed by the render's visibility_filter was modified in place before the "
+                                   "selection was used -- the lazy selection no longer stands for what `dense[mask]` would have copied; "
+                                   "set GSR_AUTOPATCH_LAZY_MASK=0 (plain bool mask, eager gathers) for code that keeps such selections")
 
     @property
     def dense(self):
+        self._check()
         if self._dense is None:
             self._dense = torch.maximum(*self.max_of)
+            self._versions = [(self.mask, self._versions[-1][1])]
         return self._dense
 
     @property
@@ -188,7 +200,7 @@ class _LazySelection:
         kwargs = kwargs or {}
         if func is torch.max and len(args) == 2 and not kwargs and isinstance(args[0], _LazySelection) and isinstance(args[1], _LazySelection) \
                 and args[0].mask is args[1].mask and args[0].dense_shape == args[1].dense_shape:
-            return _LazySelection(None, args[0].mask, max_of=(args[0].dense, args[1].dense))
+            return _LazySelection(None, args[0].mask, max_of=(args[0].dense, args[1].dense))      # (.dense checks the versions)
         unwrap = lambda a: a.materialise() if isinstance(a, _LazySelection) else a
         return func(*[unwrap(a) for a in args], **{k: unwrap(v) for k, v in kwargs.items()})
 
@@ -228,6 +240,7 @@ class LazyMask(torch.Tensor):
                 and args[2].mask is args[1] and type(args[0]) is torch.Tensor and args[0].shape == args[1].shape \
                 and args[2].dense_shape == args[0].shape and not kwargs:
             dst, m, sel = args[0], args[1].as_subclass(torch.Tensor), args[2]
+            sel._check()
             with torch._C.DisableTorchFunctionSubclass():
                 pair = getattr(sel, "max_of", None)         # torch.max(dst[mask], radii[mask]): one launch (gsr_masked_max)
                 if pair is not None and pair[0] is dst and dst.is_cuda and dst.dtype == torch.float32 and dst.is_contiguous() \
@@ -254,6 +267,9 @@ def _pose_matrix(g):
     else:
         return None
     return T.matrix().reshape(4, 4)
+
+
+_ZERO_POINTS = {}
 
 
 def _view_id(cam, g) -> int:
@@ -313,7 +329,15 @@ def render_fused(self, viewpoint_camera, scaling_modifier=1.0, invert_bg_color=F
     dev = xyz.device
     # the tensor whose .grad receives the 2D positional gradient (:800-808: `zeros_like(get_xyz, requires_grad=True) + 0` with
     # retain_grad); its values are never read by the rasterizer
-    screenspace_points = torch.zeros((xyz.shape[0], 3), dtype=torch.float32, device=dev, requires_grad=True)
+    # (one zero buffer per (N, device), a fresh LEAF over it per render -- detach() makes a new tensor object on the same storage, no
+    #  fill launch and no allocation; every render's leaf has its own .grad, and a leaf that requires grad cannot be written in place)
+    zkey = (int(xyz.shape[0]), dev)
+    zbuf = _ZERO_POINTS.get(zkey)
+    if zbuf is None:
+        if len(_ZERO_POINTS) > 8:
+            _ZERO_POINTS.clear()
+        zbuf = _ZERO_POINTS[zkey] = torch.zeros((xyz.shape[0], 3), dtype=torch.float32, device=dev)
+    screenspace_points = zbuf.detach().requires_grad_(True)
     bg = self.bg_color if not invert_bg_color else 1 - self.bg_color
     settings = R.GaussianRasterizationSettings(
         image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),

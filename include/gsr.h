@@ -196,7 +196,9 @@ typedef struct GsrBackwardArgs {
     const float *viewmatrix, *projmatrix, *campos, *bg;
     const void* geom;    /* from forward */
     const void* image;   /* from forward */
-    const void* binning; /* from forward */
+    void* binning;       /* from forward.  WRITTEN by gsr_backward (round 4): the backward blend's work-item lists and queue heads live in
+                          * this buffer, so two backwards over the SAME forward output must not run concurrently (serialise them on one
+                          * stream); a repeated backward on one stream is fine -- the lists are rebuilt by every call */
     int64_t num_rendered;
     const float* grad_color; /* [3,H,W] or NULL */
     const float* grad_depth; /* [1,H,W] or NULL */

@@ -199,6 +199,29 @@ def test_lazy_mask_statement_equals_boolean_mask_indexing(autopatch):
         assert torch.equal(e, b)
 
 
+def test_lazy_selection_refuses_to_stand_for_values_that_were_overwritten(autopatch):
+    """`dense[mask]` through the LazyMask is not gathered, so it does not snapshot `dense` the way eager indexing does; a
+    selection that is used after an in-place write to the tensor it stands for (or to the mask) says so instead of returning the
+    new values.  The trainer's single statement never does this."""
+    import pytest
+    g = torch.Generator().manual_seed(3)
+    plain = torch.rand(50, generator=g) > 0.5
+    m = autopatch.LazyMask(plain.clone())
+    a = torch.rand(50, generator=g)
+    sel = a[m]
+    want = a[plain].clone()
+    assert torch.equal(sel + 0, want)               # used right away: the eager values
+    sel = a[m]
+    a.add_(1.0)                                     # eager `a[plain]` taken before this line would still hold the OLD values
+    with pytest.raises(RuntimeError, match="modified in place"):
+        sel + 0
+    r = torch.randint(0, 40, (50,), generator=g, dtype=torch.int32)
+    mx = torch.max(a[m], r[m])
+    r.add_(1)
+    with pytest.raises(RuntimeError, match="modified in place"):
+        a[m] = mx
+
+
 def test_psnr_is_patched_in_image_utils_and_in_modules_that_imported_it_before(monkeypatch):
     """`from utils.image_utils import psnr` binds the function in the trainer module: apply() replaces it in both places, remove()
     restores both; CPU tensors keep running the original statement."""

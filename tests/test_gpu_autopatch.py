@@ -324,6 +324,49 @@ def test_deferred_adam_under_the_unmodified_trainer_equals_the_separate_step(mon
         assert torch.equal(sa[1][k], sa[0][k])
 
 
+def test_two_renders_feeding_one_backward_sum_their_gradients_on_the_deferred_route(monkeypatch):
+    """loss = f(render A) + f(render B) of the same model, one backward, one step.  Plain torch sums the two
+    gradients; the deferred route used to let the second render replace the first one's plan, both autograd nodes then wrote the
+    same shadows and step() adopted whichever ran last.  Now the first render keeps its plan, the second takes the plain gradient
+    route, and step() -- a .grad beside committed shadows -- recovers the first gradient and adds it: the model after the step
+    matches the separate-step route (GSR_AUTOPATCH_DEFERRED=0), and differs from a step on either render alone."""
+    import gsr_autopatch
+    dev = torch.device("cuda:0")
+    W, H, N = 256, 192, 6000
+    sc = parity.syn.make_scene(N, W, H, sh_degree=3, seed=12)
+    sc2 = dict(sc, **{k: parity.syn.make_scene(8, W, H, sh_degree=3, seed=5, posed=True)[k] for k in ("viewmatrix", "projmatrix", "campos")})
+    gt, gt2 = parity.syn.target_image(W, H, seed=3).to(dev), parity.syn.target_image(W, H, seed=4).to(dev)
+    cam, cam2 = refstub.StubCamera.from_scene(sc, dev, original_image=gt, uid=0), refstub.StubCamera.from_scene(sc2, dev, original_image=gt2, uid=1)
+    monkeypatch.setenv("GSR_AUTOPATCH_DEFERRED_MIN_N", "0")
+
+    def run(deferred, both=True):
+        monkeypatch.setenv("GSR_AUTOPATCH_DEFERRED", "1" if deferred else "0")
+        p, r = _autopatched_model(sc, dev)
+        o = p.optimizer
+        _iteration(r, cam, gt)                                         # moments leave zero first
+        a = gsr_autopatch.render_fused(r, cam)
+        loss = gsr_autopatch.loss_forward(_LossCfg(), a["image"], gt)["loss"]
+        if both:
+            b = gsr_autopatch.render_fused(r, cam2)
+            if deferred:
+                assert o._pending is not None                          # render A's plan survived render B
+            loss = loss + gsr_autopatch.loss_forward(_LossCfg(), b["image"], gt2)["loss"]
+        loss.backward()
+        o.step(); o.zero_grad(set_to_none=True)
+        assert o._pending is None
+        _iteration(r, cam, gt)                                         # and training goes on (deferred again)
+        return {k: getattr(p, k).detach().clone() for k in RAW}, {g["name"]: int(o.state[g["params"][0]]["step"]) for g in o.param_groups}
+    (da, sa), (db, sb), (dc, _) = run(True), run(False), run(True, both=False)
+    assert sa == sb and sa["xyz"] == 3, (sa, sb)
+    lrs = {"_xyz": 0.00016, "_features_dc": 0.0025, "_features_rest": 0.0025 / 20.0, "_opacity": 0.05, "_scaling": 0.005, "_rotation": 0.001}
+    for k in RAW:
+        bad = ((da[k] - db[k]).abs() > 0.05 * lrs[k] + 5e-7 * db[k].abs()).float().mean().item()
+        assert bad < 3e-3, (k, bad)
+    # ... and the second render's gradient is really in it: a step on render A alone ends somewhere else
+    off = ((da["_xyz"] - dc["_xyz"]).abs() > 0.05 * lrs["_xyz"]).float().mean().item()
+    assert off > 0.05, off
+
+
 def test_deferred_adam_at_sh_degree_zero_skips_the_rest_group_like_the_separate_step(monkeypatch):
     """The reference starts every model at active SH degree 0 (gaussian_model_ht.py:68; all of stage A stays there): f_rest then has
     an identically zero gradient and, while its moments are zero, the in-kernel update leaves the group out (no shadow to adopt).

@@ -962,3 +962,58 @@ def test_debug_flag_dumps_a_snapshot_on_native_errors(tmp_path, monkeypatch):
                                cov3D_precomp=None)
     snap = torch.load(tmp_path / "snapshot_fw.dump")
     assert torch.equal(snap[0], kw["means3D"]) and snap[14:16] == [48, 64]
+
+
+@pytest.mark.parametrize("case", [(50, 64, 48, 1.0), (60000, 500, 333, 1.0), (3000, 320, 240, 12.0), (300000, 980, 545, 1.0), (1000000, 980, 545, 1.0)],
+                         ids=["tiny", "60k", "large-rects", "300k", "1M"])
+def test_early_instance_count_is_the_scans(case):
+    """Round 5: a speculative forward learns R from k_preprocess's per-block sums of the Gaussians' tile counts -- published by the
+    depth sort's histogram kernel (radix_sort.h OsRider), ~10 us into the forward -- instead of from the scan behind sort + tile
+    counts (gsr_set_option("early_r")).  The two counts are the same number: R, the image, the radii and the binned list are equal
+    with the option on and off -- ordinary records, large rects counted cooperatively (scale_modifier 12), the exact first call
+    and the speculative calls after it, a capacity that overflows and is re-run, and the 27-bit depth window of the three-pass
+    sort at 1 M (whose overflow count rides along)."""
+    import ctypes as C
+    import importlib
+    import hip_runner
+    L = importlib.import_module("3dgs_hierarchical_training_amd._lib")
+    R_ = importlib.import_module("3dgs_hierarchical_training_amd.rasterizer")
+    lib = L.load()
+    N, W, H, scale = case
+    sc = parity.syn.make_scene(N, W, H, sh_degree=1, seed=N % 91, posed=True)
+    sc["scale_modifier"] = scale
+    kw = parity.scene_kwargs(sc, "sh", bg=(0.1, 0.2, 0.3))
+    dev = torch.device("cuda:0")
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+
+    def run():
+        out = hip_runner.run_hip(kw)["fwd"]
+        Rn = R_.last_call_info()["num_rendered"]
+        info = R_._LAST
+        ranges = torch.zeros(T, 2, dtype=torch.int32, device=dev)
+        lst = torch.zeros(max(Rn, 1), dtype=torch.int32, device=dev)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        assert lib.gsr_debug_read_binning(C.c_void_p(info["binning"].data_ptr()), info["binning_capacity"], Rn, W, H,
+                                          C.c_void_p(ranges.data_ptr()), C.c_void_p(lst.data_ptr()), C.c_void_p(st)) == 0
+        torch.cuda.synchronize()
+        return out, Rn, ranges.cpu(), lst.cpu()[:Rn]
+    res = {}
+    try:
+        for early in (0, 1):
+            assert lib.gsr_set_option(b"early_r", early) == 0
+            assert lib.gsr_set_option(b"reset_speculation", 1) == 0
+            runs = [run(), run(), run()]                        # exact first call, then speculative ones
+            assert lib.gsr_set_option(b"binning_capacity_hint", max(1, runs[0][1] // 3)) == 0
+            runs.append(run())                                  # a capacity that overflows: re-run with the exact size
+            res[early] = runs
+    finally:
+        lib.gsr_set_option(b"early_r", 1)
+        lib.gsr_set_option(b"binning_capacity_hint", 0)
+    base = res[0][0]
+    assert base[1] > 0
+    for early in (0, 1):
+        for k, r in enumerate(res[early]):
+            assert r[1] == base[1], (early, k, r[1], base[1])
+            for a, b in zip(r[0], base[0]):
+                assert np.array_equal(a, b), (early, k)
+            assert torch.equal(r[2], base[2]) and torch.equal(r[3], base[3]), (early, k)
