@@ -41,7 +41,7 @@ def _register_fakes():
     @torch.library.register_fake("gsr::rasterize_forward")
     def _(means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, sh_rest, viewmatrix, projmatrix, campos, bg,
           points_transform, image_height, image_width, tanfovx, tanfovy, scale_modifier, sh_degree, raw_params, prefiltered, debug,
-          prepared, batch_first_block, view_id=0):
+          prepared, batch_first_block, view_id=0, extras=0):
         N, H, W = means3D.shape[0], image_height, image_width
         f = lambda *s: means3D.new_empty(s, dtype=torch.float32)
         b = lambda n: means3D.new_empty((n,), dtype=torch.uint8)
@@ -50,20 +50,22 @@ def _register_fakes():
         B = len(batch_first_block) - 1 if len(batch_first_block) >= 3 else 1
         lead = (B,) if B > 1 else ()
         return (f(*lead, 3, H, W), means3D.new_empty((N,), dtype=torch.int32), f(*lead, 1, H, W), f(*lead, 1, H, W), b(lib.gsr_geom_bytes(int(N))),
-                b(lib.gsr_image_bytes_batched(int(W), int(H), B)), b(nbin), torch.empty((3,), dtype=torch.int64))
+                b(lib.gsr_image_bytes_batched(int(W), int(H), B)), b(nbin), torch.empty((3,), dtype=torch.int64),
+                f(*lead, 3, H, W) if (extras & 1) else f(0), b(N if ((extras & 2) and prepared.numel() == 0) else 0))
 
     @torch.library.register_fake("gsr::rasterize")
     def _(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, sh_rest, viewmatrix, projmatrix, campos,
           bg, points_transform, image_height, image_width, tanfovx, tanfovy, scale_modifier, sh_degree, raw_params, prefiltered, debug,
           cam_grad, adam_m, adam_v, adam_lr, beta1, beta2, eps, step, prepared, next_viewmatrix, next_projmatrix, next_campos,
-          next_height, next_width, next_tanfovx, next_tanfovy, next_points_transform, next_sh_degree, adam_commit, densify_stats, batch_first_block, view_id=0):
+          next_height, next_width, next_tanfovx, next_tanfovy, next_points_transform, next_sh_degree, adam_commit, densify_stats, batch_first_block, view_id=0, extras=0):
         N, H, W = means3D.shape[0], image_height, image_width
         f = lambda *s: means3D.new_empty(s, dtype=torch.float32)
         nprep = lib.gsr_prepared_bytes(int(N)) if next_viewmatrix.numel() else 0
         B = len(batch_first_block) - 1 if len(batch_first_block) >= 3 else 1
         lead = (B,) if B > 1 else ()
         return (f(*lead, 3, H, W), means3D.new_empty((N,), dtype=torch.int32), f(*lead, 1, H, W), f(*lead, 1, H, W),
-                means3D.new_empty((nprep,), dtype=torch.uint8))
+                means3D.new_empty((nprep,), dtype=torch.uint8), f(*lead, 3, H, W) if (extras & 1) else f(0),
+                means3D.new_empty((N if ((extras & 2) and prepared.numel() == 0) else 0,), dtype=torch.uint8))
 
     @torch.library.register_fake("gsr::rasterize_backward")
     def _(means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, sh_rest, viewmatrix, projmatrix, campos, bg,
@@ -135,6 +137,10 @@ def _register_fakes():
     @torch.library.register_fake("gsr::photometric_loss")
     def _(render, target, lambda_dssim, clamp):
         return render.new_empty((), dtype=torch.float32)
+
+    @torch.library.register_fake("gsr::photometric_loss_terms")
+    def _(render, target, lambda_dssim, clamp):
+        return render.new_empty((), dtype=torch.float32), render.new_empty((6,), dtype=torch.float32)
 
     @torch.library.register_fake("gsr::photometric_loss_backward")
     def _(render, target, workspace, grad_loss, lambda_dssim, clamp):

@@ -25,7 +25,7 @@ class GsrForwardArgs(C.Structure):
         ("alloc", ALLOC_FN), ("alloc_user", C.c_void_p),
         ("shs_rest", C.c_void_p), ("raw_params", C.c_int32),
         ("points_transform", C.c_void_p), ("prepared", C.c_void_p), ("batch", C.c_void_p),
-        ("view_id", C.c_int64),
+        ("view_id", C.c_int64), ("out_color_clamped", C.c_void_p), ("visible", C.c_void_p),
     ]
 
 
@@ -76,7 +76,7 @@ EXPORTS = [
     "gsr_knn_scratch_bytes", "gsr_knn_mean_dist2", "gsr_get_counter", "gsr_debug_read_binning", "gsr_debug_direct_binning_geometry", "gsr_debug_view_cache_stats", "gsr_prepared_bytes",
     "gsr_prepare_supported", "gsr_prepared_radii_offset", "gsr_stream_copy", "gsr_image_bytes_batched",
     "gsr_masked_max", "gsr_densify_stats_add", "gsr_psnr_scratch_bytes", "gsr_psnr",
-    "gsr_loss_workspace_bytes_batched", "gsr_loss_forward_batched", "gsr_loss_backward_batched",
+    "gsr_loss_workspace_bytes_batched", "gsr_loss_forward_batched", "gsr_loss_backward_batched", "gsr_loss_forward_terms",
 ]
 
 _lib = None

@@ -423,7 +423,7 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess(CamParams cp, int N,
                                                             uint32_t* __restrict__ dkey, uint32_t* __restrict__ gid,
                                                             TileRec* __restrict__ tilerec, uint32_t* __restrict__ zero_words,
                                                             int zero_count, int block0, DepthHist dh, uint2* __restrict__ early_parts = nullptr,
-                                                            uint32_t window_max = 0xffffffffu)
+                                                            uint32_t window_max = 0xffffffffu, uint8_t* __restrict__ visible = nullptr)
 {
     constexpr int NC3 = 3 * (DEG + 1) * (DEG + 1);
     __shared__ float s_sh[kPreThreads * kShStride];
@@ -551,6 +551,7 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess(CamParams cp, int N,
     splat[i] = s;
     tilerec[i] = rec;   // compact emission record: k_tile_counts / k_emit never touch the 48 B splats
     radii[i] = s.radius;
+    if (visible) visible[i] = s.radius > 0 ? 1 : 0;   // `visibility_filter = radii > 0` (gaussian_model_ht.py:905), written here instead of by a torch launch
     const uint32_t key = s.tiles > 0 ? __float_as_uint(s.depth) : 0xffffffffu;
     dkey[i] = key;
     gid[i] = (uint32_t)i;
@@ -1492,7 +1493,8 @@ __device__ __forceinline__ void blend_fwd_item(const int xcd, const int kslot, f
                                                const float* __restrict__ bg, float* __restrict__ out_color,
                                                float* __restrict__ out_depth, float* __restrict__ out_alpha,
                                                float* __restrict__ img, uint32_t* __restrict__ staged4, int interleave,
-                                               float* __restrict__ ckpt, int kCkptFirst, int tiles_y, uint16_t* __restrict__ cost_out)
+                                               float* __restrict__ ckpt, int kCkptFirst, int tiles_y, uint16_t* __restrict__ cost_out,
+                                               float* __restrict__ out_clamped)
 {
     constexpr int NT = 64;
     uint32_t visits = 0u;   // (wave, instance) visits of this item: what the balanced placement of the next render of this view predicts with
@@ -1663,9 +1665,16 @@ __device__ __forceinline__ void blend_fwd_item(const int xcd, const int kslot, f
         img[2 * P + pid] = C0; img[3 * P + pid] = C1; img[4 * P + pid] = C2;
         img[5 * P + pid] = Dd; img[6 * P + pid] = Aa;
         float* oc = out_color + (size_t)bimg * 3 * Pl + pl;   // outputs: [B, 3, H, W], [B, 1, H, W]
-        oc[0] = C0 + Tf * bg[0];
-        oc[Pl] = C1 + Tf * bg[1];
-        oc[2 * Pl] = C2 + Tf * bg[2];
+        const float o0 = C0 + Tf * bg[0], o1 = C1 + Tf * bg[1], o2 = C2 + Tf * bg[2];
+        oc[0] = o0;
+        oc[Pl] = o1;
+        oc[2 * Pl] = o2;
+        if (out_clamped) {   // `rendered_image.clamp(0, 1)` (gaussian_model_ht.py:883) written here instead of by a torch launch; NaN stays NaN
+            float* cc = out_clamped + (size_t)bimg * 3 * Pl + pl;
+            cc[0] = o0 < 0.f ? 0.f : (o0 > 1.f ? 1.f : o0);
+            cc[Pl] = o1 < 0.f ? 0.f : (o1 > 1.f ? 1.f : o1);
+            cc[2 * Pl] = o2 < 0.f ? 0.f : (o2 > 1.f ? 1.f : o2);
+        }
         out_depth[pid] = Dd;
         out_alpha[pid] = Aa;
     }
@@ -1678,7 +1687,8 @@ __global__ __launch_bounds__(64) void k_blend_fwd_w6(int W, int H, int tiles_x, 
                                                      const float* __restrict__ bg, float* __restrict__ out_color,
                                                      float* __restrict__ out_depth, float* __restrict__ out_alpha,
                                                      float* __restrict__ img, uint32_t* __restrict__ staged4, int interleave,
-                                                     float* __restrict__ ckpt, int kCkptFirst, int tiles_y, const BlendBalance bb)
+                                                     float* __restrict__ ckpt, int kCkptFirst, int tiles_y, const BlendBalance bb,
+                                                     float* __restrict__ out_clamped)
 {
     // s_a and s_b in ONE array (planes 0/1 = A rows of the two buffers, 2/3 = B rows): a visit's two reads share one address
     // register and differ in the immediate offset
@@ -1698,7 +1708,7 @@ __global__ __launch_bounds__(64) void k_blend_fwd_w6(int W, int H, int tiles_x, 
         if (e < (uint32_t)kVcEntries) cost_out = bb.cost + (size_t)e * bb.items;
     }
     blend_fwd_item<REACH>((int)(blockIdx.x & 7), kslot, s_ab, s_c, W, H, tiles_x, T, ranges, list, splat, bg, out_color, out_depth,
-                          out_alpha, img, staged4, interleave, ckpt, kCkptFirst, tiles_y, cost_out);
+                          out_alpha, img, staged4, interleave, ckpt, kCkptFirst, tiles_y, cost_out, out_clamped);
 }
 
 // (round 3, measured with tools/k6_wave_timing.py on the 1 M / 980x545 frame: the 8.6 k waves are all resident at once, eight to
@@ -3101,6 +3111,7 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
     const int opt_ppt = g_blend_ppt ? g_blend_ppt : 7, opt_map = g_tile_map, opt_ckpt = g_ckpt_first;
     const int tiles_x = (W + kTile - 1) / kTile, tiles_y = (H + kTile - 1) / kTile, T = tiles_x * tiles_y * NB;
     if (NB > 1 && opt_ppt < 6) return fail(GSR_ERR_ARG, "batch: served by the default forward blend kernel only%s");
+    if (a->out_color_clamped && opt_ppt < 6) return fail(GSR_ERR_ARG, "out_color_clamped: served by the default forward blend kernel only%s");
     out->num_rendered = 0; out->binning = nullptr; out->binning_bytes = 0; out->binning_capacity = 0;
     out->forward_flags = pack_fwd_flags(opt_ppt, opt_map, opt_ckpt);
     uint64_t R = 0;
@@ -3207,17 +3218,17 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
             hipEvent_t ea = nullptr, eb = nullptr;
             if (hipEventCreate(&ea) != hipSuccess || hipEventCreate(&eb) != hipSuccess) return fail(GSR_ERR_HIP, "hipEventCreate failed%s");
             hipExtLaunchKernelGGL(k_blend_fwd_w6<true>, dim3(8 * 4 * slots_per_xcd(opt_map, T, tiles_x)), dim3(64), 0, st, ea, eb, 0, W, H, tiles_x, T, ranges, list,
-                                  splat, a->bg, a->out_color, a->out_depth, a->out_alpha, img, staged, opt_map, ckpt, opt_ckpt, tiles_y, bb);
+                                  splat, a->bg, a->out_color, a->out_depth, a->out_alpha, img, staged, opt_map, ckpt, opt_ckpt, tiles_y, bb, a->out_color_clamped);
             std::lock_guard<std::mutex> lk(g_prof_mutex);
             g_prof_events[P_BLEND_FWD].push_back({ea, eb});
         } else {
             ProfScope ps(ppt == 7 && g_profile == 3 ? P_COUNT : P_BLEND_FWD, st);   // (mode 3, an untimed launch: no events)
             if (ppt == 7)
                 hipLaunchKernelGGL(k_blend_fwd_w6<true>, dim3(8 * 4 * slots_per_xcd(opt_map, T, tiles_x)), dim3(64), 0, st, W, H, tiles_x, T, ranges, list, splat, a->bg,
-                                   a->out_color, a->out_depth, a->out_alpha, img, staged, opt_map, ckpt, opt_ckpt, tiles_y, bb);
+                                   a->out_color, a->out_depth, a->out_alpha, img, staged, opt_map, ckpt, opt_ckpt, tiles_y, bb, a->out_color_clamped);
             else if (ppt == 6)
                 hipLaunchKernelGGL(k_blend_fwd_w6<false>, dim3(8 * 4 * slots_per_xcd(opt_map, T, tiles_x)), dim3(64), 0, st, W, H, tiles_x, T, ranges, list, splat, a->bg,
-                                   a->out_color, a->out_depth, a->out_alpha, img, staged, opt_map, ckpt, opt_ckpt, tiles_y, BlendBalance{});
+                                   a->out_color, a->out_depth, a->out_alpha, img, staged, opt_map, ckpt, opt_ckpt, tiles_y, BlendBalance{}, a->out_color_clamped);
 #ifdef GSR_AB_VARIANTS
             else if (!launch_blend_fwd_variant(ppt, W, H, tiles_x, T, ranges, list, splat, a->bg, a->out_color, a->out_depth, a->out_alpha, img, staged,
                                                opt_map, ckpt, opt_ckpt, st))
@@ -3321,7 +3332,7 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
 #define GSR_PRE_(DEG, RAW)                                                                                                          \
     hipLaunchKernelGGL((k_preprocess<DEG, RAW>), dim3(grid), dim3(kPreThreads), 0, st, cp, N, a->means3D, a->scales, a->rotations, \
                        a->cov3D_precomp, a->opacities, a->shs, a->shs_rest, a->colors_precomp, splat, a->radii, dkey, gid, ntiles,  \
-                       zero_words, zero_count, 0, DepthHist{}, early_parts, early_window)
+                       zero_words, zero_count, 0, DepthHist{}, early_parts, early_window, a->visible)
 #define GSR_PRE(DEG) do { if (a->raw_params) GSR_PRE_(DEG, true); else GSR_PRE_(DEG, false); } while (0)
     {
         ProfScope ps(P_PRE_FWD, st);

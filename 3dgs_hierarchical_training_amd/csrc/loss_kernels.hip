@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void k_loss_fwd(const float* __restrict__ raw,
 // images > 1 (a stack of independent images, gsr_loss_forward_batched): inv_count is ONE image's 1 / (C H W), so the two sums are
 // sums of per-image means; out[0] = the SUM of the images' losses, out[1] / out[2] their mean SSIM / mean L1
 __global__ __launch_bounds__(1024) void k_loss_finish(const float* __restrict__ partial, int nblocks, float inv_count, float lambda,
-                                                      float* __restrict__ out, int images)
+                                                      float* __restrict__ out, int images, int nout = 3, float* __restrict__ loss_dup = nullptr)
 {
     __shared__ double s0[1024], s1[1024];
     double a = 0, b = 0;
@@ -195,6 +195,12 @@ __global__ __launch_bounds__(1024) void k_loss_finish(const float* __restrict__ 
         const double ms = s0[0] * inv_count, ml = s1[0] * inv_count;
         out[0] = (float)((1.0 - lambda) * ml + lambda * ((double)images - ms));
         out[1] = (float)(ms / images); out[2] = (float)(ml / images);
+        if (nout >= 6) {   // what Loss.forward reports beside the loss (/root/reference/trainer/losses.py:128-136), so the caller needs no torch ops for them
+            out[3] = (float)((1.0 - lambda) * (ml / images));    // loss_rgb = (1 - lambda) * mean L1
+            out[4] = (float)(1.0 - ms / images);                 // loss_dssim = 1 - mean SSIM
+            out[5] = 0.f;                                        // loss_depth when no depth term is configured
+        }
+        if (loss_dup) *loss_dup = out[0];
     }
 }
 
@@ -315,8 +321,20 @@ size_t gsr_loss_workspace_bytes(int32_t C, int32_t H, int32_t W)
 }
 size_t gsr_loss_workspace_bytes_batched(int32_t images, int32_t C, int32_t H, int32_t W) { return gsr_loss_workspace_bytes(images * C, H, W); }
 
+static int loss_forward_impl(const float* render, const float* target, int32_t images, int32_t C, int32_t H, int32_t W, float lambda_dssim,
+                             int32_t clamp01_render, void* workspace, float* out3, void* stream, int nout, float* loss_dup = nullptr);
 int gsr_loss_forward_batched(const float* render, const float* target, int32_t images, int32_t C, int32_t H, int32_t W, float lambda_dssim,
                              int32_t clamp01_render, void* workspace, float* out3, void* stream)
+{
+    return loss_forward_impl(render, target, images, C, H, W, lambda_dssim, clamp01_render, workspace, out3, stream, 3);
+}
+int gsr_loss_forward_terms(const float* render, const float* target, int32_t images, int32_t C, int32_t H, int32_t W, float lambda_dssim,
+                           int32_t clamp01_render, void* workspace, float* out6, float* loss_copy, void* stream)
+{
+    return loss_forward_impl(render, target, images, C, H, W, lambda_dssim, clamp01_render, workspace, out6, stream, 6, loss_copy);
+}
+static int loss_forward_impl(const float* render, const float* target, int32_t images, int32_t C, int32_t H, int32_t W, float lambda_dssim,
+                             int32_t clamp01_render, void* workspace, float* out3, void* stream, int nout, float* loss_dup)
 {
     if (!render || !target || !workspace || !out3 || images <= 0 || C <= 0 || H <= 0 || W <= 0) return GSR_ERR_ARG;
     const int CT = images * C;   // channels are independent of one another in both terms: the stack is CT channel planes
@@ -326,7 +344,7 @@ int gsr_loss_forward_batched(const float* render, const float* target, int32_t i
     float* partial = reinterpret_cast<float*>(static_cast<uint8_t*>(workspace) + maps_bytes);
     const int nb = (int)(grid.x * grid.y * grid.z);
     hipLaunchKernelGGL(k_loss_fwd, grid, block, 0, (hipStream_t)stream, render, target, H, W, clamp01_render, maps, partial);
-    hipLaunchKernelGGL(k_loss_finish, dim3(1), dim3(1024), 0, (hipStream_t)stream, partial, nb, 1.0f / ((float)C * H * W), lambda_dssim, out3, images);
+    hipLaunchKernelGGL(k_loss_finish, dim3(1), dim3(1024), 0, (hipStream_t)stream, partial, nb, 1.0f / ((float)C * H * W), lambda_dssim, out3, images, nout, loss_dup);
     return hipGetLastError() == hipSuccess ? GSR_OK : GSR_ERR_HIP;
 }
 

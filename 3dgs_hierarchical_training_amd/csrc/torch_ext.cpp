@@ -96,12 +96,12 @@ std::vector<Tensor> debug_last()
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> rasterize_forward(
+std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> rasterize_forward(
     const Tensor& means3D_, const Tensor& sh_, const Tensor& colors_, const Tensor& opacities_, const Tensor& scales_,
     const Tensor& rotations_, const Tensor& cov3D_, const Tensor& sh_rest_, const Tensor& viewmatrix_, const Tensor& projmatrix_,
     const Tensor& campos_, const Tensor& bg_, const Tensor& xf_, int64_t H, int64_t W, double tanfovx, double tanfovy,
     double scale_modifier, int64_t sh_degree, bool raw_params, bool prefiltered, bool debug, const Tensor& prepared,
-    at::IntArrayRef batch_first_block, int64_t view_id)
+    at::IntArrayRef batch_first_block, int64_t view_id, int64_t extras)
 {
     TORCH_CHECK(means3D_.is_cuda(), "GaussianRasterizer: tensors must be on a ROCm/HIP device (no CPU fallback)");
     const BatchArg batch(batch_first_block);
@@ -149,6 +149,12 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> raste
     a.prepared = has(prepared) ? prepared.data_ptr() : nullptr;
     a.batch = batch.ptr();
     a.view_id = view_id;
+    // extras: bit 0 = the clamped colour image (written by the blend kernel), bit 1 = the visibility bytes radii > 0 (written by the
+    // preprocess; not available from a prepared buffer) -- what the reference's wrapper derives with one torch launch each
+    Tensor clamped = (extras & 1) ? at::empty_like(color) : at::empty({0}, fo);
+    Tensor visible = ((extras & 2) && !has(prepared)) ? at::empty({N}, bo) : at::empty({0}, bo);
+    a.out_color_clamped = has(clamped) ? clamped.data_ptr<float>() : nullptr;
+    a.visible = has(visible) ? visible.data_ptr<uint8_t>() : nullptr;
     GsrForwardOut out{};
     check(gsr_forward(&a, &out, c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()), "gsr_forward");
     // (scratch tensors die here: stream-ordered reuse by the caching allocator is safe, same stream)
@@ -162,7 +168,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> raste
         std::lock_guard<std::mutex> lk(g_last_mutex);
         g_last = {image, binning, meta, dims};
     }
-    return {color, radii, depth, alpha, geom, image, binning, meta};
+    return {color, radii, depth, alpha, geom, image, binning, meta, clamped, visible};
 }
 
 struct BwdCommon {
@@ -336,6 +342,7 @@ struct Cfg {
     Tensor next_xf;                       // ... and its points_transform, when it differs from this render's (per-frame poses)
     int64_t next_H = 0, next_W = 0, next_D = -1;   // next_D: SH degree of the next render (-1 = this render's)
     int64_t view_id = 0;                           // GsrForwardArgs::view_id
+    int64_t extras = 0;                            // bit 0: clamped colour output, bit 1: visibility bytes
     double next_tanfovx = 0, next_tanfovy = 0;
 };
 
@@ -356,7 +363,7 @@ class RasterizeFn : public torch::autograd::Function<RasterizeFn> {
         Tensor none;
         auto out = op.call(m3, s, c, o, sc, r, cv, rs, v, p, cp, b, x, cfg.H, cfg.W, cfg.tanfovx, cfg.tanfovy, cfg.scale_modifier,
                            cfg.sh_degree, cfg.raw_params, cfg.prefiltered, cfg.debug, cfg.prepared.defined() ? cfg.prepared : x.new_empty({0}, x.options().dtype(at::kByte)),
-                           cfg.batch, cfg.view_id);
+                           cfg.batch, cfg.view_id, cfg.extras);
         // hand-over buffer for the NEXT render, filled by this render's backward (stream-ordered): allocated here so that it
         // can be returned to the caller as an ordinary output
         Tensor prep_out = has(cfg.next_vm) ? at::empty({(int64_t)gsr_prepared_bytes((int32_t)m3.size(0))}, m3.options().dtype(at::kByte))
@@ -364,6 +371,9 @@ class RasterizeFn : public torch::autograd::Function<RasterizeFn> {
         // NOTE: depth is deliberately NOT saved -- the caller mutates it in place (ht3dgs_trainer.py:1290-1292)
         std::vector<Tensor> saved = {m3, s, c, o, sc, r, cv, rs, v, p, cp, b, x, std::get<4>(out), std::get<5>(out), std::get<6>(out),
                                      std::get<7>(out)};
+        const Tensor clamped = std::get<8>(out), visible = std::get<9>(out);
+        if (has(clamped)) saved.push_back(std::get<0>(out));   // the raw colour: where it lies in [0, 1] a gradient on the clamped image passes
+        ctx->saved_data["has_clamped"] = has(clamped);
         ctx->save_for_backward(saved);
         ctx->saved_data["adam_m"] = cfg.adam_m; ctx->saved_data["adam_v"] = cfg.adam_v;
         ctx->saved_data["dens"] = cfg.densify_stats;
@@ -386,17 +396,24 @@ class RasterizeFn : public torch::autograd::Function<RasterizeFn> {
         ctx->saved_data["next_H"] = cfg.next_H; ctx->saved_data["next_W"] = cfg.next_W;
         ctx->saved_data["next_tfx"] = cfg.next_tanfovx; ctx->saved_data["next_tfy"] = cfg.next_tanfovy;
         ctx->saved_data["next_D"] = cfg.next_D;
-        ctx->mark_non_differentiable({std::get<1>(out), prep_out});
+        ctx->mark_non_differentiable({std::get<1>(out), prep_out, visible});
         ctx->set_materialize_grads(false);   // unused depth / alpha outputs arrive undefined -> specialised backward
-        return {std::get<0>(out), std::get<1>(out), std::get<2>(out), std::get<3>(out), prep_out};
+        return {std::get<0>(out), std::get<1>(out), std::get<2>(out), std::get<3>(out), prep_out, clamped, visible};
     }
 
     static torch::autograd::variable_list backward(torch::autograd::AutogradContext* ctx, torch::autograd::variable_list g)
     {
         auto sv = ctx->get_saved_variables();
         const int64_t n_adam = ctx->saved_data["n_adam"].toInt();
-        const Tensor &gc = g[0], &gd = g[2], &ga = g[3];
+        Tensor gc = g[0];
+        const Tensor &gd = g[2], &ga = g[3];
         torch::autograd::variable_list out(15);   // 14 tensor inputs + the Cfg argument
+        if (g.size() > 5 && g[5].defined() && ctx->saved_data["has_clamped"].toBool()) {
+            // a gradient arrived on the CLAMPED image (a consumer that did not take the fused-clamp route): torch.clamp's rule
+            const Tensor raw = sv.back();
+            const Tensor pass = g[5] * raw.ge(0).logical_and(raw.le(1)).to(g[5].scalar_type());
+            gc = gc.defined() ? gc + pass : pass;
+        }
         if (!gc.defined() && !gd.defined() && !ga.defined()) return out;
         const int64_t H = ctx->saved_data["H"].toInt(), W = ctx->saved_data["W"].toInt(), D = ctx->saved_data["D"].toInt();
         const double tfx = ctx->saved_data["tfx"].toDouble(), tfy = ctx->saved_data["tfy"].toDouble(), smod = ctx->saved_data["smod"].toDouble();
@@ -444,14 +461,14 @@ class RasterizeFn : public torch::autograd::Function<RasterizeFn> {
     }
 };
 
-std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> rasterize(
+std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> rasterize(
     const Tensor& means3D, const Tensor& means2D, const Tensor& sh, const Tensor& colors, const Tensor& opac, const Tensor& scales,
     const Tensor& rots, const Tensor& cov, const Tensor& rest, const Tensor& vm, const Tensor& pm, const Tensor& campos, const Tensor& bg,
     const Tensor& xf, int64_t H, int64_t W, double tanfovx, double tanfovy, double scale_modifier, int64_t sh_degree, bool raw_params,
     bool prefiltered, bool debug, bool cam_grad, at::TensorList adam_m, at::TensorList adam_v, at::ArrayRef<double> adam_lr, double beta1,
     double beta2, double eps, int64_t step, const Tensor& prepared, const Tensor& next_vm, const Tensor& next_pm, const Tensor& next_campos,
     int64_t next_H, int64_t next_W, double next_tanfovx, double next_tanfovy, const Tensor& next_xf, int64_t next_sh_degree,
-    const Tensor& adam_commit, at::TensorList densify_stats, at::IntArrayRef batch_first_block, int64_t view_id)
+    const Tensor& adam_commit, at::TensorList densify_stats, at::IntArrayRef batch_first_block, int64_t view_id, int64_t extras)
 {
     Cfg cfg{H, W, sh_degree, step, tanfovx, tanfovy, scale_modifier, beta1, beta2, eps, raw_params, prefiltered, debug, cam_grad,
             std::vector<double>(adam_lr.begin(), adam_lr.end()), adam_m.vec(), adam_v.vec()};
@@ -459,6 +476,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> rasterize(
     cfg.densify_stats = densify_stats.vec();
     cfg.batch.assign(batch_first_block.begin(), batch_first_block.end());
     cfg.view_id = view_id;
+    cfg.extras = extras;
     if (!adam_m.empty()) {
         TORCH_CHECK(has(adam_commit) && adam_commit.is_cpu() && adam_commit.scalar_type() == at::kLong, "fused_adam: adam_commit must be a CPU int64 tensor");
         cfg.adam_commit = adam_commit;
@@ -471,24 +489,25 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> rasterize(
         if (has(next_xf)) cfg.next_xf = next_xf;
     }
     auto r = RasterizeFn::apply(means3D, means2D, sh, colors, opac, scales, rots, cov, rest, vm, pm, campos, bg, xf, cfg);
-    return {r[0], r[1], r[2], r[3], r[4]};
+    return {r[0], r[1], r[2], r[3], r[4], r[5], r[6]};
 }
 
 // tensors without an autograd key (torch.inference_mode): the forward alone
-std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> rasterize_forward_only(
+std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> rasterize_forward_only(
     const Tensor& means3D, const Tensor& means2D, const Tensor& sh, const Tensor& colors, const Tensor& opac, const Tensor& scales,
     const Tensor& rots, const Tensor& cov, const Tensor& rest, const Tensor& vm, const Tensor& pm, const Tensor& campos, const Tensor& bg,
     const Tensor& xf, int64_t H, int64_t W, double tanfovx, double tanfovy, double scale_modifier, int64_t sh_degree, bool raw_params,
     bool prefiltered, bool debug, bool cam_grad, at::TensorList adam_m, at::TensorList adam_v, at::ArrayRef<double> adam_lr, double beta1,
     double beta2, double eps, int64_t step, const Tensor& prepared, const Tensor& next_vm, const Tensor& next_pm, const Tensor& next_campos,
     int64_t next_H, int64_t next_W, double next_tanfovx, double next_tanfovy, const Tensor& next_xf, int64_t next_sh_degree,
-    const Tensor& adam_commit, at::TensorList densify_stats, at::IntArrayRef batch_first_block, int64_t view_id)
+    const Tensor& adam_commit, at::TensorList densify_stats, at::IntArrayRef batch_first_block, int64_t view_id, int64_t extras)
 {
     (void)means2D; (void)next_xf; (void)next_sh_degree; (void)adam_commit; (void)densify_stats; (void)cam_grad; (void)adam_m; (void)adam_v; (void)adam_lr; (void)beta1; (void)beta2; (void)eps; (void)step;
     (void)next_vm; (void)next_pm; (void)next_campos; (void)next_H; (void)next_W; (void)next_tanfovx; (void)next_tanfovy;
     auto out = rasterize_forward(means3D, sh, colors, opac, scales, rots, cov, rest, vm, pm, campos, bg, (has(xf) && xf.dim() == 2) ? xf.slice(0, 0, 3) : xf, H, W,
-                                 tanfovx, tanfovy, scale_modifier, sh_degree, raw_params, prefiltered, debug, prepared, batch_first_block, view_id);
-    return {std::get<0>(out), std::get<1>(out), std::get<2>(out), std::get<3>(out), at::empty({0}, means3D.options().dtype(at::kByte))};
+                                 tanfovx, tanfovy, scale_modifier, sh_degree, raw_params, prefiltered, debug, prepared, batch_first_block, view_id, extras);
+    return {std::get<0>(out), std::get<1>(out), std::get<2>(out), std::get<3>(out), at::empty({0}, means3D.options().dtype(at::kByte)), std::get<8>(out),
+            std::get<9>(out)};
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -518,6 +537,22 @@ std::tuple<Tensor, Tensor> photometric_loss_forward(const Tensor& render_, const
     check(gsr_loss_forward_batched(fp(render), fp(target), B, C, H, W, (float)lambda_dssim, clamp, ws.data_ptr(), out.data_ptr<float>(),
                                    c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()), "gsr_loss_forward");
     return {out, ws};
+}
+
+// the same with the six-term result vector of gsr_loss_forward_terms (single image)
+std::tuple<Tensor, Tensor, Tensor> photometric_loss_forward_terms(const Tensor& render_, const Tensor& target_, double lambda_dssim, bool clamp)
+{
+    TORCH_CHECK(render_.is_cuda(), "fused_photometric_loss: tensors must be on a ROCm/HIP device (no CPU fallback)");
+    const c10::hip::HIPGuardMasqueradingAsCUDA guard(render_.device());
+    const Tensor render = f32c(render_), target = f32c(target_);
+    TORCH_CHECK((render.dim() == 3 || render.dim() == 4) && render.sizes() == target.sizes(), "fused_photometric_loss: [C,H,W] or [B,C,H,W] render and target of one shape");
+    const int o = render.dim() == 4 ? 1 : 0;
+    const int32_t B = o ? (int32_t)render.size(0) : 1, C = (int32_t)render.size(o), H = (int32_t)render.size(o + 1), W = (int32_t)render.size(o + 2);
+    Tensor ws = at::empty({(int64_t)gsr_loss_workspace_bytes_batched(B, C, H, W)}, render.options().dtype(at::kByte));
+    Tensor out = at::empty({6}, render.options()), loss = at::empty({}, render.options());
+    check(gsr_loss_forward_terms(fp(render), fp(target), B, C, H, W, (float)lambda_dssim, clamp, ws.data_ptr(), out.data_ptr<float>(),
+                                 loss.data_ptr<float>(), c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()), "gsr_loss_forward_terms");
+    return {out, ws, loss};
 }
 
 Tensor photometric_loss_backward(const Tensor& render_, const Tensor& target_, const Tensor& ws, const Tensor& grad_loss_, double lambda_dssim,
@@ -580,6 +615,43 @@ class PhotometricLossFn : public torch::autograd::Function<PhotometricLossFn> {
 Tensor photometric_loss(const Tensor& render, const Tensor& target, double lambda_dssim, bool clamp)
 {
     return PhotometricLossFn::apply(render, target, lambda_dssim, clamp);
+}
+
+// (loss, terms): `loss` is the differentiable scalar, `terms` the six-float vector {loss, mean SSIM, mean L1, loss_rgb, loss_dssim,
+// loss_depth = 0} -- everything Loss.forward of the reference returns, from ONE forward; the caller slices it (views, no kernels).
+// Undefined upstream gradients are not materialised: the backward sees d loss alone (no zero fills for the unused vector).
+class PhotometricTermsFn : public torch::autograd::Function<PhotometricTermsFn> {
+   public:
+    static torch::autograd::variable_list forward(torch::autograd::AutogradContext* ctx, const Tensor& render, const Tensor& target, double lambda_dssim,
+                                                  bool clamp)
+    {
+        const Tensor r = f32c(render), t = f32c(target.device() == render.device() ? target : target.to(render.device()));
+        auto out = photometric_loss_forward_terms(r, t, lambda_dssim, clamp);
+        ctx->save_for_backward({r, t, std::get<1>(out)});
+        ctx->saved_data["lam"] = lambda_dssim; ctx->saved_data["clamp"] = clamp;
+        Tensor terms = std::get<0>(out), loss = std::get<2>(out);   // (the scalar in storage of its own, written by the same kernel)
+        ctx->mark_non_differentiable({terms});
+        ctx->set_materialize_grads(false);
+        return {loss, terms};
+    }
+    static torch::autograd::variable_list backward(torch::autograd::AutogradContext* ctx, torch::autograd::variable_list g)
+    {
+        if (!g[0].defined()) return {Tensor(), Tensor(), Tensor(), Tensor()};
+        static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("gsr::photometric_loss_backward", "").typed<decltype(photometric_loss_backward)>();
+        auto sv = ctx->get_saved_variables();
+        Tensor d = op.call(sv[0], sv[1], sv[2], g[0], ctx->saved_data["lam"].toDouble(), ctx->saved_data["clamp"].toBool());
+        return {d, Tensor(), Tensor(), Tensor()};
+    }
+};
+std::tuple<Tensor, Tensor> photometric_loss_terms(const Tensor& render, const Tensor& target, double lambda_dssim, bool clamp)
+{
+    auto r = PhotometricTermsFn::apply(render, target, lambda_dssim, clamp);
+    return {r[0], r[1]};
+}
+std::tuple<Tensor, Tensor> photometric_loss_terms_no_grad(const Tensor& render, const Tensor& target, double lambda_dssim, bool clamp)
+{
+    auto out = photometric_loss_forward_terms(render, target.device() == render.device() ? target : target.to(render.device()), lambda_dssim, clamp);
+    return {std::get<2>(out), std::get<0>(out)};
 }
 Tensor photometric_loss_no_grad(const Tensor& render, const Tensor& target, double lambda_dssim, bool clamp)
 {
@@ -695,7 +767,7 @@ TORCH_LIBRARY(gsr, m)
     m.def("rasterize_forward(Tensor means3D, Tensor sh, Tensor colors_precomp, Tensor opacities, Tensor scales, Tensor rotations, "
           "Tensor cov3D_precomp, Tensor sh_rest, Tensor viewmatrix, Tensor projmatrix, Tensor campos, Tensor bg, Tensor points_transform, "
           "int image_height, int image_width, float tanfovx, float tanfovy, float scale_modifier, int sh_degree, bool raw_params, "
-          "bool prefiltered, bool debug, Tensor prepared, int[] batch_first_block, int view_id=0) -> (Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)");
+          "bool prefiltered, bool debug, Tensor prepared, int[] batch_first_block, int view_id=0, int extras=0) -> (Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)");
     m.def("rasterize_backward(Tensor means3D, Tensor sh, Tensor colors_precomp, Tensor opacities, Tensor scales, Tensor rotations, "
           "Tensor cov3D_precomp, Tensor sh_rest, Tensor viewmatrix, Tensor projmatrix, Tensor campos, Tensor bg, Tensor points_transform, "
           "Tensor geom, Tensor image, Tensor binning, Tensor meta, Tensor grad_color, Tensor grad_depth, Tensor grad_alpha, "
@@ -713,12 +785,13 @@ TORCH_LIBRARY(gsr, m)
           "int image_height, int image_width, float tanfovx, float tanfovy, float scale_modifier, int sh_degree, bool raw_params, "
           "bool prefiltered, bool debug, bool cam_grad, Tensor[] adam_m, Tensor[] adam_v, float[] adam_lr, float beta1, float beta2, "
           "float eps, int step, Tensor prepared, Tensor next_viewmatrix, Tensor next_projmatrix, Tensor next_campos, int next_height, "
-          "int next_width, float next_tanfovx, float next_tanfovy, Tensor next_points_transform, int next_sh_degree, Tensor adam_commit, Tensor[] densify_stats, int[] batch_first_block, int view_id=0) -> "
-          "(Tensor, Tensor, Tensor, Tensor, Tensor)");
+          "int next_width, float next_tanfovx, float next_tanfovy, Tensor next_points_transform, int next_sh_degree, Tensor adam_commit, Tensor[] densify_stats, int[] batch_first_block, int view_id=0, int extras=0) -> "
+          "(Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)");
     m.def("mark_visible(Tensor means3D, Tensor viewmatrix, Tensor projmatrix) -> Tensor");
     m.def("photometric_loss_forward(Tensor render, Tensor target, float lambda_dssim, bool clamp) -> (Tensor, Tensor)");
     m.def("photometric_loss_backward(Tensor render, Tensor target, Tensor workspace, Tensor grad_loss, float lambda_dssim, bool clamp) -> Tensor");
     m.def("photometric_loss(Tensor render, Tensor target, float lambda_dssim, bool clamp) -> Tensor");
+    m.def("photometric_loss_terms(Tensor render, Tensor target, float lambda_dssim, bool clamp) -> (Tensor, Tensor)");
     m.def("adam_step(Tensor(a!)[] params, Tensor[] grads, Tensor(b!)[] exp_avg, Tensor(c!)[] exp_avg_sq, float[] lr, float beta1, "
           "float beta2, float eps, int step) -> ()");
     m.def("pose_step(Tensor(a!) delta, Tensor(b!) exp_avg, Tensor(c!) exp_avg_sq, Tensor d_xf, Tensor base, Tensor(d!) xf, float lr, "
@@ -750,10 +823,12 @@ TORCH_LIBRARY_IMPL(gsr, CUDA, m)   // the dispatch key of HIP tensors on a ROCm 
     m.impl("psnr", &psnr);
     m.impl("rasterize", &rasterize_forward_only);
     m.impl("photometric_loss", &photometric_loss_no_grad);
+    m.impl("photometric_loss_terms", &photometric_loss_terms_no_grad);
 }
 
 TORCH_LIBRARY_IMPL(gsr, Autograd, m)
 {
     m.impl("rasterize", &rasterize);
     m.impl("photometric_loss", &photometric_loss);
+    m.impl("photometric_loss_terms", &photometric_loss_terms);
 }

@@ -70,3 +70,13 @@ def fused_photometric_loss_terms(render: torch.Tensor, target: torch.Tensor, lam
     if render.device.type != "cuda":
         raise RuntimeError("fused_photometric_loss: tensors must be on a ROCm/HIP device (no CPU fallback)")
     return _FusedPhotometricTerms.apply(render, target, lambda_dssim, clamp)
+
+
+def fused_photometric_loss_report(render: torch.Tensor, target: torch.Tensor, lambda_dssim: float = 0.2, clamp: bool = True):
+    """(loss, terms): the differentiable loss and the six-float vector {loss, mean SSIM, mean L1, loss_rgb = (1 - lambda) mean L1,
+    loss_dssim = 1 - mean SSIM, loss_depth = 0} that the same finishing kernel wrote -- the whole return dict of `Loss.forward`
+    (/root/reference/trainer/losses.py:128-136) from one dispatcher call; autograd node in the extension (PhotometricTermsFn),
+    no gradient materialised for the vector.  Extension binding only."""
+    if render.device.type != "cuda":
+        raise RuntimeError("fused_photometric_loss: tensors must be on a ROCm/HIP device (no CPU fallback)")
+    return E.load().photometric_loss_terms(render, target, float(lambda_dssim), bool(clamp))

@@ -306,7 +306,7 @@ def _ecpu():
 
 def _rasterize_ext(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, rs, sh_rest, raw_params,
                    fused_adam, points_transform, prepared=None, prepare_next=None, next_points_transform=None, densify_stats=None,
-                   batch_first_block=None, fused_adam_deferred=False, view_id=0):
+                   batch_first_block=None, fused_adam_deferred=False, view_id=0, extras=0):
     """torch.ops.gsr.rasterize: empty tensors stand for None; the camera tensors of the settings tuple are ordinary inputs
     (their gradients are produced when one of them requires grad)."""
     ops = E.load()
@@ -365,15 +365,19 @@ def _rasterize_ext(means3D, means2D, sh, colors_precomp, opacities, scales, rota
             0.0 if nx is None else float(nx.tanfovx), 0.0 if nx is None else float(nx.tanfovy),
             e if (nx is None or next_points_transform is None) else next_points_transform.to(dev),
             -1 if nx is None else int(nx.sh_degree), _ecpu() if commit is None else commit,
-            [] if densify_stats is None else list(densify_stats), [] if nb <= 1 else [int(x) for x in batch_first_block], int(view_id))
+            [] if densify_stats is None else list(densify_stats), [] if nb <= 1 else [int(x) for x in batch_first_block], int(view_id), int(extras))
     if not rs.debug:
         out = ops.rasterize(*args)
-        return out if prepare_next is not None else out[:4]
+        if extras:       # (color, radii, depth, alpha, clamped colour, visibility bytes)
+            return out[:4] + (out[5], out[6])
+        return out[:5] if prepare_next is not None else out[:4]
     # raster_settings.debug = True: what the public module does -- on an error in the native forward, dump the arguments to
     # snapshot_fw.dump for offline inspection and re-raise (the reference always passes debug=False, gaussian_model_ht.py:821)
     try:
         out = ops.rasterize(*args)
-        return out if prepare_next is not None else out[:4]
+        if extras:
+            return out[:4] + (out[5], out[6])
+        return out[:5] if prepare_next is not None else out[:4]
     except Exception:
         torch.save([a.detach().cpu() if torch.is_tensor(a) else a for a in args[:24]], "snapshot_fw.dump")
         print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
@@ -392,7 +396,7 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
 def rasterize_gaussians_raw(means3D, means2D, features_dc, features_rest, opacity_logit, log_scales, rotations_raw,
                             raster_settings, fused_adam=None, points_transform=None, prepared=None, prepare_next=None,
                             next_points_transform=None, densify_stats=None, batch_first_block=None, fused_adam_deferred=False,
-                            view_id=0):
+                            view_id=0, extras=0):
     """Extension ("next" row f-2): rasterize straight from HTGaussianModel's raw parameters (_xyz, _features_dc,
     _features_rest, _opacity, _scaling, _rotation; /root/reference/scene/gaussian_model_ht.py:74-82) with the
     activations of :49-65,128-133,176-188 fused into the HIP kernels; gradients are w.r.t. the raw tensors.
@@ -430,12 +434,17 @@ def rasterize_gaussians_raw(means3D, means2D, features_dc, features_rest, opacit
     independent single-image fits of stage A, /root/reference/trainer/ht3dgs_trainer.py:697-698).
 
     view_id = the caller's id of the frame shown (non-zero, the same whenever the same frame is rendered; 0 = none): speed only --
-    the forward blend's balanced placement recognises the frame by it instead of by its pose (include/gsr.h GsrForwardArgs::view_id)."""
+    the forward blend's balanced placement recognises the frame by it instead of by its pose (include/gsr.h GsrForwardArgs::view_id).
+
+    extras (extension binding; not together with prepare_next): bit 0 adds the CLAMPED colour image -- `clamp(color, 0, 1)`, written by
+    the blend kernel, differentiable like torch.clamp -- and bit 1 the visibility bytes `radii > 0` (uint8 [N], written by the
+    preprocess) to the returned tuple: (color, radii, depth, alpha, clamped, visible) -- what the reference's render wrapper derives
+    with a torch launch each (gaussian_model_ht.py:883, :905)."""
     if not E.use_ctypes():
         return _rasterize_ext(means3D, means2D, features_dc, None, opacity_logit, log_scales, rotations_raw, None, raster_settings,
                               features_rest, True, fused_adam, points_transform, prepared, prepare_next, next_points_transform,
-                              densify_stats, batch_first_block, fused_adam_deferred, view_id)
-    if prepared is not None or prepare_next is not None or densify_stats is not None or batch_first_block is not None or fused_adam_deferred:
+                              densify_stats, batch_first_block, fused_adam_deferred, view_id, extras)
+    if prepared is not None or extras or prepare_next is not None or densify_stats is not None or batch_first_block is not None or fused_adam_deferred:
         raise RuntimeError("prepared / prepare_next / densify_stats / batch_first_block / fused_adam_deferred are served by the PyTorch extension binding only")
     e = torch.Tensor([])
     return _RasterizeGaussians.apply(means3D, means2D, features_dc, e, opacity_logit, log_scales, rotations_raw, e,

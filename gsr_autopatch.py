@@ -136,12 +136,18 @@ def loss_forward(self, rgb_pred, rgb_gt, depth_pred=None, depth_gt=None, rgb_los
             raise RuntimeError("gsr_autopatch.loss_forward: needs a [C,H,W] image on the GPU")
         return orig(self, rgb_pred, rgb_gt, depth_pred, depth_gt, rgb_loss_type, **kwargs)
     raw = getattr(rgb_pred, "_gsr_raw", None)      # the patched render's un-clamped colour output (render_fused below), valid while
-    if raw is not None and raw[1] == rgb_pred._version and raw[0].shape == rgb_pred.shape:     # nobody wrote into the clamped image
-        loss, ssim_v, l1_v = loss_mod.fused_photometric_loss_terms(raw[0], rgb_gt, lambda_dssim, clamp=True)  # clamp fused: same value
+    fused_clamp = raw is not None and raw[1] == rgb_pred._version and raw[0].shape == rgb_pred.shape     # nobody wrote into the clamped image
+    src = raw[0] if fused_clamp else rgb_pred
+    if _ext_binding() and os.environ.get("GSR_AUTOPATCH_LOSS_REPORT", "1") != "0":
+        # one dispatcher call: the finishing kernel wrote every entry of the returned dict (loss_rgb, loss_dssim, a zero loss_depth);
+        # the entries are views of its six-float result -- no torch kernel per term, no zero fills in the backward
+        loss, terms = loss_mod.fused_photometric_loss_report(src, rgb_gt, lambda_dssim, clamp=fused_clamp)
+        rgb_full_loss, dssim_loss, zero_depth = terms[3], terms[4], terms[5]
     else:
-        loss, ssim_v, l1_v = loss_mod.fused_photometric_loss_terms(rgb_pred, rgb_gt, lambda_dssim, clamp=False)
-    rgb_full_loss = (1.0 - lambda_dssim) * l1_v
-    dssim_loss = 1.0 - ssim_v
+        loss, ssim_v, l1_v = loss_mod.fused_photometric_loss_terms(src, rgb_gt, lambda_dssim, clamp=fused_clamp)
+        rgb_full_loss = (1.0 - lambda_dssim) * l1_v
+        dssim_loss = 1.0 - ssim_v
+        zero_depth = None
     if lambda_depth != 0.0 and depth_pred is not None and depth_gt is not None:
         depth_gt = depth_gt.to(rgb_pred.device)
         depth_pred[depth_pred < 0.02] = 0.02
@@ -149,8 +155,13 @@ def loss_forward(self, rgb_pred, rgb_gt, depth_pred=None, depth_gt=None, rgb_los
         depth_loss = self.get_depth_loss(depth_pred.squeeze(), depth_gt.squeeze())
         loss = loss + lambda_depth * depth_loss
     else:
-        depth_loss = torch.zeros((), device=rgb_pred.device)
+        depth_loss = zero_depth if zero_depth is not None else torch.zeros((), device=rgb_pred.device)
     return {'loss': loss, 'loss_rgb': rgb_full_loss, 'loss_dssim': dssim_loss, 'loss_depth': depth_loss}
+
+
+def _ext_binding() -> bool:
+    E = importlib.import_module("3dgs_hierarchical_training_amd._ext")
+    return not E.use_ctypes()
 
 
 # ---- the visibility mask of the patched render: boolean-mask statements without their host synchronisations ------------------------
@@ -358,12 +369,20 @@ def render_fused(self, viewpoint_camera, scaling_modifier=1.0, invert_bg_color=F
         #  0.40-0.42 ms per step; 0.90 against 0.98 ms at 1 M)
         if xyz.shape[0] >= int(os.environ.get("GSR_AUTOPATCH_DEFERRED_MIN_N", "0")):
             deferred = opt.deferred_ready({"xyz": xyz, "f_dc": f_dc, "f_rest": f_rest, "opacity": opacity, "scaling": scaling, "rotation": rotation})
-    image_raw, radii, depth, alpha = R.rasterize_gaussians_raw(xyz, screenspace_points, f_dc, f_rest, opacity, scaling, rotation,
-                                                               settings, points_transform=M, fused_adam=opt if deferred else None,
-                                                               fused_adam_deferred=deferred, view_id=_view_id(viewpoint_camera, g))
-    image = image_raw.clamp(0, 1)
+    if _ext_binding() and os.environ.get("GSR_AUTOPATCH_EXTRAS", "1") != "0":
+        # the clamped image and the visibility bytes come out of the kernels that hold the values (the blend's epilogue, the preprocess):
+        # no torch launch for `clamp(0, 1)` / `radii > 0`
+        image_raw, radii, depth, alpha, image, vis8 = R.rasterize_gaussians_raw(
+            xyz, screenspace_points, f_dc, f_rest, opacity, scaling, rotation, settings, points_transform=M, fused_adam=opt if deferred else None,
+            fused_adam_deferred=deferred, view_id=_view_id(viewpoint_camera, g), extras=3)
+        visible = vis8.view(torch.bool) if vis8.numel() == radii.numel() else radii > 0
+    else:
+        image_raw, radii, depth, alpha = R.rasterize_gaussians_raw(xyz, screenspace_points, f_dc, f_rest, opacity, scaling, rotation,
+                                                                   settings, points_transform=M, fused_adam=opt if deferred else None,
+                                                                   fused_adam_deferred=deferred, view_id=_view_id(viewpoint_camera, g))
+        image = image_raw.clamp(0, 1)
+        visible = radii > 0
     image._gsr_raw = (image_raw, image._version)       # lets the patched Loss.forward fuse this clamp into the loss kernels
-    visible = radii > 0
     if os.environ.get("GSR_AUTOPATCH_LAZY_MASK", "1") != "0":
         visible = LazyMask(visible)            # (the trainer's boolean-mask statistics statement without its host synchronisations)
     return {"image": image, "depth": depth, "alpha": alpha, "viewspace_points": screenspace_points,

@@ -111,6 +111,12 @@ typedef struct GsrForwardArgs {
      * points_transform within "view_pose_tol_e6" of the previous render's -- the reference keeps an identity camera and moves the
      * points, gaussian_model_ht.py:135-148, and steps the pose after every render, ht3dgs_trainer.py:162-166). */
     int64_t view_id;
+    /* ---- round 5: two results the reference's render wrapper derives with a torch launch each (gaussian_model_ht.py:883, :905), written
+     * by kernels that hold the values anyway.  NULL = not wanted.
+     *   out_color_clamped [3,H,W] (a batch: [B,3,H,W]): clamp(out_color, 0, 1), by the forward blend;
+     *   visible [N] bytes: radii > 0, by the preprocess -- NOT written by a forward that takes a `prepared` buffer (no preprocess runs). */
+    float* out_color_clamped;
+    uint8_t* visible;
 } GsrForwardArgs;
 
 typedef struct GsrForwardOut {
@@ -357,6 +363,12 @@ int gsr_loss_forward_batched(const float* render, const float* target, int32_t i
                              int32_t clamp01_render, void* workspace, float* out3, void* stream);
 int gsr_loss_backward_batched(const float* render, const float* target, int32_t images, int32_t C, int32_t H, int32_t W, float lambda_dssim,
                               int32_t clamp01_render, const void* workspace, const float* grad_loss, float* d_render, void* stream);
+/* gsr_loss_forward_batched with everything `Loss.forward` returns (/root/reference/trainer/losses.py:128-136) computed by the same
+ * finishing kernel: out6 = {loss, mean SSIM, mean L1, loss_rgb = (1 - lambda) mean L1, loss_dssim = 1 - mean SSIM, loss_depth = 0}
+ * -- the caller slices the vector instead of launching a torch kernel per term.  loss_copy (may be NULL): a second place for out6[0]
+ * (the binding's differentiable scalar lives in storage of its own). */
+int gsr_loss_forward_terms(const float* render, const float* target, int32_t images, int32_t C, int32_t H, int32_t W, float lambda_dssim,
+                           int32_t clamp01_render, void* workspace, float* out6, float* loss_copy, void* stream);
 
 /* ---- "next" row f-2: multi-tensor Adam step in one launch ------------------------------------------------
  * Same update rule as torch.optim.Adam(l, lr=0.0, eps=1e-15) of /root/reference/scene/gaussian_model_ht.py:275-289

@@ -447,3 +447,36 @@ def test_bookkeeping_kernels_equal_the_trainers_torch_statements():
             assert torch.allclose(gsr_autopatch.psnr_fused(a, b), want, rtol=0, atol=2e-4)
     same = torch.rand(3, 8, 8, device=dev)
     assert torch.isinf(gsr_autopatch.psnr_fused(same, same.clone())).all()       # mse 0 -> +inf, like the reference's expression
+
+
+def test_clamped_image_and_visibility_come_out_of_the_kernels():
+    """Round 5: `rasterize_gaussians_raw(..., extras=3)` also returns clamp(color, 0, 1) -- written by the forward blend's epilogue --
+    and the bytes radii > 0 -- written by the preprocess -- i.e. the two torch launches of the reference's wrapper
+    (gaussian_model_ht.py:883, :905).  Same values as torch's; a gradient put on the clamped image alone, on the raw image alone, or
+    on both reaches the parameters exactly as through `image_raw.clamp(0, 1)`."""
+    R = importlib.import_module("3dgs_hierarchical_training_amd.rasterizer")
+    dev = torch.device("cuda:0")
+    W, H, N = 300, 200, 15000
+    sc = parity.syn.make_scene(N, W, H, sh_degree=2, seed=8, posed=True)
+    st = ts.make_settings(sc, dev, 2, bg=torch.tensor([0.9, -0.2, 1.3]))         # a background outside [0, 1]: the clamp bites
+    g = torch.Generator().manual_seed(2)
+    w_raw, w_cl = torch.randn(3, H, W, generator=g).to(dev), torch.randn(3, H, W, generator=g).to(dev)
+    res = []
+    for fused in (True, False):
+        p = ts.GaussianParams(sc, dev, optimizer="torch")
+        with torch.no_grad():
+            p._features_dc.mul_(3.0)                                             # colours beyond 1 as well
+        m2d = torch.zeros(N, 3, device=dev, requires_grad=True)
+        if fused:
+            raw, radii, depth, alpha, clamped, vis8 = R.rasterize_gaussians_raw(p._xyz, m2d, p._features_dc, p._features_rest, p._opacity, p._scaling,
+                                                                               p._rotation, st, extras=3)
+            assert vis8.dtype == torch.uint8 and torch.equal(vis8.view(torch.bool), radii > 0)
+            assert torch.equal(clamped, raw.detach().clamp(0, 1)) and float(clamped.max()) == 1.0 and bool((raw > 1).any())
+        else:
+            raw, radii, depth, alpha = R.rasterize_gaussians_raw(p._xyz, m2d, p._features_dc, p._features_rest, p._opacity, p._scaling, p._rotation, st)
+            clamped = raw.clamp(0, 1)
+        ((clamped * w_cl).sum() + (raw * w_raw).sum()).backward()
+        res.append({k: getattr(p, k).grad.clone() for k in RAW} | {"m2d": m2d.grad.clone(), "raw": raw.detach().clone()})
+    assert torch.equal(res[0]["raw"], res[1]["raw"])
+    for k in list(RAW) + ["m2d"]:
+        assert _rel(res[0][k], res[1][k]) < 1e-5, (k, _rel(res[0][k], res[1][k]))

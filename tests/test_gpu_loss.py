@@ -40,3 +40,30 @@ def test_fused_loss_golden(golden_dir):
     ref = (1 - lam) * float(g["l1"]) + lam * (1 - float(g["ssim"]))
     out = loss_mod.fused_photometric_loss(a, b, lam, clamp=False)
     assert abs(float(out) - ref) < 1e-5
+
+
+@pytest.mark.parametrize("lam", [0.2, 0.0])
+def test_loss_report_is_the_reference_dict_from_one_forward(lam):
+    """Round 5: `photometric_loss_terms` returns the differentiable loss and the six-float vector {loss, mean SSIM, mean L1,
+    loss_rgb = (1 - lambda) mean L1, loss_dssim = 1 - mean SSIM, loss_depth = 0} written by the same finishing kernel -- every entry
+    of the dict `Loss.forward` returns (/root/reference/trainer/losses.py:128-136) without a torch kernel per term; only `loss`
+    carries a gradient, and it is the gradient of `fused_photometric_loss`."""
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(11)
+    H, W = 97, 131
+    gt = torch.rand(3, H, W, generator=g).to(dev)
+    raw = (gt.cpu() + 0.3 * torch.randn(3, H, W, generator=g)).to(dev)
+    a = raw.clone().requires_grad_(True)
+    b = raw.clone().requires_grad_(True)
+    loss, terms = loss_mod.fused_photometric_loss_report(a, gt, lam, clamp=True)
+    ref, ssim_v, l1_v = loss_mod.fused_photometric_loss_terms(b, gt, lam, clamp=True)
+    assert tuple(terms.shape) == (6,) and loss.dim() == 0 and loss.requires_grad and not terms.requires_grad
+    assert float(loss) == float(ref) == float(terms[0])
+    assert float(terms[1]) == float(ssim_v) and float(terms[2]) == float(l1_v)
+    assert abs(float(terms[3]) - (1.0 - lam) * float(l1_v)) < 1e-7 and abs(float(terms[4]) - (1.0 - float(ssim_v))) < 1e-7 and float(terms[5]) == 0.0
+    (loss * 0.75).backward()
+    (ref * 0.75).backward()
+    assert torch.equal(a.grad, b.grad)
+    with torch.no_grad():
+        l2, t2 = loss_mod.fused_photometric_loss_report(raw, gt, lam, clamp=True)
+    assert float(l2) == float(loss) and torch.equal(t2, terms)
