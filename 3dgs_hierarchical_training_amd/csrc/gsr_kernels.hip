@@ -35,6 +35,14 @@
 #include "variants.h"   // the non-default blend kernels (A/B measurements; csrc/variants.hip)
 #endif
 
+#ifndef GSR_K9_UNROLL
+#define GSR_K9_UNROLL 2
+#endif
+#ifndef GSR_K9_PREFETCH
+#define GSR_K9_PREFETCH 2      // stream elements (16 B of each moment) per thread that k_preprocess_bwd requests in front of its derivative chain.
+                               // Measured at 1 M (same-box A/B, two boxes): 0 -> 2: 320 / 331 -> 308 / 315 us and 332 / 321 -> 328 / 318 us; 3, 4, 6: 362 - 381 us --
+                               // the PREP kernel stands at 167 VGPRs with 2 (three waves per SIMD, what its LDS tile allows anyway) and drops to two waves beyond
+#endif
 namespace gsr {
 
 // ------------------------------------------------------------------------------------------------
@@ -2235,9 +2243,14 @@ __device__ __forceinline__ void adam_rows(const float* s_g, int stride, int col0
 //  from there, so that the update stream does not fetch the parameter rows a second time: 311-313 us against 300-318 box to box
 //  at 1 M, 305 against 261-289 for eight batched stage-A models -- the second fetch is served by L2 / the 256 MB infinity cache,
 //  the registers cost more than it does)
-template <bool KEEP>
+// KP > 0: the moments of the thread's first KP stream elements were loaded at the TOP of the kernel (pm / pv), underneath the
+// float64 derivative chain (round 5: the kernel is held to three waves per SIMD by its LDS tile, so ~90 VGPRs per thread sit
+// idle -- they carry the loads the stream would otherwise only issue after the chain)
+constexpr int kAdamPrefetch = GSR_K9_PREFETCH;
+template <bool KEEP, int KP = 0>
 __device__ __forceinline__ void adam_rows_lin(float* s_g, int total, float* __restrict__ p, float* __restrict__ m,
-                                              float* __restrict__ v, int tid, float step_size, float bc2, int grp, const AdamDev& ad)
+                                              float* __restrict__ v, int tid, float step_size, float bc2, int grp, const AdamDev& ad,
+                                              const float4* pm = nullptr, const float4* pv = nullptr)
 {
     float4* p4 = reinterpret_cast<float4*>(p);
     float4* m4 = reinterpret_cast<float4*>(m);
@@ -2248,8 +2261,26 @@ __device__ __forceinline__ void adam_rows_lin(float* s_g, int total, float* __re
     float4* mo4 = reinterpret_cast<float4*>(mo);
     float4* vo4 = reinterpret_cast<float4*>(vo);
     if ((((uintptr_t)m | (uintptr_t)v | (uintptr_t)po | (uintptr_t)mo | (uintptr_t)vo) & 15) == 0) {
-#pragma unroll 2
-        for (int q = tid; q < total / 4; q += kPreThreads) {
+        int q0 = tid;
+        if constexpr (KP > 0) {
+#pragma unroll
+            for (int k = 0; k < KP; k++) {
+                const int q = tid + k * kPreThreads;
+                if (q < total / 4) {
+                    float4 pp = p4[q], mm = pm[k], vv = pv[k];
+                    const float4 g = g4[q];
+                    adam_one(pp.x, g.x, mm.x, vv.x, ad.b1, ad.b2, ad.eps, step_size, bc2);
+                    adam_one(pp.y, g.y, mm.y, vv.y, ad.b1, ad.b2, ad.eps, step_size, bc2);
+                    adam_one(pp.z, g.z, mm.z, vv.z, ad.b1, ad.b2, ad.eps, step_size, bc2);
+                    adam_one(pp.w, g.w, mm.w, vv.w, ad.b1, ad.b2, ad.eps, step_size, bc2);
+                    nt_store4(po4 + q, pp); nt_store4(mo4 + q, mm); nt_store4(vo4 + q, vv);
+                    if (KEEP) g4[q] = pp;
+                }
+            }
+            q0 = tid + KP * kPreThreads;
+        }
+#pragma unroll GSR_K9_UNROLL
+        for (int q = q0; q < total / 4; q += kPreThreads) {
             float4 pp = p4[q], mm = nt_load4(m4 + q), vv = nt_load4(v4 + q);
             const float4 g = g4[q];
             adam_one(pp.x, g.x, mm.x, vv.x, ad.b1, ad.b2, ad.eps, step_size, bc2);
@@ -2364,6 +2395,18 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, in
     float* s_rest = s_sh + kPreThreads * 3;
     const bool lin = shs && shs_rest && cp.M == 16 && vec_ok(shs + (size_t)base * 3, nG * 3) &&
                      vec_ok(shs_rest + (size_t)base * NRL, nG * NRL);   // block-uniform
+    // the f_rest group's moments, first kAdamPrefetch elements of this thread's share of the update stream: requested NOW
+    float4 pf_m[kAdamPrefetch > 0 ? kAdamPrefetch : 1], pf_v[kAdamPrefetch > 0 ? kAdamPrefetch : 1];
+    bool pf_ok = false;
+    if constexpr (ADAM && kAdamPrefetch > 0) {
+        if (lin && nG == kPreThreads && ad.m[2] && (((uintptr_t)ad.m[2] | (uintptr_t)ad.v[2]) & 15) == 0) {   // (block-uniform; whole blocks only)
+            pf_ok = true;
+            const float4* m4 = reinterpret_cast<const float4*>(ad.m[2] + (size_t)base * NRL);
+            const float4* v4 = reinterpret_cast<const float4*>(ad.v[2] + (size_t)base * NRL);
+#pragma unroll
+            for (int k = 0; k < kAdamPrefetch; k++) { pf_m[k] = nt_load4(m4 + tid + k * kPreThreads); pf_v[k] = nt_load4(v4 + tid + k * kPreThreads); }
+        }
+    }
     if (lin) {
         stage_in_lin<3>(s_dc, shs + (size_t)base * 3, nG, tid);
         if (DEG > 0) stage_in_lin<NRL>(s_rest, shs_rest + (size_t)base * NRL, nG, tid);
@@ -2539,8 +2582,13 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, in
         const int rrow = cp.M * 3 - 3;
         if (lin) {
             adam_rows_lin<(PREP >= 0)>(s_dc, nG * 3, const_cast<float*>(shs) + b * 3, ad.m[1] + b * 3, ad.v[1] + b * 3, tid, ad.step_size[1], ad.inv_bc2s[1], 1, ad);
-            if (DEG > 0 || ad.m[2])   // (degree 0, moments known to be zero: the group's update is the identity -- GsrFusedAdam)
-                adam_rows_lin<(PREP >= 0)>(s_rest, nG * NRL, const_cast<float*>(shs_rest) + b * NRL, ad.m[2] + b * NRL, ad.v[2] + b * NRL, tid, ad.step_size[2], ad.inv_bc2s[2], 2, ad);
+            if (DEG > 0 || ad.m[2]) {   // (degree 0, moments known to be zero: the group's update is the identity -- GsrFusedAdam)
+                if (kAdamPrefetch > 0 && pf_ok)
+                    adam_rows_lin<(PREP >= 0), kAdamPrefetch>(s_rest, nG * NRL, const_cast<float*>(shs_rest) + b * NRL, ad.m[2] + b * NRL, ad.v[2] + b * NRL, tid,
+                                                              ad.step_size[2], ad.inv_bc2s[2], 2, ad, pf_m, pf_v);
+                else
+                    adam_rows_lin<(PREP >= 0)>(s_rest, nG * NRL, const_cast<float*>(shs_rest) + b * NRL, ad.m[2] + b * NRL, ad.v[2] + b * NRL, tid, ad.step_size[2], ad.inv_bc2s[2], 2, ad);
+            }
             if (PREP < 0) return;
             // ---- next-view tail ("prepare in backward", GsrNextView): this block holds the UPDATED parameters of its 128
             // Gaussians -- the small groups in the owners' registers, the SH rows in the LDS tile -- so it runs the forward
