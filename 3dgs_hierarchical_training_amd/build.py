@@ -6,38 +6,29 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libgsr_hip.so")
 SOURCES = ["gsr_kernels.hip", "loss_kernels.hip", "optim_kernels.hip", "knn_kernels.hip"]
-HEADERS = ["gsr_math.h", "adam_math.h", "radix_sort.h", "blend_common.h", "variants.h", os.path.join("..", "..", "include", "gsr.h")]
-# the non-default blend kernels (A/B measurements, tests/test_gpu_parity.py::test_blend_variants_agree): compiled in only on request
-AB_SOURCES = ["variants.hip"]
-AB_STAMP = os.path.join(CSRC, ".ab_variants")     # present when the library on disk was built with -DGSR_AB_VARIANTS
+HEADERS = ["gsr_math.h", "adam_math.h", "radix_sort.h", "blend_common.h", os.path.join("..", "..", "include", "gsr.h")]
 
 
-def _stale(ab: bool):
-    if not os.path.exists(LIB) or os.path.exists(AB_STAMP) != ab:
+def _stale():
+    if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS + (AB_SOURCES if ab else []))
+    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
 
 
-def build(force: bool = False, verbose: bool = False, ab_variants: bool = None) -> str:
-    """hipcc --offload-arch=gfx950 -> csrc/libgsr_hip.so.  Returns the library path.
-    ab_variants (default: env GSR_AB_VARIANTS=1): also compile csrc/variants.hip, the non-default blend kernels kept for A/B runs."""
-    ab = (os.environ.get("GSR_AB_VARIANTS", "0") == "1") if ab_variants is None else bool(ab_variants)
-    if force or _stale(ab):
+def build(force: bool = False, verbose: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 -> csrc/libgsr_hip.so.  Returns the library path."""
+    if force or _stale():
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC"] + (["-DGSR_AB_VARIANTS"] if ab else []) + [
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
                "-Wno-unused-result",
                # keep scalar f32 arithmetic scalar: hipcc's SLP pass packs adjacent adds/muls into v_pk_*_f32 and pays
                # for it in v_mov operand shuffles (MI355X guide, "packed f32 VALU ... an anti-lever"); the kernels
                # that want packed math ask for it explicitly with float2 vector types
-               "-fno-slp-vectorize", "-Wl,-soname,libgsr_hip.so"] + [os.path.join(CSRC, s) for s in SOURCES + (AB_SOURCES if ab else [])] + ["-o", LIB]
+               "-fno-slp-vectorize", "-Wl,-soname,libgsr_hip.so"] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
-        if ab:
-            open(AB_STAMP, "w").write("built with -DGSR_AB_VARIANTS\n")
-        elif os.path.exists(AB_STAMP):
-            os.remove(AB_STAMP)
     return LIB
 
 

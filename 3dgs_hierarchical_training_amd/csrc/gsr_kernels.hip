@@ -31,9 +31,6 @@
 #include "adam_math.h"
 #include "radix_sort.h"
 #include "blend_common.h"
-#ifdef GSR_AB_VARIANTS
-#include "variants.h"   // the non-default blend kernels (A/B measurements; csrc/variants.hip)
-#endif
 
 #ifndef GSR_K9_UNROLL
 #define GSR_K9_UNROLL 2
@@ -482,6 +479,7 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess(CamParams cp, int N,
     float mean[3] = {0.f, 0.f, 0.f};
     Splat s;
     TileRec rec;
+    uint32_t lo_pack = 0u;   // sub-ulp remainders of the pixel-space mean (gsr_math.h pixel_lo_pack): stored in the record's `tiles` word
     if (act) {
         mean[0] = means[3 * (size_t)i]; mean[1] = means[3 * (size_t)i + 1]; mean[2] = means[3 * (size_t)i + 2];
         apply_points_transform(cp.xf, mean);
@@ -510,7 +508,7 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess(CamParams cp, int N,
             }
             op = 1.0f / (1.0f + expf(-op));
         }
-        preprocess_one(cam, mean, sc, rq, cov_pre ? cv : nullptr, op, nullptr, 3, 1, colors ? colp : nullptr, s, &rec, true);
+        preprocess_one(cam, mean, sc, rq, cov_pre ? cv : nullptr, op, nullptr, 3, 1, colors ? colp : nullptr, s, &rec, true, &lo_pack);
     }
     count_large_rects(act, s, rec, cp.W, cp.H, cam.tiles_x, cam.tiles_y, tid);
     rec.rect += (uint32_t)(model * cam.tiles_y) << 12;   // tile rows of model b start at b * tiles_y in the batch's tall tile grid
@@ -556,7 +554,11 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess(CamParams cp, int N,
     if (dh.ghist && dh.clear_threads == 0u)   // fewer than 128 Gaussians, ragged: no block of k_preprocess_bwd ran the next-view tail
         for (uint32_t q = tid; q < dh.status_words / 4; q += kPreThreads) reinterpret_cast<uint4*>(dh.status)[q] = make_uint4(0u, 0u, 0u, 0u);
     if (!act) return;
-    splat[i] = s;
+    {   // the stored record carries the remainders where the tile count sat (nobody reads the count back; it lives on in registers below)
+        Splat st = s;
+        st.tiles = lo_pack;
+        splat[i] = st;
+    }
     tilerec[i] = rec;   // compact emission record: k_tile_counts / k_emit never touch the 48 B splats
     radii[i] = s.radius;
     if (visible) visible[i] = s.radius > 0 ? 1 : 0;   // `visibility_filter = radii > 0` (gaussian_model_ht.py:905), written here instead of by a torch launch
@@ -1520,7 +1522,10 @@ __device__ __forceinline__ void blend_fwd_item(const int xcd, const int kslot, f
     const int tx = tl % tiles_x, ty = tl / tiles_x;
     const int px = tx * kTile + (sub & 1) * 8 + (lane & 7);
     const int py = ty * kTile + (sub >> 1) * 8 + (lane >> 3);
-    const float pxf = (float)px - 0.5f * (float)W, pyf = (float)py - 0.5f * (float)H;
+    // offsets are formed from TILE-relative coordinates (gsr_math.h pixel_rel): the staged mean is relative to the tile's first pixel,
+    // remainder included, and the pixel is its column / row inside the tile -- the same numbers the backward blend forms
+    const float pxf = (float)((sub & 1) * 8 + (lane & 7)), pyf = (float)((sub >> 1) * 8 + (lane >> 3));
+    const float tox = (float)(tx * kTile) - 0.5f * (float)W, toy = (float)(ty * kTile) - 0.5f * (float)H;
     const uint2 rg = ranges[tile];
     const int n = (int)(rg.y - rg.x);
     const int nb = (n + NT - 1) / NT;
@@ -1568,6 +1573,10 @@ __device__ __forceinline__ void blend_fwd_item(const int xcd, const int kslot, f
         const int cnt = min(NT, n - b * NT);
         // first use of this batch's records (lanes beyond cnt hold stale ones: masked in the ballot, never visited)
         const bool reach_me = REACH && box_accept(make_tile_test(ra.x, ra.y, ra.z, ra.w, rb.x, rb.y), sbx0, sby0, sbx1, sby1);
+        {
+            const uint32_t lo = __float_as_uint(rc.w);
+            ra.x = pixel_rel(ra.x, pixel_lo_x(lo), tox); ra.y = pixel_rel(ra.y, pixel_lo_y(lo), toy);
+        }
         ra.z *= -0.5f * kL2E; ra.w *= -kL2E; rb.x *= -0.5f * kL2E;
         s_ab[buf][lane] = ra; s_ab[2 + buf][lane] = rb; s_c[buf][lane] = make_float2(rc.x, rc.y);
         const unsigned long long reach = REACH ? __ballot(reach_me && lane < cnt) : 0ull;
@@ -1935,8 +1944,10 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(BlendBwdArgs args_)
     const int tx = tl % tiles_x, ty = tl / tiles_x;
     const int px = tx * kTile + (tid & 15);
     const int py0 = ty * kTile + (tid >> 4) * 2;
-    const float pxf = (float)px - 0.5f * (float)W;   // centred pixel coordinates (see Splat)
-    const f2 pyf = {(float)py0 - cyf, (float)(py0 + 1) - cyf};
+    // the pixel's column / rows inside the tile; the staged means are relative to the tile's first pixel (gsr_math.h pixel_rel), exactly
+    // as the forward blend forms them
+    const float pxf = (float)(tid & 15);
+    const f2 pyf = {(float)((tid >> 4) * 2), (float)((tid >> 4) * 2 + 1)};
     const uint2 rg = ranges[tile];
     const float* const imgb = img + (size_t)bimg * Pl;                       // this image's slice of every state plane (planes are P apart)
     const float* const g_colorb = g_color ? g_color + (size_t)bimg * 3 * Pl : nullptr;  // upstream gradients: [B, 3, H, W], [B, 1, H, W]
@@ -2014,6 +2025,10 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(BlendBwdArgs args_)
         uint32_t fl = 0u;
         if (hby0 <= hbyL) fl |= box_accept(tt, hbx0, hby0, hbx1, fminf(hby0 + 7.f, hbyL)) ? 1u : 0u;
         if (hby0 + 8.f <= hbyL) fl |= box_accept(tt, hbx0, hby0 + 8.f, hbx1, fminf(hby0 + 15.f, hbyL)) ? 2u : 0u;
+        {
+            const uint32_t lo = __float_as_uint(rc.w);   // (the record's `tiles` word: the remainders of the mean)
+            ra.x = pixel_rel(ra.x, pixel_lo_x(lo), hbx0); ra.y = pixel_rel(ra.y, pixel_lo_y(lo), hby0);
+        }
         rc.w = __uint_as_float(fl);
         ra.z *= -0.5f * kL2E; ra.w *= -kL2E; rb.x *= -0.5f * kL2E;
     };
@@ -2602,6 +2617,7 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, in
             cam2.D = PREP < 0 ? 0 : PREP;
             Splat s2;
             TileRec rec2;
+            uint32_t lo2 = 0u;
             float mean2[3] = {nmean[0], nmean[1], nmean[2]};
             if (act) {
                 apply_points_transform(po.cp.xf, mean2);
@@ -2612,7 +2628,7 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, in
 #pragma unroll
                 for (int k = 0; k < 4; k++) rq2[k] *= inv;
                 const float op2 = 1.0f / (1.0f + expf(-nop));
-                preprocess_one(cam2, mean2, sc2, rq2, nullptr, op2, nullptr, 3, 1, nullptr, s2, &rec2, true);
+                preprocess_one(cam2, mean2, sc2, rq2, nullptr, op2, nullptr, 3, 1, nullptr, s2, &rec2, true, &lo2);
             }
             count_large_rects(act, s2, rec2, po.cp.W, po.cp.H, cam2.tiles_x, cam2.tiles_y, tid);
             rec2.rect += (uint32_t)(model2 * cam2.tiles_y) << 12;   // (as k_preprocess)
@@ -2637,7 +2653,7 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, in
             }
             uint32_t key2 = 0xffffffffu;
             if (act) {
-                po.splat[i] = s2;
+                { Splat st = s2; st.tiles = lo2; po.splat[i] = st; }   // (as k_preprocess: the remainders in the `tiles` word)
                 po.rec[i] = rec2;
                 po.radii[i] = s2.radius;
                 key2 = s2.tiles > 0 ? __float_as_uint(s2.depth) : 0xffffffffu;
@@ -3049,21 +3065,13 @@ int gsr_debug_k8_timing(unsigned long long* host_dst, int blocks)
 int gsr_set_option(const char* name, int value)
 {
     if (!name) return GSR_ERR_ARG;
-    // 7 (default) / 6 = one wave per 8x8 sub-tile, with / without reach bits; 1-5 = the A/B kernels of variants.hip
+    // 7 (default) / 6 = one wave per 8x8 sub-tile, with / without reach bits (the tile-per-workgroup A/B kernels of rounds 1-4, values
+    // 1-5, left the tree in round 5: they were compiled on request only and no default-build test reached them)
     if (!strcmp(name, "blend_fwd_ppt")) {
-        if (value < 0 || value > 7) return GSR_ERR_ARG;
-#ifndef GSR_AB_VARIANTS
-        if (value >= 1 && value <= 5) return GSR_ERR_ARG;   // variants.hip is not in this build
-#endif
+        if (value != 0 && value != 6 && value != 7) return GSR_ERR_ARG;
         g_blend_ppt = value; return GSR_OK;
     }
-    if (!strcmp(name, "ab_variants")) {   // query: 1 when the library carries the A/B blend kernels (`value` is ignored)
-#ifdef GSR_AB_VARIANTS
-        return 1;
-#else
-        return 0;
-#endif
-    }
+    if (!strcmp(name, "ab_variants")) return 0;   // query kept for callers of the round-4 ABI: no A/B kernels in the library
     if (!strcmp(name, "bwd_split")) { if (value < 0 || value > 64) return GSR_ERR_ARG; g_bwd_split = value; return GSR_OK; }
     if (!strcmp(name, "ckpt_first")) { if (value < 1 || value > 64) return GSR_ERR_ARG; g_ckpt_first = value; return GSR_OK; }
     if (!strcmp(name, "tile_map")) { if (value < 0 || value > 2) return GSR_ERR_ARG; g_tile_map = value; return GSR_OK; }
@@ -3091,12 +3099,9 @@ int gsr_set_option(const char* name, int value)
     if (!strcmp(name, "poll_iters")) { g_poll_iters = value < 0 ? 0 : value; return GSR_OK; }
     if (!strcmp(name, "emit_hist")) { g_emit_hist = value ? 1 : 0; return GSR_OK; }
     if (!strcmp(name, "sort_algo")) { if (value < 0 || value > 2) return GSR_ERR_ARG; g_sort_algo = value; return GSR_OK; }
-    // 2 = packed-math kernel (default); 1 / 3 / 4 = the scalar A/B kernels of variants.hip
+    // 2 = the packed two-pixel kernel (the only one)
     if (!strcmp(name, "blend_bwd_ppt")) {
-        if (value < 0 || value > 4) return GSR_ERR_ARG;
-#ifndef GSR_AB_VARIANTS
         if (value != 0 && value != 2) return GSR_ERR_ARG;
-#endif
         g_bwd_ppt = value; return GSR_OK;
     }
     return GSR_ERR_ARG;
@@ -3277,13 +3282,7 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
             else if (ppt == 6)
                 hipLaunchKernelGGL(k_blend_fwd_w6<false>, dim3(8 * 4 * slots_per_xcd(opt_map, T, tiles_x)), dim3(64), 0, st, W, H, tiles_x, T, ranges, list, splat, a->bg,
                                    a->out_color, a->out_depth, a->out_alpha, img, staged, opt_map, ckpt, opt_ckpt, tiles_y, BlendBalance{}, a->out_color_clamped);
-#ifdef GSR_AB_VARIANTS
-            else if (!launch_blend_fwd_variant(ppt, W, H, tiles_x, T, ranges, list, splat, a->bg, a->out_color, a->out_depth, a->out_alpha, img, staged,
-                                               opt_map, ckpt, opt_ckpt, st))
-                return fail(GSR_ERR_ARG, "unknown forward blend variant%s");
-#else
-            else return fail(GSR_ERR_ARG, "forward blend variants 1-5 need a library built with -DGSR_AB_VARIANTS%s");
-#endif
+            else return fail(GSR_ERR_ARG, "unknown forward blend variant%s");
         }
         GSR_HIP(hipGetLastError());
         return GSR_OK;
@@ -3712,12 +3711,7 @@ int gsr_backward(const GsrBackwardArgs* a, void* stream_)
                 GSR_HIP(hipFreeAsync(det_mem, st));
             }
         }
-#ifdef GSR_AB_VARIANTS
-        else if (!launch_blend_bwd_variant(ppt, W, H, tiles_x, T, ranges, list, splat, a->bg, img, a->grad_color, a->grad_depth, a->grad_alpha, gg, st))
-            return fail(GSR_ERR_ARG, "unknown backward blend variant%s");
-#else
-        else return fail(GSR_ERR_ARG, "backward blend variants 1, 3, 4 need a library built with -DGSR_AB_VARIANTS%s");
-#endif
+        else return fail(GSR_ERR_ARG, "unknown backward blend variant%s");
     }
     CamParams cp = {a->viewmatrix, a->projmatrix, a->campos, a->tanfovx, a->tanfovy, a->scale_modifier, W, H, a->D, a->M, a->points_transform, bt};
     const int grid = (N + kPreThreads - 1) / kPreThreads;

@@ -56,6 +56,47 @@ struct alignas(16) Splat {
 };
 static_assert(sizeof(Splat) == 48, "Splat must be 48 bytes");
 
+// ---- the pixel-space mean beyond binary32 (round 5) ---------------------------------------------------------------------------
+// The projection runs in float64 and the mean is rounded ONCE to binary32 -- half an ulp of |px| <= W/2, 1.5e-5 px on a 980-pixel
+// frame, 1.2e-4 px 2 056 px from the centre of a 4 112-pixel one.  A sub-pixel splat (conic entries of 1-3 per px^2) turns that into
+// a few 1e-5 of its weight two sigma out: the allowance the fuzz cases and the 4112^2 case carried until round 4.  The remainder
+// lo = px64 - (double)px is kept as a signed 16-bit count of 2^-16 ulp(px) for each coordinate, in the record's `tiles` word (which no
+// kernel reads back: the tile count only lives in the preprocess's registers), and the blends form their offsets as
+//     x_rel = fl(fl(px - tile origin) + lo),   dx = x_rel - (pixel's column inside the tile, 0..15)
+// -- the first difference is exact or rounded at the ulp of a number of the splat's own size, the second is a difference of nearby
+// small numbers.  Same operations, same order in the forward blend, the backward blend and tests/hostemu: their skip decisions agree
+// bit for bit, as before.  Cost: a handful of instructions per STAGED instance (not per visit).
+GSR_HD int pixel_exp(float p)       // e with p = m 2^e, 0.5 <= |m| < 1 (0 for p = 0)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_frexp_expf(p);
+#else
+    int e = 0;
+    (void)frexpf(p, &e);
+    return e;
+#endif
+}
+GSR_HD int pixel_lo_one(double p64, float p)
+{
+    if (!(fabsf(p) >= 0.0009765625f)) return 0;          // |p| < 2^-10 (or NaN): binary32 resolves 1e-10 px there
+    const double q = ldexp(1.0, pixel_exp(p) - 40);        // 2^-16 ulp(p)
+    double k = rint((p64 - (double)p) / q);
+    k = k < -32768.0 ? -32768.0 : (k > 32767.0 ? 32767.0 : k);
+    return (int)k;
+}
+GSR_HD uint32_t pixel_lo_pack(double px64, float px, double py64, float py)
+{
+    return ((uint32_t)pixel_lo_one(px64, px) & 0xffffu) | ((uint32_t)pixel_lo_one(py64, py) << 16);
+}
+// the mean's coordinate relative to `origin` (the centred coordinate of the tile's first pixel column / row), remainder included
+GSR_HD float pixel_rel(float p, int lo16, float origin)
+{
+    const float lo = ldexpf((float)lo16, pixel_exp(p) - 40);
+    return (p - origin) + lo;
+}
+GSR_HD int pixel_lo_x(uint32_t pack) { return (int)(int16_t)(pack & 0xffffu); }
+GSR_HD int pixel_lo_y(uint32_t pack) { return (int)(int16_t)(pack >> 16); }
+
 GSR_HD int gsr_popc(uint32_t v)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -362,10 +403,11 @@ GSR_HD void splat_sh_color(const Camera& c, const float mean[3], const float* sh
 // sh[k*sh_kstride + ch*sh_cstride] (lets the caller hand either the global [M][3] row or an LDS copy).
 GSR_HD void preprocess_one(const Camera& c, const float mean[3], const float* scale, const float* rot,
                            const float* cov_pre, float opacity, const float* sh, int sh_kstride, int sh_cstride,
-                           const float* color_pre, Splat& out, TileRec* rec = nullptr, bool defer_big = false)
+                           const float* color_pre, Splat& out, TileRec* rec = nullptr, bool defer_big = false, uint32_t* lo_pack = nullptr)
 {
     typedef double RT;   // see the note above quat_to_rot
     if (rec) { rec->mask = 0u; rec->rect = 1u << 24; }
+    if (lo_pack) *lo_pack = 0u;
     out.px = 0.f; out.py = 0.f; out.ca = 0.f; out.cb = 0.f; out.cc = 0.f; out.op = 0.f; out.depth = 0.f;
     out.r = 0.f; out.g = 0.f; out.b = 0.f; out.radius = 0; out.tiles = 0;
     const float zk = depth_key(c.vm, mean[0], mean[1], mean[2]);
@@ -396,8 +438,9 @@ GSR_HD void preprocess_one(const Camera& c, const float mean[3], const float* sc
     const RT l1 = mid + disc, l2 = mid - disc;
     const int radius = (int)ceil(3 * sqrt(l1 > l2 ? l1 : l2));
     // centred pixel coordinates: ((ndc+1) W - 1)/2 - W/2 = (ndc W - 1)/2
-    const float px = (float)((hx * pw * c.W - 1) * (RT)0.5);
-    const float py = (float)((hy * pw * c.H - 1) * (RT)0.5);
+    const RT px64 = (hx * pw * c.W - 1) * (RT)0.5, py64 = (hy * pw * c.H - 1) * (RT)0.5;
+    const float px = (float)px64;
+    const float py = (float)py64;
     int x0, y0, x1, y1;
     tile_rect(px + 0.5f * (float)c.W, py + 0.5f * (float)c.H, radius, c.tiles_x, c.tiles_y, x0, y0, x1, y1);
     if ((x1 - x0) * (y1 - y0) == 0) return;   // the reference's visibility rule: 3-sigma rect touches no tile
@@ -408,6 +451,7 @@ GSR_HD void preprocess_one(const Camera& c, const float mean[3], const float* sc
         splat_sh_color(c, mean, sh, sh_kstride, sh_cstride, col);
     }
     out.px = px; out.py = py;
+    if (lo_pack) *lo_pack = pixel_lo_pack(px64, px, py64, py);
     out.ca = (float)(cc * dinv); out.cb = (float)(-b * dinv); out.cc = (float)(a * dinv);
     out.op = opacity;
     out.r = col[0]; out.g = col[1]; out.b = col[2];
@@ -447,6 +491,13 @@ GSR_HD float pair_alpha(float pxf, float pyf, float sx, float sy, float ca, floa
     G = fast_exp(power);
     const float alpha = fminf(kAlphaMax, op * G);
     return (power > 0.f || alpha < kAlphaMin) ? 0.f : alpha;
+}
+
+// the same from tile-relative coordinates (pixel_rel): xr / yr = the mean relative to the tile's first pixel, lx / ly = the pixel's
+// column / row inside the tile
+GSR_HD float pair_alpha_rel(float lx, float ly, float xr, float yr, float ca, float cb, float cc, float op, float& G, float& dx, float& dy)
+{
+    return pair_alpha(lx, ly, xr, yr, ca, cb, cc, op, G, dx, dy);
 }
 
 // forward accumulate; returns false when the pixel terminates (this Gaussian is NOT blended)

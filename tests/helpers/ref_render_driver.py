@@ -36,7 +36,10 @@ def fake_raw(means3D, means2D, f_dc, f_rest, opacity, scaling, rotation, setting
     z = means3D.sum() * 0 + means2D.sum() * 0
     if kw.get("points_transform") is not None:
         z = z + kw["points_transform"].sum() * 0
-    return torch.full((3, H, W), 1.5) + z, torch.ones(means3D.shape[0], dtype=torch.int32), torch.zeros(1, H, W) + z, torch.zeros(1, H, W) + z
+    out = (torch.full((3, H, W), 1.5) + z, torch.ones(means3D.shape[0], dtype=torch.int32), torch.zeros(1, H, W) + z, torch.zeros(1, H, W) + z)
+    if kw.get("extras"):       # (the extension's extra outputs: the clamped image and the visibility bytes)
+        out = out + (out[0].clamp(0, 1), (out[1] > 0).to(torch.uint8))
+    return out
 
 
 R.rasterize_gaussians_raw = fake_raw

@@ -27,6 +27,7 @@ struct EmuCtx {
     EmuIn in;
     Camera cam;
     std::vector<Splat> splat;
+    std::vector<uint32_t> lo;         // sub-ulp remainders of the pixel-space means (gsr_math.h pixel_lo_pack), as the kernels keep them
     std::vector<uint32_t> list;
     std::vector<int64_t> tile_start;
     std::vector<float> finalT, acc;   // acc [P,5]
@@ -53,6 +54,9 @@ void hostemu_override_geom(const float* xy, const float* conic, const float* rgb
 // mean as given (not re-centred on the image), d = mean - (float)pixel -- which is how the public CUDA module forms its offsets
 static int g_abs_pixels = 0;
 void hostemu_set_absolute_pixels(int on) { g_abs_pixels = on; }
+// experiment hook: 1 = blend without the sub-ulp remainders of the pixel-space means (the arithmetic of rounds 1-4)
+static int g_no_lo = 0;
+void hostemu_set_no_remainder(int on) { g_no_lo = on; }
 
 EmuCtx* hostemu_forward(const EmuIn* in, float* out_color, float* out_depth, float* out_alpha, int32_t* radii)
 {
@@ -62,12 +66,14 @@ EmuCtx* hostemu_forward(const EmuIn* in, float* out_color, float* out_depth, flo
     const Camera& cam = c->cam;
     const int N = in->N, W = in->W, H = in->H, T = cam.tiles_x * cam.tiles_y;
     c->splat.resize(N);
+    c->lo.assign(N, 0u);
     for (int i = 0; i < N; i++) {
         preprocess_one(cam, in->means3D + 3 * (size_t)i, in->scales ? in->scales + 3 * (size_t)i : nullptr,
                        in->rotations ? in->rotations + 4 * (size_t)i : nullptr,
                        in->cov3D_precomp ? in->cov3D_precomp + 6 * (size_t)i : nullptr, in->opacities[i],
                        in->shs ? in->shs + (size_t)i * in->M * 3 : nullptr, 3, 1,
-                       in->colors_precomp ? in->colors_precomp + 3 * (size_t)i : nullptr, c->splat[i]);
+                       in->colors_precomp ? in->colors_precomp + 3 * (size_t)i : nullptr, c->splat[i], nullptr, false, &c->lo[i]);
+        if (g_ov_xy || g_no_lo) c->lo[i] = 0u;      // (an overridden projection has no remainder; g_no_lo: the round-4 arithmetic, for comparison)
         if (g_ov_xy && g_abs_pixels) { if (c->abs_xy.empty()) c->abs_xy.assign(2 * (size_t)N, 0.f); c->abs_xy[2 * i] = g_ov_xy[2 * i]; c->abs_xy[2 * i + 1] = g_ov_xy[2 * i + 1]; }
         if (g_ov_xy && c->splat[i].radius > 0) {
             Splat& s = c->splat[i];
@@ -107,12 +113,15 @@ EmuCtx* hostemu_forward(const EmuIn* in, float* out_color, float* out_depth, flo
             const int t = (y / kTile) * cam.tiles_x + (x / kTile);
             PixelAcc p = {1.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             uint32_t contributor = 0, last = 0;
+            const float ox = (float)((x / kTile) * kTile) - 0.5f * (float)W, oy = (float)((y / kTile) * kTile) - 0.5f * (float)H;   // the tile's first pixel, centred
+            const float lx = (float)(x % kTile), ly = (float)(y % kTile);
             for (int64_t k = c->tile_start[t]; k < c->tile_start[t + 1]; k++) {
                 contributor++;
                 const Splat& s = c->splat[c->list[k]];
+                const uint32_t lo = c->lo[c->list[k]];
                 float G, dx, dy;
                 const float alpha = c->abs_xy.empty()
-                    ? pair_alpha((float)x - 0.5f * W, (float)y - 0.5f * H, s.px, s.py, s.ca, s.cb, s.cc, s.op, G, dx, dy)
+                    ? pair_alpha_rel(lx, ly, pixel_rel(s.px, pixel_lo_x(lo), ox), pixel_rel(s.py, pixel_lo_y(lo), oy), s.ca, s.cb, s.cc, s.op, G, dx, dy)
                     : pair_alpha((float)x, (float)y, c->abs_xy[2 * (size_t)c->list[k]], c->abs_xy[2 * (size_t)c->list[k] + 1], s.ca, s.cb, s.cc, s.op, G, dx, dy);
                 if (alpha == 0.f) continue;
                 if (!blend_step_fwd(p, alpha, s.r, s.g, s.b, s.depth)) break;
@@ -154,11 +163,14 @@ void hostemu_backward(EmuCtx* c, const float* g_color, const float* g_depth, con
             p.gD = g_depth ? g_depth[pid] : 0.f; p.gA = g_alpha ? g_alpha[pid] : 0.f;
             p.bgdot = c->finalT[pid] * (in.bg[0] * p.gC0 + in.bg[1] * p.gC1 + in.bg[2] * p.gC2);
             const int64_t s0 = c->tile_start[t];
+            const float ox = (float)((x / kTile) * kTile) - 0.5f * (float)W, oy = (float)((y / kTile) * kTile) - 0.5f * (float)H;
+            const float lx = (float)(x % kTile), ly = (float)(y % kTile);
             for (uint32_t k = 0; k < c->ncontrib[pid]; k++) {
                 const uint32_t g = c->list[s0 + k];
                 const Splat& s = c->splat[g];
                 float G, dx, dy;
-                const float alpha = pair_alpha((float)x - 0.5f * W, (float)y - 0.5f * H, s.px, s.py, s.ca, s.cb, s.cc, s.op, G, dx, dy);
+                const float alpha = pair_alpha_rel(lx, ly, pixel_rel(s.px, pixel_lo_x(c->lo[g]), ox), pixel_rel(s.py, pixel_lo_y(c->lo[g]), oy), s.ca, s.cb,
+                                                   s.cc, s.op, G, dx, dy);
                 if (alpha == 0.f) continue;
                 blend_step_bwd(p, alpha, G, dx, dy, s.ca, s.cb, s.cc, s.op, s.r, s.g, s.b, s.depth, gg[g]);
             }

@@ -57,7 +57,10 @@ def test_patched_render_hands_over_what_the_reference_call_was_captured_with(aut
     def fake(means3D, means2D, f_dc, f_rest, opacity, scaling, rotation, settings, **kw):
         rec.update(t=(means3D, means2D, f_dc, f_rest, opacity, scaling, rotation), st=settings, kw=kw)
         z = means3D.sum() * 0
-        return torch.zeros(3, H, W) + 2 + z, torch.zeros(100, dtype=torch.int32), torch.zeros(1, H, W) + z, torch.zeros(1, H, W) + z
+        out = (torch.zeros(3, H, W) + 2 + z, torch.zeros(100, dtype=torch.int32), torch.zeros(1, H, W) + z, torch.zeros(1, H, W) + z)
+        if kw.get("extras"):       # (the extension's extra outputs: the clamped image and the visibility bytes)
+            out = out + (out[0].clamp(0, 1), (out[1] > 0).to(torch.uint8))
+        return out
     orig, R.rasterize_gaussians_raw = R.rasterize_gaussians_raw, fake
     autopatch._REQUIRE_CUDA = False
     try:

@@ -56,7 +56,7 @@ def test_more_than_65536_tiles():
     Forward tolerance 4e-5 instead of 1e-5: the blend works on binary32 pixel coordinates, and 2 056 px from the image centre
     one ulp is 2.4e-4 px -- a relative error of a * dx * ulp ~ 1e-4 in a splat's weight three sigma out (the public module
     keeps ABSOLUTE binary32 pixel coordinates, twice that).  The float64 oracle does not round there."""
-    _run_case(30000, 4112, 4112, 1, True, "sh", (0.2, 0.1, 0.0), fwd_atol=4e-5)
+    _run_case(30000, 4112, 4112, 1, True, "sh", (0.2, 0.1, 0.0))
 
 
 # BASELINE.json configs at FULL size, straight against the oracle (it is OpenMP C: seconds on the GPU box's host).
@@ -122,26 +122,20 @@ def test_parity_color_loss_only(case):
     _run_case(*case, color_only=True)
 
 
-def _needs_ab_variants(lib, ppt):
-    """The non-default blend kernels (forward 1-5, backward 1 / 3 / 4) live in csrc/variants.hip, compiled into the library only with
-    -DGSR_AB_VARIANTS (GSR_AB_VARIANTS=1 python 3dgs_hierarchical_training_amd/build.py); the default build carries 6 and 7."""
-    if ppt in (1, 2, 3, 4, 5) and lib.gsr_set_option(b"ab_variants", 0) != 1:
-        pytest.skip("library built without -DGSR_AB_VARIANTS: the A/B blend kernels are not in it")
-
-
-@pytest.mark.parametrize("ppt", [1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("ppt", [6, 7])
 def test_blend_variants_agree(ppt):
+    """The forward blend with (7, default) and without (6) its sub-tile reach bits -- a conservative skip -- against the oracle.  (The
+    tile-per-workgroup / lane-mask A/B kernels of rounds 1-4 left the tree in round 5: they needed a special build and no default-build
+    test reached them.)"""
     import importlib
     L = importlib.import_module("3dgs_hierarchical_training_amd._lib")
     lib = L.load()
-    _needs_ab_variants(lib, ppt)
     try:
         assert lib.gsr_set_option(b"blend_fwd_ppt", ppt) == 0
-        assert lib.gsr_set_option(b"blend_bwd_ppt", min(ppt, 4) if ppt <= 5 else 2) == 0
         _run_case(20000, 330, 250, 3, True, "sh", (0.2, 0.3, 0.1))
     finally:
         lib.gsr_set_option(b"blend_fwd_ppt", 0)
-        lib.gsr_set_option(b"blend_bwd_ppt", 0)
+    assert lib.gsr_set_option(b"blend_fwd_ppt", 3) != 0 and lib.gsr_set_option(b"blend_bwd_ppt", 1) != 0 and lib.gsr_set_option(b"ab_variants", 0) == 0
 
 
 @pytest.mark.parametrize("hint", [0, 1000, 1 << 26], ids=["exact-flow", "overflow-rerun", "roomy"])
@@ -273,16 +267,18 @@ def test_hip_takes_the_host_emulations_decisions(N, W, H, posed):
     # seconds even at 4 M).  Up to the metric's own workload (1 M @980x545) EVERY pixel keeps its upstream gradient; the two larger
     # frames flip a last-bit decision on ~10 pixels of two million (printed below), each worth one whole contribution of gradient
     # to a handful of Gaussians, so there a forward-only first pass finds those pixels and the compared backward runs without them
-    all_kept = N <= 300000 or (N == 1000000 and W * H <= 980 * 545)
+    # (round 5: at EVERY size a forward-only first pass finds the pixels on which the two took different last-bit decisions -- v_exp_f32
+    #  against exp2f -- and the compared backward runs without their upstream gradient; their number is printed and bounded:
+    #  0 / 2 / 1 / 9 / 1 of 76 800 ... 2 073 600 pixels with the tile-relative offsets of round 5, 0 / 0 / 1 / 9 / 1 before)
     grads = parity.upstream_grads(H, W, seed=2)
-    if not all_kept:
-        e0 = parity.hostemu_run(o, None)["fwd"]
-        h0 = hip_runner.run_hip(kw, None)["fwd"]
-        zm = max(1.0, float(np.abs(e0[2]).max()))
-        flip = (np.abs(e0[0].astype(np.float64) - h0[0]).max(0) > 2e-6) | (np.abs(e0[3].astype(np.float64) - h0[3])[0] > 2e-6) | \
-               (np.abs(e0[2].astype(np.float64) - h0[2])[0] / zm > 2e-6)
-        print(f"[parity] HIP vs host emulation {N} @{W}x{H}: {int(flip.sum())} pixels with a flipped last-bit decision carry no upstream gradient")
-        assert flip.mean() <= 2e-5
+    e0 = parity.hostemu_run(o, None)["fwd"]
+    h0 = hip_runner.run_hip(kw, None)["fwd"]
+    zm = max(1.0, float(np.abs(e0[2]).max()))
+    flip = (np.abs(e0[0].astype(np.float64) - h0[0]).max(0) > 2e-6) | (np.abs(e0[3].astype(np.float64) - h0[3])[0] > 2e-6) | \
+           (np.abs(e0[2].astype(np.float64) - h0[2])[0] / zm > 2e-6)
+    print(f"[parity] HIP vs host emulation {N} @{W}x{H}: {int(flip.sum())} pixels with a flipped last-bit decision carry no upstream gradient")
+    assert flip.mean() <= 2e-5
+    if flip.any():
         keep = (~flip).astype(np.float32)
         grads = tuple(g * keep for g in grads)
     emu = parity.hostemu_run(o, grads)
@@ -540,7 +536,7 @@ def test_fuzz_shapes_fovs_scales(case):
     tiny = W * H < 4000       # one pixel is a quarter of a per mille or more: no share bounds
     rep, out, ref = parity.oracle_case(o, lambda g: hip_runner.run_hip(kw, g), (gc, gd, ga), f"fuzz {case}",
                                        ambig_max_frac=1.0 if tiny else None, unresolved_max_frac=1.0 if tiny else None,
-                                       fwd_atol=2.5e-5 if sharp else None)
+                                       fwd_atol=2.5e-5 if (sharp and i == 13) else None)
     # (sub-pixel footprints: the binary32 arithmetic itself -- tests/hostemu, fixed order -- leaves two `scales` entries and one
     #  `rotations` entry of case 13 (257 Gaussians, 166 degree field of view, scale_modifier 0.25) 1e-3 off element-wise; the float
     #  atomics' order moves a third one across the bar in a few runs of a hundred, so a sharp case may have four such entries)
@@ -899,26 +895,24 @@ def test_backward_twice_over_one_render():
         assert (a - b).abs().max().item() <= 2e-5 * a.abs().max().item() + 1e-12
 
 
-def test_sign_encoded_forward_is_bit_identical_with_the_lane_mask_kernel():
-    """k_blend_fwd_w6 (default) represents a finished pixel by the sign of its transmittance instead of a lane mask;
-    every decision and every accumulation of a live pixel is the same instruction sequence, so the images are EQUAL."""
+def test_reach_bits_change_nothing_in_the_forward_image():
+    """k_blend_fwd_w6<true> (default) skips the instances whose exact box test fails on the wave's 8x8 block; <false> visits them all:
+    a conservative skip, the images are EQUAL."""
     import importlib
     import hip_runner
     L = importlib.import_module("3dgs_hierarchical_training_amd._lib")
     lib = L.load()
-    _needs_ab_variants(lib, 5)
     sc = parity.syn.make_scene(300000, 980, 545, sh_degree=3, seed=5, posed=True)
     kw = parity.scene_kwargs(sc, "sh", bg=(0.3, 0.2, 0.1))
     outs = {}
     try:
-        for v in (5, 6, 7):
+        for v in (6, 7):
             assert lib.gsr_set_option(b"blend_fwd_ppt", v) == 0
             outs[v] = hip_runner.run_hip(kw)["fwd"]
     finally:
         lib.gsr_set_option(b"blend_fwd_ppt", 0)
-    for v in (6, 7):      # 7 (default) adds the sub-tile reach bits: a conservative skip, the same image again
-        for name, a, b in zip(("color", "radii", "depth", "alpha"), outs[5], outs[v]):
-            assert np.array_equal(a, b), (v, name, int((a != b).sum()), float(np.abs(a.astype(np.float64) - b).max()))
+    for name, a, b in zip(("color", "radii", "depth", "alpha"), outs[6], outs[7]):
+        assert np.array_equal(a, b), (name, int((a != b).sum()), float(np.abs(a.astype(np.float64) - b).max()))
 
 
 def test_deterministic_backward_debug_mode():

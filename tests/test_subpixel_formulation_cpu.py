@@ -1,10 +1,15 @@
-"""is the 2.5e-5 forward allowance of the sub-pixel-splat fuzz cases a property of binary32, or of THIS build's
-formulation?  The kernels project in float64, round once, and keep pixel-space means relative to the image centre.  The public CUDA
-module works in binary32 throughout and forms d = mean - pixel from ABSOLUTE pixel coordinates.  Here that formulation is stated
-in plain numpy float32 (projection, cov2D, low-pass, conic, ndc2Pix -- one rounding per operation, no fused multiply-adds), pushed
-through the same sequential host blend (tests/hostemu with absolute pixel coordinates) and measured against the float64 oracle on
-the very cases that carry the allowance, next to the kernels' own arithmetic (tests/hostemu as is).  If the public formulation
-stayed inside 1e-5 the kernels would have to change; it does not -- it is the less accurate of the two on every one of them."""
+"""Sub-pixel splats and binary32: what the kernels' formulation costs against the float64 oracle, next to the public CUDA module's.
+
+VERDICT r3 item 6b asked whether the 2.5e-5 forward allowance of the sub-pixel-splat fuzz cases was a property of binary32 or of THIS
+build's formulation; VERDICT r4 item 8 asked to retire it.  Round 5 did: the kernels project in float64, round the pixel-space mean
+once -- and now keep the sub-ulp remainder of that rounding (16 bits per coordinate, gsr_math.h pixel_lo_pack) and form their offsets
+from tile-relative coordinates (pixel_rel).  Here the public module's formulation (binary32 throughout, d = mean - pixel from ABSOLUTE
+pixel coordinates) is stated in plain numpy float32 and pushed through the same sequential host blend (tests/hostemu with absolute
+pixel coordinates), next to the kernels' own arithmetic (tests/hostemu as is) and to the kernels' arithmetic of rounds 1-4 (the
+remainder switched off), on the ten fuzz cases that carried the allowance.  Result: with the remainder nine of the ten are within
+5e-7 of the oracle (3e-6 without it, up to 3.8e-5 in the public formulation); the tenth -- case 13, 257 sub-pixel splats piled onto a
+few pixels by a 166-degree field of view -- stays at 1.3e-5 in all three: a hundred-odd non-saturating layers per pixel, binary32's
+accumulation (T *= 1 - alpha, C += c alpha T), not the coordinates.  It keeps a stated allowance (tests/test_gpu_parity.py)."""
 import ctypes as C
 
 import numpy as np
@@ -96,9 +101,19 @@ def test_public_binary32_formulation_is_no_more_accurate_on_sub_pixel_splats(cas
     finally:
         lib.hostemu_set_absolute_pixels(0)
         lib.hostemu_override_geom(None, None, None)
+    lib.hostemu_set_no_remainder(1)
+    try:
+        old = parity.hostemu_run(o)["fwd"][0].astype(np.float64)
+    finally:
+        lib.hostemu_set_no_remainder(0)
     e_ours = float((np.abs(ours - ref).max(0) * keep).max())
+    e_old = float((np.abs(old - ref).max(0) * keep).max())
     e_pub = float((np.abs(pub - ref).max(0) * keep).max())
-    print(f"[6b] case {case}: max |image - oracle| on unambiguous pixels: this build's arithmetic {e_ours:.2e}, public binary32 formulation {e_pub:.2e}")
-    assert e_ours <= 2.5e-5                                     # the allowance in force (tests/test_gpu_parity.py fuzz cases)
-    assert e_pub >= 0.9 * e_ours or e_pub > 1e-5, (e_ours, e_pub)   # the public formulation does not get inside 1e-5 where this one does not
+    print(f"[6b] case {case}: max |image - oracle| on unambiguous pixels: this build's arithmetic {e_ours:.2e} (without the remainder, rounds 1-4: "
+          f"{e_old:.2e}), public binary32 formulation {e_pub:.2e}")
+    if i == 13:        # the deep stack of non-saturating layers: binary32 accumulation, in every formulation
+        assert 1e-5 < e_ours <= 1.4e-5 and e_old <= 1.5e-5 and e_pub > 1e-5
+    else:
+        assert e_ours <= 1e-6 and e_ours <= e_old + 1e-9
+    assert e_pub >= e_ours, (e_ours, e_pub)                     # the public formulation is never the more accurate one
     o.close()
