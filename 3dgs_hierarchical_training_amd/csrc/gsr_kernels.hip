@@ -55,6 +55,8 @@ static int g_bwd_ppt = 0;
 // the HBM-bound kernel than the histogram kernel does on its own (1 M: +20 us against -8 us).  Both sides of the hand-over
 // evaluate the same predicate on N.
 static int g_prep_hist_max_n = 262144;
+static int g_small_sort9 = 1;   // smallest N for which a forward with its own preprocess sorts depths in three 9-bit passes (0 = only above prep_hist_max_n).
+                                // Measured (same-box A/B, tools/ab_130k.sh): depth sort 53 -> 45 us at 130 k, 44 -> 37 us at 20 k
 static inline bool prep_counts_digits(int N) { return N <= g_prep_hist_max_n; }
 static int g_poll_iters = 400000;   // bound of gsr_forward's busy-wait for R in units of ~50 ns (20 ms); 0 = event record + hipEventSynchronize instead
 static int g_emit_hist = 1;   // 1: k_emit counts the tile sort's digits (no histogram launch); 0: k_radix_ghist
@@ -3096,6 +3098,7 @@ int gsr_set_option(const char* name, int value)
     }
     if (!strcmp(name, "profile")) { g_profile = (value == 2 || value == 3) ? value : (value ? 1 : 0); g_profile_tick = 0; return GSR_OK; }
     if (!strcmp(name, "prep_hist_max_n")) { g_prep_hist_max_n = value; return GSR_OK; }
+    if (!strcmp(name, "small_sort9")) { if (value < 0) return GSR_ERR_ARG; g_small_sort9 = value; return GSR_OK; }
     if (!strcmp(name, "poll_iters")) { g_poll_iters = value < 0 ? 0 : value; return GSR_OK; }
     if (!strcmp(name, "emit_hist")) { g_emit_hist = value ? 1 : 0; return GSR_OK; }
     if (!strcmp(name, "sort_algo")) { if (value < 0 || value > 2) return GSR_ERR_ARG; g_sort_algo = value; return GSR_OK; }
@@ -3355,7 +3358,7 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
     const bool early_r = g_early_r && speculative && depth_onesweep;
     uint2* early_parts = early_r ? reinterpret_cast<uint2*>(a->prepared ? static_cast<uint8_t*>(a->prepared) + prep_layout(N).early : fs + L.early) : nullptr;
     // visible depth keys beyond the 27-bit window of the three-pass sort are counted whenever this forward MAY sort on it
-    const uint32_t early_window = N > g_prep_hist_max_n ? (1u << 27) - 1u : 0xffffffffu;
+    const uint32_t early_window = (N > g_prep_hist_max_n || (g_small_sort9 && !a->prepared && N >= g_small_sort9)) ? (1u << 27) - 1u : 0xffffffffu;
     if (a->prepared) {
         // "prepare in backward": the preceding gsr_backward already ran the preprocess of this render on the updated
         // parameters (k_preprocess_bwd<..., PREP>); its records, sort keys and tile records are taken from the hand-over buffer
@@ -3397,7 +3400,9 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
     // large models: three 9-bit passes over the 27-bit depth window (radix_sort.h); small ones keep the four 8-bit passes whose
     // digits the producer of the keys has counted (no histogram launch).  A caller whose depths left the window once stays on
     // the full sort.
-    bool wide_depth = depth_onesweep && g_depth_sort9 && !depth_hist_done && N > g_prep_hist_max_n;
+    // (round 5: a forward that runs its own preprocess launches a digit histogram anyway, so below the threshold too three 9-bit passes
+    //  behind it beat four 8-bit ones -- one latency-bound pass less; "small_sort9" = the smallest model that takes them, 0 = off)
+    bool wide_depth = depth_onesweep && g_depth_sort9 && !depth_hist_done && (N > g_prep_hist_max_n || (g_small_sort9 && N >= g_small_sort9));
     if (wide_depth) {
         std::lock_guard<std::mutex> lk(g_state_mutex);
         auto it = g_full_depth_sort.find(hint_key);

@@ -73,13 +73,16 @@ def usable_cpus():
 # of the process -- including the one that launches kernels -- for the rest of the 100 ms period (seen as 4-70 ms stalls of
 # single steps).  Respect an explicit OMP_NUM_THREADS of the caller.
 _CPUS, _CPU_QUOTA = usable_cpus()
-os.environ.setdefault("OMP_NUM_THREADS", str(_CPUS))
-os.environ.setdefault("MKL_NUM_THREADS", str(_CPUS))
+# (N ranks of one node share the quota: each builds its synthetic scene with its share of the threads -- eight teams of sixteen under a
+#  16-CPU quota would throttle one another's launching threads exactly as described above)
+_RANK_CPUS = max(1, _CPUS // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1)))
+os.environ.setdefault("OMP_NUM_THREADS", str(_RANK_CPUS))
+os.environ.setdefault("MKL_NUM_THREADS", str(_RANK_CPUS))
 
 import torch  # noqa: E402
 
 try:
-    torch.set_num_threads(min(torch.get_num_threads(), _CPUS))
+    torch.set_num_threads(min(torch.get_num_threads(), _RANK_CPUS))
 except Exception:
     pass
 
@@ -1017,7 +1020,7 @@ def main():
         pass
     pmc, pmc_src = {}, None
     if (N, W, H, deg, args.clustered) == (1_000_000, 980, 545, 3, False):
-        for name in ("r04_pmc_blend.json", "r03_pmc_blend.json", "r02_pmc_blend.json", "r01_pmc_blend.json"):
+        for name in ("r05_pmc_blend.json", "r04_pmc_blend.json", "r03_pmc_blend.json", "r02_pmc_blend.json", "r01_pmc_blend.json"):
             pmc_file = os.path.join(REPO, "profiles", name)
             if not os.path.exists(pmc_file):
                 continue

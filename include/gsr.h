@@ -290,6 +290,12 @@ int gsr_version(void);
  *                          render of the same frame (device-side cache of 128 frames per frame size, least recently used out; a
  *                          frame is recognised by GsrForwardArgs::view_id or, without one, by its pose; single renders through
  *                          the default kernel); 0 = dispatch order = tile order.  Same image either way
+ *   "small_sort9"          (default 1) smallest model for which a forward that runs its own preprocess sorts its depth keys in three
+ *                          9-bit passes over the 27-bit window instead of four 8-bit ones (it launches a digit histogram either way);
+ *                          0 = only models above 262 144 Gaussians.  Same order either way (a depth beyond the window is detected
+ *                          and sorted again on all 32 bits)
+ *   "early_r"              1 (default) = the host learns the instance count from the preprocess's per-block sums, published by
+ *                          the depth sort's first kernel, instead of from the scan behind sort + tile counts; 0 = from the scan
  *   "view_pose_tol_e6"     (default 2000 = 2e-3) without a view id a render belongs to the cached frame whose view matrix and
  *                          points_transform are within this, x 1e-6, of its own in every entry (the nearest such frame)
  *   "tile_map"             how tiles are dealt to the eight XCDs: 2 (default) = 2x2 blocks of tiles round-robin, 1 = single
