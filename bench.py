@@ -432,13 +432,6 @@ def posed_frames_leg(ts, lib, scene, settings, dev, steps, warmup, frames=8):
     W, H = int(settings.image_width), int(settings.image_height)
     gsr_autopatch.apply()
     try:
-        p = ts.GaussianParams(scene, dev, optimizer="torch")
-        r = refstub.StubRender(p, bg=tuple(float(x) for x in settings.bg.cpu()))
-        g = r.gaussians
-        gen = torch.Generator().manual_seed(4321)
-        g.P = [refstub.StubPose(torch.cat([0.02 * torch.randn(3, generator=gen), 0.03 * torch.randn(3, generator=gen)]).tolist() if f else [0.0] * 6, dev)
-               for f in range(frames)]
-        g.rotate_seq = True
         cams = [refstub.StubCamera(W, H, settings.tanfovx, settings.tanfovy, settings.viewmatrix, settings.projmatrix, settings.campos,
                                    uid=f, original_image=syn.target_image(W, H, seed=40 + f).to(dev)) for f in range(frames)]
 
@@ -448,25 +441,34 @@ def posed_frames_leg(ts, lib, scene, settings, dev, steps, warmup, frames=8):
         class _Loss:
             cfg = _Cfg()
         loss_obj = _Loss()
-        rng = random.Random(7)
-
-        def step(i):
-            f = rng.randrange(frames)
-            g.seq_idx = f
-            pkg = gsr_autopatch.render_fused(r, cams[f])
-            gsr_autopatch.loss_forward(loss_obj, pkg["image"], cams[f].original_image)["loss"].backward()
-            with torch.no_grad():
-                p.optimizer.step()
-                p.optimizer.zero_grad(set_to_none=True)
-                g.P[f].optimizer.step()                      # camera_optimizer[fidx].step(): the pose's bits change after every render
-                g.P[f].optimizer.zero_grad(set_to_none=True)
 
         def stats():
             out = (C.c_int64 * 4)()
             lib.gsr_debug_view_cache_stats(W, H, out)
-            return out[0], out[1]
+            return out[0], out[1], out[2]
 
         def measure(balance, by_uid):
+            # every mode trains ITS OWN copy of the model from the same start, with the same frame draws: the blend's time follows the
+            # model as it trains (on noise targets: the lists deepen), so only equal trajectories compare
+            p = ts.GaussianParams(scene, dev, optimizer="torch")
+            r = refstub.StubRender(p, bg=tuple(float(x) for x in settings.bg.cpu()))
+            g = r.gaussians
+            gen = torch.Generator().manual_seed(4321)
+            g.P = [refstub.StubPose(torch.cat([0.02 * torch.randn(3, generator=gen), 0.03 * torch.randn(3, generator=gen)]).tolist() if f else [0.0] * 6, dev)
+                   for f in range(frames)]
+            g.rotate_seq = True
+            rng = random.Random(7)
+
+            def step(i):
+                f = rng.randrange(frames)
+                g.seq_idx = f
+                pkg = gsr_autopatch.render_fused(r, cams[f])
+                gsr_autopatch.loss_forward(loss_obj, pkg["image"], cams[f].original_image)["loss"].backward()
+                with torch.no_grad():
+                    p.optimizer.step()
+                    p.optimizer.zero_grad(set_to_none=True)
+                    g.P[f].optimizer.step()                      # camera_optimizer[fidx].step(): the pose's bits change after every render
+                    g.P[f].optimizer.zero_grad(set_to_none=True)
             lib.gsr_set_option(b"blend_balance", balance)
             prev = os.environ.get("GSR_AUTOPATCH_VIEW_ID")
             os.environ["GSR_AUTOPATCH_VIEW_ID"] = "1" if by_uid else "0"
@@ -486,19 +488,20 @@ def posed_frames_leg(ts, lib, scene, settings, dev, steps, warmup, frames=8):
                     os.environ.pop("GSR_AUTOPATCH_VIEW_ID", None)
                 else:
                     os.environ["GSR_AUTOPATCH_VIEW_ID"] = prev
+            del p, r, g
             look = s1[0] - s0[0]
             return {"ms_per_step": 1e3 * sec, "blend_fwd_us": (1e3 * tot / cnt) if cnt else None, "blend_launches_timed": cnt,
-                    "view_cache_hit_rate": ((s1[1] - s0[1]) / look) if look else None}
+                    "view_cache_hit_rate": ((s1[1] - s0[1]) / look) if look else None, "view_cache_entries_in_use": s1[2]}
         out = {"frames": frames, "steps": steps,
                "balance_off": measure(0, True), "balance_on_by_uid": measure(1, True), "balance_on_by_pose": measure(1, False)}
         lib.gsr_set_option(b"blend_balance", 1)
     finally:
         lib.gsr_set_option(b"blend_balance", 1)
         gsr_autopatch.remove()
-    del p
     out["note"] = ("identity camera for every frame, the pose through get_xyz (points_transform), torch.optim.Adam on the frame's six pose numbers "
                    "after every render, frames drawn at random; the pose's autograd chain (matrix exponential, 4x4 products) is torch's, as the "
-                   "reference's is lietorch's: its host time is in ms_per_step")
+                   "reference's is lietorch's: its host time is in ms_per_step; every mode trains its own copy of the model from the same start "
+                   "with the same frame draws (the blend's time follows the model as it trains)")
     return out
 
 
