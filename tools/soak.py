@@ -4,7 +4,10 @@ every 500 / 3000 steps, checking for non-finite parameters.  Needs a GPU:  gpuru
 round 2 runs the loop with the hand-over to the next view, as run_segments.py does; round 3: the model starts at SH degree 0 and is
 raised every 1 000 steps with the hand-over kept across the change, and a real `Densifier` collects its statistics inside the backward
 kernel and densifies / prunes every 500 steps on top of the random surgery; round 4, with the direct binning and the persistent backward
-blend: 40 000 steps at 1 M -> 2.95 M Gaussians in 72 s, 12 000 steps at 300 k in 9.0 s, no non-finite value, no hang)."""
+blend: 40 000 steps at 1 M in 72 s, 12 000 steps at 300 k in 9.0 s, no non-finite value, no hang; round 5, with the early instance count,
+the sub-ulp pixel remainders and the prefetched moment stream: 40 000 steps at 1 M (741 k Gaussians at the end) in 94 s on a slower box,
+12 000 steps at 300 k in 8.3 s; same-box A/B against the round-4 tree: the same trajectory -- Gaussian counts within 0.3 %, losses to
+three digits -- 8 000 steps at 1 M in 7.0 s against 7.6 s, 6 000 at 300 k in 4.0 s against 4.7 s: profiles/r05_soak.txt)."""
 import sys, time, importlib, torch
 sys.path.insert(0, '.')   # run from the repository root
 syn = importlib.import_module('3dgs_hierarchical_training_amd.synthetic')
