@@ -149,11 +149,12 @@ def test_tree_walked_by_four_processes_sharing_the_gpu():
     import sys
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "3dgs_hierarchical_training_amd", "run_segments.py"), "--backend", "gloo",
+    # round 5: the BARE command -- `run_segments.py --ranks 4` starts torch.distributed.run on itself (no launcher around it)
+    cmd = [sys.executable, os.path.join(root, "3dgs_hierarchical_training_amd", "run_segments.py"), "--ranks", "4", "--backend", "gloo",
            "--one-device", "--frames", "20", "--width", "320", "--height", "240", "--gt-gaussians", "60000", "--leaf-gaussians", "30000",
            "--leaf-iters", "20", "--phase1-iters", "3", "--phase2-iters", "6", "--stage-a", "20000", "150", "100"]
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     recs = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
