@@ -1037,6 +1037,7 @@ constexpr int kDbMaxTiles = 4096;
 constexpr int kDbCountWaves = 4;      // chunks per workgroup of k_chunk_counts (kEmitThreads / 64: balance_build shares the launch)
 struct DirectBin {
     int N, T, Tp /* T rounded up to 64 */, S, NC, G, Cg;
+    int NS, Ts, Tsp, slab_rows;   // round 5: the tile grid cut into NS slabs of slab_rows tile rows (Ts tiles, Tsp = Ts rounded up to 64); 1 slab = the whole frame
     uint16_t* M;        // [NC][Tp]  per-chunk tile counts -> exclusive prefixes inside the chunk's group
     uint32_t* GT;       // [G][Tp]   group totals -> absolute start of the group inside the tile's segment
     uint32_t* tbase;    // [T + 1]   tile bases (saturated at 2^32 - 1)
@@ -1115,7 +1116,7 @@ __global__ __launch_bounds__(kEmitThreads) void k_chunk_counts(DirectBin db, int
     const int nbuild = bb.hdr ? 8 : 0, c = (int)blockIdx.x - nbuild;
     if (c < 0) { balance_build(bb, (int)blockIdx.x); return; }
     // one workgroup per chunk: its four waves take the chunk's steps of 64 Gaussians in turn and count into ONE table (adds commute)
-    __shared__ uint32_t s_h[kDbMaxTiles / 2];   // two u16 counters per word (a chunk holds fewer than 65 536 Gaussians)
+    extern __shared__ uint32_t s_h[];           // [Tp / 2]: two u16 counters per word (a chunk holds fewer than 65 536 Gaussians)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < db.Tp / 2; i += kEmitThreads) s_h[i] = 0u;
     __syncthreads();
@@ -1260,15 +1261,22 @@ __device__ unsigned long long g_db_dbg[16];   // s_memtime ticks per part, summe
 #else
 #define DB_T(k) do { } while (0)
 #endif
+// SLAB (round 5, frames above kDbMaxTiles tiles): the tile grid is cut into db.NS slabs of whole tile rows and a chunk is walked by NS
+// waves, each with the tables of ITS slab in LDS and blind to every other tile: a small rect's mask is cut down to the slab's rows when
+// the record is loaded (whole tile rows: a contiguous bit range), a large rect is always walked outside the pair buffer (its count
+// inside a slab is not known without the walk) with its tiles tested against the slab.  Every tile belongs to one slab and the
+// chunks of a slab are the chunks of the frame, so the list is the same list.
+template <bool SLAB>
 __global__ __launch_bounds__(64) void k_chunk_scatter(DirectBin db, int W, int H, int tiles_x, int tiles_y,
                                                       const uint32_t* __restrict__ sorted_gid, const TileRec* __restrict__ sorted_rec,
                                                       const Splat* __restrict__ splat, uint32_t* __restrict__ list, uint2* __restrict__ ranges,
                                                       uint32_t cap)
 {
     extern __shared__ unsigned long long s_dyn[];
-    unsigned long long* const s_mask = s_dyn;                                  // [Tp]
-    uint32_t* const s_cnt = reinterpret_cast<uint32_t*>(s_dyn + db.Tp);       // [Tp]
-    uint32_t* const s_pair = s_cnt + db.Tp;                                    // [kDbPairs]
+    const int LT = SLAB ? db.Tsp : db.Tp;                                      // tiles this wave keeps tables for
+    unsigned long long* const s_mask = s_dyn;                                  // [LT]
+    uint32_t* const s_cnt = reinterpret_cast<uint32_t*>(s_dyn + LT);          // [LT]
+    uint32_t* const s_pair = s_cnt + LT;                                       // [kDbPairs]
     const int lane = threadIdx.x, b = (int)blockIdx.x;
     {   // the ranges: tile bases clipped to the list's capacity (an overflowing speculative launch is run again)
         const int t = b * 64 + lane;
@@ -1277,8 +1285,12 @@ __global__ __launch_bounds__(64) void k_chunk_scatter(DirectBin db, int W, int H
             ranges[t] = hi > lo ? make_uint2(lo, hi) : make_uint2(0u, 0u);   // (an empty tile reads (0, 0), as on the sort route)
         }
     }
-    const int per = (db.NC + 7) >> 3, c = (b & 7) * per + (b >> 3);
-    if ((b >> 3) >= per || c >= db.NC) return;
+    // XCD x = b & 7 owns the chunks [x per, (x + 1) per); a chunk's NS slab waves sit next to each other (they read the same records)
+    const int per = (db.NC + 7) >> 3, kk = b >> 3, c = (b & 7) * per + (SLAB ? kk / db.NS : kk), slab = SLAB ? kk % db.NS : 0;
+    if ((SLAB ? kk / db.NS : kk) >= per || c >= db.NC) return;
+    const uint32_t t0 = SLAB ? (uint32_t)(slab * db.Ts) : 0u;                                   // first tile of the slab
+    const uint32_t tn = SLAB ? (uint32_t)min(db.Ts, db.T - slab * db.Ts) : (uint32_t)db.T;       // tiles in it
+    const int srow0 = slab * db.slab_rows, srow1 = srow0 + db.slab_rows;                         // its tile rows (SLAB)
 #ifdef GSR_DB_TIMING
     unsigned long long dbt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dbt_last = __builtin_readcyclecounter();
 #endif
@@ -1288,20 +1300,21 @@ __global__ __launch_bounds__(64) void k_chunk_scatter(DirectBin db, int W, int H
         // (every row of a 980x545 frame's tables in flight at once -- the chunk's rows were written by other XCDs and come from memory,
         //  ~1.7 us a round trip: one row at a time this loop was a fifth of the kernel, sixteen at a time still three round trips)
         constexpr int kRows = 36;
-        for (int i0 = 0; i0 < db.Tp; i0 += 64 * kRows) {
+        for (int i0 = 0; i0 < LT; i0 += 64 * kRows) {
             uint32_t tb[kRows], gb[kRows], mc[kRows];   // tile base, the group's start in the tile, the chunk's start in the group
 #pragma unroll
             for (int q = 0; q < kRows; q++) {
-                const int i = i0 + 64 * q + lane;
-                const bool v = i < db.Tp;
-                tb[q] = v && i < db.T ? db.tbase[i] : 0u;
-                gb[q] = v ? gt[i] : 0u;
-                mc[q] = v ? (uint32_t)mr[i] : 0u;
+                const int i = i0 + 64 * q + lane;       // tile inside the slab; t0 + i in the frame
+                const bool v = i < LT && (uint32_t)i < tn + (SLAB ? 0u : (uint32_t)(db.Tp - db.T));
+                const int g = (int)t0 + i;
+                tb[q] = v && g < db.T ? db.tbase[g] : 0u;
+                gb[q] = v ? gt[g] : 0u;
+                mc[q] = v ? (uint32_t)mr[g] : 0u;
             }
 #pragma unroll
             for (int q = 0; q < kRows; q++) {
                 const int i = i0 + 64 * q + lane;
-                if (i < db.Tp) { s_cnt[i] = tb[q] + gb[q] + mc[q]; s_mask[i] = 0ull; }
+                if (i < LT) { s_cnt[i] = tb[q] + gb[q] + mc[q]; s_mask[i] = 0ull; }
             }
         }
     }
@@ -1316,13 +1329,19 @@ __global__ __launch_bounds__(64) void k_chunk_scatter(DirectBin db, int W, int H
     TileRec rA = load_rec(j0 + lane), rB = load_rec(j0 + 64 + lane);
     for (int j = j0 + lane; j - lane < j1; j += 64) {
         const uint32_t g = gA;
-        const TileRec r = rA;
+        TileRec r = rA;
         gA = gB; rA = rB;
         gB = load_gid(j + 128);
         rB = load_rec(j + 128);
+        if (SLAB && !(r.rect & kTileRecBig)) {   // the rect's rows inside the slab are a contiguous run of mask bits
+            const int ww = (int)((r.rect >> 24) & 63u), ry0 = (int)((r.rect >> 12) & 0xfffu);
+            const int lo = min(32, max(0, (srow0 - ry0) * ww)), hi = min(32, max(0, (srow1 - ry0) * ww));
+            const uint32_t below_hi = hi >= 32 ? 0xffffffffu : ((1u << hi) - 1u), below_lo = lo >= 32 ? 0xffffffffu : ((1u << lo) - 1u);
+            r.mask &= below_hi & ~below_lo;
+        }
         // A large rect (no mask in its record) is walked by all 64 lanes, once, and its accepted tiles go into the pair buffer like
         // everyone's; one of more tiles than the buffer holds ("huge") is walked three times instead, outside the buffer.
-        const bool big = (r.rect & kTileRecBig) != 0u && r.mask != 0u, huge = big && r.mask > (uint32_t)kDbPairs;
+        const bool big = (r.rect & kTileRecBig) != 0u && r.mask != 0u, huge = big && (SLAB || r.mask > (uint32_t)kDbPairs);
         const unsigned long long bigs = __ballot(big && !huge), huges = __ballot(huge);
         const uint32_t cnt = huge ? 0u : tilerec_count(r);
         const uint32_t incl = wave_inclusive_sum(cnt);
@@ -1336,7 +1355,8 @@ __global__ __launch_bounds__(64) void k_chunk_scatter(DirectBin db, int W, int H
             const bool mine = lane >= lo && lane < hi;
             if (!big && (with_or || mine)) {
                 uint32_t* o = s_pair + (incl - cnt - before);
-                small_rect_tiles(r, tiles_x, [&](uint32_t t) {
+                small_rect_tiles(r, tiles_x, [&](uint32_t tg) {
+                    const uint32_t t = tg - t0;          // (index inside the slab; the mask was cut down to it)
                     if (with_or) atomicOr(&s_mask[t], me);
                     if (mine) *o++ = (t << 6) | (uint32_t)lane;
                 });
@@ -1348,7 +1368,8 @@ __global__ __launch_bounds__(64) void k_chunk_scatter(DirectBin db, int W, int H
                 const uint32_t gg = (uint32_t)__builtin_amdgcn_readlane((int)g, bl), rect = (uint32_t)__builtin_amdgcn_readlane((int)r.rect, bl);
                 uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)(incl - cnt), bl) - before;
                 const Splat s = splat[gg];
-                big_rect_tiles(s, rect, W, H, tiles_x, tiles_y, lane, [&](bool ok, uint32_t t) {
+                big_rect_tiles(s, rect, W, H, tiles_x, tiles_y, lane, [&](bool ok, uint32_t tg) {
+                    const uint32_t t = tg - t0;          // (this branch only runs without slabs: t0 = 0)
                     const unsigned long long acc = __ballot(ok);
                     if (ok) {
                         if (with_or) atomicOr(&s_mask[t], 1ull << bl);
@@ -1368,7 +1389,7 @@ __global__ __launch_bounds__(64) void k_chunk_scatter(DirectBin db, int W, int H
             const int bl = (int)__builtin_ctzll(bm);
             const uint32_t gg = (uint32_t)__builtin_amdgcn_readlane((int)g, bl), rect = (uint32_t)__builtin_amdgcn_readlane((int)r.rect, bl);
             const Splat s = splat[gg];
-            big_rect_tiles(s, rect, W, H, tiles_x, tiles_y, lane, [&](bool ok, uint32_t t) { if (ok) atomicOr(&s_mask[t], 1ull << bl); });
+            big_rect_tiles(s, rect, W, H, tiles_x, tiles_y, lane, [&](bool ok, uint32_t tg) { const uint32_t t = tg - t0; if (ok && t < tn) atomicOr(&s_mask[t], 1ull << bl); });
         }
         // the loads of the step after next have had a step and this owner loop to arrive; taken HERE, in front of this step's
         // scattered stores (a wait for a load is a wait for every store issued before it: vmcnt counts both)
@@ -1421,8 +1442,9 @@ __global__ __launch_bounds__(64) void k_chunk_scatter(DirectBin db, int W, int H
             const int bl = (int)__builtin_ctzll(bm);
             const uint32_t gg = (uint32_t)__builtin_amdgcn_readlane((int)g, bl), rect = (uint32_t)__builtin_amdgcn_readlane((int)r.rect, bl);
             const Splat s = splat[gg];
-            big_rect_tiles(s, rect, W, H, tiles_x, tiles_y, lane, [&](bool ok, uint32_t t) {
-                if (ok) {
+            big_rect_tiles(s, rect, W, H, tiles_x, tiles_y, lane, [&](bool ok, uint32_t tg) {
+                const uint32_t t = tg - t0;
+                if (ok && t < tn) {
                     const uint32_t pos = s_cnt[t] + (uint32_t)__popcll(s_mask[t] & ((1ull << bl) - 1ull));
                     if (pos < cap) list[pos] = gg;
                 }
@@ -1450,19 +1472,19 @@ __global__ __launch_bounds__(64) void k_chunk_scatter(DirectBin db, int W, int H
                 else batch(std::integral_constant<int, 8>{});
             }
         } else {
-            if (!big) small_rect_tiles(r, tiles_x, [&](uint32_t t) { atomicAdd(&s_cnt[t], 1u); s_mask[t] = 0ull; });
+            if (!big) small_rect_tiles(r, tiles_x, [&](uint32_t tg) { const uint32_t t = tg - t0; atomicAdd(&s_cnt[t], 1u); s_mask[t] = 0ull; });
             for (unsigned long long bm = bigs; bm != 0ull; bm &= bm - 1ull) {
                 const int bl = (int)__builtin_ctzll(bm);
                 const uint32_t gg = (uint32_t)__builtin_amdgcn_readlane((int)g, bl), rect = (uint32_t)__builtin_amdgcn_readlane((int)r.rect, bl);
                 const Splat s = splat[gg];
-                big_rect_tiles(s, rect, W, H, tiles_x, tiles_y, lane, [&](bool ok, uint32_t t) { if (ok) { atomicAdd(&s_cnt[t], 1u); s_mask[t] = 0ull; } });
+                big_rect_tiles(s, rect, W, H, tiles_x, tiles_y, lane, [&](bool ok, uint32_t tg) { const uint32_t t = tg - t0; if (ok && t < tn) { atomicAdd(&s_cnt[t], 1u); s_mask[t] = 0ull; } });
             }
         }
         for (unsigned long long bm = huges; bm != 0ull; bm &= bm - 1ull) {
             const int bl = (int)__builtin_ctzll(bm);
             const uint32_t gg = (uint32_t)__builtin_amdgcn_readlane((int)g, bl), rect = (uint32_t)__builtin_amdgcn_readlane((int)r.rect, bl);
             const Splat s = splat[gg];
-            big_rect_tiles(s, rect, W, H, tiles_x, tiles_y, lane, [&](bool ok, uint32_t t) { if (ok) { atomicAdd(&s_cnt[t], 1u); s_mask[t] = 0ull; } });
+            big_rect_tiles(s, rect, W, H, tiles_x, tiles_y, lane, [&](bool ok, uint32_t tg) { const uint32_t t = tg - t0; if (ok && t < tn) { atomicAdd(&s_cnt[t], 1u); s_mask[t] = 0ull; } });
         }
         lds_order();
         DB_T(5);
@@ -2912,6 +2934,7 @@ static int g_ckpt_first = 1;  // 128-instance batches of a tile before the forwa
 static int g_depth_sort9 = 1;     // depth sort of large models in three 9-bit passes over (key - near-plane bits) (radix_sort.h); 0 = four 8-bit passes
 static int g_direct_bin = 1;      // tile lists by direct placement (k_chunk_counts / k_chunk_scatter) instead of emit + tile sort + ranges; 0 = the sort route
 static int g_view_pose_tol_e6 = 2000;   // balanced placement without a view id: a render belongs to the cached view whose pose is within this (x 1e-6) in every matrix entry
+static int g_db_slab_tiles = 0;   // frames above kDbMaxTiles tiles: tiles per slab of the slabbed scatter (0 = such frames keep the sort route)
 static int g_early_r = 1;         // the host learns R from the preprocess's per-block shares (published by the depth sort's histogram kernel) instead of from the scan
 static int g_blend_balance = 1;   // forward blend: place the waves by the visits each took at the previous render of the same view (balance_build)
 static int g_tile_map = 2;   // tile -> XCD map: 2 = 2x2 tile blocks interleaved (default), 1 = tiles interleaved, 0 = banded
@@ -3079,6 +3102,7 @@ int gsr_set_option(const char* name, int value)
     if (!strcmp(name, "tile_map")) { if (value < 0 || value > 2) return GSR_ERR_ARG; g_tile_map = value; return GSR_OK; }
     if (!strcmp(name, "blend_balance")) { g_blend_balance = value ? 1 : 0; return GSR_OK; }
     if (!strcmp(name, "early_r")) { g_early_r = value ? 1 : 0; return GSR_OK; }
+    if (!strcmp(name, "direct_slab_tiles")) { if (value < 0) return GSR_ERR_ARG; g_db_slab_tiles = value; return GSR_OK; }
     if (!strcmp(name, "view_pose_tol_e6")) { if (value < 0) return GSR_ERR_ARG; g_view_pose_tol_e6 = value; return GSR_OK; }
     if (!strcmp(name, "depth_sort9")) { g_depth_sort9 = value ? 1 : 0; return GSR_OK; }
     if (!strcmp(name, "direct_binning")) { g_direct_bin = value ? 1 : 0; return GSR_OK; }
@@ -3112,9 +3136,16 @@ int gsr_set_option(const char* name, int value)
 
 // geometry + scratch of the direct binning for N Gaussians on T tiles; false: this frame keeps the sort route
 struct DirectBinScratch { size_t M, GT, tbase, bsum, bytes; };
-static bool direct_bin_geometry(int N, int T, DirectBin& db, DirectBinScratch& ds)
+static bool direct_bin_geometry(int N, int T, DirectBin& db, DirectBinScratch& ds, int tiles_x = 0, int tile_rows = 0)
 {
-    if (N < 1 || T < 1 || T > kDbMaxTiles) return false;
+    if (N < 1 || T < 1) return false;
+    db.NS = 1; db.Ts = 0; db.Tsp = 0; db.slab_rows = 0;
+    if (T > kDbMaxTiles) {   // slabs of whole tile rows
+        if (g_db_slab_tiles <= 0 || tiles_x <= 0 || tile_rows <= 0 || tiles_x * tile_rows != T || tiles_x > kDbMaxTiles || T > 32768) return false;
+        const int rows = std::max(1, std::min(g_db_slab_tiles, kDbMaxTiles) / tiles_x);
+        db.slab_rows = rows; db.Ts = rows * tiles_x; db.Tsp = (db.Ts + 63) & ~63; db.NS = (tile_rows + rows - 1) / rows;
+        if (db.NS > 16) return false;
+    }
     static std::atomic<int> cus_cached{0};   // (compute units of the first device asked about: all devices of a node are alike)
     int cus = cus_cached.load(std::memory_order_relaxed);
     if (!cus) {
@@ -3123,11 +3154,11 @@ static bool direct_bin_geometry(int N, int T, DirectBin& db, DirectBinScratch& d
         cus_cached.store(cus, std::memory_order_relaxed);
     }
     db.N = N; db.T = T; db.Tp = (T + 63) & ~63;
-    const int lds = 12 * db.Tp + 4 * kDbPairs;
+    const int lds = 12 * (db.NS > 1 ? db.Tsp : db.Tp) + 4 * kDbPairs;
     const char* env = getenv("GSR_DB_WAVES_PER_CU");   // (experiments)
     int per_cu = std::min(16, (160 * 1024) / lds);
     if (env && atoi(env) > 0) per_cu = atoi(env);
-    const long long resident = (long long)cus * per_cu;
+    const long long resident = std::max<long long>(1, (long long)cus * per_cu / db.NS);   // chunks such that chunks x slabs fill the chip
     const char* env_s = getenv("GSR_DB_MIN_CHUNK");
     const int min_s = env_s && atoi(env_s) > 0 ? atoi(env_s) : 128;   // (measured at 20 k - 130 k Gaussians: 128 beats 64, 256 and 512)
     long long S = ((long long)N + resident - 1) / resident;
@@ -3191,7 +3222,7 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
     // direct binning (k_chunk_counts ... k_chunk_scatter) where the frame's tile tables fit a wave's LDS; else emit + tile sort
     DirectBin db = {};
     DirectBinScratch dbs = {};
-    const bool direct = g_direct_bin && g_sort_algo == 2 && !wide_keys && direct_bin_geometry(N, T, db, dbs);
+    const bool direct = g_direct_bin && g_sort_algo == 2 && !wide_keys && direct_bin_geometry(N, T, db, dbs, NB == 1 ? tiles_x : 0, tiles_y);
     uint2* ranges = nullptr;
     uint32_t* list = nullptr;
     auto alloc_binning = [&](uint64_t capacity) -> int {
@@ -3256,9 +3287,13 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
         if (direct) {
             if (capacity == 0) { GSR_HIP(hipMemsetAsync(ranges, 0, (size_t)T * sizeof(uint2), st)); return GSR_OK; }
             ProfScope ps(P_EMIT, st);
-            const int per = (db.NC + 7) / 8, grid = std::max(8 * per, (T + 63) / 64);
-            hipLaunchKernelGGL(k_chunk_scatter, dim3(grid), dim3(64), (size_t)12 * db.Tp + 4 * kDbPairs, st, db, W, H, tiles_x, tiles_y, sorted_gid,
-                               reinterpret_cast<const TileRec*>(fs + L.srec), splat, list, ranges, (uint32_t)std::min<uint64_t>(capacity, 0xffffffffull));
+            const int per = (db.NC + 7) / 8, grid = std::max(8 * per * db.NS, (T + 63) / 64);
+            if (db.NS > 1)
+                hipLaunchKernelGGL(k_chunk_scatter<true>, dim3(grid), dim3(64), (size_t)12 * db.Tsp + 4 * kDbPairs, st, db, W, H, tiles_x, tiles_y, sorted_gid,
+                                   reinterpret_cast<const TileRec*>(fs + L.srec), splat, list, ranges, (uint32_t)std::min<uint64_t>(capacity, 0xffffffffull));
+            else
+                hipLaunchKernelGGL(k_chunk_scatter<false>, dim3(grid), dim3(64), (size_t)12 * db.Tp + 4 * kDbPairs, st, db, W, H, tiles_x, tiles_y, sorted_gid,
+                                   reinterpret_cast<const TileRec*>(fs + L.srec), splat, list, ranges, (uint32_t)std::min<uint64_t>(capacity, 0xffffffffull));
             return GSR_OK;
         }
         return wide_keys ? launch_binning_t(uint32_t{}, capacity, n_dev, prezeroed) : launch_binning_t(uint16_t{}, capacity, n_dev, prezeroed);
@@ -3425,7 +3460,7 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
         TileRec* srec = reinterpret_cast<TileRec*>(fs + L.srec);
         unsigned long long* const host_slot = publish ? pin.s->dev : nullptr;   // (early R: the histogram kernel already told the host)
         if (direct) {
-            hipLaunchKernelGGL(k_chunk_counts, dim3(db.NC + (bal.hdr ? 8 : 0)), dim3(kEmitThreads), 0, st, db, W, H,
+            hipLaunchKernelGGL(k_chunk_counts, dim3(db.NC + (bal.hdr ? 8 : 0)), dim3(kEmitThreads), (size_t)2 * db.Tp, st, db, W, H,
                                tiles_x, tiles_y, sorted_gid, ntiles, splat, srec, bal);
             hipLaunchKernelGGL(k_chunk_scan1, dim3((db.Tp + 255) / 256, db.G), dim3(256), 0, st, db);
             hipLaunchKernelGGL(k_chunk_scan2, dim3((db.Tp + 255) / 256), dim3(256), 0, st, db, total, zjobs, host_slot, seq, wo);

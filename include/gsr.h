@@ -290,6 +290,9 @@ int gsr_version(void);
  *                          render of the same frame (device-side cache of 128 frames per frame size, least recently used out; a
  *                          frame is recognised by GsrForwardArgs::view_id or, without one, by its pose; single renders through
  *                          the default kernel); 0 = dispatch order = tile order.  Same image either way
+ *   "direct_slab_tiles"    (default 0 = off) frames above 4 096 tiles on the direct route: the tile grid is cut into slabs of whole tile
+ *                          rows of at most this many tiles and a chunk is walked by one wave per slab.  Same list bit for bit; measured
+ *                          no faster than the sort route such frames take by default
  *   "small_sort9"          (default 1) smallest model for which a forward that runs its own preprocess sorts its depth keys in three
  *                          9-bit passes over the 27-bit window instead of four 8-bit ones (it launches a digit histogram either way);
  *                          0 = only models above 262 144 Gaussians.  Same order either way (a depth beyond the window is detected

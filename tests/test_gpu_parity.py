@@ -703,6 +703,41 @@ def test_direct_binning_frame_sizes(W, H, N):
         assert np.array_equal(x, y)
 
 
+@pytest.mark.parametrize("W,H,N,slab,kind", [(1920, 1080, 200000, 2176, "syn"), (1920, 1080, 200000, 4096, "syn"), (1920, 1080, 6000, 2176, "rects"),
+                                             (1040, 1100, 50000, 1000, "syn"), (4112, 300, 30000, 3000, "syn")],
+                         ids=["1080p-4-slabs", "1080p-2-slabs", "1080p-large-and-huge-rects", "tall-5-slabs", "wide-one-row-slabs"])
+def test_slabbed_direct_binning_is_the_sort_routes_list(W, H, N, slab, kind):
+    """Round 5: frames above 4 096 tiles on the direct route -- the tile grid cut into slabs of whole tile rows, a
+    chunk of the depth order walked by one wave per slab (gsr_set_option("direct_slab_tiles", tiles per slab); off by default: DESIGN.md
+    section 8 has the measurement).  (ranges, list) and the images are the sort route's bit for bit: ordinary records whose rects straddle
+    slab boundaries, rects of hundreds of tiles and screen-filling ones (walked per slab), a ragged last slab, one-row slabs."""
+    import importlib
+    import hip_runner
+    R_ = importlib.import_module("3dgs_hierarchical_training_amd.rasterizer")
+    L = importlib.import_module("3dgs_hierarchical_training_amd._lib")
+    lib = L.load()
+    sc = parity.syn.make_scene(N, W, H, sh_degree=0, seed=W + N, sigma_px=5.0)
+    if kind == "rects":
+        g = torch.Generator().manual_seed(2)
+        big = torch.randperm(N, generator=g)[:200]
+        sc["scales"][big[:150]] *= 10.0
+        sc["scales"][big[150:]] *= 80.0
+    kw = parity.scene_kwargs(sc, "sh", bg=(0.1, 0.2, 0.3))
+    res = {}
+    try:
+        for mode in ("sort", "slab"):
+            assert lib.gsr_set_option(b"direct_slab_tiles", slab if mode == "slab" else 0) == 0
+            fwd = hip_runner.run_hip(kw)["fwd"]
+            ranges, lst = R_.last_binning()
+            res[mode] = (fwd, ranges.cpu().numpy().copy(), lst.cpu().numpy().copy(), R_._LAST["num_rendered"])
+    finally:
+        lib.gsr_set_option(b"direct_slab_tiles", 0)
+    (fa, ra, la, na), (fb, rb, lb, nb_) = res["sort"], res["slab"]
+    assert na == nb_ and na > 0 and np.array_equal(ra, rb) and np.array_equal(la[:na], lb[:nb_])
+    for x, y in zip(fa, fb):
+        assert np.array_equal(x, y)
+
+
 # ---- the reference-derived fixtures, on the HIP path ---------------------------------------------------------------------
 def _fixture_settings(g, tag, dev, noncontig):
     from diff_gaussian_rasterization import GaussianRasterizationSettings
