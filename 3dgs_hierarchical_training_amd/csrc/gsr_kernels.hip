@@ -378,6 +378,31 @@ __device__ __forceinline__ void stage_store_lin(const float4 (&r)[KN], float* ti
     }
 }
 
+// whole blocks (nG == kPreThreads): the same two halves with compile-time bounds
+template <int ROW, int KN>
+__device__ __forceinline__ void stage_load_full(float4 (&r)[KN], const float* __restrict__ src, int tid)
+{
+    static_assert(KN >= stage_regs<ROW>(), "register file too small for the rows");
+    constexpr int total4 = kPreThreads * ROW / 4;
+    const float4* s4 = reinterpret_cast<const float4*>(src);
+#pragma unroll
+    for (int q = 0; q < stage_regs<ROW>(); q++) {
+        const int v = tid + q * kPreThreads;
+        if ((q + 1) * kPreThreads <= total4 || v < total4) r[q] = s4[v];
+    }
+}
+template <int ROW, int KN>
+__device__ __forceinline__ void stage_store_lin_full(const float4 (&r)[KN], float* tile, int tid)
+{
+    constexpr int total4 = kPreThreads * ROW / 4;
+    float4* t4 = reinterpret_cast<float4*>(tile);
+#pragma unroll
+    for (int q = 0; q < stage_regs<ROW>(); q++) {
+        const int v = tid + q * kPreThreads;
+        if ((q + 1) * kPreThreads <= total4 || v < total4) t4[v] = r[q];
+    }
+}
+
 // q = normalize(_rotation), opacity = sigmoid(_opacity), SH = cat(_features_dc, _features_rest) -- so the
 // torch exp / sigmoid / normalize / cat kernels (and their backward) disappear from the train step.
 // Large rects (more than 32 candidate tiles) are counted by the whole wave, 64 candidate tiles per step, so one
@@ -2339,41 +2364,118 @@ __device__ __forceinline__ void adam_rows_lin(float* s_g, int total, float* __re
     }
 }
 
+// Round 5, whole blocks of the linear tile: the f_rest stream software-pipelined by hand.  On gfx9 one counter (vmcnt) counts a wave's
+// loads AND stores, in order, and the in-place update makes every load of the next element a may-alias of the stores in front of it:
+// the plain loop above compiles to "three loads, wait, compute, three stores, wait for nearly all of it" per element -- a load round
+// trip and a store acknowledgement in series, twelve times per thread.  Here the loads of element k + D are issued BEFORE element k is
+// computed and stored (different elements: no true dependence), so waiting for element k's loads never waits for a store younger than
+// D elements, and D x 3 loads of 16 bytes are in flight per thread throughout.  Same arithmetic, same order per element.
+#ifndef GSR_K9_DEPTH
+#define GSR_K9_DEPTH 3
+#endif
+template <bool KEEP, int KP, int ROW, int D = GSR_K9_DEPTH>
+__device__ __forceinline__ void adam_rows_lin_piped(float* s_g, float* p, float* m, float* v, int tid, float step_size, float bc2, int grp,
+                                                    const AdamDev& ad, const float4* pm, const float4* pv)
+{
+    constexpr int total4 = kPreThreads * ROW / 4;
+    constexpr int NE = (total4 + kPreThreads - 1) / kPreThreads;
+    static_assert((kPreThreads * ROW) % 4 == 0, "whole 16-byte pieces");
+    const float4* p4 = reinterpret_cast<const float4*>(p);
+    const float4* m4 = reinterpret_cast<const float4*>(m);
+    const float4* v4 = reinterpret_cast<const float4*>(v);
+    float4* g4 = reinterpret_cast<float4*>(s_g);
+    float4* po4 = reinterpret_cast<float4*>(adam_out(p, ad.dp[grp]));
+    float4* mo4 = reinterpret_cast<float4*>(adam_out(m, ad.dm[grp]));
+    float4* vo4 = reinterpret_cast<float4*>(adam_out(v, ad.dv[grp]));
+    float4 P[D], M[D], V[D];
+#pragma unroll
+    for (int k = 0; k < D && k < NE; k++) {
+        const int q = tid + k * kPreThreads;
+        if ((k + 1) * kPreThreads <= total4 || q < total4) {
+            P[k] = p4[q];
+            if (k < KP) { M[k] = pm[k]; V[k] = pv[k]; }
+            else { M[k] = nt_load4(m4 + q); V[k] = nt_load4(v4 + q); }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NE; k++) {
+        const int q = tid + k * kPreThreads, sl = k % D;
+        float4 pp = P[sl], mm = M[sl], vv = V[sl];
+        if (k + D < NE) {
+            const int qn = q + D * kPreThreads;
+            if ((k + D + 1) * kPreThreads <= total4 || qn < total4) {
+                P[sl] = p4[qn];
+                if (k + D < KP) { M[sl] = pm[k + D]; V[sl] = pv[k + D]; }
+                else { M[sl] = nt_load4(m4 + qn); V[sl] = nt_load4(v4 + qn); }
+            }
+        }
+        if ((k + 1) * kPreThreads <= total4 || q < total4) {
+            const float4 g = g4[q];
+            adam_one(pp.x, g.x, mm.x, vv.x, ad.b1, ad.b2, ad.eps, step_size, bc2);
+            adam_one(pp.y, g.y, mm.y, vv.y, ad.b1, ad.b2, ad.eps, step_size, bc2);
+            adam_one(pp.z, g.z, mm.z, vv.z, ad.b1, ad.b2, ad.eps, step_size, bc2);
+            adam_one(pp.w, g.w, mm.w, vv.w, ad.b1, ad.b2, ad.eps, step_size, bc2);
+            nt_store4(po4 + q, pp); nt_store4(mo4 + q, mm); nt_store4(vo4 + q, vv);
+            if (KEEP) g4[q] = pp;
+        }
+    }
+}
+
 // The four small groups (mean 3, opacity 1, scaling 3, rotation 4 floats) are updated by the thread that owns the Gaussian,
 // straight from its registers: neighbouring lanes touch neighbouring rows, so every fetched line is fully used, and the
 // block keeps no LDS copy of these gradients (25 instead of 30.7 kB per block: one more block per CU).
+// A workgroup barrier that orders LDS ONLY: `s_waitcnt lgkmcnt(0)` + `s_barrier`.  __syncthreads() carries a workgroup-scope fence, which
+// on gfx9 waits for EVERY outstanding vector-memory operation of the wave (vmcnt counts loads and stores alike) -- in the optimizer-in-
+// backward kernel that is a full memory round trip per barrier: the small groups' moments requested in front of the streams, the
+// streams' own stores in front of the next-view tail.  What the block's threads hand each other there lives in LDS (gradient rows, the
+// updated rows, the digit tables); through global memory a thread only ever reads what no thread of the kernel has written.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+template <bool LDS_ONLY>
+__device__ __forceinline__ void k9_barrier() { if constexpr (LDS_ONLY) lds_barrier(); else __syncthreads(); }
+
+// Round 5, the same update in two halves: the moments are REQUESTED in front of the block's row streams (adam_own_request) and the
+// update is computed behind them (adam_own_apply), so the four small groups cost the kernel no memory round trip of their own -- the
+// loads are in flight while the streams run, where registers are free (the parameter rows are read a second time there, from L2:
+// keeping the chain's copies alive across it would cost the kernel its third wave per SIMD).
 template <int K>
-__device__ __forceinline__ void adam_own(float* p, float* m, float* v, const float* g, float step_size, float bc2, int grp, const AdamDev& ad,
-                                         float* updated = nullptr)
+struct OwnMoments { float p[K], m[K], v[K]; };
+template <int K>
+__device__ __forceinline__ void adam_own_request(OwnMoments<K>& s, const float* p, const float* m, const float* v)
 {
-    float* const po = adam_out(p, ad.dp[grp]); float* const mo = adam_out(m, ad.dm[grp]); float* const vo = adam_out(v, ad.dv[grp]);
-    if (K == 4 && ((((uintptr_t)p | (uintptr_t)m | (uintptr_t)v | (uintptr_t)po | (uintptr_t)mo | (uintptr_t)vo) & 15) == 0)) {
-        float4 pp = *reinterpret_cast<const float4*>(p);
-        float4 mm = nt_load4(reinterpret_cast<const float4*>(m)), vv = nt_load4(reinterpret_cast<const float4*>(v));
-        adam_one(pp.x, g[0], mm.x, vv.x, ad.b1, ad.b2, ad.eps, step_size, bc2);
-        adam_one(pp.y, g[1], mm.y, vv.y, ad.b1, ad.b2, ad.eps, step_size, bc2);
-        adam_one(pp.z, g[2], mm.z, vv.z, ad.b1, ad.b2, ad.eps, step_size, bc2);
-        adam_one(pp.w, g[3], mm.w, vv.w, ad.b1, ad.b2, ad.eps, step_size, bc2);
-        nt_store4(reinterpret_cast<float4*>(po), pp);
-        nt_store4(reinterpret_cast<float4*>(mo), mm);
-        nt_store4(reinterpret_cast<float4*>(vo), vv);
-        if (updated) { updated[0] = pp.x; updated[1] = pp.y; updated[2] = pp.z; updated[3] = pp.w; }
+    if (K == 4 && ((((uintptr_t)p | (uintptr_t)m | (uintptr_t)v) & 15) == 0)) {
+        const float4 pp = *reinterpret_cast<const float4*>(p);
+        const float4 mm = nt_load4(reinterpret_cast<const float4*>(m)), vv = nt_load4(reinterpret_cast<const float4*>(v));
+        s.p[0] = pp.x; s.p[1] = pp.y; s.p[2] = pp.z; s.p[K - 1] = pp.w;
+        s.m[0] = mm.x; s.m[1] = mm.y; s.m[2] = mm.z; s.m[K - 1] = mm.w;
+        s.v[0] = vv.x; s.v[1] = vv.y; s.v[2] = vv.z; s.v[K - 1] = vv.w;
         return;
     }
-    float pp[K], mm[K], vv[K];
 #pragma unroll
-    for (int c = 0; c < K; c++) { pp[c] = p[c]; mm[c] = __builtin_nontemporal_load(m + c); vv[c] = __builtin_nontemporal_load(v + c); }
+    for (int c = 0; c < K; c++) { s.p[c] = p[c]; s.m[c] = __builtin_nontemporal_load(m + c); s.v[c] = __builtin_nontemporal_load(v + c); }
+}
+template <int K>
+__device__ __forceinline__ void adam_own_apply(float* p, float* m, float* v, OwnMoments<K>& s, const float* g, float step_size,
+                                               float bc2, int grp, const AdamDev& ad, float* updated = nullptr)
+{
+    float* const po = adam_out(p, ad.dp[grp]); float* const mo = adam_out(m, ad.dm[grp]); float* const vo = adam_out(v, ad.dv[grp]);
+    float pp[K];
 #pragma unroll
-    for (int c = 0; c < K; c++) adam_one(pp[c], g[c], mm[c], vv[c], ad.b1, ad.b2, ad.eps, step_size, bc2);
+    for (int c = 0; c < K; c++) { pp[c] = s.p[c]; adam_one(pp[c], g[c], s.m[c], s.v[c], ad.b1, ad.b2, ad.eps, step_size, bc2); }
     if (updated) {
 #pragma unroll
         for (int c = 0; c < K; c++) updated[c] = pp[c];
     }
+    if (K == 4 && ((((uintptr_t)po | (uintptr_t)mo | (uintptr_t)vo) & 15) == 0)) {
+        nt_store4(reinterpret_cast<float4*>(po), make_float4(pp[0], pp[1], pp[2], pp[K - 1]));
+        nt_store4(reinterpret_cast<float4*>(mo), make_float4(s.m[0], s.m[1], s.m[2], s.m[K - 1]));
+        nt_store4(reinterpret_cast<float4*>(vo), make_float4(s.v[0], s.v[1], s.v[2], s.v[K - 1]));
+        return;
+    }
 #pragma unroll
     for (int c = 0; c < K; c++) {
         __builtin_nontemporal_store(pp[c], po + c);
-        __builtin_nontemporal_store(mm[c], mo + c);
-        __builtin_nontemporal_store(vv[c], vo + c);
+        __builtin_nontemporal_store(s.m[c], mo + c);
+        __builtin_nontemporal_store(s.v[c], vo + c);
     }
 }
 
@@ -2383,6 +2485,15 @@ __device__ __forceinline__ void adam_own(float* p, float* m, float* v, const flo
 // CAM = true additionally produces dL/d(viewmatrix, projmatrix, campos) (north_star's dL/dviewmatrix; BASELINE
 // config 5): per-thread contributions are reduced over the block and written as one 35-float partial per block;
 // k_cam_reduce sums the partials deterministically.
+#ifdef GSR_K9_TIMING   // experiment build only (tools/k9_timing.sh): where a wave of the per-Gaussian backward spends its time
+constexpr int kK9DbgWaves = 16384;
+__device__ unsigned long long g_k9_dbg[kK9DbgWaves * 8];   // [wave][phase], the last launch
+#define K9_T(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); if ((threadIdx.x & 63) == 0) k9t[k] += now_ - k9t_last; k9t_last = now_; } while (0)
+#define K9_T_FLUSH() do { const int w_ = (int)blockIdx.x * (kPreThreads / 64) + (int)(threadIdx.x >> 6); if ((threadIdx.x & 63) == 0 && w_ < kK9DbgWaves) { k9t[7] = k9t_last; for (int q_ = 0; q_ < 8; q_++) g_k9_dbg[w_ * 8 + q_] = k9t[q_]; } } while (0)
+#else
+#define K9_T(k) do { } while (0)
+#define K9_T_FLUSH() do { } while (0)
+#endif
 constexpr int kCamVals = 47;   // viewmatrix 16 + projmatrix 16 + campos 3 + points_transform 12
 
 // ADAM = true (needs RAW, shs + shs_rest, no cov_pre): optimizer-in-backward, see GsrFusedAdam in include/gsr.h.  The
@@ -2409,10 +2520,18 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, in
     __shared__ float s_cam[CAM ? (kPreThreads / 64) * kCamVals : 1];
     // PREP (with ADAM): the updated raw parameters of this thread's Gaussian, kept for the next-view tail
     float nmean[3] = {0.f, 0.f, 0.f}, nsc[3] = {0.f, 0.f, 0.f}, nrq[4] = {1.f, 0.f, 0.f, 0.f}, nop = 0.f;
+    OwnMoments<3> om_mean, om_sc;   // ADAM: the small groups' moments, requested behind the derivative chain, used behind the row streams
+    OwnMoments<1> om_op;
+    OwnMoments<4> om_rq;
+    float own_g[11];                // their gradients: mean 3 | opacity 1 | scale 3 | rotation 4
     const int tid = threadIdx.x;
     const int base = blockIdx.x * kPreThreads;
     const int i = base + tid;
     const int nG = min(kPreThreads, N - base);
+#ifdef GSR_K9_TIMING
+    unsigned long long k9t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, k9t_last = __builtin_readcyclecounter();
+    k9t[6] = k9t_last;   // start stamp (k9t[7] = end stamp)
+#endif
     select_view(cp, (int)blockIdx.x);   // batched render: this block's model and its camera
     CamGrads cg;
     float xg[12];   // dL/d(points_transform) share of this thread
@@ -2446,10 +2565,42 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, in
             for (int k = 0; k < kAdamPrefetch; k++) { pf_m[k] = nt_load4(m4 + tid + k * kPreThreads); pf_v[k] = nt_load4(v4 + tid + k * kPreThreads); }
         }
     }
+    // ADAM (round 5): what this thread reads of its OWN Gaussian -- the blend-gradient row, the raw small rows (the optimizer reads them
+    // whether the Gaussian is live or not), -- is requested here, in front of the SH rows' trip through
+    // LDS, so the derivative chain finds its inputs when the barrier opens instead of starting a second memory round trip there.
+    float4 e_g0 = make_float4(0.f, 0.f, 0.f, 0.f), e_g1 = e_g0, e_g2 = e_g0;
+    float e_mean[3] = {0.f, 0.f, 0.f}, e_sc[3] = {0.f, 0.f, 0.f}, e_rq[4] = {1.f, 0.f, 0.f, 0.f}, e_op = 0.f;
+    int e_rad = 0;
+    float e_ds[3] = {0.f, 0.f, 0.f}, e_m2dn = 0.f;
+    if constexpr (ADAM) {
+        if (i < N) {
+            const float4* gp = reinterpret_cast<const float4*>(ggrad + (size_t)i * kGG);
+            e_g0 = gp[0]; e_g1 = gp[1]; e_g2 = gp[2];
+#pragma unroll
+            for (int k = 0; k < 3; k++) { e_mean[k] = means[3 * (size_t)i + k]; e_sc[k] = scales[3 * (size_t)i + k]; }
+#pragma unroll
+            for (int k = 0; k < 4; k++) e_rq[k] = rots[4 * (size_t)i + k];
+            e_op = opac_raw[i];
+        }
+    }
     if (lin) {
-        stage_in_lin<3>(s_dc, shs + (size_t)base * 3, nG, tid);
-        if (DEG > 0) stage_in_lin<NRL>(s_rest, shs_rest + (size_t)base * NRL, nG, tid);
-        __syncthreads();
+        // every 16-byte piece of the block's rows is requested before the first one is waited for (round 5: the copy loop
+        // `tile[v] = src[v]` has a run-time trip count, hipcc does not unroll it, and each of its twelve turns was a memory round trip
+        // of its own -- a fifth of a wave's life in this kernel, tools/k9_timing.sh)
+        float4 r_dc[stage_regs<3>()], r_rest[stage_regs<NRL>()];
+        if (nG == kPreThreads) {   // (block-uniform) a whole block: no per-piece bound but the static one of the last turn
+            stage_load_full<3>(r_dc, shs + (size_t)base * 3, tid);
+            if (DEG > 0) stage_load_full<NRL>(r_rest, shs_rest + (size_t)base * NRL, tid);
+            stage_store_lin_full<3>(r_dc, s_dc, tid);
+            if (DEG > 0) stage_store_lin_full<NRL>(r_rest, s_rest, tid);
+        } else {
+            stage_load<3>(r_dc, shs + (size_t)base * 3, nG, tid);
+            if (DEG > 0) stage_load<NRL>(r_rest, shs_rest + (size_t)base * NRL, nG, tid);
+            stage_store_lin<3>(r_dc, s_dc, nG, tid);
+            if (DEG > 0) stage_store_lin<NRL>(r_rest, s_rest, nG, tid);
+        }
+        k9_barrier<ADAM>();
+        K9_T(0);
     } else if (shs) {
         if (shs_rest) {
             const size_t row = (size_t)(cp.M - 1) * 3;
@@ -2487,11 +2638,12 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, in
         // radius > 0 test, and the 48-byte splat record is not read by this kernel at all (the activated opacity the
         // sigmoid chain needs is recomputed from the logit exactly as the forward computed it).
         const float4* gp = reinterpret_cast<const float4*>(ggrad + (size_t)i * kGG);
-        const float4 g0 = gp[0], g1 = gp[1], g2 = gp[2];   // gx gy gA gB | gC gop gr gg | gb gz - -
+        const float4 g0 = ADAM ? e_g0 : gp[0], g1 = ADAM ? e_g1 : gp[1], g2 = ADAM ? e_g2 : gp[2];   // gx gy gA gB | gC gop gr gg | gb gz - -
         const bool live = g0.x != 0.f || g0.y != 0.f || g0.z != 0.f || g0.w != 0.f || g1.x != 0.f || g1.y != 0.f || g1.z != 0.f ||
                           g1.w != 0.f || g2.x != 0.f || g2.y != 0.f;
         if (live) {
-            const float mraw[3] = {means[3 * (size_t)i], means[3 * (size_t)i + 1], means[3 * (size_t)i + 2]};
+            const float mraw[3] = {ADAM ? e_mean[0] : means[3 * (size_t)i], ADAM ? e_mean[1] : means[3 * (size_t)i + 1],
+                                   ADAM ? e_mean[2] : means[3 * (size_t)i + 2]};
             float mean[3] = {mraw[0], mraw[1], mraw[2]};
             apply_points_transform(cp.xf, mean);
             float sc[3] = {0, 0, 0}, rq[4] = {1, 0, 0, 0}, cv[6];
@@ -2500,9 +2652,9 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, in
                 for (int k = 0; k < 6; k++) cv[k] = cov_pre[6 * (size_t)i + k];
             } else {
 #pragma unroll
-                for (int k = 0; k < 3; k++) sc[k] = scales[3 * (size_t)i + k];
+                for (int k = 0; k < 3; k++) sc[k] = ADAM ? e_sc[k] : scales[3 * (size_t)i + k];
 #pragma unroll
-                for (int k = 0; k < 4; k++) rq[k] = rots[4 * (size_t)i + k];
+                for (int k = 0; k < 4; k++) rq[k] = ADAM ? e_rq[k] : rots[4 * (size_t)i + k];
             }
             float rinv = 1.f;
             if (RAW && !cov_pre) {
@@ -2519,7 +2671,7 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, in
             dop = g1.y;
             grgb[0] = g1.z; grgb[1] = g1.w; grgb[2] = g2.x;
             if (RAW) {   // chain through exp / normalize / sigmoid
-                const float sg = 1.0f / (1.0f + expf(-opac_raw[i]));   // the activated opacity, as k_preprocess computes it
+                const float sg = 1.0f / (1.0f + expf(-(ADAM ? e_op : opac_raw[i])));   // the activated opacity, as k_preprocess computes it
                 dop *= sg * (1.f - sg);
 #pragma unroll
                 for (int k = 0; k < 3; k++) o.scale[k] *= sc[k];
@@ -2558,8 +2710,12 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, in
         } else if (shs) {
             for (int e = 0; e < NC3; e++) s_sh[tid * kShStride + e] = 0.f;
         }
+        K9_T(1);
         d_means2d[3 * (size_t)i] = m2d[0]; d_means2d[3 * (size_t)i + 1] = m2d[1]; d_means2d[3 * (size_t)i + 2] = 0.f;
-        if (ds.radii) {   // what the reference's train_step does with radii and means2D.grad after every backward
+        if (ADAM) {   // (the statistics' words are requested with the small groups' moments and updated behind the streams)
+            if (ds.radii) { e_rad = ds.radii[i]; e_ds[0] = ds.max_radii[i]; e_ds[1] = ds.grad_accum[i]; e_ds[2] = ds.denom[i]; }
+            e_m2dn = sqrtf(m2d[0] * m2d[0] + m2d[1] * m2d[1]);
+        } else if (ds.radii) {   // what the reference's train_step does with radii and means2D.grad after every backward
             const int r = ds.radii[i];   // (ht3dgs_trainer.py:141-147, gaussian_model_ht.py:718-721): visible = radii > 0
             if (r > 0) {
                 ds.max_radii[i] = fmaxf(ds.max_radii[i], (float)r);
@@ -2567,12 +2723,17 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, in
                 ds.denom[i] += 1.f;
             }
         }
-        if (ADAM) {   // this thread is the only reader of its Gaussian's small rows, and it has read them
-            const size_t gi = (size_t)i;
-            adam_own<3>(const_cast<float*>(means) + 3 * gi, ad.m[0] + 3 * gi, ad.v[0] + 3 * gi, dmean, ad.step_size[0], ad.inv_bc2s[0], 0, ad, PREP >= 0 ? nmean : nullptr);
-            adam_own<1>(const_cast<float*>(opac_raw) + gi, ad.m[3] + gi, ad.v[3] + gi, &dop, ad.step_size[3], ad.inv_bc2s[3], 3, ad, PREP >= 0 ? &nop : nullptr);
-            adam_own<3>(const_cast<float*>(scales) + 3 * gi, ad.m[4] + 3 * gi, ad.v[4] + 3 * gi, dsc, ad.step_size[4], ad.inv_bc2s[4], 4, ad, PREP >= 0 ? nsc : nullptr);
-            adam_own<4>(const_cast<float*>(rots) + 4 * gi, ad.m[5] + 4 * gi, ad.v[5] + 4 * gi, drq, ad.step_size[5], ad.inv_bc2s[5], 5, ad, PREP >= 0 ? nrq : nullptr);
+        if (ADAM) {   // this thread is the only reader of its Gaussian's small rows, and it has read them: their moments are requested
+            const size_t gi = (size_t)i;   // here and used behind the row streams (own_apply below)
+            adam_own_request<3>(om_mean, means + 3 * gi, ad.m[0] + 3 * gi, ad.v[0] + 3 * gi);
+            adam_own_request<1>(om_op, opac_raw + gi, ad.m[3] + gi, ad.v[3] + gi);
+            adam_own_request<3>(om_sc, scales + 3 * gi, ad.m[4] + 3 * gi, ad.v[4] + 3 * gi);
+            adam_own_request<4>(om_rq, rots + 4 * gi, ad.m[5] + 4 * gi, ad.v[5] + 4 * gi);
+#pragma unroll
+            for (int k = 0; k < 3; k++) { own_g[k] = dmean[k]; own_g[4 + k] = dsc[k]; }
+            own_g[3] = dop;
+#pragma unroll
+            for (int k = 0; k < 4; k++) own_g[7 + k] = drq[k];
         } else {
 #pragma unroll
         for (int k = 0; k < 3; k++) d_means[3 * (size_t)i + k] = dmean[k];
@@ -2595,6 +2756,7 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, in
         }
         }
     }
+    K9_T(2);
     if (CAM) {
         const int lane = tid & 63, wave = tid >> 6;
         float cv35[kCamVals];
@@ -2616,10 +2778,38 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, in
         }
     }
     if (ADAM) {
-        __syncthreads();   // every thread's parameters are read, every gradient row is in LDS
+        lds_barrier();   // every thread's parameters are read, every gradient row is in LDS
         const size_t b = (size_t)base;
         const int rrow = cp.M * 3 - 3;
         if (lin) {
+            // whole blocks with every stream 16-byte aligned: the f_dc group's one element per thread is requested in front of the f_rest
+            // pipeline and updated behind it (its loads are then the oldest in flight and its stores wait for nobody)
+            const bool piped = kAdamPrefetch > 0 && pf_ok && ((ad.dp[2] | ad.dm[2] | ad.dv[2]) & 15) == 0 && (DEG > 0 || ad.m[2]) &&
+                               ((((uintptr_t)(ad.m[1] + b * 3)) | ((uintptr_t)(ad.v[1] + b * 3)) | (uintptr_t)ad.dp[1] | (uintptr_t)ad.dm[1] | (uintptr_t)ad.dv[1]) & 15) == 0;
+            if (piped) {
+                constexpr int dc4 = kPreThreads * 3 / 4;
+                float* const pd = const_cast<float*>(shs) + b * 3;
+                float4 dP = make_float4(0.f, 0.f, 0.f, 0.f), dM = dP, dV = dP;
+                if (tid < dc4) {
+                    dP = reinterpret_cast<const float4*>(pd)[tid];
+                    dM = nt_load4(reinterpret_cast<const float4*>(ad.m[1] + b * 3) + tid);
+                    dV = nt_load4(reinterpret_cast<const float4*>(ad.v[1] + b * 3) + tid);
+                }
+                adam_rows_lin_piped<(PREP >= 0), kAdamPrefetch, NRL>(s_rest, const_cast<float*>(shs_rest) + b * NRL, ad.m[2] + b * NRL, ad.v[2] + b * NRL, tid,
+                                                                     ad.step_size[2], ad.inv_bc2s[2], 2, ad, pf_m, pf_v);
+                if (tid < dc4) {
+                    float4* g4 = reinterpret_cast<float4*>(s_dc);
+                    const float4 g = g4[tid];
+                    adam_one(dP.x, g.x, dM.x, dV.x, ad.b1, ad.b2, ad.eps, ad.step_size[1], ad.inv_bc2s[1]);
+                    adam_one(dP.y, g.y, dM.y, dV.y, ad.b1, ad.b2, ad.eps, ad.step_size[1], ad.inv_bc2s[1]);
+                    adam_one(dP.z, g.z, dM.z, dV.z, ad.b1, ad.b2, ad.eps, ad.step_size[1], ad.inv_bc2s[1]);
+                    adam_one(dP.w, g.w, dM.w, dV.w, ad.b1, ad.b2, ad.eps, ad.step_size[1], ad.inv_bc2s[1]);
+                    nt_store4(reinterpret_cast<float4*>(adam_out(pd, ad.dp[1])) + tid, dP);
+                    nt_store4(reinterpret_cast<float4*>(adam_out(ad.m[1] + b * 3, ad.dm[1])) + tid, dM);
+                    nt_store4(reinterpret_cast<float4*>(adam_out(ad.v[1] + b * 3, ad.dv[1])) + tid, dV);
+                    if (PREP >= 0) g4[tid] = dP;
+                }
+            } else {
             adam_rows_lin<(PREP >= 0)>(s_dc, nG * 3, const_cast<float*>(shs) + b * 3, ad.m[1] + b * 3, ad.v[1] + b * 3, tid, ad.step_size[1], ad.inv_bc2s[1], 1, ad);
             if (DEG > 0 || ad.m[2]) {   // (degree 0, moments known to be zero: the group's update is the identity -- GsrFusedAdam)
                 if (kAdamPrefetch > 0 && pf_ok)
@@ -2628,13 +2818,27 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, in
                 else
                     adam_rows_lin<(PREP >= 0)>(s_rest, nG * NRL, const_cast<float*>(shs_rest) + b * NRL, ad.m[2] + b * NRL, ad.v[2] + b * NRL, tid, ad.step_size[2], ad.inv_bc2s[2], 2, ad);
             }
-            if (PREP < 0) return;
+            }
+            if (i < N) {   // the small groups' update, from the moments requested in front of the streams
+                const size_t gi = (size_t)i;
+                adam_own_apply<3>(const_cast<float*>(means) + 3 * gi, ad.m[0] + 3 * gi, ad.v[0] + 3 * gi, om_mean, own_g, ad.step_size[0], ad.inv_bc2s[0], 0, ad, PREP >= 0 ? nmean : nullptr);
+                adam_own_apply<1>(const_cast<float*>(opac_raw) + gi, ad.m[3] + gi, ad.v[3] + gi, om_op, own_g + 3, ad.step_size[3], ad.inv_bc2s[3], 3, ad, PREP >= 0 ? &nop : nullptr);
+                adam_own_apply<3>(const_cast<float*>(scales) + 3 * gi, ad.m[4] + 3 * gi, ad.v[4] + 3 * gi, om_sc, own_g + 4, ad.step_size[4], ad.inv_bc2s[4], 4, ad, PREP >= 0 ? nsc : nullptr);
+                adam_own_apply<4>(const_cast<float*>(rots) + 4 * gi, ad.m[5] + 4 * gi, ad.v[5] + 4 * gi, om_rq, own_g + 7, ad.step_size[5], ad.inv_bc2s[5], 5, ad, PREP >= 0 ? nrq : nullptr);
+                if (ds.radii && e_rad > 0) {   // what the reference's train_step does with radii and means2D.grad after every backward
+                    ds.max_radii[i] = fmaxf(e_ds[0], (float)e_rad);   // (ht3dgs_trainer.py:141-147, gaussian_model_ht.py:718-721): visible = radii > 0
+                    ds.grad_accum[i] = e_ds[1] + e_m2dn;
+                    ds.denom[i] = e_ds[2] + 1.f;
+                }
+            }
+            K9_T(3);
+            if (PREP < 0) { K9_T_FLUSH(); return; }
             // ---- next-view tail ("prepare in backward", GsrNextView): this block holds the UPDATED parameters of its 128
             // Gaussians -- the small groups in the owners' registers, the SH rows in the LDS tile -- so it runs the forward
             // preprocess of the NEXT render on them right here: the next gsr_forward skips k_preprocess (no second read of the
             // 236 bytes per Gaussian, and ~2 400 VALU instructions per wave that hide under this kernel's HBM time).
             // Same functions, same order of operations as k_preprocess<PREP, true>: the records are bit-identical.
-            __syncthreads();
+            lds_barrier();
             const bool act = i < N;
             const int model2 = select_view(po.cp, (int)blockIdx.x);
             Camera cam2 = load_camera(po.cp);
@@ -2662,7 +2866,7 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, in
                 const uint32_t far = (nt > 0u && __float_as_uint(s2.depth) - kDepthKeyBias > po.early_window) ? 1u : 0u;
                 const uint32_t st_ = wave_inclusive_sum(nt), sf_ = wave_inclusive_sum(far);
                 if ((tid & 63) == 63) { s_early2[0][tid >> 6] = st_; s_early2[1][tid >> 6] = sf_; }
-                __syncthreads();
+                lds_barrier();
                 if (tid == 0) {
                     uint32_t t0 = 0u, t1 = 0u;
 #pragma unroll
@@ -2684,19 +2888,20 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, in
                 po.dkey[i] = key2;
                 po.gid[i] = (uint32_t)i;
             }
+            K9_T(4);
             if (po.dh.ghist) {
                 // the depth sort's digit counts of this block's 128 keys (all in one run: 128 divides the sort's tile): four
                 // 256-entry tables in the SH tile, which nobody reads any more; then one global add per non-empty bin
-                __syncthreads();
+                lds_barrier();
                 uint32_t* h = reinterpret_cast<uint32_t*>(s_sh);
 #pragma unroll
                 for (int q = 0; q < 1024 / kPreThreads; q++) h[q * kPreThreads + tid] = 0u;
-                __syncthreads();
+                lds_barrier();
                 if (act) {
 #pragma unroll
                     for (int p = 0; p < 4; p++) atomicAdd(&h[p * 256 + ((key2 >> (8 * p)) & 255u)], 1u);
                 }
-                __syncthreads();
+                lds_barrier();
                 const uint32_t x = (uint32_t)base / onesweep_run_len<uint32_t>((uint32_t)N);
 #pragma unroll
                 for (int q = 0; q < 1024 / kPreThreads; q++) {
@@ -2707,7 +2912,21 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, in
                 for (uint32_t q = blockIdx.x * kPreThreads + tid; q < po.dh.status_words / 4; q += po.dh.clear_threads)
                     reinterpret_cast<uint4*>(po.dh.status)[q] = make_uint4(0u, 0u, 0u, 0u);
             }
+            K9_T(5);
+            K9_T_FLUSH();
             return;
+        }
+        if (i < N) {   // the small groups' update, from the moments requested in front of the streams
+            const size_t gi = (size_t)i;
+            adam_own_apply<3>(const_cast<float*>(means) + 3 * gi, ad.m[0] + 3 * gi, ad.v[0] + 3 * gi, om_mean, own_g, ad.step_size[0], ad.inv_bc2s[0], 0, ad, PREP >= 0 ? nmean : nullptr);
+            adam_own_apply<1>(const_cast<float*>(opac_raw) + gi, ad.m[3] + gi, ad.v[3] + gi, om_op, own_g + 3, ad.step_size[3], ad.inv_bc2s[3], 3, ad, PREP >= 0 ? &nop : nullptr);
+            adam_own_apply<3>(const_cast<float*>(scales) + 3 * gi, ad.m[4] + 3 * gi, ad.v[4] + 3 * gi, om_sc, own_g + 4, ad.step_size[4], ad.inv_bc2s[4], 4, ad, PREP >= 0 ? nsc : nullptr);
+            adam_own_apply<4>(const_cast<float*>(rots) + 4 * gi, ad.m[5] + 4 * gi, ad.v[5] + 4 * gi, om_rq, own_g + 7, ad.step_size[5], ad.inv_bc2s[5], 5, ad, PREP >= 0 ? nrq : nullptr);
+            if (ds.radii && e_rad > 0) {   // what the reference's train_step does with radii and means2D.grad after every backward
+                ds.max_radii[i] = fmaxf(e_ds[0], (float)e_rad);   // (ht3dgs_trainer.py:141-147, gaussian_model_ht.py:718-721): visible = radii > 0
+                ds.grad_accum[i] = e_ds[1] + e_m2dn;
+                ds.denom[i] = e_ds[2] + 1.f;
+            }
         }
         adam_rows(s_sh, kShStride, 0, 3, 3, const_cast<float*>(shs) + b * 3, ad.m[1] + b * 3, ad.v[1] + b * 3, nG, tid, ad.step_size[1], ad.inv_bc2s[1], 1, ad);
         if (DEG == 0 && !ad.m[2]) {}   // f_rest skipped: see GsrFusedAdam
@@ -3066,6 +3285,13 @@ int gsr_prepare_supported(int32_t M, int32_t D, int32_t raw_params) { return (ra
 const char* gsr_last_error(void) { return g_err; }
 int gsr_version(void) { return 100; }
 
+#ifdef GSR_K9_TIMING
+int gsr_debug_k9_timing(unsigned long long* host_dst, int reset)
+{
+    (void)reset;
+    return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_k9_dbg), sizeof(unsigned long long) * 8 * kK9DbgWaves);
+}
+#endif
 #ifdef GSR_DB_TIMING
 int gsr_debug_db_timing(unsigned long long* host_dst) { return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_db_dbg), sizeof(unsigned long long) * 16); }
 #endif

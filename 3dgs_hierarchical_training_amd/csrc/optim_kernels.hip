@@ -36,6 +36,32 @@ __global__ __launch_bounds__(kAdamThreads) void k_adam(AdamBatch B)
     const uint64_t base = (uint64_t)(blockIdx.x - B.block_start[ti]) * kAdamChunk;
     const float step_size = t.lr / B.bc1, inv_bc2s = 1.f / B.bc2_sqrt;
     const bool aligned = ((((uintptr_t)t.param | (uintptr_t)t.grad | (uintptr_t)t.exp_avg | (uintptr_t)t.exp_avg_sq) & 15) == 0);
+    // whole, aligned chunks: the four turns' sixteen loads are requested before the first turn is computed (the update is in place, so
+    // the compiler must take a later turn's loads for may-aliases of an earlier turn's stores and, left to itself, runs the turns one
+    // memory round trip after the other -- vmcnt counts loads and stores alike on gfx9)
+    if (aligned && base + kAdamChunk <= t.n) {
+        float4 p[4], g[4], m[4], v[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const uint64_t i = base + (uint64_t)(r * kAdamThreads + threadIdx.x) * kAdamVec;
+            p[r] = nt_load4(reinterpret_cast<const float4*>(t.param + i));
+            g[r] = nt_load4(reinterpret_cast<const float4*>(t.grad + i));
+            m[r] = nt_load4(reinterpret_cast<const float4*>(t.exp_avg + i));
+            v[r] = nt_load4(reinterpret_cast<const float4*>(t.exp_avg_sq + i));
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const uint64_t i = base + (uint64_t)(r * kAdamThreads + threadIdx.x) * kAdamVec;
+            adam_one(p[r].x, g[r].x, m[r].x, v[r].x, B.beta1, B.beta2, B.eps, step_size, inv_bc2s);
+            adam_one(p[r].y, g[r].y, m[r].y, v[r].y, B.beta1, B.beta2, B.eps, step_size, inv_bc2s);
+            adam_one(p[r].z, g[r].z, m[r].z, v[r].z, B.beta1, B.beta2, B.eps, step_size, inv_bc2s);
+            adam_one(p[r].w, g[r].w, m[r].w, v[r].w, B.beta1, B.beta2, B.eps, step_size, inv_bc2s);
+            nt_store4(reinterpret_cast<float4*>(t.param + i), p[r]);
+            nt_store4(reinterpret_cast<float4*>(t.exp_avg + i), m[r]);
+            nt_store4(reinterpret_cast<float4*>(t.exp_avg_sq + i), v[r]);
+        }
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const uint64_t i = base + (uint64_t)(r * kAdamThreads + threadIdx.x) * kAdamVec;
