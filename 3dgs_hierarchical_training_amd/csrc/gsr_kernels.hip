@@ -1895,9 +1895,19 @@ struct BlendBwdArgs {
     const uint2* items;
 };
 
+#ifdef GSR_K8_PHASES   // experiment build only (tools/k8_phases.sh): where a wave of the backward blend spends its time
+__device__ unsigned long long g_k8ph[8192 * 8];   // [wave of the last launch][phase]
+#define K8_T(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); k8t[k] += now_ - k8t_last; k8t_last = now_; } while (0)
+#else
+#define K8_T(k) do { } while (0)
+#endif
 template <bool HAS_DA>
 __global__ __launch_bounds__(128) void k_blend_bwd2(BlendBwdArgs args_)
 {
+#ifdef GSR_K8_PHASES
+    unsigned long long k8t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, k8t_last = __builtin_readcyclecounter();
+    k8t[6] = k8t_last;
+#endif
     constexpr int NT = 128, NV = HAS_DA ? 10 : 9;   // (two waves per workgroup)
     // single staging buffer: a batch is ~10^4 cycles of compute, so the second barrier per batch is free, and the
     // smaller LDS footprint lets more tiles share a CU (latency hiding: waves were 33% in s_waitcnt / barriers)
@@ -1963,7 +1973,13 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(BlendBwdArgs args_)
     // ---- next item -------------------------------------------------------------------------------------------------------
     uint32_t qcount = hdr->count[qx];
     while (qi >= qcount) {           // (workgroup-uniform: qi and qx are)
-        if (++tried == 8) return;
+        if (++tried == 8) {
+#ifdef GSR_K8_PHASES
+            const uint32_t w_ = blockIdx.x * 2u + (threadIdx.x >> 6);
+            if ((threadIdx.x & 63) == 0 && w_ < 8192u) { k8t[7] = __builtin_readcyclecounter(); for (int q_ = 0; q_ < 8; q_++) g_k8ph[w_ * 8 + q_] = k8t[q_]; }
+#endif
+            return;
+        }
         qx = (qx + 1) & 7;
         qcount = hdr->count[qx];
         qi = 0xffffffffu;
@@ -1978,6 +1994,7 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(BlendBwdArgs args_)
         __syncthreads();
     }
     const uint2 item = ka->items[hdr->offset[qx] + qi];
+    K8_T(0);   // pull / list bookkeeping
 #ifdef GSR_K6_TIMING
     const uint32_t dbg_slot = qi < 8192u ? (uint32_t)qx * 8192u + qi : 65536u;   // (probe table: 8 lists x 8 192 items)
     if (tid == 0 && dbg_slot < 65536) { g_k8_dbg[4 * (size_t)dbg_slot] = wall_clock64(); g_k8_dbg[4 * (size_t)dbg_slot + 1] = 0ull; }
@@ -2054,6 +2071,7 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(BlendBwdArgs args_)
         }
     }
 
+    K8_T(1);   // pixel state in (planes, upstream gradients, checkpoint) + the two barriers
     float4 ra = {0, 0, 0, 0}, rb = ra, rc = ra;
     uint32_t rg_id = 0;
     // the staged copy carries the conic pre-multiplied for the exponent in base 2, exactly as k_blend_fwd_w stages it
@@ -2066,10 +2084,33 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(BlendBwdArgs args_)
     // (wave, instance) iterations were such misses).  rc.w (Splat::tiles, unused by the blend) carries the two bits.
     const float hbx0 = (float)(tx * kTile) - 0.5f * (float)W, hbx1 = fminf(hbx0 + (float)(kTile - 1), (float)(W - 1) - 0.5f * (float)W);
     const float hby0 = (float)(ty * kTile) - cyf, hbyL = (float)(H - 1) - cyf;
-    auto stage = [&](int idx) {
-        rg_id = list[rg.x + idx];
-        const float4* sp = reinterpret_cast<const float4*>(splat + rg_id);
-        ra = sp[0]; rb = sp[1]; rc = sp[2];
+    // Round 5: the two-level gather (list -> record) of a batch is REQUESTED one batch ahead and first TOUCHED at the top of the batch that
+    // stages it.  Until now `stage(next)` sat behind the barrier with its arithmetic (the box tests of the reach bits) right behind its
+    // loads, so hipcc put `s_waitcnt vmcnt(0)` -- two dependent memory round trips, index then record -- in front of every batch's
+    // visits (the forward blend had the same fault until round 3).  Now the record of batch b + 1 is requested with an index that was
+    // itself requested during batch b - 1, and nothing between the requests and the next batch's top reads either.
+    uint32_t id_nxt = 0u;     // list entry of this thread's instance in the batch after the one in (ra, rb, rc)
+    bool pend = false;        // (ra, rb, rc) hold a raw record that stage_finish has not yet turned into its staged form
+    // (EVERY lane requests, a lane without an instance from a clamped position: behind a divergent branch the loaded registers meet the
+    //  old ones at a join, hipcc copies them there, and the copy waits for the load)
+    auto stage_request = [&](uint32_t id, bool want) {
+        rg_id = id;
+        // three whole 16-byte loads into three aligned register quads: left to itself hipcc trims the record's unused words away and
+        // lands a lone dword in a register whose neighbour is the broadcast operand of a packed instruction of the visit -- which then
+        // waits for the load (`v_pk_fma v[38:39], v[28:29], ...` with the load's v29 in flight)
+        typedef float vf4 __attribute__((ext_vector_type(4)));
+        const vf4* sp = reinterpret_cast<const vf4*>(splat + id);
+        const vf4 q0 = sp[0], q1 = sp[1], q2 = sp[2];
+        ra = make_float4(q0.x, q0.y, q0.z, q0.w); rb = make_float4(q1.x, q1.y, q1.z, q1.w); rc = make_float4(q2.x, q2.y, q2.z, q2.w);
+        pend = want;
+    };
+    auto list_at = [&](int idx) -> uint32_t { return list[rg.x + (uint32_t)min(idx, n - 1)]; };
+    auto stage_finish = [&]() {
+#if defined(__HIP_DEVICE_COMPILE__)
+        // the record's two words the blend does not read stay "used" until here: a register the allocator takes for dead it hands to the
+        // visit loop as a temporary, and writing it waits for the load that is still filling its quad
+        asm volatile("" :: "v"(rb.z), "v"(rc.z));
+#endif
         const TileTest tt = make_tile_test(ra.x, ra.y, ra.z, ra.w, rb.x, rb.y);
         uint32_t fl = 0u;
         if (hby0 <= hbyL) fl |= box_accept(tt, hbx0, hby0, hbx1, fminf(hby0 + 7.f, hbyL)) ? 1u : 0u;
@@ -2080,16 +2121,20 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(BlendBwdArgs args_)
         }
         rc.w = __uint_as_float(fl);
         ra.z *= -0.5f * kL2E; ra.w *= -kL2E; rb.x *= -0.5f * kL2E;
+        pend = false;
     };
-    if (b0 * NT + tid < n) stage(b0 * NT + tid);
+    stage_request(list_at(b0 * NT + tid), b0 * NT + tid < n);
+    id_nxt = list_at((b0 + 1) * NT + tid);
     for (int b = b0; b < b1; b++) {
         const int buf = 0;
         if (b > b0) __syncthreads();   // everyone is done reading the previous batch (and its flush read s_gid)
+        if (pend) stage_finish();      // first touch of the record requested a batch ago
         s_ab[0][tid] = ra; s_ab[1][tid] = make_float4(rb.x, rb.y, rb.w, rc.x); s_gid[buf][tid] = rg_id;
         if constexpr (HAS_DA) s_c[tid] = make_float4(rc.y, rc.w, rb.z, 0.f); else s_c[tid] = make_float2(rc.y, rc.w);
         __syncthreads();
-        const int nxt = (b + 1) * NT + tid;
-        if (nxt < n && b + 1 < b1) stage(nxt);
+        stage_request(id_nxt, (b + 1) * NT + tid < n && b + 1 < b1);   // (its index arrived during the last batch)
+        id_nxt = list_at((b + 2) * NT + tid);
+        K8_T(2);   // staging: wait for the record, box tests, LDS, barriers, next requests
         const int cnt = min(NT, n - b * NT);
         // a wave only walks as far as ITS pixels' last contributor (the tile-wide n bounds the staging and the barriers)
         const int cntw = min(cnt, nw - b * NT);
@@ -2179,7 +2224,9 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(BlendBwdArgs args_)
                 if (part_slot >= 0) atomicAdd(&(&s_part[0][0])[part_off + row], t);
             }
         }
+        K8_T(3);   // visits
         __syncthreads();
+        K8_T(4);   // barrier behind the visits (waiting for the other wave)
         // flush: 16 lanes per Gaussian, lane r adds component r, so one atomic instruction touches 8 records of
         // 9-10 CONSECUTIVE floats (8 cache lines per wave instruction) instead of 64 scattered records -- device-scope
         // float atomics are fabric transactions on this chip, and they were 27% of this kernel when issued one
@@ -2204,6 +2251,7 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(BlendBwdArgs args_)
                 }
             }
         }
+        K8_T(5);   // flush
     }
 #ifdef GSR_K6_TIMING
     if (threadIdx.x == 0 && dbg_slot < 65536) {
@@ -3285,6 +3333,12 @@ int gsr_prepare_supported(int32_t M, int32_t D, int32_t raw_params) { return (ra
 const char* gsr_last_error(void) { return g_err; }
 int gsr_version(void) { return 100; }
 
+#ifdef GSR_K8_PHASES
+int gsr_debug_k8_phases(unsigned long long* host_dst) { return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_k8ph), sizeof(unsigned long long) * 8 * 8192); }
+#endif
+#ifdef GSR_OS_TIMING
+int gsr_debug_os_timing(unsigned long long* host_dst) { return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_os_dbg), sizeof(unsigned long long) * 8 * 4096); }
+#endif
 #ifdef GSR_K9_TIMING
 int gsr_debug_k9_timing(unsigned long long* host_dst, int reset)
 {
@@ -3366,7 +3420,8 @@ static bool direct_bin_geometry(int N, int T, DirectBin& db, DirectBinScratch& d
 {
     if (N < 1 || T < 1) return false;
     db.NS = 1; db.Ts = 0; db.Tsp = 0; db.slab_rows = 0;
-    if (T > kDbMaxTiles) {   // slabs of whole tile rows
+    static const bool force_slabs = getenv("GSR_DB_FORCE_SLABS") != nullptr;   // (experiments: the slabbed scatter on a frame that fits one wave's tables)
+    if (T > kDbMaxTiles || (force_slabs && g_db_slab_tiles > 0 && tiles_x > 0 && tile_rows > 0 && tiles_x * tile_rows == T)) {   // slabs of whole tile rows
         if (g_db_slab_tiles <= 0 || tiles_x <= 0 || tile_rows <= 0 || tiles_x * tile_rows != T || tiles_x > kDbMaxTiles || T > 32768) return false;
         const int rows = std::max(1, std::min(g_db_slab_tiles, kDbMaxTiles) / tiles_x);
         db.slab_rows = rows; db.Ts = rows * tiles_x; db.Tsp = (db.Ts + 63) & ~63; db.NS = (tile_rows + rows - 1) / rows;

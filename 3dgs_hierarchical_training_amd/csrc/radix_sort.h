@@ -417,6 +417,12 @@ constexpr int kOsTile = 4096;
 
 // NB = digit table size: 256, or 64 when the digits of the sort are at most 6 bits wide (a quarter of the LDS tables:
 // five instead of three workgroups per CU for 16-bit keys).  Status words keep their 256-word stride in memory.
+#ifdef GSR_OS_TIMING   // experiment build only (tools/os_timing.sh): where a workgroup of a sort pass spends its time
+__device__ unsigned long long g_os_dbg[4096 * 8];   // [workgroup of the last u32 launch][phase]
+#define OS_T(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); if (threadIdx.x == 0) ost[k] += now_ - ost_last; ost_last = now_; } while (0)
+#else
+#define OS_T(k) do { } while (0)
+#endif
 template <typename KeyT, int NB>
 __global__ __launch_bounds__(OsCfg<KeyT>::kThreads) void k_onesweep(const KeyT* __restrict__ kin, const uint32_t* __restrict__ vin,
                                                          KeyT* __restrict__ kout, uint32_t* __restrict__ vout, uint32_t n, int shift,
@@ -442,6 +448,10 @@ __global__ __launch_bounds__(OsCfg<KeyT>::kThreads) void k_onesweep(const KeyT* 
     __shared__ uint32_t s_wsum[kOsWaves];
     __shared__ uint32_t s_tile;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+#ifdef GSR_OS_TIMING
+    unsigned long long ost[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ost_last = __builtin_readcyclecounter();
+    ost[6] = ost_last;
+#endif
     // ticket == nullptr: the whole grid is co-resident (host checked), so blockIdx order is as good as ticket order and
     // the ~2 us global-atomic round trip at the head of every block's latency chain is saved
     // The FIRST pass cuts the key array into eight runs of tiles with their own look-back chains (run = blockIdx & 7): the
@@ -474,8 +484,10 @@ __global__ __launch_bounds__(OsCfg<KeyT>::kThreads) void k_onesweep(const KeyT* 
             key[r] = (KeyT)~(KeyT)0; val[r] = 0u; dig[r] = (uint32_t)(NB - 1);
         }
     }
+    OS_T(0);   // keys requested (their first use is inside the ranking)
     wave_rank<kOsIPT, NB>(s_mask[wave], s_cnt[wave], dig, rnk, lane);
     __syncthreads();
+    OS_T(1);   // loads landed + ranking + barrier
     // threads 0..255 = digits (the upper half of the block only takes part in the barriers of the scans)
     const bool is_digit = tid < NB;
     uint32_t mine = 0;   // this tile's count of digit `tid` (padding counted in digit 255; removed below)
@@ -502,6 +514,7 @@ __global__ __launch_bounds__(OsCfg<KeyT>::kThreads) void k_onesweep(const KeyT* 
         }
     }
     const uint32_t dbase = block_scan_excl<kOsWaves>(gtot, s_wsum, tid) + gpre;
+    OS_T(2);   // publish + the two block scans
     if (is_digit) {
         // decoupled look-back over earlier tiles
         // (windows of 4 independent loads: the walk is a chain of L2 round trips, and the chain is what a block waits on)
@@ -536,6 +549,7 @@ __global__ __launch_bounds__(OsCfg<KeyT>::kThreads) void k_onesweep(const KeyT* 
         s_gbase[tid] = dbase + excl - lstart;
     }
     __syncthreads();
+    OS_T(3);   // look-back (thread 0 is a digit thread) + barrier
 #pragma unroll
     for (int r = 0; r < kOsIPT; r++) {
         const uint32_t lp = s_start[dig[r]] + s_cnt[wave][dig[r]] + rnk[r];
@@ -543,6 +557,7 @@ __global__ __launch_bounds__(OsCfg<KeyT>::kThreads) void k_onesweep(const KeyT* 
         s_vals[lp] = val[r];
     }
     __syncthreads();
+    OS_T(4);   // the tile in digit order in LDS
 #pragma unroll
     for (int r = 0; r < kOsIPT; r++) {
         const uint32_t p = r * kOsThreads + tid;
@@ -554,6 +569,10 @@ __global__ __launch_bounds__(OsCfg<KeyT>::kThreads) void k_onesweep(const KeyT* 
             vout[g] = s_vals[p];
         }
     }
+#ifdef GSR_OS_TIMING
+    OS_T(5);
+    if (tid == 0 && sizeof(KeyT) == 4 && blockIdx.x < 4096) { ost[7] = ost_last; for (int q = 0; q < 8; q++) g_os_dbg[blockIdx.x * 8 + q] = ost[q]; }
+#endif
 }
 
 inline size_t onesweep_scratch_bytes(uint32_t n)
