@@ -1612,6 +1612,8 @@ __device__ __forceinline__ void blend_fwd_item(const int xcd, const int kslot, f
     for (int b = 0; b < nb; b++) {
         const int buf = b & 1;
         if (__all(Tr < 0.f)) break;
+        // (round 5, measured and not kept: the six stores moved behind the staging, so that they do not sit between the batch's record
+        //  loads and their first use in the wave's in-order vmcnt queue -- 98-100 us against 97)
         if (ckpt && !(b & 1) && (b >> 1) >= kCkptFirst) {   // 128-instance boundary deep in a long list: checkpoint
             float* c = ckpt + ((size_t)(rg.x >> 7) + tile + (b >> 1) - kCkptFirst) * kCkptFloats + sub * 64 + lane;
             c[0] = fabsf(Tr); c[256] = C0; c[512] = C1; c[768] = C2; c[1024] = Dd; c[1280] = Aa;

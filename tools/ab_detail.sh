@@ -1,6 +1,6 @@
 D=3dgs_hierarchical_training_amd/csrc
 cp $D/libgsr_hip.so /tmp/cur.so
-for r in 1 2 3 4; do for w in old new; do
+for r in 1 2 3 4 5 6; do for w in old new; do
 cp gpurun_libs/lib_$w.so $D/libgsr_hip.so
 timeout 600 python bench.py --steps 60 --warmup 5 --no-cpu-baseline --no-extras 2>/dev/null | python -c "
 import sys, json
