@@ -355,18 +355,29 @@ __global__ __launch_bounds__(256) void k_radix_ghist(const KeyT* __restrict__ ke
     const uint32_t len = (uint32_t)(hi - lo);
     const uint32_t nv = (((uintptr_t)kr & 15) == 0) ? len / KPV : 0u;
     const uint4* k4 = reinterpret_cast<const uint4*>(kr);
-    for (uint32_t i = sub * 256 + tid; i < nv; i += bpr * 256) {
-        const uint4 q = k4[i];
-        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+    // four 16-byte loads in flight per thread (round 5: the loop's trip count is a run-time value, hipcc does not unroll it, and each
+    // turn was a memory round trip of its own in a kernel that has four of them per thread at 1 M keys)
+    for (uint32_t i0 = sub * 256 + tid; i0 < nv; i0 += 4u * bpr * 256u) {
+        uint4 qq[4];
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
+        for (int u = 0; u < 4; u++) {
+            const uint32_t i = i0 + (uint32_t)u * bpr * 256u;
+            qq[u] = k4[i < nv ? i : i0];
+        }
 #pragma unroll
-            for (int e = 0; e < KPV / 4; e++) {
-                const uint32_t kraw = (uint32_t)(sizeof(KeyT) == 4 ? w[c] : ((w[c] >> (16 * e)) & 0xffffu));
-                beyond |= (kraw - bias > kclamp) && kraw != (uint32_t)(KeyT)~(KeyT)0;
-                const uint32_t k = min(kraw - bias, kclamp) >> begin_bit;
+        for (int u = 0; u < 4; u++) {
+            if (i0 + (uint32_t)u * bpr * 256u >= nv) break;
+            const uint32_t w[4] = {qq[u].x, qq[u].y, qq[u].z, qq[u].w};
 #pragma unroll
-                for (int p = 0; p < PASSES; p++) atomicAdd(&h[p][(k >> (dbits * p)) & dmask[p]], 1u);
+            for (int c = 0; c < 4; c++) {
+#pragma unroll
+                for (int e = 0; e < KPV / 4; e++) {
+                    const uint32_t kraw = (uint32_t)(sizeof(KeyT) == 4 ? w[c] : ((w[c] >> (16 * e)) & 0xffffu));
+                    beyond |= (kraw - bias > kclamp) && kraw != (uint32_t)(KeyT)~(KeyT)0;
+                    const uint32_t k = min(kraw - bias, kclamp) >> begin_bit;
+#pragma unroll
+                    for (int p = 0; p < PASSES; p++) atomicAdd(&h[p][(k >> (dbits * p)) & dmask[p]], 1u);
+                }
             }
         }
     }
