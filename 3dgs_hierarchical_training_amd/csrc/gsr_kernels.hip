@@ -2442,7 +2442,7 @@ __device__ __forceinline__ void adam_rows_lin_piped(float* s_g, float* p, float*
     for (int k = 0; k < D && k < NE; k++) {
         const int q = tid + k * kPreThreads;
         if ((k + 1) * kPreThreads <= total4 || q < total4) {
-            P[k] = p4[q];
+            P[k] = p4[q];   // (a second fetch of these rows -- the tile that held them carries the gradients now; timed with the fetch left out: 302 -> 295 us)
             if (k < KP) { M[k] = pm[k]; V[k] = pv[k]; }
             else { M[k] = nt_load4(m4 + q); V[k] = nt_load4(v4 + q); }
         }
@@ -3340,6 +3340,7 @@ int gsr_debug_k8_phases(unsigned long long* host_dst) { return (int)hipMemcpyFro
 #endif
 #ifdef GSR_OS_TIMING
 int gsr_debug_os_timing(unsigned long long* host_dst) { return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_os_dbg), sizeof(unsigned long long) * 8 * 4096); }
+int gsr_debug_gh_timing(unsigned long long* host_dst) { return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_gh_dbg), sizeof(unsigned long long) * 8 * 512); }
 #endif
 #ifdef GSR_K9_TIMING
 int gsr_debug_k9_timing(unsigned long long* host_dst, int reset)

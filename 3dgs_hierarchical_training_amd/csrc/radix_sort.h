@@ -318,6 +318,9 @@ struct OsRider {
 };
 __device__ __forceinline__ void onesweep_rider_publish(const OsRider& rd, unsigned long long (*s_r)[16]);
 
+#ifdef GSR_OS_TIMING
+__device__ unsigned long long g_gh_dbg[512 * 8];   // [workgroup of the last histogram launch][phase]
+#endif
 // GS = stride of the digit tables (256; 512 for 9-bit digits).  bias / kclamp: the digit is taken of min(key - bias, kclamp)
 // (0 / all ones: of the key); a key beyond the window that is not the all-ones padding key is counted in *overflow.
 template <typename KeyT, int PASSES, int GS = 256>
@@ -327,10 +330,18 @@ __global__ __launch_bounds__(256) void k_radix_ghist(const KeyT* __restrict__ ke
                                                      uint32_t* __restrict__ status, uint32_t status_words, int dbits, int bits, uint32_t bias = 0u,
                                                      uint32_t kclamp = 0xffffffffu, unsigned int* __restrict__ overflow = nullptr, OsRider rider = OsRider{})
 {
+#ifdef GSR_OS_TIMING
+    unsigned long long ght[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ght_last = __builtin_readcyclecounter();
+    ght[6] = ght_last;
+#define GH_T(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); ght[k] += now_ - ght_last; ght_last = now_; } while (0)
+#else
+#define GH_T(k) do { } while (0)
+#endif
     if (rider.host && blockIdx.x == gridDim.x - 1) {   // (block-uniform)
         __shared__ unsigned long long s_r[2][16];
         onesweep_rider_publish(rider, s_r);
     }
+    GH_T(0);   // rider (last block only)
     // digit p covers key bits [dbits p, min(dbits (p + 1), bits)) above begin_bit (<= 8 wide: the tables keep 256 entries)
     uint32_t dmask[PASSES];
 #pragma unroll
@@ -346,6 +357,7 @@ __global__ __launch_bounds__(256) void k_radix_ghist(const KeyT* __restrict__ ke
     for (int p = 0; p < PASSES; p++)
         for (int d = tid; d < GS; d += 256) h[p][d] = 0;
     __syncthreads();
+    GH_T(1);   // status clear issued, tables zeroed
     constexpr uint64_t kT = (uint64_t)OsCfg<KeyT>::kTile;
     const uint64_t ntiles = ((uint64_t)n + kT - 1) / kT, per = (ntiles + kOsRanges - 1) / kOsRanges;
     const uint32_t bpr = gridDim.x / kOsRanges, x = blockIdx.x / bpr, sub = blockIdx.x - x * bpr;
@@ -389,17 +401,37 @@ __global__ __launch_bounds__(256) void k_radix_ghist(const KeyT* __restrict__ ke
         for (int p = 0; p < PASSES; p++) atomicAdd(&h[p][(k >> (dbits * p)) & dmask[p]], 1u);
     }
     if (overflow && __any(beyond) && (threadIdx.x & 63) == 0) atomicAdd(overflow, 1u);
+    GH_T(2);   // keys counted into LDS
     __syncthreads();
+    GH_T(3);
 #pragma unroll
     for (int p = 0; p < PASSES; p++)
         for (int d = tid; d < GS; d += 256)
             if (h[p][d]) atomicAdd(&ghist[(p * kOsRanges + x) * GS + d], h[p][d]);
+#ifdef GSR_OS_TIMING
+    GH_T(4);   // global adds issued
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    GH_T(5);   // ... and acknowledged
+    if (tid == 0 && blockIdx.x < 512) { ght[7] = ght_last; for (int q = 0; q < 8; q++) g_gh_dbg[blockIdx.x * 8 + q] = ght[q]; }
+#endif
 }
 
 __device__ __forceinline__ void onesweep_rider_publish(const OsRider& rd, unsigned long long (*s_r)[16])
 {
     unsigned long long a = 0ull, b = 0ull;
-    for (uint32_t q = threadIdx.x; q < rd.nparts; q += blockDim.x) { const uint2 v = rd.parts[q]; a += v.x; b += v.y; }
+    // eight loads in flight per thread: this workgroup alone sums the producer's per-block shares (7 813 of them at 1 M Gaussians), the
+    // plain loop ran one memory round trip per turn -- 31 in a row -- and the whole histogram launch waited for it (14 us where its
+    // other workgroups take 6: tools/os_timing.sh)
+    for (uint32_t q0 = threadIdx.x; q0 < rd.nparts; q0 += 8u * blockDim.x) {
+        uint2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const uint32_t q = q0 + (uint32_t)u * blockDim.x;
+            v[u] = q < rd.nparts ? rd.parts[q] : make_uint2(0u, 0u);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) { a += v[u].x; b += v[u].y; }
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off, 64); b += __shfl_xor(b, off, 64); }
     if ((threadIdx.x & 63u) == 0u) { s_r[0][threadIdx.x >> 6] = a; s_r[1][threadIdx.x >> 6] = b; }

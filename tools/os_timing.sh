@@ -37,6 +37,14 @@ print(f"  workgroup lifetime mean {life.mean():.0f} p10 {np.percentile(life, 10)
 print(f"  start offsets: p50 {np.percentile(a[:, 6] - t0, 50):.0f} p90 {np.percentile(a[:, 6] - t0, 90):.0f} max {(a[:, 6] - t0).max():.0f}")
 for k, n in enumerate(names):
     print(f"  {n:40s} mean {a[:, k].mean():8.0f}  p90 {np.percentile(a[:, k], 90):8.0f}  max {a[:, k].max():8.0f}")
+gb = (ctypes.c_ulonglong * (8 * 512))()
+raw.gsr_debug_gh_timing(gb)
+g = np.frombuffer(gb, dtype=np.uint64).reshape(512, 8).astype(np.float64)
+g = g[g[:, 7] > 0]
+gl = g[:, 7] - g[:, 6]
+print(f"histogram kernel: {len(g)} workgroups; lifetime mean {gl.mean():.0f} p10 {np.percentile(gl, 10):.0f} p90 {np.percentile(gl, 90):.0f} max {gl.max():.0f}")
+for k, n in enumerate(["rider (last workgroup)", "status clear issued + tables zeroed", "keys counted into LDS", "barrier", "global adds issued", "global adds acknowledged"]):
+    print(f"  {n:40s} mean {g[:, k].mean():8.0f}  p90 {np.percentile(g[:, k], 90):8.0f}  max {g[:, k].max():8.0f}")
 q = np.argsort(a[:, 7])[-5:]
 print("  last five to finish: workgroup, start, end, look-back ticks:", [(int(i), int(a[i, 6] - t0), int(a[i, 7] - t0), int(a[i, 3])) for i in q])
 PY
