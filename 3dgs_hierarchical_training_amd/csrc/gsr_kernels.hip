@@ -1134,12 +1134,21 @@ __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x)
 #endif
 }
 
+// sorted_gid == nullptr (the tile-sort route, round 5): the chunks cut the Gaussians in INDEX order -- no depth sort in front of the
+// binning; the tile lists then come out in index order and k_tile_sort orders each by depth -- the records are read where they lie (no
+// gather, no sorted copy) and the launch's last workgroup carries the rider that publishes R (radix_sort.h OsRider: on the other route
+// it rides on the depth sort's first kernel).
 __global__ __launch_bounds__(kEmitThreads) void k_chunk_counts(DirectBin db, int W, int H, int tiles_x, int tiles_y,
                                                                const uint32_t* __restrict__ sorted_gid, const TileRec* __restrict__ tilerec,
-                                                               const Splat* __restrict__ splat, TileRec* __restrict__ sorted_rec, BlendBalance bb)
+                                                               const Splat* __restrict__ splat, TileRec* __restrict__ sorted_rec, BlendBalance bb,
+                                                               OsRider rider = OsRider{})
 {
     const int nbuild = bb.hdr ? 8 : 0, c = (int)blockIdx.x - nbuild;
     if (c < 0) { balance_build(bb, (int)blockIdx.x); return; }
+    if (rider.host && blockIdx.x == gridDim.x - 1) {   // (block-uniform)
+        __shared__ unsigned long long s_r[2][16];
+        onesweep_rider_publish(rider, s_r);
+    }
     // one workgroup per chunk: its four waves take the chunk's steps of 64 Gaussians in turn and count into ONE table (adds commute)
     extern __shared__ uint32_t s_h[];           // [Tp / 2]: two u16 counters per word (a chunk holds fewer than 65 536 Gaussians)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1148,7 +1157,7 @@ __global__ __launch_bounds__(kEmitThreads) void k_chunk_counts(DirectBin db, int
     const int j0 = c * db.S + wave * 64, j1 = min(db.N, c * db.S + db.S);
     constexpr int kStride = 64 * kDbCountWaves;
     // two loads ahead: the index of this wave's step after next and the record of its next step are in flight while a step is counted
-    auto load_gid = [&](int j) -> uint32_t { return j < j1 ? sorted_gid[j] : 0xffffffffu; };
+    auto load_gid = [&](int j) -> uint32_t { return j < j1 ? (sorted_gid ? sorted_gid[j] : (uint32_t)j) : 0xffffffffu; };
     auto load_rec = [&](uint32_t g) -> TileRec { TileRec r; r.mask = 0u; r.rect = 1u << 24; if (g != 0xffffffffu) r = tilerec[g]; return r; };
     uint32_t gA = load_gid(j0 + lane), gB = load_gid(j0 + kStride + lane);
     TileRec rA = load_rec(gA);
@@ -1158,7 +1167,7 @@ __global__ __launch_bounds__(kEmitThreads) void k_chunk_counts(DirectBin db, int
         gA = gB;
         rA = load_rec(gA);
         gB = load_gid(j + 2 * kStride);
-        if (j < j1) sorted_rec[j] = r;
+        if (sorted_rec && j < j1) sorted_rec[j] = r;
         const bool big = (r.rect & kTileRecBig) != 0u;
         if (!big) small_rect_tiles(r, tiles_x, [&](uint32_t t) { atomicAdd(&s_h[t >> 1], 1u << (16u * (t & 1u))); });
         for (unsigned long long bm = __ballot(big && r.mask != 0u); bm != 0ull; bm &= bm - 1ull) {
@@ -1291,11 +1300,14 @@ __device__ unsigned long long g_db_dbg[16];   // s_memtime ticks per part, summe
 // the record is loaded (whole tile rows: a contiguous bit range), a large rect is always walked outside the pair buffer (its count
 // inside a slab is not known without the walk) with its tiles tested against the slab.  Every tile belongs to one slab and the
 // chunks of a slab are the chunks of the frame, so the list is the same list.
-template <bool SLAB>
+// PAIRS (the tile-sort route, round 5): the chunks cut the Gaussians in index order (sorted_gid == nullptr, sorted_rec = the records where
+// the preprocess left them) and what is placed is the PAIR (depth key, Gaussian) -- eight bytes per store instead of four -- into
+// `pairs`; k_tile_sort orders every tile's pairs by key and writes the list.
+template <bool SLAB, bool PAIRS = false>
 __global__ __launch_bounds__(64) void k_chunk_scatter(DirectBin db, int W, int H, int tiles_x, int tiles_y,
                                                       const uint32_t* __restrict__ sorted_gid, const TileRec* __restrict__ sorted_rec,
                                                       const Splat* __restrict__ splat, uint32_t* __restrict__ list, uint2* __restrict__ ranges,
-                                                      uint32_t cap)
+                                                      uint32_t cap, const uint32_t* __restrict__ dkey = nullptr, uint2* __restrict__ pairs = nullptr)
 {
     extern __shared__ unsigned long long s_dyn[];
     const int LT = SLAB ? db.Tsp : db.Tp;                                      // tiles this wave keeps tables for
@@ -1347,17 +1359,21 @@ __global__ __launch_bounds__(64) void k_chunk_scatter(DirectBin db, int W, int H
     DB_T(0);
     const unsigned long long me = 1ull << lane, lt = lanemask_lt();
     const int j0 = c * db.S, j1 = min(db.N, j0 + db.S);
-    auto load_gid = [&](int j) -> uint32_t { return j < j1 ? sorted_gid[j] : 0u; };
+    auto load_gid = [&](int j) -> uint32_t { return j < j1 ? (PAIRS ? (uint32_t)j : sorted_gid[j]) : 0u; };
     auto load_rec = [&](int j) -> TileRec { TileRec r; r.mask = 0u; r.rect = 1u << 24; if (j < j1) r = sorted_rec[j]; return r; };
+    auto load_key = [&](int j) -> uint32_t { return (PAIRS && j < j1) ? dkey[j] : 0u; };
     // two steps of loads in flight (a sorted record arrives from HBM after ~1.5 us under this kernel's traffic)
     uint32_t gA = load_gid(j0 + lane), gB = load_gid(j0 + 64 + lane);
     TileRec rA = load_rec(j0 + lane), rB = load_rec(j0 + 64 + lane);
+    uint32_t kA = load_key(j0 + lane), kB = load_key(j0 + 64 + lane);
     for (int j = j0 + lane; j - lane < j1; j += 64) {
         const uint32_t g = gA;
         TileRec r = rA;
-        gA = gB; rA = rB;
+        const uint32_t kd = kA;   // (PAIRS) this lane's Gaussian's depth key
+        gA = gB; rA = rB; kA = kB;
         gB = load_gid(j + 128);
         rB = load_rec(j + 128);
+        kB = load_key(j + 128);
         if (SLAB && !(r.rect & kTileRecBig)) {   // the rect's rows inside the slab are a contiguous run of mask bits
             const int ww = (int)((r.rect >> 24) & 63u), ry0 = (int)((r.rect >> 12) & 0xfffu);
             const int lo = min(32, max(0, (srow0 - ry0) * ww)), hi = min(32, max(0, (srow1 - ry0) * ww));
@@ -1419,6 +1435,7 @@ __global__ __launch_bounds__(64) void k_chunk_scatter(DirectBin db, int W, int H
         // the loads of the step after next have had a step and this owner loop to arrive; taken HERE, in front of this step's
         // scattered stores (a wait for a load is a wait for every store issued before it: vmcnt counts both)
         asm volatile("" : "+v"(gA), "+v"(rA.mask), "+v"(rA.rect));   // (the NEXT step's: issued a step ago)
+        if (PAIRS) asm volatile("" : "+v"(kA));
         lds_order();
         DB_T(3);
         // place: the pairs, 64 at a time, four rounds per batch of LDS round trips
@@ -1430,7 +1447,7 @@ __global__ __launch_bounds__(64) void k_chunk_scatter(DirectBin db, int W, int H
                 const uint32_t left = P - p0;
                 auto batch = [&](auto rounds_tag) {
                     constexpr int RN = decltype(rounds_tag)::value;
-                    uint32_t e[RN], go[RN], base[RN];
+                    uint32_t e[RN], go[RN], base[RN], ko[PAIRS ? RN : 1];
                     unsigned long long mk[RN];
 #pragma unroll
                     for (int q = 0; q < RN; q++) e[q] = s_pair[(p0 + 64u * q + (uint32_t)lane) & (uint32_t)(kDbPairs - 1)];   // (in bounds whatever P is)
@@ -1440,6 +1457,7 @@ __global__ __launch_bounds__(64) void k_chunk_scatter(DirectBin db, int W, int H
                         e[q] = v ? e[q] : 0xffffffffu;
                         const uint32_t t = v ? e[q] >> 6 : 0u;
                         go[q] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((e[q] & 63u) << 2), (int)g);   // (every lane: an owner's index is fetched from ITS lane)
+                        if (PAIRS) ko[q] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((e[q] & 63u) << 2), (int)kd);
                         mk[q] = s_mask[t];
                         base[q] = s_cnt[t];
                     }
@@ -1447,7 +1465,10 @@ __global__ __launch_bounds__(64) void k_chunk_scatter(DirectBin db, int W, int H
                     for (int q = 0; q < RN; q++)
                         if (e[q] != 0xffffffffu) {
                             const uint32_t pos = base[q] + (uint32_t)__popcll(mk[q] & ((1ull << (e[q] & 63u)) - 1ull));
-                            if (pos < cap) list[pos] = go[q];   // (plain stores: merged in this XCD's L2; nontemporal ones measured 166 us against 50)
+                            if (pos < cap) {
+                                if (PAIRS) pairs[pos] = make_uint2(ko[q], go[q]);
+                                else list[pos] = go[q];   // (plain stores: merged in this XCD's L2; nontemporal ones measured 166 us against 50)
+                            }
                         }
                 };
                 if (left <= 128u) batch(std::integral_constant<int, 2>{});
@@ -1471,7 +1492,10 @@ __global__ __launch_bounds__(64) void k_chunk_scatter(DirectBin db, int W, int H
                 const uint32_t t = tg - t0;
                 if (ok && t < tn) {
                     const uint32_t pos = s_cnt[t] + (uint32_t)__popcll(s_mask[t] & ((1ull << bl) - 1ull));
-                    if (pos < cap) list[pos] = gg;
+                    if (pos < cap) {
+                        if (PAIRS) pairs[pos] = make_uint2((uint32_t)__builtin_amdgcn_readlane((int)kd, bl), gg);
+                        else list[pos] = gg;
+                    }
                 }
             });
         }
@@ -1521,6 +1545,172 @@ __global__ __launch_bounds__(64) void k_chunk_scatter(DirectBin db, int W, int H
         atomicAdd(&g_db_dbg[7], (unsigned long long)((j1 - j0 + 63) / 64));
     }
 #endif
+}
+
+// ------------------------------------------------------------------------------------------------
+// Tile-sort route (round 5): NO global depth sort.  The direct binning runs over the Gaussians in index order (k_chunk_counts /
+// k_chunk_scatter<.., PAIRS>), every tile's (depth key, Gaussian) pairs land in its segment in index order, and ONE workgroup per tile
+// sorts its segment by key -- stable, so equal keys stay in index order: exactly the order the stable global sort of (key, index) gave
+// the tile, the list is the other routes' list bit for bit.  What it replaces at 1 M Gaussians: a histogram launch and three
+// look-back passes over 1 M keys (71 us, latency-bound: a chain over 245 tiles per pass) and the 8-byte gather of the tile records
+// in depth order; what it costs: 4.5 M pairs sorted where they are, in LDS, by 2 170 independent workgroups.
+// Segments of up to 4 096 pairs are sorted from registers through one LDS buffer (the onesweep passes' ranking, radix_sort.h
+// wave_rank: 8-bit digits, a digit all keys of the tile share is skipped); longer ones go through global memory a chunk at a time
+// (pairs <-> pairs_alt), same passes.
+// ------------------------------------------------------------------------------------------------
+// Two launches share the tiles by length: 256-thread workgroups take the segments of up to 1 024 pairs (one, two or four pairs per
+// thread: a ranking round per pair and pass is what a pass costs), 1 024-thread workgroups the longer ones (up to 4 096 pairs from
+// registers, beyond that a chunk of 4 096 at a time through global memory); a workgroup whose tile belongs to the other launch leaves
+// at once.
+constexpr int kTsCap = 4096, kTsSmallMax = 1024;
+
+template <int THREADS, int IPT>
+__device__ __forceinline__ void tile_sort_regs(const uint2* __restrict__ src, uint32_t* __restrict__ dst, uint32_t n,
+                                               unsigned long long (*s_mask)[256], uint32_t (*s_cnt)[256], uint32_t* s_keys, uint32_t* s_vals,
+                                               uint32_t* s_start, uint32_t* s_wsum, uint32_t* s_bits)
+{
+    constexpr int WAVES = THREADS / 64;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    uint32_t key[IPT], val[IPT], dig[IPT], rnk[IPT];
+    uint32_t k_or = 0u, k_and = 0xffffffffu;
+#pragma unroll
+    for (int r = 0; r < IPT; r++) {
+        const uint32_t p = (uint32_t)(wave * (IPT * 64) + r * 64 + lane);   // wave-major: the order wave_rank keeps
+        if (p < n) { const uint2 e = src[p]; key[r] = e.x; val[r] = e.y; k_or |= e.x; k_and &= e.x; }
+        else { key[r] = 0xffffffffu; val[r] = 0u; }   // padding: behind every real pair (a key is the bit pattern of a positive float), and it stays there
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { k_or |= (uint32_t)__shfl_xor((int)k_or, off, 64); k_and &= (uint32_t)__shfl_xor((int)k_and, off, 64); }
+    if (lane == 0) { s_bits[wave] = k_or; s_bits[WAVES + wave] = k_and; }
+    __syncthreads();
+    uint32_t differ = 0u;
+    {
+        uint32_t o = 0u, a = 0xffffffffu;
+#pragma unroll
+        for (int w = 0; w < WAVES; w++) { o |= s_bits[w]; a &= s_bits[WAVES + w]; }
+        differ = o & ~a;   // bits in which two of the tile's keys differ
+    }
+#pragma unroll 1
+    for (int shift = 0; shift < 32; shift += 8) {
+        if (((differ >> shift) & 0xffu) == 0u) continue;   // (uniform) every key of the tile has the same digit here
+#pragma unroll
+        for (int r = 0; r < IPT; r++) dig[r] = (key[r] >> shift) & 0xffu;
+        wave_rank<IPT, 256>(s_mask[wave], s_cnt[wave], dig, rnk, lane);
+        __syncthreads();
+        uint32_t mine = 0u;   // threads 0..255 = digits: the waves' counts -> exclusive prefixes in wave order, and the digit's total
+        if (tid < 256) {
+#pragma unroll
+            for (int w = 0; w < WAVES; w++) { const uint32_t c = s_cnt[w][tid]; s_cnt[w][tid] = mine; mine += c; }
+        }
+        const uint32_t ex = block_scan_excl<WAVES>(mine, s_wsum, tid);   // (threads beyond the digits add zero behind them)
+        if (tid < 256) s_start[tid] = ex;
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < IPT; r++) {
+            const uint32_t lp = s_start[dig[r]] + s_cnt[wave][dig[r]] + rnk[r];
+            s_keys[lp] = key[r]; s_vals[lp] = val[r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < IPT; r++) {
+            const uint32_t p = (uint32_t)(wave * (IPT * 64) + r * 64 + lane);
+            key[r] = s_keys[p]; val[r] = s_vals[p];
+        }
+        __syncthreads();   // (the key / value buffer IS the ranking's mask tables: nobody clears a table while a neighbour still reads pairs)
+    }
+#pragma unroll
+    for (int r = 0; r < IPT; r++) {
+        const uint32_t p = (uint32_t)(wave * (IPT * 64) + r * 64 + lane);
+        if (p < n) dst[p] = val[r];
+    }
+}
+
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_tile_sort(const uint2* __restrict__ ranges, uint2* pairs, uint2* pairs_alt, uint32_t* __restrict__ list, int T)
+{
+    constexpr int WAVES = THREADS / 64, CAP = THREADS == 256 ? kTsSmallMax : kTsCap;
+    static_assert(CAP * 8 == WAVES * 256 * 8, "the pair buffer aliases the mask tables exactly");
+    __shared__ unsigned long long s_mask[WAVES][256];   // ranking: XOR masks; between a pass's ranking and the next: the pairs in digit order
+    __shared__ uint32_t s_cnt[WAVES][256];
+    __shared__ uint32_t s_start[256], s_wsum[WAVES], s_bits[2 * WAVES], s_base[256], s_hist[256];
+    uint32_t* const s_keys = reinterpret_cast<uint32_t*>(&s_mask[0][0]);
+    uint32_t* const s_vals = s_keys + CAP;
+    const int t = (int)blockIdx.x;
+    if (t >= T) return;
+    const uint2 rg = ranges[t];
+    const uint32_t n = rg.y - rg.x;
+    if (n == 0u) return;
+    if (THREADS == 256) {
+        if (n > (uint32_t)kTsSmallMax) return;   // (the other launch's)
+        if (n <= 256u) tile_sort_regs<THREADS, 1>(pairs + rg.x, list + rg.x, n, s_mask, s_cnt, s_keys, s_vals, s_start, s_wsum, s_bits);
+        else if (n <= 512u) tile_sort_regs<THREADS, 2>(pairs + rg.x, list + rg.x, n, s_mask, s_cnt, s_keys, s_vals, s_start, s_wsum, s_bits);
+        else tile_sort_regs<THREADS, 4>(pairs + rg.x, list + rg.x, n, s_mask, s_cnt, s_keys, s_vals, s_start, s_wsum, s_bits);
+        return;
+    }
+    if (n <= (uint32_t)kTsSmallMax) return;
+    if (n <= 2048u) { tile_sort_regs<THREADS, 2>(pairs + rg.x, list + rg.x, n, s_mask, s_cnt, s_keys, s_vals, s_start, s_wsum, s_bits); return; }
+    if (n <= (uint32_t)kTsCap) { tile_sort_regs<THREADS, 4>(pairs + rg.x, list + rg.x, n, s_mask, s_cnt, s_keys, s_vals, s_start, s_wsum, s_bits); return; }
+    // ---- a long segment: the same passes through global memory, a chunk of kTsCap pairs at a time (this workgroup alone reads and
+    // writes the segment; its barriers order its own global accesses)
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    constexpr int IPT = kTsCap / THREADS;
+    uint2* src = pairs + rg.x;
+    uint2* dst = pairs_alt + rg.x;
+    uint32_t k_or = 0u, k_and = 0xffffffffu;
+    for (uint32_t i = (uint32_t)tid; i < n; i += THREADS) { const uint32_t k = src[i].x; k_or |= k; k_and &= k; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { k_or |= (uint32_t)__shfl_xor((int)k_or, off, 64); k_and &= (uint32_t)__shfl_xor((int)k_and, off, 64); }
+    if (lane == 0) { s_bits[wave] = k_or; s_bits[WAVES + wave] = k_and; }
+    __syncthreads();
+    uint32_t differ = 0u;
+    {
+        uint32_t o = 0u, a = 0xffffffffu;
+#pragma unroll
+        for (int w = 0; w < WAVES; w++) { o |= s_bits[w]; a &= s_bits[WAVES + w]; }
+        differ = o & ~a;
+    }
+#pragma unroll 1
+    for (int shift = 0; shift < 32; shift += 8) {
+        if (((differ >> shift) & 0xffu) == 0u) continue;
+        __syncthreads();
+        if (tid < 256) s_hist[tid] = 0u;                    // digit counts of the whole segment
+        __syncthreads();
+        for (uint32_t i = (uint32_t)tid; i < n; i += THREADS) atomicAdd(&s_hist[(src[i].x >> shift) & 0xffu], 1u);
+        __syncthreads();
+        const uint32_t tot = tid < 256 ? s_hist[tid] : 0u;
+        const uint32_t ex = block_scan_excl<WAVES>(tot, s_wsum, tid);
+        if (tid < 256) s_base[tid] = ex;
+        __syncthreads();
+        for (uint32_t c0 = 0u; c0 < n; c0 += (uint32_t)kTsCap) {
+            const uint32_t m = min((uint32_t)kTsCap, n - c0);
+            uint32_t key[IPT], val[IPT], dig[IPT], rnk[IPT];
+#pragma unroll
+            for (int r = 0; r < IPT; r++) {
+                const uint32_t p = (uint32_t)(wave * (IPT * 64) + r * 64 + lane);
+                if (p < m) { const uint2 e = src[c0 + p]; key[r] = e.x; val[r] = e.y; dig[r] = (e.x >> shift) & 0xffu; }
+                else { key[r] = 0xffffffffu; val[r] = 0u; dig[r] = 255u; }   // (padding: behind the chunk's real pairs of digit 255, never written)
+            }
+            wave_rank<IPT, 256>(s_mask[wave], s_cnt[wave], dig, rnk, lane);
+            __syncthreads();
+            uint32_t mine = 0u;
+            if (tid < 256) {
+#pragma unroll
+                for (int w = 0; w < WAVES; w++) { const uint32_t c = s_cnt[w][tid]; s_cnt[w][tid] = mine; mine += c; }
+                s_start[tid] = s_base[tid];
+            }
+            __syncthreads();
+            if (tid < 256) s_base[tid] += mine - (tid == 255 ? (uint32_t)kTsCap - m : 0u);   // (the padding was counted in digit 255)
+#pragma unroll
+            for (int r = 0; r < IPT; r++) {
+                const uint32_t p = (uint32_t)(wave * (IPT * 64) + r * 64 + lane);
+                if (p < m) dst[s_start[dig[r]] + s_cnt[wave][dig[r]] + rnk[r]] = make_uint2(key[r], val[r]);
+            }
+            __syncthreads();   // (s_start / s_cnt are rewritten by the next chunk; the stores above are ordered in front of the next pass's loads)
+        }
+        uint2* tmp = src; src = dst; dst = tmp;
+    }
+    __syncthreads();
+    for (uint32_t i = (uint32_t)tid; i < n; i += THREADS) list[rg.x + i] = src[i].y;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -3201,6 +3391,11 @@ static int g_bwd_split = 0;  // workgroups a long tile's backward is split over 
                              // 16 x 17 408 workgroups for eight batched images spent 170 of 860 us on them) -- about 35 000 workgroups
 static int g_ckpt_first = 1;  // 128-instance batches of a tile before the forward starts leaving checkpoints
 static int g_depth_sort9 = 1;     // depth sort of large models in three 9-bit passes over (key - near-plane bits) (radix_sort.h); 0 = four 8-bit passes
+static int g_tile_sort = 1;       // round 5: no global depth sort in front of the direct binning -- every tile's pairs are sorted by depth where they lie (k_tile_sort).
+                                  // 0 = off (depth sort + direct binning), 1 = where it wins: tile lists of up to g_tile_sort_max_avg pairs on average (by the caller's
+                                  // last R, or 4 N before there is one), 2 = wherever the direct binning runs
+static int g_tile_sort_max_avg = 800;   // measured (tools/ab_tile_sort*.sh, 980x545): 20 k ... 300 k Gaussians (50 ... 620 pairs per tile) -3 ... -6 % of the step,
+                                        // 1 M (2 070 per tile) +6 %: the per-tile sorts move R pairs where the depth sort moves N keys
 static int g_direct_bin = 1;      // tile lists by direct placement (k_chunk_counts / k_chunk_scatter) instead of emit + tile sort + ranges; 0 = the sort route
 static int g_view_pose_tol_e6 = 2000;   // balanced placement without a view id: a render belongs to the cached view whose pose is within this (x 1e-6) in every matrix entry
 static int g_db_slab_tiles = 0;   // frames above kDbMaxTiles tiles: tiles per slab of the slabbed scatter (0 = such frames keep the sort route)
@@ -3385,6 +3580,8 @@ int gsr_set_option(const char* name, int value)
     if (!strcmp(name, "tile_map")) { if (value < 0 || value > 2) return GSR_ERR_ARG; g_tile_map = value; return GSR_OK; }
     if (!strcmp(name, "blend_balance")) { g_blend_balance = value ? 1 : 0; return GSR_OK; }
     if (!strcmp(name, "early_r")) { g_early_r = value ? 1 : 0; return GSR_OK; }
+    if (!strcmp(name, "tile_sort")) { if (value < 0 || value > 2) return GSR_ERR_ARG; g_tile_sort = value; return GSR_OK; }
+    if (!strcmp(name, "tile_sort_max_avg")) { if (value < 0) return GSR_ERR_ARG; g_tile_sort_max_avg = value; return GSR_OK; }
     if (!strcmp(name, "direct_slab_tiles")) { if (value < 0) return GSR_ERR_ARG; g_db_slab_tiles = value; return GSR_OK; }
     if (!strcmp(name, "view_pose_tol_e6")) { if (value < 0) return GSR_ERR_ARG; g_view_pose_tol_e6 = value; return GSR_OK; }
     if (!strcmp(name, "depth_sort9")) { g_depth_sort9 = value ? 1 : 0; return GSR_OK; }
@@ -3507,8 +3704,12 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
     DirectBin db = {};
     DirectBinScratch dbs = {};
     const bool direct = g_direct_bin && g_sort_algo == 2 && !wide_keys && direct_bin_geometry(N, T, db, dbs, NB == 1 ? tiles_x : 0, tiles_y);
+    // tile-sort route (round 5): the binning runs over the Gaussians in index order and k_tile_sort orders every tile's pairs by depth:
+    // single renders whose tile tables fit one wave (no slabs), onesweep configuration
+    bool tsort = false;   // (decided below, once the caller's capacity hint is known)
     uint2* ranges = nullptr;
     uint32_t* list = nullptr;
+    uint2 *pairs = nullptr, *pairs_alt = nullptr;
     auto alloc_binning = [&](uint64_t capacity) -> int {
         B = bin_layout((int64_t)capacity, W, H, NB);
         bin = static_cast<uint8_t*>(a->alloc(B.bytes, GSR_ALLOC_BINNING, a->alloc_user));
@@ -3516,12 +3717,21 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
         ranges = reinterpret_cast<uint2*>(bin + B.ranges);
         list = reinterpret_cast<uint32_t*>(bin + B.list);
         bs = nullptr;
+        if (capacity > 0 && tsort) {   // the (depth key, Gaussian) pairs the scatter places, and the second buffer long segments are sorted through
+            const size_t pb = align256((size_t)capacity * sizeof(uint2));
+            uint8_t* pm = static_cast<uint8_t*>(a->alloc(2 * pb, GSR_ALLOC_SCRATCH, a->alloc_user));
+            if (!pm) return fail(GSR_ERR_ALLOC, "pair buffer allocation failed%s");
+            pairs = reinterpret_cast<uint2*>(pm);
+            pairs_alt = reinterpret_cast<uint2*>(pm + pb);
+        }
         if (capacity == 0 || direct) return GSR_OK;
         S = bin_scratch_layout((int64_t)capacity, wide_keys ? 4 : 2);
         bs = static_cast<uint8_t*>(a->alloc(S.bytes, GSR_ALLOC_SCRATCH, a->alloc_user));
         if (!bs) return fail(GSR_ERR_ALLOC, "binning scratch allocation failed%s");
         return GSR_OK;
     };
+    const TileRec* ts_rec = nullptr;      // (tile-sort route) the tile records and depth keys where the preprocess left them
+    const uint32_t* ts_dkey = nullptr;
     // emit + tile sort + ranges for `capacity` instances; n_dev != nullptr: the real count is read on the device.
     // prezeroed: ranges, the staged counters and the head of the sort scratch were cleared by k_block_scan.
     auto launch_binning_t = [&](auto key_tag, uint64_t capacity, const unsigned long long* n_dev, bool prezeroed) -> int {
@@ -3570,8 +3780,19 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
     auto launch_binning = [&](uint64_t capacity, const unsigned long long* n_dev, bool prezeroed) -> int {
         if (direct) {
             if (capacity == 0) { GSR_HIP(hipMemsetAsync(ranges, 0, (size_t)T * sizeof(uint2), st)); return GSR_OK; }
-            ProfScope ps(P_EMIT, st);
             const int per = (db.NC + 7) / 8, grid = std::max(8 * per * db.NS, (T + 63) / 64);
+            if (tsort) {
+                {
+                    ProfScope ps(P_EMIT, st);
+                    hipLaunchKernelGGL((k_chunk_scatter<false, true>), dim3(grid), dim3(64), (size_t)12 * db.Tp + 4 * kDbPairs, st, db, W, H, tiles_x, tiles_y,
+                                       (const uint32_t*)nullptr, ts_rec, splat, list, ranges, (uint32_t)std::min<uint64_t>(capacity, 0xffffffffull), ts_dkey, pairs);
+                }
+                ProfScope ps2(P_SORT_TILE, st);
+                hipLaunchKernelGGL(k_tile_sort<256>, dim3(T), dim3(256), 0, st, ranges, pairs, pairs_alt, list, T);
+                hipLaunchKernelGGL(k_tile_sort<1024>, dim3(T), dim3(1024), 0, st, ranges, pairs, pairs_alt, list, T);
+                return GSR_OK;
+            }
+            ProfScope ps(P_EMIT, st);
             if (db.NS > 1)
                 hipLaunchKernelGGL(k_chunk_scatter<true>, dim3(grid), dim3(64), (size_t)12 * db.Tsp + 4 * kDbPairs, st, db, W, H, tiles_x, tiles_y, sorted_gid,
                                    reinterpret_cast<const TileRec*>(fs + L.srec), splat, list, ranges, (uint32_t)std::min<uint64_t>(capacity, 0xffffffffull));
@@ -3647,6 +3868,11 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
     }
     const bool speculative = g_speculate && g_sort_algo == 2 && hint > 0;
     const uint64_t cap = speculative ? hint : 0;
+    {
+        const int ts_mode = g_tile_sort;
+        const uint64_t avg = (hint > 0 ? hint : (uint64_t)N * 4u) / (uint64_t)T;
+        tsort = direct && NB == 1 && db.NS == 1 && (ts_mode == 2 || (ts_mode == 1 && avg <= (uint64_t)g_tile_sort_max_avg));
+    }
 
     fs = static_cast<uint8_t*>(a->alloc(align256(L.bytes) + (direct ? dbs.bytes : 0), GSR_ALLOC_SCRATCH, a->alloc_user));   // (+ the chunk tables of the direct binning)
     if (!fs) return fail(GSR_ERR_ALLOC, "scratch allocation failed%s");
@@ -3728,24 +3954,29 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
         if (it != g_full_depth_sort.end() && it->second) wide_depth = false;
     }
     const unsigned int* window_overflow = wide_depth ? onesweep_overflow_word(depth_scratch) : nullptr;   // (in the sort's zeroed scratch head)
+    if (tsort) wide_depth = false;   // (no depth sort, no window)
+    const unsigned int* window_overflow_ = tsort ? nullptr : window_overflow;
     PinLease pin(acquire_pin_slot(dev_id));
     if (!pin.s) return fail(GSR_ERR_HIP, "pinned read-back slot allocation failed%s");
     OsRider rider = {};
     if (early_r) { rider.parts = early_parts; rider.nparts = (uint32_t)grid; rider.host = pin.s->dev; rider.seq = ++pin.s->seq; }
-    {
+    ts_rec = ntiles; ts_dkey = dkey;
+    if (!tsort) {
         ProfScope ps(P_SORT_DEPTH, st);
         GSR_HIP(depth_onesweep ? onesweep_sort_pairs<uint32_t>(dkey, gid, dkey_alt, gid_alt, (uint32_t)N, 0, wide_depth ? 27 : 32, depth_scratch, &in_alt, st,
                                                                nullptr, true, depth_hist_done, wide_depth ? 9 : 8, kDepthKeyBias, early_r ? &rider : nullptr)
                                : radix_sort_pairs<uint32_t>(dkey, gid, dkey_alt, gid_alt, (uint32_t)N, 0, 32, fs + L.sort, &in_alt, st));
     }
-    sorted_gid = in_alt ? gid_alt : gid;
+    sorted_gid = tsort ? nullptr : (in_alt ? gid_alt : gid);
     // tiles-touched in depth order: R to the pinned slot, and what the binning needs (block offsets / the chunk tables)
     auto launch_counts = [&](const BlendBalance& bal, const ZeroJobs& zjobs, const unsigned int* wo, unsigned long long seq, bool publish = true) {
         TileRec* srec = reinterpret_cast<TileRec*>(fs + L.srec);
         unsigned long long* const host_slot = publish ? pin.s->dev : nullptr;   // (early R: the histogram kernel already told the host)
         if (direct) {
+            // (tile-sort route: index order, no sorted copy of the records, and -- no depth sort to ride on -- the rider that publishes R)
             hipLaunchKernelGGL(k_chunk_counts, dim3(db.NC + (bal.hdr ? 8 : 0)), dim3(kEmitThreads), (size_t)2 * db.Tp, st, db, W, H,
-                               tiles_x, tiles_y, sorted_gid, ntiles, splat, srec, bal);
+                               tiles_x, tiles_y, sorted_gid, ntiles, splat, tsort ? (TileRec*)nullptr : srec, bal,
+                               (tsort && early_r && !publish) ? rider : OsRider{});
             hipLaunchKernelGGL(k_chunk_scan1, dim3((db.Tp + 255) / 256, db.G), dim3(256), 0, st, db);
             hipLaunchKernelGGL(k_chunk_scan2, dim3((db.Tp + 255) / 256), dim3(256), 0, st, db, total, zjobs, host_slot, seq, wo);
         } else {
@@ -3802,8 +4033,8 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
             zj.p[0] = nullptr; zj.words[0] = 0u;   // (the scatter writes every tile's range; there is no sort scratch)
             zj.p[2] = nullptr; zj.words[2] = 0u;
         }
-        if (early_r) launch_counts(bb, zj, window_overflow, 0ull, false);
-        else launch_counts(bb, zj, window_overflow, ++pin.s->seq);
+        if (early_r) launch_counts(bb, zj, window_overflow_, 0ull, false);
+        else launch_counts(bb, zj, window_overflow_, ++pin.s->seq);
     }
     GSR_HIP(hipGetLastError());
 

@@ -655,32 +655,40 @@ def test_direct_binning_is_the_sort_routes_list(name):
     kw = parity.scene_kwargs(sc, "sh", bg=(0.1, 0.2, 0.3))
     res = {}
     try:
-        for direct in (0, 1):
+        # 0 = emit + tile sort + ranges; 1 = depth sort + direct placement; 2 = direct placement in index order + per-tile depth sort
+        for route, (direct, tsort) in enumerate(((0, 0), (1, 0), (1, 2))):   # (tile_sort 2 = wherever the direct binning runs, whatever the lists' lengths)
             assert lib.gsr_set_option(b"direct_binning", direct) == 0
+            assert lib.gsr_set_option(b"tile_sort", tsort) == 0
             if name == "overflow-rerun":
                 assert lib.gsr_set_option(b"binning_capacity_hint", 5000) == 0
             fwd = hip_runner.run_hip(kw)["fwd"]
             ranges, lst = R_.last_binning()
-            res[direct] = (fwd, ranges.cpu().numpy().copy(), lst.cpu().numpy().copy(), R_._LAST["num_rendered"])
+            res[route] = (fwd, ranges.cpu().numpy().copy(), lst.cpu().numpy().copy(), R_._LAST["num_rendered"])
     finally:
         lib.gsr_set_option(b"direct_binning", 1)
+        lib.gsr_set_option(b"tile_sort", 1)
         lib.gsr_set_option(b"binning_capacity_hint", 0)
-    (fa, ra, la, na), (fb, rb, lb, nb_) = res[0], res[1]
-    assert na == nb_ and na > 0
-    assert np.array_equal(ra, rb), "tile ranges differ"
-    assert np.array_equal(la[:na], lb[:nb_]), "instance lists differ"
-    for x, y in zip(fa, fb):
-        assert np.array_equal(x, y)
+    (fa, ra, la, na) = res[0]
+    assert na > 0
+    for route in (1, 2):
+        (fb, rb, lb, nb_) = res[route]
+        assert na == nb_, f"route {route}"
+        assert np.array_equal(ra, rb), f"route {route}: tile ranges differ"
+        assert np.array_equal(la[:na], lb[:nb_]), f"route {route}: instance lists differ"
+        for x, y in zip(fa, fb):
+            assert np.array_equal(x, y), f"route {route}"
     counts = np.diff(rb, axis=1)[:, 0]
     print(f"{name}: R {na}, longest tile list {counts.max()}, tiles in use {(counts > 0).sum()} of {counts.shape[0]}")
 
 
-@pytest.mark.parametrize("W,H,N", [(16, 16, 500), (17, 33, 900), (640, 480, 20000), (1024, 1024, 50000), (1040, 1024, 20000), (250, 3000, 8000)],
-                         ids=["one-tile", "2x3-tiles", "vga", "4096-tiles", "4160-tiles-sort-route", "tall"])
+@pytest.mark.parametrize("W,H,N", [(16, 16, 500), (17, 33, 900), (640, 480, 20000), (1024, 1024, 50000), (1040, 1024, 20000), (250, 3000, 8000),
+                                   (16, 16, 30000), (40, 24, 60000)],
+                         ids=["one-tile", "2x3-tiles", "vga", "4096-tiles", "4160-tiles-sort-route", "tall", "one-long-list", "six-long-lists"])
 def test_direct_binning_frame_sizes(W, H, N):
-    """Direct placement against the sort route over frame geometries: a single tile, ragged edge tiles, exactly the 4 096 tiles the
-    LDS tables hold, one tile row more (both options then take the sort route: the test is the option's no-op there), a tall frame
-    (tile ids in a narrow grid)."""
+    """Direct placement (behind the depth sort, and in index order with the per-tile depth sort behind it) against the sort route over
+    frame geometries: a single tile, ragged edge tiles, exactly the 4 096 tiles the LDS tables hold, one tile row more (every option then
+    takes the sort route: the test is the options' no-op there), a tall frame (tile ids in a narrow grid), and tiles whose lists are
+    longer than what k_tile_sort sorts in LDS (its pass through global memory, a chunk at a time)."""
     import importlib
     import hip_runner
     R_ = importlib.import_module("3dgs_hierarchical_training_amd.rasterizer")
@@ -690,17 +698,23 @@ def test_direct_binning_frame_sizes(W, H, N):
     kw = parity.scene_kwargs(sc, "sh")
     res = {}
     try:
-        for direct in (0, 1):
+        for route, (direct, tsort) in enumerate(((0, 0), (1, 0), (1, 2))):   # (tile_sort 2 = wherever the direct binning runs, whatever the lists' lengths)
             assert lib.gsr_set_option(b"direct_binning", direct) == 0
+            assert lib.gsr_set_option(b"tile_sort", tsort) == 0
             fwd = hip_runner.run_hip(kw)["fwd"]
             ranges, lst = R_.last_binning()
-            res[direct] = (fwd, ranges.cpu().numpy().copy(), lst.cpu().numpy().copy(), R_._LAST["num_rendered"])
+            res[route] = (fwd, ranges.cpu().numpy().copy(), lst.cpu().numpy().copy(), R_._LAST["num_rendered"])
     finally:
         lib.gsr_set_option(b"direct_binning", 1)
-    (fa, ra, la, na), (fb, rb, lb, nb_) = res[0], res[1]
-    assert na == nb_ and na > 0 and np.array_equal(ra, rb) and np.array_equal(la[:na], lb[:nb_])
-    for x, y in zip(fa, fb):
-        assert np.array_equal(x, y)
+        lib.gsr_set_option(b"tile_sort", 1)
+    (fa, ra, la, na) = res[0]
+    assert na > 0
+    for route in (1, 2):
+        (fb, rb, lb, nb_) = res[route]
+        assert na == nb_ and np.array_equal(ra, rb) and np.array_equal(la[:na], lb[:nb_]), f"route {route}"
+        for x, y in zip(fa, fb):
+            assert np.array_equal(x, y), f"route {route}"
+    print(f"{W}x{H}: R {na}, longest tile list {np.diff(ra, axis=1).max()}")
 
 
 @pytest.mark.parametrize("W,H,N,slab,kind", [(1920, 1080, 200000, 2176, "syn"), (1920, 1080, 200000, 4096, "syn"), (1920, 1080, 6000, 2176, "rects"),
