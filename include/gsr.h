@@ -286,6 +286,12 @@ int gsr_version(void);
  *                          depth-ordered Gaussians, column scans, one wave per chunk that places every (Gaussian, tile) pair at
  *                          its final position -- on frames of up to 4 096 tiles; 0 = emit + stable tile sort + ranges (what larger
  *                          frames always take).  Same list, bit for bit
+ *   "tile_sort"            1 (default) = where the direct binning runs on a single render AND the caller's tile lists are short (at most
+ *                          "tile_sort_max_avg" pairs per tile on average, by the caller's last instance count), the global depth sort is
+ *                          left out: the binning walks the Gaussians in index order, places (depth key, Gaussian) pairs, and one
+ *                          workgroup per tile sorts its segment by key, stable; 2 = wherever the direct binning runs; 0 = never.
+ *                          Same list, bit for bit (equal keys stay in index order, as under the stable global sort)
+ *   "tile_sort_max_avg"    (default 800) see "tile_sort"
  *   "blend_balance"        1 (default) = the forward blend places its sub-tile waves by the visits each took at the previous
  *                          render of the same frame (device-side cache of 128 frames per frame size, least recently used out; a
  *                          frame is recognised by GsrForwardArgs::view_id or, without one, by its pose; single renders through

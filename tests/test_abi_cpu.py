@@ -105,3 +105,19 @@ def test_direct_binning_geometry_invariants():
     for N, T in ((0, 100), (1000, 0), (1000, 4097), (1000, 8160)):
         assert lib.gsr_debug_direct_binning_geometry(N, T, out) == 0 and out[0] == 0
 
+
+
+def test_tile_sort_option_values():
+    """`tile_sort` takes 0 / 1 / 2 (off / where the lists are short / wherever the direct binning runs) and nothing else; its threshold
+    is a non-negative count.  No GPU needed: options are host state."""
+    L = importlib.import_module("3dgs_hierarchical_training_amd._lib")
+    lib = L.load()
+    try:
+        for v in (0, 2, 1):
+            assert lib.gsr_set_option(b"tile_sort", v) == 0
+        assert lib.gsr_set_option(b"tile_sort", 3) != 0 and lib.gsr_set_option(b"tile_sort", -1) != 0
+        assert lib.gsr_set_option(b"tile_sort_max_avg", 0) == 0 and lib.gsr_set_option(b"tile_sort_max_avg", 800) == 0
+        assert lib.gsr_set_option(b"tile_sort_max_avg", -5) != 0
+    finally:
+        lib.gsr_set_option(b"tile_sort", 1)
+        lib.gsr_set_option(b"tile_sort_max_avg", 800)
