@@ -825,20 +825,26 @@ __device__ void balance_build(const BlendBalance bb, const int x)
     }
 }
 
+// sorted_gid == nullptr (the tile-sort route on the emit path, round 5): index order -- no depth sort in front, the records are counted
+// where they lie (no gather, no sorted copy), and the launch's last workgroup carries the rider that publishes R.
 __global__ __launch_bounds__(kEmitThreads) void k_tile_counts(int N, const uint32_t* __restrict__ sorted_gid,
                                                               const TileRec* __restrict__ tilerec, uint32_t* __restrict__ block_sums,
-                                                              TileRec* __restrict__ sorted_rec, BlendBalance bb, int nb)
+                                                              TileRec* __restrict__ sorted_rec, BlendBalance bb, int nb, OsRider rider = OsRider{})
 {
     // (eight extra workgroups when bb.hdr is set -- the FIRST eight, so that they run beside the counting, not behind it)
     const int nbuild = bb.hdr ? 8 : 0, blk = (int)blockIdx.x - nbuild;
     if (blk < 0) { balance_build(bb, (int)blockIdx.x); return; }
     (void)nb;
+    if (rider.host && blockIdx.x == gridDim.x - 1) {   // (block-uniform)
+        __shared__ unsigned long long s_r[2][16];
+        onesweep_rider_publish(rider, s_r);
+    }
     __shared__ uint32_t s_wave[4];
     const int j = blk * kEmitThreads + threadIdx.x;
     uint32_t t = 0;
     if (j < N) {   // the one random gather of the records: k_emit reads them back in depth order, coalesced
-        const TileRec r = tilerec[sorted_gid[j]];
-        sorted_rec[j] = r;
+        const TileRec r = tilerec[sorted_gid ? sorted_gid[j] : (uint32_t)j];
+        if (sorted_rec) sorted_rec[j] = r;
         t = tilerec_count(r);
     }
     uint32_t total;
@@ -913,7 +919,7 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit(int N, int W, int H, int 
     TileRec r;
     r.mask = 0u; r.rect = 1u << 24;
     if (j < N) {
-        g = sorted_gid[j];
+        g = sorted_gid ? sorted_gid[j] : (uint32_t)j;   // (nullptr: index order -- the tile-sort route)
         r = tilerec[j];   // already in depth order (k_tile_counts)
     }
     const uint32_t cnt = tilerec_count(r);
@@ -1558,14 +1564,17 @@ __global__ __launch_bounds__(64) void k_chunk_scatter(DirectBin db, int W, int H
 // wave_rank: 8-bit digits, a digit all keys of the tile share is skipped); longer ones go through global memory a chunk at a time
 // (pairs <-> pairs_alt), same passes.
 // ------------------------------------------------------------------------------------------------
-// Two launches share the tiles by length: 256-thread workgroups take the segments of up to 1 024 pairs (one, two or four pairs per
-// thread: a ranking round per pair and pass is what a pass costs), 1 024-thread workgroups the longer ones (up to 4 096 pairs from
-// registers, beyond that a chunk of 4 096 at a time through global memory); a workgroup whose tile belongs to the other launch leaves
-// at once.
-constexpr int kTsCap = 4096, kTsSmallMax = 1024;
+// Two launches share the tiles by length: single waves take the segments of up to 512 pairs (k_tile_sort_wave below), 1 024-thread
+// workgroups the longer ones (up to 4 096 pairs from registers, beyond that a chunk of 4 096 at a time through global memory).  The
+// second launch is a handful of persistent workgroups that walk the tile ranges for long segments (a frame has few or none: 17 360
+// workgroups of 1 024 threads that leave at once took 18 us to dispatch).
+constexpr int kTsCap = 4096, kTsSmallMax = 512;
 
-template <int THREADS, int IPT>
-__device__ __forceinline__ void tile_sort_regs(const uint2* __restrict__ src, uint32_t* __restrict__ dst, uint32_t n,
+// GATHER (the route behind the emit path: batched renders, frames above 4 096 tiles): the segment holds Gaussian indices only, in index
+// order (the stable tile-key sort kept it); the keys are fetched from the per-Gaussian depth keys.  `dst` is then the segment itself:
+// every index is read before the first barrier, every result written behind the last.
+template <int THREADS, int IPT, bool GATHER = false>
+__device__ __forceinline__ void tile_sort_regs(const uint2* __restrict__ src, uint32_t* dst, uint32_t n, const uint32_t* __restrict__ dkey,
                                                unsigned long long (*s_mask)[256], uint32_t (*s_cnt)[256], uint32_t* s_keys, uint32_t* s_vals,
                                                uint32_t* s_start, uint32_t* s_wsum, uint32_t* s_bits)
 {
@@ -1576,8 +1585,21 @@ __device__ __forceinline__ void tile_sort_regs(const uint2* __restrict__ src, ui
 #pragma unroll
     for (int r = 0; r < IPT; r++) {
         const uint32_t p = (uint32_t)(wave * (IPT * 64) + r * 64 + lane);   // wave-major: the order wave_rank keeps
-        if (p < n) { const uint2 e = src[p]; key[r] = e.x; val[r] = e.y; k_or |= e.x; k_and &= e.x; }
-        else { key[r] = 0xffffffffu; val[r] = 0u; }   // padding: behind every real pair (a key is the bit pattern of a positive float), and it stays there
+        if (GATHER) val[r] = p < n ? dst[p] : 0u;
+        else if (p < n) { const uint2 e = src[p]; key[r] = e.x; val[r] = e.y; }
+        if (!GATHER && p >= n) { key[r] = 0xffffffffu; val[r] = 0u; }   // padding: behind every real pair (a key is the bit pattern of a positive float), and it stays there
+    }
+    if (GATHER) {
+#pragma unroll
+        for (int r = 0; r < IPT; r++) {
+            const uint32_t p = (uint32_t)(wave * (IPT * 64) + r * 64 + lane);
+            key[r] = p < n ? dkey[val[r]] : 0xffffffffu;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < IPT; r++) {
+        const uint32_t p = (uint32_t)(wave * (IPT * 64) + r * 64 + lane);
+        if (p < n) { k_or |= key[r]; k_and &= key[r]; }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { k_or |= (uint32_t)__shfl_xor((int)k_or, off, 64); k_and &= (uint32_t)__shfl_xor((int)k_and, off, 64); }
@@ -1625,8 +1647,89 @@ __device__ __forceinline__ void tile_sort_regs(const uint2* __restrict__ src, ui
     }
 }
 
-template <int THREADS>
-__global__ __launch_bounds__(THREADS) void k_tile_sort(const uint2* __restrict__ ranges, uint2* pairs, uint2* pairs_alt, uint32_t* __restrict__ list, int T)
+// Segments of up to kTsSmallMax (512) pairs: ONE WAVE per tile (round 5, second form: the four-wave workgroups spent their time in barriers --
+// six per pass -- and a CU held seven of them; a lone wave needs none, its LDS operations execute in program order, and twenty of
+// them share a CU).  Pair p of the segment sits in register p / 64 of lane p % 64; a pass ranks the digits round by round
+// (wave_rank), scans the 256 digit counts four per lane, scatters the pairs into LDS and reads them back in order.
+template <int IPT, bool GATHER>
+__device__ __forceinline__ void tile_sort_wave(const uint2* __restrict__ src, uint32_t* dst, uint32_t n, const uint32_t* __restrict__ dkey,
+                                               unsigned long long* s_mask, uint32_t* s_cnt, uint32_t* s_start, uint32_t* s_keys, uint32_t* s_vals)
+{
+    const int lane = threadIdx.x;
+    uint32_t key[IPT], val[IPT], dig[IPT], rnk[IPT];
+#pragma unroll
+    for (int r = 0; r < IPT; r++) {
+        const uint32_t p = (uint32_t)(r * 64 + lane);
+        if (GATHER) val[r] = p < n ? dst[p] : 0u;
+        else if (p < n) { const uint2 e = src[p]; key[r] = e.x; val[r] = e.y; }
+        if (!GATHER && p >= n) { key[r] = 0xffffffffu; val[r] = 0u; }   // padding: behind every real pair, and it stays there
+    }
+    if (GATHER) {
+#pragma unroll
+        for (int r = 0; r < IPT; r++) key[r] = (uint32_t)(r * 64 + lane) < n ? dkey[val[r]] : 0xffffffffu;
+    }
+    uint32_t k_or = 0u, k_and = 0xffffffffu;
+#pragma unroll
+    for (int r = 0; r < IPT; r++)
+        if ((uint32_t)(r * 64 + lane) < n) { k_or |= key[r]; k_and &= key[r]; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { k_or |= (uint32_t)__shfl_xor((int)k_or, off, 64); k_and &= (uint32_t)__shfl_xor((int)k_and, off, 64); }
+    const uint32_t differ = k_or & ~k_and;   // bits in which two of the tile's keys differ (wave-uniform)
+#pragma unroll 1
+    for (int shift = 0; shift < 32; shift += 8) {
+        if (((differ >> shift) & 0xffu) == 0u) continue;
+#pragma unroll
+        for (int r = 0; r < IPT; r++) dig[r] = (key[r] >> shift) & 0xffu;
+        wave_rank<IPT, 256>(s_mask, s_cnt, dig, rnk, lane);   // s_cnt[d] = the segment's count of digit d (padding in 255, behind the real pairs)
+        lds_order();
+        {   // exclusive scan of the 256 counts: four digits per lane
+            const uint4 c = reinterpret_cast<const uint4*>(s_cnt)[lane];
+            const uint32_t sum = c.x + c.y + c.z + c.w;
+            const uint32_t ex = wave_inclusive_sum(sum) - sum;
+            reinterpret_cast<uint4*>(s_start)[lane] = make_uint4(ex, ex + c.x, ex + c.x + c.y, ex + c.x + c.y + c.z);
+        }
+        lds_order();
+#pragma unroll
+        for (int r = 0; r < IPT; r++) {
+            const uint32_t lp = s_start[dig[r]] + rnk[r];
+            s_keys[lp] = key[r]; s_vals[lp] = val[r];
+        }
+        lds_order();
+#pragma unroll
+        for (int r = 0; r < IPT; r++) { key[r] = s_keys[r * 64 + lane]; val[r] = s_vals[r * 64 + lane]; }
+        lds_order();
+    }
+#pragma unroll
+    for (int r = 0; r < IPT; r++) {
+        const uint32_t p = (uint32_t)(r * 64 + lane);
+        if (p < n) dst[p] = val[r];
+    }
+}
+
+template <bool GATHER = false>
+__global__ __launch_bounds__(64) void k_tile_sort_wave(const uint2* __restrict__ ranges, const uint2* __restrict__ pairs, uint32_t* list, int T,
+                                                       const uint32_t* __restrict__ dkey = nullptr)
+{
+    __shared__ unsigned long long s_mask[256];
+    __shared__ __attribute__((aligned(16))) uint32_t s_cnt[256];
+    __shared__ __attribute__((aligned(16))) uint32_t s_start[256];
+    __shared__ uint32_t s_keys[kTsSmallMax], s_vals[kTsSmallMax];
+    const int t = (int)blockIdx.x;
+    if (t >= T) return;
+    const uint2 rg = ranges[t];
+    const uint32_t n = rg.y - rg.x;
+    if (n == 0u || n > (uint32_t)kTsSmallMax) return;   // (longer segments: k_tile_sort<1024>)
+    const uint2* src = pairs + rg.x;
+    uint32_t* dst = list + rg.x;
+    if (n <= 64u) tile_sort_wave<1, GATHER>(src, dst, n, dkey, s_mask, s_cnt, s_start, s_keys, s_vals);
+    else if (n <= 128u) tile_sort_wave<2, GATHER>(src, dst, n, dkey, s_mask, s_cnt, s_start, s_keys, s_vals);
+    else if (n <= 256u) tile_sort_wave<4, GATHER>(src, dst, n, dkey, s_mask, s_cnt, s_start, s_keys, s_vals);
+    else tile_sort_wave<8, GATHER>(src, dst, n, dkey, s_mask, s_cnt, s_start, s_keys, s_vals);
+}
+
+template <int THREADS, bool GATHER = false>
+__global__ __launch_bounds__(THREADS) void k_tile_sort(const uint2* __restrict__ ranges, uint2* pairs, uint2* pairs_alt, uint32_t* list, int T,
+                                                       const uint32_t* __restrict__ dkey = nullptr)
 {
     constexpr int WAVES = THREADS / 64, CAP = THREADS == 256 ? kTsSmallMax : kTsCap;
     static_assert(CAP * 8 == WAVES * 256 * 8, "the pair buffer aliases the mask tables exactly");
@@ -1635,27 +1738,41 @@ __global__ __launch_bounds__(THREADS) void k_tile_sort(const uint2* __restrict__
     __shared__ uint32_t s_start[256], s_wsum[WAVES], s_bits[2 * WAVES], s_base[256], s_hist[256];
     uint32_t* const s_keys = reinterpret_cast<uint32_t*>(&s_mask[0][0]);
     uint32_t* const s_vals = s_keys + CAP;
-    const int t = (int)blockIdx.x;
-    if (t >= T) return;
+    static_assert(THREADS == 1024, "the short segments are k_tile_sort_wave's");
+    // persistent: this workgroup's share of the tiles is t = blockIdx + k gridDim.  Its threads look at one tile each and collect the
+    // long ones (one memory round trip for the whole share: walking it tile by tile was 34 dependent loads per workgroup on a batched frame)
+    __shared__ uint32_t s_todo[256];
+    __shared__ uint32_t s_ntodo;
+    if (threadIdx.x == 0) s_ntodo = 0u;
+    __syncthreads();
+    for (int k = (int)threadIdx.x; (int)blockIdx.x + k * (int)gridDim.x < T; k += THREADS) {
+        const int tt = (int)blockIdx.x + k * (int)gridDim.x;
+        const uint2 q = ranges[tt];
+        if (q.y - q.x > (uint32_t)kTsSmallMax) { const uint32_t slot = atomicAdd(&s_ntodo, 1u); if (slot < 256u) s_todo[slot] = (uint32_t)tt; }
+    }
+    __syncthreads();
+    const uint32_t ntodo = s_ntodo;
+    const bool walk_all = ntodo > 256u;   // (more long tiles in this share than the table holds: walk the share)
+    const int nloop = walk_all ? (T - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : (int)ntodo;
+    for (int it = 0; it < nloop; it++) {
+    const int t = walk_all ? (int)blockIdx.x + it * (int)gridDim.x : (int)s_todo[it];
     const uint2 rg = ranges[t];
     const uint32_t n = rg.y - rg.x;
-    if (n == 0u) return;
-    if (THREADS == 256) {
-        if (n > (uint32_t)kTsSmallMax) return;   // (the other launch's)
-        if (n <= 256u) tile_sort_regs<THREADS, 1>(pairs + rg.x, list + rg.x, n, s_mask, s_cnt, s_keys, s_vals, s_start, s_wsum, s_bits);
-        else if (n <= 512u) tile_sort_regs<THREADS, 2>(pairs + rg.x, list + rg.x, n, s_mask, s_cnt, s_keys, s_vals, s_start, s_wsum, s_bits);
-        else tile_sort_regs<THREADS, 4>(pairs + rg.x, list + rg.x, n, s_mask, s_cnt, s_keys, s_vals, s_start, s_wsum, s_bits);
-        return;
-    }
-    if (n <= (uint32_t)kTsSmallMax) return;
-    if (n <= 2048u) { tile_sort_regs<THREADS, 2>(pairs + rg.x, list + rg.x, n, s_mask, s_cnt, s_keys, s_vals, s_start, s_wsum, s_bits); return; }
-    if (n <= (uint32_t)kTsCap) { tile_sort_regs<THREADS, 4>(pairs + rg.x, list + rg.x, n, s_mask, s_cnt, s_keys, s_vals, s_start, s_wsum, s_bits); return; }
+    if (n <= (uint32_t)kTsSmallMax) continue;   // (the other launch's; uniform)
+    __syncthreads();   // (the previous tile's LDS is done with)
+    if (n <= 1024u) { tile_sort_regs<THREADS, 1, GATHER>(pairs + rg.x, list + rg.x, n, dkey, s_mask, s_cnt, s_keys, s_vals, s_start, s_wsum, s_bits); continue; }
+    if (n <= 2048u) { tile_sort_regs<THREADS, 2, GATHER>(pairs + rg.x, list + rg.x, n, dkey, s_mask, s_cnt, s_keys, s_vals, s_start, s_wsum, s_bits); continue; }
+    if (n <= (uint32_t)kTsCap) { tile_sort_regs<THREADS, 4, GATHER>(pairs + rg.x, list + rg.x, n, dkey, s_mask, s_cnt, s_keys, s_vals, s_start, s_wsum, s_bits); continue; }
     // ---- a long segment: the same passes through global memory, a chunk of kTsCap pairs at a time (this workgroup alone reads and
     // writes the segment; its barriers order its own global accesses)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     constexpr int IPT = kTsCap / THREADS;
     uint2* src = pairs + rg.x;
     uint2* dst = pairs_alt + rg.x;
+    if (GATHER) {   // the pairs of this segment, from its indices and the per-Gaussian keys
+        for (uint32_t i = (uint32_t)tid; i < n; i += THREADS) { const uint32_t g = list[rg.x + i]; src[i] = make_uint2(dkey[g], g); }
+        __syncthreads();
+    }
     uint32_t k_or = 0u, k_and = 0xffffffffu;
     for (uint32_t i = (uint32_t)tid; i < n; i += THREADS) { const uint32_t k = src[i].x; k_or |= k; k_and &= k; }
 #pragma unroll
@@ -1711,6 +1828,7 @@ __global__ __launch_bounds__(THREADS) void k_tile_sort(const uint2* __restrict__
     }
     __syncthreads();
     for (uint32_t i = (uint32_t)tid; i < n; i += THREADS) list[rg.x + i] = src[i].y;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -3394,6 +3512,7 @@ static int g_depth_sort9 = 1;     // depth sort of large models in three 9-bit p
 static int g_tile_sort = 1;       // round 5: no global depth sort in front of the direct binning -- every tile's pairs are sorted by depth where they lie (k_tile_sort).
                                   // 0 = off (depth sort + direct binning), 1 = where it wins: tile lists of up to g_tile_sort_max_avg pairs on average (by the caller's
                                   // last R, or 4 N before there is one), 2 = wherever the direct binning runs
+static int g_tile_sort_emit_max_n = 400000;   // behind the emit path (batched renders, frames above 4 096 tiles): models of up to this many Gaussians
 static int g_tile_sort_max_avg = 800;   // measured (tools/ab_tile_sort*.sh, 980x545): 20 k ... 300 k Gaussians (50 ... 620 pairs per tile) -3 ... -6 % of the step,
                                         // 1 M (2 070 per tile) +6 %: the per-tile sorts move R pairs where the depth sort moves N keys
 static int g_direct_bin = 1;      // tile lists by direct placement (k_chunk_counts / k_chunk_scatter) instead of emit + tile sort + ranges; 0 = the sort route
@@ -3758,7 +3877,7 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
         {
             ProfScope ps(P_EMIT, st);
             hipLaunchKernelGGL(k_emit<KeyT>, dim3(nb), dim3(kEmitThreads), 0, st, N, W, H, tiles_x, tiles_y, sorted_gid, splat,
-                               reinterpret_cast<const TileRec*>(fs + L.srec), block_sums, tkey, v0,
+                               tsort ? ts_rec : reinterpret_cast<const TileRec*>(fs + L.srec), block_sums, tkey, v0,
                                (uint32_t)capacity, eh);
         }
         int in_alt = 0;
@@ -3775,6 +3894,11 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
             constexpr uint32_t kpb = 256u * (16u / (uint32_t)sizeof(KeyT));   // keys per block
             hipLaunchKernelGGL(k_tile_ranges<KeyT>, dim3(((uint32_t)capacity + kpb - 1) / kpb), dim3(256), 0, st, (uint32_t)capacity, skey, ranges, n_dev);
         }
+        if (tsort) {   // the lists came out in index order (no depth sort in front, the tile sort is stable): every tile's by depth now
+            ProfScope ps(P_SORT_DEPTH, st);
+            hipLaunchKernelGGL(k_tile_sort_wave<true>, dim3(T), dim3(64), 0, st, ranges, pairs, list, T, ts_dkey);
+            hipLaunchKernelGGL((k_tile_sort<1024, true>), dim3(std::min(T, 512)), dim3(1024), 0, st, ranges, pairs, pairs_alt, list, T, ts_dkey);
+        }
         return GSR_OK;
     };
     auto launch_binning = [&](uint64_t capacity, const unsigned long long* n_dev, bool prezeroed) -> int {
@@ -3788,8 +3912,8 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
                                        (const uint32_t*)nullptr, ts_rec, splat, list, ranges, (uint32_t)std::min<uint64_t>(capacity, 0xffffffffull), ts_dkey, pairs);
                 }
                 ProfScope ps2(P_SORT_TILE, st);
-                hipLaunchKernelGGL(k_tile_sort<256>, dim3(T), dim3(256), 0, st, ranges, pairs, pairs_alt, list, T);
-                hipLaunchKernelGGL(k_tile_sort<1024>, dim3(T), dim3(1024), 0, st, ranges, pairs, pairs_alt, list, T);
+                hipLaunchKernelGGL(k_tile_sort_wave<false>, dim3(T), dim3(64), 0, st, ranges, pairs, list, T, (const uint32_t*)nullptr);
+                hipLaunchKernelGGL(k_tile_sort<1024>, dim3(std::min(T, 512)), dim3(1024), 0, st, ranges, pairs, pairs_alt, list, T);
                 return GSR_OK;
             }
             ProfScope ps(P_EMIT, st);
@@ -3871,7 +3995,12 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
     {
         const int ts_mode = g_tile_sort;
         const uint64_t avg = (hint > 0 ? hint : (uint64_t)N * 4u) / (uint64_t)T;
-        tsort = direct && NB == 1 && db.NS == 1 && (ts_mode == 2 || (ts_mode == 1 && avg <= (uint64_t)g_tile_sort_max_avg));
+        // (behind the direct binning: single renders whose tile tables fit one wave; behind the emit path -- batched renders, frames above
+        //  4 096 tiles -- wherever both sorts are the onesweep ones)
+        // (on the emit path the keys are gathered per pair and the lists of a large model spread widely: measured at 1920x1080, 300 k
+        //  Gaussians -1.7 % of the step, 1 M +1 ... +12 %; eight stage-A models in one launch chain -2.5 %: small models only)
+        const bool auto_ok = ts_mode == 1 && avg <= (uint64_t)g_tile_sort_max_avg && (direct || N / std::max(1, NB) <= g_tile_sort_emit_max_n);
+        tsort = (ts_mode == 2 || auto_ok) && g_sort_algo == 2 && (direct ? (NB == 1 && db.NS == 1) : true);
     }
 
     fs = static_cast<uint8_t*>(a->alloc(align256(L.bytes) + (direct ? dbs.bytes : 0), GSR_ALLOC_SCRATCH, a->alloc_user));   // (+ the chunk tables of the direct binning)
@@ -3980,7 +4109,8 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
             hipLaunchKernelGGL(k_chunk_scan1, dim3((db.Tp + 255) / 256, db.G), dim3(256), 0, st, db);
             hipLaunchKernelGGL(k_chunk_scan2, dim3((db.Tp + 255) / 256), dim3(256), 0, st, db, total, zjobs, host_slot, seq, wo);
         } else {
-            hipLaunchKernelGGL(k_tile_counts, dim3(nb + (bal.hdr ? 8 : 0)), dim3(kEmitThreads), 0, st, N, sorted_gid, ntiles, block_sums, srec, bal, nb);
+            hipLaunchKernelGGL(k_tile_counts, dim3(nb + (bal.hdr ? 8 : 0)), dim3(kEmitThreads), 0, st, N, sorted_gid, ntiles, block_sums,
+                               tsort ? (TileRec*)nullptr : srec, bal, nb, (tsort && early_r && !publish) ? rider : OsRider{});
             // the scan writes R straight into the pinned slot (device-visible host memory): no copy launch behind it
             hipLaunchKernelGGL(k_block_scan, dim3(1), dim3(1024), 0, st, block_sums, nb, total, zjobs, host_slot, seq, wo);
         }

@@ -655,8 +655,9 @@ def test_direct_binning_is_the_sort_routes_list(name):
     kw = parity.scene_kwargs(sc, "sh", bg=(0.1, 0.2, 0.3))
     res = {}
     try:
-        # 0 = emit + tile sort + ranges; 1 = depth sort + direct placement; 2 = direct placement in index order + per-tile depth sort
-        for route, (direct, tsort) in enumerate(((0, 0), (1, 0), (1, 2))):   # (tile_sort 2 = wherever the direct binning runs, whatever the lists' lengths)
+        # 0 = depth sort + emit + tile-key sort + ranges; 1 = depth sort + direct placement; 2 = direct placement in index order + per-tile
+        # depth sort; 3 = emit in index order + tile-key sort + ranges + per-tile depth sort
+        for route, (direct, tsort) in enumerate(((0, 0), (1, 0), (1, 2), (0, 2))):   # (tile_sort 2 = on every frame and model, whatever the lists' lengths)
             assert lib.gsr_set_option(b"direct_binning", direct) == 0
             assert lib.gsr_set_option(b"tile_sort", tsort) == 0
             if name == "overflow-rerun":
@@ -670,7 +671,7 @@ def test_direct_binning_is_the_sort_routes_list(name):
         lib.gsr_set_option(b"binning_capacity_hint", 0)
     (fa, ra, la, na) = res[0]
     assert na > 0
-    for route in (1, 2):
+    for route in (1, 2, 3):
         (fb, rb, lb, nb_) = res[route]
         assert na == nb_, f"route {route}"
         assert np.array_equal(ra, rb), f"route {route}: tile ranges differ"
@@ -698,7 +699,7 @@ def test_direct_binning_frame_sizes(W, H, N):
     kw = parity.scene_kwargs(sc, "sh")
     res = {}
     try:
-        for route, (direct, tsort) in enumerate(((0, 0), (1, 0), (1, 2))):   # (tile_sort 2 = wherever the direct binning runs, whatever the lists' lengths)
+        for route, (direct, tsort) in enumerate(((0, 0), (1, 0), (1, 2), (0, 2))):   # (tile_sort 2 = on every frame and model, whatever the lists' lengths)
             assert lib.gsr_set_option(b"direct_binning", direct) == 0
             assert lib.gsr_set_option(b"tile_sort", tsort) == 0
             fwd = hip_runner.run_hip(kw)["fwd"]
@@ -709,7 +710,7 @@ def test_direct_binning_frame_sizes(W, H, N):
         lib.gsr_set_option(b"tile_sort", 1)
     (fa, ra, la, na) = res[0]
     assert na > 0
-    for route in (1, 2):
+    for route in (1, 2, 3):
         (fb, rb, lb, nb_) = res[route]
         assert na == nb_ and np.array_equal(ra, rb) and np.array_equal(la[:na], lb[:nb_]), f"route {route}"
         for x, y in zip(fa, fb):

@@ -5,6 +5,11 @@ bt = importlib.import_module("3dgs_hierarchical_training_amd.batched")
 ts = importlib.import_module("3dgs_hierarchical_training_amd.train_step")
 host = importlib.import_module("3dgs_hierarchical_training_amd.host"); host.cap_host_threads()
 dev = torch.device("cuda:0")
+import os
+L = importlib.import_module("3dgs_hierarchical_training_amd._lib")
+for kv in os.environ.get("GSR_OPTS", "").split(","):
+    if "=" in kv:
+        k, v = kv.split("="); assert L.load().gsr_set_option(k.encode(), int(v)) == 0
 seq = sequence.FrameSequence(12, 400000, 980, 545, dev, seed=0)
 B = 8
 pairs = list(range(B))
@@ -18,6 +23,12 @@ tgt0 = torch.stack([seq.target(p) for p in pairs])
 for it in range(10):
     ts.train_step(params, ident, tgt0, next_settings=ident)
 torch.cuda.synchronize()
+import time
+t0 = time.perf_counter()
+for it in range(60):
+    ts.train_step(params, ident, tgt0, next_settings=ident)
+torch.cuda.synchronize()
+print("GSR_OPTS", os.environ.get("GSR_OPTS", ""), "batched step ms", 1e3 * (time.perf_counter() - t0) / 60, flush=True)
 from torch.profiler import profile, ProfilerActivity
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
     for it in range(5):
