@@ -1564,11 +1564,11 @@ __global__ __launch_bounds__(64) void k_chunk_scatter(DirectBin db, int W, int H
 // wave_rank: 8-bit digits, a digit all keys of the tile share is skipped); longer ones go through global memory a chunk at a time
 // (pairs <-> pairs_alt), same passes.
 // ------------------------------------------------------------------------------------------------
-// Two launches share the tiles by length: single waves take the segments of up to 512 pairs (k_tile_sort_wave below), 1 024-thread
+// Two launches share the tiles by length: single waves take the segments of up to 1 024 pairs (k_tile_sort_wave below), 1 024-thread
 // workgroups the longer ones (up to 4 096 pairs from registers, beyond that a chunk of 4 096 at a time through global memory).  The
 // second launch is a handful of persistent workgroups that walk the tile ranges for long segments (a frame has few or none: 17 360
 // workgroups of 1 024 threads that leave at once took 18 us to dispatch).
-constexpr int kTsCap = 4096, kTsSmallMax = 512;
+constexpr int kTsCap = 4096, kTsSmallMax = 1024;
 
 // GATHER (the route behind the emit path: batched renders, frames above 4 096 tiles): the segment holds Gaussian indices only, in index
 // order (the stable tile-key sort kept it); the keys are fetched from the per-Gaussian depth keys.  `dst` is then the segment itself:
@@ -1647,7 +1647,7 @@ __device__ __forceinline__ void tile_sort_regs(const uint2* __restrict__ src, ui
     }
 }
 
-// Segments of up to kTsSmallMax (512) pairs: ONE WAVE per tile (round 5, second form: the four-wave workgroups spent their time in barriers --
+// Segments of up to kTsSmallMax (1 024) pairs: ONE WAVE per tile (round 5, second form: the four-wave workgroups spent their time in barriers --
 // six per pass -- and a CU held seven of them; a lone wave needs none, its LDS operations execute in program order, and twenty of
 // them share a CU).  Pair p of the segment sits in register p / 64 of lane p % 64; a pass ranks the digits round by round
 // (wave_rank), scans the 256 digit counts four per lane, scatters the pairs into LDS and reads them back in order.
@@ -1706,6 +1706,9 @@ __device__ __forceinline__ void tile_sort_wave(const uint2* __restrict__ src, ui
     }
 }
 
+// (measured and not kept: segments of 513 ... 1 024 pairs in a launch of their own, so that the sixteen pairs per lane they need do not
+//  set the register budget of the short ones -- 8 kB and 60 VGPRs per tile instead of 12 kB and 101: eight batched stage-A models 47 -> 41
+//  us, but a model of 300 k Gaussians, most of whose tiles lie in between, 28 -> 39 us for the extra launch)
 template <bool GATHER = false>
 __global__ __launch_bounds__(64) void k_tile_sort_wave(const uint2* __restrict__ ranges, const uint2* __restrict__ pairs, uint32_t* list, int T,
                                                        const uint32_t* __restrict__ dkey = nullptr)
@@ -1724,7 +1727,8 @@ __global__ __launch_bounds__(64) void k_tile_sort_wave(const uint2* __restrict__
     if (n <= 64u) tile_sort_wave<1, GATHER>(src, dst, n, dkey, s_mask, s_cnt, s_start, s_keys, s_vals);
     else if (n <= 128u) tile_sort_wave<2, GATHER>(src, dst, n, dkey, s_mask, s_cnt, s_start, s_keys, s_vals);
     else if (n <= 256u) tile_sort_wave<4, GATHER>(src, dst, n, dkey, s_mask, s_cnt, s_start, s_keys, s_vals);
-    else tile_sort_wave<8, GATHER>(src, dst, n, dkey, s_mask, s_cnt, s_start, s_keys, s_vals);
+    else if (n <= 512u) tile_sort_wave<8, GATHER>(src, dst, n, dkey, s_mask, s_cnt, s_start, s_keys, s_vals);
+    else tile_sort_wave<16, GATHER>(src, dst, n, dkey, s_mask, s_cnt, s_start, s_keys, s_vals);
 }
 
 template <int THREADS, bool GATHER = false>
@@ -1760,7 +1764,6 @@ __global__ __launch_bounds__(THREADS) void k_tile_sort(const uint2* __restrict__
     const uint32_t n = rg.y - rg.x;
     if (n <= (uint32_t)kTsSmallMax) continue;   // (the other launch's; uniform)
     __syncthreads();   // (the previous tile's LDS is done with)
-    if (n <= 1024u) { tile_sort_regs<THREADS, 1, GATHER>(pairs + rg.x, list + rg.x, n, dkey, s_mask, s_cnt, s_keys, s_vals, s_start, s_wsum, s_bits); continue; }
     if (n <= 2048u) { tile_sort_regs<THREADS, 2, GATHER>(pairs + rg.x, list + rg.x, n, dkey, s_mask, s_cnt, s_keys, s_vals, s_start, s_wsum, s_bits); continue; }
     if (n <= (uint32_t)kTsCap) { tile_sort_regs<THREADS, 4, GATHER>(pairs + rg.x, list + rg.x, n, dkey, s_mask, s_cnt, s_keys, s_vals, s_start, s_wsum, s_bits); continue; }
     // ---- a long segment: the same passes through global memory, a chunk of kTsCap pairs at a time (this workgroup alone reads and
@@ -3513,7 +3516,7 @@ static int g_tile_sort = 1;       // round 5: no global depth sort in front of t
                                   // 0 = off (depth sort + direct binning), 1 = where it wins: tile lists of up to g_tile_sort_max_avg pairs on average (by the caller's
                                   // last R, or 4 N before there is one), 2 = wherever the direct binning runs
 static int g_tile_sort_emit_max_n = 400000;   // behind the emit path (batched renders, frames above 4 096 tiles): models of up to this many Gaussians
-static int g_tile_sort_max_avg = 800;   // measured (tools/ab_tile_sort*.sh, 980x545): 20 k ... 300 k Gaussians (50 ... 620 pairs per tile) -3 ... -6 % of the step,
+static int g_tile_sort_max_avg = 700;   // measured (tools/ab_tile_sort*.sh, 980x545): 20 k ... 300 k Gaussians (50 ... 620 pairs per tile) -3 ... -6 % of the step,
                                         // 1 M (2 070 per tile) +6 %: the per-tile sorts move R pairs where the depth sort moves N keys
 static int g_direct_bin = 1;      // tile lists by direct placement (k_chunk_counts / k_chunk_scatter) instead of emit + tile sort + ranges; 0 = the sort route
 static int g_view_pose_tol_e6 = 2000;   // balanced placement without a view id: a render belongs to the cached view whose pose is within this (x 1e-6) in every matrix entry

@@ -291,7 +291,7 @@ int gsr_version(void);
  *                          left out: the binning walks the Gaussians in index order, places (depth key, Gaussian) pairs, and one
  *                          workgroup per tile sorts its segment by key, stable; 2 = wherever the direct binning runs; 0 = never.
  *                          Same list, bit for bit (equal keys stay in index order, as under the stable global sort)
- *   "tile_sort_max_avg"    (default 800) see "tile_sort"
+ *   "tile_sort_max_avg"    (default 700) see "tile_sort"
  *   "blend_balance"        1 (default) = the forward blend places its sub-tile waves by the visits each took at the previous
  *                          render of the same frame (device-side cache of 128 frames per frame size, least recently used out; a
  *                          frame is recognised by GsrForwardArgs::view_id or, without one, by its pose; single renders through

@@ -7,7 +7,7 @@ import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); s=d['stage_ms']
 print('$*', 'ms %.4f' % d['ms_per_step'], 'median %.4f' % d['step_host_ms']['median'], {k: round(1e3*v,1) for k,v in s.items() if v and k in ('sort_depth','sort_tile','emit','scan')})"
 }
-for n in 20000 50000 130000 300000; do for rep in 1 2 3; do
+for n in ${SIZES:-20000 50000 130000 300000}; do for rep in 1 2 3; do
   run tile_sort=0 --gaussians $n --sh-degree 0
   run tile_sort=1 --gaussians $n --sh-degree 0
 done; done
