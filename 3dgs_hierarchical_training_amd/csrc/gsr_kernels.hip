@@ -268,7 +268,10 @@ __device__ __forceinline__ float row_sum_to_lane15(float v)
     return v;
 }
 
-constexpr int kPreThreads = 128;
+#ifndef GSR_PRE_THREADS
+#define GSR_PRE_THREADS 128      // (experiment: 64 = one wave per block of the per-Gaussian kernels -- same waves per CU, barriers that cost nothing; the
+#endif                           //  batched parameter store pads its models to 128: single renders only)
+constexpr int kPreThreads = GSR_PRE_THREADS;
 constexpr uint32_t kDepthKeyBias = 0x3E4CCCCDu;   // bit pattern of the near plane, 0.2f (gsr_math.h kNearZ): no visible Gaussian's depth key lies below it
 __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x);   // (defined with the direct binning)
 constexpr int kShStride = 49;   // 48 floats + 1 pad: conflict-free column reads
