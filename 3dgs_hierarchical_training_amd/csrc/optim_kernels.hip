@@ -297,7 +297,9 @@ extern "C" int gsr_pose_step_camera(float* delta6, float* exp_avg6, float* exp_a
 // ---- measurement hook: the practical HBM ceiling of the box -------------------------------------------------------------------
 // A float4 streaming copy (read + write), what bench.py reports as roofline.peak_measured next to the 8 TB/s vendor peak.
 // variant 0: plain 16-byte loads / stores, grid-stride; 1: the same with the nt bit; 2: four independent 16-byte loads in flight
-// per lane before the first store (nt): the form the per-Gaussian backward's moment streams use.
+// per lane before the first store (nt): the form the per-Gaussian backward's moment streams use; 3 (round 5): persistent workgroups,
+// contiguous runs, eight loads in flight per lane -- what the chip's memory system delivers to a kernel that asks for it this way
+// (tools/overlap_persist.py: 6.4-6.8 TB/s with six streams), and the honest ceiling for `frac_of_measured`.
 namespace gsr {
 template <int VARIANT>
 __global__ __launch_bounds__(256) void k_stream_copy(const float4* __restrict__ src, float4* __restrict__ dst, size_t n4)
@@ -309,6 +311,18 @@ __global__ __launch_bounds__(256) void k_stream_copy(const float4* __restrict__ 
             const float4 a = nt_load4(src + i), b = nt_load4(src + i + stride), c = nt_load4(src + i + 2 * stride), d = nt_load4(src + i + 3 * stride);
             nt_store4(dst + i, a); nt_store4(dst + i + stride, b); nt_store4(dst + i + 2 * stride, c); nt_store4(dst + i + 3 * stride, d);
         }
+    }
+    if (VARIANT == 3) {   // a few persistent workgroups, each with a contiguous run of 256 x 8 pieces per turn and eight loads in flight per lane
+        constexpr int U = 8;
+        const size_t turn = (size_t)gridDim.x * 256u * U;
+        for (size_t q0 = (size_t)blockIdx.x * 256u * U + threadIdx.x; q0 < n4; q0 += turn) {
+            float4 x[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) { const size_t q = q0 + (size_t)u * 256u; if (q < n4) x[u] = nt_load4(src + q); }
+#pragma unroll
+            for (int u = 0; u < U; u++) { const size_t q = q0 + (size_t)u * 256u; if (q < n4) nt_store4(dst + q, x[u]); }
+        }
+        return;
     }
     for (; i < n4; i += stride) {
         if (VARIANT == 0) dst[i] = src[i];
@@ -327,6 +341,7 @@ extern "C" int gsr_stream_copy(const void* src, void* dst, size_t bytes, int var
     if (variant == 0) hipLaunchKernelGGL(gsr::k_stream_copy<0>, dim3(blocks), dim3(256), 0, st, s, d, n4);
     else if (variant == 1) hipLaunchKernelGGL(gsr::k_stream_copy<1>, dim3(blocks), dim3(256), 0, st, s, d, n4);
     else if (variant == 2) hipLaunchKernelGGL(gsr::k_stream_copy<2>, dim3(blocks), dim3(256), 0, st, s, d, n4);
+    else if (variant == 3) hipLaunchKernelGGL(gsr::k_stream_copy<3>, dim3(blocks), dim3(256), 0, st, s, d, n4);
     else return GSR_ERR_ARG;
     return hipGetLastError() == hipSuccess ? GSR_OK : GSR_ERR_HIP;
 }

@@ -172,8 +172,8 @@ def cpu_baseline(scene, threads):
 
 
 def copy_ceiling(lib, dev, nbytes=1 << 30, reps=10):
-    """The practical HBM ceiling of THIS box: the library's own float4 streaming copy (gsr_stream_copy: plain, nt, and nt with four
-    loads in flight per lane; several grid sizes), read + write bytes / time, best form reported.  No kernel of the step can
+    """The practical HBM ceiling of THIS box: the library's own float4 streaming copy (gsr_stream_copy: plain, nt, nt with four
+    loads in flight per lane, and persistent workgroups with eight; several grid sizes), read + write bytes / time, best form reported.  No kernel of the step can
     stream faster than this, so no `frac_of_measured` may exceed 1."""
     a = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     b = torch.empty_like(a)
@@ -181,8 +181,8 @@ def copy_ceiling(lib, dev, nbytes=1 << 30, reps=10):
     st = torch.cuda.current_stream(dev).cuda_stream
     best, form = 0.0, None
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    for variant in (0, 1, 2):
-        for blocks in (2048, 4096, 8192, 16384):
+    for variant in (0, 1, 2, 3):
+        for blocks in ((256, 512, 1024, 2048) if variant == 3 else (2048, 4096, 8192, 16384)):
             for _ in range(2):
                 lib.gsr_stream_copy(a.data_ptr(), b.data_ptr(), nbytes, variant, blocks, C.c_void_p(st))
             torch.cuda.synchronize(dev)

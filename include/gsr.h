@@ -441,7 +441,8 @@ int gsr_knn_mean_dist2(const float* points /*[N,3]*/, int32_t N, float* out /*[N
 
 /* Measurement hook (bench.py roofline.peak_measured): float4 streaming copy of `bytes` bytes (a multiple of 16, 16-byte aligned
  * pointers) with `blocks` workgroups of 256 threads.  variant 0 = plain loads / stores, 1 = nt bit, 2 = four loads in flight per
- * lane (nt).  The achieved read + write rate is the practical HBM ceiling of the box for a streaming kernel. */
+ * lane (nt), 3 = persistent workgroups (a few hundred), contiguous runs, eight loads in flight per lane (nt).  The best achieved read +
+ * write rate is the practical HBM ceiling of the box for a streaming kernel. */
 int gsr_stream_copy(const void* src, void* dst, size_t bytes, int variant, int blocks, void* stream);
 
 /* Building blocks exported for the unit tests of tests/test_gpu_blocks.py (device pointers). */
