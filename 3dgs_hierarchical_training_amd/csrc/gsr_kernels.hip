@@ -1859,6 +1859,10 @@ __device__ unsigned long long g_k8_dbg[4 * 65536];
 __device__ unsigned long long g_k6_cyc[2 * 65536];   // per forward-blend wave: cycles in staging / in the visit loops
 __device__ uint32_t g_k6_cnt[2 * 65536];   // per forward-blend wave: visits, taken visits   // the same for the backward blend's workgroups (wave 0)
 #endif
+#ifndef GSR_FWD_BUFS
+#define GSR_FWD_BUFS 2      // staging buffers of a forward-blend wave (round 5, measured: 1 -- a lone wave's LDS operations execute in order, so the next
+#endif                      // batch may overwrite the one just visited; 2.5 instead of 5 kB per wave -- the same 96-97 us: LDS does not bound its residency)
+constexpr int kFwdBufs = GSR_FWD_BUFS;
 template <bool REACH>
 __device__ __forceinline__ void blend_fwd_item(const int xcd, const int kslot, float4 (*s_ab)[64], float2 (*s_c)[64],
                                                int W, int H, int tiles_x, int T, const uint2* __restrict__ ranges,
@@ -1924,7 +1928,7 @@ __device__ __forceinline__ void blend_fwd_item(const int xcd, const int kslot, f
     }
     int batches = 0;
     for (int b = 0; b < nb; b++) {
-        const int buf = b & 1;
+        const int buf = b & (kFwdBufs - 1);
         if (__all(Tr < 0.f)) break;
         // (round 5, measured and not kept: the six stores moved behind the staging, so that they do not sit between the batch's record
         //  loads and their first use in the wave's in-order vmcnt queue -- 98-100 us against 97)
@@ -1943,7 +1947,7 @@ __device__ __forceinline__ void blend_fwd_item(const int xcd, const int kslot, f
             ra.x = pixel_rel(ra.x, pixel_lo_x(lo), tox); ra.y = pixel_rel(ra.y, pixel_lo_y(lo), toy);
         }
         ra.z *= -0.5f * kL2E; ra.w *= -kL2E; rb.x *= -0.5f * kL2E;
-        s_ab[buf][lane] = ra; s_ab[2 + buf][lane] = rb; s_c[buf][lane] = make_float2(rc.x, rc.y);
+        s_ab[buf][lane] = ra; s_ab[kFwdBufs + buf][lane] = rb; s_c[buf][lane] = make_float2(rc.x, rc.y);
         const unsigned long long reach = REACH ? __ballot(reach_me && lane < cnt) : 0ull;
         visits += REACH ? (uint32_t)__popcll(reach) : (uint32_t)cnt;
         // the staging area belongs to this wave alone: LDS instructions of one wave execute in issue order, so the broadcast
@@ -1961,7 +1965,7 @@ __device__ __forceinline__ void blend_fwd_item(const int xcd, const int kslot, f
         id_nn = list[rg.x + min(nxt + NT, n - 1)];
         auto alpha_of = [&](int j, float& p2) {
             const float4 A = s_ab[buf][j];
-            const float2 Bq = *reinterpret_cast<const float2*>(&s_ab[2 + buf][j]);   // C', opacity
+            const float2 Bq = *reinterpret_cast<const float2*>(&s_ab[kFwdBufs + buf][j]);   // C', opacity
             const float dx = A.x - pxf, dy = A.y - pyf;
             p2 = fmaf(Bq.x * dy, dy, fmaf(A.w, dy, A.z * dx) * dx);   // log2 of the Gaussian weight
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1983,7 +1987,7 @@ __device__ __forceinline__ void blend_fwd_item(const int xcd, const int kslot, f
 #ifdef GSR_K6_TIMING
             dbg_taken++;
 #endif
-            const float4 B = s_ab[2 + buf][j];
+            const float4 B = s_ab[kFwdBufs + buf][j];
             const float2 C = s_c[buf][j];
             const float am = hit ? alpha : 0.f;
             const float test_T = Tr * (1.f - am);             // negative for a finished pixel: fails the stop test below
@@ -2074,8 +2078,8 @@ __global__ __launch_bounds__(64) void k_blend_fwd_w6(int W, int H, int tiles_x, 
 {
     // s_a and s_b in ONE array (planes 0/1 = A rows of the two buffers, 2/3 = B rows): a visit's two reads share one address
     // register and differ in the immediate offset
-    __shared__ float4 s_ab[4][64];
-    __shared__ float2 s_c[2][64];
+    __shared__ float4 s_ab[2 * kFwdBufs][64];
+    __shared__ float2 s_c[kFwdBufs][64];
     // balanced placement (see balance_build): the slot -> item table of this render, and where this item's visits are recorded
     int kslot = (int)(blockIdx.x >> 3);
     uint16_t* cost_out = nullptr;
