@@ -1,15 +1,20 @@
 // gsr_kernels.hip -- hand-written HIP kernels (gfx950 / CDNA4, wave64) + the C ABI of include/gsr.h.
 //
-// Pipeline (DESIGN.md has the byte accounting):
-//   forward   K1 k_preprocess      per Gaussian: cull, project, cov2D, conic, radius, SH colour -> 48-B Splat
-//             K2 radix sort        32-bit depth keys over N (4 passes)           -> depth order
-//             K3 k_tile_counts / k_block_scan  tiles-touched in depth order -> offsets, R (written to pinned host memory)
-//             K4 k_emit            cooperative, coalesced emission of (tile u16, gid u32) in depth order
-//             K5 radix sort        16-bit tile keys over R (<=2 passes, stable) -> (tile, depth, id) order
-//             K6 k_tile_ranges     per-tile [start,end)
-//             K7 k_blend_fwd       per-tile front-to-back compositing, LDS-staged double-buffered lists
-//   backward  K8 k_blend_bwd       front-to-back replay, wave64 DPP reductions, one atomic set per (tile, Gaussian)
-//             K9 k_preprocess_bwd  per Gaussian: conic/cov2D/cov3D/projection/SH chain rule
+// Pipeline (DESIGN.md section 4 has a cell per kernel with its time and roof; three binning routes build the same lists bit for bit):
+//   forward   K1 k_preprocess      per Gaussian: cull, project, cov2D, conic, radius, SH colour -> 48-B Splat, 8-B TileRec, depth key
+//                                  (in the fused training loop its work rides in K9: "prepare in backward")
+//             K2 onesweep sort     depth keys over N: histogram + three 9-bit passes (radix_sort.h)        -> depth order
+//             K3-K6 direct binning k_chunk_counts / k_chunk_scan1 / k_chunk_scan2 / k_chunk_scatter: every (Gaussian, tile) pair written
+//                                  once, at its final place (frames of up to 4 096 tiles)
+//             K3s-K6s emit path    k_tile_counts / k_block_scan, k_emit, onesweep sort of 16-bit tile keys over R, k_tile_ranges
+//                                  (larger frames, batched renders)
+//             K2t tile-sort route  no K2: binning in INDEX order, then k_tile_sort_wave / k_tile_sort<1024> order every tile's segment by
+//                                  depth key, stable (models with short tile lists)
+//             K7 k_blend_fwd_w6    one wave per 8x8 pixel block, front-to-back compositing, LDS-staged lists, checkpoints
+//   backward  K8p k_bwd_prologue   zero-fill of the per-Gaussian accumulators + the backward blend's work items
+//             K8 k_blend_bwd2      persistent workgroups, front-to-back replay from checkpoints, DPP reductions, one atomic set per (tile, Gaussian)
+//             K9 k_preprocess_bwd  per Gaussian: conic / cov2D / cov3D / projection / SH chain rule (float64), optionally the Adam update of
+//                                  all six parameter groups and the next render's K1
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <type_traits>
