@@ -2599,6 +2599,305 @@ __global__ __launch_bounds__(128) void k_blend_bwd2(BlendBwdArgs args_)
     }
 }
 
+// K8s (round 5): the same replay with ONE pixel per lane and FOUR waves per tile -- wave w owns the 8x8 block (w & 1, w >> 1) of the tile, the
+// forward blend's sub-tile w, lane = its lane -- for scenes of small splats: a staged instance carries four reach bits instead of two and a
+// wave visits it only when its own 64 pixels can see it (a pixel-sized splat reaches one or two of the four blocks, but always a whole
+// 16x8 half).  Scalar arithmetic (nothing to pack), the same reduction, staging, work items, checkpoints and flush as k_blend_bwd2.
+template <bool HAS_DA>
+__global__ __launch_bounds__(256) void k_blend_bwd1(BlendBwdArgs args_)
+{
+    constexpr int NT = 128, NTH = 256, NV = HAS_DA ? 10 : 9;   // (instances per staged batch; threads = four waves per workgroup)
+    // (staging planes, partial rows, work items and flush: see k_blend_bwd2)
+    __shared__ float4 s_ab[2][NT];
+    __shared__ typename std::conditional<HAS_DA, float4, float2>::type s_c[NT];
+    __shared__ uint32_t s_gid[1][NT];
+    __shared__ float s_part[NT][NV];
+    uint32_t* const s_max = &s_gid[0][0];   // [4], only until the staging below (a barrier sits between)
+    __shared__ uint32_t s_pull;
+    constexpr float kL2E = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
+#pragma unroll
+    for (int k = 0; k < NV; k++) if (threadIdx.x < NT) s_part[threadIdx.x][k] = 0.f;   // every flush re-zeroes what it consumed
+    int qx = (int)(blockIdx.x & 7u), tried = 0;
+    uint32_t qi = blockIdx.x >> 3;
+    for (;;) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const __attribute__((address_space(4))) BlendBwdArgs* KArgs;
+    KArgs ka = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka));
+    int tid = (int)threadIdx.x;
+    asm volatile("" : "+v"(tid));
+#else
+    const BlendBwdArgs* ka = &args_;
+    int tid = (int)threadIdx.x;
+#endif
+    const int lane = tid & 63, wave = tid >> 6;
+    const int part_slot = reduce2_slot<NV>(lane);          // which of a visit's NV totals this lane ends up with (-1: none)
+    const uint32_t part_off = (uint32_t)(part_slot < 0 ? 0 : part_slot);
+    const int W = ka->W, H = ka->H, tiles_x = ka->tiles_x, tiles_y = ka->tiles_y, T = ka->T, kCkptFirst = ka->kCkptFirst;
+    BwdItemHdr* const hdr = ka->hdr;
+    const uint2* const __restrict__ ranges = ka->ranges;
+    const uint32_t* const __restrict__ list = ka->list;
+    const Splat* const __restrict__ splat = ka->splat;
+    const float* const __restrict__ bg = ka->bg;
+    const float* const __restrict__ img = ka->img;
+    const float* const __restrict__ g_color = ka->g_color;
+    const float* const __restrict__ g_depth = ka->g_depth;
+    const float* const __restrict__ g_alpha = ka->g_alpha;
+    float* const __restrict__ ggrad = ka->ggrad;
+    const float* const __restrict__ ckpt = ka->ckpt;
+    float* const __restrict__ det_part = ka->det_part;
+    // ---- next item -------------------------------------------------------------------------------------------------------
+    uint32_t qcount = hdr->count[qx];
+    while (qi >= qcount) {           // (workgroup-uniform: qi and qx are)
+        if (++tried == 8) {
+            return;
+        }
+        qx = (qx + 1) & 7;
+        qcount = hdr->count[qx];
+        qi = 0xffffffffu;
+        if (qcount == 0u) continue;
+        if (tid == 0) {
+            uint32_t v = __hip_atomic_load(&hdr->head[qx][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (v < qcount) v = __hip_atomic_fetch_add(&hdr->head[qx][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_pull = v;
+        }
+        __syncthreads();
+        qi = s_pull;
+        __syncthreads();
+    }
+    const uint2 item = ka->items[hdr->offset[qx] + qi];
+    const int Tl = tiles_x * tiles_y;
+    const size_t Pl = (size_t)W * H, P = Pl * (size_t)(T / Tl);
+    const float cyf = 0.5f * (float)H;
+    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
+    const int tile = (int)item.x;
+    int b0 = (int)(item.y & 0x7fffffffu);
+    int b1 = (item.y & 0x80000000u) ? 0x7fffffff : (b0 == 0 ? kCkptFirst : b0 + 1);
+    const int bimg = tile / Tl, tl = tile - bimg * Tl;   // batched render: see k_blend_fwd_w6
+    const int tx = tl % tiles_x, ty = tl / tiles_x;
+    const int sbx = (wave & 1) * 8, sby = (wave >> 1) * 8;   // this wave's 8x8 block inside the tile (= the forward blend's sub-tile `wave`)
+    const int px = tx * kTile + sbx + (lane & 7);
+    const int py = ty * kTile + sby + (lane >> 3);
+    // the pixel's column / row inside the tile; the staged means are relative to the tile's first pixel (gsr_math.h pixel_rel), exactly
+    // as the forward blend forms them
+    const float pxf = (float)(sbx + (lane & 7)), pyf = (float)(sby + (lane >> 3));
+    const uint2 rg = ranges[tile];
+    const float* const imgb = img + (size_t)bimg * Pl;                       // this image's slice of every state plane (planes are P apart)
+    const float* const g_colorb = g_color ? g_color + (size_t)bimg * 3 * Pl : nullptr;  // upstream gradients: [B, 3, H, W], [B, 1, H, W]
+    const float* const g_depthb = g_depth ? g_depth + (size_t)bimg * Pl : nullptr;
+    const float* const g_alphab = g_alpha ? g_alpha + (size_t)bimg * Pl : nullptr;
+    do {
+
+    // S = <gC, suffix colour> + gD * suffix depth + gA * suffix alpha + T_final <bg, gC>: the only combination of the
+    // suffix sums the gradient needs, so ONE running value per pixel replaces five (and the bg term rides along)
+    float Tt = 1.f, S = 0.f, gC0 = 0.f, gC1 = 0.f, gC2 = 0.f, gD = 0.f, gA = 0.f;
+    uint32_t ncon = 0u;
+    if (px < W && py < H) {
+        const size_t pid = (size_t)py * W + px;
+        ncon = reinterpret_cast<const uint32_t*>(imgb)[P + pid];
+        if (g_colorb) { gC0 = g_colorb[pid]; gC1 = g_colorb[Pl + pid]; gC2 = g_colorb[2 * Pl + pid]; }
+        float s = gC0 * imgb[2 * P + pid] + gC1 * imgb[3 * P + pid] + gC2 * imgb[4 * P + pid];
+        if (HAS_DA) {
+            if (g_depthb) gD = g_depthb[pid];
+            if (g_alphab) gA = g_alphab[pid];
+            s += gD * imgb[5 * P + pid] + gA * imgb[6 * P + pid];
+        }
+        S = s + imgb[pid] * (bg0 * gC0 + bg1 * gC1 + bg2 * gC2);
+    }
+    uint32_t nmax = ncon;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, off, 64));
+    if (lane == 0) s_max[wave] = nmax;
+    __syncthreads();
+    const int n = (int)max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+    const int nw = (int)s_max[wave];
+    __syncthreads();   // s_max is s_gid: nobody stages before everyone has read it
+    const int nb = (n + NT - 1) / NT;
+    b1 = min(b1, nb);
+    if (b0 >= b1) break;    // (uniform) the staged depth over-estimated the deepest contributor
+    if (b0 > 0) {   // resume from the forward's checkpoint at batch b0: T there, S = what is still to come
+        const float* c = ckpt + ((size_t)(rg.x >> 7) + tile + b0 - kCkptFirst) * kCkptFloats;
+        const int pi = wave * 64 + lane;   // k_blend_fwd_w's (sub-tile, lane): this very wave and lane
+        if (ncon > (uint32_t)(b0 * NT)) {   // the pixel was still blending at this boundary: its wave wrote the slot
+            Tt = c[pi];
+            float s = gC0 * c[256 + pi] + gC1 * c[512 + pi] + gC2 * c[768 + pi];
+            if (HAS_DA) s += gD * c[1024 + pi] + gA * c[1280 + pi];
+            S -= s;
+        } else {                            // finished earlier: takes no part here (and its slot may be unwritten)
+            Tt = 0.f; S = 0.f; ncon = 0u;
+        }
+    }
+
+    float4 ra = {0, 0, 0, 0}, rb = ra, rc = ra;
+    uint32_t rg_id = 0;
+    // (the staged copy: as k_blend_bwd2; rc.w carries FOUR reach bits, one per 8x8 block: the box test of the forward blend's sub-tiles)
+    const float hbx0 = (float)(tx * kTile) - 0.5f * (float)W, hbx1 = fminf(hbx0 + (float)(kTile - 1), (float)(W - 1) - 0.5f * (float)W);
+    const float hby0 = (float)(ty * kTile) - cyf, hbyL = (float)(H - 1) - cyf, hbxL = (float)(W - 1) - 0.5f * (float)W;
+    (void)hbx1;
+    // (records requested one batch ahead, first touched at the top of the batch that stages them: see k_blend_bwd2)
+    uint32_t id_nxt = 0u;     // list entry of this thread's instance in the batch after the one in (ra, rb, rc)
+    bool pend = false;        // (ra, rb, rc) hold a raw record that stage_finish has not yet turned into its staged form
+    // (EVERY lane requests, a lane without an instance from a clamped position: behind a divergent branch the loaded registers meet the
+    //  old ones at a join, hipcc copies them there, and the copy waits for the load)
+    auto stage_request = [&](uint32_t id, bool want) {
+        rg_id = id;
+        // three whole 16-byte loads into three aligned register quads: left to itself hipcc trims the record's unused words away and
+        // lands a lone dword in a register whose neighbour is the broadcast operand of a packed instruction of the visit -- which then
+        // waits for the load (`v_pk_fma v[38:39], v[28:29], ...` with the load's v29 in flight)
+        typedef float vf4 __attribute__((ext_vector_type(4)));
+        const vf4* sp = reinterpret_cast<const vf4*>(splat + id);
+        const vf4 q0 = sp[0], q1 = sp[1], q2 = sp[2];
+        ra = make_float4(q0.x, q0.y, q0.z, q0.w); rb = make_float4(q1.x, q1.y, q1.z, q1.w); rc = make_float4(q2.x, q2.y, q2.z, q2.w);
+        pend = want;
+    };
+    auto list_at = [&](int idx) -> uint32_t { return list[rg.x + (uint32_t)min(idx, n - 1)]; };
+    auto stage_finish = [&]() {
+#if defined(__HIP_DEVICE_COMPILE__)
+        // the record's two words the blend does not read stay "used" until here: a register the allocator takes for dead it hands to the
+        // visit loop as a temporary, and writing it waits for the load that is still filling its quad
+        asm volatile("" :: "v"(rb.z), "v"(rc.z));
+#endif
+        const TileTest tt = make_tile_test(ra.x, ra.y, ra.z, ra.w, rb.x, rb.y);
+        uint32_t fl = 0u;
+#pragma unroll
+        for (int sb = 0; sb < 4; sb++) {   // block sb = (sb & 1, sb >> 1): its pixel box clipped to the frame, as k_blend_fwd_w6 tests its sub-tile
+            const float x0 = hbx0 + (float)((sb & 1) * 8), y0 = hby0 + (float)((sb >> 1) * 8);
+            if (x0 <= hbxL && y0 <= hbyL) fl |= box_accept(tt, x0, y0, fminf(x0 + 7.f, hbxL), fminf(y0 + 7.f, hbyL)) ? (1u << sb) : 0u;
+        }
+        {
+            const uint32_t lo = __float_as_uint(rc.w);   // (the record's `tiles` word: the remainders of the mean)
+            ra.x = pixel_rel(ra.x, pixel_lo_x(lo), hbx0); ra.y = pixel_rel(ra.y, pixel_lo_y(lo), hby0);
+        }
+        rc.w = __uint_as_float(fl);
+        ra.z *= -0.5f * kL2E; ra.w *= -kL2E; rb.x *= -0.5f * kL2E;
+        pend = false;
+    };
+    const bool stager = tid < NT;   // (waves 0 and 1 stage the batch of 128; all four visit it)
+    if (stager) {
+        stage_request(list_at(b0 * NT + tid), b0 * NT + tid < n);
+        id_nxt = list_at((b0 + 1) * NT + tid);
+    }
+    for (int b = b0; b < b1; b++) {
+        const int buf = 0;
+        if (b > b0) __syncthreads();   // everyone is done reading the previous batch (and its flush read s_gid)
+        if (pend) stage_finish();      // first touch of the record requested a batch ago
+        if (stager) {
+            s_ab[0][tid] = ra; s_ab[1][tid] = make_float4(rb.x, rb.y, rb.w, rc.x); s_gid[buf][tid] = rg_id;
+            if constexpr (HAS_DA) s_c[tid] = make_float4(rc.y, rc.w, rb.z, 0.f); else s_c[tid] = make_float2(rc.y, rc.w);
+        }
+        __syncthreads();
+        if (stager) {
+            stage_request(id_nxt, (b + 1) * NT + tid < n && b + 1 < b1);   // (its index arrived during the last batch)
+            id_nxt = list_at((b + 2) * NT + tid);
+        }
+        const int cnt = min(NT, n - b * NT);
+        // a wave only walks as far as ITS pixels' last contributor (the tile-wide n bounds the staging and the barriers)
+        const int cntw = min(cnt, nw - b * NT);
+        // the reach bits of the batch as two wave-uniform 64-bit masks: the loop below visits set bits only, so an
+        // instance this half cannot reach costs nothing at all
+        const uint32_t wbit = 1u << wave;
+        const bool r0 = lane < cntw && (__float_as_uint(s_c[lane].y) & wbit);
+        const bool r1 = lane + 64 < cntw && (__float_as_uint(s_c[lane + 64].y) & wbit);
+        const unsigned long long reach[2] = {__ballot(r0), __ballot(r1)};
+#pragma unroll 1
+        for (int half = 0; half < 2; half++)
+        for (unsigned long long rm = reach[half]; rm != 0ull; rm &= rm - 1ull) {
+            const int j = half * 64 + (int)__builtin_ctzll(rm);
+            const float4 A = s_ab[0][j], B = s_ab[1][j];   // (manual LDS prefetch measured slower)
+            const auto C = s_c[j];
+            const uint32_t idx = (uint32_t)(b * NT + j + 1);
+            const float ca = A.z, cb = A.w, cc = B.x, op = B.y, cr = B.z, cg = B.w, cbl = C.x;   // ca/cb/cc: A', B', C'
+            float zd = 0.f;
+            if constexpr (HAS_DA) zd = C.z;
+            const float dx = A.x - pxf, dy = A.y - pyf;
+            const float p2 = __builtin_fmaf(cc * dy, dy, __builtin_fmaf(cb, dy, ca * dx) * dx);   // log2 of the Gaussian weight (= k_blend_fwd_w, = k_blend_bwd2 per component)
+#if defined(__HIP_DEVICE_COMPILE__)
+            float G = __builtin_amdgcn_exp2f(p2);
+#else
+            float G = exp2f(p2);
+#endif
+            float alpha = op * G;   // clamped to kAlphaMax only once the visit is taken (the 1/255 test below reads the same either way)
+            const bool c0p = !(p2 > 0.f), c0a = !(alpha < kAlphaMin), c0n = idx <= ncon;
+            const bool v0 = c0p && c0a && c0n;
+            // (wave-uniform test on the compare masks themselves: see k_blend_bwd2)
+            const unsigned long long any0 = __builtin_amdgcn_ballot_w64(c0p) & __builtin_amdgcn_ballot_w64(c0a) & __builtin_amdgcn_ballot_w64(c0n);
+            if (any0 != 0ull) {
+                G = v0 ? G : 0.f;
+                alpha = fminf(kAlphaMax, op * G);
+                const float w = alpha * Tt;
+                float gc = gC0 * cr + gC1 * cg + gC2 * cbl;          // <gC, colour of this Gaussian> (+ depth / alpha terms)
+                if (HAS_DA) gc += gD * zd + gA;
+                S -= gc * w;
+                const float om = 1.f - alpha;
+                const float dLda = gc * Tt - S * fast_rcp(om);
+                const float dLdpow = G * (op * dLda);
+                // the moments of dLdpow over the pixels (the per-record combination happens once, in the flush: k_blend_bwd2)
+                const float t_my = dLdpow * dy;
+                float v[10];
+                v[0] = dLdpow * dx;
+                v[1] = t_my;
+                v[2] = v[0] * dx;
+                v[3] = t_my * dx;
+                v[4] = t_my * dy;
+                v[5] = G * dLda;
+                v[6] = w * gC0;
+                v[7] = w * gC1;
+                v[8] = w * gC2;
+                if (HAS_DA) v[9] = w * gD;
+                Tt *= om;
+                // (measured: finishing the reduction with ds_add_f32 from the row leaders is 1.7x SLOWER -- four lanes on one
+                //  address serialise; the transposed DPP reduction below halves the VALU cost instead)
+                const float t = wave_reduce_transposed2<NV>(v, lane);
+                // nine (ten) lanes of the first row hold one total each (reduce2_slot).  The row offset is a SCALAR product (j is
+                // wave-uniform); left to itself the compiler folds it into a v_mad_u64_u32 per visit.
+                uint32_t row;
+#if defined(__HIP_DEVICE_COMPILE__)
+                asm("s_mul_i32 %0, %1, %2" : "=s"(row) : "s"(j), "n"(NV));
+#else
+                row = (uint32_t)j * NV;
+#endif
+                if (part_slot >= 0) atomicAdd(&(&s_part[0][0])[part_off + row], t);
+            }
+        }
+        __syncthreads();
+        // flush: 16 lanes per Gaussian, lane r adds component r, so one atomic instruction touches 8 records of
+        // 9-10 CONSECUTIVE floats (8 cache lines per wave instruction) instead of 64 scattered records -- device-scope
+        // float atomics are fabric transactions on this chip, and they were 27% of this kernel when issued one
+        // component at a time per lane
+        {
+            const int r = tid & 15, q = tid >> 4;   // 16 groups of 16 lanes
+            for (int jj = q; jj < cnt; jj += NTH / 16) {
+                if (r < NV) {
+                    float v = s_part[jj][r];
+                    if (r < 2) {        // moments -> d/d(pixel-space mean): this lane also needs the OTHER first-order moment
+                        const float mo = s_part[jj][r ^ 1];
+                        const float cb = s_ab[0][jj].w;                                // B'
+                        const float c2 = 2.f * (r == 0 ? s_ab[0][jj].z : s_ab[1][jj].x);   // 2 A' (gx) or 2 C' (gy)
+                        v = fmaf(cb, mo, c2 * v);
+                    } else if (r < 5) v *= (r == 3 ? -1.f : -0.5f);                       // second moments -> conic gradients
+                    __builtin_amdgcn_wave_barrier();   // every lane of the group has read both first moments before any is cleared
+                    s_part[jj][r] = 0.f;   // ready for the next batch (its writers sit behind a barrier)
+                    // deterministic debug mode: the (tile, instance) partial goes to its own slot, k_det_reduce sums a
+                    // Gaussian's slots in list order afterwards; default: one coalesced atomic per record row
+                    if (det_part) det_part[((size_t)rg.x + (size_t)b * NT + jj) * kDetStride + r] = r < 2 ? v * kLn2 : v;
+                    else if (v != 0.f) atomicAdd(ggrad + (size_t)s_gid[buf][jj] * kGG + r, r < 2 ? v * kLn2 : v);
+                }
+            }
+        }
+    }
+    } while (0);
+    // ---- pull the next index of this list ----------------------------------------------------------------------------------
+    // (at the END of the item: issued at its top -- to hide the round trip behind the item -- the returning atomic sat at the head
+    //  of the wave's in-order vmcnt queue, and at t = 0 all 3 584 workgroups pull at once, ~450 per head word: the wave of thread 0
+    //  could not consume its own pixel loads until its pull had come back, 220-230 us per launch against 180-190 without)
+    __syncthreads();   // (s_pull: everyone has read the previous value)
+    if (tid == 0) s_pull = __hip_atomic_fetch_add(&hdr->head[qx][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    qi = s_pull;
+    tried = 0;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Optimizer-in-backward (GsrFusedAdam): gradients of one block's Gaussians sit in LDS as padded rows; the block's
 // parameter / moment rows are contiguous in memory, so the update is a 16-byte stream over p, m, v with the gradient
@@ -3740,9 +4039,9 @@ int gsr_set_option(const char* name, int value)
     if (!strcmp(name, "poll_iters")) { g_poll_iters = value < 0 ? 0 : value; return GSR_OK; }
     if (!strcmp(name, "emit_hist")) { g_emit_hist = value ? 1 : 0; return GSR_OK; }
     if (!strcmp(name, "sort_algo")) { if (value < 0 || value > 2) return GSR_ERR_ARG; g_sort_algo = value; return GSR_OK; }
-    // 2 = the packed two-pixel kernel (the only one)
+    // 2 = the packed two-pixel kernel (default; 0 = default); 1 = one pixel per lane, four waves per tile (k_blend_bwd1: scenes of small splats)
     if (!strcmp(name, "blend_bwd_ppt")) {
-        if (value != 0 && value != 2) return GSR_ERR_ARG;
+        if (value < 0 || value > 2) return GSR_ERR_ARG;
         g_bwd_ppt = value; return GSR_OK;
     }
     return GSR_ERR_ARG;
@@ -4281,19 +4580,23 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
 }
 
 // workgroups of the backward blend the device holds at once (occupancy x compute units), per kernel variant
-static int blend_bwd_resident(int has_da)
+static int blend_bwd_resident(int has_da, int ppt = 2)
 {
-    static int cached[2] = {0, 0};
-    if (cached[has_da]) return cached[has_da];
+    static int cached[2][2] = {{0, 0}, {0, 0}};
+    const int v = ppt == 1 ? 1 : 0;
+    if (cached[v][has_da]) return cached[v][has_da];
     int dev = 0, cus = 256, per_cu = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-    hipError_t e = has_da ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_blend_bwd2<true>, 128, 0)
-                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_blend_bwd2<false>, 128, 0);
-    if (e != hipSuccess || per_cu < 1) per_cu = 12;
+    hipError_t e;
+    if (v) e = has_da ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_blend_bwd1<true>, 256, 0)
+                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_blend_bwd1<false>, 256, 0);
+    else e = has_da ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_blend_bwd2<true>, 128, 0)
+                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_blend_bwd2<false>, 128, 0);
+    if (e != hipSuccess || per_cu < 1) per_cu = v ? 6 : 12;
     const char* env = getenv("GSR_BWD_WG_PER_CU");   // (experiments)
     if (env && atoi(env) > 0) per_cu = atoi(env);
-    return cached[has_da] = per_cu * cus;
+    return cached[v][has_da] = per_cu * cus;
 }
 
 int gsr_backward(const GsrBackwardArgs* a, void* stream_)
@@ -4340,7 +4643,7 @@ int gsr_backward(const GsrBackwardArgs* a, void* stream_)
     uint32_t* prep_head = (a->next_view && a->prepared_out) ? reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(a->prepared_out) + prep_layout(N).sort) : nullptr;
     bool prep_head_cleared = false;
     const int bwd_ppt = g_bwd_ppt ? g_bwd_ppt : 2;
-    const bool blend_items = a->num_rendered > 0 && bwd_ppt == 2;
+    const bool blend_items = a->num_rendered > 0 && (bwd_ppt == 2 || bwd_ppt == 1);
     // ONE launch clears the per-Gaussian accumulators and (workgroup 0) builds the backward blend's work items from the forward's
     // staged depths -- where the 48 N-byte memset stood
     BwdItemHdr* item_hdr = nullptr;
@@ -4360,7 +4663,7 @@ int gsr_backward(const GsrBackwardArgs* a, void* stream_)
             items = reinterpret_cast<const uint2*>(binw + B.items + kItemHdrBytes);
             // persistent grid: what the chip holds at once (never more workgroups than there can be items), a multiple of 8
             const int64_t bound = (a->num_rendered >> 7) + T;
-            const int resident = blend_bwd_resident((a->grad_depth || a->grad_alpha) ? 1 : 0);
+            const int resident = blend_bwd_resident((a->grad_depth || a->grad_alpha) ? 1 : 0, bwd_ppt);
             bwd_grid = (int)std::max<int64_t>(8, (std::min<int64_t>(resident, bound) + 7) / 8 * 8);
         }
         const uint32_t list_cap = (uint32_t)bwd_list_cap(a->binning_capacity > 0 ? a->binning_capacity : a->num_rendered, (size_t)T);
@@ -4371,10 +4674,10 @@ int gsr_backward(const GsrBackwardArgs* a, void* stream_)
     }
     if (a->num_rendered > 0) {
         const int ppt = bwd_ppt;
-        if (NB > 1 && ppt != 2) return fail(GSR_ERR_ARG, "batch: served by the default backward blend kernel only%s");
+        if (NB > 1 && ppt != 2 && ppt != 1) return fail(GSR_ERR_ARG, "batch: served by the persistent backward blend kernels only%s");
         const float* img = static_cast<const float*>(a->image);
         ProfScope ps(P_BLEND_BWD, st);
-        if (ppt == 2) {
+        if (ppt == 2 || ppt == 1) {
             // (checkpoints are written by k_blend_fwd_w only)
             const float* ckpt = reinterpret_cast<const float*>(bin + B.ckpt);
             // deterministic debug mode: R-sized slots + a sort of the instance positions by Gaussian id (stream-ordered
@@ -4396,7 +4699,10 @@ int gsr_backward(const GsrBackwardArgs* a, void* stream_)
             }
             BlendBwdArgs ba = {W, H, tiles_x, tiles_y, T, f_map, f_ckpt, 0, ranges, list, splat, a->bg, img, a->grad_color, a->grad_depth,
                                a->grad_alpha, gg, ckpt, det_part, item_hdr, items};
-            if (a->grad_depth || a->grad_alpha) hipLaunchKernelGGL(k_blend_bwd2<true>, dim3(bwd_grid), dim3(128), 0, st, ba);
+            if (ppt == 1) {
+                if (a->grad_depth || a->grad_alpha) hipLaunchKernelGGL(k_blend_bwd1<true>, dim3(bwd_grid), dim3(256), 0, st, ba);
+                else hipLaunchKernelGGL(k_blend_bwd1<false>, dim3(bwd_grid), dim3(256), 0, st, ba);
+            } else if (a->grad_depth || a->grad_alpha) hipLaunchKernelGGL(k_blend_bwd2<true>, dim3(bwd_grid), dim3(128), 0, st, ba);
             else hipLaunchKernelGGL(k_blend_bwd2<false>, dim3(bwd_grid), dim3(128), 0, st, ba);
             if (g_deterministic) {
                 uint32_t* k0 = reinterpret_cast<uint32_t*>(det_mem + o_k0); uint32_t* k1 = reinterpret_cast<uint32_t*>(det_mem + o_k1);

@@ -271,7 +271,9 @@ int gsr_version(void);
  *                          instances the sub-tile cannot see skipped by reach bits (default); 6 = without the reach bits.
  *                          1-5 = the A/B kernels of csrc/variants.hip (tile-per-workgroup kernels, the packed two-pixel kernel,
  *                          the lane-mask predecessor of the default): accepted only by a library built with -DGSR_AB_VARIANTS
- *   "blend_bwd_ppt"        backward blend kernel: 2 = packed two-pixel kernel (default); 1, 3, 4 = scalar A/B kernels (variants.hip)
+ *   "blend_bwd_ppt"        backward blend kernel: 2 (default; 0 = default) = two pixels per lane, packed math, two waves per tile; 1 = one pixel per lane,
+ *                          four waves per tile, four reach bits per staged instance (k_blend_bwd1: same results within rounding; -7 % of the kernel
+ *                          on random scenes of up to ~130 k Gaussians, +2 % on pixel-sized splats, equal from 300 k on)
  *   "ab_variants"          query: returns 1 when the library carries the A/B kernels, 0 otherwise (the value is ignored)
  *   "sort_algo"            2 = onesweep for both sorts (default); 1 = onesweep depth sort only; 0 = hist + scan + scatter
  *   "bwd_split"            1 = the backward of a tile is ONE work item (off); anything else (default 0) = one item per 128-instance

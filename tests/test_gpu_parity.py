@@ -135,7 +135,24 @@ def test_blend_variants_agree(ppt):
         _run_case(20000, 330, 250, 3, True, "sh", (0.2, 0.3, 0.1))
     finally:
         lib.gsr_set_option(b"blend_fwd_ppt", 0)
-    assert lib.gsr_set_option(b"blend_fwd_ppt", 3) != 0 and lib.gsr_set_option(b"blend_bwd_ppt", 1) != 0 and lib.gsr_set_option(b"ab_variants", 0) == 0
+    assert lib.gsr_set_option(b"blend_fwd_ppt", 3) != 0 and lib.gsr_set_option(b"blend_bwd_ppt", 3) != 0 and lib.gsr_set_option(b"ab_variants", 0) == 0
+
+
+@pytest.mark.parametrize("case", [CASES[0], CASES[2], CASES[4], CASES[5], (30000, 330, 250, 1, True, "sh", (0.1, 0.0, 0.2))],
+                         ids=lambda c: f"{c[0]}-{c[1]}x{c[2]}-d{c[3]}-{c[5]}")
+@pytest.mark.parametrize("color_only", [False, True], ids=["depth-alpha-grads", "colour-only"])
+def test_backward_blend_one_pixel_per_lane_against_the_oracle(case, color_only):
+    """`blend_bwd_ppt` 1 (k_blend_bwd1: one pixel per lane, four waves per tile, four reach bits per staged instance -- the backward blend
+    for scenes of small splats) against the float64 oracle, gradients of every input, with and without the depth / alpha terms, ragged tile
+    grids, deep lists (checkpoint resume) included."""
+    import importlib
+    L = importlib.import_module("3dgs_hierarchical_training_amd._lib")
+    lib = L.load()
+    try:
+        assert lib.gsr_set_option(b"blend_bwd_ppt", 1) == 0
+        _run_case(*case, color_only=color_only)
+    finally:
+        lib.gsr_set_option(b"blend_bwd_ppt", 0)
 
 
 @pytest.mark.parametrize("hint", [0, 1000, 1 << 26], ids=["exact-flow", "overflow-rerun", "roomy"])
