@@ -153,6 +153,13 @@ def load():
         getattr(lib, fn).restype = C.c_int
         getattr(lib, fn).argtypes = [C.c_void_p] * 4 + [C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_size_t,
                                                         C.POINTER(C.c_int), C.c_void_p]
+    # GSR_OPTS="name=value,name=value": library options applied once, at load -- how A/B tools and test runs put a non-default route under
+    # every caller of the process (tools/ab_*.sh; `GSR_OPTS=tile_sort=2 pytest tests -m gpu`).  An option the library refuses is an error.
+    for kv in os.environ.get("GSR_OPTS", "").split(","):
+        if "=" in kv:
+            k, v = kv.split("=", 1)
+            if lib.gsr_set_option(k.strip().encode(), int(v)) != 0:
+                raise RuntimeError(f"GSR_OPTS: gsr_set_option({k.strip()!r}, {v}) refused")
     _lib = lib
     return lib
 

@@ -4642,7 +4642,9 @@ int gsr_backward(const GsrBackwardArgs* a, void* stream_)
     // the prologue's workgroup 0 (no launch of their own) and filled by the per-Gaussian kernel behind the blend
     uint32_t* prep_head = (a->next_view && a->prepared_out) ? reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(a->prepared_out) + prep_layout(N).sort) : nullptr;
     bool prep_head_cleared = false;
-    const int bwd_ppt = g_bwd_ppt ? g_bwd_ppt : 2;
+    // (the fixed-order debug mode runs the two-pixel kernel whatever the option says: its two waves add their partials into the tile's LDS
+    //  row commutatively, the four waves of k_blend_bwd1 do not -- a + b + c + d depends on the order the LDS atomics land in)
+    const int bwd_ppt = g_deterministic ? 2 : (g_bwd_ppt ? g_bwd_ppt : 2);
     const bool blend_items = a->num_rendered > 0 && (bwd_ppt == 2 || bwd_ppt == 1);
     // ONE launch clears the per-Gaussian accumulators and (workgroup 0) builds the backward blend's work items from the forward's
     // staged depths -- where the 48 N-byte memset stood

@@ -320,6 +320,7 @@ int gsr_version(void);
  *   "deterministic_backward" 1 = debug mode: the blend backward writes every (tile, Gaussian) partial gradient to its own slot and
  *                          a second kernel sums each Gaussian's slots in list order -- no float atomics, bit-identical gradients
  *                          from run to run (the default accumulates with atomics in arrival order); several times slower
+ *                          (always through the two-pixel kernel: the four waves of "blend_bwd_ppt" 1 add into a tile's LDS row in arrival order)
  *   "profile"              1 = HIP events around every stage on the caller's stream (an event pair costs ~10 us of stream
  *                          bubble per stage), 2 = only the forward blend kernel is timed, through the start / stop timestamps of
  *                          its own dispatch (hipExtLaunchKernelGGL: still ~11 us of idle queue around the launch), 3 = as 2 on

@@ -803,6 +803,7 @@ def test_three_pass_depth_sort_and_its_window_overflow():
     scales_far[idx] = scales_far[idx] * f
     try:
         assert lib.gsr_set_option(b"reset_speculation", 1) == 0
+        assert lib.gsr_set_option(b"tile_sort", 0) == 0      # the global depth sort is the subject: the per-tile sort route has none
         res = {}
         for mode in (0, 1):
             assert lib.gsr_set_option(b"depth_sort9", mode) == 0
@@ -824,6 +825,7 @@ def test_three_pass_depth_sort_and_its_window_overflow():
                 assert torch.equal(a, b), key
     finally:
         lib.gsr_set_option(b"depth_sort9", 1)
+        lib.gsr_set_option(b"tile_sort", 1)
         lib.gsr_set_option(b"reset_speculation", 1)
 
 
