@@ -4,6 +4,7 @@ import ctypes as C
 import importlib
 import os
 import re
+import sys
 
 import pytest
 import torch
@@ -120,4 +121,18 @@ def test_tile_sort_option_values():
         assert lib.gsr_set_option(b"tile_sort_max_avg", -5) != 0
     finally:
         lib.gsr_set_option(b"tile_sort", 1)
-        lib.gsr_set_option(b"tile_sort_max_avg", 800)
+        lib.gsr_set_option(b"tile_sort_max_avg", 700)
+
+
+def test_options_from_the_environment_at_load():
+    """`GSR_OPTS=name=value,...` is applied by _lib.load() (a whole test run or bench under a non-default route of the library); a name or
+    value the library refuses is an error at load, not a silently ignored word.  Own processes: the options are process state."""
+    import subprocess
+    code = ("import importlib, sys; sys.path.insert(0, '.'); L = importlib.import_module('3dgs_hierarchical_training_amd._lib'); "
+            "lib = L.load(); print('loaded', lib.gsr_set_option(b'tile_sort', 1))")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ok = subprocess.run([sys.executable, "-c", code], cwd=root, env={**os.environ, "GSR_OPTS": "tile_sort=2, blend_bwd_ppt=1"}, capture_output=True, text=True)
+    assert ok.returncode == 0 and "loaded 0" in ok.stdout, ok.stderr[-400:]
+    for bad in ("no_such_option=1", "tile_sort=7"):
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, env={**os.environ, "GSR_OPTS": bad}, capture_output=True, text=True)
+        assert r.returncode != 0 and "GSR_OPTS" in r.stderr, (bad, r.stdout, r.stderr[-400:])
