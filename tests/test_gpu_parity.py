@@ -50,6 +50,82 @@ def test_parity_vs_oracle(case):
     _run_case(*case)
 
 
+def _pixel_gaussian_scene(W, H, stride, surface, seed=0):
+    """A stage-A single-image model as the reference initialises it (one Gaussian per strided pixel, un-projected with the frame's
+    depth into the frame's own camera, identity rotation, footprint-sized, band 0 of 16 stored SH coefficients:
+    /root/reference/trainer/ht3dgs_trainer.py:352-363, :172-212; 3dgs_hierarchical_training_amd/sequence.py pixel_scene) -- built on the
+    host from an analytic depth map.  surface = "plane": every Gaussian at EXACTLY the same depth (the whole depth order is the tie
+    rule: index order); "waves": a smooth surface (runs of nearly equal depths along its level lines)."""
+    import math
+    syn = parity.syn
+    cam = syn.make_camera(W, H)
+    g = torch.Generator().manual_seed(seed)
+    ys, xs = torch.meshgrid(torch.arange(stride // 2, H, stride), torch.arange(stride // 2, W, stride), indexing="ij")
+    ys, xs = ys.reshape(-1), xs.reshape(-1)
+    u, v = xs.float() / W, ys.float() / H
+    if surface == "plane":
+        z = torch.full(u.shape, 4.0)
+    else:
+        z = 3.0 + 0.8 * torch.sin(6.0 * u) * torch.cos(5.0 * v) + 0.5 * u
+    n = z.shape[0]
+    # (centres a fraction of a pixel off the pixel centres, as after the first iterations of the fit: ON the centres every 3-sigma rect
+    #  and every alpha threshold of the grid sits on a binary32 rounding edge at once -- a third of the pixels, measured)
+    x = (xs.float() + 0.5 - 0.5 * W + 0.6 * (torch.rand(n, generator=g) - 0.5)) / cam["fx"] * z
+    y = (ys.float() + 0.5 - 0.5 * H + 0.6 * (torch.rand(n, generator=g) - 0.5)) / cam["fy"] * z
+    sc = {k: cam[k] for k in ("image_width", "image_height", "tanfovx", "tanfovy", "viewmatrix", "projmatrix", "campos")}
+    sc["sh_degree"] = 0
+    sc["means3D"] = torch.stack((x, y, z), 1).float().contiguous()
+    # footprint-sized, a little anisotropic and a little turned: a model some iterations into its fit
+    sc["scales"] = ((0.7 * stride * z / cam["fx"])[:, None] * (0.8 + 0.4 * torch.rand(n, 3, generator=g))).float().contiguous()
+    rot = torch.zeros(n, 4); rot[:, 0] = 1.0
+    rot[:, 1:] = 0.05 * torch.randn(n, 3, generator=g)
+    sc["rotations"] = (rot / rot.norm(dim=1, keepdim=True)).contiguous()
+    sc["opacities"] = (0.5 + 0.4 * torch.rand(n, 1, generator=g)).contiguous()
+    shs = torch.zeros(n, 16, 3)
+    col = torch.stack((0.5 + 0.4 * torch.sin(9.0 * u), 0.5 + 0.4 * torch.cos(7.0 * v), 0.5 + 0.3 * torch.sin(5.0 * (u + v))), 1)
+    shs[:, 0] = (col - 0.5) / 0.28209479177387814
+    sc["shs"] = shs.contiguous()
+    return sc
+
+
+@pytest.mark.parametrize("W,H,stride,surface", [(490, 272, 2, "plane"), (490, 272, 2, "waves"), (333, 250, 1, "waves"), (980, 545, 4, "plane")],
+                         ids=["plane-stride2", "waves-stride2", "waves-every-pixel-ragged", "plane-stride4-full-frame"])
+def test_parity_on_a_single_image_model_of_pixel_gaussians(W, H, stride, surface):
+    """Stage A's model -- 70 % of a scene's render calls go to models of this kind -- against the float64 oracle, forward and backward
+    (colour loss only, as the reference's; and with the depth / alpha terms), on the binning route these models take by default (index-order
+    placement + per-tile depth sort) AND on the global depth sort: both within the north_star's tolerances of the oracle, and the
+    two routes' images and lists equal bit for bit.  Grids of equal or nearly equal depths make the tie rule (depth bits, then index)
+    carry the whole order."""
+    import hip_runner
+    R_ = importlib.import_module("3dgs_hierarchical_training_amd.rasterizer")
+    lib = importlib.import_module("3dgs_hierarchical_training_amd._lib").load()
+    sc = _pixel_gaussian_scene(W, H, stride, surface)
+    kw = parity.scene_kwargs(sc, "sh", bg=(0.05, 0.1, 0.15))
+    imgs = {}
+    try:
+        for tsort in (1, 0):
+            assert lib.gsr_set_option(b"tile_sort", tsort) == 0
+            for color_only in (True, False):
+                o = binding.OracleRender(**kw)
+                gc, gd, ga = parity.upstream_grads(H, W, seed=5)
+                if color_only:
+                    gd = ga = None
+                what = f"pixel-Gaussians {W}x{H}/{stride}/{surface}/tile_sort={tsort}/{'colour' if color_only else 'all'}"
+                rep, out, ref = parity.oracle_case(o, lambda g: hip_runner.run_hip(kw, g), (gc, gd, ga), what)
+                grep = parity.check_grads(out["grads"], ref, what)
+                rep.pop("grad_mask")
+                print(what, rep, {k: "%.1e" % v for k, v in grep.items()})
+                o.close()
+            fwd = hip_runner.run_hip(kw)["fwd"]
+            ranges, lst = R_.last_binning()
+            imgs[tsort] = (fwd, ranges.cpu().numpy().copy(), lst.cpu().numpy()[:R_._LAST["num_rendered"]].copy())
+    finally:
+        lib.gsr_set_option(b"tile_sort", 1)
+    assert np.array_equal(imgs[0][1], imgs[1][1]) and np.array_equal(imgs[0][2], imgs[1][2]), "the two routes' tile lists differ"
+    for a, b in zip(imgs[0][0], imgs[1][0]):
+        assert np.array_equal(a, b)
+
+
 def test_more_than_65536_tiles():
     """4112 x 4112 pixels = 257 x 257 = 66 049 tiles: tile ids no longer fit 16 bits, so the instance stream carries 32-bit
     keys (three 6-bit passes of the wide onesweep).  The public module this replaces has no image-size limit.
