@@ -45,6 +45,28 @@ constexpr int kStrIn1 = 68;       // rows of 42 scalars
 constexpr int kStrH2 = 68;        // rows of 32 row-filtered pairs = 64 words
 constexpr int kStrH1 = 36;        // rows of 32 row-filtered scalars
 
+// Which tile a workgroup takes.  The hardware deals workgroups to the eight XCDs round-robin in launch order, so with tile = launch
+// index every XCD's L2 sees every eighth tile of the frame and fetches each tile's 5-pixel halo for itself (counted: 2.1 x the
+// image through the fabric).  Here XCD x takes the x-th contiguous eighth of the (channel, row, column) order instead: a tile's
+// neighbours left and right and in the rows above and below run on the same L2.  GSR_LOSS_XCD_MAP=0: tile = launch index.
+#ifndef GSR_LOSS_XCD_MAP
+#define GSR_LOSS_XCD_MAP 1
+#endif
+struct LossTile { int bx, by, c; };
+__device__ __forceinline__ LossTile loss_tile()
+{
+#if GSR_LOSS_XCD_MAP
+    const uint32_t gx = gridDim.x, gy = gridDim.y, n = gx * gy * gridDim.z;
+    const uint32_t lin = (blockIdx.z * gy + blockIdx.y) * gx + blockIdx.x;
+    const uint32_t q = n >> 3, r = n & 7u, x = lin & 7u, k = lin >> 3;
+    const uint32_t t = (x < r ? x * (q + 1u) : r * (q + 1u) + (x - r) * q) + k;
+    const uint32_t row = t / gx;
+    return LossTile{(int)(t - row * gx), (int)(row % gy), (int)(row / gy)};
+#else
+    return LossTile{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z};
+#endif
+}
+
 // Both kernels are bound by VALU issue (a few hundred instructions per pixel, next to 40 bytes of traffic), so what is
 // minimised is instructions per output: 32x32 tiles (1.7 staged inputs per output instead of 2.6 at 16x16) and a sliding
 // window -- a thread produces FOUR adjacent outputs of a filter pass from 14 inputs it loads once (3.5 LDS reads per
@@ -63,11 +85,12 @@ __global__ __launch_bounds__(256) void k_loss_fwd(const float* __restrict__ raw,
     __shared__ __attribute__((aligned(16))) float s_hC[kIH * kStrH1];    // row-filtered x y
     __shared__ float s_red[2][4];
     const int tid = threadIdx.x;
-    const int c = blockIdx.z;
+    const LossTile lt = loss_tile();
+    const int c = lt.c;
     const size_t P = (size_t)H * W;
     const float* x = raw + (size_t)c * P;
     const float* y = gt + (size_t)c * P;
-    const int ox = blockIdx.x * kTW - kHalo, oy = blockIdx.y * kTH - kHalo;
+    const int ox = lt.bx * kTW - kHalo, oy = lt.by * kTH - kHalo;
     {   // all loads of the thread are issued before the first LDS store (their latency is paid once, not per round)
         float xv[kLoadRounds], yv[kLoadRounds];
 #pragma unroll
@@ -140,12 +163,12 @@ __global__ __launch_bounds__(256) void k_loss_fwd(const float* __restrict__ raw,
                 mA[i] = lfma2(w, a[i + k], mA[i]); mB[i] = lfma2(w, b[i + k], mB[i]); mC[i] = fmaf(w, d[i + k], mC[i]);
             }
     }
-    const int gx = blockIdx.x * kTW + cc;
+    const int gx = lt.bx * kTW + cc;
     const size_t CP = (size_t)gridDim.z * P;
     float ssim = 0.f, l1 = 0.f;
 #pragma unroll
     for (int i = 0; i < kRP; i++) {
-        const int gy = blockIdx.y * kTH + r0 + i;
+        const int gy = lt.by * kTH + r0 + i;
         if (gx < W && gy < H) {
             const float mu1 = mA[i].x, mu2 = mA[i].y, e11 = mB[i].x, e22 = mB[i].y, e12 = mC[i];
             const float s11 = e11 - mu1 * mu1, s22 = e22 - mu2 * mu2, s12 = e12 - mu1 * mu2;
@@ -170,7 +193,7 @@ __global__ __launch_bounds__(256) void k_loss_fwd(const float* __restrict__ raw,
     if ((tid & 63) == 0) { s_red[0][tid >> 6] = ssim; s_red[1][tid >> 6] = l1; }
     __syncthreads();
     if (tid == 0) {
-        const size_t b = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        const size_t b = ((size_t)lt.c * gridDim.y + lt.by) * gridDim.x + lt.bx;   // the TILE's slot: the finishing sum does not see the map
         partial[2 * b] = s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3];
         partial[2 * b + 1] = s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3];
     }
@@ -213,9 +236,10 @@ __global__ __launch_bounds__(256) void k_loss_bwd(const float* __restrict__ raw,
     __shared__ __attribute__((aligned(16))) float s_hA[kIH * kStrH2];
     __shared__ __attribute__((aligned(16))) float s_hC[kIH * kStrH1];
     const int tid = threadIdx.x;
-    const int c = blockIdx.z;
+    const LossTile lt = loss_tile();
+    const int c = lt.c;
     const size_t P = (size_t)H * W, CP = (size_t)gridDim.z * P;
-    const int ox = blockIdx.x * kTW - kHalo, oy = blockIdx.y * kTH - kHalo;
+    const int ox = lt.bx * kTW - kHalo, oy = lt.by * kTH - kHalo;
     {
         float a[kLoadRounds], bb[kLoadRounds], d[kLoadRounds];
 #pragma unroll
@@ -269,7 +293,7 @@ __global__ __launch_bounds__(256) void k_loss_bwd(const float* __restrict__ raw,
     }
     __syncthreads();
     const int cc = tid & (kTW - 1), r0 = (tid / kTW) * kRP;
-    const int gx = blockIdx.x * kTW + cc;
+    const int gx = lt.bx * kTW + cc;
     if (gx >= W) return;
     lf2 cA[kRP];
     float c2[kRP];
@@ -293,7 +317,7 @@ __global__ __launch_bounds__(256) void k_loss_bwd(const float* __restrict__ raw,
     }
 #pragma unroll
     for (int i = 0; i < kRP; i++) {
-        const int gy = blockIdx.y * kTH + r0 + i;
+        const int gy = lt.by * kTH + r0 + i;
         if (gy >= H) break;
         const size_t pid = (size_t)c * P + (size_t)gy * W + gx;
         const float r = raw[pid], yv = gt[pid];
