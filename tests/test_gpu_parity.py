@@ -811,6 +811,65 @@ def test_direct_binning_frame_sizes(W, H, N):
     print(f"{W}x{H}: R {na}, longest tile list {np.diff(ra, axis=1).max()}")
 
 
+@pytest.mark.parametrize("L", [1, 63, 64, 65, 128, 129, 256, 257, 512, 513, 1023, 1024, 1025, 2048, 2049, 4095, 4096, 4097, 8191, 8193, 12289])
+def test_tile_sort_segment_lengths_at_the_kernels_boundaries(L):
+    """The per-tile depth sort picks its form by a segment's length: one wave with 1 / 2 / 4 / 8 / 16 pairs per lane up to 1 024 pairs,
+    the persistent 1 024-thread workgroup in LDS up to 4 096, a pass through global memory in chunks of 4 096 beyond.  One tile
+    (16 x 16 frame) holding EXACTLY L Gaussians, and a second frame of two tiles holding L and L + 1: every boundary of that choice from
+    both sides, with a third of the depths drawn from sixteen values (ties: index order).  Lists, ranges and images of the four routes
+    equal bit for bit."""
+    import hip_runner
+    R_ = importlib.import_module("3dgs_hierarchical_training_amd.rasterizer")
+    lib = importlib.import_module("3dgs_hierarchical_training_amd._lib").load()
+    syn = parity.syn
+
+    def scene(W, per_tile):
+        H = 16
+        cam = syn.make_camera(W, H)
+        g = torch.Generator().manual_seed(L * 7 + W)
+        xs, zs = [], []
+        for t, n in enumerate(per_tile):
+            z = 1.0 + 9.0 * torch.rand(n, generator=g)
+            tie = torch.rand(n, generator=g) < 0.33
+            z[tie] = 2.0 + 0.5 * torch.randint(0, 16, (int(tie.sum()),), generator=g).float()
+            px = 16.0 * t + 8.0 + 3.0 * (torch.rand(n, generator=g) - 0.5)        # well inside tile t: sigma ~0.5 px reaches no neighbour
+            py = 8.0 + 3.0 * (torch.rand(n, generator=g) - 0.5)
+            xs.append(torch.stack(((px - 0.5 * W) / cam["fx"] * z, (py - 0.5 * H) / cam["fy"] * z, z), 1))
+            zs.append(z)
+        xyz, z = torch.cat(xs), torch.cat(zs)
+        n = xyz.shape[0]
+        sc = {k: cam[k] for k in ("image_width", "image_height", "tanfovx", "tanfovy", "viewmatrix", "projmatrix", "campos")}
+        sc["sh_degree"] = 0
+        sc["means3D"] = xyz.float().contiguous()
+        sc["scales"] = (0.5 * z / cam["fx"])[:, None].repeat(1, 3).float().contiguous()
+        rot = torch.zeros(n, 4); rot[:, 0] = 1.0
+        sc["rotations"] = rot
+        sc["opacities"] = torch.full((n, 1), 0.02)                                  # faint: the tile never saturates, every entry is consumed
+        sc["shs"] = (0.5 * torch.randn(n, 1, 3, generator=g)).contiguous()
+        return sc
+
+    for W, per_tile in ((16, [L]), (32, [L, L + 1])):
+        kw = parity.scene_kwargs(scene(W, per_tile), "sh", bg=(0.2, 0.1, 0.0))
+        res = {}
+        try:
+            for route, (direct, tsort) in enumerate(((0, 0), (1, 0), (1, 2), (0, 2))):
+                assert lib.gsr_set_option(b"direct_binning", direct) == 0
+                assert lib.gsr_set_option(b"tile_sort", tsort) == 0
+                fwd = hip_runner.run_hip(kw)["fwd"]
+                ranges, lst = R_.last_binning()
+                res[route] = (fwd, ranges.cpu().numpy().copy(), lst.cpu().numpy()[:R_._LAST["num_rendered"]].copy())
+        finally:
+            lib.gsr_set_option(b"direct_binning", 1)
+            lib.gsr_set_option(b"tile_sort", 1)
+        fa, ra, la = res[0]
+        assert [int(b - a) for a, b in ra] == per_tile, (W, ra)                     # the lists have exactly the lengths under test
+        for route in (1, 2, 3):
+            fb, rb, lb = res[route]
+            assert np.array_equal(ra, rb) and np.array_equal(la, lb), f"{W}: route {route}"
+            for x, y in zip(fa, fb):
+                assert np.array_equal(x, y), f"{W}: route {route}"
+
+
 @pytest.mark.parametrize("W,H,N,slab,kind", [(1920, 1080, 200000, 2176, "syn"), (1920, 1080, 200000, 4096, "syn"), (1920, 1080, 6000, 2176, "rects"),
                                              (1040, 1100, 50000, 1000, "syn"), (4112, 300, 30000, 3000, "syn")],
                          ids=["1080p-4-slabs", "1080p-2-slabs", "1080p-large-and-huge-rects", "tall-5-slabs", "wide-one-row-slabs"])
