@@ -811,6 +811,45 @@ def test_direct_binning_frame_sizes(W, H, N):
     print(f"{W}x{H}: R {na}, longest tile list {np.diff(ra, axis=1).max()}")
 
 
+@pytest.mark.parametrize("N", [1, 2, 63, 64, 65, 4095, 4096, 4097, 8191, 8192, 8193, 32767, 32768, 32769, 36864, 65537])
+def test_depth_order_at_the_sorts_tile_boundaries(N):
+    """The global depth sort works in tiles of 4 096 keys, its first pass in eight runs of tiles with their own look-back chains: Gaussian
+    counts on both sides of one tile, two tiles, eight tiles (one per run) and nine.  Independent of any other route of the library:
+    every tile's list must ascend in (the oracle's binary32 depth, then Gaussian index) -- sortedness with the reference's tie rule --
+    and hold each Gaussian once; then the per-tile-sort route must give the same lists."""
+    import hip_runner
+    R_ = importlib.import_module("3dgs_hierarchical_training_amd.rasterizer")
+    lib = importlib.import_module("3dgs_hierarchical_training_amd._lib").load()
+    W, H = 64, 48
+    sc = parity.syn.make_scene(N, W, H, sh_degree=0, seed=N, frac_behind=0.0)
+    if N >= 64:      # a fifth of the depths from thirty-two values: ties inside and across the sort's tiles
+        g = torch.Generator().manual_seed(N)
+        tie = torch.rand(N, generator=g) < 0.2
+        znew = 2.0 + 0.25 * torch.randint(0, 32, (int(tie.sum()),), generator=g).float()
+        sc["means3D"][tie] = sc["means3D"][tie] * (znew / sc["means3D"][tie][:, 2])[:, None]      # along the viewing ray: same pixel, new depth
+    kw = parity.scene_kwargs(sc, "sh")
+    o = binding.OracleRender(**kw)
+    o.forward()
+    depth = o.geom()["depth"]
+    o.close()
+    res = {}
+    try:
+        for tsort in (0, 2):
+            assert lib.gsr_set_option(b"tile_sort", tsort) == 0
+            hip_runner.run_hip(kw)
+            ranges, lst = R_.last_binning()
+            res[tsort] = (ranges.cpu().numpy().copy(), lst.cpu().numpy()[:R_._LAST["num_rendered"]].copy())
+    finally:
+        lib.gsr_set_option(b"tile_sort", 1)
+    ranges, lst = res[0]
+    assert lst.shape[0] > 0 or N < 3
+    for a, b in ranges:
+        ids = lst[a:b].astype(np.int64)
+        d = depth[ids]
+        assert np.all((d[1:] > d[:-1]) | ((d[1:] == d[:-1]) & (ids[1:] > ids[:-1]))), "a tile's list does not ascend in (depth, index)"
+    assert np.array_equal(res[0][0], res[2][0]) and np.array_equal(res[0][1], res[2][1]), "the per-tile sort route's lists differ"
+
+
 @pytest.mark.parametrize("L", [1, 63, 64, 65, 128, 129, 256, 257, 512, 513, 1023, 1024, 1025, 2048, 2049, 4095, 4096, 4097, 8191, 8193, 12289])
 def test_tile_sort_segment_lengths_at_the_kernels_boundaries(L):
     """The per-tile depth sort picks its form by a segment's length: one wave with 1 / 2 / 4 / 8 / 16 pairs per lane up to 1 024 pairs,
