@@ -850,6 +850,67 @@ def test_depth_order_at_the_sorts_tile_boundaries(N):
     assert np.array_equal(res[0][0], res[2][0]) and np.array_equal(res[0][1], res[2][1]), "the per-tile sort route's lists differ"
 
 
+def _stacked_tiles_scene(per_tile, seed, sigma_px=0.5, opacity=0.02, tie_frac=0.33):
+    """A 16-pixel-high frame of len(per_tile) tiles, tile t holding exactly per_tile[t] Gaussians stacked in depth around its centre (none
+    reaches a neighbouring tile), `tie_frac` of the depths drawn from sixteen values.  Faint opacities: no pixel saturates, every list
+    entry is consumed."""
+    syn = parity.syn
+    W, H = 16 * len(per_tile), 16
+    cam = syn.make_camera(W, H)
+    g = torch.Generator().manual_seed(seed)
+    xs, zs = [], []
+    for t, n in enumerate(per_tile):
+        z = 1.0 + 9.0 * torch.rand(n, generator=g)
+        tie = torch.rand(n, generator=g) < tie_frac
+        z[tie] = 2.0 + 0.5 * torch.randint(0, 16, (int(tie.sum()),), generator=g).float()
+        px = 16.0 * t + 8.0 + 3.0 * (torch.rand(n, generator=g) - 0.5)
+        py = 8.0 + 3.0 * (torch.rand(n, generator=g) - 0.5)
+        xs.append(torch.stack(((px - 0.5 * W) / cam["fx"] * z, (py - 0.5 * H) / cam["fy"] * z, z), 1))
+        zs.append(z)
+    xyz, z = torch.cat(xs), torch.cat(zs)
+    n = xyz.shape[0]
+    sc = {k: cam[k] for k in ("image_width", "image_height", "tanfovx", "tanfovy", "viewmatrix", "projmatrix", "campos")}
+    sc["sh_degree"] = 0
+    sc["means3D"] = xyz.float().contiguous()
+    sc["scales"] = ((sigma_px * z / cam["fx"])[:, None] * (0.8 + 0.4 * torch.rand(n, 3, generator=g))).float().contiguous()
+    rot = torch.zeros(n, 4); rot[:, 0] = 1.0
+    rot[:, 1:] = 0.1 * torch.randn(n, 3, generator=g)
+    sc["rotations"] = (rot / rot.norm(dim=1, keepdim=True)).contiguous()
+    sc["opacities"] = torch.full((n, 1), float(opacity)) * (0.7 + 0.6 * torch.rand(n, 1, generator=g))
+    sc["shs"] = (0.5 * torch.randn(n, 1, 3, generator=g)).contiguous()
+    return sc
+
+
+@pytest.mark.parametrize("L,opacity", [(L, 0.02) for L in (63, 64, 65, 127, 128, 129, 255, 256, 257, 383, 385, 511, 513, 641)] + [(129, 0.5), (513, 0.5)],
+                         ids=lambda v: str(v))
+def test_blend_batches_and_checkpoints_at_exact_list_lengths_against_the_oracle(L, opacity):
+    """The blends stage a list 64 (forward) / 128 (backward) entries at a time, the forward leaves a checkpoint every 128 and the backward
+    cuts a tile's replay into work items at them: two tiles holding EXACTLY L and L + 1 entries (asserted), splats of ~2 px covering a good
+    part of their tile, against the float64 oracle -- forward and backward, colour loss only and with the depth / alpha terms.  Faint
+    opacities (every entry consumed: the boundaries are reached) and two saturating cases (the lists end early)."""
+    import hip_runner
+    R_ = importlib.import_module("3dgs_hierarchical_training_amd.rasterizer")
+    sc = _stacked_tiles_scene([L, L + 1], seed=L, sigma_px=2.0, opacity=opacity, tie_frac=0.1)
+    kw = parity.scene_kwargs(sc, "sh", bg=(0.2, 0.1, 0.0))
+    H, W = 16, 32
+    for color_only in (True, False):
+        o = binding.OracleRender(**kw)
+        gc, gd, ga = parity.upstream_grads(H, W, seed=L)
+        if color_only:
+            gd = ga = None
+        what = f"stacked tiles {L}/{L + 1}, opacity {opacity}, {'colour' if color_only else 'all'}"
+        rep, out, ref = parity.oracle_case(o, lambda g: hip_runner.run_hip(kw, g), (gc, gd, ga), what, ambig_max_frac=0.2)
+        parity.check_grads(out["grads"], ref, what)
+        o.close()
+    ranges, _ = R_.last_binning()
+    lens = [int(b - a) for a, b in ranges.cpu().numpy()]
+    if opacity < 0.1:
+        assert lens == [L, L + 1]
+        assert R_.last_call_info()["staged"] >= 2 * L, "the lists were not consumed to their ends"
+    else:            # (at this opacity a few splats of one tile reach the other: longer lists, which end early anyway)
+        assert lens[0] >= L and lens[1] >= L + 1
+
+
 @pytest.mark.parametrize("L", [1, 63, 64, 65, 128, 129, 256, 257, 512, 513, 1023, 1024, 1025, 2048, 2049, 4095, 4096, 4097, 8191, 8193, 12289])
 def test_tile_sort_segment_lengths_at_the_kernels_boundaries(L):
     """The per-tile depth sort picks its form by a segment's length: one wave with 1 / 2 / 4 / 8 / 16 pairs per lane up to 1 024 pairs,
@@ -860,35 +921,8 @@ def test_tile_sort_segment_lengths_at_the_kernels_boundaries(L):
     import hip_runner
     R_ = importlib.import_module("3dgs_hierarchical_training_amd.rasterizer")
     lib = importlib.import_module("3dgs_hierarchical_training_amd._lib").load()
-    syn = parity.syn
-
-    def scene(W, per_tile):
-        H = 16
-        cam = syn.make_camera(W, H)
-        g = torch.Generator().manual_seed(L * 7 + W)
-        xs, zs = [], []
-        for t, n in enumerate(per_tile):
-            z = 1.0 + 9.0 * torch.rand(n, generator=g)
-            tie = torch.rand(n, generator=g) < 0.33
-            z[tie] = 2.0 + 0.5 * torch.randint(0, 16, (int(tie.sum()),), generator=g).float()
-            px = 16.0 * t + 8.0 + 3.0 * (torch.rand(n, generator=g) - 0.5)        # well inside tile t: sigma ~0.5 px reaches no neighbour
-            py = 8.0 + 3.0 * (torch.rand(n, generator=g) - 0.5)
-            xs.append(torch.stack(((px - 0.5 * W) / cam["fx"] * z, (py - 0.5 * H) / cam["fy"] * z, z), 1))
-            zs.append(z)
-        xyz, z = torch.cat(xs), torch.cat(zs)
-        n = xyz.shape[0]
-        sc = {k: cam[k] for k in ("image_width", "image_height", "tanfovx", "tanfovy", "viewmatrix", "projmatrix", "campos")}
-        sc["sh_degree"] = 0
-        sc["means3D"] = xyz.float().contiguous()
-        sc["scales"] = (0.5 * z / cam["fx"])[:, None].repeat(1, 3).float().contiguous()
-        rot = torch.zeros(n, 4); rot[:, 0] = 1.0
-        sc["rotations"] = rot
-        sc["opacities"] = torch.full((n, 1), 0.02)                                  # faint: the tile never saturates, every entry is consumed
-        sc["shs"] = (0.5 * torch.randn(n, 1, 3, generator=g)).contiguous()
-        return sc
-
     for W, per_tile in ((16, [L]), (32, [L, L + 1])):
-        kw = parity.scene_kwargs(scene(W, per_tile), "sh", bg=(0.2, 0.1, 0.0))
+        kw = parity.scene_kwargs(_stacked_tiles_scene(per_tile, seed=L * 7 + W), "sh", bg=(0.2, 0.1, 0.0))
         res = {}
         try:
             for route, (direct, tsort) in enumerate(((0, 0), (1, 0), (1, 2), (0, 2))):
