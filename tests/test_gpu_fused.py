@@ -265,6 +265,37 @@ def test_ctypes_binding_route_matches_the_extension(monkeypatch):
         assert np.abs(a["grads"][k] - b["grads"][k]).max() <= 2e-5 * np.abs(a["grads"][k]).max() + 1e-12, k
 
 
+@pytest.mark.parametrize("fail_tag", ["binning", "scratch"])
+def test_allocator_that_returns_null_is_an_error_not_a_crash(monkeypatch, fail_tag):
+    """The C ABI takes its R-sized buffers from the caller's allocator callback (include/gsr.h GsrAllocFn).  A callback that returns NULL
+    -- the caller out of memory -- makes gsr_forward return GSR_ERR_ALLOC with a message, touches nothing, and leaves the library
+    usable: the next call with a working allocator renders the image it rendered before."""
+    import hip_runner
+    R_ = importlib.import_module("3dgs_hierarchical_training_amd.rasterizer")
+    L_ = importlib.import_module("3dgs_hierarchical_training_amd._lib")
+    sc = parity.syn.make_scene(5000, 160, 120, sh_degree=1, seed=12)
+    kw = parity.scene_kwargs(sc, "sh")
+    monkeypatch.setenv("GSR_BINDING", "ctypes")
+    ref = hip_runner.run_hip(kw)["fwd"]
+    good = R_._Workspace._alloc
+    calls = {"n": 0}
+
+    def failing(self, nbytes, tag, user):
+        is_bin = tag == L_.GSR_ALLOC_BINNING
+        if (fail_tag == "binning") == is_bin:
+            calls["n"] += 1
+            return None
+        return good(self, nbytes, tag, user)
+    monkeypatch.setattr(R_._Workspace, "_alloc", failing)
+    with pytest.raises(RuntimeError) as ei:
+        hip_runner.run_hip(kw)
+    assert calls["n"] >= 1 and "code -3" in str(ei.value) and "allocation failed" in str(ei.value), str(ei.value)
+    monkeypatch.setattr(R_._Workspace, "_alloc", good)
+    again = hip_runner.run_hip(kw)["fwd"]
+    for x, y in zip(ref, again):
+        assert np.array_equal(x, y)
+
+
 def test_calc_importance_matches_oracle():
     """Merge-time pruning score (ht3dgs_trainer.py:1427-1462): |dL/dSH| with grad_out = 1 through clamp(0,1),
     summed over views, / num_pixels -- against the float64 oracle's backward."""
