@@ -112,6 +112,18 @@ def _register_fakes():
           beta1, beta2, eps, step):
         return None
 
+    @torch.library.register_fake("gsr::pose_matrix_forward")
+    def _(delta, base):
+        return delta.new_empty((3, 4), dtype=torch.float32)
+
+    @torch.library.register_fake("gsr::pose_matrix")
+    def _(delta, base):
+        return delta.new_empty((3, 4), dtype=torch.float32)
+
+    @torch.library.register_fake("gsr::pose_matrix_backward")
+    def _(delta, base, d_xf):
+        return torch.empty_like(delta)
+
     @torch.library.register_fake("gsr::masked_max_")
     def _(dst, src, mask):
         return None

@@ -76,7 +76,7 @@ EXPORTS = [
     "gsr_knn_scratch_bytes", "gsr_knn_mean_dist2", "gsr_get_counter", "gsr_debug_read_binning", "gsr_debug_direct_binning_geometry", "gsr_debug_view_cache_stats", "gsr_prepared_bytes",
     "gsr_prepare_supported", "gsr_prepared_radii_offset", "gsr_stream_copy", "gsr_image_bytes_batched",
     "gsr_masked_max", "gsr_densify_stats_add", "gsr_psnr_scratch_bytes", "gsr_psnr",
-    "gsr_loss_workspace_bytes_batched", "gsr_loss_forward_batched", "gsr_loss_backward_batched", "gsr_loss_forward_terms",
+    "gsr_loss_workspace_bytes_batched", "gsr_loss_forward_batched", "gsr_loss_backward_batched", "gsr_loss_forward_terms", "gsr_pose_grad", "gsr_struct_bytes",
 ]
 
 _lib = None
@@ -137,6 +137,16 @@ def load():
     lib.gsr_mark_visible.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.gsr_last_error.restype = C.c_char_p
     lib.gsr_version.restype = C.c_int
+    lib.gsr_struct_bytes.restype = C.c_size_t
+    lib.gsr_struct_bytes.argtypes = [C.c_int32]
+    # the ctypes mirrors above must be the structs the library was compiled with (a shorter struct makes the library
+    # write through garbage pointers)
+    for which, cls in ((0, GsrForwardArgs), (1, GsrBackwardArgs), (2, GsrForwardOut)):
+        if lib.gsr_struct_bytes(which) != C.sizeof(cls):
+            raise RuntimeError(f"libgsr_hip.so was built from another include/gsr.h: {cls.__name__} is {lib.gsr_struct_bytes(which)} bytes "
+                               f"in the library, {C.sizeof(cls)} in _lib.py")
+    lib.gsr_pose_grad.restype = C.c_int
+    lib.gsr_pose_grad.argtypes = [C.c_void_p] * 5
     lib.gsr_set_option.restype = C.c_int
     lib.gsr_set_option.argtypes = [C.c_char_p, C.c_int]
     lib.gsr_stream_copy.restype = C.c_int

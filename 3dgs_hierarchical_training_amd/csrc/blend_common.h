@@ -1,4 +1,4 @@
-// blend_common.h -- what the blend kernels of gsr_kernels.hip and the A/B variants of variants.hip share: image-state layout,
+// blend_common.h -- what the blend kernels of gsr_kernels.hip share: image-state layout,
 // checkpoint layout, tile -> XCD maps, the wave64 DPP sum and the packed-float helpers.
 #pragma once
 #include <hip/hip_runtime.h>

@@ -1847,8 +1847,8 @@ __global__ __launch_bounds__(THREADS) void k_tile_sort(const uint2* __restrict__
 // stages the tile's list itself in batches of 64 through LDS (the gathers of the other three hit L2), needs no workgroup
 // barrier, and stops as soon as ITS 64 pixels are saturated.  block b: XCD b & 7, slot b >> 3 -> (tile, sub-tile) through
 // slot_tile, so a tile's four waves share an XCD (and its L2).  Image state planes and checkpoints: blend_common.h.
-// (The tile-per-workgroup kernels, the packed two-pixel kernel and the lane-mask predecessor k_blend_fwd_w of this kernel
-//  live in variants.hip, built only with -DGSR_AB_VARIANTS.)
+// (The tile-per-workgroup kernels, the packed two-pixel kernel and the lane-mask predecessor k_blend_fwd_w of this kernel left the
+//  tree in round 5; DESIGN_HISTORY.md has their measurements.)
 // "Sign-encoded done": in k_blend_fwd_w `done` is a lane mask the compiler carries in SGPR pairs:
 // every iteration opens with xor / and_saveexec / branch on it and closes by merging the lanes that just stopped back in
 // -- about sixteen scalar instructions per (wave, instance), as many as the arithmetic (41.5 M SALU next to 46 M VALU
@@ -3961,7 +3961,11 @@ size_t gsr_prepared_bytes(int32_t N) { return prep_layout(N).bytes; }
 size_t gsr_prepared_radii_offset(int32_t N) { return prep_layout(N).radii; }
 int gsr_prepare_supported(int32_t M, int32_t D, int32_t raw_params) { return (raw_params && M == 16 && D >= 0 && D <= 3) ? 1 : 0; }
 const char* gsr_last_error(void) { return g_err; }
-int gsr_version(void) { return 100; }
+int gsr_version(void) { return 110; }
+size_t gsr_struct_bytes(int32_t which)
+{
+    return which == 0 ? sizeof(GsrForwardArgs) : which == 1 ? sizeof(GsrBackwardArgs) : which == 2 ? sizeof(GsrForwardOut) : 0;
+}
 
 #ifdef GSR_K8_PHASES
 int gsr_debug_k8_phases(unsigned long long* host_dst) { return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_k8ph), sizeof(unsigned long long) * 8 * 8192); }

@@ -217,6 +217,42 @@ extern "C" int gsr_pose_step(float* delta6, float* exp_avg6, float* exp_avg_sq6,
     return hipGetLastError() == hipSuccess ? GSR_OK : GSR_ERR_HIP;
 }
 
+// The chain alone: dL/d(delta) of M = Exp(delta) * base from dL/dM, written to d_delta6_out -- the backward of the autograd node
+// gsr_autopatch puts where the unmodified trainer's `P[k].retr()` stands (torch_ext.cpp PoseMatrixFn): the trainer's own
+// optimizer object (its Adam over the frame's six numbers) then finds `.grad` where autograd always leaves it.  The same central
+// differences in float64 as pose_grad_and_adam above.
+namespace gsr {
+
+__global__ __launch_bounds__(64) void k_pose_grad(const float* __restrict__ delta, const float* __restrict__ d_xf, const float* __restrict__ base,
+                                                   float* __restrict__ d_delta)
+{
+    __shared__ double s_M[12][12];
+    const int lane = threadIdx.x;
+    double d[6], B[12];
+    for (int k = 0; k < 6; k++) d[k] = (double)delta[k];
+    if (base) for (int q = 0; q < 12; q++) B[q] = (double)base[q];
+    const double h = 1e-6;
+    if (lane < 12) {
+        d[lane >> 1] += (lane & 1) ? -h : h;
+        se3_exp_times(d, base ? B : nullptr, s_M[lane]);
+    }
+    __syncthreads();
+    if (lane < 6) {
+        double acc = 0.0;
+        for (int q = 0; q < 12; q++) acc += (double)d_xf[q] * (s_M[2 * lane][q] - s_M[2 * lane + 1][q]) / (2.0 * h);
+        d_delta[lane] = (float)acc;
+    }
+}
+
+}  // namespace gsr
+
+extern "C" int gsr_pose_grad(const float* delta6, const float* d_points_transform12, const float* base12, float* d_delta6_out, void* stream)
+{
+    if (!delta6 || !d_points_transform12 || !d_delta6_out) return GSR_ERR_ARG;
+    hipLaunchKernelGGL(gsr::k_pose_grad, dim3(1), dim3(64), 0, (hipStream_t)stream, delta6, d_points_transform12, base12, d_delta6_out);
+    return hipGetLastError() == hipSuccess ? GSR_OK : GSR_ERR_HIP;
+}
+
 // ------------------------------------------------------------------------------------------------
 // The same pose step when the pose lives in the CAMERA of the render instead of a transform of the means: the render's
 // three camera tensors are functions of the world-to-camera matrix M = Exp(delta) * base,

@@ -680,6 +680,53 @@ void pose_step(Tensor delta, Tensor exp_avg, Tensor exp_avg_sq, const Tensor& d_
     torch::autograd::impl::bump_version(delta);
 }
 
+// The pose matrix as an autograd node (round 6; what gsr_autopatch puts where the unmodified trainer evaluates `P[k].retr()`,
+// /root/reference/scene/gaussian_model_ht.py:135-148): M = Exp(delta) * base as a [3,4] tensor from the pose's six tangent numbers,
+// one one-wave kernel forward (gsr_pose_step with step 0), one backward (gsr_pose_grad: dL/dM -> dL/d(delta)); `delta` keeps its own
+// shape ([6] or lietorch's [1,6]) and receives its .grad the usual way, so whichever optimizer owns it -- the FusedPoseAdam
+// gsr_autopatch hands out, or a stock torch.optim.Adam -- steps it unchanged.  base: [3,4] / [4,4] or empty (identity).
+Tensor pose_matrix_forward(const Tensor& delta, const Tensor& base)
+{
+    TORCH_CHECK(delta.is_cuda(), "pose_matrix: tensors must be on a ROCm/HIP device (no CPU fallback)");
+    const c10::hip::HIPGuardMasqueradingAsCUDA guard(delta.device());
+    TORCH_CHECK(delta.scalar_type() == at::kFloat && delta.numel() == 6, "pose_matrix: delta must hold six float32 numbers (tau, phi)");
+    const Tensor d = delta.contiguous(), b = has(base) ? f32c(base) : base;
+    TORCH_CHECK(!has(b) || b.numel() >= 12, "pose_matrix: base must hold a 3x4 (or 4x4) matrix");
+    Tensor xf = at::empty({3, 4}, d.options());
+    check(gsr_pose_step(const_cast<float*>(d.data_ptr<float>()), nullptr, nullptr, nullptr, fp(b), xf.data_ptr<float>(), 0.f, 0.9f, 0.999f, 1e-8f, 0,
+                        c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()), "gsr_pose_step");
+    return xf;
+}
+Tensor pose_matrix_backward(const Tensor& delta, const Tensor& base, const Tensor& d_xf)
+{
+    TORCH_CHECK(delta.is_cuda(), "pose_matrix: tensors must be on a ROCm/HIP device (no CPU fallback)");
+    const c10::hip::HIPGuardMasqueradingAsCUDA guard(delta.device());
+    const Tensor d = delta.contiguous(), b = has(base) ? f32c(base) : base, g = f32c(d_xf);
+    TORCH_CHECK(d.scalar_type() == at::kFloat && d.numel() == 6 && g.numel() >= 12, "pose_matrix backward: delta [6], dL/dM [3,4]");
+    Tensor out = at::empty(delta.sizes(), d.options());
+    check(gsr_pose_grad(d.data_ptr<float>(), g.data_ptr<float>(), fp(b), out.data_ptr<float>(),
+                        c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()), "gsr_pose_grad");
+    return out;
+}
+class PoseMatrixFn : public torch::autograd::Function<PoseMatrixFn> {
+   public:
+    static Tensor forward(torch::autograd::AutogradContext* ctx, const Tensor& delta, const Tensor& base)
+    {
+        static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("gsr::pose_matrix_forward", "").typed<decltype(pose_matrix_forward)>();
+        ctx->save_for_backward({delta, base});
+        ctx->set_materialize_grads(false);
+        return op.call(delta, base);
+    }
+    static torch::autograd::variable_list backward(torch::autograd::AutogradContext* ctx, torch::autograd::variable_list g)
+    {
+        if (!g[0].defined()) return {Tensor(), Tensor()};
+        static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("gsr::pose_matrix_backward", "").typed<decltype(pose_matrix_backward)>();
+        auto sv = ctx->get_saved_variables();
+        return {op.call(sv[0], sv[1], g[0]), Tensor()};
+    }
+};
+Tensor pose_matrix(const Tensor& delta, const Tensor& base) { return PoseMatrixFn::apply(delta, base); }
+
 // Camera-route pose step: the frame's viewmatrix / projmatrix / campos tensors are rewritten in place from their own gradients.
 void pose_step_camera(Tensor delta, Tensor exp_avg, Tensor exp_avg_sq, const Tensor& d_vm, const Tensor& d_pm, const Tensor& d_cp,
                       const Tensor& projT, const Tensor& base, Tensor vm, Tensor pm, Tensor cp, double lr, double beta1, double beta2,
@@ -799,6 +846,9 @@ TORCH_LIBRARY(gsr, m)
     m.def("pose_step_camera(Tensor(a!) delta, Tensor(b!) exp_avg, Tensor(c!) exp_avg_sq, Tensor d_viewmatrix, Tensor d_projmatrix, "
           "Tensor d_campos, Tensor projection_T, Tensor base, Tensor(d!) viewmatrix, Tensor(e!) projmatrix, Tensor(f!) campos, float lr, "
           "float beta1, float beta2, float eps, int step) -> ()");
+    m.def("pose_matrix_forward(Tensor delta, Tensor base) -> Tensor");
+    m.def("pose_matrix_backward(Tensor delta, Tensor base, Tensor d_xf) -> Tensor");
+    m.def("pose_matrix(Tensor delta, Tensor base) -> Tensor");
     m.def("knn_mean_dist2(Tensor points) -> Tensor");
     m.def("masked_max_(Tensor(a!) dst, Tensor src, Tensor mask) -> ()");
     m.def("densify_stats_add_(Tensor(a!) accum, Tensor(b!) denom, Tensor grad, Tensor mask) -> ()");
@@ -817,6 +867,9 @@ TORCH_LIBRARY_IMPL(gsr, CUDA, m)   // the dispatch key of HIP tensors on a ROCm 
     m.impl("adam_step", &adam_step);
     m.impl("pose_step", &pose_step);
     m.impl("pose_step_camera", &pose_step_camera);
+    m.impl("pose_matrix_forward", &pose_matrix_forward);
+    m.impl("pose_matrix_backward", &pose_matrix_backward);
+    m.impl("pose_matrix", &pose_matrix_forward);
     m.impl("knn_mean_dist2", &knn_mean_dist2);
     m.impl("masked_max_", &masked_max_);
     m.impl("densify_stats_add_", &densify_stats_add_);
@@ -831,4 +884,5 @@ TORCH_LIBRARY_IMPL(gsr, Autograd, m)
     m.impl("rasterize", &rasterize);
     m.impl("photometric_loss", &photometric_loss);
     m.impl("photometric_loss_terms", &photometric_loss_terms);
+    m.impl("pose_matrix", &pose_matrix);
 }

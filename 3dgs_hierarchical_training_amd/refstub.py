@@ -29,35 +29,71 @@ class StubCamera:
                    scene["projmatrix"].to(device), scene["campos"].to(device), uid, original_image)
 
 
-class _StubSE3:
-    """What `P[k].retr()` returns, as far as `get_xyz` and gsr_autopatch read it: `.act(points)` and `.matrix()` ([1,4,4])."""
+class SE3:
+    """Stand-in for `lietorch.SE3` as far as the reference's model file uses it (/root/reference/scene/gaussian_model_ht.py:135-166,
+    346-386): `SE3(pose7)` with `.data` = [..., 7] (tx ty tz qx qy qz qw), `tangent_shape`, `retr(a)` = Exp(a) * self,
+    `act(points)`, `matrix()`, `inv()`, `*`.  lietorch is a third-party CUDA extension that exists neither in this image nor on the
+    GPU box; this class states its PUBLIC behaviour with plain torch (pose.py's closed forms), so that the trainer's pose
+    statements can be driven -- and timed as a torch chain -- without it.  An element that came out of an operation carries its
+    matrix only (`.data` is then None): enough for `act` / `matrix` / `inv` / `*`, which is all the reference asks of one."""
 
-    def __init__(self, M):
-        self.M = M
+    def __init__(self, data=None, _matrix=None):
+        self.data = data
+        self._matrix = _matrix
+
+    @property
+    def tangent_shape(self):
+        return tuple(self.data.shape[:-1]) + (6,)
+
+    def _M(self):
+        if self._matrix is None:
+            from . import pose
+            return pose.pose7_to_matrix(self.data.reshape(7))
+        return self._matrix
+
+    def retr(self, a):
+        from . import pose
+        return SE3(_matrix=pose.se3_exp(a.reshape(6)) @ self._M())
 
     def matrix(self):
-        return self.M[None]
+        return self._M()[None]
+
+    def inv(self):
+        M = self._M()
+        Rt = M[:3, :3].t()
+        top = torch.cat((Rt, -(Rt @ M[:3, 3:4])), dim=1)
+        return SE3(_matrix=torch.cat((top, M[3:4]), dim=0))
 
     def act(self, x):
-        return x @ self.M[:3, :3].t() + self.M[:3, 3]
+        M = self._M()
+        return x @ M[:3, :3].t() + M[:3, 3]
+
+    def __mul__(self, other):
+        return SE3(_matrix=self._M() @ other._M())
 
 
-class StubPose:
-    """One frame's pose parameter the way `HTGaussianModel` keeps it (`self.P[k]`, a lietorch SE3 parameter with an Adam of its own,
-    gaussian_model_ht.py:296-311): six numbers (rotation vector, translation), `retr()` -> the rigid transform with its autograd
-    link.  (lietorch is not in the image; the exponential of the rotation part is torch.linalg.matrix_exp.)"""
+class LieGroupParameter(torch.Tensor):
+    """Stand-in for `lietorch.LieGroupParameter`: a float32 tensor SUBCLASS of the group's tangent shape, zeros at construction,
+    `__torch_function__` disabled, the group element in `.group`; `retr()` = Exp(self) * group (lietorch/groups.py, public API).
+    A stock torch.optim.Adam updates the six tangent numbers in place (addcdiv_), the group element stays."""
+    __torch_function__ = torch._C._disabled_torch_function_impl
 
-    def __init__(self, w0, device, lr: float = 1e-4):
-        self.w = torch.tensor([float(v) for v in w0], device=device, requires_grad=True)
-        self.optimizer = torch.optim.Adam([self.w], lr=lr, eps=1e-15)
-        self._row = torch.tensor([[0.0, 0.0, 0.0, 1.0]], device=device)
+    def __new__(cls, group, requires_grad=True):
+        data = torch.zeros(group.tangent_shape, device=group.data.device, dtype=group.data.dtype, requires_grad=True)
+        return torch.Tensor._make_subclass(cls, data, requires_grad)
+
+    def __init__(self, group, requires_grad=True):
+        self.group = group
 
     def retr(self):
-        w = self.w
-        z = torch.zeros((), device=w.device)
-        K = torch.stack([torch.stack([z, -w[2], w[1]]), torch.stack([w[2], z, -w[0]]), torch.stack([-w[1], w[0], z])])
-        top = torch.cat([torch.linalg.matrix_exp(K), w[3:, None]], 1)
-        return _StubSE3(torch.cat([top, self._row], 0))
+        return self.group.retr(self)
+
+    def inv(self):
+        return self.retr().inv()
+
+
+def pose7_identity(device):
+    return torch.tensor([[0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0]], device=device)
 
 
 class StubGaussians:

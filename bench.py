@@ -425,9 +425,11 @@ def posed_frames_leg(ts, lib, scene, settings, dev, steps, warmup, frames=8):
     + the trainer's calls, `frames` frames with their own targets, camera uid = frame index.  Reported with the forward blend's balanced
     placement on and off (same process, same model): ms per step, the blend kernel's own duration (its dispatch's timestamps, every third
     launch), and the view-cost cache's hit rate -- by the camera's uid (what gsr_autopatch passes) and by pose alone (GSR_AUTOPATCH_VIEW_ID=0)."""
+    import math
     import random
     import gsr_autopatch
     refstub = importlib.import_module("3dgs_hierarchical_training_amd.refstub")
+    pose_mod = importlib.import_module("3dgs_hierarchical_training_amd.pose")
     syn = importlib.import_module("3dgs_hierarchical_training_amd.synthetic")
     W, H = int(settings.image_width), int(settings.image_height)
     gsr_autopatch.apply()
@@ -447,16 +449,28 @@ def posed_frames_leg(ts, lib, scene, settings, dev, steps, warmup, frames=8):
             lib.gsr_debug_view_cache_stats(W, H, out)
             return out[0], out[1], out[2]
 
-        def measure(balance, by_uid):
+        def measure(balance, by_uid, pose_fused=True):
             # every mode trains ITS OWN copy of the model from the same start, with the same frame draws: the blend's time follows the
             # model as it trains (on noise targets: the lists deepen), so only equal trajectories compare
+            prev_pf = os.environ.get("GSR_AUTOPATCH_POSE_FUSED")
+            os.environ["GSR_AUTOPATCH_POSE_FUSED"] = "1" if pose_fused else "0"
             p = ts.GaussianParams(scene, dev, optimizer="torch")
             r = refstub.StubRender(p, bg=tuple(float(x) for x in settings.bg.cpu()))
             g = r.gaussians
             gen = torch.Generator().manual_seed(4321)
-            g.P = [refstub.StubPose(torch.cat([0.02 * torch.randn(3, generator=gen), 0.03 * torch.randn(3, generator=gen)]).tolist() if f else [0.0] * 6, dev)
-                   for f in range(frames)]
+            # the model's own statements: init_RT_seq (gaussian_model_ht.py:362-377: one LieGroupParameter(SE3(pose7)) per frame) and
+            # training_setup(fit_pose=True) (:296-311: one Adam per frame over it) -- lietorch's public API as refstub states it in torch
+            g.P = []
+            for f in range(frames):
+                w = torch.cat([0.02 * torch.randn(3, generator=gen), 0.03 * torch.randn(3, generator=gen)]) if f else torch.zeros(6)
+                Mf = pose_mod.se3_exp(torch.cat([w[3:], w[:3]]).double())
+                tr = float(Mf[0, 0] + Mf[1, 1] + Mf[2, 2])
+                qw = math.sqrt(max(1e-12, 1.0 + tr)) / 2
+                q = torch.tensor([float(Mf[2, 1] - Mf[1, 2]) / (4 * qw), float(Mf[0, 2] - Mf[2, 0]) / (4 * qw), float(Mf[1, 0] - Mf[0, 1]) / (4 * qw), qw])
+                g.P.append(refstub.LieGroupParameter(refstub.SE3(torch.cat([Mf[:3, 3].float(), q.float()])[None].to(dev))))
             g.rotate_seq = True
+            g.camera_optimizer = [torch.optim.Adam([{'params': [g.P[f]], 'lr': 1e-4, "name": "R"}], lr=0.0, eps=1e-15) for f in range(frames)]
+            kinds = {type(o).__name__ for o in g.camera_optimizer}
             rng = random.Random(7)
 
             def step(i):
@@ -467,8 +481,8 @@ def posed_frames_leg(ts, lib, scene, settings, dev, steps, warmup, frames=8):
                 with torch.no_grad():
                     p.optimizer.step()
                     p.optimizer.zero_grad(set_to_none=True)
-                    g.P[f].optimizer.step()                      # camera_optimizer[fidx].step(): the pose's bits change after every render
-                    g.P[f].optimizer.zero_grad(set_to_none=True)
+                    g.camera_optimizer[f].step()                      # ht3dgs_trainer.py:162-166: the pose's bits change after every render
+                    g.camera_optimizer[f].zero_grad(set_to_none=True)
             lib.gsr_set_option(b"blend_balance", balance)
             prev = os.environ.get("GSR_AUTOPATCH_VIEW_ID")
             os.environ["GSR_AUTOPATCH_VIEW_ID"] = "1" if by_uid else "0"
@@ -484,24 +498,29 @@ def posed_frames_leg(ts, lib, scene, settings, dev, steps, warmup, frames=8):
                 tot, cnt = read_profile(lib, ["blend_fwd"])["blend_fwd"]
             finally:
                 lib.gsr_set_option(b"profile", 0)
-                if prev is None:
-                    os.environ.pop("GSR_AUTOPATCH_VIEW_ID", None)
-                else:
-                    os.environ["GSR_AUTOPATCH_VIEW_ID"] = prev
+                for k, v in (("GSR_AUTOPATCH_VIEW_ID", prev), ("GSR_AUTOPATCH_POSE_FUSED", prev_pf)):
+                    if v is None:
+                        os.environ.pop(k, None)
+                    else:
+                        os.environ[k] = v
             del p, r, g
             look = s1[0] - s0[0]
             return {"ms_per_step": 1e3 * sec, "blend_fwd_us": (1e3 * tot / cnt) if cnt else None, "blend_launches_timed": cnt,
-                    "view_cache_hit_rate": ((s1[1] - s0[1]) / look) if look else None, "view_cache_entries_in_use": s1[2]}
+                    "view_cache_hit_rate": ((s1[1] - s0[1]) / look) if look else None, "view_cache_entries_in_use": s1[2],
+                    "pose_optimizer": sorted(kinds)}
         out = {"frames": frames, "steps": steps,
-               "balance_off": measure(0, True), "balance_on_by_uid": measure(1, True), "balance_on_by_pose": measure(1, False)}
+               "balance_off": measure(0, True), "balance_on_by_uid": measure(1, True), "balance_on_by_pose": measure(1, False),
+               "lietorch_chain_and_stock_adam": measure(1, True, pose_fused=False)}
         lib.gsr_set_option(b"blend_balance", 1)
     finally:
         lib.gsr_set_option(b"blend_balance", 1)
         gsr_autopatch.remove()
-    out["note"] = ("identity camera for every frame, the pose through get_xyz (points_transform), torch.optim.Adam on the frame's six pose numbers "
-                   "after every render, frames drawn at random; the pose's autograd chain (matrix exponential, 4x4 products) is torch's, as the "
-                   "reference's is lietorch's: its host time is in ms_per_step; every mode trains its own copy of the model from the same start "
-                   "with the same frame draws (the blend's time follows the model as it trains)")
+    out["note"] = ("identity camera for every frame, the frame's lietorch-shaped LieGroupParameter through get_xyz, camera_optimizer[f].step() after "
+                   "every render, frames drawn at random.  Round 6: gsr_autopatch puts ONE autograd node (gsr::pose_matrix) where P[f].retr() "
+                   "stands and hands out FusedPoseAdam for torch.optim.Adam over such a parameter: three one-wave kernels per iteration; "
+                   "'lietorch_chain_and_stock_adam' = GSR_AUTOPATCH_POSE_FUSED=0, the group's chain (exponential map, product, matrix()) and "
+                   "its autograd stated in torch + the stock Adam, what rounds 4-5 reported here.  Every mode trains its own copy of the model "
+                   "from the same start with the same frame draws (the blend's time follows the model as it trains)")
     return out
 
 

@@ -31,6 +31,13 @@ Importing this module BEFORE the trainer swaps both for the HIP kernels of this 
     `radii`).  `override_color`, `compute_cov3D_python`, `convert_SHs_python`, CPU tensors or an unexpected parameter layout
     fall back to the ORIGINAL method.  `GSR_AUTOPATCH_RENDER=0` leaves the method alone; `GSR_AUTOPATCH_POSE=0` keeps pose
     renders (rotate_xyz / rotate_seq) on the original method.
+  * the frame poses (round 6): a lietorch SE3 `LieGroupParameter` that `get_xyz` reads (`P[k]`, gaussian_model_ht.py:135-148,
+    :346-386) reaches the rasterizer through ONE autograd node over its six tangent numbers (`torch.ops.gsr.pose_matrix`: the [3,4]
+    `points_transform` from one one-wave kernel, `.grad` of the parameter from another), and the pose optimizers the reference
+    builds over such parameters -- `camera_optimizer[k]` (:296-311, stepped after every render: ht3dgs_trainer.py:162-166) and
+    stage A's `training_setup_fix_position(gaussian_rot=False)` (:321-333) -- are `FusedPoseAdam` objects: one launch per
+    `step()`.  The reference's ~50 small lietorch / torch launches per iteration (exponential map, group product, `matrix()`, their
+    backward, Adam on six numbers) become three.  `GSR_AUTOPATCH_POSE_FUSED=0` keeps lietorch's chain and the stock Adam.
   * `HTGaussianModel.add_densification_stats` (same module) accumulates the same two sums without the boolean-mask gathers
     (each of them a `nonzero` + host synchronisation): one masked-add launch over N (gsr_densify_stats_add).
   * the render's `visibility_filter` is a bool-tensor subclass (`LazyMask`) under which the trainer's
@@ -93,6 +100,26 @@ def _wants_fused(params, kw) -> bool:
     return True
 
 
+def _wants_pose(params, kw) -> bool:
+    """The reference's pose optimizers: `torch.optim.Adam([{'params': [P[k]], 'lr': ..., 'name': 'R'}], lr=0.0, eps=1e-15)` -- one per
+    frame (`camera_optimizer[k]`, /root/reference/scene/gaussian_model_ht.py:296-311) or the model's `optimizer` during stage A's pose
+    fit (`training_setup_fix_position(gaussian_rot=False)`, :321-333): every parameter a lietorch SE3 `LieGroupParameter` on the GPU."""
+    if os.environ.get("GSR_AUTOPATCH_POSE_FUSED", "1") == "0":
+        return False
+    try:
+        groups = list(params)
+    except TypeError:
+        return False
+    if not groups or not all(isinstance(g, dict) for g in groups) or kw.get("amsgrad") or kw.get("weight_decay") or kw.get("maximize"):
+        return False
+    P = importlib.import_module("3dgs_hierarchical_training_amd.pose_opt")
+    for g in groups:
+        ps = [g["params"]] if torch.is_tensor(g["params"]) else list(g["params"])
+        if not ps or not all(P.is_lie_pose(q) and (q.is_cuda or not _REQUIRE_CUDA) for q in ps):
+            return False
+    return True
+
+
 class _AdamMeta(type(_ORIG_ADAM)):
     """`isinstance(opt, torch.optim.Adam)` keeps answering True for everything the patched name constructs (stock Adam objects and
     FusedAdam), as it did before the patch."""
@@ -101,14 +128,14 @@ class _AdamMeta(type(_ORIG_ADAM)):
         if cls is _AdamDispatch:
             if isinstance(inst, _ORIG_ADAM):
                 return True
-            optim = sys.modules.get("3dgs_hierarchical_training_amd.optim")
-            return optim is not None and isinstance(inst, optim.FusedAdam)
+            optim, pose_opt = sys.modules.get("3dgs_hierarchical_training_amd.optim"), sys.modules.get("3dgs_hierarchical_training_amd.pose_opt")
+            return (optim is not None and isinstance(inst, optim.FusedAdam)) or (pose_opt is not None and isinstance(inst, pose_opt.FusedPoseAdam))
         return super().__instancecheck__(inst)
 
 
 class _AdamDispatch(_ORIG_ADAM, metaclass=_AdamMeta):
-    """`torch.optim.Adam` while the patch is applied: constructs FusedAdam for the reference's six-group optimizer and the stock
-    Adam for everything else.  (Returning an object that is not an instance of this class from __new__ skips __init__.)
+    """`torch.optim.Adam` while the patch is applied: constructs FusedAdam for the reference's six-group optimizer, FusedPoseAdam
+    for its pose optimizers (groups of lietorch SE3 parameters, `_wants_pose`) and the stock Adam for everything else.  (Returning an object that is not an instance of this class from __new__ skips __init__.)
     A SUBCLASS defined while the patch is applied (`class My(torch.optim.Adam)`) constructs normally: the dispatch only fires for
     the patched name itself."""
 
@@ -120,6 +147,10 @@ class _AdamDispatch(_ORIG_ADAM, metaclass=_AdamMeta):
             optim, _ = _pkg()
             groups = [dict(g, params=[g["params"]] if torch.is_tensor(g["params"]) else list(g["params"])) for g in params]
             return optim.FusedAdam(groups, lr=kw.get("lr", 1e-3), betas=kw.get("betas", (0.9, 0.999)), eps=kw.get("eps", 1e-8))
+        if _wants_pose(params, kw) and not args:
+            P = importlib.import_module("3dgs_hierarchical_training_amd.pose_opt")
+            groups = [dict(g, params=[g["params"]] if torch.is_tensor(g["params"]) else list(g["params"])) for g in params]
+            return P.FusedPoseAdam(groups, lr=kw.get("lr", 1e-3), betas=kw.get("betas", (0.9, 0.999)), eps=kw.get("eps", 1e-8))
         return _ORIG_ADAM(params, *args, **kw)
 
 
@@ -267,16 +298,26 @@ class LazyMask(torch.Tensor):
 
 # ---- CF3DGS_Render.render on the raw-parameter path ------------------------------------------------------------------------------
 def _pose_matrix(g):
-    """The transform `get_xyz` applies to the means (/root/reference/scene/gaussian_model_ht.py:135-148), as a [4,4] matrix that
-    keeps its autograd link to the pose parameter (lietorch's `matrix()` is `act` on the basis vectors), or None."""
+    """The transform `get_xyz` applies to the means (/root/reference/scene/gaussian_model_ht.py:135-148) as a matrix that keeps its
+    autograd link to the pose parameter, or None.  A lietorch SE3 `LieGroupParameter` on the GPU (what `init_RT` / `init_RT_seq` /
+    `update_RT_seq` build, :346-386) goes through ONE autograd node over its six tangent numbers (`pose_opt.pose_matrix`: a [3,4]
+    tensor, one kernel forward, one backward that leaves `.grad` on the parameter): no `retr()` chain, no matrix exponential in
+    torch, nothing N-sized.  Any other pose object -- or `rotate_xyz_inverse`, or GSR_AUTOPATCH_POSE_FUSED=0 -- keeps the original
+    statement: lietorch's `matrix()` of `retr()` ([4,4]; `matrix()` is `act` on the basis vectors)."""
+    inverse = False
     if getattr(g, "rotate_xyz", False):
-        T = g.P[0].retr()
+        p = g.P[0]
     elif getattr(g, "rotate_xyz_inverse", False):
-        T = g.P[0].retr().inv()
+        p, inverse = g.P[0], True
     elif getattr(g, "rotate_seq", False):
-        T = g.P[g.seq_idx].retr()
+        p = g.P[g.seq_idx]
     else:
         return None
+    if not inverse and os.environ.get("GSR_AUTOPATCH_POSE_FUSED", "1") != "0":
+        P = importlib.import_module("3dgs_hierarchical_training_amd.pose_opt")
+        if P.is_lie_pose(p) and (p.is_cuda or not _REQUIRE_CUDA):
+            return P.pose_matrix(p, _ops())
+    T = p.retr().inv() if inverse else p.retr()
     return T.matrix().reshape(4, 4)
 
 
@@ -342,11 +383,16 @@ def render_fused(self, viewpoint_camera, scaling_modifier=1.0, invert_bg_color=F
     # retain_grad); its values are never read by the rasterizer
     # (one zero buffer per (N, device), a fresh LEAF over it per render -- detach() makes a new tensor object on the same storage, no
     #  fill launch and no allocation; every render's leaf has its own .grad, and a leaf that requires grad cannot be written in place)
+    # every render's leaf aliases this storage, so an in-place write under no_grad would reach all later renders -- the
+    # buffer's version counter (shared by every detach() of it) must still be the one it was created with, else a fresh one is made
+    # (a write through `.data` carries a counter of its own and is NOT seen: the values of `viewspace_points` are never read by the
+    # rasterizer, only its .grad is written); and only the two most recent sizes are kept (a model and its frozen teacher), not one N x 12 B buffer per densification size
     zkey = (int(xyz.shape[0]), dev)
     zbuf = _ZERO_POINTS.get(zkey)
-    if zbuf is None:
-        if len(_ZERO_POINTS) > 8:
-            _ZERO_POINTS.clear()
+    if zbuf is None or zbuf._version != 0:
+        while len(_ZERO_POINTS) >= 2:
+            _ZERO_POINTS.pop(next(iter(_ZERO_POINTS)))
+        _ZERO_POINTS.pop(zkey, None)
         zbuf = _ZERO_POINTS[zkey] = torch.zeros((xyz.shape[0], 3), dtype=torch.float32, device=dev)
     screenspace_points = zbuf.detach().requires_grad_(True)
     bg = self.bg_color if not invert_bg_color else 1 - self.bg_color

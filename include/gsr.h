@@ -264,17 +264,20 @@ int gsr_mark_visible(int32_t N, const float* means3D, const float* viewmatrix, c
                      uint8_t* present, void* stream);
 
 const char* gsr_last_error(void);
+/* 100 * major + minor.  110 (round 6): GsrForwardArgs ends with view_id, out_color_clamped, visible (appended in round 5 under
+ * version 100: a caller compiled against a shorter struct must be rebuilt -- check gsr_version() >= 110 AND
+ * gsr_struct_bytes(0) == sizeof(GsrForwardArgs), gsr_struct_bytes(1) == sizeof(GsrBackwardArgs) at start-up). */
 int gsr_version(void);
+size_t gsr_struct_bytes(int32_t which); /* 0 GsrForwardArgs, 1 GsrBackwardArgs, 2 GsrForwardOut; anything else 0 */
 
 /* Process-wide knobs (value 0 = default unless stated):
  *   "blend_fwd_ppt"        forward blend kernel: 7 = one wave per 8x8 sub-tile, finished pixels encoded in the sign of T,
  *                          instances the sub-tile cannot see skipped by reach bits (default); 6 = without the reach bits.
- *                          1-5 = the A/B kernels of csrc/variants.hip (tile-per-workgroup kernels, the packed two-pixel kernel,
- *                          the lane-mask predecessor of the default): accepted only by a library built with -DGSR_AB_VARIANTS
+ *                          Any other value is refused (the A/B kernels rounds 1-4 selected with 1-5 left the tree in round 5)
  *   "blend_bwd_ppt"        backward blend kernel: 2 (default; 0 = default) = two pixels per lane, packed math, two waves per tile; 1 = one pixel per lane,
  *                          four waves per tile, four reach bits per staged instance (k_blend_bwd1: same results within rounding; -7 % of the kernel
  *                          on random scenes of up to ~130 k Gaussians, +2 % on pixel-sized splats, equal from 300 k on)
- *   "ab_variants"          query: returns 1 when the library carries the A/B kernels, 0 otherwise (the value is ignored)
+ *   "ab_variants"          query kept for callers of the round-4 ABI: always returns 0 (no A/B kernels in the library)
  *   "sort_algo"            2 = onesweep for both sorts (default); 1 = onesweep depth sort only; 0 = hist + scan + scatter
  *   "bwd_split"            1 = the backward of a tile is ONE work item (off); anything else (default 0) = one item per 128-instance
  *                          batch beyond the first "ckpt_first" (default 1) batches, each resuming from the per-pixel checkpoint the
@@ -411,6 +414,12 @@ int gsr_adam_step(const GsrAdamTensor* tensors, int32_t count, float beta1, floa
  * step = 0: only evaluates M for the current delta.  base12 = NULL: identity.  All pointers device; one one-thread kernel. */
 int gsr_pose_step(float* delta6, float* exp_avg6, float* exp_avg_sq6, const float* d_points_transform12, const float* base12,
                   float* points_transform_out12, float lr, float beta1, float beta2, float eps, int64_t step, void* stream);
+
+/* The chain of gsr_pose_step alone (round 6): d_delta6_out = dL/d(delta) of M = Exp(delta) * base given dL/dM
+ * (d_points_transform12, as written by gsr_backward), nothing updated.  It is the backward of the autograd node that stands where the
+ * unmodified trainer evaluates `P[k].retr()` (scene/gaussian_model_ht.py:135-148): `.grad` of the frame's six pose numbers is
+ * left where the trainer's own optimizer object looks for it (trainer/ht3dgs_trainer.py:162-166).  base12 = NULL: identity. */
+int gsr_pose_grad(const float* delta6, const float* d_points_transform12, const float* base12, float* d_delta6_out, void* stream);
 
 /* The same step when the pose lives in the render's CAMERA (the reference's camera_optimizer stepping a frame's pose after each
  * render of it, trainer/ht3dgs_trainer.py:162-166): viewmatrix = M^T, projmatrix = viewmatrix * projection_T, campos = -R^T t for

@@ -480,3 +480,191 @@ def test_clamped_image_and_visibility_come_out_of_the_kernels():
     assert torch.equal(res[0]["raw"], res[1]["raw"])
     for k in list(RAW) + ["m2d"]:
         assert _rel(res[0][k], res[1][k]) < 1e-5, (k, _rel(res[0][k], res[1][k]))
+
+
+# ---- round 6: the frame poses of the unmodified trainer (lietorch LieGroupParameter + its Adam) on the kernels -----------------------
+def _lie(dev, pose7=None, delta=None):
+    p = refstub.LieGroupParameter(refstub.SE3(torch.tensor([pose7 if pose7 is not None else [0.0, 0, 0, 0, 0, 0, 1]], device=dev)))
+    if delta is not None:
+        with torch.no_grad():
+            p.copy_(torch.tensor([delta], device=dev))
+    return p
+
+
+@pytest.mark.parametrize("with_base", [False, True], ids=["identity-base", "posed-base"])
+def test_pose_matrix_node_equals_the_lietorch_statement_and_its_autograd(with_base):
+    """`torch.ops.gsr.pose_matrix` (what stands for `P[k].retr()` on the patched render): the [3,4] matrix of Exp(delta) * group
+    against the float64 torch statement to float32 rounding, its backward (gsr_pose_grad) against autograd through that statement
+    -- at delta = 0 (the series branch, every pose's first render) and away from it; `.grad` lands on the parameter in ITS shape."""
+    import gsr_autopatch
+    pose = importlib.import_module("3dgs_hierarchical_training_amd.pose")
+    pose_opt = importlib.import_module("3dgs_hierarchical_training_amd.pose_opt")
+    dev = torch.device("cuda:0")
+    ops = gsr_autopatch._ops()
+    pose7 = [0.3, -0.2, 0.5, 0.1, -0.2, 0.3, 0.9] if with_base else None
+    Wt = torch.randn(3, 4, generator=torch.Generator().manual_seed(5)).to(dev)
+    for delta in (None, [0.02, -0.01, 0.03, 0.015, -0.02, 0.01], [0.3, -0.2, 0.1, 0.4, 0.5, -0.3]):
+        p = _lie(dev, pose7, delta)
+        M = pose_opt.pose_matrix(p, ops)
+        d64 = p.detach().double().reshape(6).requires_grad_(True)
+        q = p.group.data.double().reshape(7)
+        q = torch.cat((q[:3], q[3:] / q[3:].norm()))
+        ref = pose.retr_matrix(d64, q)[:3]
+        assert tuple(M.shape) == (3, 4) and float((M.detach().double() - ref.detach()).abs().max()) < 1e-6
+        (M * Wt).sum().backward()
+        (ref * Wt.double()).sum().backward()
+        assert tuple(p.grad.shape) == (1, 6)
+        assert _rel(p.grad.reshape(6).double(), d64.grad) < 2e-6, (delta, p.grad, d64.grad)
+        with torch.no_grad():                                   # no graph: the same matrix, nothing recorded
+            assert torch.equal(pose_opt.pose_matrix(p, ops), M.detach())
+
+
+def test_fused_pose_adam_is_torch_adam_over_the_pose_node():
+    """The optimizer `torch.optim.Adam([{'params': [P[k]], 'lr': ..., 'name': 'R'}], lr=0.0, eps=1e-15)` returns while the patch is
+    applied (gaussian_model_ht.py:296-311), stepping a lietorch parameter through the pose node, against the stock class stepping the
+    same parameter through lietorch's own chain (refstub's torch statement of it): same trajectory of the six numbers over 40 steps,
+    same state, with the learning-rate statement of `update_learning_rate_camera` in between."""
+    import gsr_autopatch
+    pose_opt = importlib.import_module("3dgs_hierarchical_training_amd.pose_opt")
+    dev = torch.device("cuda:0")
+    pose7 = [0.1, 0.05, -0.2, 0.05, -0.1, 0.02, 0.99]
+    Wt = torch.randn(3, 4, generator=torch.Generator().manual_seed(9)).to(dev)
+    gsr_autopatch.apply()
+    try:
+        pa = _lie(dev, pose7)
+        oa = torch.optim.Adam([{'params': [pa], 'lr': 1e-3, "name": "R"}], lr=0.0, eps=1e-15)
+    finally:
+        gsr_autopatch.remove()
+    assert isinstance(oa, pose_opt.FusedPoseAdam)
+    pb = _lie(dev, pose7)
+    ob = torch.optim.Adam([{'params': [pb], 'lr': 1e-3, "name": "R"}], lr=0.0, eps=1e-15)
+    assert type(ob) is torch.optim.Adam
+    ops = gsr_autopatch._ops()
+    for it in range(1, 41):
+        lr = 1e-3 * (0.98 ** it)
+        for o in (oa, ob):
+            for g in o.param_groups:
+                g["lr"] = lr
+        Ma = pose_opt.pose_matrix(pa, ops)
+        Mb = pb.retr().matrix().reshape(4, 4)[:3]
+        assert torch.allclose(Ma, Mb, atol=2e-6)
+        ((Wt * Ma).sum() + 0.5 * (Ma ** 2).sum()).backward()
+        ((Wt * Mb).sum() + 0.5 * (Mb ** 2).sum()).backward()
+        assert _rel(pa.grad, pb.grad) < 1e-4, it
+        oa.step(); ob.step()
+        oa.zero_grad(set_to_none=True); ob.zero_grad(set_to_none=True)
+        assert pa.grad is None
+        assert torch.allclose(pa.detach(), pb.detach(), atol=5e-6, rtol=1e-4), (it, pa, pb)
+    assert float(pb.detach().abs().max()) > 0.01
+    sa, sb = oa.state[pa], ob.state[pb]
+    assert sa["step"] == 40 and float(sb["step"]) == 40.0
+    assert torch.allclose(sa["exp_avg"], sb["exp_avg"], rtol=1e-3, atol=1e-8) and torch.allclose(sa["exp_avg_sq"], sb["exp_avg_sq"], rtol=1e-3, atol=1e-12)
+    assert torch.equal(pa.group.data, pb.group.data)             # the group element stays; the six tangent numbers carry the update
+
+
+@pytest.mark.parametrize("mode", ["rotate_seq", "rotate_xyz"])
+def test_unmodified_trainers_pose_iteration_fused_equals_its_lietorch_chain(mode, monkeypatch):
+    """The reference's pose iteration (ht3dgs_trainer.py:102-166 under `rotate_seq` with `camera_optimizer[fidx]`, and stage A's
+    `train_relative_pose` with the pose in `gaussians.optimizer`): render -> loss -> backward -> optimizer.step() on the patched
+    pieces, with the pose on the kernels (pose node + FusedPoseAdam) against GSR_AUTOPATCH_POSE_FUSED=0 (lietorch's chain stated in
+    torch + the stock Adam).  Same images, same pose trajectory, same model after its own (deferred) Adam steps."""
+    import gsr_autopatch
+    dev = torch.device("cuda:0")
+    W, H, N = 256, 192, 8000
+    sc = parity.syn.make_scene(N, W, H, sh_degree=3, seed=6, posed=False)
+    gt = parity.syn.target_image(W, H, seed=3).to(dev)
+    res = {}
+    for fused in (True, False):
+        monkeypatch.setenv("GSR_AUTOPATCH_POSE_FUSED", "1" if fused else "0")
+        gsr_autopatch.apply()
+        try:
+            p = ts.GaussianParams(sc, dev, optimizer="torch")
+            r = refstub.StubRender(p)
+            g = r.gaussians
+            cam = refstub.StubCamera.from_scene(sc, dev, uid=1)
+            if mode == "rotate_seq":
+                g.P = [_lie(dev), _lie(dev, [0.01, -0.02, 0.015, 0.01, 0.0, -0.01, 1.0])]
+                g.rotate_seq, g.seq_idx = True, 1
+                cam_opt = [torch.optim.Adam([{'params': [q], 'lr': 1e-3, "name": "R"}], lr=0.0, eps=1e-15) for q in g.P]
+                live, popt = g.P[1], cam_opt[1]
+            else:
+                g.P = [_lie(dev)]
+                g.rotate_xyz = True
+                live = g.P[0]
+                popt = torch.optim.Adam([{'params': [live], 'lr': 1e-3, "name": "R"}], lr=0.0, eps=1e-15)      # training_setup_fix_position
+            assert type(popt).__name__ == ("FusedPoseAdam" if fused else "Adam")
+            imgs, traj = [], []
+            for it in range(12):
+                pkg = gsr_autopatch.render_fused(r, cam)
+                gsr_autopatch.loss_forward(_LossCfg(), pkg["image"], gt)["loss"].backward()
+                if it == 0:
+                    pg0 = live.grad.clone()
+                imgs.append(pkg["image"].detach().clone())
+                if mode == "rotate_seq":
+                    p.optimizer.step()
+                p.optimizer.zero_grad(set_to_none=True)
+                popt.step()
+                popt.zero_grad(set_to_none=True)
+                traj.append(live.detach().clone().reshape(6))
+            g0 = {k: getattr(p, k).detach().clone() for k in ("_xyz", "_opacity", "_scaling")}      # the model after its twelve (deferred) Adam steps
+            res[fused] = (imgs, torch.stack(traj), g0, pg0, g.P[0].grad if mode == "rotate_seq" else None)
+        finally:
+            gsr_autopatch.remove()
+    (ia, ta, ga, pga, oa), (ib, tb, gb, pgb, ob) = res[True], res[False]
+    assert oa is None and ob is None
+    d0 = (ia[0] - ib[0]).abs()
+    assert float(d0.mean()) <= 1e-6 and float((d0 > 5e-6).float().mean()) <= 2e-4
+    assert _rel(pga, pgb) < 2e-4, _rel(pga, pgb)
+    for k in ga:      # (twelve sign-like first Adam steps on gradients whose atomic sums differ in the last bits run to run: not the 1e-4 of one gradient)
+        assert _rel(ga[k], gb[k]) < 2e-3, k
+    assert mode == "rotate_xyz" or not torch.equal(ga["_xyz"], parity.syn.make_scene(N, W, H, sh_degree=3, seed=6, posed=False)["means3D"].to(dev))
+    # twelve Adam steps of lr 1e-3 move each number by ~1e-2; the two routes round the pose gradient differently (float64 central
+    # differences in the kernel, float32 autograd through the torch chain) and Adam's first steps are sign-like: agreement to a few
+    # percent of a step is what two float32 evaluations of the same loop give
+    assert float(tb.abs().max()) > 5e-3
+    assert float((ta - tb).abs().max()) < 2e-4, float((ta - tb).abs().max())
+    dl = (ia[-1] - ib[-1]).abs()
+    assert float(dl.mean()) <= 2e-4
+
+
+def test_stage_a_pose_fit_under_the_unmodified_trainers_statements_recovers_the_pose():
+    """compute_relative_pose's second half (ht3dgs_trainer.py:308-333, :367-378) the way the unmodified trainer runs it: a frozen
+    model, `init_RT(None)`, `training_setup_fix_position(gaussian_rot=False)` -> Adam over the one LieGroupParameter, render through
+    `get_xyz`'s pose, loss, backward, optimizer.step() -- on the patched render + pose node + FusedPoseAdam.  It must recover the
+    relative pose as the library's own loop (stage_a.fit_pair, gsr_pose_step) does from the same start."""
+    import gsr_autopatch
+    sequence = importlib.import_module("3dgs_hierarchical_training_amd.sequence")
+    dev = torch.device("cuda:0")
+    W, H = 320, 240
+    seq = sequence.FrameSequence(3, 60_000, W, H, dev, seed=0)
+    T = seq.true_rel_pose(0, 1)
+    scene = seq.pixel_scene(0, stride=1, seed=0)      # one Gaussian per pixel of frame 0: explains its image from the start (stage_a.fit_pair)
+    tgt1 = seq.target(1)
+    ident = ts.with_sh_degree(seq.settings_for_pose(torch.eye(4)), 0)
+    gsr_autopatch.apply()
+    try:
+        p = ts.GaussianParams(scene, dev, optimizer="torch")
+        p.active_sh_degree = 0                          # a stage-A model never leaves degree 0 (gaussian_model_ht.py:68)
+        r = refstub.StubRender(p, bg=tuple(float(x) for x in ident.bg.cpu()))
+        g = r.gaussians
+        g.P = [_lie(dev)]
+        g.rotate_xyz = True
+        opt = torch.optim.Adam([{'params': [g.P[0]], 'lr': 2e-3, "name": "R"}], lr=0.0, eps=1e-15)
+        assert type(opt).__name__ == "FusedPoseAdam"
+        cam = refstub.StubCamera(W, H, ident.tanfovx, ident.tanfovy, ident.viewmatrix, ident.projmatrix, ident.campos, uid=1)
+        losses = []
+        for it in range(250):
+            pkg = gsr_autopatch.render_fused(r, cam)
+            out = gsr_autopatch.loss_forward(_LossCfg(), pkg["image"], tgt1)
+            out["loss"].backward()
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+            p.optimizer.zero_grad(set_to_none=True)
+            if it % 50 == 0 or it == 249:
+                losses.append(float(out["loss"]))
+        M = torch.eye(4)
+        M[:3] = importlib.import_module("3dgs_hierarchical_training_amd.pose_opt").pose_matrix(g.P[0], gsr_autopatch._ops()).detach().cpu()
+    finally:
+        gsr_autopatch.remove()
+    err0, err = float((torch.eye(4) - T).abs().max()), float((M - T).abs().max())
+    assert losses[-1] < losses[0] and err < 0.3 * err0, (losses, err0, err)
