@@ -3660,16 +3660,18 @@ __global__ __launch_bounds__(256) void k_det_reduce(uint32_t R, const uint32_t* 
     if (i >= R) return;
     const uint32_t g = gid_sorted[i];
     if (i > 0 && gid_sorted[i - 1] == g) return;
-    float acc[kDetStride];
+    // (round 6: the run is summed in float64 -- the mode is a debugging aid, and with the cross-tile sum exact what is left of a
+    //  gradient's error is the per-tile part: tests/test_gpu_parity.py::test_needle_gradient_error_is_the_binary32_accumulation)
+    double acc[kDetStride];
 #pragma unroll
-    for (int r = 0; r < kDetStride; r++) acc[r] = 0.f;
+    for (int r = 0; r < kDetStride; r++) acc[r] = 0.0;
     for (uint32_t j = i; j < R && gid_sorted[j] == g; j++) {
         const float* p = part + (size_t)pos_sorted[j] * kDetStride;
 #pragma unroll
-        for (int r = 0; r < kDetStride; r++) acc[r] += p[r];
+        for (int r = 0; r < kDetStride; r++) acc[r] += (double)p[r];
     }
 #pragma unroll
-    for (int r = 0; r < kDetStride; r++) ggrad[(size_t)g * kGG + r] = acc[r];
+    for (int r = 0; r < kDetStride; r++) ggrad[(size_t)g * kGG + r] = (float)acc[r];
 }
 
 // one block per camera entry (and, batched, per model: blockIdx.y, over that model's blocks): deterministic sum of the partials

@@ -77,7 +77,8 @@ class DistTransport:
         if self.host_staging and t.is_cuda:
             t = t.detach().cpu()
         if dst == self.rank:
-            self._to_self.append(t.detach())
+            # a copy, not an alias: a blocking send lets the caller reuse the buffer as soon as send() returns
+            self._to_self.append(t.detach().clone())
             return
         dist.send(t, dst, group=self.group)
 

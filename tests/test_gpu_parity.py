@@ -129,9 +129,9 @@ def test_parity_on_a_single_image_model_of_pixel_gaussians(W, H, stride, surface
 def test_more_than_65536_tiles():
     """4112 x 4112 pixels = 257 x 257 = 66 049 tiles: tile ids no longer fit 16 bits, so the instance stream carries 32-bit
     keys (three 6-bit passes of the wide onesweep).  The public module this replaces has no image-size limit.
-    Forward tolerance 4e-5 instead of 1e-5: the blend works on binary32 pixel coordinates, and 2 056 px from the image centre
-    one ulp is 2.4e-4 px -- a relative error of a * dx * ulp ~ 1e-4 in a splat's weight three sigma out (the public module
-    keeps ABSOLUTE binary32 pixel coordinates, twice that).  The float64 oracle does not round there."""
+    Forward tolerance 1e-5, as everywhere: since round 5 the blends form their offsets from TILE-relative coordinates plus the
+    16-bit remainder of the projected mean (gsr_math.h pixel_lo_pack / pixel_rel), so the binary32 pixel grid 2 056 px from the
+    image centre (one ulp = 2.4e-4 px) no longer reaches a splat's weight (rounds 1-4 carried 4e-5 here)."""
     _run_case(30000, 4112, 4112, 1, True, "sh", (0.2, 0.1, 0.0))
 
 
@@ -1085,6 +1085,59 @@ def test_cov3d_fixture_kernel_route_equals_python_route(golden_dir):
     d = np.abs(a["fwd"][0] - b["fwd"][0])
     assert (d > 1e-5).mean() < 2e-3 and d.max() < 5e-3       # float32-rounded covariance: equal up to rare alpha-cut flips
     assert np.mean(a["fwd"][1] != b["fwd"][1]) < 0.05         # radii (ceil of 3 sigma) may differ by one on a rounding edge
+
+
+def test_cov3d_fixture_pins_the_raw_parameter_backward(golden_dir):
+    """cov3d.npz carries the reference's OWN derivatives of `build_scaling_rotation` / `strip_symmetric`
+    (utils/general_utils.py:62-108) -- through `build_rotation`'s internal normalisation of the RAW quaternion (:77-79) -- as full
+    Jacobians d cov6 / d scales, d cov6 / d rot_raw (tools/make_golden.py gen_cov3d, one autograd pass of the reference's code per
+    packed entry).  The kernels' RAW-parameter route (`rasterize_gaussians_raw`: exp / normalize in-kernel, K9's float64 chain) must
+    return dL/d(log scale) and dL/d(rot_raw) equal to the render's dL/dcov6 -- taken from the cov3D_precomp route on the same
+    covariance -- chained through those Jacobians."""
+    import hip_runner
+    R_ = importlib.import_module("3dgs_hierarchical_training_amd.rasterizer")
+    g = np.load(os.path.join(golden_dir, "cov3d.npz"), allow_pickle=False)
+    n = g["scales"].shape[0]
+    W, H = 160, 120
+    dev = torch.device("cuda:0")
+    sc = parity.syn.make_scene(n, W, H, sh_degree=0, seed=12, frac_behind=0.0)
+    smod = float(g["scale_modifier"])
+    zc = sc["means3D"][:, 2:3]
+    unit = torch.tensor(g["scales"] / g["scales"].max())
+    scales = (unit * 6.0 * zc / sc["fx"] / smod).float()                       # fixture scales brought to ~6 px on screen
+    k = (scales.double() / torch.tensor(g["scales"]).double())[:, :1]          # uniform factor per Gaussian: cov scales by k^2
+    cov = (torch.tensor(g["cov"]).double() * k ** 2).float()
+    shs = sc["shs"].clone()
+    gc, gd, ga = parity.upstream_grads(H, W, seed=4)
+    base = dict(means3D=sc["means3D"], opacities=sc["opacities"], viewmatrix=sc["viewmatrix"], projmatrix=sc["projmatrix"],
+                campos=sc["campos"], bg=torch.zeros(3), image_height=H, image_width=W, tanfovx=sc["tanfovx"], tanfovy=sc["tanfovy"],
+                sh_degree=0, shs=shs)
+    b = hip_runner.run_hip(dict(base, cov3D_precomp=cov, scale_modifier=1.0), (gc, gd, ga))
+    dcov_fix = torch.tensor(b["grads"]["cov3D_precomp"]).double() * k ** 2     # dL / d(fixture's cov6)
+    want_rot = torch.einsum("nj,njk->nk", dcov_fix, torch.tensor(g["jac_rot_raw"]).double())
+    want_logs = torch.einsum("nj,njk->nk", dcov_fix, torch.tensor(g["jac_scales"]).double()) * torch.tensor(g["scales"]).double()
+    # the raw route: log-scales, the fixture's UN-normalised quaternions, opacity logits, _features_dc / _features_rest
+    t = lambda x: x.to(dev).float().contiguous().requires_grad_(True)
+    xyz, dc, rest = t(sc["means3D"]), t(shs[:, :1]), t(shs[:, 1:])
+    op, logs, rot = t(torch.logit(sc["opacities"].double()).float()), t(torch.log(scales.double()).float()), t(torch.tensor(g["rot_raw"]))
+    st = R_.GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=float(sc["tanfovx"]), tanfovy=float(sc["tanfovy"]),
+                                          bg=torch.zeros(3, device=dev), scale_modifier=smod, viewmatrix=sc["viewmatrix"].to(dev),
+                                          projmatrix=sc["projmatrix"].to(dev), sh_degree=0, campos=sc["campos"].to(dev), prefiltered=False, debug=False)
+    m2d = torch.zeros(n, 3, device=dev, requires_grad=True)
+    color, radii, depth, alpha = R_.rasterize_gaussians_raw(xyz, m2d, dc, rest, op, logs, rot, st)[:4]
+    d = np.abs(color.detach().cpu().numpy() - b["fwd"][0])
+    assert (d > 1e-5).mean() < 2e-3 and d.max() < 5e-3       # float32-rounded covariance: equal up to rare alpha-cut flips
+    ((color * torch.from_numpy(gc).to(dev)).sum() + (depth[0] * torch.from_numpy(gd).to(dev)).sum() + (alpha[0] * torch.from_numpy(ga).to(dev)).sum()).backward()
+    rel = lambda a, r: float((a.double().cpu() - r).norm() / r.norm())
+    e_rot, e_logs = rel(rot.grad, want_rot), rel(logs.grad, want_logs)
+    print(f"raw-parameter backward vs the reference's Jacobians: d rot_raw {e_rot:.2e}, d log-scale {e_logs:.2e}")
+    assert float(want_rot.abs().max()) > 0 and float(want_logs.abs().max()) > 0
+    # (the two routes render from covariances that differ in the last bit of binary32, and the fixture's Jacobians are binary32
+    #  autograd of the reference's code: 1e-4 relative, norm-wise, is the north_star's gradient bar)
+    assert e_rot < 1e-4 and e_logs < 1e-4, (e_rot, e_logs)
+    # the gradient of a raw quaternion is orthogonal to it (normalisation removes the radial direction): a property of the reference's chain
+    radial = (rot.grad.double().cpu() * torch.tensor(g["rot_raw"]).double()).sum(1).abs().max() / rot.grad.double().abs().max().cpu()
+    assert float(radial) < 1e-5
 
 
 def test_models_of_different_size_alternate_without_overflow_reruns():

@@ -144,10 +144,21 @@ def gen_cov3d(out):
         cov = strip_symmetric(L @ L.transpose(1, 2))
         w = torch.randn(N, 6, generator=g)
         (cov * w).sum().backward()
+        # round 6: the full Jacobians of the six packed entries, one autograd pass of the reference's construction per entry --
+        # d cov6[j] / d scales [N,6,3] and d cov6[j] / d rot_raw [N,6,4] (through build_rotation's internal normalisation,
+        # general_utils.py:77-79) -- so that a GPU test can chain ANY dL/dcov6 (the render's) to the raw parameters the
+        # reference's way and hold the kernels' raw-parameter backward to it
+        jac_s, jac_q = [], []
+        for j in range(6):
+            s2, q2 = s.detach().clone().requires_grad_(True), q_raw.detach().clone().requires_grad_(True)
+            L2 = build_scaling_rotation(mod * s2, q2)
+            strip_symmetric(L2 @ L2.transpose(1, 2))[:, j].sum().backward()
+            jac_s.append(s2.grad.clone())
+            jac_q.append(q2.grad.clone())
     qn = torch.nn.functional.normalize(q_raw.detach())
     np.savez_compressed(os.path.join(out, "cov3d.npz"), scales=t2n(s), rot_raw=t2n(q_raw), rot_unit=t2n(qn),
                         scale_modifier=np.float32(mod), cov=t2n(cov), w=t2n(w), dscales=t2n(s.grad),
-                        drot_raw=t2n(q_raw.grad))
+                        drot_raw=t2n(q_raw.grad), jac_scales=t2n(torch.stack(jac_s, 1)), jac_rot_raw=t2n(torch.stack(jac_q, 1)))
 
 
 def gen_camera(out):
@@ -270,12 +281,16 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
     ap.add_argument("--only-oracle", action="store_true", help="regenerate the self-generated oracle_*.npz only (no reference needed)")
+    ap.add_argument("--only-cov3d", action="store_true", help="regenerate cov3d.npz only (needs the reference)")
     args = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     if args.only_oracle:
         gen_oracle(OUT)
         return
     captured = install_shim(args.ref)
+    if args.only_cov3d:
+        gen_cov3d(OUT)
+        return
     gen_sh(OUT)
     gen_cov3d(OUT)
     gen_camera(OUT)
