@@ -657,10 +657,22 @@ struct ZeroJobs {
 
 // one workgroup of NTHR threads: exclusive scan of block_sums[nb] in place; total (64-bit) -> *total_out and, when
 // host_out is given, into pinned host memory (device-visible): the count reaches the host without a copy launch
+// late_out (round 6): with early R the host has read its count -- and the sorts' give-up counter -- from the rider on the
+// depth sort's FIRST kernel, before this forward's look-backs ran.  The scan still reports what it saw, into spare words of the same
+// pinned slot: {total, sequence, give-ups} at late_out[0..2]; the host compares them with the early values the next time it takes the
+// slot (or enters gsr_backward) and fails loudly on a mismatch (late_check).
+__device__ __forceinline__ void scan_report_late(unsigned long long* late_out, unsigned long long all, unsigned long long seq)
+{
+    __atomic_store_n(late_out, all, __ATOMIC_RELAXED);
+    __atomic_store_n(late_out + 2, (unsigned long long)g_onesweep_giveups, __ATOMIC_RELAXED);
+    __threadfence_system();
+    __atomic_store_n(late_out + 1, seq, __ATOMIC_RELAXED);
+    __threadfence_system();
+}
 template <int NTHR>
 __device__ __forceinline__ void block_scan_body(uint32_t* block_sums, int nb, unsigned long long* total_out, const ZeroJobs& zj,
                                                 unsigned long long* host_out, unsigned long long host_seq, unsigned long long* s_wsum /*[NTHR/64]*/,
-                                                const unsigned int* window_overflow = nullptr)
+                                                const unsigned int* window_overflow = nullptr, unsigned long long* late_out = nullptr)
 {
     constexpr int NWV = NTHR / 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -701,6 +713,7 @@ __device__ __forceinline__ void block_scan_body(uint32_t* block_sums, int nb, un
             __atomic_store_n(host_out + 1, host_seq, __ATOMIC_RELAXED);
             __threadfence_system();
         }
+        if (late_out) scan_report_late(late_out, all, host_seq);
     }
 }
 
@@ -750,7 +763,10 @@ struct BlendBalance {       // kernel-argument bundle; hdr == nullptr: off
 // by ~1e-4..1e-3 per step and the entry follows it (the stored pose is replaced on every hit); two frames closer than `tol` to each other
 // share an entry, which is harmless: their visit counts are as correlated as one frame's with itself a few steps later.
 // Every builder workgroup decides for itself (they cannot synchronise); the decisions may differ when another stream touches the cache
-// in between -- each XCD's slice of perm carries its own valid flag, so any mix is still a permutation per XCD.
+// in between -- or when workgroup 0 of THIS launch, which keeps the books, has already rewritten the entry's key / pose while another
+// builder is still reading them (an unordered read of words that only ever hold a former or a new pose: the reader takes the entry or
+// misses it) -- each XCD's slice of perm carries its own valid flag, so any mix is still a permutation per XCD: speed, never the image.
+// (The header and the cost tables are cleared synchronously when they are allocated, so no word of them is ever uninitialised.)
 __device__ __forceinline__ unsigned long long view_id_key(long long id)
 {
     unsigned long long h = 1469598103934665603ull ^ (unsigned long long)id;
@@ -865,10 +881,10 @@ __global__ __launch_bounds__(kEmitThreads) void k_tile_counts(int N, const uint3
 //  coherent loads by 256 threads are a long latency chain; the single-workgroup launch below stays)
 __global__ __launch_bounds__(1024) void k_block_scan(uint32_t* __restrict__ block_sums, int nb, unsigned long long* __restrict__ total_out,
                                                      ZeroJobs zj, unsigned long long* __restrict__ host_out, unsigned long long host_seq,
-                                                     const unsigned int* __restrict__ window_overflow)
+                                                     const unsigned int* __restrict__ window_overflow, unsigned long long* __restrict__ late_out = nullptr)
 {
     __shared__ unsigned long long s_wsum[16];
-    block_scan_body<1024>(block_sums, nb, total_out, zj, host_out, host_seq, s_wsum, window_overflow);
+    block_scan_body<1024>(block_sums, nb, total_out, zj, host_out, host_seq, s_wsum, window_overflow, late_out);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1229,7 +1245,7 @@ __global__ __launch_bounds__(256) void k_chunk_scan1(DirectBin db)
 constexpr int kDbMaxGroups = 64;
 __global__ __launch_bounds__(256) void k_chunk_scan2(DirectBin db, unsigned long long* __restrict__ total_out, ZeroJobs zj,
                                                      unsigned long long* __restrict__ host_out, unsigned long long host_seq,
-                                                     const unsigned int* __restrict__ window_overflow)
+                                                     const unsigned int* __restrict__ window_overflow, unsigned long long* __restrict__ late_out = nullptr)
 {
     __shared__ unsigned long long s_lo[4], s_all[4];
     __shared__ uint32_t s_w[4];
@@ -1284,6 +1300,7 @@ __global__ __launch_bounds__(256) void k_chunk_scan2(DirectBin db, unsigned long
             __atomic_store_n(host_out + 1, host_seq, __ATOMIC_RELAXED);
             __threadfence_system();
         }
+        if (late_out) scan_report_late(late_out, all, host_seq);
     }
 }
 
@@ -3813,7 +3830,10 @@ static std::vector<ViewCostCache> g_view_costs;   // guarded by g_state_mutex
 static std::map<std::tuple<int, int, int, int>, bool> g_full_depth_sort;   // callers whose depths left the 27-bit window once: four 8-bit passes from then on
 
 struct PinSlot { unsigned long long* host = nullptr; unsigned long long* dev = nullptr; hipEvent_t ev = nullptr; bool busy = false;
-                 unsigned long long seq = 0; };   // seq: number of the slot's last use; the scan kernel echoes it behind the count
+                 unsigned long long seq = 0;      // seq: number of the slot's last use; the scan kernel echoes it behind the count
+                 // early R: what the host took from the rider, to be held against the scan's own report (words 4..6 of the slot) the next
+                 // time the slot is taken or gsr_backward is entered (late_check)
+                 bool pending = false; unsigned long long pending_seq = 0, pending_R = 0, pending_giveups = 0; };
 static std::mutex g_state_mutex;
 static std::map<int, std::vector<PinSlot*>> g_pin_slots;                     // device -> slots
 static std::map<std::tuple<int, int, int, int>, uint64_t> g_hints;         // (device, W, H, bucket of N) -> capacity
@@ -3861,9 +3881,34 @@ static PinSlot* acquire_pin_slot(int dev)
         hipHostGetDevicePointer((void**)&s->dev, s->host, 0) != hipSuccess ||
         hipEventCreateWithFlags(&s->ev, hipEventDisableTiming) != hipSuccess) { delete s; return nullptr; }
     s->host[0] = 0; s->host[1] = 0;
+    for (int q = 4; q < 8; q++) s->host[q] = 0;
     s->busy = true;
     v.push_back(s);
     return s;
+}
+static std::atomic<long long> g_late_checks{0}, g_late_mismatches{0};
+static int g_debug_late_bias = 0;
+// The scan's late report of a forward that took its count early (scan_report_late).  wait: poll for it (the slot is about to be
+// reused -- in a training loop the report arrived a backward ago; a back-to-back forward waits for its predecessor's scan, which runs
+// long before that forward's blend ends, so the device stays fed).  Returns 0 = nothing pending / not there yet / consistent; 1 = the
+// early count and the scan's total differ, or a sort look-back gave up during that forward.
+static int late_check(PinSlot* s, bool wait, unsigned long long* got_total, unsigned long long* want_total)
+{
+    if (!s->pending) return 0;
+    volatile unsigned long long* hp = s->host;
+    if (hp[5] != s->pending_seq) {
+        if (!wait) return 0;
+        const auto limit = std::chrono::steady_clock::now() + std::chrono::milliseconds(200);
+        while (hp[5] != s->pending_seq && std::chrono::steady_clock::now() < limit) cpu_relax();
+        if (hp[5] != s->pending_seq) { (void)hipDeviceSynchronize(); }
+        if (hp[5] != s->pending_seq) { s->pending = false; return 0; }   // (the forward never reached its scan: it failed, and said so)
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    s->pending = false;
+    g_late_checks++;
+    *got_total = hp[4]; *want_total = s->pending_R;
+    if (hp[4] != s->pending_R || hp[6] != s->pending_giveups) { g_late_mismatches++; return 1; }
+    return 0;
 }
 struct PinLease {   // releases the slot on every exit path
     PinSlot* s;
@@ -4019,6 +4064,7 @@ int gsr_set_option(const char* name, int value)
     if (!strcmp(name, "tile_map")) { if (value < 0 || value > 2) return GSR_ERR_ARG; g_tile_map = value; return GSR_OK; }
     if (!strcmp(name, "blend_balance")) { g_blend_balance = value ? 1 : 0; return GSR_OK; }
     if (!strcmp(name, "early_r")) { g_early_r = value ? 1 : 0; return GSR_OK; }
+    if (!strcmp(name, "debug_late_bias")) { g_debug_late_bias = value; return GSR_OK; }   // tests: added ONCE to the early count a forward remembers for its late check
     if (!strcmp(name, "tile_sort")) { if (value < 0 || value > 2) return GSR_ERR_ARG; g_tile_sort = value; return GSR_OK; }
     if (!strcmp(name, "tile_sort_max_avg")) { if (value < 0) return GSR_ERR_ARG; g_tile_sort_max_avg = value; return GSR_OK; }
     if (!strcmp(name, "direct_slab_tiles")) { if (value < 0) return GSR_ERR_ARG; g_db_slab_tiles = value; return GSR_OK; }
@@ -4407,6 +4453,14 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
     const unsigned int* window_overflow_ = tsort ? nullptr : window_overflow;
     PinLease pin(acquire_pin_slot(dev_id));
     if (!pin.s) return fail(GSR_ERR_HIP, "pinned read-back slot allocation failed%s");
+    {   // the slot's previous forward took its count early: hold it against what that forward's scan reported (scan_report_late)
+        unsigned long long got = 0, want = 0;
+        if (late_check(pin.s, true, &got, &want)) {
+            char msg[200];
+            snprintf(msg, sizeof msg, "a PREVIOUS forward's binning was invalid: early instance count %llu, its scan counted %llu (or a sort look-back gave up)%%s", want, got);
+            return fail(GSR_ERR_HIP, msg);
+        }
+    }
     OsRider rider = {};
     if (early_r) { rider.parts = early_parts; rider.nparts = (uint32_t)grid; rider.host = pin.s->dev; rider.seq = ++pin.s->seq; }
     ts_rec = ntiles; ts_dkey = dkey;
@@ -4421,18 +4475,19 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
     auto launch_counts = [&](const BlendBalance& bal, const ZeroJobs& zjobs, const unsigned int* wo, unsigned long long seq, bool publish = true) {
         TileRec* srec = reinterpret_cast<TileRec*>(fs + L.srec);
         unsigned long long* const host_slot = publish ? pin.s->dev : nullptr;   // (early R: the histogram kernel already told the host)
+        unsigned long long* const late_slot = publish ? nullptr : pin.s->dev + 4;  // (... and the scan reports behind it: scan_report_late)
         if (direct) {
             // (tile-sort route: index order, no sorted copy of the records, and -- no depth sort to ride on -- the rider that publishes R)
             hipLaunchKernelGGL(k_chunk_counts, dim3(db.NC + (bal.hdr ? 8 : 0)), dim3(kEmitThreads), (size_t)2 * db.Tp, st, db, W, H,
                                tiles_x, tiles_y, sorted_gid, ntiles, splat, tsort ? (TileRec*)nullptr : srec, bal,
                                (tsort && early_r && !publish) ? rider : OsRider{});
             hipLaunchKernelGGL(k_chunk_scan1, dim3((db.Tp + 255) / 256, db.G), dim3(256), 0, st, db);
-            hipLaunchKernelGGL(k_chunk_scan2, dim3((db.Tp + 255) / 256), dim3(256), 0, st, db, total, zjobs, host_slot, seq, wo);
+            hipLaunchKernelGGL(k_chunk_scan2, dim3((db.Tp + 255) / 256), dim3(256), 0, st, db, total, zjobs, host_slot, seq, wo, late_slot);
         } else {
             hipLaunchKernelGGL(k_tile_counts, dim3(nb + (bal.hdr ? 8 : 0)), dim3(kEmitThreads), 0, st, N, sorted_gid, ntiles, block_sums,
                                tsort ? (TileRec*)nullptr : srec, bal, nb, (tsort && early_r && !publish) ? rider : OsRider{});
             // the scan writes R straight into the pinned slot (device-visible host memory): no copy launch behind it
-            hipLaunchKernelGGL(k_block_scan, dim3(1), dim3(1024), 0, st, block_sums, nb, total, zjobs, host_slot, seq, wo);
+            hipLaunchKernelGGL(k_block_scan, dim3(1), dim3(1024), 0, st, block_sums, nb, total, zjobs, host_slot, seq, wo, late_slot);
         }
     };
     {
@@ -4456,8 +4511,16 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
                         if (c.dev == dev_id && c.W == W && c.H == H && c.map == opt_map && c.items == items) mem = c.mem;
                     if (!mem && g_view_costs.size() < 16) {
                         if (hipMalloc((void**)&mem, hdr_bytes + (size_t)kVcEntries * items * sizeof(uint16_t)) == hipSuccess) {
-                            hipMemsetAsync(mem, 0, hdr_bytes, st);   // (a reader on another stream that beats this clear sees garbage hashes: a miss)
-                            g_view_costs.push_back({dev_id, W, H, opt_map, items, mem});
+                            // cleared SYNCHRONOUSLY, once per (device, frame geometry), before anybody can look at it (with
+                            // pose-keyed entries an uncleared header is not "garbage hashes = a miss" -- a key that reads 2 with pose
+                            // floats inside the tolerance would be a hit on garbage cost tables); a failed clear = no cache
+                            if (hipMemset(mem, 0, hdr_bytes + (size_t)kVcEntries * items * sizeof(uint16_t)) == hipSuccess) {
+                                g_view_costs.push_back({dev_id, W, H, opt_map, items, mem});
+                            } else {
+                                (void)hipGetLastError();
+                                (void)hipFree(mem);
+                                mem = nullptr;
+                            }
                         } else {
                             (void)hipGetLastError();
                             mem = nullptr;
@@ -4483,7 +4546,7 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
             zj.p[0] = nullptr; zj.words[0] = 0u;   // (the scatter writes every tile's range; there is no sort scratch)
             zj.p[2] = nullptr; zj.words[2] = 0u;
         }
-        if (early_r) launch_counts(bb, zj, window_overflow_, 0ull, false);
+        if (early_r) launch_counts(bb, zj, window_overflow_, rider.seq, false);
         else launch_counts(bb, zj, window_overflow_, ++pin.s->seq);
     }
     GSR_HIP(hipGetLastError());
@@ -4539,6 +4602,10 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
         }
         if (fresh)
             return fail(GSR_ERR_HIP, "a radix-sort look-back gave up (status words overwritten?): the binning of this or the previous forward is invalid%s");
+        if (early_r) {   // R and the give-up counter came from the rider, in front of this forward's own sorts: checked again behind them
+            pin.s->pending = true; pin.s->pending_seq = rider.seq; pin.s->pending_R = R + (unsigned long long)g_debug_late_bias; pin.s->pending_giveups = gv;
+            g_debug_late_bias = 0;
+        }
     }
     bool resorted = false;
     if (wide_depth && static_cast<volatile unsigned long long*>(pin.s->host)[3] != 0ull) {
@@ -4617,6 +4684,24 @@ int gsr_backward(const GsrBackwardArgs* a, void* stream_)
     rc = batch_dev(a->batch, N, H, bt);
     if (rc) return rc;
     const int NB = bt.B;
+    {   // early R: a forward's count is held against its scan's own report as soon as that has arrived (no waiting here)
+        int dev_id = 0;
+        (void)hipGetDevice(&dev_id);
+        unsigned long long got = 0, want = 0;
+        bool bad = false;
+        {
+            std::lock_guard<std::mutex> lk(g_state_mutex);
+            auto it = g_pin_slots.find(dev_id);
+            if (it != g_pin_slots.end())
+                for (PinSlot* s : it->second)
+                    if (!s->busy && late_check(s, false, &got, &want)) { bad = true; break; }
+        }
+        if (bad) {
+            char msg[200];
+            snprintf(msg, sizeof msg, "a forward's binning was invalid: early instance count %llu, its scan counted %llu (or a sort look-back gave up)%%s", want, got);
+            return fail(GSR_ERR_HIP, msg);
+        }
+    }
     // the forward's kernel variant / tile map / checkpoint layout travel with its output (forward_flags); a caller of the
     // round-1 ABI (flags 0) gets the process-wide options as before
     int f_ppt = g_blend_ppt ? g_blend_ppt : 7, f_map = g_tile_map, f_ckpt = g_ckpt_first;
@@ -4910,6 +4995,8 @@ int64_t gsr_get_counter(const char* name)
 {
     if (!name) return -1;
     if (!strcmp(name, "spec_overflows")) return g_spec_overflows.load();
+    if (!strcmp(name, "late_checks")) return g_late_checks.load();
+    if (!strcmp(name, "late_mismatches")) return g_late_mismatches.load();
     if (!strcmp(name, "depth_window_resorts")) return g_depth_window_resorts.load();
     if (!strcmp(name, "blend_bwd_resident")) return blend_bwd_resident(0);
     if (!strcmp(name, "spec_forwards")) return g_spec_forwards.load();

@@ -309,7 +309,12 @@ size_t gsr_struct_bytes(int32_t which); /* 0 GsrForwardArgs, 1 GsrBackwardArgs, 
  *                          0 = only models above 262 144 Gaussians.  Same order either way (a depth beyond the window is detected
  *                          and sorted again on all 32 bits)
  *   "early_r"              1 (default) = the host learns the instance count from the preprocess's per-block sums, published by
- *                          the depth sort's first kernel, instead of from the scan behind sort + tile counts; 0 = from the scan
+ *                          the depth sort's first kernel, instead of from the scan behind sort + tile counts; 0 = from the scan.
+ *                          The scan still reports its own total and the sorts' give-up counter into spare words of the pinned slot;
+ *                          the next gsr_forward that takes the slot (waiting for the report if it must) and every gsr_backward (if
+ *                          it has arrived) hold the early values against them and FAIL (GSR_ERR_HIP) on a difference: a forward
+ *                          whose count or sort went wrong is reported by the next call into the library, not never
+ *                          (counters "late_checks", "late_mismatches"; "debug_late_bias": tests, falsifies the next remembered count)
  *   "view_pose_tol_e6"     (default 2000 = 2e-3) without a view id a render belongs to the cached frame whose view matrix and
  *                          points_transform are within this, x 1e-6, of its own in every entry (the nearest such frame)
  *   "tile_map"             how tiles are dealt to the eight XCDs: 2 (default) = 2x2 blocks of tiles round-robin, 1 = single
