@@ -76,7 +76,7 @@ EXPORTS = [
     "gsr_knn_scratch_bytes", "gsr_knn_mean_dist2", "gsr_get_counter", "gsr_debug_read_binning", "gsr_debug_direct_binning_geometry", "gsr_debug_view_cache_stats", "gsr_prepared_bytes",
     "gsr_prepare_supported", "gsr_prepared_radii_offset", "gsr_stream_copy", "gsr_image_bytes_batched",
     "gsr_masked_max", "gsr_densify_stats_add", "gsr_psnr_scratch_bytes", "gsr_psnr",
-    "gsr_loss_workspace_bytes_batched", "gsr_loss_forward_batched", "gsr_loss_backward_batched", "gsr_loss_forward_terms", "gsr_pose_grad", "gsr_struct_bytes",
+    "gsr_loss_workspace_bytes_batched", "gsr_loss_forward_batched", "gsr_loss_backward_batched", "gsr_loss_forward_terms", "gsr_pose_grad", "gsr_struct_bytes", "gsr_debug_list_cut_stats",
 ]
 
 _lib = None
@@ -157,6 +157,8 @@ def load():
     lib.gsr_debug_direct_binning_geometry.argtypes = [C.c_int32, C.c_int32, C.POINTER(C.c_int64)]
     lib.gsr_debug_view_cache_stats.restype = C.c_int
     lib.gsr_debug_view_cache_stats.argtypes = [C.c_int32, C.c_int32, C.POINTER(C.c_int64)]
+    lib.gsr_debug_list_cut_stats.restype = C.c_int
+    lib.gsr_debug_list_cut_stats.argtypes = [C.c_int32, C.c_int32, C.POINTER(C.c_int64)]
     lib.gsr_debug_read_binning.restype = C.c_int
     lib.gsr_debug_read_binning.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     for fn in ["gsr_sort_pairs_u32", "gsr_sort_pairs_u16"]:

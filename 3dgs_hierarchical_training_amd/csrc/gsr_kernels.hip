@@ -89,9 +89,9 @@ static inline void cpu_relax()
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // Optional per-kernel timing with HIP events on the caller's stream (bench.py roofline leg).
-enum ProfId { P_PRE_FWD, P_SORT_DEPTH, P_SCAN, P_EMIT, P_SORT_TILE, P_RANGES, P_BLEND_FWD, P_BLEND_BWD, P_PRE_BWD, P_COUNT };
+enum ProfId { P_PRE_FWD, P_SORT_DEPTH, P_SCAN, P_EMIT, P_SORT_TILE, P_RANGES, P_BLEND_FWD, P_BLEND_BWD, P_PRE_BWD, P_CUT_REPAIR, P_COUNT };
 static const char* kProfNames[P_COUNT] = {"preprocess_fwd", "sort_depth", "scan", "emit", "sort_tile", "ranges",
-                                          "blend_fwd", "blend_bwd", "preprocess_bwd"};
+                                          "blend_fwd", "blend_bwd", "preprocess_bwd", "cut_repair"};
 static int g_profile = 0;
 static std::atomic<unsigned> g_profile_tick{0};   // mode 3: every third launch of the forward blend is timed
 struct ProfPair { hipEvent_t a, b; };
@@ -810,6 +810,7 @@ __device__ void balance_build(const BlendBalance bb, const int x)
         bb.hdr->stamp[rec] = now; bb.hdr->clock = now;
         bb.hdr->pad[0] += 1u; bb.hdr->pad[1] += e >= 0 ? 1u : 0u;      // lookups / hits (gsr_debug_view_cache_stats)
         bb.cur[0] = (uint32_t)rec;
+        bb.cur[9] = e >= 0 ? 1u : 0u;      // (the list cut asks builder 0 alone: the keeper of the books decides which entry's keys count)
     }
     if (tid == 0) bb.cur[1 + x] = e >= 0 ? 1u : 0u;
     if (e < 0) return;          // first render of this view: identity placement (the blend ignores perm)
@@ -1099,6 +1100,64 @@ struct DirectBin {
     uint32_t* bsum;     // [G][slabs] instances per (group, 256-tile slab)
 };
 
+// ------------------------------------------------------------------------------------------------
+// Lists cut where the tile stopped last time (round 6).  At the headline the forward blends stage R_eff = 0.75 M of the R = 4.5 M
+// instances the binning places (17 %; 4 % at 4 M Gaussians): a tile whose 256 pixels saturate after the nearest few hundred splats
+// never reads the rest of its list.  The frame is recognised anyway (the view-cost cache of the balanced placement), so every tile
+// remembers the DEPTH up to which its four waves staged instances at the frame's previous render, and the scatter -- the expensive
+// half of the direct binning -- leaves out what lies behind it:
+//   * nothing about the LAYOUT changes: counts, scans, tile bases and R are the full ones, every pair keeps the position the full
+//     binning gives it; a tile's list is simply only written up to a chunk boundary of the depth order (`chunk[t]` = the last chunk
+//     tile t keeps: the first chunk that starts behind the remembered depth x (1 + margin)), and the blends are handed the END OF
+//     THE VALID PREFIX as the tile's range end (`tend[t]`, from the chunk tables: no counting).  Chunks behind every tile's cut do
+//     not run at all; chunks in front of every cut run unchanged; a chunk in between masks the closed tiles' bits out of its
+//     records' tile masks (k_chunk_scatter CUT: one funnel shift per rect row against a bitmap of the open tiles).
+//   * the speculation is verified ON THE DEVICE and repaired there: a blend wave that reaches the end of a cut list with a live
+//     pixel flags its tile; two more launches -- the same scatter over the chunks behind the flagged tiles' cuts, for those tiles
+//     only, and the same blend over the flagged tiles with their full range -- follow every cut render and find nothing to do
+//     (a word read per workgroup) unless a tile was flagged.  The host never learns of it and never waits: image, radii, lists'
+//     valid prefixes, checkpoints and gradients are those of the full binning, bit for bit, by construction -- the instances a
+//     pixel blends are the same instances in the same order (tests/test_gpu_listcut.py).
+// What changes is what lies in the list buffer BEHIND a tile's valid prefix (stale words nobody reads) and ranges[t].y.
+// Off (`"list_cut"` 0, a frame seen for the first time, another model under the same frame id, the tile-sort / sort / slabbed /
+// batched routes): `chunk[t]` = the last chunk for every tile and the code below is the round-5 code.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t kCutOpenKey = 0xffffffffu;   // a tile that reached the end of its FULL list with a live pixel: never cut
+struct ListCut {            // kernel-argument bundle; key == nullptr: off
+    uint32_t* key;          // [kVcEntries][T] (cache): depth key up to which tile t's waves staged at the entry's last render
+    uint32_t* owner_n;      // [kVcEntries] (cache): the model size those keys belong to (another model under the same frame: no cut)
+    uint32_t* stats;        // [8] (cache): [0] cut renders, [1] renders that needed a repair, [2] tiles repaired, [3] chunks skipped (sum)
+    const uint32_t* cur;    // the placement's per-call words: [0] the frame's cache entry, [9] the entry was a hit (written by k_chunk_counts' builder 0)
+    uint16_t* chunk;        // [Tp] per call: last chunk of the depth order tile t keeps
+    uint32_t* tend;         // [Tp] per call: end of tile t's valid prefix (absolute list position)
+    uint32_t* flag;         // [Tp] per call: tile t ran out of its cut list with a live pixel
+    uint32_t* ctl;          // [8] per call: [0] max, [1] min of chunk[] over the tiles, [2] tiles flagged
+    uint32_t* bkey;         // [NC] per call: depth key of the first Gaussian of every chunk
+    const uint32_t* skey;   // the depth keys in depth order
+    const uint32_t* tbase;  // [T + 1] the tile bases of the FULL binning (DirectBin::tbase)
+    float margin;           // relative slack on the remembered depth
+    int enable;             // 0: tables are written for "everything kept" (the caller asked for full lists on a route that can cut)
+};
+
+// bits [L, L + n) of a linear bitmap (n <= 32; one word of padding behind the last)
+__device__ __forceinline__ uint32_t bitmap_extract(const unsigned long long* bm, uint32_t L, uint32_t n)
+{
+    const uint32_t w = L >> 6, sh = L & 63u;
+    const unsigned long long lo = bm[w], hi = bm[w + 1];
+    const unsigned long long v = sh ? ((lo >> sh) | (hi << (64u - sh))) : lo;
+    return (uint32_t)v & (n >= 32u ? 0xffffffffu : ((1u << n) - 1u));
+}
+// the bits of a small rect's tile mask whose tiles are open
+__device__ __forceinline__ uint32_t open_tiles_mask(const TileRec& r, int tiles_x, const unsigned long long* s_open)
+{
+    const uint32_t ww = (r.rect >> 24) & 63u, rx0 = r.rect & 0xfffu, ry0 = (r.rect >> 12) & 0xfffu;
+    uint32_t open = 0u;
+    if (ww == 0u) return 0u;
+    for (uint32_t m = r.mask, row = 0u, sh = 0u; (m >> sh) != 0u && sh < 32u; row++, sh += ww)
+        open |= bitmap_extract(s_open, (ry0 + row) * (uint32_t)tiles_x + rx0, min(ww, 32u - sh)) << sh;
+    return open;
+}
+
 // all 64 lanes walk the candidate tiles of ONE large rect (more than 32 tiles: no mask in its TileRec), 64 at a time, in the
 // emission's order (row-major over the tight rect, the exact test per tile): f(accepted, tile key) on every lane, every round
 template <typename F>
@@ -1171,10 +1230,14 @@ __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x)
 __global__ __launch_bounds__(kEmitThreads) void k_chunk_counts(DirectBin db, int W, int H, int tiles_x, int tiles_y,
                                                                const uint32_t* __restrict__ sorted_gid, const TileRec* __restrict__ tilerec,
                                                                const Splat* __restrict__ splat, TileRec* __restrict__ sorted_rec, BlendBalance bb,
-                                                               OsRider rider = OsRider{})
+                                                               OsRider rider = OsRider{}, ListCut cut = ListCut{})
 {
     const int nbuild = bb.hdr ? 8 : 0, c = (int)blockIdx.x - nbuild;
     if (c < 0) { balance_build(bb, (int)blockIdx.x); return; }
+    if (cut.key && threadIdx.x == 0) {     // list cut: where every chunk of the depth order starts, and this call's control words
+        cut.bkey[c] = cut.skey[(size_t)c * db.S];
+        if (c == 0) { cut.ctl[0] = 0u; cut.ctl[1] = 0xffffffffu; cut.ctl[2] = 0u; }
+    }
     if (rider.host && blockIdx.x == gridDim.x - 1) {   // (block-uniform)
         __shared__ unsigned long long s_r[2][16];
         onesweep_rider_publish(rider, s_r);
@@ -1245,9 +1308,13 @@ __global__ __launch_bounds__(256) void k_chunk_scan1(DirectBin db)
 constexpr int kDbMaxGroups = 64;
 __global__ __launch_bounds__(256) void k_chunk_scan2(DirectBin db, unsigned long long* __restrict__ total_out, ZeroJobs zj,
                                                      unsigned long long* __restrict__ host_out, unsigned long long host_seq,
-                                                     const unsigned int* __restrict__ window_overflow, unsigned long long* __restrict__ late_out = nullptr)
+                                                     const unsigned int* __restrict__ window_overflow, unsigned long long* __restrict__ late_out = nullptr,
+                                                     ListCut cut = ListCut{})
 {
+    extern __shared__ uint32_t s_bkey[];     // [NC] (list cut): the chunks' first depth keys
     __shared__ unsigned long long s_lo[4], s_all[4];
+    if (cut.key)
+        for (int i = threadIdx.x; i < db.NC; i += 256) s_bkey[i] = cut.bkey[i];
     __shared__ uint32_t s_w[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int slab = (int)blockIdx.x, nslab = (int)gridDim.x, t = slab * 256 + tid;
@@ -1288,7 +1355,41 @@ __global__ __launch_bounds__(256) void k_chunk_scan2(DirectBin db, unsigned long
 #pragma unroll
     for (int w = 0; w < 4; w++) add += w < wave ? s_w[w] : 0u;
     // (beyond 2^32 instances the host fails the call: positions only have to stay in bounds)
-    if (t < db.T) db.tbase[t] = (uint32_t)min(lo + add + inc - tot, 0xffffffffull);
+    const uint32_t base_t = (uint32_t)min(lo + add + inc - tot, 0xffffffffull);
+    if (t < db.T) db.tbase[t] = base_t;
+    if (cut.key) {
+        // the tile's cut: the last chunk that starts at or in front of (the depth its waves reached last time) x (1 + margin); the
+        // key is taken and reset -- this render's blends rebuild it with atomic maxima (blend_fwd_item)
+        uint32_t ck = (uint32_t)(db.NC - 1);
+        if (t < db.T) {
+            const uint32_t e = cut.cur[0] < (uint32_t)kVcEntries ? cut.cur[0] : 0u;
+            uint32_t* kp = cut.key + (size_t)e * db.T + t;
+            const bool use = cut.enable && cut.cur[9] != 0u && cut.owner_n[e] == (uint32_t)db.N;
+            const uint32_t k = *kp;
+            *kp = 0u;
+            if (use && k != kCutOpenKey && k != 0u) {
+                const float d = __uint_as_float(k);
+                const uint32_t kc = __float_as_uint(fmaf(d, cut.margin, d));
+                int a = 0, b = db.NC;            // chunks [0, a) start at or in front of kc
+                while (a < b) { const int m = (a + b) >> 1; if (s_bkey[m] <= kc) a = m + 1; else b = m; }
+                ck = (uint32_t)max(a - 1, 0);
+            }
+            cut.chunk[t] = (uint16_t)ck;
+            const uint32_t c1 = ck + 1u;
+            const uint32_t kept = c1 >= (uint32_t)db.NC ? tot : db.GT[(size_t)(c1 / (uint32_t)db.Cg) * db.Tp + t] + (uint32_t)db.M[(size_t)c1 * db.Tp + t];
+            cut.tend[t] = base_t + kept;
+            cut.flag[t] = 0u;
+        }
+        // the extremes over the frame: chunks behind the largest do not run, chunks up to the smallest run as they always did
+        uint32_t mx = t < db.T ? ck : 0u, mn = t < db.T ? ck : 0xffffffffu;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { mx = max(mx, (uint32_t)__shfl_xor((int)mx, off, 64)); mn = min(mn, (uint32_t)__shfl_xor((int)mn, off, 64)); }
+        if (lane == 0) { atomicMax(&cut.ctl[0], mx); atomicMin(&cut.ctl[1], mn); }
+        if (slab == 0 && tid == 0) {
+            const uint32_t e = cut.cur[0] < (uint32_t)kVcEntries ? cut.cur[0] : 0u;
+            cut.owner_n[e] = (uint32_t)db.N;
+        }
+    }
     if (slab == 0 && tid == 0) {
         db.tbase[db.T] = (uint32_t)min(all, 0xffffffffull);
         *total_out = all;
@@ -1334,28 +1435,47 @@ __device__ unsigned long long g_db_dbg[16];   // s_memtime ticks per part, summe
 // PAIRS (the tile-sort route, round 5): the chunks cut the Gaussians in index order (sorted_gid == nullptr, sorted_rec = the records where
 // the preprocess left them) and what is placed is the PAIR (depth key, Gaussian) -- eight bytes per store instead of four -- into
 // `pairs`; k_tile_sort orders every tile's pairs by key and writes the list.
-template <bool SLAB, bool PAIRS = false>
+// CUT (round 6, see ListCut): 1 = the cut pass -- chunks behind every tile's cut do not run, a chunk in front of every cut runs as
+// ever, one in between keeps only the pairs of tiles that are still open (their bits are masked out of the records' tile masks, and
+// everything downstream sees a record with fewer tiles) -- and the ranges end at the tiles' valid prefixes; 2 = the repair pass:
+// nothing unless a blend wave flagged a tile, then the chunks BEHIND the flagged tiles' cuts, for those tiles only, at the positions
+// the full binning gives them (the chunk tables are the full ones: a tile's kept and left-out pairs never share a chunk).
+template <bool SLAB, bool PAIRS = false, int CUT = 0>
 __global__ __launch_bounds__(64) void k_chunk_scatter(DirectBin db, int W, int H, int tiles_x, int tiles_y,
                                                       const uint32_t* __restrict__ sorted_gid, const TileRec* __restrict__ sorted_rec,
                                                       const Splat* __restrict__ splat, uint32_t* __restrict__ list, uint2* __restrict__ ranges,
-                                                      uint32_t cap, const uint32_t* __restrict__ dkey = nullptr, uint2* __restrict__ pairs = nullptr)
+                                                      uint32_t cap, const uint32_t* __restrict__ dkey = nullptr, uint2* __restrict__ pairs = nullptr,
+                                                      ListCut cut = ListCut{})
 {
+    static_assert(!CUT || (!SLAB && !PAIRS), "the list cut serves the plain direct binning");
     extern __shared__ unsigned long long s_dyn[];
     const int LT = SLAB ? db.Tsp : db.Tp;                                      // tiles this wave keeps tables for
     unsigned long long* const s_mask = s_dyn;                                  // [LT]
     uint32_t* const s_cnt = reinterpret_cast<uint32_t*>(s_dyn + LT);          // [LT]
     uint32_t* const s_pair = s_cnt + LT;                                       // [kDbPairs]
+    unsigned long long* const s_open = reinterpret_cast<unsigned long long*>(s_pair + kDbPairs);   // [LT / 64 + 2] (CUT): bit t = tile t is open for this chunk
     const int lane = threadIdx.x, b = (int)blockIdx.x;
+    if (CUT == 2 && cut.ctl[2] == 0u) return;     // the repair pass: no tile was flagged -- every wave of the launch leaves here
+    if (CUT == 2 && b == 0 && lane == 0) { cut.stats[1] += 1u; cut.stats[2] += cut.ctl[2]; }
     {   // the ranges: tile bases clipped to the list's capacity (an overflowing speculative launch is run again)
         const int t = b * 64 + lane;
         if (t < db.T) {
-            const uint32_t lo = min(db.tbase[t], cap), hi = min(db.tbase[t + 1], cap);
-            ranges[t] = hi > lo ? make_uint2(lo, hi) : make_uint2(0u, 0u);   // (an empty tile reads (0, 0), as on the sort route)
+            const uint32_t lo = min(db.tbase[t], cap), hi = min(CUT == 1 ? cut.tend[t] : db.tbase[t + 1], cap);
+            if (CUT != 2 || cut.flag[t]) ranges[t] = hi > lo ? make_uint2(lo, hi) : make_uint2(0u, 0u);   // (an empty tile reads (0, 0), as on the sort route)
+        }
+        if (CUT == 1 && b == 0 && lane == 0) {     // the books of the cut: whose keys these will be, and the counters
+            const uint32_t e = cut.cur[0] < (uint32_t)kVcEntries ? cut.cur[0] : 0u;
+            cut.owner_n[e] = (uint32_t)db.N;
+            cut.stats[0] += 1u;
+            cut.stats[3] += (uint32_t)(db.NC - 1) - min(cut.ctl[0], (uint32_t)(db.NC - 1));
         }
     }
     // XCD x = b & 7 owns the chunks [x per, (x + 1) per); a chunk's NS slab waves sit next to each other (they read the same records)
     const int per = (db.NC + 7) >> 3, kk = b >> 3, c = (b & 7) * per + (SLAB ? kk / db.NS : kk), slab = SLAB ? kk % db.NS : 0;
     if ((SLAB ? kk / db.NS : kk) >= per || c >= db.NC) return;
+    if (CUT == 1 && (uint32_t)c > cut.ctl[0]) return;     // behind every tile's cut
+    if (CUT == 2 && (uint32_t)c <= cut.ctl[1]) return;    // in front of every tile's cut: nothing was left out here
+    const bool mixed = CUT == 2 || (CUT == 1 && (uint32_t)c > cut.ctl[1]);   // (wave-uniform) some tiles are closed for this chunk
     const uint32_t t0 = SLAB ? (uint32_t)(slab * db.Ts) : 0u;                                   // first tile of the slab
     const uint32_t tn = SLAB ? (uint32_t)min(db.Ts, db.T - slab * db.Ts) : (uint32_t)db.T;       // tiles in it
     const int srow0 = slab * db.slab_rows, srow1 = srow0 + db.slab_rows;                         // its tile rows (SLAB)
@@ -1386,6 +1506,17 @@ __global__ __launch_bounds__(64) void k_chunk_scatter(DirectBin db, int W, int H
             }
         }
     }
+    if (CUT && mixed) {   // the open tiles of this chunk, one bit each, in tile order
+        for (int i0 = 0; i0 < LT; i0 += 64) {
+            const int i = i0 + lane;
+            bool op = false;
+            if (i < db.T) op = CUT == 1 ? (uint32_t)c <= (uint32_t)cut.chunk[i] : (cut.flag[i] != 0u && (uint32_t)c > (uint32_t)cut.chunk[i]);
+            const unsigned long long bits = __ballot(op);
+            if (lane == 0) s_open[i0 >> 6] = bits;
+        }
+        if (lane < 2) s_open[(LT >> 6) + lane] = 0ull;
+    }
+    auto tile_open = [&](uint32_t t) -> bool { return !(CUT && mixed) || ((s_open[t >> 6] >> (t & 63u)) & 1ull) != 0ull; };
     lds_order();
     DB_T(0);
     const unsigned long long me = 1ull << lane, lt = lanemask_lt();
@@ -1411,6 +1542,7 @@ __global__ __launch_bounds__(64) void k_chunk_scatter(DirectBin db, int W, int H
             const uint32_t below_hi = hi >= 32 ? 0xffffffffu : ((1u << hi) - 1u), below_lo = lo >= 32 ? 0xffffffffu : ((1u << lo) - 1u);
             r.mask &= below_hi & ~below_lo;
         }
+        if (CUT && mixed && !(r.rect & kTileRecBig)) r.mask &= open_tiles_mask(r, tiles_x, s_open);   // the closed tiles leave the record
         // A large rect (no mask in its record) is walked by all 64 lanes, once, and its accepted tiles go into the pair buffer like
         // everyone's; one of more tiles than the buffer holds ("huge") is walked three times instead, outside the buffer.
         const bool big = (r.rect & kTileRecBig) != 0u && r.mask != 0u, huge = big && (SLAB || r.mask > (uint32_t)kDbPairs);
@@ -1443,9 +1575,10 @@ __global__ __launch_bounds__(64) void k_chunk_scatter(DirectBin db, int W, int H
                 big_rect_tiles(s, rect, W, H, tiles_x, tiles_y, lane, [&](bool ok, uint32_t tg) {
                     const uint32_t t = tg - t0;          // (this branch only runs without slabs: t0 = 0)
                     const unsigned long long acc = __ballot(ok);
-                    if (ok) {
-                        if (with_or) atomicOr(&s_mask[t], 1ull << bl);
-                        if (in_run) s_pair[(o + (uint32_t)__popcll(acc & lt)) & (uint32_t)(kDbPairs - 1)] = (t << 6) | (uint32_t)bl;
+                    if (ok) {      // (a closed tile's slot of the pair buffer holds the "no pair" word: the record's count is the full one)
+                        const bool op = tile_open(t);
+                        if (with_or && op) atomicOr(&s_mask[t], 1ull << bl);
+                        if (in_run) s_pair[(o + (uint32_t)__popcll(acc & lt)) & (uint32_t)(kDbPairs - 1)] = op ? ((t << 6) | (uint32_t)bl) : 0xffffffffu;
                     }
                     o += (uint32_t)__popcll(acc);
                 });
@@ -1461,7 +1594,7 @@ __global__ __launch_bounds__(64) void k_chunk_scatter(DirectBin db, int W, int H
             const int bl = (int)__builtin_ctzll(bm);
             const uint32_t gg = (uint32_t)__builtin_amdgcn_readlane((int)g, bl), rect = (uint32_t)__builtin_amdgcn_readlane((int)r.rect, bl);
             const Splat s = splat[gg];
-            big_rect_tiles(s, rect, W, H, tiles_x, tiles_y, lane, [&](bool ok, uint32_t tg) { const uint32_t t = tg - t0; if (ok && t < tn) atomicOr(&s_mask[t], 1ull << bl); });
+            big_rect_tiles(s, rect, W, H, tiles_x, tiles_y, lane, [&](bool ok, uint32_t tg) { const uint32_t t = tg - t0; if (ok && t < tn && tile_open(t)) atomicOr(&s_mask[t], 1ull << bl); });
         }
         // the loads of the step after next have had a step and this owner loop to arrive; taken HERE, in front of this step's
         // scattered stores (a wait for a load is a wait for every store issued before it: vmcnt counts both)
@@ -1486,7 +1619,7 @@ __global__ __launch_bounds__(64) void k_chunk_scatter(DirectBin db, int W, int H
                     for (int q = 0; q < RN; q++) {
                         const bool v = 64u * q + (uint32_t)lane < left;
                         e[q] = v ? e[q] : 0xffffffffu;
-                        const uint32_t t = v ? e[q] >> 6 : 0u;
+                        const uint32_t t = e[q] != 0xffffffffu ? e[q] >> 6 : 0u;   // ("no pair": beyond the step's pairs, or a closed tile of a large rect)
                         go[q] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((e[q] & 63u) << 2), (int)g);   // (every lane: an owner's index is fetched from ITS lane)
                         if (PAIRS) ko[q] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((e[q] & 63u) << 2), (int)kd);
                         mk[q] = s_mask[t];
@@ -1521,7 +1654,7 @@ __global__ __launch_bounds__(64) void k_chunk_scatter(DirectBin db, int W, int H
             const Splat s = splat[gg];
             big_rect_tiles(s, rect, W, H, tiles_x, tiles_y, lane, [&](bool ok, uint32_t tg) {
                 const uint32_t t = tg - t0;
-                if (ok && t < tn) {
+                if (ok && t < tn && tile_open(t)) {
                     const uint32_t pos = s_cnt[t] + (uint32_t)__popcll(s_mask[t] & ((1ull << bl) - 1ull));
                     if (pos < cap) {
                         if (PAIRS) pairs[pos] = make_uint2((uint32_t)__builtin_amdgcn_readlane((int)kd, bl), gg);
@@ -1544,7 +1677,7 @@ __global__ __launch_bounds__(64) void k_chunk_scatter(DirectBin db, int W, int H
                     for (int q = 0; q < RN; q++) e[q] = s_pair[(p0 + 64u * q + (uint32_t)lane) & (uint32_t)(kDbPairs - 1)];
 #pragma unroll
                     for (int q = 0; q < RN; q++)
-                        if (64u * q + (uint32_t)lane < left) { atomicAdd(&s_cnt[e[q] >> 6], 1u); s_mask[e[q] >> 6] = 0ull; }
+                        if (64u * q + (uint32_t)lane < left && e[q] != 0xffffffffu) { atomicAdd(&s_cnt[e[q] >> 6], 1u); s_mask[e[q] >> 6] = 0ull; }
                 };
                 if (left <= 128u) batch(std::integral_constant<int, 2>{});
                 else if (left <= 256u) batch(std::integral_constant<int, 4>{});
@@ -1557,14 +1690,14 @@ __global__ __launch_bounds__(64) void k_chunk_scatter(DirectBin db, int W, int H
                 const int bl = (int)__builtin_ctzll(bm);
                 const uint32_t gg = (uint32_t)__builtin_amdgcn_readlane((int)g, bl), rect = (uint32_t)__builtin_amdgcn_readlane((int)r.rect, bl);
                 const Splat s = splat[gg];
-                big_rect_tiles(s, rect, W, H, tiles_x, tiles_y, lane, [&](bool ok, uint32_t tg) { const uint32_t t = tg - t0; if (ok && t < tn) { atomicAdd(&s_cnt[t], 1u); s_mask[t] = 0ull; } });
+                big_rect_tiles(s, rect, W, H, tiles_x, tiles_y, lane, [&](bool ok, uint32_t tg) { const uint32_t t = tg - t0; if (ok && t < tn && tile_open(t)) { atomicAdd(&s_cnt[t], 1u); s_mask[t] = 0ull; } });
             }
         }
         for (unsigned long long bm = huges; bm != 0ull; bm &= bm - 1ull) {
             const int bl = (int)__builtin_ctzll(bm);
             const uint32_t gg = (uint32_t)__builtin_amdgcn_readlane((int)g, bl), rect = (uint32_t)__builtin_amdgcn_readlane((int)r.rect, bl);
             const Splat s = splat[gg];
-            big_rect_tiles(s, rect, W, H, tiles_x, tiles_y, lane, [&](bool ok, uint32_t tg) { const uint32_t t = tg - t0; if (ok && t < tn) { atomicAdd(&s_cnt[t], 1u); s_mask[t] = 0ull; } });
+            big_rect_tiles(s, rect, W, H, tiles_x, tiles_y, lane, [&](bool ok, uint32_t tg) { const uint32_t t = tg - t0; if (ok && t < tn && tile_open(t)) { atomicAdd(&s_cnt[t], 1u); s_mask[t] = 0ull; } });
         }
         lds_order();
         DB_T(5);
@@ -1893,8 +2026,10 @@ __device__ __forceinline__ void blend_fwd_item(const int xcd, const int kslot, f
                                                float* __restrict__ out_depth, float* __restrict__ out_alpha,
                                                float* __restrict__ img, uint32_t* __restrict__ staged4, int interleave,
                                                float* __restrict__ ckpt, int kCkptFirst, int tiles_y, uint16_t* __restrict__ cost_out,
-                                               float* __restrict__ out_clamped)
+                                               float* __restrict__ out_clamped, const ListCut& cut, const int cut_pass)
 {
+    // cut_pass (see ListCut): 0 = full lists; 1 = the lists may be cut: a wave that runs out of a cut list with a live pixel flags its
+    // tile, every other wave records the depth it needed; 2 = the repair pass: only flagged tiles, on their full lists
     constexpr int NT = 64;
     uint32_t visits = 0u;   // (wave, instance) visits of this item: what the balanced placement of the next render of this view predicts with
 #ifdef GSR_K6_TIMING
@@ -1906,6 +2041,7 @@ __device__ __forceinline__ void blend_fwd_item(const int xcd, const int kslot, f
     const int sub = kslot & 3;
     const int lane = (int)(threadIdx.x & 63u);
     if (tile < 0) { if (cost_out && lane == 0) cost_out[xcd + 8 * kslot] = 0; return; }
+    if (cut_pass == 2 && cut.flag[tile] == 0u) return;
     // batched render: T = B tiles_x tiles_y tiles of a tall grid, image `bimg` owns the tile rows [bimg tiles_y, (bimg + 1) tiles_y)
     const int Tl = tiles_x * tiles_y, bimg = tile / Tl, tl = tile - bimg * Tl;
     const int tx = tl % tiles_x, ty = tl / tiles_x;
@@ -2055,6 +2191,25 @@ __device__ __forceinline__ void blend_fwd_item(const int xcd, const int kslot, f
     }
     if (lane == 0) staged4[tile * 4 + sub] = (uint32_t)min(n, batches * NT);
     if (cost_out && lane == 0) cost_out[xcd + 8 * kslot] = (uint16_t)min(visits, 65535u);
+    if (cut_pass) {
+        // what this tile needs of its list next time: the depth of the last instance any of its waves staged -- or everything, when a
+        // wave reaches the end of the FULL list with a live pixel.  A wave that reaches the end of a CUT list with a live pixel has
+        // not seen what it needs: it flags the tile, and the repair pass blends the tile again on its full list.
+        const bool live = !__all(Tr < 0.f);
+        if (lane == 0) {
+            if (cut_pass == 1 && live && cut.tend[tile] < cut.tbase[tile + 1]) {
+                if (atomicExch(&cut.flag[tile], 1u) == 0u) atomicAdd(&cut.ctl[2], 1u);
+            } else {
+                uint32_t k = live ? kCutOpenKey : 0u;
+                if (!live && batches > 0) {
+                    const int lb = batches - 1, lc = min(NT, n - lb * NT);
+                    k = __float_as_uint(s_ab[kFwdBufs + (lb & (kFwdBufs - 1))][lc - 1].z);     // view depth of the last staged instance (positive)
+                }
+                const uint32_t e = cut.cur[0] < (uint32_t)kVcEntries ? cut.cur[0] : 0u;
+                if (k) atomicMax(cut.key + (size_t)e * (size_t)T + tile, k);
+            }
+        }
+    }
 #ifdef GSR_K6_TIMING
     if (lane == 0 && xcd + 8 * kslot < 65536) {
         unsigned long long* d = g_k6_dbg + 4 * (size_t)(xcd + 8 * kslot);
@@ -2096,8 +2251,9 @@ __global__ __launch_bounds__(64) void k_blend_fwd_w6(int W, int H, int tiles_x, 
                                                      float* __restrict__ out_depth, float* __restrict__ out_alpha,
                                                      float* __restrict__ img, uint32_t* __restrict__ staged4, int interleave,
                                                      float* __restrict__ ckpt, int kCkptFirst, int tiles_y, const BlendBalance bb,
-                                                     float* __restrict__ out_clamped)
+                                                     float* __restrict__ out_clamped, const ListCut cut = ListCut{}, const int cut_pass = 0)
 {
+    if (cut_pass == 2 && cut.ctl[2] == 0u) return;      // the repair pass: no tile was flagged -- every wave of the launch leaves here
     // s_a and s_b in ONE array (planes 0/1 = A rows of the two buffers, 2/3 = B rows): a visit's two reads share one address
     // register and differ in the immediate offset
     __shared__ float4 s_ab[2 * kFwdBufs][64];
@@ -2109,14 +2265,14 @@ __global__ __launch_bounds__(64) void k_blend_fwd_w6(int W, int H, int tiles_x, 
         const uint32_t* __restrict__ cur = bb.cur;
         const uint16_t* __restrict__ perm = bb.perm;
         const uint32_t e = cur[0];
-        if (cur[1 + (blockIdx.x & 7u)]) {       // this XCD's slice of the table was built (each builder workgroup says so itself)
+        if (cut_pass != 2 && cur[1 + (blockIdx.x & 7u)]) {       // this XCD's slice of the table was built (each builder workgroup says so itself); the repair pass: dispatch order
             const int k = (int)perm[blockIdx.x];
             if (k < bb.nslots4) kslot = k;
         }
         if (e < (uint32_t)kVcEntries) cost_out = bb.cost + (size_t)e * bb.items;
     }
     blend_fwd_item<REACH>((int)(blockIdx.x & 7), kslot, s_ab, s_c, W, H, tiles_x, T, ranges, list, splat, bg, out_color, out_depth,
-                          out_alpha, img, staged4, interleave, ckpt, kCkptFirst, tiles_y, cost_out, out_clamped);
+                          out_alpha, img, staged4, interleave, ckpt, kCkptFirst, tiles_y, cost_out, out_clamped, cut, cut_pass);
 }
 
 // (round 3, measured with tools/k6_wave_timing.py on the 1 M / 980x545 frame: the 8.6 k waves are all resident at once, eight to
@@ -3665,10 +3821,14 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess_bwd(CamParams cp, in
 // Deterministic-accumulation debug mode (gsr_set_option "deterministic_backward"): instance positions sorted by Gaussian id
 // (stable: a Gaussian's instances stay in list = tile order); the first position of each run sums the run's partial
 // records in that order and writes the Gaussian's row -- no float atomics, the same bits on every run.
-__global__ __launch_bounds__(256) void k_det_iota(uint32_t R, uint32_t* __restrict__ pos)
+// (round 6: the list words behind a tile's valid prefix are not written when the forward cut its lists -- ListCut -- and hold whatever
+//  the buffer held before.  No wave of the backward blend visits such a position, so its slot of partials is zero; the copy of the
+//  list this mode sorts only has to keep such a word INSIDE the table: an id below N adds zeros to that Gaussian's run.)
+__global__ __launch_bounds__(256) void k_det_iota(uint32_t R, uint32_t* __restrict__ pos, const uint32_t* __restrict__ list, uint32_t* __restrict__ ids,
+                                                  uint32_t n_gaussians)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i < R) pos[i] = i;
+    if (i < R) { pos[i] = i; ids[i] = min(list[i], n_gaussians - 1u); }
 }
 __global__ __launch_bounds__(256) void k_det_reduce(uint32_t R, const uint32_t* __restrict__ gid_sorted, const uint32_t* __restrict__ pos_sorted,
                                                     const float* __restrict__ part, float* __restrict__ ggrad)
@@ -3825,7 +3985,7 @@ static BinScratch bin_scratch_layout(int64_t R, int key_bytes = 4)
 // invalid-handle error), and a slot is held by one call at a time: callers on several threads / devices do not serialise
 // on each other while they enqueue or wait.
 // the per-view cost cache of the balanced forward blend: one per (device, frame geometry), a handful at most
-struct ViewCostCache { int dev, W, H, map, items; uint8_t* mem; };
+struct ViewCostCache { int dev, W, H, map, items; uint8_t* mem; size_t bytes; };
 static std::vector<ViewCostCache> g_view_costs;   // guarded by g_state_mutex
 static std::map<std::tuple<int, int, int, int>, bool> g_full_depth_sort;   // callers whose depths left the 27-bit window once: four 8-bit passes from then on
 
@@ -3854,6 +4014,8 @@ static int g_tile_sort_max_avg = 700;   // measured (tools/ab_tile_sort*.sh, 980
 static int g_direct_bin = 1;      // tile lists by direct placement (k_chunk_counts / k_chunk_scatter) instead of emit + tile sort + ranges; 0 = the sort route
 static int g_view_pose_tol_e6 = 2000;   // balanced placement without a view id: a render belongs to the cached view whose pose is within this (x 1e-6) in every matrix entry
 static int g_db_slab_tiles = 0;   // frames above kDbMaxTiles tiles: tiles per slab of the slabbed scatter (0 = such frames keep the sort route)
+static int g_list_cut = 1;        // round 6: tile lists written only up to where the tile stopped at the frame's previous render (ListCut); 0 = full lists
+static int g_list_cut_margin_e3 = 50;   // ... x (1 + this / 1000) of the depth its waves reached
 static int g_early_r = 1;         // the host learns R from the preprocess's per-block shares (published by the depth sort's histogram kernel) instead of from the scan
 static int g_blend_balance = 1;   // forward blend: place the waves by the visits each took at the previous render of the same view (balance_build)
 static int g_tile_map = 2;   // tile -> XCD map: 2 = 2x2 tile blocks interleaved (default), 1 = tiles interleaved, 0 = banded
@@ -4064,6 +4226,16 @@ int gsr_set_option(const char* name, int value)
     if (!strcmp(name, "tile_map")) { if (value < 0 || value > 2) return GSR_ERR_ARG; g_tile_map = value; return GSR_OK; }
     if (!strcmp(name, "blend_balance")) { g_blend_balance = value ? 1 : 0; return GSR_OK; }
     if (!strcmp(name, "early_r")) { g_early_r = value ? 1 : 0; return GSR_OK; }
+    if (!strcmp(name, "list_cut")) { g_list_cut = value ? 1 : 0; return GSR_OK; }
+    if (!strcmp(name, "view_cache_reset")) {   // tests: every per-frame cache of the current device forgets its frames (placement costs, list cuts, counters)
+        int dev_id = 0;
+        if (hipGetDevice(&dev_id) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return GSR_ERR_HIP;
+        std::lock_guard<std::mutex> lk(g_state_mutex);
+        for (auto& c : g_view_costs)
+            if (c.dev == dev_id && hipMemset(c.mem, 0, c.bytes) != hipSuccess) return GSR_ERR_HIP;
+        return GSR_OK;
+    }
+    if (!strcmp(name, "list_cut_margin_e3")) { g_list_cut_margin_e3 = value < 0 ? 50 : value; return GSR_OK; }
     if (!strcmp(name, "debug_late_bias")) { g_debug_late_bias = value; return GSR_OK; }   // tests: added ONCE to the early count a forward remembers for its late check
     if (!strcmp(name, "tile_sort")) { if (value < 0 || value > 2) return GSR_ERR_ARG; g_tile_sort = value; return GSR_OK; }
     if (!strcmp(name, "tile_sort_max_avg")) { if (value < 0) return GSR_ERR_ARG; g_tile_sort_max_avg = value; return GSR_OK; }
@@ -4100,7 +4272,7 @@ int gsr_set_option(const char* name, int value)
 }
 
 // geometry + scratch of the direct binning for N Gaussians on T tiles; false: this frame keeps the sort route
-struct DirectBinScratch { size_t M, GT, tbase, bsum, bytes; };
+struct DirectBinScratch { size_t M, GT, tbase, bsum, cut_chunk, cut_tend, cut_flag, cut_ctl, cut_bkey, bytes; };
 static bool direct_bin_geometry(int N, int T, DirectBin& db, DirectBinScratch& ds, int tiles_x = 0, int tile_rows = 0)
 {
     if (N < 1 || T < 1) return false;
@@ -4142,6 +4314,12 @@ static bool direct_bin_geometry(int N, int T, DirectBin& db, DirectBinScratch& d
     ds.GT = o; o += align256((size_t)db.G * db.Tp * sizeof(uint32_t));
     ds.tbase = o; o += align256((size_t)(db.Tp + 1) * sizeof(uint32_t));
     ds.bsum = o; o += align256((size_t)db.G * ((db.Tp + 255) / 256) * sizeof(uint32_t));
+    // the list cut's per-call tables (ListCut): the tiles' last chunk, valid end and flag, the control words, the chunks' first keys
+    ds.cut_chunk = o; o += align256((size_t)db.Tp * sizeof(uint16_t));
+    ds.cut_tend = o; o += align256((size_t)db.Tp * sizeof(uint32_t));
+    ds.cut_flag = o; o += align256((size_t)db.Tp * sizeof(uint32_t));
+    ds.cut_ctl = o; o += 256;
+    ds.cut_bkey = o; o += align256((size_t)db.NC * sizeof(uint32_t));
     ds.bytes = o;
     return true;
 }
@@ -4169,6 +4347,8 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
     out->forward_flags = pack_fwd_flags(opt_ppt, opt_map, opt_ckpt);
     uint64_t R = 0;
     BlendBalance bb = {};   // filled in front of k_tile_counts (whose extra workgroups build the placement the blend reads)
+    ListCut lc = {};        // filled with it: the list cut lives in the same per-frame cache
+    uint64_t lc_capacity = 0;   // capacity of the last launch_binning (the repair pass scatters against the same)
     Splat* splat = static_cast<Splat*>(a->geom);
     float* img = static_cast<float*>(a->image);
     uint32_t* staged = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(a->image) + image_staged_offset(W, H, NB));
@@ -4286,7 +4466,12 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
             if (db.NS > 1)
                 hipLaunchKernelGGL(k_chunk_scatter<true>, dim3(grid), dim3(64), (size_t)12 * db.Tsp + 4 * kDbPairs, st, db, W, H, tiles_x, tiles_y, sorted_gid,
                                    reinterpret_cast<const TileRec*>(fs + L.srec), splat, list, ranges, (uint32_t)std::min<uint64_t>(capacity, 0xffffffffull));
-            else
+            else if (lc.key) {
+                lc_capacity = capacity;
+                hipLaunchKernelGGL((k_chunk_scatter<false, false, 1>), dim3(grid), dim3(64), (size_t)12 * db.Tp + 4 * kDbPairs + 8 * (db.Tp / 64 + 2), st, db, W, H,
+                                   tiles_x, tiles_y, sorted_gid, reinterpret_cast<const TileRec*>(fs + L.srec), splat, list, ranges,
+                                   (uint32_t)std::min<uint64_t>(capacity, 0xffffffffull), (const uint32_t*)nullptr, (uint2*)nullptr, lc);
+            } else
                 hipLaunchKernelGGL(k_chunk_scatter<false>, dim3(grid), dim3(64), (size_t)12 * db.Tp + 4 * kDbPairs, st, db, W, H, tiles_x, tiles_y, sorted_gid,
                                    reinterpret_cast<const TileRec*>(fs + L.srec), splat, list, ranges, (uint32_t)std::min<uint64_t>(capacity, 0xffffffffull));
             return GSR_OK;
@@ -4304,18 +4489,31 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
             hipEvent_t ea = nullptr, eb = nullptr;
             if (hipEventCreate(&ea) != hipSuccess || hipEventCreate(&eb) != hipSuccess) return fail(GSR_ERR_HIP, "hipEventCreate failed%s");
             hipExtLaunchKernelGGL(k_blend_fwd_w6<true>, dim3(8 * 4 * slots_per_xcd(opt_map, T, tiles_x)), dim3(64), 0, st, ea, eb, 0, W, H, tiles_x, T, ranges, list,
-                                  splat, a->bg, a->out_color, a->out_depth, a->out_alpha, img, staged, opt_map, ckpt, opt_ckpt, tiles_y, bb, a->out_color_clamped);
+                                  splat, a->bg, a->out_color, a->out_depth, a->out_alpha, img, staged, opt_map, ckpt, opt_ckpt, tiles_y, bb, a->out_color_clamped,
+                                  lc, lc.key ? 1 : 0);
             std::lock_guard<std::mutex> lk(g_prof_mutex);
             g_prof_events[P_BLEND_FWD].push_back({ea, eb});
         } else {
             ProfScope ps(ppt == 7 && g_profile == 3 ? P_COUNT : P_BLEND_FWD, st);   // (mode 3, an untimed launch: no events)
             if (ppt == 7)
                 hipLaunchKernelGGL(k_blend_fwd_w6<true>, dim3(8 * 4 * slots_per_xcd(opt_map, T, tiles_x)), dim3(64), 0, st, W, H, tiles_x, T, ranges, list, splat, a->bg,
-                                   a->out_color, a->out_depth, a->out_alpha, img, staged, opt_map, ckpt, opt_ckpt, tiles_y, bb, a->out_color_clamped);
+                                   a->out_color, a->out_depth, a->out_alpha, img, staged, opt_map, ckpt, opt_ckpt, tiles_y, bb, a->out_color_clamped,
+                                   lc, lc.key ? 1 : 0);
             else if (ppt == 6)
                 hipLaunchKernelGGL(k_blend_fwd_w6<false>, dim3(8 * 4 * slots_per_xcd(opt_map, T, tiles_x)), dim3(64), 0, st, W, H, tiles_x, T, ranges, list, splat, a->bg,
                                    a->out_color, a->out_depth, a->out_alpha, img, staged, opt_map, ckpt, opt_ckpt, tiles_y, BlendBalance{}, a->out_color_clamped);
             else return fail(GSR_ERR_ARG, "unknown forward blend variant%s");
+        }
+        if (ppt == 7 && lc.key && lc_capacity > 0) {
+            // the repair pass of the list cut: the same scatter over the chunks behind the flagged tiles' cuts and the same blend over
+            // the flagged tiles' full lists -- every workgroup of both launches reads one word and leaves unless a wave flagged a tile
+            ProfScope ps(P_CUT_REPAIR, st);
+            const int per = (db.NC + 7) / 8, grid = std::max(8 * per * db.NS, (T + 63) / 64);
+            hipLaunchKernelGGL((k_chunk_scatter<false, false, 2>), dim3(grid), dim3(64), (size_t)12 * db.Tp + 4 * kDbPairs + 8 * (db.Tp / 64 + 2), st, db, W, H,
+                               tiles_x, tiles_y, sorted_gid, reinterpret_cast<const TileRec*>(fs + L.srec), splat, list, ranges,
+                               (uint32_t)std::min<uint64_t>(lc_capacity, 0xffffffffull), (const uint32_t*)nullptr, (uint2*)nullptr, lc);
+            hipLaunchKernelGGL(k_blend_fwd_w6<true>, dim3(8 * 4 * slots_per_xcd(opt_map, T, tiles_x)), dim3(64), 0, st, W, H, tiles_x, T, ranges, list, splat, a->bg,
+                               a->out_color, a->out_depth, a->out_alpha, img, staged, opt_map, ckpt, opt_ckpt, tiles_y, bb, a->out_color_clamped, lc, 2);
         }
         GSR_HIP(hipGetLastError());
         return GSR_OK;
@@ -4480,9 +4678,10 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
             // (tile-sort route: index order, no sorted copy of the records, and -- no depth sort to ride on -- the rider that publishes R)
             hipLaunchKernelGGL(k_chunk_counts, dim3(db.NC + (bal.hdr ? 8 : 0)), dim3(kEmitThreads), (size_t)2 * db.Tp, st, db, W, H,
                                tiles_x, tiles_y, sorted_gid, ntiles, splat, tsort ? (TileRec*)nullptr : srec, bal,
-                               (tsort && early_r && !publish) ? rider : OsRider{});
+                               (tsort && early_r && !publish) ? rider : OsRider{}, lc);
             hipLaunchKernelGGL(k_chunk_scan1, dim3((db.Tp + 255) / 256, db.G), dim3(256), 0, st, db);
-            hipLaunchKernelGGL(k_chunk_scan2, dim3((db.Tp + 255) / 256), dim3(256), 0, st, db, total, zjobs, host_slot, seq, wo, late_slot);
+            hipLaunchKernelGGL(k_chunk_scan2, dim3((db.Tp + 255) / 256), dim3(256), lc.key ? (size_t)db.NC * 4 : 0, st, db, total, zjobs, host_slot, seq, wo,
+                               late_slot, lc);
         } else {
             hipLaunchKernelGGL(k_tile_counts, dim3(nb + (bal.hdr ? 8 : 0)), dim3(kEmitThreads), 0, st, N, sorted_gid, ntiles, block_sums,
                                tsort ? (TileRec*)nullptr : srec, bal, nb, (tsort && early_r && !publish) ? rider : OsRider{});
@@ -4504,18 +4703,22 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
             const int nslots4 = 4 * slots_per_xcd(opt_map, T, tiles_x), items = 8 * nslots4;
             if (g_blend_balance && NB == 1 && opt_ppt == 7 && items <= 65535 && nslots4 <= 20 * kEmitThreads && a->viewmatrix) {
                 const size_t hdr_bytes = align256(sizeof(ViewCostHdr));
+                // header | visit counts [entries][items] | list cut: depth keys [entries][T], the model size they belong to [entries]
+                const size_t vc_cut = align256(hdr_bytes + (size_t)kVcEntries * items * sizeof(uint16_t));
+                const size_t vc_own = vc_cut + align256((size_t)kVcEntries * T * sizeof(uint32_t));
+                const size_t vc_bytes = vc_own + align256((size_t)kVcEntries * sizeof(uint32_t));
                 uint8_t* mem = nullptr;
                 {
                     std::lock_guard<std::mutex> lk(g_state_mutex);
                     for (auto& c : g_view_costs)
                         if (c.dev == dev_id && c.W == W && c.H == H && c.map == opt_map && c.items == items) mem = c.mem;
                     if (!mem && g_view_costs.size() < 16) {
-                        if (hipMalloc((void**)&mem, hdr_bytes + (size_t)kVcEntries * items * sizeof(uint16_t)) == hipSuccess) {
+                        if (hipMalloc((void**)&mem, vc_bytes) == hipSuccess) {
                             // cleared SYNCHRONOUSLY, once per (device, frame geometry), before anybody can look at it (with
                             // pose-keyed entries an uncleared header is not "garbage hashes = a miss" -- a key that reads 2 with pose
                             // floats inside the tolerance would be a hit on garbage cost tables); a failed clear = no cache
-                            if (hipMemset(mem, 0, hdr_bytes + (size_t)kVcEntries * items * sizeof(uint16_t)) == hipSuccess) {
-                                g_view_costs.push_back({dev_id, W, H, opt_map, items, mem});
+                            if (hipMemset(mem, 0, vc_bytes) == hipSuccess) {
+                                g_view_costs.push_back({dev_id, W, H, opt_map, items, mem, vc_bytes});
                             } else {
                                 (void)hipGetLastError();
                                 (void)hipFree(mem);
@@ -4536,6 +4739,23 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
                     bb.vm = a->viewmatrix; bb.pt = a->points_transform; bb.view_id = (long long)a->view_id;
                     bb.tol = 1e-6f * (float)g_view_pose_tol_e6;
                     bb.items = items; bb.nslots4 = nslots4; bb.W = W; bb.H = H;
+                    // the list cut: the plain direct binning behind a global depth sort, one model, the default blend
+                    if (direct && !tsort && db.NS == 1 && db.NC <= 16000 && T == db.T) {
+                        uint8_t* dm = fs + align256(L.bytes);
+                        lc.key = reinterpret_cast<uint32_t*>(mem + vc_cut);
+                        lc.owner_n = reinterpret_cast<uint32_t*>(mem + vc_own);
+                        lc.stats = &bb.hdr->pad[2];
+                        lc.cur = bb.cur;
+                        lc.chunk = reinterpret_cast<uint16_t*>(dm + dbs.cut_chunk);
+                        lc.tend = reinterpret_cast<uint32_t*>(dm + dbs.cut_tend);
+                        lc.flag = reinterpret_cast<uint32_t*>(dm + dbs.cut_flag);
+                        lc.ctl = reinterpret_cast<uint32_t*>(dm + dbs.cut_ctl);
+                        lc.bkey = reinterpret_cast<uint32_t*>(dm + dbs.cut_bkey);
+                        lc.skey = in_alt ? dkey_alt : dkey;
+                        lc.tbase = reinterpret_cast<uint32_t*>(dm + dbs.tbase);
+                        lc.margin = 1e-3f * (float)g_list_cut_margin_e3;
+                        lc.enable = g_list_cut;
+                    }
                 }
             }
         }
@@ -4800,8 +5020,7 @@ int gsr_backward(const GsrBackwardArgs* a, void* stream_)
             if (g_deterministic) {
                 uint32_t* k0 = reinterpret_cast<uint32_t*>(det_mem + o_k0); uint32_t* k1 = reinterpret_cast<uint32_t*>(det_mem + o_k1);
                 uint32_t* v0 = reinterpret_cast<uint32_t*>(det_mem + o_v0); uint32_t* v1 = reinterpret_cast<uint32_t*>(det_mem + o_v1);
-                GSR_HIP(hipMemcpyAsync(k0, list, (size_t)Rn * 4, hipMemcpyDeviceToDevice, st));
-                hipLaunchKernelGGL(k_det_iota, dim3((Rn + 255) / 256), dim3(256), 0, st, Rn, v0);
+                hipLaunchKernelGGL(k_det_iota, dim3((Rn + 255) / 256), dim3(256), 0, st, Rn, v0, list, k0, (uint32_t)N);
                 int nbits = 1;
                 while ((1ll << nbits) < (long long)N) nbits++;
                 int in_alt = 0;
@@ -4963,6 +5182,27 @@ int gsr_debug_view_cache_stats(int32_t W, int32_t H, int64_t out[4])
             return fail(GSR_ERR_HIP, "view cache read-back failed%s");
         out[0] += h.pad[0]; out[1] += h.pad[1]; out[3] += 1;
         for (int i = 0; i < kVcEntries; i++) out[2] += h.key[i] != 0ull;
+    }
+    return GSR_OK;
+}
+
+int gsr_debug_list_cut_stats(int32_t W, int32_t H, int64_t out[4])
+{
+    // the list cut's counters of the CURRENT device for this frame size (ListCut::stats): renders that ran with the cut machinery,
+    // renders whose repair pass found flagged tiles, tiles repaired, chunks of the depth order the scatter skipped (summed)
+    int dev_id = 0;
+    if (hipGetDevice(&dev_id) != hipSuccess) return fail(GSR_ERR_HIP, "hipGetDevice failed%s");
+    out[0] = out[1] = out[2] = out[3] = 0;
+    std::vector<uint8_t*> mems;
+    {
+        std::lock_guard<std::mutex> lk(g_state_mutex);
+        for (auto& c : g_view_costs) if (c.dev == dev_id && c.W == W && c.H == H) mems.push_back(c.mem);
+    }
+    for (uint8_t* m : mems) {
+        ViewCostHdr h;
+        if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(&h, m, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess)
+            return fail(GSR_ERR_HIP, "view cache read-back failed%s");
+        for (int q = 0; q < 4; q++) out[q] += h.pad[2 + q];
     }
     return GSR_OK;
 }

@@ -87,7 +87,7 @@ except Exception:
     pass
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-STAGES = ["preprocess_fwd", "sort_depth", "scan", "emit", "sort_tile", "ranges", "blend_fwd", "blend_bwd", "preprocess_bwd"]
+STAGES = ["preprocess_fwd", "sort_depth", "scan", "emit", "sort_tile", "ranges", "blend_fwd", "blend_bwd", "preprocess_bwd", "cut_repair"]
 
 
 def parse():
