@@ -1101,62 +1101,48 @@ struct DirectBin {
 };
 
 // ------------------------------------------------------------------------------------------------
-// Lists cut where the tile stopped last time (round 6).  At the headline the forward blends stage R_eff = 0.75 M of the R = 4.5 M
+// Lists cut where the tiles stopped last time (round 6).  At the headline the forward blends stage R_eff = 0.75 M of the R = 4.5 M
 // instances the binning places (17 %; 4 % at 4 M Gaussians): a tile whose 256 pixels saturate after the nearest few hundred splats
 // never reads the rest of its list.  The frame is recognised anyway (the view-cost cache of the balanced placement), so every tile
 // remembers the DEPTH up to which its four waves staged instances at the frame's previous render, and the scatter -- the expensive
-// half of the direct binning -- leaves out what lies behind it:
+// half of the direct binning -- leaves out what lies behind:
 //   * nothing about the LAYOUT changes: counts, scans, tile bases and R are the full ones, every pair keeps the position the full
-//     binning gives it; a tile's list is simply only written up to a chunk boundary of the depth order (`chunk[t]` = the last chunk
-//     tile t keeps: the first chunk that starts behind the remembered depth x (1 + margin)), and the blends are handed the END OF
-//     THE VALID PREFIX as the tile's range end (`tend[t]`, from the chunk tables: no counting).  Chunks behind every tile's cut do
-//     not run at all; chunks in front of every cut run unchanged; a chunk in between masks the closed tiles' bits out of its
-//     records' tile masks (k_chunk_scatter CUT: one funnel shift per rect row against a bitmap of the open tiles).
+//     binning gives it; lists are simply only WRITTEN up to a chunk boundary of the depth order, and the blends are handed the end
+//     of the valid prefix as the tile's range end (from the chunk tables: no counting).
+//   * one cut for the frame, exceptions for the few: tile t's own cut is the last chunk that starts at or in front of (the depth it
+//     needed) x (1 + margin); C* is the chunk behind which at most `dmax` tiles' cuts lie (k_chunk_scan2: a histogram of the cuts in
+//     LDS, every block for itself).  The chunks up to C* are scattered exactly as ever -- for EVERY tile, so all but the `dmax`
+//     deepest tiles keep more than they asked for -- and a scatter wave of a chunk behind C* only serves the few "deep" tiles whose own
+//     cut lies behind it (cut_chunk_tiles: the chunk's records against a handful of tiles, ~1 % of the scatter's work).  A tile that
+//     reached the end of its full list with a live pixel (kCutOpenKey) is a deep tile that keeps everything.
 //   * the speculation is verified ON THE DEVICE and repaired there: a blend wave that reaches the end of a cut list with a live
-//     pixel flags its tile; two more launches -- the same scatter over the chunks behind the flagged tiles' cuts, for those tiles
-//     only, and the same blend over the flagged tiles with their full range -- follow every cut render and find nothing to do
-//     (a word read per workgroup) unless a tile was flagged.  The host never learns of it and never waits: image, radii, lists'
-//     valid prefixes, checkpoints and gradients are those of the full binning, bit for bit, by construction -- the instances a
-//     pixel blends are the same instances in the same order (tests/test_gpu_listcut.py).
+//     pixel flags its tile; two launches that follow every cut render -- the flagged tiles' left-out chunks (the same cut_chunk_tiles)
+//     and the same blend over the flagged tiles' full lists -- find nothing to do (a word read per workgroup) unless a tile was
+//     flagged.  The host never learns of it and never waits: image, radii, the lists' valid prefixes, checkpoints and gradients are
+//     those of the full binning, bit for bit, by construction -- the instances a pixel blends are the same instances in the same
+//     order (tests/test_gpu_listcut.py).
 // What changes is what lies in the list buffer BEHIND a tile's valid prefix (stale words nobody reads) and ranges[t].y.
-// Off (`"list_cut"` 0, a frame seen for the first time, another model under the same frame id, the tile-sort / sort / slabbed /
-// batched routes): `chunk[t]` = the last chunk for every tile and the code below is the round-5 code.
+// Off ("list_cut" 0, a frame seen for the first time, another model under the same frame, the tile-sort / sort / slabbed / batched
+// routes): every tile's cut is the last chunk and the code below is the round-5 code.
 // ------------------------------------------------------------------------------------------------
 constexpr uint32_t kCutOpenKey = 0xffffffffu;   // a tile that reached the end of its FULL list with a live pixel: never cut
 struct ListCut {            // kernel-argument bundle; key == nullptr: off
     uint32_t* key;          // [kVcEntries][T] (cache): depth key up to which tile t's waves staged at the entry's last render
     uint32_t* owner_n;      // [kVcEntries] (cache): the model size those keys belong to (another model under the same frame: no cut)
-    uint32_t* stats;        // [8] (cache): [0] cut renders, [1] renders that needed a repair, [2] tiles repaired, [3] chunks skipped (sum)
+    uint32_t* stats;        // [8] (cache): [0] cut renders, [1] renders that needed a repair, [2] tiles repaired, [3] chunks left to the deep tiles (sum), [4] deep tiles (sum)
     const uint32_t* cur;    // the placement's per-call words: [0] the frame's cache entry, [9] the entry was a hit (written by k_chunk_counts' builder 0)
-    uint16_t* chunk;        // [Tp] per call: last chunk of the depth order tile t keeps
+    uint16_t* chunk;        // [Tp] per call: tile t's OWN cut: the last chunk of the depth order it asks for (what is written: max(that, C*))
+    uint32_t* hist;         // [NC] per call: tiles per own cut
     uint32_t* tend;         // [Tp] per call: end of tile t's valid prefix (absolute list position)
     uint32_t* flag;         // [Tp] per call: tile t ran out of its cut list with a live pixel
-    uint32_t* ctl;          // [8] per call: [0] max, [1] min of chunk[] over the tiles, [2] tiles flagged
+    uint32_t* ctl;          // [8] per call: [0] C* (written by the cut pass for the repair pass), [1] deep tiles, [2] tiles flagged
     uint32_t* bkey;         // [NC] per call: depth key of the first Gaussian of every chunk
     const uint32_t* skey;   // the depth keys in depth order
     const uint32_t* tbase;  // [T + 1] the tile bases of the FULL binning (DirectBin::tbase)
     float margin;           // relative slack on the remembered depth
+    int dmax;               // tiles that may keep more than the frame's cut
     int enable;             // 0: tables are written for "everything kept" (the caller asked for full lists on a route that can cut)
 };
-
-// bits [L, L + n) of a linear bitmap (n <= 32; one word of padding behind the last)
-__device__ __forceinline__ uint32_t bitmap_extract(const unsigned long long* bm, uint32_t L, uint32_t n)
-{
-    const uint32_t w = L >> 6, sh = L & 63u;
-    const unsigned long long lo = bm[w], hi = bm[w + 1];
-    const unsigned long long v = sh ? ((lo >> sh) | (hi << (64u - sh))) : lo;
-    return (uint32_t)v & (n >= 32u ? 0xffffffffu : ((1u << n) - 1u));
-}
-// the bits of a small rect's tile mask whose tiles are open
-__device__ __forceinline__ uint32_t open_tiles_mask(const TileRec& r, int tiles_x, const unsigned long long* s_open)
-{
-    const uint32_t ww = (r.rect >> 24) & 63u, rx0 = r.rect & 0xfffu, ry0 = (r.rect >> 12) & 0xfffu;
-    uint32_t open = 0u;
-    if (ww == 0u) return 0u;
-    for (uint32_t m = r.mask, row = 0u, sh = 0u; (m >> sh) != 0u && sh < 32u; row++, sh += ww)
-        open |= bitmap_extract(s_open, (ry0 + row) * (uint32_t)tiles_x + rx0, min(ww, 32u - sh)) << sh;
-    return open;
-}
 
 // all 64 lanes walk the candidate tiles of ONE large rect (more than 32 tiles: no mask in its TileRec), 64 at a time, in the
 // emission's order (row-major over the tight rect, the exact test per tile): f(accepted, tile key) on every lane, every round
@@ -1236,7 +1222,8 @@ __global__ __launch_bounds__(kEmitThreads) void k_chunk_counts(DirectBin db, int
     if (c < 0) { balance_build(bb, (int)blockIdx.x); return; }
     if (cut.key && threadIdx.x == 0) {     // list cut: where every chunk of the depth order starts, and this call's control words
         cut.bkey[c] = cut.skey[(size_t)c * db.S];
-        if (c == 0) { cut.ctl[0] = 0u; cut.ctl[1] = 0xffffffffu; cut.ctl[2] = 0u; }
+        cut.hist[c] = 0u;
+        if (c == 0) { cut.ctl[0] = (uint32_t)(db.NC - 1); cut.ctl[1] = 0u; cut.ctl[2] = 0u; }
     }
     if (rider.host && blockIdx.x == gridDim.x - 1) {   // (block-uniform)
         __shared__ unsigned long long s_r[2][16];
@@ -1358,16 +1345,14 @@ __global__ __launch_bounds__(256) void k_chunk_scan2(DirectBin db, unsigned long
     const uint32_t base_t = (uint32_t)min(lo + add + inc - tot, 0xffffffffull);
     if (t < db.T) db.tbase[t] = base_t;
     if (cut.key) {
-        // the tile's cut: the last chunk that starts at or in front of (the depth its waves reached last time) x (1 + margin); the
-        // key is taken and reset -- this render's blends rebuild it with atomic maxima (blend_fwd_item)
-        uint32_t ck = (uint32_t)(db.NC - 1);
+        // the tile's own cut: the last chunk that starts at or in front of (the depth its waves reached last time) x (1 + margin), into
+        // chunk[t] and a histogram over the chunks; the frame's cut C* is read off that histogram by the scatter's waves (cut_frame)
         if (t < db.T) {
             const uint32_t e = cut.cur[0] < (uint32_t)kVcEntries ? cut.cur[0] : 0u;
-            uint32_t* kp = cut.key + (size_t)e * db.T + t;
             const bool use = cut.enable && cut.cur[9] != 0u && cut.owner_n[e] == (uint32_t)db.N;
-            const uint32_t k = *kp;
-            *kp = 0u;
-            if (use && k != kCutOpenKey && k != 0u) {
+            uint32_t ck = (uint32_t)(db.NC - 1);
+            const uint32_t k = use ? cut.key[(size_t)e * db.T + t] : kCutOpenKey;
+            if (k != kCutOpenKey && k != 0u) {
                 const float d = __uint_as_float(k);
                 const uint32_t kc = __float_as_uint(fmaf(d, cut.margin, d));
                 int a = 0, b = db.NC;            // chunks [0, a) start at or in front of kc
@@ -1375,19 +1360,9 @@ __global__ __launch_bounds__(256) void k_chunk_scan2(DirectBin db, unsigned long
                 ck = (uint32_t)max(a - 1, 0);
             }
             cut.chunk[t] = (uint16_t)ck;
-            const uint32_t c1 = ck + 1u;
-            const uint32_t kept = c1 >= (uint32_t)db.NC ? tot : db.GT[(size_t)(c1 / (uint32_t)db.Cg) * db.Tp + t] + (uint32_t)db.M[(size_t)c1 * db.Tp + t];
-            cut.tend[t] = base_t + kept;
             cut.flag[t] = 0u;
-        }
-        // the extremes over the frame: chunks behind the largest do not run, chunks up to the smallest run as they always did
-        uint32_t mx = t < db.T ? ck : 0u, mn = t < db.T ? ck : 0xffffffffu;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { mx = max(mx, (uint32_t)__shfl_xor((int)mx, off, 64)); mn = min(mn, (uint32_t)__shfl_xor((int)mn, off, 64)); }
-        if (lane == 0) { atomicMax(&cut.ctl[0], mx); atomicMin(&cut.ctl[1], mn); }
-        if (slab == 0 && tid == 0) {
-            const uint32_t e = cut.cur[0] < (uint32_t)kVcEntries ? cut.cur[0] : 0u;
-            cut.owner_n[e] = (uint32_t)db.N;
+            if (use) atomicAdd(&cut.hist[ck], 1u);       // (nothing to cut: no histogram -- 2 000 adds to ONE word took 20 us)
+            if (t == 0) cut.ctl[3] = use ? 1u : 0u;
         }
     }
     if (slab == 0 && tid == 0) {
@@ -1421,6 +1396,131 @@ __global__ __launch_bounds__(256) void k_chunk_scan2(DirectBin db, unsigned long
 constexpr int kDbPairs = 1024;        // pair buffer (a step whose small rects hold more is cut into runs of lanes that fit)
 __device__ __forceinline__ void lds_order() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 
+// The frame's cut C*: the chunk behind which at most `dmax` tiles' own cuts lie, read off the histogram k_chunk_scan2 built (one wave;
+// every wave of the scatter does this for itself -- a few coalesced loads -- instead of a launch or a cross-block step in the scan).
+// deep = the tiles whose own cut lies behind C*.
+__device__ __forceinline__ uint32_t cut_frame(const ListCut& cut, const int NC, uint32_t& deep)
+{
+    const int lane = threadIdx.x & 63;
+    deep = 0u;
+    if (cut.ctl[3] == 0u) return (uint32_t)(NC - 1);      // nothing is cut this render (k_chunk_scan2 says so): no histogram was built
+    // every word of the histogram requested before the first is used (the dependent form -- load, scan, decide, next 64 -- was 1.5 us
+    // per round trip in front of every scatter wave); beyond 32 x 64 chunks the remainder goes the slow way
+    constexpr int kR = 32;
+    uint32_t v[kR];
+#pragma unroll
+    for (int q = 0; q < kR; q++) { const int c = NC - 1 - 64 * q - lane; v[q] = (64 * q < NC && c >= 0) ? cut.hist[c] : 0u; }
+    uint32_t acc = 0u;
+#pragma unroll
+    for (int q = 0; q < kR; q++) {
+        if (64 * q >= NC) break;
+        const int c = NC - 1 - 64 * q - lane;
+        const uint32_t inc = acc + wave_inclusive_sum(v[q]);
+        const unsigned long long over = __ballot(c >= 0 && inc > (uint32_t)cut.dmax);
+        if (over) {
+            const int l = (int)__builtin_ctzll(over);
+            deep = (uint32_t)__builtin_amdgcn_readlane((int)(inc - v[q]), l);
+            return (uint32_t)(NC - 1 - 64 * q - l);
+        }
+        acc = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+    }
+    for (int top = NC - 1 - 64 * kR; top >= 0; top -= 64) {
+        const int c = top - lane;
+        const uint32_t w = c >= 0 ? cut.hist[c] : 0u;
+        const uint32_t inc = acc + wave_inclusive_sum(w);
+        const unsigned long long over = __ballot(c >= 0 && inc > (uint32_t)cut.dmax);
+        if (over) {
+            const int l = (int)__builtin_ctzll(over);
+            deep = (uint32_t)__builtin_amdgcn_readlane((int)(inc - w), l);
+            return (uint32_t)(top - l);
+        }
+        acc = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+    }
+    deep = acc;
+    return 0u;
+}
+
+// The pairs of a FEW tiles in one chunk of the depth order, written where the full binning puts them: position = the tile's base + the
+// chunk's start inside the tile (the chunk tables) + the number of the chunk's earlier Gaussians that touch the tile.  One wave; the
+// chunk's records 64 at a time, lane = Gaussian (two steps of loads in flight), against every wanted tile in turn (a rect test and a
+// mask bit; a large rect -- no mask in its record -- evaluates the exact tile test on that one tile).  want(t) says which tiles: the deep
+// tiles of a cut render whose own cut lies at or behind this chunk, or the flagged tiles of a repair pass whose cut lies in front of it.
+template <typename Want>
+__device__ __forceinline__ void cut_chunk_tiles(const DirectBin& db, const int c, const int W, const int H, const int tiles_x, const int tiles_y,
+                                                const uint32_t* __restrict__ sorted_gid, const TileRec* __restrict__ sorted_rec,
+                                                const Splat* __restrict__ splat, uint32_t* __restrict__ list, const uint32_t cap,
+                                                uint32_t* s_txy /*[64]*/, uint32_t* s_pos /*[64]*/, Want&& want)
+{
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lt = lanemask_lt();
+    const int j0 = c * db.S, j1 = min(db.N, j0 + db.S);
+    const uint32_t* gt = db.GT + (size_t)(c / db.Cg) * db.Tp;
+    const uint16_t* mr = db.M + (size_t)c * db.Tp;
+    auto load_rec = [&](int j) -> TileRec { TileRec r; r.mask = 0u; r.rect = 1u << 24; if (j < j1) r = sorted_rec[j]; return r; };
+    auto load_gid = [&](int j) -> uint32_t { return j < j1 ? sorted_gid[j] : 0u; };
+    // which tiles are wanted: asked for ALL tiles at once (bit q of `mine` = tile 64 q + lane), every load in flight together -- asked
+    // block by block, with a ballot and a branch between the loads, this was 34 memory round trips in a row in front of every chunk
+    unsigned long long mine = 0ull;
+#pragma unroll
+    for (int q = 0; q < kDbMaxTiles / 64; q++) {
+        const int t = 64 * q + lane;
+        if (64 * q < db.T && t < db.T && want((uint32_t)t)) mine |= 1ull << q;
+    }
+    for (int t0 = 0; t0 < db.T;) {
+        // the next (up to) 64 wanted tiles, in tile order: whole blocks of 64 tiles as long as they fit
+        int nt = 0;
+        while (t0 < db.T) {
+            const int t = t0 + lane;
+            const bool w = ((mine >> (t0 >> 6)) & 1ull) != 0ull;
+            const unsigned long long b = __ballot(w);
+            const int got = (int)__popcll(b);
+            if (nt + got > 64) break;            // (nt > 0 here: a block holds at most 64) -- the next round starts with this block
+            if (w) {
+                const int k = nt + (int)__popcll(b & lt);
+                s_txy[k] = ((uint32_t)(t / tiles_x) << 16) | (uint32_t)(t % tiles_x);
+                s_pos[k] = db.tbase[t] + gt[t] + (uint32_t)mr[t];
+            }
+            nt += got;
+            t0 += 64;
+        }
+        if (nt == 0) break;
+        lds_order();
+        TileRec rA = load_rec(j0 + lane), rB = load_rec(j0 + 64 + lane);
+        uint32_t gA = load_gid(j0 + lane), gB = load_gid(j0 + 64 + lane);
+        for (int j = j0; j < j1; j += 64) {
+            const TileRec r = rA;
+            const uint32_t g = gA;
+            rA = rB; gA = gB;
+            rB = load_rec(j + 128 + lane);
+            gB = load_gid(j + 128 + lane);
+            const bool big = (r.rect & kTileRecBig) != 0u && r.mask != 0u;
+            const uint32_t ww = (r.rect >> 24) & 63u, rx0 = r.rect & 0xfffu, ry0 = (r.rect >> 12) & 0xfffu;
+            TileTest tt = {};
+            int bx0 = 0, by0 = 0, bx1 = 0, by1 = 0;
+            if (big) {
+                const Splat sp = splat[g];
+                tile_rect_tight(sp.px, sp.py, sp.radius, sp.ca, sp.cb, sp.cc, sp.op, W, H, tiles_x, tiles_y, bx0, by0, bx1, by1);
+                tt = make_tile_test(sp.px, sp.py, sp.ca, sp.cb, sp.cc, sp.op);
+            }
+            const bool any_big = __ballot(big) != 0ull;
+            for (int k = 0; k < nt; k++) {
+                const uint32_t txy = s_txy[k], tx = txy & 0xffffu, ty = txy >> 16;
+                const uint32_t dx = tx - rx0, dy = ty - ry0, bit = dy * ww + dx;      // (unsigned: a tile left of / above the rect wraps)
+                bool in = !big && dx < ww && bit < 32u && ((r.mask >> bit) & 1u) != 0u;
+                if (any_big && big) in = (int)tx >= bx0 && (int)tx < bx1 && (int)ty >= by0 && (int)ty < by1 && tile_accept(tt, (int)tx, (int)ty, W, H);
+                const unsigned long long b = __ballot(in);
+                if (b == 0ull) continue;
+                const uint32_t p0 = s_pos[k];
+                if (in) { const uint32_t pos = p0 + (uint32_t)__popcll(b & lt); if (pos < cap) list[pos] = g; }
+                lds_order();
+                if (lane == 0) s_pos[k] = p0 + (uint32_t)__popcll(b);
+                lds_order();
+            }
+        }
+        lds_order();
+    }
+}
+
 #ifdef GSR_DB_TIMING
 __device__ unsigned long long g_db_dbg[16];   // s_memtime ticks per part, summed over the waves of every launch (tools/db_timing.sh)
 #define DB_T(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); if (lane == 0) dbt[k] += now_ - dbt_last; dbt_last = now_; } while (0)
@@ -1435,11 +1535,9 @@ __device__ unsigned long long g_db_dbg[16];   // s_memtime ticks per part, summe
 // PAIRS (the tile-sort route, round 5): the chunks cut the Gaussians in index order (sorted_gid == nullptr, sorted_rec = the records where
 // the preprocess left them) and what is placed is the PAIR (depth key, Gaussian) -- eight bytes per store instead of four -- into
 // `pairs`; k_tile_sort orders every tile's pairs by key and writes the list.
-// CUT (round 6, see ListCut): 1 = the cut pass -- chunks behind every tile's cut do not run, a chunk in front of every cut runs as
-// ever, one in between keeps only the pairs of tiles that are still open (their bits are masked out of the records' tile masks, and
-// everything downstream sees a record with fewer tiles) -- and the ranges end at the tiles' valid prefixes; 2 = the repair pass:
-// nothing unless a blend wave flagged a tile, then the chunks BEHIND the flagged tiles' cuts, for those tiles only, at the positions
-// the full binning gives them (the chunk tables are the full ones: a tile's kept and left-out pairs never share a chunk).
+// CUT (round 6, see ListCut): 1 = the cut pass -- the chunks up to C* are scattered as ever, a wave of a chunk behind C* serves the few deep
+// tiles whose own cut lies at or behind its chunk (cut_chunk_tiles), and the ranges end at the tiles' valid prefixes; 2 = the repair
+// pass: nothing unless a blend wave flagged a tile, then the flagged tiles' pairs in the chunks behind their cuts.
 template <bool SLAB, bool PAIRS = false, int CUT = 0>
 __global__ __launch_bounds__(64) void k_chunk_scatter(DirectBin db, int W, int H, int tiles_x, int tiles_y,
                                                       const uint32_t* __restrict__ sorted_gid, const TileRec* __restrict__ sorted_rec,
@@ -1453,29 +1551,52 @@ __global__ __launch_bounds__(64) void k_chunk_scatter(DirectBin db, int W, int H
     unsigned long long* const s_mask = s_dyn;                                  // [LT]
     uint32_t* const s_cnt = reinterpret_cast<uint32_t*>(s_dyn + LT);          // [LT]
     uint32_t* const s_pair = s_cnt + LT;                                       // [kDbPairs]
-    unsigned long long* const s_open = reinterpret_cast<unsigned long long*>(s_pair + kDbPairs);   // [LT / 64 + 2] (CUT): bit t = tile t is open for this chunk
     const int lane = threadIdx.x, b = (int)blockIdx.x;
     if (CUT == 2 && cut.ctl[2] == 0u) return;     // the repair pass: no tile was flagged -- every wave of the launch leaves here
-    if (CUT == 2 && b == 0 && lane == 0) { cut.stats[1] += 1u; cut.stats[2] += cut.ctl[2]; }
+    uint32_t cstar = 0u, ndeep = 0u;
+    if (CUT == 1) cstar = cut_frame(cut, db.NC, ndeep);
+    if (CUT == 2) cstar = cut.ctl[0];
     {   // the ranges: tile bases clipped to the list's capacity (an overflowing speculative launch is run again)
         const int t = b * 64 + lane;
         if (t < db.T) {
-            const uint32_t lo = min(db.tbase[t], cap), hi = min(CUT == 1 ? cut.tend[t] : db.tbase[t + 1], cap);
+            uint32_t tend = db.tbase[t + 1];
+            if (CUT == 1) {    // what is written of tile t: the chunks up to its own cut or the frame's, whichever lies behind
+                const uint32_t c1 = max((uint32_t)cut.chunk[t], cstar) + 1u;
+                if (c1 < (uint32_t)db.NC) tend = db.tbase[t] + db.GT[(size_t)(c1 / (uint32_t)db.Cg) * db.Tp + t] + (uint32_t)db.M[(size_t)c1 * db.Tp + t];
+                cut.tend[t] = tend;
+            }
+            const uint32_t lo = min(db.tbase[t], cap), hi = min(tend, cap);
             if (CUT != 2 || cut.flag[t]) ranges[t] = hi > lo ? make_uint2(lo, hi) : make_uint2(0u, 0u);   // (an empty tile reads (0, 0), as on the sort route)
+            if (CUT == 1) {    // this render's blends rebuild the tile's key with atomic maxima (blend_fwd_item)
+                const uint32_t e = cut.cur[0] < (uint32_t)kVcEntries ? cut.cur[0] : 0u;
+                cut.key[(size_t)e * db.T + t] = 0u;
+            }
         }
-        if (CUT == 1 && b == 0 && lane == 0) {     // the books of the cut: whose keys these will be, and the counters
-            const uint32_t e = cut.cur[0] < (uint32_t)kVcEntries ? cut.cur[0] : 0u;
-            cut.owner_n[e] = (uint32_t)db.N;
-            cut.stats[0] += 1u;
-            cut.stats[3] += (uint32_t)(db.NC - 1) - min(cut.ctl[0], (uint32_t)(db.NC - 1));
+        if (CUT && b == 0 && lane == 0) {     // the books of the cut
+            if (CUT == 1) {
+                const uint32_t e = cut.cur[0] < (uint32_t)kVcEntries ? cut.cur[0] : 0u;
+                cut.owner_n[e] = (uint32_t)db.N;
+                cut.ctl[0] = cstar; cut.ctl[1] = ndeep;
+                cut.stats[0] += 1u;
+                cut.stats[3] += (uint32_t)(db.NC - 1) - min(cstar, (uint32_t)(db.NC - 1));
+                cut.stats[4] += ndeep;
+            } else { cut.stats[1] += 1u; cut.stats[2] += cut.ctl[2]; }
         }
     }
     // XCD x = b & 7 owns the chunks [x per, (x + 1) per); a chunk's NS slab waves sit next to each other (they read the same records)
     const int per = (db.NC + 7) >> 3, kk = b >> 3, c = (b & 7) * per + (SLAB ? kk / db.NS : kk), slab = SLAB ? kk % db.NS : 0;
     if ((SLAB ? kk / db.NS : kk) >= per || c >= db.NC) return;
-    if (CUT == 1 && (uint32_t)c > cut.ctl[0]) return;     // behind every tile's cut
-    if (CUT == 2 && (uint32_t)c <= cut.ctl[1]) return;    // in front of every tile's cut: nothing was left out here
-    const bool mixed = CUT == 2 || (CUT == 1 && (uint32_t)c > cut.ctl[1]);   // (wave-uniform) some tiles are closed for this chunk
+    if (CUT && (uint32_t)c > cstar) {             // behind the frame's cut: only a few tiles want this chunk's pairs
+        if (CUT == 1 && ndeep == 0u) return;                               // (no deep tile at all)
+        uint32_t* const s_tile = s_pair;                                   // (the pair buffer is not in use on this path)
+        uint32_t* const s_pos = s_pair + 64;
+        if (CUT == 1) cut_chunk_tiles(db, c, W, H, tiles_x, tiles_y, sorted_gid, sorted_rec, splat, list, cap, s_tile, s_pos,
+                                      [&](uint32_t t) { return (uint32_t)cut.chunk[t] >= (uint32_t)c; });
+        else cut_chunk_tiles(db, c, W, H, tiles_x, tiles_y, sorted_gid, sorted_rec, splat, list, cap, s_tile, s_pos,
+                             [&](uint32_t t) { return cut.flag[t] != 0u && (uint32_t)cut.chunk[t] < (uint32_t)c; });
+        return;
+    }
+    if (CUT == 2) return;                         // (the chunks up to C* were written for every tile)
     const uint32_t t0 = SLAB ? (uint32_t)(slab * db.Ts) : 0u;                                   // first tile of the slab
     const uint32_t tn = SLAB ? (uint32_t)min(db.Ts, db.T - slab * db.Ts) : (uint32_t)db.T;       // tiles in it
     const int srow0 = slab * db.slab_rows, srow1 = srow0 + db.slab_rows;                         // its tile rows (SLAB)
@@ -1506,17 +1627,6 @@ __global__ __launch_bounds__(64) void k_chunk_scatter(DirectBin db, int W, int H
             }
         }
     }
-    if (CUT && mixed) {   // the open tiles of this chunk, one bit each, in tile order
-        for (int i0 = 0; i0 < LT; i0 += 64) {
-            const int i = i0 + lane;
-            bool op = false;
-            if (i < db.T) op = CUT == 1 ? (uint32_t)c <= (uint32_t)cut.chunk[i] : (cut.flag[i] != 0u && (uint32_t)c > (uint32_t)cut.chunk[i]);
-            const unsigned long long bits = __ballot(op);
-            if (lane == 0) s_open[i0 >> 6] = bits;
-        }
-        if (lane < 2) s_open[(LT >> 6) + lane] = 0ull;
-    }
-    auto tile_open = [&](uint32_t t) -> bool { return !(CUT && mixed) || ((s_open[t >> 6] >> (t & 63u)) & 1ull) != 0ull; };
     lds_order();
     DB_T(0);
     const unsigned long long me = 1ull << lane, lt = lanemask_lt();
@@ -1542,7 +1652,6 @@ __global__ __launch_bounds__(64) void k_chunk_scatter(DirectBin db, int W, int H
             const uint32_t below_hi = hi >= 32 ? 0xffffffffu : ((1u << hi) - 1u), below_lo = lo >= 32 ? 0xffffffffu : ((1u << lo) - 1u);
             r.mask &= below_hi & ~below_lo;
         }
-        if (CUT && mixed && !(r.rect & kTileRecBig)) r.mask &= open_tiles_mask(r, tiles_x, s_open);   // the closed tiles leave the record
         // A large rect (no mask in its record) is walked by all 64 lanes, once, and its accepted tiles go into the pair buffer like
         // everyone's; one of more tiles than the buffer holds ("huge") is walked three times instead, outside the buffer.
         const bool big = (r.rect & kTileRecBig) != 0u && r.mask != 0u, huge = big && (SLAB || r.mask > (uint32_t)kDbPairs);
@@ -1575,10 +1684,9 @@ __global__ __launch_bounds__(64) void k_chunk_scatter(DirectBin db, int W, int H
                 big_rect_tiles(s, rect, W, H, tiles_x, tiles_y, lane, [&](bool ok, uint32_t tg) {
                     const uint32_t t = tg - t0;          // (this branch only runs without slabs: t0 = 0)
                     const unsigned long long acc = __ballot(ok);
-                    if (ok) {      // (a closed tile's slot of the pair buffer holds the "no pair" word: the record's count is the full one)
-                        const bool op = tile_open(t);
-                        if (with_or && op) atomicOr(&s_mask[t], 1ull << bl);
-                        if (in_run) s_pair[(o + (uint32_t)__popcll(acc & lt)) & (uint32_t)(kDbPairs - 1)] = op ? ((t << 6) | (uint32_t)bl) : 0xffffffffu;
+                    if (ok) {
+                        if (with_or) atomicOr(&s_mask[t], 1ull << bl);
+                        if (in_run) s_pair[(o + (uint32_t)__popcll(acc & lt)) & (uint32_t)(kDbPairs - 1)] = (t << 6) | (uint32_t)bl;
                     }
                     o += (uint32_t)__popcll(acc);
                 });
@@ -1594,7 +1702,7 @@ __global__ __launch_bounds__(64) void k_chunk_scatter(DirectBin db, int W, int H
             const int bl = (int)__builtin_ctzll(bm);
             const uint32_t gg = (uint32_t)__builtin_amdgcn_readlane((int)g, bl), rect = (uint32_t)__builtin_amdgcn_readlane((int)r.rect, bl);
             const Splat s = splat[gg];
-            big_rect_tiles(s, rect, W, H, tiles_x, tiles_y, lane, [&](bool ok, uint32_t tg) { const uint32_t t = tg - t0; if (ok && t < tn && tile_open(t)) atomicOr(&s_mask[t], 1ull << bl); });
+            big_rect_tiles(s, rect, W, H, tiles_x, tiles_y, lane, [&](bool ok, uint32_t tg) { const uint32_t t = tg - t0; if (ok && t < tn) atomicOr(&s_mask[t], 1ull << bl); });
         }
         // the loads of the step after next have had a step and this owner loop to arrive; taken HERE, in front of this step's
         // scattered stores (a wait for a load is a wait for every store issued before it: vmcnt counts both)
@@ -1619,7 +1727,7 @@ __global__ __launch_bounds__(64) void k_chunk_scatter(DirectBin db, int W, int H
                     for (int q = 0; q < RN; q++) {
                         const bool v = 64u * q + (uint32_t)lane < left;
                         e[q] = v ? e[q] : 0xffffffffu;
-                        const uint32_t t = e[q] != 0xffffffffu ? e[q] >> 6 : 0u;   // ("no pair": beyond the step's pairs, or a closed tile of a large rect)
+                        const uint32_t t = v ? e[q] >> 6 : 0u;
                         go[q] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((e[q] & 63u) << 2), (int)g);   // (every lane: an owner's index is fetched from ITS lane)
                         if (PAIRS) ko[q] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((e[q] & 63u) << 2), (int)kd);
                         mk[q] = s_mask[t];
@@ -1654,7 +1762,7 @@ __global__ __launch_bounds__(64) void k_chunk_scatter(DirectBin db, int W, int H
             const Splat s = splat[gg];
             big_rect_tiles(s, rect, W, H, tiles_x, tiles_y, lane, [&](bool ok, uint32_t tg) {
                 const uint32_t t = tg - t0;
-                if (ok && t < tn && tile_open(t)) {
+                if (ok && t < tn) {
                     const uint32_t pos = s_cnt[t] + (uint32_t)__popcll(s_mask[t] & ((1ull << bl) - 1ull));
                     if (pos < cap) {
                         if (PAIRS) pairs[pos] = make_uint2((uint32_t)__builtin_amdgcn_readlane((int)kd, bl), gg);
@@ -1677,7 +1785,7 @@ __global__ __launch_bounds__(64) void k_chunk_scatter(DirectBin db, int W, int H
                     for (int q = 0; q < RN; q++) e[q] = s_pair[(p0 + 64u * q + (uint32_t)lane) & (uint32_t)(kDbPairs - 1)];
 #pragma unroll
                     for (int q = 0; q < RN; q++)
-                        if (64u * q + (uint32_t)lane < left && e[q] != 0xffffffffu) { atomicAdd(&s_cnt[e[q] >> 6], 1u); s_mask[e[q] >> 6] = 0ull; }
+                        if (64u * q + (uint32_t)lane < left) { atomicAdd(&s_cnt[e[q] >> 6], 1u); s_mask[e[q] >> 6] = 0ull; }
                 };
                 if (left <= 128u) batch(std::integral_constant<int, 2>{});
                 else if (left <= 256u) batch(std::integral_constant<int, 4>{});
@@ -1690,14 +1798,14 @@ __global__ __launch_bounds__(64) void k_chunk_scatter(DirectBin db, int W, int H
                 const int bl = (int)__builtin_ctzll(bm);
                 const uint32_t gg = (uint32_t)__builtin_amdgcn_readlane((int)g, bl), rect = (uint32_t)__builtin_amdgcn_readlane((int)r.rect, bl);
                 const Splat s = splat[gg];
-                big_rect_tiles(s, rect, W, H, tiles_x, tiles_y, lane, [&](bool ok, uint32_t tg) { const uint32_t t = tg - t0; if (ok && t < tn && tile_open(t)) { atomicAdd(&s_cnt[t], 1u); s_mask[t] = 0ull; } });
+                big_rect_tiles(s, rect, W, H, tiles_x, tiles_y, lane, [&](bool ok, uint32_t tg) { const uint32_t t = tg - t0; if (ok && t < tn) { atomicAdd(&s_cnt[t], 1u); s_mask[t] = 0ull; } });
             }
         }
         for (unsigned long long bm = huges; bm != 0ull; bm &= bm - 1ull) {
             const int bl = (int)__builtin_ctzll(bm);
             const uint32_t gg = (uint32_t)__builtin_amdgcn_readlane((int)g, bl), rect = (uint32_t)__builtin_amdgcn_readlane((int)r.rect, bl);
             const Splat s = splat[gg];
-            big_rect_tiles(s, rect, W, H, tiles_x, tiles_y, lane, [&](bool ok, uint32_t tg) { const uint32_t t = tg - t0; if (ok && t < tn && tile_open(t)) { atomicAdd(&s_cnt[t], 1u); s_mask[t] = 0ull; } });
+            big_rect_tiles(s, rect, W, H, tiles_x, tiles_y, lane, [&](bool ok, uint32_t tg) { const uint32_t t = tg - t0; if (ok && t < tn) { atomicAdd(&s_cnt[t], 1u); s_mask[t] = 0ull; } });
         }
         lds_order();
         DB_T(5);
@@ -4014,8 +4122,11 @@ static int g_tile_sort_max_avg = 700;   // measured (tools/ab_tile_sort*.sh, 980
 static int g_direct_bin = 1;      // tile lists by direct placement (k_chunk_counts / k_chunk_scatter) instead of emit + tile sort + ranges; 0 = the sort route
 static int g_view_pose_tol_e6 = 2000;   // balanced placement without a view id: a render belongs to the cached view whose pose is within this (x 1e-6) in every matrix entry
 static int g_db_slab_tiles = 0;   // frames above kDbMaxTiles tiles: tiles per slab of the slabbed scatter (0 = such frames keep the sort route)
-static int g_list_cut = 1;        // round 6: tile lists written only up to where the tile stopped at the frame's previous render (ListCut); 0 = full lists
+static int g_list_cut = 1;        // round 6: tile lists written only up to where the tiles stopped at the frame's previous render (ListCut); 0 = full lists,
+                                  // 1 = for models of at least g_list_cut_min_n Gaussians (where it was measured to pay), 2 = wherever the route allows
+static int g_list_cut_min_n = 2000000;
 static int g_list_cut_margin_e3 = 50;   // ... x (1 + this / 1000) of the depth its waves reached
+static int g_list_cut_deep = 8;        // tiles whose own cut may lie behind the frame's (served by cut_chunk_tiles)
 static int g_early_r = 1;         // the host learns R from the preprocess's per-block shares (published by the depth sort's histogram kernel) instead of from the scan
 static int g_blend_balance = 1;   // forward blend: place the waves by the visits each took at the previous render of the same view (balance_build)
 static int g_tile_map = 2;   // tile -> XCD map: 2 = 2x2 tile blocks interleaved (default), 1 = tiles interleaved, 0 = banded
@@ -4226,7 +4337,8 @@ int gsr_set_option(const char* name, int value)
     if (!strcmp(name, "tile_map")) { if (value < 0 || value > 2) return GSR_ERR_ARG; g_tile_map = value; return GSR_OK; }
     if (!strcmp(name, "blend_balance")) { g_blend_balance = value ? 1 : 0; return GSR_OK; }
     if (!strcmp(name, "early_r")) { g_early_r = value ? 1 : 0; return GSR_OK; }
-    if (!strcmp(name, "list_cut")) { g_list_cut = value ? 1 : 0; return GSR_OK; }
+    if (!strcmp(name, "list_cut")) { g_list_cut = value < 0 || value > 2 ? 1 : value; return GSR_OK; }
+    if (!strcmp(name, "list_cut_min_n")) { g_list_cut_min_n = value < 0 ? 2000000 : value; return GSR_OK; }
     if (!strcmp(name, "view_cache_reset")) {   // tests: every per-frame cache of the current device forgets its frames (placement costs, list cuts, counters)
         int dev_id = 0;
         if (hipGetDevice(&dev_id) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return GSR_ERR_HIP;
@@ -4236,6 +4348,7 @@ int gsr_set_option(const char* name, int value)
         return GSR_OK;
     }
     if (!strcmp(name, "list_cut_margin_e3")) { g_list_cut_margin_e3 = value < 0 ? 50 : value; return GSR_OK; }
+    if (!strcmp(name, "list_cut_deep")) { g_list_cut_deep = value < 0 ? 8 : value; return GSR_OK; }
     if (!strcmp(name, "debug_late_bias")) { g_debug_late_bias = value; return GSR_OK; }   // tests: added ONCE to the early count a forward remembers for its late check
     if (!strcmp(name, "tile_sort")) { if (value < 0 || value > 2) return GSR_ERR_ARG; g_tile_sort = value; return GSR_OK; }
     if (!strcmp(name, "tile_sort_max_avg")) { if (value < 0) return GSR_ERR_ARG; g_tile_sort_max_avg = value; return GSR_OK; }
@@ -4272,7 +4385,7 @@ int gsr_set_option(const char* name, int value)
 }
 
 // geometry + scratch of the direct binning for N Gaussians on T tiles; false: this frame keeps the sort route
-struct DirectBinScratch { size_t M, GT, tbase, bsum, cut_chunk, cut_tend, cut_flag, cut_ctl, cut_bkey, bytes; };
+struct DirectBinScratch { size_t M, GT, tbase, bsum, cut_chunk, cut_tend, cut_flag, cut_ctl, cut_bkey, cut_hist, bytes; };
 static bool direct_bin_geometry(int N, int T, DirectBin& db, DirectBinScratch& ds, int tiles_x = 0, int tile_rows = 0)
 {
     if (N < 1 || T < 1) return false;
@@ -4320,6 +4433,7 @@ static bool direct_bin_geometry(int N, int T, DirectBin& db, DirectBinScratch& d
     ds.cut_flag = o; o += align256((size_t)db.Tp * sizeof(uint32_t));
     ds.cut_ctl = o; o += 256;
     ds.cut_bkey = o; o += align256((size_t)db.NC * sizeof(uint32_t));
+    ds.cut_hist = o; o += align256((size_t)db.NC * sizeof(uint32_t));
     ds.bytes = o;
     return true;
 }
@@ -4468,7 +4582,7 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
                                    reinterpret_cast<const TileRec*>(fs + L.srec), splat, list, ranges, (uint32_t)std::min<uint64_t>(capacity, 0xffffffffull));
             else if (lc.key) {
                 lc_capacity = capacity;
-                hipLaunchKernelGGL((k_chunk_scatter<false, false, 1>), dim3(grid), dim3(64), (size_t)12 * db.Tp + 4 * kDbPairs + 8 * (db.Tp / 64 + 2), st, db, W, H,
+                hipLaunchKernelGGL((k_chunk_scatter<false, false, 1>), dim3(grid), dim3(64), (size_t)12 * db.Tp + 4 * kDbPairs, st, db, W, H,
                                    tiles_x, tiles_y, sorted_gid, reinterpret_cast<const TileRec*>(fs + L.srec), splat, list, ranges,
                                    (uint32_t)std::min<uint64_t>(capacity, 0xffffffffull), (const uint32_t*)nullptr, (uint2*)nullptr, lc);
             } else
@@ -4509,7 +4623,7 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
             // the flagged tiles' full lists -- every workgroup of both launches reads one word and leaves unless a wave flagged a tile
             ProfScope ps(P_CUT_REPAIR, st);
             const int per = (db.NC + 7) / 8, grid = std::max(8 * per * db.NS, (T + 63) / 64);
-            hipLaunchKernelGGL((k_chunk_scatter<false, false, 2>), dim3(grid), dim3(64), (size_t)12 * db.Tp + 4 * kDbPairs + 8 * (db.Tp / 64 + 2), st, db, W, H,
+            hipLaunchKernelGGL((k_chunk_scatter<false, false, 2>), dim3(grid), dim3(64), (size_t)12 * db.Tp + 4 * kDbPairs, st, db, W, H,
                                tiles_x, tiles_y, sorted_gid, reinterpret_cast<const TileRec*>(fs + L.srec), splat, list, ranges,
                                (uint32_t)std::min<uint64_t>(lc_capacity, 0xffffffffull), (const uint32_t*)nullptr, (uint2*)nullptr, lc);
             hipLaunchKernelGGL(k_blend_fwd_w6<true>, dim3(8 * 4 * slots_per_xcd(opt_map, T, tiles_x)), dim3(64), 0, st, W, H, tiles_x, T, ranges, list, splat, a->bg,
@@ -4740,7 +4854,7 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
                     bb.tol = 1e-6f * (float)g_view_pose_tol_e6;
                     bb.items = items; bb.nslots4 = nslots4; bb.W = W; bb.H = H;
                     // the list cut: the plain direct binning behind a global depth sort, one model, the default blend
-                    if (direct && !tsort && db.NS == 1 && db.NC <= 16000 && T == db.T) {
+                    if (direct && !tsort && db.NS == 1 && db.NC <= 16000 && T == db.T && (g_list_cut == 2 || (g_list_cut == 1 && N >= g_list_cut_min_n))) {
                         uint8_t* dm = fs + align256(L.bytes);
                         lc.key = reinterpret_cast<uint32_t*>(mem + vc_cut);
                         lc.owner_n = reinterpret_cast<uint32_t*>(mem + vc_own);
@@ -4751,10 +4865,12 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
                         lc.flag = reinterpret_cast<uint32_t*>(dm + dbs.cut_flag);
                         lc.ctl = reinterpret_cast<uint32_t*>(dm + dbs.cut_ctl);
                         lc.bkey = reinterpret_cast<uint32_t*>(dm + dbs.cut_bkey);
+                        lc.hist = reinterpret_cast<uint32_t*>(dm + dbs.cut_hist);
                         lc.skey = in_alt ? dkey_alt : dkey;
                         lc.tbase = reinterpret_cast<uint32_t*>(dm + dbs.tbase);
                         lc.margin = 1e-3f * (float)g_list_cut_margin_e3;
-                        lc.enable = g_list_cut;
+                        lc.dmax = std::max(0, g_list_cut_deep);
+                        lc.enable = 1;
                     }
                 }
             }
@@ -5186,13 +5302,14 @@ int gsr_debug_view_cache_stats(int32_t W, int32_t H, int64_t out[4])
     return GSR_OK;
 }
 
-int gsr_debug_list_cut_stats(int32_t W, int32_t H, int64_t out[4])
+int gsr_debug_list_cut_stats(int32_t W, int32_t H, int64_t out[5])
 {
     // the list cut's counters of the CURRENT device for this frame size (ListCut::stats): renders that ran with the cut machinery,
-    // renders whose repair pass found flagged tiles, tiles repaired, chunks of the depth order the scatter skipped (summed)
+    // renders whose repair pass found flagged tiles, tiles repaired, chunks of the depth order behind the frame's cut (summed), deep
+    // tiles (summed)
     int dev_id = 0;
     if (hipGetDevice(&dev_id) != hipSuccess) return fail(GSR_ERR_HIP, "hipGetDevice failed%s");
-    out[0] = out[1] = out[2] = out[3] = 0;
+    out[0] = out[1] = out[2] = out[3] = out[4] = 0;
     std::vector<uint8_t*> mems;
     {
         std::lock_guard<std::mutex> lk(g_state_mutex);
@@ -5202,7 +5319,7 @@ int gsr_debug_list_cut_stats(int32_t W, int32_t H, int64_t out[4])
         ViewCostHdr h;
         if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(&h, m, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess)
             return fail(GSR_ERR_HIP, "view cache read-back failed%s");
-        for (int q = 0; q < 4; q++) out[q] += h.pad[2 + q];
+        for (int q = 0; q < 5; q++) out[q] += h.pad[2 + q];
     }
     return GSR_OK;
 }

@@ -964,6 +964,11 @@ def main():
     sync_all()
     counters = ("forward_calls", "forward_ns", "forward_wait_ns", "backward_calls", "backward_ns", "spec_overflows", "spec_forwards", "exact_forwards")
     c0 = {k: lib.gsr_get_counter(k.encode()) for k in counters}
+
+    def cut_stats():
+        out = (C.c_int64 * 5)()
+        return [int(v) for v in out] if lib.gsr_debug_list_cut_stats(W, H, out) == 0 else [0] * 5
+    lc0 = cut_stats()      # (synchronises the device: outside the timed region)
     t0 = time.perf_counter()
     stamps = [t0]
     for _ in range(args.steps):
@@ -972,6 +977,7 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     c1 = {k: lib.gsr_get_counter(k.encode()) for k in c0}
+    lc1 = cut_stats()
     lib.gsr_set_option(b"profile", 0)
     prof_blend = read_profile(lib, ["blend_fwd"])["blend_fwd"]
     # R_eff of every view (the roofline's algorithmic bytes are the mean over the views the timed launches rendered)
@@ -1194,6 +1200,12 @@ def main():
         "fwd_bwd_ms": fwd_ms + bwd_ms, "rasterizer_fwd_ms": fwd_ms, "rasterizer_bwd_ms": bwd_ms,
         "stage_ms": stage_ms, "step_host_ms": step_host, "roofline": roofline, "roofline_other_kernels": others,
         "spec_overflows": c1["spec_overflows"] - c0["spec_overflows"],
+        # the list cut (include/gsr.h "list_cut") over the timed steps: renders that ran it, renders whose lists had to be repaired on the
+        # device (a tile needed more than it kept: the counter of re-runs), tiles repaired, and per render the chunks of the depth
+        # order behind the frame's cut (of `chunks`) and the deep tiles served one by one
+        "list_cut": {"renders": lc1[0] - lc0[0], "renders_repaired": lc1[1] - lc0[1], "tiles_repaired": lc1[2] - lc0[2],
+                     "chunks_behind_cut_per_render": (lc1[3] - lc0[3]) / max(1, lc1[0] - lc0[0]),
+                     "deep_tiles_per_render": (lc1[4] - lc0[4]) / max(1, lc1[0] - lc0[0])},
         "speculative_forwards": c1["spec_forwards"] - c0["spec_forwards"], "exact_forwards": c1["exact_forwards"] - c0["exact_forwards"],
         "rccl": rccl,
     }

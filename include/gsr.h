@@ -308,19 +308,22 @@ size_t gsr_struct_bytes(int32_t which); /* 0 GsrForwardArgs, 1 GsrBackwardArgs, 
  *                          9-bit passes over the 27-bit window instead of four 8-bit ones (it launches a digit histogram either way);
  *                          0 = only models above 262 144 Gaussians.  Same order either way (a depth beyond the window is detected
  *                          and sorted again on all 32 bits)
- *   "list_cut"             1 (default) = on the plain direct-binning route (frames of up to 4 096 tiles behind the global depth sort,
- *                          single renders, default blend, "blend_balance" on) a tile's list is WRITTEN only up to where the tile
- *                          stopped at the previous render of the same frame (the frame is recognised as for "blend_balance"; the
- *                          remembered quantity is the view depth of the last instance any of the tile's four waves staged, x
- *                          (1 + "list_cut_margin_e3" / 1000), rounded up to a chunk of the depth order): counts, scans, tile bases, R
- *                          and every pair's position are the full binning's, the blends get the end of the valid prefix as the
- *                          range end.  Verified and repaired on the device, never by the host: a wave that runs out of a cut list
- *                          with a live pixel flags its tile, and two launches that follow every such render -- the scatter over
- *                          the left-out chunks for the flagged tiles, the blend over the flagged tiles' full lists -- find
- *                          nothing to do otherwise.  Image, radii, every pixel's contributors, checkpoints and all gradients are
- *                          bit-identical to full lists; ranges[t].y and the list words behind it are what differ
- *                          (gsr_debug_read_binning returns the valid prefixes).  0 = full lists (gsr_debug_list_cut_stats)
- *   "list_cut_margin_e3"   (default 50) see "list_cut"
+ *   "list_cut"             1 (default) = for models of at least "list_cut_min_n" Gaussians (default 2 000 000: where it was measured to pay;
+ *                          2 = whatever the size), on the plain direct-binning route (frames of up to 4 096 tiles behind the global depth sort,
+ *                          single renders, default blend, "blend_balance" on) the tile lists are WRITTEN only up to where the tiles
+ *                          stopped at the previous render of the same frame (the frame is recognised as for "blend_balance"; a tile
+ *                          remembers the view depth of the last instance any of its four waves staged, x (1 + "list_cut_margin_e3" /
+ *                          1000), rounded up to a chunk of the depth order).  One cut for the frame -- the chunk behind which at
+ *                          most "list_cut_deep" tiles' cuts lie; the chunks up to it are scattered as ever, for every tile -- and
+ *                          the few deeper tiles are served one by one in the chunks behind it.  Counts, scans, tile bases, R and
+ *                          every pair's position are the full binning's; the blends get the end of the valid prefix as the range
+ *                          end.  Verified and repaired on the device, never by the host: a wave that runs out of a cut list with a
+ *                          live pixel flags its tile, and two launches that follow every such render -- the flagged tiles' left-out
+ *                          pairs, the blend over the flagged tiles' full lists -- find nothing to do otherwise.  Image, radii,
+ *                          every pixel's contributors, checkpoints and all gradients are bit-identical to full lists; ranges[t].y
+ *                          and the list words behind it are what differ (gsr_debug_read_binning returns the valid prefixes).
+ *                          0 = full lists (gsr_debug_list_cut_stats)
+ *   "list_cut_margin_e3"   (default 50), "list_cut_deep" (default 8): see "list_cut"
  *   "early_r"              1 (default) = the host learns the instance count from the preprocess's per-block sums, published by
  *                          the depth sort's first kernel, instead of from the scan behind sort + tile counts; 0 = from the scan.
  *                          The scan still reports its own total and the sorts' give-up counter into spare words of the pinned slot;
@@ -377,8 +380,9 @@ int gsr_debug_direct_binning_geometry(int32_t N, int32_t T, int64_t out[7]);
  * or by pose within "view_pose_tol_e6") and placed its waves by that frame's previous visit counts. */
 int gsr_debug_view_cache_stats(int32_t W, int32_t H, int64_t out[4]);
 /* The list cut's counters ("list_cut") of the CURRENT device for frames of W x H (synchronises the device): out = {renders that ran
- * the cut machinery, renders whose repair pass found flagged tiles, tiles repaired, chunks of the depth order skipped (summed)}. */
-int gsr_debug_list_cut_stats(int32_t W, int32_t H, int64_t out[4]);
+ * the cut machinery, renders whose repair pass found flagged tiles, tiles repaired, chunks of the depth order behind the frame's cut
+ * (summed), deep tiles (summed)}. */
+int gsr_debug_list_cut_stats(int32_t W, int32_t H, int64_t out[5]);
 /* Sum of the recorded durations of stage `name` ("preprocess_fwd", "sort_depth", "scan", "emit", "sort_tile",
  * "ranges", "blend_fwd", "blend_bwd", "preprocess_bwd") since the last read; synchronises on the events.  With the direct binning
  * "scan" = k_chunk_counts + the two column scans, "emit" = k_chunk_scatter, "sort_tile" / "ranges" record nothing. */

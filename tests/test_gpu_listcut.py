@@ -24,7 +24,7 @@ R_ = importlib.import_module("3dgs_hierarchical_training_amd.rasterizer")
 
 
 def _stats(lib, W, H):
-    out = (C.c_int64 * 4)()
+    out = (C.c_int64 * 5)()
     assert lib.gsr_debug_list_cut_stats(W, H, out) == 0
     return [int(v) for v in out]
 
@@ -65,7 +65,7 @@ def _two_ways(lib, kws, W, H, grads, margin=None, hint=None):
     assert lib.gsr_set_option(b"tile_sort", 0) == 0
     try:
         for cut in (1, 0):
-            assert lib.gsr_set_option(b"list_cut", cut) == 0
+            assert lib.gsr_set_option(b"list_cut", 2 if cut else 0) == 0       # (2: whatever the model's size)
             assert lib.gsr_set_option(b"list_cut_margin_e3", -1 if margin is None else margin) == 0
             assert lib.gsr_set_option(b"view_cache_reset", 1) == 0
             assert lib.gsr_set_option(b"reset_speculation", 1) == 0
@@ -178,6 +178,7 @@ def test_oracle_parity_of_a_cut_render():
     kw = parity.scene_kwargs(sc, "sh", bg=(0.3, 0.2, 0.1))
     assert lib.gsr_set_option(b"view_cache_reset", 1) == 0
     assert lib.gsr_set_option(b"tile_sort", 0) == 0
+    assert lib.gsr_set_option(b"list_cut", 2) == 0
     try:
         hip_runner.run_hip(kw); hip_runner.run_hip(kw)
         s0 = _stats(lib, W, H)
@@ -187,5 +188,6 @@ def test_oracle_parity_of_a_cut_render():
         s1 = _stats(lib, W, H)
     finally:
         lib.gsr_set_option(b"tile_sort", 1)
+        lib.gsr_set_option(b"list_cut", 1)
     assert s1[0] - s0[0] == 2 and s1[3] > s0[3] and s1[1] == s0[1]
     o.close()
