@@ -427,8 +427,8 @@ def test_faint_elongated_splats():
     finally:
         lib.gsr_set_option(b"deterministic_backward", 0)
     # (norm-wise 1e-4 on every tensor; element-wise a needle's conic gradients also cancel INSIDE a tile -- its 256 pixels are summed in
-    #  binary32 by the wave reduction -- so up to 0.2 % of the entries of `scales` stay outside the per-entry bar: measured 0.15 %)
-    parity.check_grads(out["grads"], ref, "needles, fixed-order float64 cross-tile sums", rtol=parity.GRAD_RTOL, elem_bad_max=2e-3)
+    #  binary32 by the wave reduction -- so a fraction of a percent of the entries of `scales` stays outside the per-entry bar: measured 0.004 ... 0.15 % run to run)
+    parity.check_grads(out["grads"], ref, "needles, fixed-order float64 cross-tile sums", rtol=parity.GRAD_RTOL, elem_bad_max=5e-3)
 
 
 def test_deep_lists_split_backward():
