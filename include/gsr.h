@@ -341,6 +341,9 @@ size_t gsr_struct_bytes(int32_t which); /* 0 GsrForwardArgs, 1 GsrBackwardArgs, 
  *                          are kept per caller -- (device, image size, half-octave bucket of N) -- so models of different
  *                          size alternating on one process (teacher / student, stage-A models) do not disturb each other
  *   "reset_speculation"    forget every capacity hint and zero the counters of gsr_get_counter
+ *   "view_cache_reset"     (tests) every per-frame cache of the current device forgets its frames: the balanced placement's visit
+ *                          counts, the list cut's remembered depths, the counters of gsr_debug_view_cache_stats /
+ *                          gsr_debug_list_cut_stats (synchronises the device)
  *   "deterministic_backward" 1 = debug mode: the blend backward writes every (tile, Gaussian) partial gradient to its own slot and
  *                          a second kernel sums each Gaussian's slots in list order -- no float atomics, bit-identical gradients
  *                          from run to run (the default accumulates with atomics in arrival order); several times slower
