@@ -113,8 +113,8 @@ def test_cut_lists_render_what_full_lists_render(case):
 
 
 def test_tiles_that_need_more_than_they_kept_are_repaired_on_the_device():
-    """The same frame, the same model size, but between two renders the model turns transparent (opacities x 0.15) and then moves
-    away from the camera: tiles now need far more of their lists than they kept -- with NO margin.  The waves that run out of
+    """The same frame, the same model size, but between two renders the model turns transparent (opacities x 0.15): tiles now need
+    far more of their lists than they kept -- with NO margin.  The waves that run out of
     their cut lists flag their tiles and the repair pass re-blends those on full lists: everything equals the full-list render,
     the counters say that repairs happened, and the render after that keeps what the repaired tiles needed (no repair again)."""
     lib = L.load()
