@@ -4826,7 +4826,7 @@ int gsr_forward(const GsrForwardArgs* a, GsrForwardOut* out, void* stream_)
                     std::lock_guard<std::mutex> lk(g_state_mutex);
                     for (auto& c : g_view_costs)
                         if (c.dev == dev_id && c.W == W && c.H == H && c.map == opt_map && c.items == items) mem = c.mem;
-                    if (!mem && g_view_costs.size() < 16) {
+                    if (!mem && g_view_costs.size() < 64) {   // (frame geometries per process; round 6: 64 -- a test session renders more than 16 sizes)
                         if (hipMalloc((void**)&mem, vc_bytes) == hipSuccess) {
                             // cleared SYNCHRONOUSLY, once per (device, frame geometry), before anybody can look at it (with
                             // pose-keyed entries an uncleared header is not "garbage hashes = a miss" -- a key that reads 2 with pose
